@@ -1,0 +1,198 @@
+/*
+ * metakssd_hip.h -- C ABI of libmetakssd_hip.so, the MI355X (gfx950) engine for MetaKSSD's
+ * k-mer sketching hot path (`metakssd dist -L <.shuf> [-A]`, FASTQ/FASTA -> sketch).
+ *
+ * The reference has no FFI layer: the seam is a pair of C functions over file-static globals
+ * (SURVEY.md 8b).  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference checkout):
+ *
+ *   reference                                               this ABI
+ *   ------------------------------------------------------  ---------------------------------------
+ *   read_dim_shuffle_file()      command_shuffle.c:215-235   mk_shuf_read / mk_shuf_free
+ *   write_dim_shuffle_file()     command_shuffle.c:174-213   mk_shuf_generate / mk_shuf_write (seeded)
+ *   get_hashsz()                 command_dist.c:286-315   }  mk_params_init
+ *   seq2co_global_var_initial()  iseq2comem.c:54-86       }
+ *   CO[tid]=malloc(hashsize*8)   command_dist.c:344-348      mk_engine_create / mk_engine_destroy
+ *   memset(co,0,..)              iseq2comem.c:663            mk_sketch_begin
+ *   mt_shortreads2koc() loop     iseq2comem.c:675-721        mk_sketch_push_reads[_device]  (MK_MODE_KOC)
+ *   fasta2co()/uniq_fasta2co()   iseq2comem.c:218-315,729-828  same entry points on overlapped windows
+ *                                                            (MK_MODE_SET / MK_MODE_UNIQ_SET)
+ *   write_fqkoc2files()          iseq2comem.c:516-562     }  mk_sketch_finish -> mk_result
+ *   wrt_co2cmpn_use_inn_subctx() iseq2comem.c:625-652     }
+ *   err(errno,"...too crowd")    iseq2comem.c:708-709        MK_ERR_CROWDED (never exit() in here)
+ *   -- (no counterpart: single process) --                   mk_partial_count/export/import (multi-GPU merge)
+ *
+ * Conventions: plain pointers and sizes only; every function returns MK_OK (0) or a negative
+ * MK_ERR_* code and never calls exit(); mk_last_error() gives the text.  One engine per GPU;
+ * calls on one engine must be serialised by the caller.  Nothing in this library falls back to a
+ * CPU implementation: without a usable HIP device mk_engine_create fails with MK_ERR_NO_DEVICE.
+ */
+#ifndef METAKSSD_HIP_H
+#define METAKSSD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MK_ABI_VERSION 1
+
+enum {
+  MK_OK = 0,
+  MK_ERR_ARG = -1,       /* bad argument / unsupported parameter combination */
+  MK_ERR_NO_DEVICE = -2, /* no HIP device, or device index out of range */
+  MK_ERR_HIP = -3,       /* a HIP runtime call failed (text in mk_last_error) */
+  MK_ERR_CROWDED = -4,   /* more than hashlimit distinct keys: iseq2comem.c:708-709 */
+  MK_ERR_STATE = -5,     /* call out of order (push before begin, ...) */
+  MK_ERR_IO = -6,
+  MK_ERR_FORMAT = -7, /* malformed .shuf / primer index out of 0..24 (command_dist.c:291-303) */
+  MK_ERR_NOMEM = -8
+};
+
+/* sketch flavours (which reference function pair is being replaced) */
+enum {
+  MK_MODE_KOC = 0,     /* -A FASTQ: mt_shortreads2koc + write_fqkoc2files: ids + 16-bit counts      */
+  MK_MODE_SET = 1,     /* FASTA:    fasta2co + wrt_co2cmpn_use_inn_subctx: ids, key 0 never stored  */
+  MK_MODE_UNIQ_SET = 2 /* FASTA -u: uniq_fasta2co: keys seen more than once are dropped at the dump */
+};
+
+/* ---- .shuf (command_shuffle.h:4-16) -------------------------------------------------------- */
+typedef struct mk_shuf {
+  int32_t id, k, subk, drlevel; /* dim_shuffle_stat_t, 16-byte file header */
+  int32_t *table;               /* permutation of 0 .. 16^subk-1 */
+  uint64_t len;                 /* 16^subk */
+} mk_shuf;
+
+int mk_shuf_read(const char *path, mk_shuf *out);
+/* Format-compatible deterministic generator (the reference's is srand(time)): Fisher-Yates driven by
+ * a counter-based splitmix64 stream; id = low 31 bits of mix(seed). */
+int mk_shuf_generate(int32_t k, int32_t subk, int32_t drlevel, uint64_t seed, mk_shuf *out);
+int mk_shuf_write(const mk_shuf *s, const char *path);
+void mk_shuf_free(mk_shuf *s);
+
+/* ---- derived parameters ------------------------------------------- */
+typedef struct mk_params {
+  int32_t shuf_id, k, subk, drlevel;
+  int32_t half_outctx_len; /* k - subk                         iseq2comem.c:59 */
+  int32_t TL;              /* 2k                               iseq2comem.c:70 */
+  int32_t crvsaddmove;     /* 4k-2                             iseq2comem.c:68 */
+  int32_t component_num;   /* iseq2comem.c:64-65 */
+  int32_t comp_code_bits;  /* iseq2comem.c:518 */
+  int32_t dim_start, dim_end; /* iseq2comem.c:80-84 */
+  uint32_t hashsize;       /* primer[4(k-drlevel)-15]          command_dist.c:288-305 */
+  uint32_t hashlimit;      /* (uint)(hashsize*0.6)             iseq2comem.c:61 */
+  uint64_t tupmask, domask, undomask; /* iseq2comem.c:69,74-76 */
+  const int32_t *shuf_table; /* host pointer, 16^subk entries; must outlive mk_engine_create */
+  uint64_t shuf_len;
+} mk_params;
+
+int mk_params_init(const mk_shuf *shuf, mk_params *out);
+
+/* ---- engine ---------------------------------------------------------------------------------- */
+typedef struct mk_engine mk_engine;
+
+typedef struct mk_component {
+  uint32_t *ids;    /* host memory, engine-owned, reference slot order */
+  uint16_t *counts; /* NULL unless MK_MODE_KOC */
+  uint64_t n;
+} mk_component;
+
+typedef struct mk_result {
+  int32_t component_num;
+  uint64_t total;           /* what write_fqkoc2files()/wrt_co2cmpn_use_inn_subctx() return */
+  mk_component *components; /* component_num entries; valid until mk_result_release / next begin */
+} mk_result;
+
+/* kernel-time accounting (hipEvent pairs on the engine's stream), filled while profiling is on */
+typedef struct mk_profile {
+  double scan_ms;        /* sum over scan-kernel launches since mk_profile_reset */
+  uint64_t scan_launches;
+  double clear_ms;       /* table clear in mk_sketch_begin */
+  double finish_ms;      /* compaction + priority layout + ordered dump (device part of finish) */
+  uint64_t bases_scanned; /* sum of nreads*stride handed to scan launches (row bytes, not bases) */
+  uint64_t rows_scanned;
+} mk_profile;
+
+int mk_device_count(int *n);
+int mk_engine_create(const mk_params *p, int device, mk_engine **out);
+int mk_engine_destroy(mk_engine *e);
+/* run all engine work on a caller-owned hipStream_t (e.g. torch's current stream); NULL = engine's own */
+int mk_engine_set_stream(mk_engine *e, void *hip_stream);
+const char *mk_last_error(const mk_engine *e); /* e may be NULL: last error of a failed create */
+
+int mk_sketch_begin(mk_engine *e, int mode);
+/* Fixed-stride rows, each an ASCII sequence line terminated by '\n' (the layout of the reference's
+ * fq_buff[l][FQ_LEN], iseq2comem.c:659,673); a row without '\n' ends at `stride`.  stride % 4 == 0,
+ * 4 <= stride <= 4096.  Read i of this call has global ordinal first_read_ordinal + i: ordinals define
+ * the sequential order whose table layout the result reproduces, so they must increase in file order.
+ * Host variant: returns once `rows` may be reused (device copy done; the scan may still be running). */
+int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t stride, uint64_t nreads, uint64_t first_read_ordinal);
+int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev, uint32_t stride, uint64_t nreads,
+                                uint64_t first_read_ordinal);
+int mk_sketch_finish(mk_engine *e, mk_result *out);
+int mk_result_release(mk_engine *e, mk_result *r);
+int mk_engine_sync(mk_engine *e);
+
+/* pinned host memory for the caller's read batches (hipHostMalloc) */
+int mk_host_alloc(void **p, size_t bytes);
+int mk_host_free(void *p);
+
+/* ---- multi-GPU merge: distinct keys of this engine's shard ---------------------- */
+/* number of distinct keys currently held (runs the compaction kernel) */
+int mk_partial_count(mk_engine *e, uint64_t *n);
+/* copy {key, min(count,65535), first ordinal} of every distinct key into caller DEVICE buffers */
+int mk_partial_export(mk_engine *e, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t *ords_dev, uint64_t capacity,
+                      uint64_t *n_out);
+/* fold another shard's export (DEVICE buffers) into this engine: counts add, first ordinals take min */
+int mk_partial_import(mk_engine *e, const uint64_t *keys_dev, const uint32_t *counts_dev, const uint64_t *ords_dev,
+                      uint64_t n);
+
+/* ---- profiling --------------------------------------------------------------------------------- */
+int mk_profile_enable(mk_engine *e, int on);
+int mk_profile_reset(mk_engine *e);
+int mk_profile_get(mk_engine *e, mk_profile *out); /* synchronises the stream */
+
+/* ---- synthetic input: read i = len bases i.i.d. uniform from a counter-based PRNG --
+ * word(i,j) = mix64(mix64(seed ^ i) + j);  base b of read i = "ACGT"[(word(i,b/32) >> 2(b%32)) & 3]
+ * rows[i*stride .. ] = bases, '\n', zero padding.  Host and device versions produce identical bytes. */
+int mk_synth_rows_host(uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len, uint32_t stride, uint8_t *rows);
+int mk_synth_rows_device(int device, void *hip_stream, uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len,
+                         uint32_t stride, uint8_t *rows_dev);
+/* FASTQ text of the same reads: "@r<i>\n<bases>\n+\n<'I'*len>\n" */
+int mk_synth_fastq_write(const char *path, uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len);
+
+/* ---- host-side stage I helpers (run_stageI bookkeeping, command_dist.c:341-500) ----------------- */
+/* FASTQ framing of mt_shortreads2koc's reader (iseq2comem.c:672-673) over a memory buffer: copies
+ * each record's sequence line (with its '\n') into rows[i*stride]; records whose 4th line is missing
+ * are dropped.  Returns the number of rows written through *nrows and the bytes consumed through
+ * *consumed (so a caller can stream).  final!=0 means `buf` ends the file. */
+int mk_fastq_frame(const uint8_t *buf, size_t n, int final, uint8_t *rows, uint32_t stride, uint64_t max_rows,
+                   uint64_t *nrows, size_t *consumed);
+/* FASTA front end of fasta2co (iseq2comem.c:240-279): strips line breaks, maps headers/invalid bytes to
+ * window resets and cuts the base stream into rows of `stride` bytes overlapping by TL-1 bases so that
+ * every k-mer lies in exactly one row.  Call mk_fasta_window_init once per file, then feed the file in
+ * any chunking; when *consumed < n (max_rows reached) call again with the rest; pass final!=0 with
+ * the last chunk (n may be 0) to flush the pending row. */
+typedef struct mk_fasta_state {
+  uint32_t TL;        /* k-mer length in bases (2k) */
+  uint32_t in_header; /* inside a '>' line */
+  uint32_t fill;      /* bytes in pending[] */
+  uint32_t fresh;     /* of which not yet part of any emitted row */
+  uint8_t pending[4096];
+} mk_fasta_state;
+int mk_fasta_window_init(mk_fasta_state *st, int32_t TL);
+int mk_fasta_window(mk_fasta_state *st, const uint8_t *buf, size_t n, int final, uint8_t *rows, uint32_t stride,
+                    uint64_t max_rows, uint64_t *nrows, size_t *consumed);
+
+/* sketch directory writer: combco.N / combco.index.N / combco.N.a / cofiles.stat
+ * (command_dist.c:408-500; co_dstat_t global_basic.h:116-126, padding zeroed) */
+typedef struct mk_sketchdir mk_sketchdir;
+int mk_sketchdir_open(const char *outdir, const mk_params *p, int koc, int nfiles, mk_sketchdir **out);
+int mk_sketchdir_add(mk_sketchdir *d, const char *input_path, const mk_result *r);
+int mk_sketchdir_close(mk_sketchdir *d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,148 @@
+/*
+ * mk_frontend.c -- host front ends that turn input text into fixed-stride rows for the engine,
+ * plus the synthetic-read generator (host C, no GPU).
+ *
+ * Replaces the reader halves of the reference's sketch functions:
+ *   FASTQ  : the 4x fgets framing of mt_shortreads2koc(), iseq2comem.c:672-673
+ *   FASTA  : the byte loop of fasta2co()/uniq_fasta2co(), iseq2comem.c:240-279 (line breaks skipped
+ *            without resetting the k-mer window, '>' header lines skipped with a reset, any other
+ *            non-ACGT byte resets)
+ */
+#include "metakssd_hip.h"
+#include "mk_host_internal.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MK_FQ_LEN 4096 /* iseq2comem.c:656: fgets() never returns more than FQ_LEN-1 characters */
+
+int mk_synth_rows_host(uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len, uint32_t stride, uint8_t *rows) {
+  if (!rows || stride < len + 1) return MK_ERR_ARG;
+  static const char acgt[4] = {'A', 'C', 'G', 'T'};
+  for (uint64_t r = 0; r < nreads; r++) {
+    uint8_t *row = rows + r * (uint64_t)stride;
+    uint64_t w = 0;
+    for (uint32_t b = 0; b < len; b++) {
+      if ((b & 31) == 0) w = mk_synth_word(seed, first_read + r, b >> 5);
+      row[b] = (uint8_t)acgt[(w >> (2 * (b & 31))) & 3];
+    }
+    row[len] = '\n';
+    memset(row + len + 1, 0, stride - len - 1);
+  }
+  return MK_OK;
+}
+
+int mk_synth_fastq_write(const char *path, uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len) {
+  if (!path || len == 0 || len > 4094) return MK_ERR_ARG;
+  FILE *f = fopen(path, "wb");
+  if (!f) return MK_ERR_IO;
+  uint8_t *row = (uint8_t *)malloc(len + 8);
+  char *qual = (char *)malloc(len + 2);
+  if (!row || !qual) { fclose(f); free(row); free(qual); return MK_ERR_NOMEM; }
+  memset(qual, 'I', len);
+  qual[len] = '\n';
+  int ok = 1;
+  for (uint64_t r = 0; r < nreads && ok; r++) {
+    mk_synth_rows_host(seed, first_read + r, 1, len, len + 1, row);
+    ok = fprintf(f, "@r%llu\n", (unsigned long long)(first_read + r)) > 0 && fwrite(row, 1, len + 1, f) == len + 1 &&
+         fwrite("+\n", 1, 2, f) == 2 && fwrite(qual, 1, len + 1, f) == len + 1;
+  }
+  free(row);
+  free(qual);
+  if (fclose(f) != 0) ok = 0;
+  return ok ? MK_OK : MK_ERR_IO;
+}
+
+/* one text line starting at p: returns its length including the '\n' (or up to `end` when the file ends
+ * without one, only if final); 0 = incomplete line, need more data */
+static size_t mk_line(const uint8_t *p, const uint8_t *end, int final) {
+  const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+  if (nl) return (size_t)(nl - p) + 1;
+  return final ? (size_t)(end - p) : 0;
+}
+
+int mk_fastq_frame(const uint8_t *buf, size_t n, int final, uint8_t *rows, uint32_t stride, uint64_t max_rows,
+                   uint64_t *nrows, size_t *consumed) {
+  if (!buf || !rows || !nrows || !consumed || stride < 4 || stride > 4096 || (stride & 3)) return MK_ERR_ARG;
+  const uint8_t *p = buf, *end = buf + n;
+  uint64_t r = 0;
+  int rc = MK_OK;
+  while (r < max_rows && p < end) {
+    /* four lines per record; a record missing any of them is dropped (the && chain at iseq2comem.c:673) */
+    size_t l1 = mk_line(p, end, final);
+    if (!l1) break;
+    const uint8_t *s = p + l1;
+    size_t l2 = s < end ? mk_line(s, end, final) : 0;
+    if (!l2) { if (final) p = end; break; }
+    const uint8_t *q = s + l2;
+    size_t l3 = q < end ? mk_line(q, end, final) : 0;
+    if (!l3) { if (final) p = end; break; }
+    const uint8_t *t = q + l3;
+    size_t l4 = t < end ? mk_line(t, end, final) : 0;
+    if (!l4) { if (final) p = end; break; }
+    /* the reference frames with fgets(…,4096,…): a line of 4095+ characters is split and the record
+     * structure is lost (SURVEY.md 8a note 7).  That input is outside the contract: refuse it. */
+    if (l1 >= MK_FQ_LEN || l2 >= MK_FQ_LEN || l3 >= MK_FQ_LEN || l4 >= MK_FQ_LEN) { rc = MK_ERR_FORMAT; break; }
+    if (s[l2 - 1] != '\n') {
+      /* sequence line is the unterminated last line of the file: then lines 3 and 4 cannot exist */
+      p = end;
+      break;
+    }
+    if (l2 > stride) { rc = MK_ERR_ARG; break; } /* caller must re-frame from here with a larger stride */
+    uint8_t *row = rows + r * (uint64_t)stride;
+    memcpy(row, s, l2);
+    if (l2 < stride) memset(row + l2, 0, stride - l2);
+    r++;
+    p = t + l4;
+  }
+  *nrows = r;
+  *consumed = (size_t)(p - buf);
+  return rc;
+}
+
+int mk_fasta_window_init(mk_fasta_state *st, int32_t TL) {
+  if (!st || TL < 2 || TL > 32) return MK_ERR_ARG;
+  memset(st, 0, sizeof *st);
+  st->TL = (uint32_t)TL;
+  return MK_OK;
+}
+
+/* close the pending row: terminate, copy out, keep the last TL-1 bytes as the next row's overlap */
+static void mk_fasta_emit(mk_fasta_state *st, uint8_t *row, uint32_t stride) {
+  const uint32_t keep = st->TL - 1;
+  memcpy(row, st->pending, st->fill);
+  row[st->fill] = '\n';
+  if (st->fill + 1 < stride) memset(row + st->fill + 1, 0, stride - st->fill - 1);
+  uint32_t nk = st->fill < keep ? st->fill : keep;
+  memmove(st->pending, st->pending + st->fill - nk, nk);
+  st->fill = nk;
+  st->fresh = 0;
+}
+
+int mk_fasta_window(mk_fasta_state *st, const uint8_t *buf, size_t n, int final, uint8_t *rows, uint32_t stride,
+                    uint64_t max_rows, uint64_t *nrows, size_t *consumed) {
+  if (!st || !rows || !nrows || !consumed || stride > 4096 || (stride & 3) || stride < 2 * st->TL + 4) return MK_ERR_ARG;
+  const uint32_t cap = stride - 1; /* payload bytes per row; the last byte is the '\n' terminator */
+  uint64_t r = 0;
+  size_t pos = 0;
+  while (pos < n) {
+    if (st->fill == cap) { /* row full: every k-mer ending in it is complete, cut here */
+      if (r == max_rows) break;
+      mk_fasta_emit(st, rows + r++ * (uint64_t)stride, stride);
+    }
+    uint8_t ch = buf[pos++];
+    if (st->in_header) { /* '>' line: skipped up to its '\n' (iseq2comem.c:259-271) */
+      if (ch == '\n') st->in_header = 0;
+      continue;
+    }
+    if (ch == '\n' || ch == '\r') continue; /* line breaks do not reset the window (iseq2comem.c:257) */
+    if (ch == '>') st->in_header = 1;        /* the '>' itself stays in the stream as one reset byte */
+    st->pending[st->fill++] = ch; /* ACGTacgt roll in the kernel; any other byte resets (iseq2comem.c:258,275-279) */
+    st->fresh++;
+  }
+  if (final && pos >= n && st->fresh > 0 && r < max_rows) mk_fasta_emit(st, rows + r++ * (uint64_t)stride, stride);
+  *nrows = r;
+  *consumed = pos;
+  return MK_OK;
+}

@@ -1,0 +1,24 @@
+/* mk_host_internal.h -- small helpers shared by the host C files and the HIP translation units */
+#ifndef MK_HOST_INTERNAL_H
+#define MK_HOST_INTERNAL_H
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MK_HD __host__ __device__
+#else
+#define MK_HD
+#endif
+
+/* splitmix64 finaliser used as a counter-based PRNG (synthetic reads, .shuf generator) */
+static inline MK_HD uint64_t mk_mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+/* word j (32 bases) of synthetic read i: SURVEY.md 8d / metakssd_hip.h */
+static inline MK_HD uint64_t mk_synth_word(uint64_t seed, uint64_t read, uint64_t j) {
+  return mk_mix64(mk_mix64(seed ^ read) + j);
+}
+#endif

@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""oracle/check_vs_ref.py -- TEST INFRASTRUCTURE ONLY.
+
+Pins the oracle restatement (oracle/kssd_oracle_cli) against the REAL reference
+(oracle/_ref/metakssd, compiled from /root/reference by `make -C oracle ref`):
+both run `dist -L <.shuf> [-A] [-u] -p 1 -o <dir> <inputs>` on the same generated inputs and the
+payload files (combco.N, combco.N.a, combco.index.N) must be byte-identical; cofiles.stat is
+compared field-wise (the reference leaves 3 padding bytes uninitialised).
+
+Runs only where oracle/_ref/metakssd exists (this container).  Usage:
+    python oracle/check_vs_ref.py [--keep DIR] [--big]
+"""
+import argparse
+import ctypes
+import filecmp
+import os
+import random
+import shutil
+import struct
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.path.join(HERE, "_ref", "metakssd")
+ORA = os.path.join(HERE, "kssd_oracle_cli")
+
+
+def host_lib():
+    """the product's host-side C helpers (.shuf generator, synthetic FASTQ writer) -- input generators only"""
+    for cand in (os.path.join(ROOT, "metakssd_amd", "lib", "libmetakssd_hip.so"), "/tmp/libmkhost.so"):
+        if os.path.exists(cand):
+            return ctypes.CDLL(cand)
+    raise SystemExit("build the product library first (python -c 'import __graft_entry__ as g; g.build()')")
+
+
+class Shuf(ctypes.Structure):
+    _fields_ = [("id", ctypes.c_int32), ("k", ctypes.c_int32), ("subk", ctypes.c_int32), ("drlevel", ctypes.c_int32),
+                ("table", ctypes.POINTER(ctypes.c_int32)), ("len", ctypes.c_uint64)]
+
+
+def gen_shuf(lib, path, k, subk, drl, seed):
+    s = Shuf()
+    rc = lib.mk_shuf_generate(k, subk, drl, ctypes.c_uint64(seed), ctypes.byref(s))
+    assert rc == 0, rc
+    assert lib.mk_shuf_write(ctypes.byref(s), path.encode()) == 0
+    lib.mk_shuf_free(ctypes.byref(s))
+
+
+def parse_stat(path):
+    b = open(path, "rb").read()
+    shuf_id, koc = struct.unpack_from("<IB", b, 0)
+    kmerlen, dim_rd_len, comp_num, infile_num, all_ctx = struct.unpack_from("<iiiiQ", b, 8)
+    cts = struct.unpack_from("<%dI" % infile_num, b, 32)
+    names = []
+    off = 32 + 4 * infile_num
+    for i in range(infile_num):
+        raw = b[off + 256 * i: off + 256 * (i + 1)]
+        names.append(raw.split(b"\0", 1)[0].decode())
+    assert len(b) == off + 256 * infile_num
+    return dict(shuf_id=shuf_id, koc=koc, kmerlen=kmerlen, dim_rd_len=dim_rd_len, comp_num=comp_num,
+                infile_num=infile_num, all_ctx=all_ctx, cts=list(cts), names=names)
+
+
+def run(cmd, cwd):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return r.returncode, r.stdout.decode(errors="replace"), r.stderr.decode(errors="replace")
+
+
+def compare_dirs(a, b, single_input=True):
+    """payload byte-equality + stat field equality; returns list of problems"""
+    bad = []
+    sa, sb = parse_stat(os.path.join(a, "cofiles.stat")), parse_stat(os.path.join(b, "cofiles.stat"))
+    if sa != sb:
+        bad.append("cofiles.stat fields differ: %r vs %r" % (sa, sb))
+    names = sorted(f for f in os.listdir(a) if f.startswith("combco"))
+    namesb = sorted(f for f in os.listdir(b) if f.startswith("combco"))
+    if names != namesb:
+        bad.append("file sets differ: %r vs %r" % (names, namesb))
+    for f in names:
+        if f in namesb and not filecmp.cmp(os.path.join(a, f), os.path.join(b, f), shallow=False):
+            bad.append("%s differs" % f)
+    return bad
+
+
+RC = str.maketrans("ACGTacgt", "TGCAtgca")
+
+
+def revcomp(s):
+    return s.translate(RC)[::-1]
+
+
+def write_fq(path, seqs, crlf=False, final_newline=True, drop_last_qual=False):
+    nl = "\r\n" if crlf else "\n"
+    out = []
+    for i, s in enumerate(seqs):
+        rec = ["@r%d" % i, s, "+", "I" * len(s)]
+        if drop_last_qual and i == len(seqs) - 1:
+            rec = rec[:3]
+        out.append(nl.join(rec) + nl)
+    txt = "".join(out)
+    if not final_newline:
+        txt = txt[:-len(nl)]
+    open(path, "w", newline="").write(txt)
+
+
+def rand_seq(rng, n):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--keep", default=None)
+    ap.add_argument("--big", action="store_true", help="also run the 1.5 M-read K9 collision case")
+    args = ap.parse_args()
+    if not os.path.exists(REF):
+        raise SystemExit("oracle/_ref/metakssd missing: run `make -C oracle ref` where /root/reference exists")
+    subprocess.check_call(["make", "-s", "-C", HERE])
+    lib = host_lib()
+    lib.mk_shuf_generate.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_uint64, ctypes.POINTER(Shuf)]
+    lib.mk_synth_fastq_write.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
+    work = args.keep or tempfile.mkdtemp(prefix="kssd_chk_")
+    os.makedirs(work, exist_ok=True)
+    rng = random.Random(20260101)
+    failures = 0
+
+    shufs = {}
+    # L0K6 (subk 3, level 0): dim_end = max(16^3,4096) = whole space => EVERY k-mer accepted, table 131071 slots:
+    #   a few hundred reads give load ~0.5 (collision order), a few thousand overflow hashlimit (abort path).
+    # L1K7 (subk 4, level 1): 1/16 of k-mers accepted, same table size.
+    for name, (k, subk, drl, seed) in {"L3K11": (11, 6, 3, 11), "L3K9": (9, 6, 3, 9), "L3K10": (10, 6, 3, 10),
+                                       "L2K11": (11, 5, 2, 211), "L0K6": (6, 3, 0, 6), "L1K7": (7, 4, 1, 7)}.items():
+        p = os.path.join(work, name + ".shuf")
+        if not os.path.exists(p):
+            gen_shuf(lib, p, k, subk, drl, seed)
+        shufs[name] = p
+
+    # L0K6 variant whose table maps inner substring 0 to 0, so poly-A / poly-T reads produce key 0
+    import array
+    zpath = os.path.join(work, "L0K6z.shuf")
+    raw = open(shufs["L0K6"], "rb").read()
+    tab = array.array("i", raw[16:])
+    j = tab.index(0)
+    tab[j], tab[0] = tab[0], 0
+    open(zpath, "wb").write(raw[:16] + tab.tobytes())
+    shufs["L0K6z"] = zpath
+
+    def case(label, shuf, inputs, flags, expect_abort=False):
+        nonlocal failures
+        o_ref, o_ora = os.path.join(work, label + ".ref"), os.path.join(work, label + ".ora")
+        for d in (o_ref, o_ora):
+            shutil.rmtree(d, ignore_errors=True)
+        rc1, out1, err1 = run([REF, "dist", "-L", shufs[shuf]] + flags + ["-p", "1", "-o", o_ref] + inputs, work)
+        rc2, out2, err2 = run([ORA, "-L", shufs[shuf]] + flags + ["-o", o_ora] + inputs, work)
+        # the reference aborts through err(errno, "...too crowd...") (iseq2comem.c:708-709); errno is 0 there,
+        # so its exit status is 0: the abort is recognised by the message, and by cofiles.stat never being written
+        ref_abort = "too crowd" in err1 and not os.path.exists(os.path.join(o_ref, "cofiles.stat"))
+        if expect_abort or ref_abort:
+            ok = expect_abort and ref_abort and rc2 != 0
+            print("%s %-28s both abort: ref abort=%s ora rc=%d" % ("ok  " if ok else "FAIL", label, ref_abort, rc2))
+            failures += 0 if ok else 1
+            return
+        if rc1 != 0 or rc2 != 0:
+            print("FAIL %-28s ref rc=%d ora rc=%d\n%s\n%s" % (label, rc1, rc2, err1[-300:], err2[-300:]))
+            failures += 1
+            return
+        bad = compare_dirs(o_ref, o_ora)
+        st = parse_stat(os.path.join(o_ref, "cofiles.stat"))
+        if bad:
+            failures += 1
+            print("FAIL %-28s %s" % (label, "; ".join(bad)))
+        else:
+            print("ok   %-28s distinct=%d comps=%d" % (label, st["all_ctx"], st["comp_num"]))
+
+    # ---- FASTQ -A cases -------------------------------------------------------------------
+    fq = os.path.join(work, "syn100k.fq")
+    lib.mk_synth_fastq_write(fq.encode(), 1, 0, 100000, 150)
+    case("L3K11_syn100k", "L3K11", [fq], ["-A"])          # BASELINE config 1
+    case("L3K9_syn100k", "L3K9", [fq], ["-A"])            # hashsize 131071, load ~0.02
+
+    # dense-collision case: K9 table (131071 slots), reads drawn from a small genome pool => many repeats
+    pool = rand_seq(rng, 200000)
+    seqs = []
+    for i in range(60000):
+        a = rng.randrange(0, len(pool) - 150)
+        s = pool[a:a + 150]
+        if rng.random() < 0.5:
+            s = revcomp(s)
+        if rng.random() < 0.05:
+            j = rng.randrange(150)
+            s = s[:j] + "N" + s[j + 1:]
+        seqs.append(s)
+    fq2 = os.path.join(work, "pool60k.fq")
+    write_fq(fq2, seqs)
+    case("L3K9_pool60k", "L3K9", [fq2], ["-A"])
+    case("L3K11_pool60k", "L3K11", [fq2], ["-A"])
+
+    # ragged lengths, lower case, N runs, CRLF, truncated last record, no final newline
+    seqs = []
+    for i in range(20000):
+        L = rng.choice([0, 1, 21, 22, 23, 50, 100, 150, 151, 250, 300])
+        s = rand_seq(rng, L)
+        if rng.random() < 0.3:
+            s = s.lower()
+        if L > 30 and rng.random() < 0.3:
+            j = rng.randrange(L - 5)
+            s = s[:j] + "NNN" + s[j + 3:]
+        seqs.append(s)
+    fq3 = os.path.join(work, "ragged.fq")
+    write_fq(fq3, seqs)
+    case("L3K9_ragged", "L3K9", [fq3], ["-A"])
+    fq4 = os.path.join(work, "ragged_crlf.fq")
+    write_fq(fq4, seqs[:5000], crlf=True)
+    case("L3K9_ragged_crlf", "L3K9", [fq4], ["-A"])
+    fq5 = os.path.join(work, "trunc.fq")
+    write_fq(fq5, seqs[:3001], drop_last_qual=True)
+    case("L3K9_trunc_last", "L3K9", [fq5], ["-A"])
+    fq6 = os.path.join(work, "nonl.fq")
+    write_fq(fq6, seqs[:3000], final_newline=False)
+    case("L3K9_no_final_nl", "L3K9", [fq6], ["-A"])
+
+    # saturation: one read repeated 70 000 times (every accepted k-mer in it reaches 65535)
+    one = rand_seq(rng, 150)
+    fq7 = os.path.join(work, "sat.fq")
+    write_fq(fq7, [one] * 70000)
+    case("L3K9_saturate", "L3K9", [fq7], ["-A"])
+    # poly-A / key-0 neighbourhood and homopolymers
+    fq8 = os.path.join(work, "homo.fq")
+    write_fq(fq8, ["A" * 150, "C" * 150, "G" * 150, "T" * 150, "AC" * 75, "ACGT" * 40] * 50)
+    case("L3K9_homopolymer", "L3K9", [fq8], ["-A"])
+    case("L3K11_homopolymer", "L3K11", [fq8], ["-A"])
+    # accept-everything table: collisions galore from tiny inputs
+    fq9 = os.path.join(work, "dense400.fq")
+    write_fq(fq9, [rand_seq(rng, 150) for _ in range(400)])
+    case("L0K6_dense400_load0.4", "L0K6", [fq9], ["-A"])
+    fq10 = os.path.join(work, "dense_pool.fq")
+    write_fq(fq10, seqs[:4000] if False else [pool[a:a + 150] for a in (rng.randrange(0, 30000) for _ in range(6000))])
+    case("L0K6_pool_counts", "L0K6", [fq10], ["-A"])
+    case("L1K7_pool_counts", "L1K7", [fq10, ], ["-A"])
+    case("L0K6_saturate", "L0K6", [fq7], ["-A"])
+    case("L0K6z_key0", "L0K6z", [fq8], ["-A"])
+    case("L0K6_ragged", "L0K6", [fq3], ["-A"], expect_abort=True)   # > hashlimit distinct keys: both must abort
+    fq11 = os.path.join(work, "ragged500.fq")
+    write_fq(fq11, seqs[:500])
+    case("L0K6_ragged500", "L0K6", [fq11], ["-A"])
+    case("L1K7_ragged", "L1K7", [fq3], ["-A"], expect_abort=True)
+    case("L1K7_ragged500", "L1K7", [fq11], ["-A"])
+    # gz input goes through zcat in both
+    subprocess.check_call("gzip -kf %s" % fq3, shell=True)
+    case("L3K9_ragged_gz", "L3K9", [fq3 + ".gz"], ["-A"])
+    # 16 components
+    case("L2K11_pool60k", "L2K11", [fq2], ["-A"])
+
+    # ---- FASTA cases (config 5 family): single file each so the reference's random file order is moot --
+    def write_fa(path, contigs, width=70):
+        with open(path, "w") as f:
+            for i, c in enumerate(contigs):
+                f.write(">contig_%d some description\n" % i)
+                for j in range(0, len(c), width):
+                    f.write(c[j:j + width] + "\n")
+
+    g = rand_seq(rng, 400000)
+    contigs = [g[:150000], g[150000:150050] + "N" * 37 + g[150050:300000], g[100000:180000], revcomp(g[300000:400000]).lower()]
+    fa1 = os.path.join(work, "g1.fa")
+    write_fa(fa1, contigs)
+    for sh in ("L3K10", "L3K9", "L2K11"):
+        case("%s_fasta" % sh, sh, [fa1], [])
+        case("%s_fasta_uniq" % sh, sh, [fa1], ["-u"])
+    fa3 = os.path.join(work, "g3.fasta")
+    write_fa(fa3, [g[:30000], g[10000:20000], "A" * 100 + g[500:900] + "T" * 50])
+    for sh in ("L0K6", "L0K6z", "L1K7"):
+        case("%s_fasta_dense" % sh, sh, [fa3], [])
+        case("%s_fasta_dense_uniq" % sh, sh, [fa3], ["-u"])
+    case("L0K6_fasta_crowded", "L0K6", [fa1], [], expect_abort=True)
+    fa2 = os.path.join(work, "g2.fna")
+    write_fa(fa2, [rand_seq(rng, 30011), "ACGT" * 10, "", rand_seq(rng, 21), rand_seq(rng, 22)], width=60)
+    case("L3K10_fasta_small", "L3K10", [fa2], [])
+
+    if args.big:
+        fqb = os.path.join(work, "syn1p5m.fq")
+        lib.mk_synth_fastq_write(fqb.encode(), 7, 0, 1500000, 150)
+        case("L3K9_syn1p5m_load0.37", "L3K9", [fqb], ["-A"])
+
+    print("%d failure(s); work dir %s" % (failures, work))
+    if not args.keep:
+        shutil.rmtree(work, ignore_errors=True)
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

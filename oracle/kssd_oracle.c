@@ -1,0 +1,470 @@
+/*
+ * kssd_oracle.c -- TEST INFRASTRUCTURE ONLY (see kssd_oracle.h).
+ *
+ * Plain-C restatement of the reference's `dist -L <.shuf> [-A]` sketching path at -p 1.
+ * Written from the algorithm, not from the text, of /root/reference; each block cites the
+ * reference lines whose behaviour it restates.  Pinned against the compiled reference by
+ * oracle/check_vs_ref.sh (byte-for-byte on combco.N / combco.N.a / combco.index.N, field-wise on
+ * cofiles.stat) and by the golden vectors in tests/golden/.
+ */
+#define _GNU_SOURCE
+#include "kssd_oracle.h"
+
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- constants of the format (global_basic.h:35-44, command_shuffle.h:20, iseq2comem.h:6-7) ---- */
+#define KO_COMPONENT_SZ 8
+#define KO_CTX_SPC_USE_L 8
+#define KO_LD_FCTR 0.6
+#define KO_MIN_SUBCTX_DIM_SMP_SZ 4096
+#define KO_OCCRC_BIT 16
+#define KO_OCCRC_MAX 0xffffULL
+#define KO_HIBIT 0x8000000000000000ULL
+#define KO_PATHLEN 256
+#define KO_FQ_LEN 4096 /* iseq2comem.c:656 */
+
+/* table sizes: primes just under 2^8 .. 2^32 (global_basic.c:75-82) */
+static const unsigned int ko_primes[25] = {
+    251u,       509u,       1021u,      2039u,       4093u,       8191u,       16381u,      32749u,     65521u,
+    131071u,    262139u,    524287u,    1048573u,    2097143u,    4194301u,    8388593u,    16777213u,  33554393u,
+    67108859u,  134217689u, 268435399u, 536870909u,  1073741789u, 2147483647u, 4294967291u};
+
+/* Basemap (global_basic.c:62-69): A/a=0 C/c=1 G/g=2 T/t=3, everything else -1.  Bytes >= 128 index the
+ * reference's 128-entry table out of bounds (undefined); the oracle defines them as invalid. */
+static inline int ko_code(unsigned char ch) {
+  switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+  }
+}
+
+int ko_params_derive(int shuf_id, int k, int subk, int drlevel, ko_params *P) {
+  if (!P || k < 1 || k > 16 || subk < 0 || subk > k || subk >= 8 || drlevel < 0 || drlevel > subk) return KO_ERR_ARG;
+  memset(P, 0, sizeof *P);
+  P->shuf_id = shuf_id;
+  P->k = k;
+  P->subk = subk;
+  P->drlevel = drlevel;
+  /* get_hashsz(): command_dist.c:288-305 */
+  int pidx = 4 * (k - drlevel) - KO_CTX_SPC_USE_L - 7;
+  if (pidx < 0 || pidx > 24) return KO_ERR_PRIMER;
+  P->hashsize = ko_primes[pidx];
+  /* seq2co_global_var_initial(): iseq2comem.c:56-84 */
+  P->half_outctx_len = k - subk;
+  P->hashlimit = (unsigned int)(P->hashsize * KO_LD_FCTR); /* double product truncated, :61 */
+  P->component_num = (k - drlevel > KO_COMPONENT_SZ) ? (int)(1UL << (4 * (k - drlevel - KO_COMPONENT_SZ))) : 1;
+  P->comp_code_bits = (k - drlevel > KO_COMPONENT_SZ) ? 4 * (k - drlevel - KO_COMPONENT_SZ) : 0; /* :518 */
+  P->crvsaddmove = 4 * k - 2;
+  P->tupmask = 0xffffffffffffffffULL >> (64 - 4 * k);
+  P->TL = 2 * k;
+  P->domask = ((1ULL << (subk * 4)) - 1) << (2 * P->half_outctx_len);
+  P->undomask = ((1ULL << (P->half_outctx_len * 2)) - 1) << (2 * (k + subk));
+  P->dim_start = 0;
+  ko_llong subspace = 1ULL << (4 * (subk - drlevel));
+  P->dim_end = P->dim_start + (int)(subspace > KO_MIN_SUBCTX_DIM_SMP_SZ ? subspace : KO_MIN_SUBCTX_DIM_SMP_SZ);
+  return KO_OK;
+}
+
+/* probe sequence: HASH(K,I,S) = (K%S + I*(1 + K%(S-1))) % S in 64-bit arithmetic (global_basic.h:282-284) */
+static inline ko_llong ko_probe(ko_llong key, ko_llong i, ko_llong S) { return (key % S + i * (1 + key % (S - 1))) % S; }
+
+/* accept test + key reduction (iseq2comem.c:691-699).  returns 1 and sets *key when accepted */
+static inline int ko_reduce(const ko_params *P, const int *shuf, ko_llong tuple, ko_llong crvs, ko_llong *key) {
+  ko_llong uni = tuple < crvs ? tuple : crvs;
+  unsigned int dim_tup = (unsigned int)((uni & P->domask) >> (P->half_outctx_len * 2));
+  ko_llong pf = (ko_llong)(long long)shuf[dim_tup]; /* int widened to llong (:693) */
+  if (pf >= (ko_llong)(long long)P->dim_end || pf < (ko_llong)(long long)P->dim_start) return 0;
+  pf -= (ko_llong)P->dim_start;
+  ko_llong lowmask = (1ULL << (P->half_outctx_len * 2)) - 1;
+  *key = (((uni & P->undomask) + ((uni & lowmask) << (P->TL * 2 - P->half_outctx_len * 4))) >> (P->drlevel * 4)) + pf;
+  return 1;
+}
+
+/* counted insert (iseq2comem.c:701-718) */
+static inline int ko_insert_koc(const ko_params *P, ko_llong *co, ko_llong key, unsigned int *keycount) {
+  ko_llong S = P->hashsize;
+  for (ko_llong i = 0; i < S; i++) {
+    ko_llong n = ko_probe(key, i, S);
+    if (co[n] == 0) {
+      co[n] = (key << KO_OCCRC_BIT) + 1;
+      if (++*keycount > P->hashlimit) return KO_ERR_CROWDED; /* :708-709 */
+      return KO_OK;
+    }
+    if ((co[n] >> KO_OCCRC_BIT) == key) {
+      if ((co[n] & KO_OCCRC_MAX) < KO_OCCRC_MAX) co[n] += 1; /* saturates at 65535, :712-714 */
+      return KO_OK;
+    }
+  }
+  return KO_OK; /* table full: the reference falls out of the loop silently */
+}
+
+/* one read line: iseq2comem.c:677-720.  `row` must contain a '\n' within `maxlen` bytes. */
+static int ko_walk_read_koc(const ko_params *P, const int *shuf, const unsigned char *row, size_t maxlen, ko_llong *co,
+                            unsigned int *keycount) {
+  int base = 1;
+  ko_llong tuple = 0, crvs = 0;
+  for (size_t pos = 0; pos < maxlen && row[pos] != '\n'; pos++) {
+    int b = ko_code(row[pos]);
+    if (b < 0) { base = 1; continue; }
+    tuple = ((tuple << 2) | (ko_llong)b) & P->tupmask;
+    crvs = (crvs >> 2) + (((ko_llong)b ^ 3ULL) << P->crvsaddmove);
+    base++;
+    if (base > P->TL) {
+      ko_llong key;
+      if (!ko_reduce(P, shuf, tuple, crvs, &key)) continue;
+      int rc = ko_insert_koc(P, co, key, keycount);
+      if (rc) return rc;
+    }
+  }
+  return KO_OK;
+}
+
+int ko_koc_from_rows(const ko_params *P, const int *shuf, const unsigned char *rows, size_t stride, size_t nreads,
+                     ko_llong *co, int clear_first, unsigned int *keycount_io) {
+  unsigned int kc = keycount_io ? *keycount_io : 0;
+  if (clear_first) { memset(co, 0, (size_t)P->hashsize * sizeof(ko_llong)); kc = 0; }
+  for (size_t t = 0; t < nreads; t++) {
+    int rc = ko_walk_read_koc(P, shuf, rows + t * stride, stride, co, &kc);
+    if (rc) return rc;
+  }
+  if (keycount_io) *keycount_io = kc;
+  return KO_OK;
+}
+
+int ko_koc_from_rows_omp(const ko_params *P, const int *shuf, const unsigned char *rows, size_t stride, size_t nreads,
+                         ko_llong *co, int clear_first, int nthreads) {
+  if (clear_first) memset(co, 0, (size_t)P->hashsize * sizeof(ko_llong));
+  const ko_llong S = P->hashsize;
+  (void)nthreads;
+  /* same structure as iseq2comem.c:675-721: guided parallel-for over reads, unsynchronised
+   * check-then-write insert with atomic write / atomic increment -- benign for timing only. */
+#pragma omp parallel for num_threads(nthreads) schedule(guided)
+  for (long t = 0; t < (long)nreads; t++) {
+    const unsigned char *row = rows + (size_t)t * stride;
+    int base = 1;
+    ko_llong tuple = 0, crvs = 0;
+    for (size_t pos = 0; pos < stride && row[pos] != '\n'; pos++) {
+      int b = ko_code(row[pos]);
+      if (b < 0) { base = 1; continue; }
+      tuple = ((tuple << 2) | (ko_llong)b) & P->tupmask;
+      crvs = (crvs >> 2) + (((ko_llong)b ^ 3ULL) << P->crvsaddmove);
+      base++;
+      if (base <= P->TL) continue;
+      ko_llong key;
+      if (!ko_reduce(P, shuf, tuple, crvs, &key)) continue;
+      for (ko_llong i = 0; i < S; i++) {
+        ko_llong n = ko_probe(key, i, S);
+        ko_llong cur;
+#pragma omp atomic read
+        cur = co[n];
+        if (cur == 0) {
+#pragma omp atomic write
+          co[n] = (key << KO_OCCRC_BIT) + 1;
+          break;
+        } else if ((cur >> KO_OCCRC_BIT) == key) {
+          if ((cur & KO_OCCRC_MAX) < KO_OCCRC_MAX) {
+#pragma omp atomic
+            co[n] += 1;
+          }
+          break;
+        }
+      }
+    }
+  }
+  return KO_OK;
+}
+
+/* ---- fgets() over a memory stream, including the EOF indicator feof() reports ---- */
+typedef struct { const unsigned char *p, *end; int eof; } ko_ms;
+static unsigned char *ko_ms_gets(ko_ms *s, unsigned char *buf, int size) {
+  int n = 0;
+  while (n < size - 1) {
+    if (s->p == s->end) { s->eof = 1; break; }
+    unsigned char c = *s->p++;
+    buf[n++] = c;
+    if (c == '\n') break;
+  }
+  if (n == 0) return NULL;
+  buf[n] = 0;
+  return buf;
+}
+
+int ko_koc_from_fastq_bytes(const ko_params *P, const int *shuf, const unsigned char *fq, size_t n, ko_llong *co,
+                            ko_llong *nreads_out) {
+  /* reader: iseq2comem.c:672-673.  Four fgets(…,FQ_LEN,…) per record, line 2 kept; a record whose
+   * 4th fgets fails is dropped.  Batching by 65536 does not change the sequential result. */
+  ko_ms s = {fq, fq + n, 0};
+  unsigned char tmp[KO_FQ_LEN], seq[KO_FQ_LEN];
+  unsigned int keycount = 0;
+  ko_llong nreads = 0;
+  memset(co, 0, (size_t)P->hashsize * sizeof(ko_llong)); /* :663 */
+  while (!s.eof) {
+    if (!(ko_ms_gets(&s, tmp, KO_FQ_LEN) && ko_ms_gets(&s, seq, KO_FQ_LEN) && ko_ms_gets(&s, tmp, KO_FQ_LEN) &&
+          ko_ms_gets(&s, tmp, KO_FQ_LEN)))
+      continue; /* inner for-loop ends; outer while re-tests feof (:672) */
+    size_t len = strlen((char *)seq);
+    if (len == 0 || seq[len - 1] != '\n') return KO_ERR_CONTRACT; /* line >= 4095 chars: reference walks into stale buffer */
+    int rc = ko_walk_read_koc(P, shuf, seq, len, co, &keycount);
+    if (rc) return rc;
+    nreads++;
+  }
+  if (nreads_out) *nreads_out = nreads;
+  return KO_OK;
+}
+
+unsigned int ko_dump_koc(const ko_params *P, const ko_llong *co, uint32_t **ids, uint16_t **cnts, size_t *n_out) {
+  /* iseq2comem.c:539-553: slot order; component = key % component_num; id = key >> comp_code_bits */
+  unsigned int wr = 0;
+  for (int c = 0; c < P->component_num; c++) n_out[c] = 0;
+  for (ko_llong s = 0; s < P->hashsize; s++) {
+    if (co[s] == 0) continue;
+    ko_llong key = co[s] >> KO_OCCRC_BIT;
+    int c = (int)(key % (ko_llong)P->component_num);
+    if (ids) {
+      ids[c][n_out[c]] = (uint32_t)(co[s] >> (P->comp_code_bits + KO_OCCRC_BIT));
+      cnts[c][n_out[c]] = (uint16_t)(co[s] & KO_OCCRC_MAX);
+    }
+    n_out[c]++;
+    wr++;
+  }
+  return wr;
+}
+
+int ko_co_from_fasta_bytes(const ko_params *P, const int *shuf, const unsigned char *fa, size_t n, ko_llong *co, int uniq) {
+  /* fasta2co(): iseq2comem.c:218-315; uniq_fasta2co(): :729-828.  The 64 KiB refill window is
+   * transparent to the result except for the header-skip loop reading buff[-1] right after a refill
+   * (:268, undefined) which the oracle does not model. */
+  ko_llong S = P->hashsize;
+  memset(co, 0, (size_t)S * sizeof(ko_llong));
+  if (n == 0) return KO_ERR_CONTRACT; /* :235 err() on empty input */
+  ko_llong tuple = 0, crvs = 0, base = 1;
+  unsigned int keycount = 0;
+  for (size_t pos = 0; pos < n; pos++) {
+    unsigned char ch = fa[pos];
+    int b = ko_code(ch);
+    if (b >= 0) {
+      tuple = ((tuple << 2) | (ko_llong)b) & P->tupmask;
+      crvs = (crvs >> 2) + (((ko_llong)b ^ 3ULL) << P->crvsaddmove);
+      base++;
+    } else if (ch == '\n' || ch == '\r') {
+      continue; /* line breaks do not reset the window (:257) */
+    } else if (ch == '>') {
+      while (pos < n && fa[pos] != '\n') pos++; /* skip header (:259-271) */
+      if (pos >= n) return KO_ERR_CONTRACT;     /* header without newline at EOF: reference err()s (:269) */
+      base = 1;
+      continue;
+    } else {
+      base = 1; /* any other byte, alphabetic or not (:258,:275-279) */
+      continue;
+    }
+    if (base > (ko_llong)P->TL) {
+      ko_llong key;
+      if (!ko_reduce(P, shuf, tuple, crvs, &key)) continue;
+      for (ko_llong i = 0; i < S; i++) {
+        ko_llong s = ko_probe(key, i, S);
+        if (co[s] == 0) {
+          co[s] = key; /* key 0 leaves the slot empty yet counts (:300-305) */
+          if (++keycount > P->hashlimit) return KO_ERR_CROWDED;
+          break;
+        }
+        if (!uniq) {
+          if (co[s] == key) break;
+        } else if ((co[s] | KO_HIBIT) == (key | KO_HIBIT)) {
+          co[s] |= KO_HIBIT; /* second sighting flags the slot (:819-821) */
+          break;
+        }
+      }
+    }
+  }
+  return KO_OK;
+}
+
+unsigned int ko_dump_co(const ko_params *P, const ko_llong *co, uint32_t **ids, size_t *n_out) {
+  /* iseq2comem.c:638-646: skips empty and HIBIT-flagged slots; file = slot % component_num */
+  unsigned int wr = 0;
+  for (int c = 0; c < P->component_num; c++) n_out[c] = 0;
+  for (ko_llong s = 0; s < P->hashsize; s++) {
+    if (co[s] == 0 || co[s] >= KO_HIBIT) continue;
+    int c = (int)(co[s] % (ko_llong)P->component_num);
+    if (ids) ids[c][n_out[c]] = (uint32_t)(co[s] >> P->comp_code_bits);
+    n_out[c]++;
+    wr++;
+  }
+  return wr;
+}
+
+int ko_shuf_read(const char *path, int header[4], int **table_out, size_t *len_out) {
+  /* command_shuffle.c:215-235: 16-byte header {id,k,subk,drlevel} then int32[16^subk] */
+  size_t pl = strlen(path);
+  if (pl < 5 || strcmp(path + pl - 5, ".shuf") != 0) return KO_ERR_ARG;
+  FILE *f = fopen(path, "rb");
+  if (!f) return KO_ERR_IO;
+  if (fread(header, sizeof(int), 4, f) != 4) { fclose(f); return KO_ERR_IO; }
+  if (header[2] < 0 || header[2] >= 8) { fclose(f); return KO_ERR_ARG; }
+  size_t len = (size_t)1 << (4 * header[2]);
+  int *t = malloc(len * sizeof(int));
+  if (!t) { fclose(f); return KO_ERR_IO; }
+  if (fread(t, sizeof(int), len, f) != len) { free(t); fclose(f); return KO_ERR_IO; }
+  fclose(f);
+  *table_out = t;
+  *len_out = len;
+  return KO_OK;
+}
+
+/* ---- stage I driver: command_dist.c:341-500 at -p 1 with the given file order ---- */
+static int ko_has_suffix(const char *name, const char *suf) {
+  size_t a = strlen(name), b = strlen(suf);
+  return a >= b && strcmp(name + a - b, suf) == 0;
+}
+static int ko_is_fastq_name(const char *name) {
+  /* isOK_fmt_infile(name, fastq_fmt): strip one .gz/.bz2 then test .fq/.fastq (global_basic.h:162-186) */
+  char tmp[KO_PATHLEN * 2];
+  snprintf(tmp, sizeof tmp, "%s", name);
+  if (ko_has_suffix(tmp, ".gz")) tmp[strlen(tmp) - 3] = 0;
+  else if (ko_has_suffix(tmp, ".bz2")) tmp[strlen(tmp) - 4] = 0;
+  return ko_has_suffix(tmp, ".fq") || ko_has_suffix(tmp, ".fastq");
+}
+static unsigned char *ko_slurp_zcat(const char *path, size_t *n_out) {
+  /* every input goes through `zcat -fc` (iseq2comem.c:216,666-669) */
+  char cmd[KO_PATHLEN * 2 + 16];
+  snprintf(cmd, sizeof cmd, "zcat -fc %s", path);
+  FILE *p = popen(cmd, "r");
+  if (!p) return NULL;
+  size_t cap = 1 << 20, n = 0;
+  unsigned char *buf = malloc(cap);
+  for (;;) {
+    if (n == cap) { cap *= 2; buf = realloc(buf, cap); }
+    size_t r = fread(buf + n, 1, cap - n, p);
+    if (r == 0) break;
+    n += r;
+  }
+  pclose(p);
+  *n_out = n;
+  return buf;
+}
+
+int ko_dist_stage1(const char *shuf_path, int abundance, int uniq, const char *outdir, int nfiles, const char **files) {
+  int header[4], *shuf = NULL;
+  size_t shuf_len = 0;
+  int rc = ko_shuf_read(shuf_path, header, &shuf, &shuf_len);
+  if (rc) return rc;
+  ko_params P;
+  rc = ko_params_derive(header[0], header[1], header[2], header[3], &P);
+  if (rc) { free(shuf); return rc; }
+  mkdir(outdir, 0777);
+  ko_llong *co = malloc((size_t)P.hashsize * sizeof(ko_llong));
+  if (!co) { free(shuf); return KO_ERR_IO; }
+
+  int C = P.component_num;
+  FILE **fid = calloc(C, sizeof(FILE *)), **fab = calloc(C, sizeof(FILE *));
+  size_t **index = calloc(C, sizeof(size_t *));
+  char path[KO_PATHLEN * 2];
+  for (int c = 0; c < C; c++) {
+    snprintf(path, sizeof path, "%s/combco.%d", outdir, c);
+    fid[c] = fopen(path, "wb");
+    index[c] = calloc(nfiles + 1, sizeof(size_t));
+    if (!fid[c]) return KO_ERR_IO;
+  }
+  uint32_t **ids = calloc(C, sizeof(uint32_t *));
+  uint16_t **cnts = calloc(C, sizeof(uint16_t *));
+  size_t *nout = calloc(C, sizeof(size_t));
+  unsigned int *ctx_ct = calloc(nfiles, sizeof(unsigned int));
+  ko_llong all_ctx_ct = 0;
+  int abundance_at_start = abundance;
+
+  for (int i = 0; i < nfiles && rc == KO_OK; i++) {
+    size_t n = 0;
+    unsigned char *bytes = ko_slurp_zcat(files[i], &n);
+    if (!bytes) { rc = KO_ERR_IO; break; }
+    int is_fq = ko_is_fastq_name(files[i]);
+    if (is_fq && abundance) {
+      rc = ko_koc_from_fastq_bytes(&P, shuf, bytes, n, co, NULL);
+      if (rc == KO_OK) {
+        ko_dump_koc(&P, co, NULL, NULL, nout);
+        for (int c = 0; c < C; c++) { ids[c] = malloc(4 * (nout[c] + 1)); cnts[c] = malloc(2 * (nout[c] + 1)); }
+        ctx_ct[i] = ko_dump_koc(&P, co, ids, cnts, nout);
+      }
+    } else if (is_fq) {
+      rc = KO_ERR_ARG; /* fastq2co 4-bit path (-n/-Q): not restated */
+    } else {
+      if (abundance) abundance = 0; /* command_dist.c:389-392: -A is switched off for good by the first FASTA */
+      rc = ko_co_from_fasta_bytes(&P, shuf, bytes, n, co, uniq);
+      if (rc == KO_OK) {
+        ko_dump_co(&P, co, NULL, nout);
+        for (int c = 0; c < C; c++) { ids[c] = malloc(4 * (nout[c] + 1)); cnts[c] = NULL; }
+        ctx_ct[i] = ko_dump_co(&P, co, ids, nout);
+      }
+    }
+    free(bytes);
+    if (rc) break;
+    all_ctx_ct += ctx_ct[i];
+    for (int c = 0; c < C; c++) {
+      fwrite(ids[c], 4, nout[c], fid[c]);
+      index[c][i + 1] = index[c][i] + nout[c];
+      if (cnts[c]) {
+        if (!fab[c]) {
+          snprintf(path, sizeof path, "%s/combco.%d.a", outdir, c);
+          fab[c] = fopen(path, "wb");
+        }
+        fwrite(cnts[c], 2, nout[c], fab[c]);
+      }
+      free(ids[c]);
+      free(cnts[c]);
+      ids[c] = NULL;
+      cnts[c] = NULL;
+    }
+  }
+  (void)abundance_at_start;
+  for (int c = 0; c < C; c++) {
+    if (fid[c]) fclose(fid[c]);
+    if (fab[c]) fclose(fab[c]);
+    if (rc == KO_OK) {
+      snprintf(path, sizeof path, "%s/combco.index.%d", outdir, c);
+      FILE *fi = fopen(path, "wb");
+      if (!fi) { rc = KO_ERR_IO; break; }
+      fwrite(index[c], sizeof(size_t), nfiles + 1, fi); /* command_dist.c:464 */
+      fclose(fi);
+    }
+    free(index[c]);
+  }
+  if (rc == KO_OK) {
+    /* cofiles.stat: co_dstat_t (global_basic.h:116-126) 32 bytes, padding zeroed here */
+    unsigned char hdr[32];
+    memset(hdr, 0, sizeof hdr);
+    uint32_t u32;
+    int32_t i32;
+    u32 = (uint32_t)P.shuf_id; memcpy(hdr + 0, &u32, 4);
+    hdr[4] = abundance ? 1 : 0;
+    i32 = P.k * 2; memcpy(hdr + 8, &i32, 4);
+    i32 = P.drlevel * 2; memcpy(hdr + 12, &i32, 4);
+    i32 = C; memcpy(hdr + 16, &i32, 4);
+    i32 = nfiles; memcpy(hdr + 20, &i32, 4);
+    memcpy(hdr + 24, &all_ctx_ct, 8);
+    snprintf(path, sizeof path, "%s/cofiles.stat", outdir);
+    FILE *fs = fopen(path, "wb");
+    if (!fs) rc = KO_ERR_IO;
+    else {
+      fwrite(hdr, 1, 32, fs);
+      fwrite(ctx_ct, sizeof(unsigned int), nfiles, fs);
+      for (int i = 0; i < nfiles; i++) {
+        char name[KO_PATHLEN];
+        memset(name, 0, sizeof name);
+        strncpy(name, files[i], KO_PATHLEN - 1);
+        fwrite(name, 1, KO_PATHLEN, fs);
+      }
+      fclose(fs);
+    }
+  }
+  free(fid); free(fab); free(index); free(ids); free(cnts); free(nout); free(ctx_ct); free(co); free(shuf);
+  return rc;
+}

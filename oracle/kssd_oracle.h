@@ -1,0 +1,75 @@
+/*
+ * kssd_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the MetaKSSD `dist -L <.shuf> [-A]` sketching path.  It is the
+ * parity checker for the HIP engine; nothing in the product (metakssd_amd/, include/) may link,
+ * import or execute it.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * Every function cites the reference file:line it restates (paths relative to /root/reference).
+ * Parity is PINNED: oracle/check_vs_ref.sh runs this restatement and the compiled reference
+ * (oracle/_ref/metakssd, built from the reference's own sources by oracle/Makefile) on the same
+ * inputs and compares the payload files byte for byte; tests/golden/ holds vectors produced by
+ * the compiled reference (tests/golden/make_golden.py).
+ */
+#ifndef KSSD_ORACLE_H
+#define KSSD_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef unsigned long long ko_llong; /* global_basic.h:51 */
+
+/* everything seq2co_global_var_initial() + get_hashsz() derive (iseq2comem.c:54-86, command_dist.c:286-315) */
+typedef struct ko_params {
+  int shuf_id, k, subk, drlevel; /* dim_shuffle_stat_t, command_shuffle.h:4-10 */
+  int half_outctx_len;           /* iseq2comem.c:59 */
+  int TL;                        /* iseq2comem.c:70 */
+  int crvsaddmove;               /* iseq2comem.c:68 */
+  int component_num;             /* iseq2comem.c:64-65 */
+  int comp_code_bits;            /* iseq2comem.c:518 */
+  int dim_start, dim_end;        /* iseq2comem.c:80-84 */
+  unsigned int hashsize;         /* command_dist.c:288-305 */
+  unsigned int hashlimit;        /* iseq2comem.c:61 */
+  ko_llong tupmask, domask, undomask; /* iseq2comem.c:69,74-76 */
+} ko_params;
+
+enum { KO_OK = 0, KO_ERR_PRIMER = -1, KO_ERR_CROWDED = -2, KO_ERR_ARG = -3, KO_ERR_IO = -4, KO_ERR_CONTRACT = -5 };
+
+int ko_params_derive(int shuf_id, int k, int subk, int drlevel, ko_params *out);
+
+/* -A FASTQ path: mt_shortreads2koc() at -p 1 (iseq2comem.c:657-727).  co[] has hashsize slots and
+ * is cleared here like the reference does (:663). */
+int ko_koc_from_fastq_bytes(const ko_params *P, const int *shuf, const unsigned char *fq, size_t n, ko_llong *co,
+                            ko_llong *nreads_out);
+/* same per-read loop (iseq2comem.c:676-720) over already framed fixed-stride rows ('\n' terminated);
+ * clear_first=0 continues filling the same table (the reference's batches do exactly that, :672-722). */
+int ko_koc_from_rows(const ko_params *P, const int *shuf, const unsigned char *rows, size_t stride, size_t nreads,
+                     ko_llong *co, int clear_first, unsigned int *keycount_io);
+/* OpenMP form of the same loop, racy exactly like the reference (:675,:703-714); only for timing. */
+int ko_koc_from_rows_omp(const ko_params *P, const int *shuf, const unsigned char *rows, size_t stride, size_t nreads,
+                         ko_llong *co, int clear_first, int nthreads);
+
+/* write_fqkoc2files() (iseq2comem.c:516-562) into memory: ids[c], cnts[c] must hold n_out[c] entries;
+ * call once with ids==NULL to size (n_out filled), then again. */
+unsigned int ko_dump_koc(const ko_params *P, const ko_llong *co, uint32_t **ids, uint16_t **cnts, size_t *n_out);
+
+/* FASTA path: fasta2co() (iseq2comem.c:218-315) / uniq_fasta2co() (:729-828) over a byte stream. */
+int ko_co_from_fasta_bytes(const ko_params *P, const int *shuf, const unsigned char *fa, size_t n, ko_llong *co, int uniq);
+/* wrt_co2cmpn_use_inn_subctx() (iseq2comem.c:625-652) into memory; same two-call protocol. */
+unsigned int ko_dump_co(const ko_params *P, const ko_llong *co, uint32_t **ids, size_t *n_out);
+
+/* read_dim_shuffle_file() (command_shuffle.c:215-235) */
+int ko_shuf_read(const char *path, int header[4], int **table_out, size_t *len_out);
+
+/* whole `dist -L shuf [-A] [-u] -o outdir files...` stage I at -p 1, files in the GIVEN order
+ * (the reference permutes them with a time-seeded shuffle, command_dist.c:215) :
+ * run_stageI() command_dist.c:341-500.  cofiles.stat padding and post-NUL path bytes are zeroed. */
+int ko_dist_stage1(const char *shuf_path, int abundance, int uniq, const char *outdir, int nfiles, const char **files);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,25 @@
+/* kssd_oracle_cli.c -- TEST INFRASTRUCTURE ONLY: command-line face of the oracle restatement.
+ * usage: kssd_oracle_cli -L x.shuf [-A] [-u] -o outdir file...   (mirrors `metakssd dist`, -p 1, given file order) */
+#include "kssd_oracle.h"
+#include <stdio.h>
+#include <string.h>
+
+int main(int argc, char **argv) {
+  const char *shuf = NULL, *out = NULL;
+  int A = 0, u = 0, nf = 0;
+  const char *files[4096];
+  for (int i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "-L") && i + 1 < argc) shuf = argv[++i];
+    else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
+    else if (!strcmp(argv[i], "-A")) A = 1;
+    else if (!strcmp(argv[i], "-u")) u = 1;
+    else if (nf < 4096) files[nf++] = argv[i];
+  }
+  if (!shuf || !out || nf == 0) {
+    fprintf(stderr, "usage: %s -L x.shuf [-A] [-u] -o outdir file...\n", argv[0]);
+    return 2;
+  }
+  int rc = ko_dist_stage1(shuf, A, u, out, nf, files);
+  if (rc) fprintf(stderr, "kssd_oracle_cli: error %d\n", rc);
+  return rc ? 1 : 0;
+}
