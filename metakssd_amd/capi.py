@@ -1,0 +1,307 @@
+"""ctypes binding of libmetakssd_hip.so (include/metakssd_hip.h) -- the binding a Python caller of the
+reference's sketching path would use.  No compute happens here and there is no fallback: if the
+shared library is missing, import fails; if no HIP device is usable, Engine() raises.
+
+Names follow the reference's domain: shuf, params, sketch, reads/rows, components.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmetakssd_hip.so")
+
+MK_OK = 0
+MK_ERR_ARG, MK_ERR_NO_DEVICE, MK_ERR_HIP, MK_ERR_CROWDED = -1, -2, -3, -4
+MK_ERR_STATE, MK_ERR_IO, MK_ERR_FORMAT, MK_ERR_NOMEM = -5, -6, -7, -8
+MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET = 0, 1, 2
+
+
+class MkError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("metakssd_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class CrowdedError(MkError):
+    """more than hashlimit distinct keys: the reference aborts with 'the context space is too crowd' (iseq2comem.c:708-709)"""
+
+
+class ShufC(C.Structure):
+    _fields_ = [("id", C.c_int32), ("k", C.c_int32), ("subk", C.c_int32), ("drlevel", C.c_int32),
+                ("table", C.POINTER(C.c_int32)), ("len", C.c_uint64)]
+
+
+class ParamsC(C.Structure):
+    _fields_ = [("shuf_id", C.c_int32), ("k", C.c_int32), ("subk", C.c_int32), ("drlevel", C.c_int32),
+                ("half_outctx_len", C.c_int32), ("TL", C.c_int32), ("crvsaddmove", C.c_int32),
+                ("component_num", C.c_int32), ("comp_code_bits", C.c_int32),
+                ("dim_start", C.c_int32), ("dim_end", C.c_int32),
+                ("hashsize", C.c_uint32), ("hashlimit", C.c_uint32),
+                ("tupmask", C.c_uint64), ("domask", C.c_uint64), ("undomask", C.c_uint64),
+                ("shuf_table", C.POINTER(C.c_int32)), ("shuf_len", C.c_uint64)]
+
+
+class ComponentC(C.Structure):
+    _fields_ = [("ids", C.POINTER(C.c_uint32)), ("counts", C.POINTER(C.c_uint16)), ("n", C.c_uint64)]
+
+
+class ResultC(C.Structure):
+    _fields_ = [("component_num", C.c_int32), ("total", C.c_uint64), ("components", C.POINTER(ComponentC))]
+
+
+class ProfileC(C.Structure):
+    _fields_ = [("scan_ms", C.c_double), ("scan_launches", C.c_uint64), ("clear_ms", C.c_double),
+                ("finish_ms", C.c_double), ("bases_scanned", C.c_uint64), ("rows_scanned", C.c_uint64)]
+
+
+class FastaStateC(C.Structure):
+    _fields_ = [("TL", C.c_uint32), ("in_header", C.c_uint32), ("fill", C.c_uint32), ("fresh", C.c_uint32),
+                ("pending", C.c_uint8 * 4096)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C metakssd_amd/csrc)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u8p, u64, u32, i32 = C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32, C.c_int32
+    sig = {
+        "mk_shuf_read": [C.c_char_p, C.POINTER(ShufC)],
+        "mk_shuf_generate": [i32, i32, i32, u64, C.POINTER(ShufC)],
+        "mk_shuf_write": [C.POINTER(ShufC), C.c_char_p],
+        "mk_params_init": [C.POINTER(ShufC), C.POINTER(ParamsC)],
+        "mk_device_count": [C.POINTER(C.c_int)],
+        "mk_engine_create": [C.POINTER(ParamsC), C.c_int, C.POINTER(vp)],
+        "mk_engine_destroy": [vp],
+        "mk_engine_set_stream": [vp, vp],
+        "mk_sketch_begin": [vp, C.c_int],
+        "mk_sketch_push_reads": [vp, vp, u32, u64, u64],
+        "mk_sketch_push_reads_device": [vp, vp, u32, u64, u64],
+        "mk_sketch_finish": [vp, C.POINTER(ResultC)],
+        "mk_result_release": [vp, C.POINTER(ResultC)],
+        "mk_engine_sync": [vp],
+        "mk_host_alloc": [C.POINTER(vp), C.c_size_t],
+        "mk_host_free": [vp],
+        "mk_partial_count": [vp, C.POINTER(u64)],
+        "mk_partial_export": [vp, vp, vp, vp, u64, C.POINTER(u64)],
+        "mk_partial_import": [vp, vp, vp, vp, u64],
+        "mk_profile_enable": [vp, C.c_int],
+        "mk_profile_reset": [vp],
+        "mk_profile_get": [vp, C.POINTER(ProfileC)],
+        "mk_synth_rows_host": [u64, u64, u64, u32, u32, vp],
+        "mk_synth_rows_device": [C.c_int, vp, u64, u64, u64, u32, u32, vp],
+        "mk_synth_fastq_write": [C.c_char_p, u64, u64, u64, u32],
+        "mk_fastq_frame": [vp, C.c_size_t, C.c_int, vp, u32, u64, C.POINTER(u64), C.POINTER(C.c_size_t)],
+        "mk_fasta_window_init": [C.POINTER(FastaStateC), i32],
+        "mk_fasta_window": [C.POINTER(FastaStateC), vp, C.c_size_t, C.c_int, vp, u32, u64, C.POINTER(u64),
+                            C.POINTER(C.c_size_t)],
+        "mk_sketchdir_open": [C.c_char_p, C.POINTER(ParamsC), C.c_int, C.c_int, C.POINTER(vp)],
+        "mk_sketchdir_add": [vp, C.c_char_p, C.POINTER(ResultC)],
+        "mk_sketchdir_close": [vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.mk_shuf_free.argtypes = [C.POINTER(ShufC)]
+    lib.mk_shuf_free.restype = None
+    lib.mk_last_error.argtypes = [vp]
+    lib.mk_last_error.restype = C.c_char_p
+    return lib
+
+
+lib = _load()
+
+
+def _check(rc, eng=None):
+    if rc == MK_OK:
+        return
+    msg = lib.mk_last_error(eng).decode(errors="replace") if (eng or rc in (MK_ERR_NO_DEVICE, MK_ERR_HIP, MK_ERR_NOMEM)) else ""
+    raise (CrowdedError if rc == MK_ERR_CROWDED else MkError)(rc, msg)
+
+
+class Shuf:
+    """a .shuf dimension-shuffle table (command_shuffle.h:4-16)"""
+
+    def __init__(self, c):
+        self.c = c
+
+    @classmethod
+    def read(cls, path):
+        c = ShufC()
+        _check(lib.mk_shuf_read(os.fsencode(path), C.byref(c)))
+        return cls(c)
+
+    @classmethod
+    def generate(cls, k, subk, drlevel, seed):
+        c = ShufC()
+        _check(lib.mk_shuf_generate(k, subk, drlevel, seed, C.byref(c)))
+        return cls(c)
+
+    def write(self, path):
+        _check(lib.mk_shuf_write(C.byref(self.c), os.fsencode(path)))
+
+    @property
+    def table(self):
+        return np.ctypeslib.as_array(self.c.table, shape=(self.c.len,))
+
+    def params(self):
+        p = ParamsC()
+        _check(lib.mk_params_init(C.byref(self.c), C.byref(p)))
+        return p
+
+    def __del__(self):
+        try:
+            lib.mk_shuf_free(C.byref(self.c))
+        except Exception:
+            pass
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib.mk_device_count(C.byref(n))
+    return n.value if rc == MK_OK else 0
+
+
+def synth_rows_host(seed, first_read, nreads, length, stride):
+    rows = np.empty(nreads * stride, dtype=np.uint8)
+    _check(lib.mk_synth_rows_host(seed, first_read, nreads, length, stride, rows.ctypes.data))
+    return rows
+
+
+def fastq_frame(buf, stride, final=True, max_rows=None):
+    """FASTQ bytes -> fixed-stride rows (numpy u8 [nrows*stride]); returns (rows, nrows, consumed, rc)"""
+    b = np.frombuffer(buf, dtype=np.uint8)
+    max_rows = max_rows if max_rows is not None else len(b) // 4 + 1
+    rows = np.zeros(max(1, max_rows) * stride, dtype=np.uint8)
+    n, used = C.c_uint64(0), C.c_size_t(0)
+    rc = lib.mk_fastq_frame(b.ctypes.data if len(b) else None, len(b), 1 if final else 0, rows.ctypes.data, stride,
+                            max_rows, C.byref(n), C.byref(used))
+    return rows[: n.value * stride], n.value, used.value, rc
+
+
+def fasta_windows(buf, TL, stride, chunk=None):
+    """FASTA bytes -> overlapped fixed-stride rows; `chunk` feeds the input in pieces of that many bytes"""
+    b = np.frombuffer(buf, dtype=np.uint8)
+    st = FastaStateC()
+    _check(lib.mk_fasta_window_init(C.byref(st), TL))
+    out = []
+    max_rows = 4096
+    rows = np.zeros(max_rows * stride, dtype=np.uint8)
+    pos, step = 0, (chunk or max(1, len(b)))
+    while True:
+        end = min(len(b), pos + step)
+        final = end >= len(b)
+        off = pos
+        while True:
+            n, used = C.c_uint64(0), C.c_size_t(0)
+            ptr = b[off:end].ctypes.data if end > off else None
+            _check(lib.mk_fasta_window(C.byref(st), ptr, end - off, 1 if final else 0, rows.ctypes.data, stride, max_rows,
+                                       C.byref(n), C.byref(used)))
+            if n.value:
+                out.append(rows[: n.value * stride].copy())
+            off += used.value
+            if off >= end and n.value < max_rows:
+                break
+        pos = end
+        if final:
+            break
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
+
+
+class Engine:
+    """one GPU's sketch engine (mk_engine): begin -> push_reads* -> finish"""
+
+    def __init__(self, shuf, device=0):
+        self.shuf = shuf  # keeps the host table alive
+        self.params = shuf.params()
+        self.h = C.c_void_p()
+        rc = lib.mk_engine_create(C.byref(self.params), device, C.byref(self.h))
+        if rc != MK_OK:
+            raise MkError(rc, lib.mk_last_error(None).decode(errors="replace"))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib.mk_engine_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        _check(lib.mk_engine_set_stream(self.h, C.c_void_p(stream_handle)), self.h)
+
+    def begin(self, mode=MK_MODE_KOC):
+        _check(lib.mk_sketch_begin(self.h, mode), self.h)
+
+    def push_reads(self, rows, stride, first_read_ordinal=0):
+        """rows: host numpy u8 array of nreads*stride bytes"""
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        assert rows.size % stride == 0
+        n = rows.size // stride
+        if n:
+            _check(lib.mk_sketch_push_reads(self.h, rows.ctypes.data, stride, n, first_read_ordinal), self.h)
+        return n
+
+    def push_reads_device(self, dev_ptr, stride, nreads, first_read_ordinal=0):
+        _check(lib.mk_sketch_push_reads_device(self.h, C.c_void_p(dev_ptr), stride, nreads, first_read_ordinal), self.h)
+
+    def finish(self):
+        """-> list over components of (ids u32 array, counts u16 array or None), copies of the engine-owned result"""
+        r = ResultC()
+        _check(lib.mk_sketch_finish(self.h, C.byref(r)), self.h)
+        out = []
+        for c in range(r.component_num):
+            comp = r.components[c]
+            n = comp.n
+            ids = np.ctypeslib.as_array(comp.ids, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+            cnt = None
+            if comp.counts:
+                cnt = np.ctypeslib.as_array(comp.counts, shape=(n,)).copy() if n else np.zeros(0, np.uint16)
+            out.append((ids, cnt))
+        self.last_total = r.total
+        lib.mk_result_release(self.h, C.byref(r))
+        return out
+
+    def finish_raw(self):
+        r = ResultC()
+        _check(lib.mk_sketch_finish(self.h, C.byref(r)), self.h)
+        return r
+
+    def sync(self):
+        _check(lib.mk_engine_sync(self.h), self.h)
+
+    def partial_count(self):
+        n = C.c_uint64(0)
+        _check(lib.mk_partial_count(self.h, C.byref(n)), self.h)
+        return n.value
+
+    def partial_export(self, keys_ptr, counts_ptr, ords_ptr, capacity):
+        n = C.c_uint64(0)
+        _check(lib.mk_partial_export(self.h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), C.c_void_p(ords_ptr), capacity,
+                                     C.byref(n)), self.h)
+        return n.value
+
+    def partial_import(self, keys_ptr, counts_ptr, ords_ptr, n):
+        _check(lib.mk_partial_import(self.h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), C.c_void_p(ords_ptr), n), self.h)
+
+    def profile_enable(self, on=True):
+        _check(lib.mk_profile_enable(self.h, 1 if on else 0), self.h)
+
+    def profile_reset(self):
+        _check(lib.mk_profile_reset(self.h), self.h)
+
+    def profile(self):
+        p = ProfileC()
+        _check(lib.mk_profile_get(self.h, C.byref(p)), self.h)
+        return {f: getattr(p, f) for f, _ in ProfileC._fields_}
+
+
+def synth_rows_device(device, stream, seed, first_read, nreads, length, stride, dev_ptr):
+    _check(lib.mk_synth_rows_device(device, C.c_void_p(stream), seed, first_read, nreads, length, stride, C.c_void_p(dev_ptr)))

@@ -1,0 +1,551 @@
+/*
+ * mk_engine.hip -- C-ABI implementation of the MI355X sketch engine (see include/metakssd_hip.h).
+ *
+ * One engine owns, on one GPU: the .shuf table and the accepted-subspace list, the accumulation table
+ * (hashsize slots: key, first ordinal, count), the layout table (hashsize x u32), the distinct-key
+ * list and the output arrays.  There is no CPU implementation behind these entry points.
+ */
+#include "metakssd_hip.h"
+#include "mk_kernels.hip.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+static thread_local char g_create_error[512] = "";
+
+struct mk_evpair { hipEvent_t a, b; };
+
+struct mk_engine {
+  int device = 0;
+  int num_cu = 0;
+  mk_params P{};
+  mk_keyparams kp{};
+  char err[512] = "";
+  hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+
+  int32_t *d_shuf = nullptr;
+  uint32_t *d_accept = nullptr;
+  uint32_t n_accept = 0;
+  uint32_t bm_bits = 0;
+
+  void *d_tab = nullptr; /* key[S] | ordinv[S] | cnt[S] */
+  size_t tab_bytes = 0;
+  mk_table tab{};
+  uint32_t *d_slot = nullptr;
+  mk_dist dist{};
+  uint32_t *d_chunk = nullptr;
+  uint32_t nchunks = 0;
+  unsigned long long *d_counters = nullptr; /* [0]=distinct, [1]=dump total, [2..3]=err flags (as u32) */
+  unsigned long long *h_counters = nullptr; /* pinned mirror */
+  uint32_t *d_out_ids = nullptr;
+  uint16_t *d_out_cnt = nullptr;
+  uint64_t out_cap = 0;
+  uint32_t *h_ids = nullptr;
+  uint16_t *h_cnt = nullptr;
+  uint64_t h_cap = 0;
+  std::vector<mk_component> comps;
+
+  /* host-push staging: two device buffers, copy stream ahead of the compute stream */
+  uint8_t *d_stage[2] = {nullptr, nullptr};
+  size_t stage_bytes = 0;
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_scanned[2] = {nullptr, nullptr};
+  int stage_next = 0;
+
+  int mode = -1;
+  bool begun = false, compacted = false;
+  uint64_t D = 0;
+
+  bool profiling = false;
+  std::vector<mk_evpair> ev_scan, ev_clear, ev_finish, ev_pool;
+  uint64_t prof_rows = 0, prof_bytes = 0;
+};
+
+static int mk_fail(mk_engine *e, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) snprintf(e->err, sizeof e->err, "%s", buf);
+  else snprintf(g_create_error, sizeof g_create_error, "%s", buf);
+  return code;
+}
+
+#define MK_HIP(e, call)                                                                                   \
+  do {                                                                                                    \
+    hipError_t _r = (call);                                                                               \
+    if (_r != hipSuccess) return mk_fail((e), _r == hipErrorOutOfMemory ? MK_ERR_NOMEM : MK_ERR_HIP,      \
+                                         "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_r)); \
+  } while (0)
+
+extern "C" const char *mk_last_error(const mk_engine *e) { return e ? e->err : g_create_error; }
+
+extern "C" int mk_device_count(int *n) {
+  if (!n) return MK_ERR_ARG;
+  int c = 0;
+  hipError_t r = hipGetDeviceCount(&c);
+  if (r != hipSuccess) { *n = 0; return mk_fail(nullptr, MK_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(r)); }
+  *n = c;
+  return MK_OK;
+}
+
+extern "C" int mk_host_alloc(void **p, size_t bytes) {
+  if (!p) return MK_ERR_ARG;
+  hipError_t r = hipHostMalloc(p, bytes, hipHostMallocDefault);
+  return r == hipSuccess ? MK_OK : mk_fail(nullptr, MK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(r));
+}
+extern "C" int mk_host_free(void *p) { return hipHostFree(p) == hipSuccess ? MK_OK : MK_ERR_HIP; }
+
+static mk_evpair mk_ev_get(mk_engine *e) {
+  mk_evpair p{nullptr, nullptr};
+  if (!e->ev_pool.empty()) { p = e->ev_pool.back(); e->ev_pool.pop_back(); return p; }
+  hipEventCreate(&p.a);
+  hipEventCreate(&p.b);
+  return p;
+}
+
+extern "C" int mk_engine_destroy(mk_engine *e) {
+  if (!e) return MK_ERR_ARG;
+  hipSetDevice(e->device);
+  hipDeviceSynchronize();
+  hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_tab); hipFree(e->d_slot);
+  hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
+  hipFree(e->d_chunk); hipFree(e->d_counters); hipFree(e->d_out_ids); hipFree(e->d_out_cnt);
+  if (e->h_counters) hipHostFree(e->h_counters);
+  if (e->h_ids) hipHostFree(e->h_ids);
+  if (e->h_cnt) hipHostFree(e->h_cnt);
+  for (int i = 0; i < 2; i++) {
+    hipFree(e->d_stage[i]);
+    if (e->ev_copied[i]) hipEventDestroy(e->ev_copied[i]);
+    if (e->ev_scanned[i]) hipEventDestroy(e->ev_scanned[i]);
+  }
+  for (auto *v : {&e->ev_scan, &e->ev_clear, &e->ev_finish, &e->ev_pool})
+    for (auto &p : *v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  if (e->own_stream) hipStreamDestroy(e->own_stream);
+  if (e->copy_stream) hipStreamDestroy(e->copy_stream);
+  delete e;
+  return MK_OK;
+}
+
+static int mk_engine_init(mk_engine *e, const mk_params *p) {
+  MK_HIP(e, hipSetDevice(e->device));
+  hipDeviceProp_t prop;
+  MK_HIP(e, hipGetDeviceProperties(&prop, e->device));
+  e->num_cu = prop.multiProcessorCount;
+  MK_HIP(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+  MK_HIP(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  e->stream = e->own_stream;
+  for (int i = 0; i < 2; i++) {
+    MK_HIP(e, hipEventCreateWithFlags(&e->ev_copied[i], hipEventDisableTiming));
+    MK_HIP(e, hipEventCreateWithFlags(&e->ev_scanned[i], hipEventDisableTiming));
+  }
+
+  e->P = *p;
+  mk_keyparams &kp = e->kp;
+  kp.tupmask = p->tupmask; kp.domask = p->domask; kp.undomask = p->undomask;
+  kp.lowmask = (1ull << (2 * p->half_outctx_len)) - 1ull;
+  kp.TL = (uint32_t)p->TL; kp.crvsaddmove = (uint32_t)p->crvsaddmove;
+  kp.out2 = 2u * (uint32_t)p->half_outctx_len;
+  kp.key_lshift = 2u * (uint32_t)p->TL - 4u * (uint32_t)p->half_outctx_len;
+  kp.dr4 = 4u * (uint32_t)p->drlevel;
+  kp.dim_start = p->dim_start; kp.dim_end = p->dim_end;
+  kp.S = p->hashsize;
+
+  /* .shuf table + the list of accepted inner substrings (iseq2comem.c:693-694) */
+  const uint64_t L = p->shuf_len;
+  std::vector<uint32_t> acc;
+  for (uint64_t d = 0; d < L; d++) {
+    int32_t v = p->shuf_table[d];
+    if (v >= p->dim_start && v < p->dim_end) acc.push_back((uint32_t)d);
+  }
+  e->n_accept = (uint32_t)acc.size();
+  MK_HIP(e, hipMalloc(&e->d_shuf, L * sizeof(int32_t)));
+  MK_HIP(e, hipMemcpy(e->d_shuf, p->shuf_table, L * sizeof(int32_t), hipMemcpyHostToDevice));
+  MK_HIP(e, hipMalloc(&e->d_accept, (acc.size() + 1) * sizeof(uint32_t)));
+  if (!acc.empty()) MK_HIP(e, hipMemcpy(e->d_accept, acc.data(), acc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  /* LDS filter: 2^bm_bits bits, never wider than the inner substring itself (then it is exact) */
+  e->bm_bits = (uint32_t)(4 * p->subk < 19 ? 4 * p->subk : 19);
+  if (e->bm_bits < 5) e->bm_bits = 5;
+
+  const uint64_t S = p->hashsize;
+  e->tab_bytes = S * (8 + 8 + 4);
+  MK_HIP(e, hipMalloc(&e->d_tab, e->tab_bytes));
+  e->tab.key = (unsigned long long *)e->d_tab;
+  e->tab.ordinv = e->tab.key + S;
+  e->tab.cnt = (uint32_t *)(e->tab.ordinv + S);
+  MK_HIP(e, hipMalloc(&e->d_slot, S * sizeof(uint32_t)));
+  e->dist.cap = (uint64_t)p->hashlimit + 1;
+  MK_HIP(e, hipMalloc(&e->dist.key, e->dist.cap * 8));
+  MK_HIP(e, hipMalloc(&e->dist.ord, e->dist.cap * 8));
+  MK_HIP(e, hipMalloc(&e->dist.cnt, e->dist.cap * 4));
+  e->nchunks = (uint32_t)((S + MK_DUMP_CHUNK - 1) / MK_DUMP_CHUNK);
+  MK_HIP(e, hipMalloc(&e->d_chunk, (size_t)e->nchunks * sizeof(uint32_t)));
+  MK_HIP(e, hipMalloc(&e->d_counters, 8 * sizeof(unsigned long long)));
+  MK_HIP(e, hipMemset(e->d_counters, 0, 8 * sizeof(unsigned long long)));
+  MK_HIP(e, hipHostMalloc((void **)&e->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+  e->tab.err = (uint32_t *)(e->d_counters + 2);
+  e->comps.resize((size_t)p->component_num);
+  return MK_OK;
+}
+
+extern "C" int mk_engine_create(const mk_params *p, int device, mk_engine **out) {
+  if (!p || !out || !p->shuf_table) return mk_fail(nullptr, MK_ERR_ARG, "mk_engine_create: null argument");
+  if (p->k < 1 || p->k > 16 || p->hashsize < 251u || p->shuf_len != (1ull << (4 * p->subk)))
+    return mk_fail(nullptr, MK_ERR_ARG, "mk_engine_create: inconsistent mk_params (use mk_params_init)");
+  int n = 0;
+  hipError_t r = hipGetDeviceCount(&n);
+  if (r != hipSuccess || n <= 0)
+    return mk_fail(nullptr, MK_ERR_NO_DEVICE, "no HIP device (%s); this library has no CPU path",
+                   r == hipSuccess ? "device count 0" : hipGetErrorString(r));
+  if (device < 0 || device >= n) return mk_fail(nullptr, MK_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+  mk_engine *e = new mk_engine();
+  e->device = device;
+  int rc = mk_engine_init(e, p);
+  if (rc != MK_OK) {
+    snprintf(g_create_error, sizeof g_create_error, "%s", e->err);
+    mk_engine_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return MK_OK;
+}
+
+extern "C" int mk_engine_set_stream(mk_engine *e, void *hip_stream) {
+  if (!e) return MK_ERR_ARG;
+  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  return MK_OK;
+}
+
+extern "C" int mk_engine_sync(mk_engine *e) {
+  if (!e) return MK_ERR_ARG;
+  MK_HIP(e, hipSetDevice(e->device));
+  MK_HIP(e, hipStreamSynchronize(e->copy_stream));
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  return MK_OK;
+}
+
+extern "C" int mk_profile_enable(mk_engine *e, int on) { if (!e) return MK_ERR_ARG; e->profiling = on != 0; return MK_OK; }
+
+extern "C" int mk_profile_reset(mk_engine *e) {
+  if (!e) return MK_ERR_ARG;
+  MK_HIP(e, hipSetDevice(e->device));
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  for (auto *v : {&e->ev_scan, &e->ev_clear, &e->ev_finish}) {
+    for (auto &p : *v) e->ev_pool.push_back(p);
+    v->clear();
+  }
+  e->prof_rows = e->prof_bytes = 0;
+  return MK_OK;
+}
+
+extern "C" int mk_profile_get(mk_engine *e, mk_profile *out) {
+  if (!e || !out) return MK_ERR_ARG;
+  MK_HIP(e, hipSetDevice(e->device));
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  memset(out, 0, sizeof *out);
+  auto sum = [&](std::vector<mk_evpair> &v) {
+    double s = 0;
+    for (auto &p : v) { float ms = 0; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) s += ms; }
+    return s;
+  };
+  out->scan_ms = sum(e->ev_scan);
+  out->scan_launches = e->ev_scan.size();
+  out->clear_ms = sum(e->ev_clear);
+  out->finish_ms = sum(e->ev_finish);
+  out->rows_scanned = e->prof_rows;
+  out->bases_scanned = e->prof_bytes;
+  return MK_OK;
+}
+
+extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
+  if (!e || mode < MK_MODE_KOC || mode > MK_MODE_UNIQ_SET) return MK_ERR_ARG;
+  MK_HIP(e, hipSetDevice(e->device));
+  mk_evpair ev{};
+  if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
+  /* the table clear the reference does with memset(co,0,..) (iseq2comem.c:223,663) */
+  MK_HIP(e, hipMemsetAsync(e->d_tab, 0, e->tab_bytes, e->stream));
+  MK_HIP(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->stream));
+  if (e->profiling) { MK_HIP(e, hipEventRecord(ev.b, e->stream)); e->ev_clear.push_back(ev); }
+  e->mode = mode;
+  e->begun = true;
+  e->compacted = false;
+  e->D = 0;
+  return MK_OK;
+}
+
+/* ---- scan launch -------------------------------------------------------------------------------------- */
+template <int K, bool V>
+static hipError_t mk_launch_scan_t(const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t r = hipFuncSetAttribute((const void *)mk_scan_kernel<K, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (r != hipSuccess) return r;
+    configured = lds;
+  }
+  hipLaunchKernelGGL((mk_scan_kernel<K, V>), grid, dim3(MK_SCAN_THREADS), lds, s, a);
+  return hipGetLastError();
+}
+
+static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride, uint64_t nreads, uint64_t first_ord) {
+  if (nreads == 0) return MK_OK;
+  mk_scan_args a{};
+  a.rows = rows_dev; a.nreads = nreads; a.first_ord = first_ord; a.stride = stride;
+  const bool vec = (stride % 16u == 0) && (((uintptr_t)rows_dev & 15u) == 0);
+  /* column blocks: fewest blocks of at most MK_MAX_CB bytes, equal width, 16-byte (vec) / 4-byte granular */
+  const uint32_t g = vec ? 16u : 4u;
+  a.ncb = (stride + MK_MAX_CB - 1) / MK_MAX_CB;
+  a.CB = ((stride + a.ncb - 1) / a.ncb + g - 1) / g * g;
+  if (a.CB > MK_MAX_CB) { a.ncb++; a.CB = ((stride + a.ncb - 1) / a.ncb + g - 1) / g * g; }
+  a.ncb = (stride + a.CB - 1) / a.CB;
+  a.ppr = a.CB / g;
+  a.ppr_inv = (1u << 20) / a.ppr + 1u;
+  a.rowdw = (a.CB / 4u) | 1u;
+  a.wave_lds_dwords = ((64u * a.rowdw + 1u) & ~1u) + 4u * MK_QCAP;
+  a.bm_words = (1u << e->bm_bits) / 32u;
+  a.bm_mask = (1u << e->bm_bits) - 1u;
+  a.accept = e->d_accept; a.n_accept = e->n_accept;
+  a.shuf = e->d_shuf;
+  a.kp = e->kp;
+  a.tab = e->tab;
+  const size_t lds = ((size_t)a.bm_words + (size_t)MK_SCAN_WAVES * a.wave_lds_dwords) * 4u;
+  if (lds > 160u * 1024u) return mk_fail(e, MK_ERR_ARG, "scan: LDS budget exceeded (%zu bytes)", lds);
+  const uint64_t ntiles = (nreads + 63) / 64;
+  uint64_t blocks = (ntiles + MK_SCAN_WAVES - 1) / MK_SCAN_WAVES;
+  if (blocks > (uint64_t)e->num_cu) blocks = (uint64_t)e->num_cu;
+  dim3 grid((unsigned)blocks);
+
+  mk_evpair ev{};
+  if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
+  hipError_t r;
+  switch (e->P.k) {
+    case 11: r = vec ? mk_launch_scan_t<11, true>(a, grid, lds, e->stream) : mk_launch_scan_t<11, false>(a, grid, lds, e->stream); break;
+    case 10: r = vec ? mk_launch_scan_t<10, true>(a, grid, lds, e->stream) : mk_launch_scan_t<10, false>(a, grid, lds, e->stream); break;
+    default: r = vec ? mk_launch_scan_t<0, true>(a, grid, lds, e->stream) : mk_launch_scan_t<0, false>(a, grid, lds, e->stream); break;
+  }
+  if (r != hipSuccess) return mk_fail(e, MK_ERR_HIP, "scan launch: %s", hipGetErrorString(r));
+  if (e->profiling) {
+    MK_HIP(e, hipEventRecord(ev.b, e->stream));
+    e->ev_scan.push_back(ev);
+    e->prof_rows += nreads;
+    e->prof_bytes += nreads * stride;
+  }
+  e->compacted = false;
+  return MK_OK;
+}
+
+static int mk_check_push(mk_engine *e, const void *rows, uint32_t stride) {
+  if (!e) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "push before mk_sketch_begin");
+  if (!rows || stride < 4 || stride > 4096 || (stride & 3u)) return mk_fail(e, MK_ERR_ARG, "push: stride must be a multiple of 4 in 4..4096");
+  return MK_OK;
+}
+
+extern "C" int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev, uint32_t stride, uint64_t nreads,
+                                           uint64_t first_read_ordinal) {
+  int rc = mk_check_push(e, rows_dev, stride);
+  if (rc) return rc;
+  MK_HIP(e, hipSetDevice(e->device));
+  if ((first_read_ordinal + nreads) >> 52) return mk_fail(e, MK_ERR_ARG, "read ordinal too large");
+  return mk_launch_scan(e, rows_dev, stride, nreads, first_read_ordinal);
+}
+
+extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t stride, uint64_t nreads,
+                                    uint64_t first_read_ordinal) {
+  int rc = mk_check_push(e, rows, stride);
+  if (rc) return rc;
+  MK_HIP(e, hipSetDevice(e->device));
+  if ((first_read_ordinal + nreads) >> 52) return mk_fail(e, MK_ERR_ARG, "read ordinal too large");
+  const size_t chunk_max = (size_t)64 << 20;
+  if (!e->d_stage[0]) {
+    e->stage_bytes = chunk_max;
+    for (int i = 0; i < 2; i++) MK_HIP(e, hipMalloc(&e->d_stage[i], e->stage_bytes));
+  }
+  uint64_t rows_per_chunk = e->stage_bytes / stride;
+  rows_per_chunk &= ~(uint64_t)63;
+  for (uint64_t done = 0; done < nreads;) {
+    const uint64_t n = nreads - done < rows_per_chunk ? nreads - done : rows_per_chunk;
+    const int b = e->stage_next;
+    e->stage_next ^= 1;
+    /* copy stream: wait until the scan that last read this buffer is finished, then H2D */
+    MK_HIP(e, hipStreamWaitEvent(e->copy_stream, e->ev_scanned[b], 0));
+    MK_HIP(e, hipMemcpyAsync(e->d_stage[b], rows + done * stride, n * stride, hipMemcpyHostToDevice, e->copy_stream));
+    MK_HIP(e, hipEventRecord(e->ev_copied[b], e->copy_stream));
+    MK_HIP(e, hipStreamWaitEvent(e->stream, e->ev_copied[b], 0));
+    rc = mk_launch_scan(e, e->d_stage[b], stride, n, first_read_ordinal + done);
+    if (rc) return rc;
+    MK_HIP(e, hipEventRecord(e->ev_scanned[b], e->stream));
+    done += n;
+  }
+  MK_HIP(e, hipStreamSynchronize(e->copy_stream)); /* caller's buffer is free again; the last scan may still run */
+  return MK_OK;
+}
+
+/* ---- compaction / partials --------------------------------------------------------------------------- */
+static int mk_compact(mk_engine *e) {
+  if (e->compacted) return MK_OK;
+  MK_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(unsigned long long), e->stream));
+  const int drop0 = e->mode != MK_MODE_KOC; /* co[n]=0 stays "empty" in the set flavours: iseq2comem.c:300-302 */
+  const unsigned blocks = (unsigned)(e->num_cu * 8);
+  hipLaunchKernelGGL(mk_compact_kernel, dim3(blocks), dim3(256), 0, e->stream, e->tab, e->kp.S, e->dist, e->d_counters, drop0);
+  MK_HIP(e, hipGetLastError());
+  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  const uint32_t errflags = (uint32_t)(e->h_counters[2] & 0xffffffffu);
+  e->D = e->h_counters[0];
+  if ((errflags & 1u) || e->D > e->P.hashlimit)
+    return mk_fail(e, MK_ERR_CROWDED, "the context space is too crowd (%llu distinct keys > hashlimit %u), try k=%d",
+                   (unsigned long long)e->D, e->P.hashlimit, e->P.k + 1);
+  e->compacted = true;
+  return MK_OK;
+}
+
+extern "C" int mk_partial_count(mk_engine *e, uint64_t *n) {
+  if (!e || !n) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "partial_count before mk_sketch_begin");
+  MK_HIP(e, hipSetDevice(e->device));
+  int rc = mk_compact(e);
+  if (rc) return rc;
+  *n = e->D;
+  return MK_OK;
+}
+
+extern "C" int mk_partial_export(mk_engine *e, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t *ords_dev, uint64_t capacity,
+                                 uint64_t *n_out) {
+  if (!e || !n_out) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "partial_export before mk_sketch_begin");
+  MK_HIP(e, hipSetDevice(e->device));
+  int rc = mk_compact(e);
+  if (rc) return rc;
+  *n_out = e->D;
+  if (e->D > capacity) return mk_fail(e, MK_ERR_ARG, "partial_export: capacity %llu < %llu keys", (unsigned long long)capacity, (unsigned long long)e->D);
+  if (e->D == 0) return MK_OK;
+  if (!keys_dev || !counts_dev || !ords_dev) return MK_ERR_ARG;
+  MK_HIP(e, hipMemcpyAsync(keys_dev, e->dist.key, e->D * 8, hipMemcpyDeviceToDevice, e->stream));
+  MK_HIP(e, hipMemcpyAsync(counts_dev, e->dist.cnt, e->D * 4, hipMemcpyDeviceToDevice, e->stream));
+  MK_HIP(e, hipMemcpyAsync(ords_dev, e->dist.ord, e->D * 8, hipMemcpyDeviceToDevice, e->stream));
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  return MK_OK;
+}
+
+extern "C" int mk_partial_import(mk_engine *e, const uint64_t *keys_dev, const uint32_t *counts_dev, const uint64_t *ords_dev,
+                                 uint64_t n) {
+  if (!e) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "partial_import before mk_sketch_begin");
+  if (n == 0) return MK_OK;
+  if (!keys_dev || !counts_dev || !ords_dev) return MK_ERR_ARG;
+  MK_HIP(e, hipSetDevice(e->device));
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > (uint64_t)e->num_cu * 16) blocks = (uint64_t)e->num_cu * 16;
+  hipLaunchKernelGGL(mk_import_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, e->tab, e->kp.S,
+                     (const unsigned long long *)keys_dev, counts_dev, (const unsigned long long *)ords_dev, n);
+  MK_HIP(e, hipGetLastError());
+  e->compacted = false;
+  return MK_OK;
+}
+
+/* ---- finish: layout + dump ------------------------------------------------------------------------------ */
+extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
+  if (!e || !out) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "finish before mk_sketch_begin");
+  MK_HIP(e, hipSetDevice(e->device));
+  mk_evpair ev{};
+  if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
+  int rc = mk_compact(e);
+  if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
+  const uint64_t D = e->D;
+  const uint32_t S = e->kp.S;
+  const int C = e->P.component_num;
+  const bool koc = e->mode == MK_MODE_KOC;
+
+  /* output capacity */
+  if (D > e->out_cap) {
+    hipFree(e->d_out_ids); hipFree(e->d_out_cnt);
+    e->d_out_ids = nullptr; e->d_out_cnt = nullptr;
+    uint64_t cap = D + D / 8 + 1024;
+    MK_HIP(e, hipMalloc(&e->d_out_ids, cap * 4));
+    MK_HIP(e, hipMalloc(&e->d_out_cnt, cap * 2));
+    e->out_cap = cap;
+  }
+  if (D > e->h_cap) {
+    if (e->h_ids) hipHostFree(e->h_ids);
+    if (e->h_cnt) hipHostFree(e->h_cnt);
+    e->h_ids = nullptr; e->h_cnt = nullptr;
+    uint64_t cap = D + D / 8 + 1024;
+    MK_HIP(e, hipHostMalloc((void **)&e->h_ids, cap * 4, hipHostMallocDefault));
+    MK_HIP(e, hipHostMalloc((void **)&e->h_cnt, cap * 2, hipHostMallocDefault));
+    e->h_cap = cap;
+  }
+
+  uint64_t total = 0;
+  if (D > 0) {
+    MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), e->stream));
+    uint64_t lb = (D + 255) / 256;
+    if (lb > (uint64_t)e->num_cu * 16) lb = (uint64_t)e->num_cu * 16;
+    hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)lb), dim3(256), 0, e->stream, e->dist, D, e->d_slot, S, e->tab.err);
+    MK_HIP(e, hipGetLastError());
+
+    mk_dump_args da{};
+    da.slot = e->d_slot; da.S = S; da.d = e->dist;
+    da.comp_num = (uint32_t)C; da.comp_code_bits = (uint32_t)e->P.comp_code_bits;
+    da.uniq_only = e->mode == MK_MODE_UNIQ_SET;
+    da.nchunks = e->nchunks;
+    const unsigned dblocks = (e->nchunks + 3) / 4; /* 4 waves (chunks) per 256-thread block */
+    for (int c = 0; c < C; c++) {
+      da.comp = (uint32_t)c;
+      hipLaunchKernelGGL(mk_dump_count_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, e->d_chunk);
+      hipLaunchKernelGGL(mk_dump_scan_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_chunk, e->nchunks, e->d_counters + 1);
+      hipLaunchKernelGGL(mk_dump_write_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, (const uint32_t *)e->d_chunk,
+                         e->d_out_ids + total, koc ? e->d_out_cnt + total : nullptr);
+      MK_HIP(e, hipGetLastError());
+      MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+      MK_HIP(e, hipStreamSynchronize(e->stream));
+      const uint64_t nc = e->h_counters[1];
+      if (total + nc > D) return mk_fail(e, MK_ERR_HIP, "dump produced more entries than distinct keys");
+      e->comps[c].n = nc;
+      e->comps[c].ids = e->h_ids + total;
+      e->comps[c].counts = koc ? e->h_cnt + total : nullptr;
+      total += nc;
+    }
+    if ((uint32_t)(e->h_counters[2] & 0xffffffffu) & 2u) return mk_fail(e, MK_ERR_HIP, "layout kernel did not converge");
+    if (total) {
+      MK_HIP(e, hipMemcpyAsync(e->h_ids, e->d_out_ids, total * 4, hipMemcpyDeviceToHost, e->stream));
+      if (koc) MK_HIP(e, hipMemcpyAsync(e->h_cnt, e->d_out_cnt, total * 2, hipMemcpyDeviceToHost, e->stream));
+    }
+  } else {
+    for (int c = 0; c < C; c++) { e->comps[c].n = 0; e->comps[c].ids = e->h_ids; e->comps[c].counts = koc ? e->h_cnt : nullptr; }
+  }
+  if (e->profiling) { MK_HIP(e, hipEventRecord(ev.b, e->stream)); e->ev_finish.push_back(ev); }
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  out->component_num = C;
+  out->total = total;
+  out->components = e->comps.data();
+  e->begun = false;
+  return MK_OK;
+}
+
+extern "C" int mk_result_release(mk_engine *e, mk_result *r) {
+  if (!e || !r) return MK_ERR_ARG;
+  r->components = nullptr;
+  r->total = 0;
+  return MK_OK;
+}
+
+/* ---- synthetic reads on the device --------------------------------------------------------------------- */
+extern "C" int mk_synth_rows_device(int device, void *hip_stream, uint64_t seed, uint64_t first_read, uint64_t nreads,
+                                    uint32_t len, uint32_t stride, uint8_t *rows_dev) {
+  if (!rows_dev || stride < len + 1 || (stride & 15u) || ((uintptr_t)rows_dev & 15u))
+    return mk_fail(nullptr, MK_ERR_ARG, "mk_synth_rows_device: stride must be a multiple of 16 and > len");
+  if (hipSetDevice(device) != hipSuccess) return mk_fail(nullptr, MK_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+  if (nreads == 0) return MK_OK;
+  uint64_t total = nreads * (stride >> 4);
+  uint64_t blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(mk_synth_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, seed, first_read, nreads, len,
+                     stride, rows_dev);
+  hipError_t r = hipGetLastError();
+  return r == hipSuccess ? MK_OK : mk_fail(nullptr, MK_ERR_HIP, "synth launch: %s", hipGetErrorString(r));
+}

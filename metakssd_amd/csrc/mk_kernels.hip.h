@@ -1,0 +1,487 @@
+/*
+ * mk_kernels.hip.h -- device code of the MI355X sketch engine (gfx950, wave64).
+ *
+ * Kernels (DESIGN.md has the data layout and the roofline of each):
+ *   mk_scan_kernel      rows of ASCII bases -> rolling canonical k-mer -> LDS filter of the accepted
+ *                       inner-substring subspace -> exact .shuf check -> key -> counted upsert.
+ *                       Restates the per-read loop of mt_shortreads2koc(), iseq2comem.c:676-720
+ *                       (and of fasta2co(), :248-311, on overlapped windows).
+ *   mk_import_kernel    fold another shard's {key,count,first ordinal} list into the table (multi-GPU).
+ *   mk_compact_kernel   table -> dense list of distinct keys.
+ *   mk_layout_kernel    priority insertion: rebuilds the slot layout the reference's SEQUENTIAL
+ *                       first-come-first-served double hashing (global_basic.h:282-284,
+ *                       iseq2comem.c:701-718) would have produced, from first-occurrence ordinals.
+ *   mk_dump_*           slot-order compaction = write_fqkoc2files(), iseq2comem.c:539-553 /
+ *                       wrt_co2cmpn_use_inn_subctx(), :638-646.
+ *   mk_synth_kernel     synthetic reads (same bytes as mk_synth_rows_host).
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "host/mk_host_internal.h"
+
+#define MK_WAVE 64
+#define MK_SCAN_THREADS 512            /* 8 waves per workgroup, one workgroup per CU */
+#define MK_SCAN_WAVES (MK_SCAN_THREADS / MK_WAVE)
+#define MK_QCAP 128                    /* candidate queue entries per wave (64 pending + one full push) */
+#define MK_MAX_CB 128                  /* widest column block staged per step, bytes */
+#define MK_MAX_PIECES 8                /* 16-byte pieces per lane per step = MK_MAX_CB/16 */
+#define MK_EMPTY32 0xFFFFFFFFu
+#define MK_CNT_SAT 0x7FFFFFFFu         /* stop adding long before a u32 count could wrap */
+
+struct mk_keyparams {
+  uint64_t tupmask, domask, undomask, lowmask;
+  uint32_t TL, crvsaddmove, out2 /*2*half_outctx_len*/, key_lshift /*2*TL-4*out*/, dr4 /*4*drlevel*/;
+  int32_t dim_start, dim_end;
+  uint32_t S; /* hashsize */
+};
+
+struct mk_table {
+  unsigned long long *key; /* key+1, 0 = empty                      [S] */
+  unsigned long long *ordinv; /* ~(first ordinal), max-combined     [S] */
+  uint32_t *cnt;           /* occurrences (not yet clamped)         [S] */
+  uint32_t *err;           /* [0] = table-full flag */
+};
+
+struct mk_scan_args {
+  const uint8_t *rows;
+  uint64_t nreads, first_ord;
+  uint32_t stride;
+  uint32_t CB, ncb;   /* column block width (bytes, multiple of 4), blocks per row */
+  uint32_t ppr;       /* pieces per row per block: CB/16 (vec path) or CB/4 (dword path) */
+  uint32_t ppr_inv;   /* floor(2^20/ppr)+1 : q/ppr == (q*ppr_inv)>>20 for q < 2^20/ppr */
+  uint32_t rowdw;     /* LDS dwords per staged row (odd => conflict-free row reads) */
+  uint32_t wave_lds_dwords;
+  uint32_t bm_words, bm_mask;
+  const uint32_t *accept; /* inner substrings d with dim_start <= shuf[d] < dim_end */
+  uint32_t n_accept;
+  const int32_t *shuf;
+  mk_keyparams kp;
+  mk_table tab;
+};
+
+/* ------------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ uint32_t mk_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t mk_mbcnt(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ void mk_wave_lds_fence() {
+  /* same-wave LDS producer -> consumer: DS operations of one wave execute in order; this only stops
+   * the compiler from moving LDS accesses across the hand-off */
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* probe step of HASH(K,I,S) = (K%S + I*(1+K%(S-1))) % S, incrementally: n_{i+1} = (n_i + h2) mod S */
+__device__ __forceinline__ void mk_probe_init(uint64_t key, uint32_t S, uint32_t &n, uint32_t &h2) {
+  n = (uint32_t)(key % S);
+  h2 = 1u + (uint32_t)(key % (uint64_t)(S - 1));
+}
+__device__ __forceinline__ uint32_t mk_probe_next(uint32_t n, uint32_t h2, uint32_t S) {
+  uint64_t t = (uint64_t)n + h2;
+  return (uint32_t)(t >= S ? t - S : t);
+}
+
+/* key reduction: iseq2comem.c:696-699 */
+__device__ __forceinline__ uint64_t mk_reduce_key(const mk_keyparams &kp, uint64_t uni, uint64_t pf) {
+  return (((uni & kp.undomask) + ((uni & kp.lowmask) << kp.key_lshift)) >> kp.dr4) + pf;
+}
+
+/* counted upsert into the accumulation table (arrival order is irrelevant: counts add, first ordinals
+ * combine by min; the reference-order layout is rebuilt afterwards by mk_layout_kernel) */
+__device__ __forceinline__ void mk_upsert(const mk_table &tab, uint32_t S, uint64_t key, uint64_t ord, uint32_t add) {
+  uint32_t n, h2;
+  mk_probe_init(key, S, n, h2);
+  const unsigned long long want = key + 1ull;
+  for (uint32_t i = 0; i < S; i++) {
+    unsigned long long cur = __hip_atomic_load(&tab.key[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0ull) {
+      unsigned long long prev = atomicCAS(&tab.key[n], 0ull, want);
+      cur = prev == 0ull ? want : prev;
+    }
+    if (cur == want) {
+      atomicMax(&tab.ordinv[n], ~(unsigned long long)ord);
+      uint32_t c = __hip_atomic_load(&tab.cnt[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c < MK_CNT_SAT) atomicAdd(&tab.cnt[n], add);
+      return;
+    }
+    n = mk_probe_next(n, h2, S);
+  }
+  atomicOr(&tab.err[0], 1u); /* every slot taken by other keys */
+}
+
+/* exact accept test + upsert for up to 64 queued candidates (one per lane) */
+__device__ __noinline__ void mk_drain(const mk_scan_args &a, const uint64_t *q_uni, const uint64_t *q_ord, uint32_t n,
+                                      uint32_t lane) {
+  if (lane < n) {
+    uint64_t uni = q_uni[lane], ord = q_ord[lane];
+    uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
+    int32_t pf = a.shuf[dim]; /* iseq2comem.c:693 */
+    if (pf >= a.kp.dim_start && pf < a.kp.dim_end) {
+      uint64_t key = mk_reduce_key(a.kp, uni, (uint64_t)(pf - a.kp.dim_start));
+      mk_upsert(a.tab, a.kp.S, key, ord, 1u);
+    }
+  }
+}
+
+/* per-wave scan state that lives across column blocks of a tile */
+struct mk_lane_state {
+  uint64_t fwd, rc;
+  uint32_t run;  /* valid bases since the last reset (the reference's base-1) */
+  bool done;     /* this lane's row hit its '\n' (or does not exist) */
+};
+
+template <int K>
+struct mk_kcfg {
+  /* K == 0: everything from runtime parameters; K > 0: k-mer geometry folded at compile time */
+  static __device__ __forceinline__ uint32_t TL(const mk_keyparams &kp) { return K ? 2u * K : kp.TL; }
+  static __device__ __forceinline__ uint32_t crv(const mk_keyparams &kp) { return K ? 4u * K - 2u : kp.crvsaddmove; }
+  static __device__ __forceinline__ uint64_t mask(const mk_keyparams &kp) {
+    return K ? (0xffffffffffffffffull >> (64 - 4 * (K ? K : 1))) : kp.tupmask;
+  }
+};
+
+/* push the candidates of this base position (lanes with hit) into the wave queue; drain when 64 are pending */
+__device__ __forceinline__ void mk_push(const mk_scan_args &a, uint64_t m, bool hit, uint64_t uni, uint64_t ord,
+                                        uint64_t *q_uni, uint64_t *q_ord, uint32_t &qn, uint32_t lane) {
+  uint32_t off = qn + mk_mbcnt(m);
+  if (hit) { q_uni[off] = uni; q_ord[off] = ord; }
+  qn += (uint32_t)__popcll(m);
+  if (qn >= 64) {
+    mk_wave_lds_fence();
+    mk_drain(a, q_uni, q_ord, 64, lane);
+    /* move the tail (fewer than 64 entries) to the front */
+    uint64_t tu = q_uni[64 + lane], to = q_ord[64 + lane];
+    mk_wave_lds_fence();
+    q_uni[lane] = tu; q_ord[lane] = to;
+    mk_wave_lds_fence();
+    qn -= 64;
+  }
+}
+
+template <int K, bool VEC16>
+__global__ void __launch_bounds__(MK_SCAN_THREADS) mk_scan_kernel(const mk_scan_args a) {
+  extern __shared__ __align__(16) uint32_t lds[];
+  using cfg = mk_kcfg<K>;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t *bitmap = lds;
+  uint32_t *tile = lds + a.bm_words + wave * a.wave_lds_dwords;
+  uint64_t *q_uni = (uint64_t *)(tile + ((64u * a.rowdw + 1u) & ~1u));
+  uint64_t *q_ord = q_uni + MK_QCAP;
+
+  /* ---- LDS filter: one bit per (inner substring mod 2^bm_bits), set for the accepted subspace ---- */
+  for (uint32_t i = threadIdx.x; i < a.bm_words; i += blockDim.x) bitmap[i] = 0u;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < a.n_accept; i += blockDim.x) {
+    uint32_t d = a.accept[i] & a.bm_mask;
+    atomicOr(&bitmap[d >> 5], 1u << (d & 31u));
+  }
+  __syncthreads();
+
+  const uint32_t TL = cfg::TL(a.kp), crv = cfg::crv(a.kp), out2 = a.kp.out2;
+  const uint64_t tupmask = cfg::mask(a.kp);
+  const uint64_t ntiles = (a.nreads + 63u) >> 6;
+  const uint64_t wave_global = (uint64_t)blockIdx.x * MK_SCAN_WAVES + wave;
+  const uint64_t nwaves = (uint64_t)gridDim.x * MK_SCAN_WAVES;
+  if (wave_global >= ntiles) return;
+  const uint64_t my_tiles = (ntiles - wave_global + nwaves - 1) / nwaves;
+  const uint64_t nsteps = my_tiles * a.ncb;
+
+  using piece_t = typename std::conditional<VEC16, uint4, uint32_t>::type;
+  constexpr int NP = VEC16 ? MK_MAX_PIECES : MK_MAX_CB / 4;
+  piece_t regs[NP];
+
+  /* piece q of a step: row r = q / ppr of the tile, piece c = q % ppr of the column block */
+  auto issue_loads = [&](uint64_t step) {
+    const uint64_t tile_id = wave_global + (step / a.ncb) * nwaves;
+    const uint32_t cb = (uint32_t)(step % a.ncb);
+    const uint64_t row0 = tile_id << 6;
+    const uint32_t rows_here = (uint32_t)min((uint64_t)64, a.nreads - row0);
+    const uint8_t *base = a.rows + row0 * a.stride + (uint64_t)cb * a.CB;
+    const uint32_t cols_here = min(a.CB, a.stride - cb * a.CB);
+    const uint32_t pw = VEC16 ? 16u : 4u;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      if ((uint32_t)i < a.ppr) {
+        uint32_t q = lane + 64u * i;
+        uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr;
+        piece_t v;
+        if constexpr (VEC16) v = make_uint4(0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au);
+        else v = 0x0a0a0a0au;
+        if (r < rows_here && c * pw < cols_here) v = *(const piece_t *)(base + (uint64_t)r * a.stride + c * pw);
+        regs[i] = v;
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      if ((uint32_t)i < a.ppr) {
+        uint32_t q = lane + 64u * i;
+        uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr;
+        if constexpr (VEC16) {
+          uint32_t *p = tile + r * a.rowdw + c * 4u;
+          p[0] = regs[i].x; p[1] = regs[i].y; p[2] = regs[i].z; p[3] = regs[i].w;
+        } else {
+          tile[r * a.rowdw + c] = regs[i];
+        }
+      }
+    }
+  };
+
+  mk_lane_state st;
+  uint32_t qn = 0;
+  const uint32_t *myrow = tile + lane * a.rowdw;
+
+  issue_loads(0);
+  for (uint64_t step = 0; step < nsteps; step++) {
+    const uint64_t tile_id = wave_global + (step / a.ncb) * nwaves;
+    const uint32_t cb = (uint32_t)(step % a.ncb);
+    const uint64_t row0 = tile_id << 6;
+    mk_wave_lds_fence();
+    commit();
+    mk_wave_lds_fence();
+    if (step + 1 < nsteps) issue_loads(step + 1);
+
+    if (cb == 0) {
+      st.fwd = 0; st.rc = 0; st.run = 0;
+      st.done = row0 + lane >= a.nreads;
+    }
+    const uint32_t col0 = cb * a.CB;
+    const uint32_t ndw = min(a.CB, a.stride - col0) >> 2;
+    const uint64_t ord_row = (a.first_ord + row0 + lane) << 12;
+    if (__all(st.done)) continue;
+
+    for (uint32_t d = 0; d < ndw; d++) {
+      const uint32_t w = myrow[d];
+      const uint32_t tt = (w >> 1) ^ (w >> 2);
+      const uint32_t codes = tt & 0x03030303u;
+      /* expected upper-case letter of each code, compared with the byte folded to upper case */
+      const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u, codes);
+      const uint32_t x = (w & 0xDFDFDFDFu) ^ expect; /* byte j zero <=> byte j in ACGTacgt */
+      const uint32_t pos0 = col0 + 4u * d;
+
+      /* one base: roll, and (if a full k-mer is under the window) test the filter */
+      auto step_base = [&](uint32_t j, bool valid_known, bool complete_known) {
+        const uint32_t code = (codes >> (8u * j)) & 3u;
+        bool roll = true;
+        if (!valid_known) {
+          const uint32_t ch = (w >> (8u * j)) & 0xffu;
+          const bool valid = ((x >> (8u * j)) & 0xffu) == 0u;
+          if (!st.done && ch == '\n') st.done = true;
+          roll = valid && !st.done;
+          if (!roll && !st.done) st.run = 0; /* any other byte restarts the window (iseq2comem.c:688) */
+        }
+        if (roll) {
+          st.fwd = ((st.fwd << 2) | code) & tupmask;
+          st.rc = (st.rc >> 2) | ((uint64_t)(code ^ 3u) << crv);
+          st.run++;
+        }
+        const bool complete = complete_known ? true : (roll && st.run >= TL);
+        const uint64_t uni = st.fwd < st.rc ? st.fwd : st.rc;
+        const uint32_t idx = (uint32_t)(uni >> out2) & a.bm_mask;
+        const bool hit = complete && ((bitmap[idx >> 5] >> (idx & 31u)) & 1u);
+        const uint64_t m = __ballot(hit);
+        if (m) mk_push(a, m, hit, uni, ord_row | (pos0 + j), q_uni, q_ord, qn, lane);
+      };
+
+      if (__all(x == 0u && !st.done)) {
+        if (__all(st.run + 1u >= TL)) { /* every lane has a full window from the first base of this dword on */
+          step_base(0, true, true); step_base(1, true, true); step_base(2, true, true); step_base(3, true, true);
+        } else if (__all(st.run + 4u < TL)) { /* no lane completes a k-mer in this dword: roll only */
+#pragma unroll
+          for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t code = (codes >> (8u * j)) & 3u;
+            st.fwd = ((st.fwd << 2) | code) & tupmask;
+            st.rc = (st.rc >> 2) | ((uint64_t)(code ^ 3u) << crv);
+          }
+          st.run += 4u;
+        } else {
+          step_base(0, true, false); step_base(1, true, false); step_base(2, true, false); step_base(3, true, false);
+        }
+      } else {
+        step_base(0, false, false); step_base(1, false, false); step_base(2, false, false); step_base(3, false, false);
+        if (__all(st.done)) break;
+      }
+    }
+  }
+  if (qn) {
+    mk_wave_lds_fence();
+    mk_drain(a, q_uni, q_ord, qn, lane);
+  }
+}
+
+/* ---- multi-GPU: fold an exported shard into this table -------------------------------------------- */
+__global__ void __launch_bounds__(256) mk_import_kernel(mk_table tab, uint32_t S, const unsigned long long *keys,
+                                                        const uint32_t *counts, const unsigned long long *ords, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    mk_upsert(tab, S, keys[i], ords[i], counts[i]);
+}
+
+/* ---- table -> dense list of distinct keys ------------------------------------------------------------ */
+struct mk_dist {
+  unsigned long long *key;
+  unsigned long long *ord;
+  uint32_t *cnt; /* clamped to 65535: min(sum,65535) == min(sum of clamped,65535) */
+  uint64_t cap;
+};
+
+__global__ void __launch_bounds__(256) mk_compact_kernel(mk_table tab, uint32_t S, mk_dist out, unsigned long long *counter,
+                                                         int drop_key0) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t rounds = ((uint64_t)S + stride - 1) / stride;
+  for (uint64_t it = 0; it < rounds; it++) {
+    const uint64_t n = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long k1 = n < S ? tab.key[n] : 0ull;
+    bool occ = k1 != 0ull && !(drop_key0 && k1 == 1ull);
+    const uint64_t m = __ballot(occ);
+    if (m == 0) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0);
+    if (occ) {
+      const uint64_t idx = base + mk_mbcnt(m);
+      if (idx < out.cap) {
+        out.key[idx] = k1 - 1ull;
+        out.ord[idx] = ~tab.ordinv[n];
+        uint32_t c = tab.cnt[n];
+        out.cnt[idx] = c > 65535u ? 65535u : c;
+      }
+    }
+  }
+}
+
+/* ---- reference-order slot layout by priority insertion ------------------------------------------------
+ * Sequential FCFS insertion puts key K in the first slot of its probe sequence that no EARLIER key holds.
+ * That fixed point is unique, so it can be reached in any order: a walking key takes a slot from a later
+ * occupant and the evicted key resumes from the start of its own sequence. */
+__global__ void __launch_bounds__(256) mk_layout_kernel(mk_dist d, uint64_t D, uint32_t *slot, uint32_t S, uint32_t *err) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t cur = (uint32_t)i;
+    unsigned long long ord = d.ord[cur];
+    uint32_t n, h2;
+    mk_probe_init(d.key[cur], S, n, h2);
+    uint64_t guard = 0;
+    for (;;) {
+      if (++guard > 8ull * S) { atomicOr(&err[0], 2u); break; }
+      uint32_t old = __hip_atomic_load(&slot[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == MK_EMPTY32) {
+        if (atomicCAS(&slot[n], MK_EMPTY32, cur) == MK_EMPTY32) break;
+        continue; /* lost the race: look at the new occupant */
+      }
+      if (d.ord[old] < ord) { n = mk_probe_next(n, h2, S); continue; } /* earlier key keeps the slot */
+      if (atomicCAS(&slot[n], old, cur) != old) continue;
+      cur = old; /* evicted: re-walk its own sequence (everything before this slot is held by earlier keys) */
+      ord = d.ord[cur];
+      mk_probe_init(d.key[cur], S, n, h2);
+    }
+  }
+}
+
+/* ---- slot-order dump, one component at a time ----------------------------------------------------------
+ * each wave owns a contiguous chunk of MK_DUMP_CHUNK slots */
+#define MK_DUMP_CHUNK 4096u
+
+struct mk_dump_args {
+  const uint32_t *slot;
+  uint32_t S;
+  mk_dist d;
+  uint32_t comp_num, comp, comp_code_bits;
+  int uniq_only; /* MK_MODE_UNIQ_SET: keep keys seen exactly once */
+  uint32_t nchunks;
+};
+
+__device__ __forceinline__ bool mk_dump_pred(const mk_dump_args &a, uint64_t n, uint32_t &idx) {
+  idx = n < a.S ? a.slot[n] : MK_EMPTY32;
+  if (idx == MK_EMPTY32) return false;
+  if (a.comp_num > 1 && (uint32_t)(a.d.key[idx] % a.comp_num) != a.comp) return false;
+  if (a.uniq_only && a.d.cnt[idx] != 1u) return false;
+  return true;
+}
+
+__global__ void __launch_bounds__(256) mk_dump_count_kernel(mk_dump_args a, uint32_t *chunk_count) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (chunk >= a.nchunks) return;
+  uint32_t total = 0;
+  for (uint32_t it = 0; it < MK_DUMP_CHUNK / 64u; it++) {
+    uint32_t idx;
+    bool p = mk_dump_pred(a, (uint64_t)chunk * MK_DUMP_CHUNK + it * 64u + lane, idx);
+    total += (uint32_t)__popcll(__ballot(p));
+  }
+  if (lane == 0) chunk_count[chunk] = total;
+}
+
+/* exclusive scan of chunk counts by one workgroup; total -> *total_out */
+__global__ void __launch_bounds__(1024) mk_dump_scan_kernel(uint32_t *chunk_count, uint32_t nchunks, unsigned long long *total_out) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long carry_s;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nchunks; base += 1024u) {
+    const uint32_t i = base + threadIdx.x;
+    unsigned long long v = i < nchunks ? chunk_count[i] : 0ull, incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      unsigned long long t = __shfl_up(incl, o);
+      if ((int)lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned long long woff = 0;
+    for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
+    const unsigned long long carry = carry_s;
+    if (i < nchunks) chunk_count[i] = (uint32_t)(carry + woff + incl - v);
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry_s;
+}
+
+__global__ void __launch_bounds__(256) mk_dump_write_kernel(mk_dump_args a, const uint32_t *chunk_off, uint32_t *out_ids,
+                                                            uint16_t *out_cnt) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (chunk >= a.nchunks) return;
+  uint32_t off = chunk_off[chunk];
+  for (uint32_t it = 0; it < MK_DUMP_CHUNK / 64u; it++) {
+    uint32_t idx;
+    bool p = mk_dump_pred(a, (uint64_t)chunk * MK_DUMP_CHUNK + it * 64u + lane, idx);
+    const uint64_t m = __ballot(p);
+    if (p) {
+      const uint32_t o = off + mk_mbcnt(m);
+      out_ids[o] = (uint32_t)(a.d.key[idx] >> a.comp_code_bits);
+      if (out_cnt) out_cnt[o] = (uint16_t)a.d.cnt[idx];
+    }
+    off += (uint32_t)__popcll(m);
+  }
+}
+
+/* ---- synthetic reads: 16 bytes of one row per thread ------------------------------------------------- */
+__global__ void __launch_bounds__(256) mk_synth_kernel(uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len,
+                                                       uint32_t stride, uint8_t *rows) {
+  const uint32_t ppr = stride >> 4; /* stride % 16 == 0 */
+  const uint64_t total = nreads * ppr;
+  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = q / ppr;
+    const uint32_t c = (uint32_t)(q - r * ppr), b0 = c * 16u;
+    uint32_t v[4] = {0, 0, 0, 0};
+    if (b0 <= len) {
+      const uint64_t w = mk_synth_word(seed, first_read + r, b0 >> 5); /* 16 bases never straddle a 32-base word */
+#pragma unroll
+      for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t b = b0 + j;
+        uint32_t ch = 0;
+        if (b < len) ch = (0x54474341u >> (8u * (uint32_t)((w >> (2u * (b & 31u))) & 3u))) & 0xffu;
+        else if (b == len) ch = '\n';
+        v[j >> 2] |= ch << (8u * (j & 3u));
+      }
+    }
+    *(uint4 *)(rows + r * stride + b0) = make_uint4(v[0], v[1], v[2], v[3]);
+  }
+}

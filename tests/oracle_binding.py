@@ -1,0 +1,98 @@
+"""ctypes binding of oracle/libkssd_oracle.so -- TEST INFRASTRUCTURE ONLY (the parity checker)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libkssd_oracle.so")
+
+
+class KoParams(C.Structure):
+    _fields_ = [("shuf_id", C.c_int), ("k", C.c_int), ("subk", C.c_int), ("drlevel", C.c_int),
+                ("half_outctx_len", C.c_int), ("TL", C.c_int), ("crvsaddmove", C.c_int),
+                ("component_num", C.c_int), ("comp_code_bits", C.c_int), ("dim_start", C.c_int), ("dim_end", C.c_int),
+                ("hashsize", C.c_uint), ("hashlimit", C.c_uint),
+                ("tupmask", C.c_ulonglong), ("domask", C.c_ulonglong), ("undomask", C.c_ulonglong)]
+
+
+def load():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libkssd_oracle.so"])
+    lib = C.CDLL(LIB)
+    vp = C.c_void_p
+    lib.ko_params_derive.argtypes = [C.c_int] * 4 + [C.POINTER(KoParams)]
+    lib.ko_koc_from_fastq_bytes.argtypes = [C.POINTER(KoParams), vp, vp, C.c_size_t, vp, C.POINTER(C.c_ulonglong)]
+    lib.ko_koc_from_rows.argtypes = [C.POINTER(KoParams), vp, vp, C.c_size_t, C.c_size_t, vp, C.c_int, C.POINTER(C.c_uint)]
+    lib.ko_koc_from_rows_omp.argtypes = [C.POINTER(KoParams), vp, vp, C.c_size_t, C.c_size_t, vp, C.c_int, C.c_int]
+    lib.ko_dump_koc.argtypes = [C.POINTER(KoParams), vp, vp, vp, vp]
+    lib.ko_dump_koc.restype = C.c_uint
+    lib.ko_co_from_fasta_bytes.argtypes = [C.POINTER(KoParams), vp, vp, C.c_size_t, vp, C.c_int]
+    lib.ko_dump_co.argtypes = [C.POINTER(KoParams), vp, vp, vp]
+    lib.ko_dump_co.restype = C.c_uint
+    return lib
+
+
+class Oracle:
+    """the reference algorithm at -p 1 for one .shuf (table given as numpy int32)"""
+
+    def __init__(self, shuf_id, k, subk, drlevel, table):
+        self.lib = load()
+        self.P = KoParams()
+        rc = self.lib.ko_params_derive(shuf_id, k, subk, drlevel, C.byref(self.P))
+        if rc:
+            raise ValueError("ko_params_derive rc=%d" % rc)
+        self.table = np.ascontiguousarray(table, dtype=np.int32)
+        self.co = np.zeros(self.P.hashsize, dtype=np.uint64)
+        self.keycount = C.c_uint(0)
+
+    def _dump(self, koc):
+        Cn = self.P.component_num
+        nout = (C.c_size_t * Cn)()
+        if koc:
+            self.lib.ko_dump_koc(C.byref(self.P), self.co.ctypes.data, None, None, nout)
+        else:
+            self.lib.ko_dump_co(C.byref(self.P), self.co.ctypes.data, None, nout)
+        ids = [np.zeros(nout[c], np.uint32) for c in range(Cn)]
+        cnts = [np.zeros(nout[c], np.uint16) for c in range(Cn)]
+        pi = (C.c_void_p * Cn)(*[a.ctypes.data for a in ids])
+        pc = (C.c_void_p * Cn)(*[a.ctypes.data for a in cnts])
+        if koc:
+            self.lib.ko_dump_koc(C.byref(self.P), self.co.ctypes.data, pi, pc, nout)
+            return [(ids[c], cnts[c]) for c in range(Cn)]
+        self.lib.ko_dump_co(C.byref(self.P), self.co.ctypes.data, pi, nout)
+        return [(ids[c], None) for c in range(Cn)]
+
+    def koc_from_fastq(self, data):
+        b = np.frombuffer(data, dtype=np.uint8)
+        n = C.c_ulonglong(0)
+        rc = self.lib.ko_koc_from_fastq_bytes(C.byref(self.P), self.table.ctypes.data, b.ctypes.data if len(b) else None,
+                                              len(b), self.co.ctypes.data, C.byref(n))
+        if rc:
+            return rc, None
+        return 0, self._dump(True)
+
+    def koc_from_rows(self, rows, stride, clear=True, dump=True):
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        n = rows.size // stride
+        rc = self.lib.ko_koc_from_rows(C.byref(self.P), self.table.ctypes.data, rows.ctypes.data, stride, n,
+                                       self.co.ctypes.data, 1 if clear else 0, C.byref(self.keycount))
+        if rc:
+            return rc, None
+        return 0, (self._dump(True) if dump else None)
+
+    def koc_from_rows_omp(self, rows, stride, nthreads):
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        n = rows.size // stride
+        return self.lib.ko_koc_from_rows_omp(C.byref(self.P), self.table.ctypes.data, rows.ctypes.data, stride, n,
+                                             self.co.ctypes.data, 1, nthreads)
+
+    def co_from_fasta(self, data, uniq=False):
+        b = np.frombuffer(data, dtype=np.uint8)
+        rc = self.lib.ko_co_from_fasta_bytes(C.byref(self.P), self.table.ctypes.data, b.ctypes.data if len(b) else None,
+                                             len(b), self.co.ctypes.data, 1 if uniq else 0)
+        if rc:
+            return rc, None
+        return 0, self._dump(False)

@@ -1,0 +1,245 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle, bit-exact.
+
+Oracle = oracle/kssd_oracle.c, pinned against the compiled reference (oracle/check_vs_ref.py, tests/golden).
+Cases follow SURVEY.md 8c: collision-order (dense tables), counts, saturation, key 0, lower case, N resets,
+ragged and empty rows, FASTA windows (set / uniq), 16 components, crowded abort, multi-push and shard merge.
+"""
+import numpy as np
+import pytest
+
+import util_inputs as ui
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from metakssd_amd import capi as c
+    if c.device_count() < 1:
+        pytest.fail("no HIP device: the -m gpu tests must run on the MI355X box")
+    return c
+
+
+_engines = {}
+
+
+@pytest.fixture(scope="module")
+def engine_for(capi, shufs):
+    def get(name):
+        if name not in _engines:
+            _engines[name] = capi.Engine(shufs(name), 0)
+        return _engines[name]
+    yield get
+    for e in _engines.values():
+        e.close()
+    _engines.clear()
+
+
+def assert_same(got, want, label=""):
+    assert len(got) == len(want), label
+    for c, ((gi, gc), (wi, wc)) in enumerate(zip(got, want)):
+        assert len(gi) == len(wi), "%s component %d: %d ids vs oracle %d" % (label, c, len(gi), len(wi))
+        assert np.array_equal(gi, wi), "%s component %d: id order/content differs" % (label, c)
+        if wc is not None:
+            assert gc is not None and np.array_equal(gc, wc), "%s component %d: counts differ" % (label, c)
+
+
+def run_koc(capi, eng, rows, stride, pushes=1):
+    eng.begin(capi.MK_MODE_KOC)
+    n = rows.size // stride
+    per = (n + pushes - 1) // pushes if n else 0
+    done = 0
+    while done < n:
+        m = min(per, n - done)
+        eng.push_reads(rows[done * stride:(done + m) * stride], stride, done)
+        done += m
+    return eng.finish()
+
+
+@pytest.mark.parametrize("name,nreads", [("L3K11", 100000), ("L3K9", 100000), ("L1K7", 3000), ("L0K6", 400),
+                                         ("L3K10", 50000), ("L2K11", 20000)])
+def test_synthetic_uniform_reads(capi, engine_for, shufs, oracle_for, name, nreads):
+    """config 2 of BASELINE.json (100 k synthetic 150 bp reads, L3K11) and its dense-table siblings"""
+    rows = capi.synth_rows_host(1, 0, nreads, 150, 160)
+    got = run_koc(capi, engine_for(name), rows, 160)
+    rc, want = oracle_for(shufs(name)).koc_from_rows(rows, 160)
+    assert rc == 0
+    assert sum(len(w[0]) for w in want) > 0
+    assert_same(got, want, name)
+
+
+@pytest.mark.parametrize("name", ["L0K6", "L1K7", "L3K9"])
+def test_pool_reads_counts_rc_N_lowercase(capi, engine_for, shufs, oracle_for, name):
+    rs = np.random.RandomState(5)
+    seqs = ui.pool_reads(rs, 30000, 6000)
+    rows = ui.rows_from_seqs(seqs, 160)
+    got = run_koc(capi, engine_for(name), rows, 160)
+    rc, want = oracle_for(shufs(name)).koc_from_rows(rows, 160)
+    assert rc == 0
+    assert_same(got, want, name)
+    if name == "L0K6":
+        assert want[0][1].max() > 5  # counts really are exercised
+
+
+@pytest.mark.parametrize("stride", [304, 308, 512, 4096])
+@pytest.mark.parametrize("name", ["L0K6", "L1K7"])
+def test_ragged_rows_and_strides(capi, engine_for, shufs, oracle_for, name, stride):
+    """empty rows, rows shorter than a k-mer, rows spanning several column blocks, non-16-byte strides"""
+    rs = np.random.RandomState(stride)
+    seqs = ui.ragged_reads(rs, 700 if name == "L0K6" else 3000)
+    rows = ui.rows_from_seqs(seqs, stride)
+    got = run_koc(capi, engine_for(name), rows, stride)
+    rc, want = oracle_for(shufs(name)).koc_from_rows(rows, stride)
+    assert rc == 0
+    assert_same(got, want, "%s stride %d" % (name, stride))
+
+
+def test_long_rows_4095_bases(capi, engine_for, shufs, oracle_for):
+    rs = np.random.RandomState(77)
+    seqs = [ui.rand_seq(rs, 4095) for _ in range(130)] + [b"", ui.rand_seq(rs, 22)]
+    rows = ui.rows_from_seqs(seqs, 4096)
+    got = run_koc(capi, engine_for("L1K7"), rows, 4096)
+    rc, want = oracle_for(shufs("L1K7")).koc_from_rows(rows, 4096)
+    assert rc == 0
+    assert_same(got, want)
+
+
+def test_row_without_newline_ends_at_stride(capi, engine_for, shufs, oracle_for):
+    rs = np.random.RandomState(78)
+    stride = 64
+    rows = ui.ACGT[rs.randint(0, 4, size=stride * 500)].copy()  # no '\n' anywhere
+    got = run_koc(capi, engine_for("L0K6"), rows, stride)
+    rc, want = oracle_for(shufs("L0K6")).koc_from_rows(rows, stride)
+    assert rc == 0
+    assert_same(got, want)
+
+
+def test_saturation_65535(capi, engine_for, shufs, oracle_for):
+    rs = np.random.RandomState(9)
+    one = ui.rand_seq(rs, 150)
+    rows = ui.rows_from_seqs([one] * 70000, 160)
+    got = run_koc(capi, engine_for("L0K6"), rows, 160)
+    rc, want = oracle_for(shufs("L0K6")).koc_from_rows(rows, 160)
+    assert rc == 0
+    assert want[0][1].max() == 65535
+    assert_same(got, want)
+
+
+def test_key_zero_and_homopolymers(capi, engine_for, shufs, oracle_for):
+    seqs = [b"A" * 150, b"C" * 150, b"G" * 150, b"T" * 150, b"AC" * 75, b"ACGT" * 37] * 50
+    rows = ui.rows_from_seqs(seqs, 160)
+    got = run_koc(capi, engine_for("L0K6z"), rows, 160)
+    rc, want = oracle_for(shufs("L0K6z")).koc_from_rows(rows, 160)
+    assert rc == 0
+    assert 0 in want[0][0]  # key 0 is representable under -A
+    assert_same(got, want)
+
+
+def test_multi_push_equals_single_push(capi, engine_for, shufs, oracle_for):
+    rows = capi.synth_rows_host(4, 0, 500, 150, 160)
+    a = run_koc(capi, engine_for("L0K6"), rows, 160, pushes=1)
+    b = run_koc(capi, engine_for("L0K6"), rows, 160, pushes=7)
+    assert_same(a, b)
+    rc, want = oracle_for(shufs("L0K6")).koc_from_rows(rows, 160)
+    assert_same(a, want)
+
+
+def test_crowded_table_is_an_error_not_an_exit(capi, engine_for):
+    rows = capi.synth_rows_host(5, 0, 5000, 150, 160)  # ~ 600 k distinct 12-mers >> hashlimit 78 642
+    eng = engine_for("L0K6")
+    eng.begin(capi.MK_MODE_KOC)
+    eng.push_reads(rows, 160, 0)
+    with pytest.raises(capi.CrowdedError):
+        eng.finish()
+    # the engine stays usable
+    rows = capi.synth_rows_host(5, 0, 100, 150, 160)
+    got = run_koc(capi, eng, rows, 160)
+    assert len(got[0][0]) > 0
+
+
+@pytest.mark.parametrize("uniq", [False, True])
+@pytest.mark.parametrize("name", ["L0K6", "L0K6z", "L1K7", "L3K10", "L2K11"])
+def test_fasta_windows_set_and_uniq(capi, engine_for, shufs, oracle_for, name, uniq):
+    """config 5 family: fasta2co / uniq_fasta2co semantics through overlapped windows"""
+    rs = np.random.RandomState(31)
+    big = name in ("L3K10", "L2K11")
+    g = ui.rand_seq(rs, 400000 if big else 30000)
+    if big:
+        contigs = [g[:150000], g[150000:150050] + b"N" * 37 + g[150050:300000], g[100000:180000],
+                   ui.revcomp(g[300000:400000]).lower()]
+    else:
+        contigs = [g[:20000], g[5000:12000], b"A" * 100 + g[500:900] + b"T" * 50, g[20000:20021], b"", g[20021:]]
+    fa = ui.fasta_bytes(contigs)
+    TL = 2 * shufs(name).c.k
+    for stride, chunk in ((256, None), (512, 1000), (4096, 77777)):
+        rows = capi.fasta_windows(fa, TL, stride, chunk=chunk)
+        eng = engine_for(name)
+        eng.begin(capi.MK_MODE_UNIQ_SET if uniq else capi.MK_MODE_SET)
+        eng.push_reads(rows, stride, 0)
+        got = eng.finish()
+        rc, want = oracle_for(shufs(name)).co_from_fasta(fa, uniq=uniq)
+        assert rc == 0
+        assert_same(got, want, "%s uniq=%s stride=%d" % (name, uniq, stride))
+
+
+def test_shard_merge_equals_single_engine(capi, shufs, oracle_for):
+    """two engines sketch disjoint contiguous read ranges with global ordinals; the second one's
+    distinct-key list is imported into the first; the merged result equals the sequential sketch"""
+    import ctypes as C
+    shuf = shufs("L0K6")
+    rs = np.random.RandomState(41)
+    seqs = ui.pool_reads(rs, 20000, 5000)
+    rows = ui.rows_from_seqs(seqs, 160)
+    n = len(seqs)
+    cut = 2300
+    e0, e1 = capi.Engine(shuf, 0), capi.Engine(shuf, 0)
+    try:
+        for e in (e0, e1):
+            e.begin(capi.MK_MODE_KOC)
+        e0.push_reads(rows[:cut * 160], 160, 0)
+        e1.push_reads(rows[cut * 160:], 160, cut)
+        d1 = e1.partial_count()
+        assert d1 > 0
+        # device buffers for the exchange (what RCCL would carry): allocate through hipMalloc via ctypes
+        hip = C.CDLL("libamdhip64.so")
+        bufs = []
+        for nbytes in (8 * d1, 4 * d1, 8 * d1):
+            p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+            bufs.append(p)
+        got_n = e1.partial_export(bufs[0].value, bufs[1].value, bufs[2].value, d1)
+        assert got_n == d1
+        e0.partial_import(bufs[0].value, bufs[1].value, bufs[2].value, d1)
+        merged = e0.finish()
+        for p in bufs:
+            hip.hipFree(p)
+    finally:
+        e0.close()
+        e1.close()
+    rc, want = oracle_for(shuf).koc_from_rows(rows, 160)
+    assert rc == 0
+    assert_same(merged, want)
+    assert n == 5000
+
+
+def test_device_resident_push_and_device_synth(capi, engine_for, shufs, oracle_for):
+    """bench path: reads generated on the device, pushed from HBM; bytes identical to the host generator"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    nreads, stride = 2000, 160
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), C.c_size_t(nreads * stride)) == 0
+    capi.synth_rows_device(0, None, 99, 1000, nreads, 150, stride, p.value)
+    assert hip.hipDeviceSynchronize() == 0
+    back = np.zeros(nreads * stride, np.uint8)
+    assert hip.hipMemcpy(C.c_void_p(back.ctypes.data), p, C.c_size_t(back.size), 2) == 0
+    host = capi.synth_rows_host(99, 1000, nreads, 150, stride)
+    assert np.array_equal(back, host)
+    eng = engine_for("L1K7")
+    eng.begin(capi.MK_MODE_KOC)
+    eng.push_reads_device(p.value, stride, nreads, 0)
+    got = eng.finish()
+    hip.hipFree(p)
+    rc, want = oracle_for(shufs("L1K7")).koc_from_rows(host, stride)
+    assert rc == 0
+    assert_same(got, want)

@@ -1,0 +1,78 @@
+"""deterministic test inputs (numpy RandomState streams are stable across numpy versions)"""
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, np.uint8)
+for a, b in zip(b"ACGTacgtN", b"TGCAtgcaN"):
+    _COMP[a] = b
+
+
+def rand_seq(rs, n):
+    return ACGT[rs.randint(0, 4, size=n)].tobytes()
+
+
+def revcomp(s):
+    return _COMP[np.frombuffer(s, np.uint8)][::-1].tobytes()
+
+
+def rows_from_seqs(seqs, stride):
+    rows = np.zeros(len(seqs) * stride, dtype=np.uint8)
+    for i, s in enumerate(seqs):
+        assert len(s) + 1 <= stride
+        rows[i * stride: i * stride + len(s)] = np.frombuffer(s, np.uint8)
+        rows[i * stride + len(s)] = 10
+    return rows
+
+
+def fastq_bytes(seqs, crlf=False, final_newline=True, drop_last_qual=False):
+    nl = b"\r\n" if crlf else b"\n"
+    out = []
+    for i, s in enumerate(seqs):
+        rec = [b"@r%d" % i, s, b"+", b"I" * len(s)]
+        if drop_last_qual and i == len(seqs) - 1:
+            rec = rec[:3]
+        out.append(nl.join(rec) + nl)
+    txt = b"".join(out)
+    if not final_newline and txt:
+        txt = txt[: -len(nl)]
+    return txt
+
+
+def fasta_bytes(contigs, width=70):
+    out = []
+    for i, c in enumerate(contigs):
+        out.append(b">contig_%d some description\n" % i)
+        for j in range(0, len(c), width):
+            out.append(c[j:j + width] + b"\n")
+    return b"".join(out)
+
+
+def pool_reads(rs, pool_len, nreads, read_len=150, p_rc=0.5, p_n=0.05, p_lower=0.1):
+    pool = rand_seq(rs, pool_len)
+    seqs = []
+    for _ in range(nreads):
+        a = rs.randint(0, pool_len - read_len)
+        s = pool[a:a + read_len]
+        if rs.rand() < p_rc:
+            s = revcomp(s)
+        if rs.rand() < p_n:
+            j = rs.randint(0, read_len)
+            s = s[:j] + b"N" + s[j + 1:]
+        if rs.rand() < p_lower:
+            s = s.lower()
+        seqs.append(s)
+    return seqs
+
+
+def ragged_reads(rs, nreads, lens=(0, 1, 21, 22, 23, 50, 100, 150, 151, 250, 300)):
+    seqs = []
+    for _ in range(nreads):
+        L = int(lens[rs.randint(0, len(lens))])
+        s = rand_seq(rs, L)
+        if rs.rand() < 0.3:
+            s = s.lower()
+        if L > 30 and rs.rand() < 0.3:
+            j = rs.randint(0, L - 5)
+            s = s[:j] + b"NNN" + s[j + 3:]
+        seqs.append(s)
+    return seqs
