@@ -167,9 +167,11 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   MK_HIP(e, hipMemcpy(e->d_shuf, p->shuf_table, L * sizeof(int32_t), hipMemcpyHostToDevice));
   MK_HIP(e, hipMalloc(&e->d_accept, (acc.size() + 1) * sizeof(uint32_t)));
   if (!acc.empty()) MK_HIP(e, hipMemcpy(e->d_accept, acc.data(), acc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  /* LDS filter: 2^bm_bits bits, never wider than the inner substring itself (then it is exact) */
-  e->bm_bits = (uint32_t)(4 * p->subk < 19 ? 4 * p->subk : 19);
-  if (e->bm_bits < 5) e->bm_bits = 5;
+  /* LDS filter: 2^bm_bits words of 32 bits indexed by the inner substring's bits 10.. (at most 64 KiB) */
+  {
+    int wb = 4 * p->subk - 10;
+    e->bm_bits = (uint32_t)(wb < 0 ? 0 : wb > 14 ? 14 : wb);
+  }
 
   const uint64_t S = p->hashsize;
   e->tab_bytes = S * (8 + 8 + 4);
@@ -305,8 +307,8 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   a.ppr_inv = (1u << 20) / a.ppr + 1u;
   a.rowdw = (a.CB / 4u) | 1u;
   a.wave_lds_dwords = ((64u * a.rowdw + 1u) & ~1u) + 4u * MK_QCAP;
-  a.bm_words = (1u << e->bm_bits) / 32u;
-  a.bm_mask = (1u << e->bm_bits) - 1u;
+  a.bm_words = 1u << e->bm_bits;
+  a.dimmask = (uint32_t)((1ull << (4 * e->P.subk)) - 1ull);
   a.accept = e->d_accept; a.n_accept = e->n_accept;
   a.shuf = e->d_shuf;
   a.kp = e->kp;

@@ -53,7 +53,8 @@ struct mk_scan_args {
   uint32_t ppr_inv;   /* floor(2^20/ppr)+1 : q/ppr == (q*ppr_inv)>>20 for q < 2^20/ppr */
   uint32_t rowdw;     /* LDS dwords per staged row (odd => conflict-free row reads) */
   uint32_t wave_lds_dwords;
-  uint32_t bm_words, bm_mask;
+  uint32_t bm_words;  /* LDS filter words (power of two) */
+  uint32_t dimmask;   /* 2^(4*subk)-1: the inner substring after uni >> out2 */
   const uint32_t *accept; /* inner substrings d with dim_start <= shuf[d] < dim_end */
   uint32_t n_accept;
   const int32_t *shuf;
@@ -113,8 +114,8 @@ __device__ __forceinline__ void mk_upsert(const mk_table &tab, uint32_t S, uint6
 }
 
 /* exact accept test + upsert for up to 64 queued candidates (one per lane) */
-__device__ __noinline__ void mk_drain(const mk_scan_args &a, const uint64_t *q_uni, const uint64_t *q_ord, uint32_t n,
-                                      uint32_t lane) {
+__device__ __forceinline__ void mk_drain(const mk_scan_args &a, const uint64_t *q_uni, const uint64_t *q_ord, uint32_t n,
+                                         uint32_t lane) {
   if (lane < n) {
     uint64_t uni = q_uni[lane], ord = q_ord[lane];
     uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
@@ -126,12 +127,11 @@ __device__ __noinline__ void mk_drain(const mk_scan_args &a, const uint64_t *q_u
   }
 }
 
-/* per-wave scan state that lives across column blocks of a tile */
-struct mk_lane_state {
-  uint64_t fwd, rc;
-  uint32_t run;  /* valid bases since the last reset (the reference's base-1) */
-  bool done;     /* this lane's row hit its '\n' (or does not exist) */
-};
+/* LDS filter over the accepted inner substrings: a blocked Bloom filter, one 32-bit word per probe.
+ * word = bits 10.. of the substring, the two bit positions = its bits 0-4 and 5-9.  With 4096 accepted
+ * substrings in 16384 words the false-positive rate is about 0.07 %; correctness never depends on it
+ * (every candidate is re-checked against the .shuf table in mk_drain). */
+__device__ __forceinline__ uint32_t mk_filter_mask(uint32_t x) { return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u)); }
 
 template <int K>
 struct mk_kcfg {
@@ -143,23 +143,6 @@ struct mk_kcfg {
   }
 };
 
-/* push the candidates of this base position (lanes with hit) into the wave queue; drain when 64 are pending */
-__device__ __forceinline__ void mk_push(const mk_scan_args &a, uint64_t m, bool hit, uint64_t uni, uint64_t ord,
-                                        uint64_t *q_uni, uint64_t *q_ord, uint32_t &qn, uint32_t lane) {
-  uint32_t off = qn + mk_mbcnt(m);
-  if (hit) { q_uni[off] = uni; q_ord[off] = ord; }
-  qn += (uint32_t)__popcll(m);
-  if (qn >= 64) {
-    mk_wave_lds_fence();
-    mk_drain(a, q_uni, q_ord, 64, lane);
-    /* move the tail (fewer than 64 entries) to the front */
-    uint64_t tu = q_uni[64 + lane], to = q_ord[64 + lane];
-    mk_wave_lds_fence();
-    q_uni[lane] = tu; q_ord[lane] = to;
-    mk_wave_lds_fence();
-    qn -= 64;
-  }
-}
 
 template <int K, bool VEC16>
 __global__ void __launch_bounds__(MK_SCAN_THREADS) mk_scan_kernel(const mk_scan_args a) {
@@ -171,17 +154,18 @@ __global__ void __launch_bounds__(MK_SCAN_THREADS) mk_scan_kernel(const mk_scan_
   uint64_t *q_uni = (uint64_t *)(tile + ((64u * a.rowdw + 1u) & ~1u));
   uint64_t *q_ord = q_uni + MK_QCAP;
 
-  /* ---- LDS filter: one bit per (inner substring mod 2^bm_bits), set for the accepted subspace ---- */
   for (uint32_t i = threadIdx.x; i < a.bm_words; i += blockDim.x) bitmap[i] = 0u;
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < a.n_accept; i += blockDim.x) {
-    uint32_t d = a.accept[i] & a.bm_mask;
-    atomicOr(&bitmap[d >> 5], 1u << (d & 31u));
+    const uint32_t d = a.accept[i];
+    atomicOr(&bitmap[(d >> 10) & (a.bm_words - 1u)], mk_filter_mask(d));
   }
   __syncthreads();
 
   const uint32_t TL = cfg::TL(a.kp), crv = cfg::crv(a.kp), out2 = a.kp.out2;
   const uint64_t tupmask = cfg::mask(a.kp);
+  const uint32_t dimmask = a.dimmask;
+  const uint32_t wmask4 = (a.bm_words - 1u) << 2;
   const uint64_t ntiles = (a.nreads + 63u) >> 6;
   const uint64_t wave_global = (uint64_t)blockIdx.x * MK_SCAN_WAVES + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * MK_SCAN_WAVES;
@@ -231,8 +215,10 @@ __global__ void __launch_bounds__(MK_SCAN_THREADS) mk_scan_kernel(const mk_scan_
     }
   };
 
-  mk_lane_state st;
-  uint32_t qn = 0;
+  uint64_t fwd = 0, rc = 0;
+  uint32_t run = 0;  /* valid bases since the last reset (the reference's base-1) */
+  bool done = true;  /* this lane's row hit its '\n' (or does not exist) */
+  uint32_t qn = 0;   /* queued candidates, wave-uniform */
   const uint32_t *myrow = tile + lane * a.rowdw;
 
   issue_loads(0);
@@ -246,65 +232,107 @@ __global__ void __launch_bounds__(MK_SCAN_THREADS) mk_scan_kernel(const mk_scan_
     if (step + 1 < nsteps) issue_loads(step + 1);
 
     if (cb == 0) {
-      st.fwd = 0; st.rc = 0; st.run = 0;
-      st.done = row0 + lane >= a.nreads;
+      fwd = 0; rc = 0; run = 0;
+      done = row0 + lane >= a.nreads;
     }
     const uint32_t col0 = cb * a.CB;
     const uint32_t ndw = min(a.CB, a.stride - col0) >> 2;
     const uint64_t ord_row = (a.first_ord + row0 + lane) << 12;
-    if (__all(st.done)) continue;
+    if (__all(done)) continue;
 
-    for (uint32_t d = 0; d < ndw; d++) {
+    /* The four k-mers that end in dword d are looked up in the LDS filter while dword d is rolled; the
+     * results are examined one iteration later (LDS latency hidden behind the next dword's arithmetic).
+     * pu: canonical k-mers of the previous dword; pw and pm: their filter words and masks.  A base with no
+     * complete k-mer carries mask 1 / word 0, i.e. "no hit". */
+    uint64_t pu0 = 0, pu1 = 0, pu2 = 0, pu3 = 0;
+    uint32_t pm0 = 1, pm1 = 1, pm2 = 1, pm3 = 1, pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
+    bool pend = false;
+    uint32_t pend_pos0 = 0;
+
+    for (uint32_t d = 0; d <= ndw; d++) {
+      if (pend) {
+        const uint32_t t0 = pm0 & ~pw0, t1 = pm1 & ~pw1, t2 = pm2 & ~pw2, t3 = pm3 & ~pw3;
+        const uint32_t mn = min(min(t0, t1), min(t2, t3));
+        if (__any(mn == 0u)) { /* some lane has a filter hit among the four bases (rare) */
+#pragma unroll 1
+          for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t t = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : t3;
+            const uint64_t uni = j == 0 ? pu0 : j == 1 ? pu1 : j == 2 ? pu2 : pu3;
+            const bool hit = t == 0u;
+            const uint64_t m = __ballot(hit);
+            if (m == 0) continue;
+            const uint32_t off = qn + mk_mbcnt(m);
+            if (hit) { q_uni[off] = uni; q_ord[off] = ord_row | (uint64_t)(pend_pos0 + j); }
+            qn = __builtin_amdgcn_readfirstlane(qn + (uint32_t)__popcll(m));
+            if (qn >= 64u) {
+              mk_wave_lds_fence();
+              mk_drain(a, q_uni, q_ord, 64u, lane);
+              const uint64_t tu = q_uni[64u + lane], to = q_ord[64u + lane];
+              mk_wave_lds_fence();
+              q_uni[lane] = tu; q_ord[lane] = to;
+              mk_wave_lds_fence();
+              qn -= 64u;
+            }
+          }
+        }
+        pend = false;
+      }
+      if (d == ndw) break;
+
       const uint32_t w = myrow[d];
       const uint32_t tt = (w >> 1) ^ (w >> 2);
       const uint32_t codes = tt & 0x03030303u;
       /* expected upper-case letter of each code, compared with the byte folded to upper case */
       const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u, codes);
       const uint32_t x = (w & 0xDFDFDFDFu) ^ expect; /* byte j zero <=> byte j in ACGTacgt */
-      const uint32_t pos0 = col0 + 4u * d;
 
-      /* one base: roll, and (if a full k-mer is under the window) test the filter */
-      auto step_base = [&](uint32_t j, bool valid_known, bool complete_known) {
-        const uint32_t code = (codes >> (8u * j)) & 3u;
-        bool roll = true;
-        if (!valid_known) {
-          const uint32_t ch = (w >> (8u * j)) & 0xffu;
-          const bool valid = ((x >> (8u * j)) & 0xffu) == 0u;
-          if (!st.done && ch == '\n') st.done = true;
-          roll = valid && !st.done;
-          if (!roll && !st.done) st.run = 0; /* any other byte restarts the window (iseq2comem.c:688) */
-        }
-        if (roll) {
-          st.fwd = ((st.fwd << 2) | code) & tupmask;
-          st.rc = (st.rc >> 2) | ((uint64_t)(code ^ 3u) << crv);
-          st.run++;
-        }
-        const bool complete = complete_known ? true : (roll && st.run >= TL);
-        const uint64_t uni = st.fwd < st.rc ? st.fwd : st.rc;
-        const uint32_t idx = (uint32_t)(uni >> out2) & a.bm_mask;
-        const bool hit = complete && ((bitmap[idx >> 5] >> (idx & 31u)) & 1u);
-        const uint64_t m = __ballot(hit);
-        if (m) mk_push(a, m, hit, uni, ord_row | (pos0 + j), q_uni, q_ord, qn, lane);
+      auto roll = [&](uint32_t code) {
+        fwd = ((fwd << 2) | code) & tupmask;
+        rc = (rc >> 2) | ((uint64_t)(code ^ 3u) << crv);
+      };
+      auto lookup = [&](uint64_t uni, uint32_t &mask, uint32_t &word) {
+        uint32_t xx = (uint32_t)(uni >> out2);
+        if (K == 0) xx &= dimmask;
+        word = *(const uint32_t *)((const char *)bitmap + ((xx >> 8) & wmask4));
+        mask = mk_filter_mask(xx);
       };
 
-      if (__all(x == 0u && !st.done)) {
-        if (__all(st.run + 1u >= TL)) { /* every lane has a full window from the first base of this dword on */
-          step_base(0, true, true); step_base(1, true, true); step_base(2, true, true); step_base(3, true, true);
-        } else if (__all(st.run + 4u < TL)) { /* no lane completes a k-mer in this dword: roll only */
-#pragma unroll
-          for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t code = (codes >> (8u * j)) & 3u;
-            st.fwd = ((st.fwd << 2) | code) & tupmask;
-            st.rc = (st.rc >> 2) | ((uint64_t)(code ^ 3u) << crv);
-          }
-          st.run += 4u;
-        } else {
-          step_base(0, true, false); step_base(1, true, false); step_base(2, true, false); step_base(3, true, false);
+      if (__all(x == 0u && !done)) {
+        if (__all(run + 1u >= TL)) { /* every lane has a full window from the first base of this dword on */
+          roll(codes & 3u);          pu0 = fwd < rc ? fwd : rc; lookup(pu0, pm0, pw0);
+          roll((codes >> 8) & 3u);   pu1 = fwd < rc ? fwd : rc; lookup(pu1, pm1, pw1);
+          roll((codes >> 16) & 3u);  pu2 = fwd < rc ? fwd : rc; lookup(pu2, pm2, pw2);
+          roll((codes >> 24) & 3u);  pu3 = fwd < rc ? fwd : rc; lookup(pu3, pm3, pw3);
+          run += 4u;
+          pend = true;
+        } else if (__all(run + 4u < TL)) { /* no lane completes a k-mer in this dword: roll only */
+          roll(codes & 3u); roll((codes >> 8) & 3u); roll((codes >> 16) & 3u); roll((codes >> 24) & 3u);
+          run += 4u;
+        } else { /* all valid, some lanes still short of a full window */
+          roll(codes & 3u);          pu0 = fwd < rc ? fwd : rc; lookup(pu0, pm0, pw0); run++; if (run < TL) { pm0 = 1u; pw0 = 0u; }
+          roll((codes >> 8) & 3u);   pu1 = fwd < rc ? fwd : rc; lookup(pu1, pm1, pw1); run++; if (run < TL) { pm1 = 1u; pw1 = 0u; }
+          roll((codes >> 16) & 3u);  pu2 = fwd < rc ? fwd : rc; lookup(pu2, pm2, pw2); run++; if (run < TL) { pm2 = 1u; pw2 = 0u; }
+          roll((codes >> 24) & 3u);  pu3 = fwd < rc ? fwd : rc; lookup(pu3, pm3, pw3); run++; if (run < TL) { pm3 = 1u; pw3 = 0u; }
+          pend = true;
         }
       } else {
-        step_base(0, false, false); step_base(1, false, false); step_base(2, false, false); step_base(3, false, false);
-        if (__all(st.done)) break;
+        /* general case: newline, N, ragged rows.  Byte by byte, exactly iseq2comem.c:682-690 */
+        auto general = [&](uint32_t j, uint64_t &pu, uint32_t &pm, uint32_t &pw) {
+          const uint32_t ch = (w >> (8u * j)) & 0xffu;
+          const bool valid = ((x >> (8u * j)) & 0xffu) == 0u;
+          if (!done && ch == '\n') done = true;
+          const bool ok = valid && !done;
+          if (ok) { roll((codes >> (8u * j)) & 3u); run++; }
+          else if (!done) run = 0; /* any other byte restarts the window (iseq2comem.c:688) */
+          pu = fwd < rc ? fwd : rc;
+          lookup(pu, pm, pw);
+          if (!(ok && run >= TL)) { pm = 1u; pw = 0u; }
+        };
+        general(0, pu0, pm0, pw0); general(1, pu1, pm1, pw1); general(2, pu2, pm2, pw2); general(3, pu3, pm3, pw3);
+        pend = true;
       }
+      pend_pos0 = col0 + 4u * d;
+      if (__all(done)) d = ndw - 1u; /* nothing left in this tile: resolve what is pending and stop */
     }
   }
   if (qn) {
@@ -328,28 +356,43 @@ struct mk_dist {
   uint64_t cap;
 };
 
+/* each wave owns a contiguous chunk of MK_COMPACT_CHUNK slots: pass 1 counts its occupied slots, one
+ * atomicAdd per chunk reserves the output range, pass 2 (chunk still cache-hot) writes the entries */
+#define MK_COMPACT_CHUNK 4096u
 __global__ void __launch_bounds__(256) mk_compact_kernel(mk_table tab, uint32_t S, mk_dist out, unsigned long long *counter,
                                                          int drop_key0) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t rounds = ((uint64_t)S + stride - 1) / stride;
-  for (uint64_t it = 0; it < rounds; it++) {
-    const uint64_t n = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long k1 = n < S ? tab.key[n] : 0ull;
-    bool occ = k1 != 0ull && !(drop_key0 && k1 == 1ull);
-    const uint64_t m = __ballot(occ);
-    if (m == 0) continue;
+  const uint64_t nchunks = ((uint64_t)S + MK_COMPACT_CHUNK - 1) / MK_COMPACT_CHUNK;
+  const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t ch = wave0; ch < nchunks; ch += nw) {
+    const uint64_t base_slot = ch * MK_COMPACT_CHUNK;
+    uint32_t total = 0;
+    for (uint32_t it = 0; it < MK_COMPACT_CHUNK / 64u; it++) {
+      const uint64_t n = base_slot + it * 64u + lane;
+      const unsigned long long k1 = n < S ? tab.key[n] : 0ull;
+      const bool occ = k1 != 0ull && !(drop_key0 && k1 == 1ull);
+      total += (uint32_t)__popcll(__ballot(occ));
+    }
+    if (total == 0) continue;
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+    if (lane == 0) base = atomicAdd(counter, (unsigned long long)total);
     base = __shfl(base, 0);
-    if (occ) {
-      const uint64_t idx = base + mk_mbcnt(m);
-      if (idx < out.cap) {
-        out.key[idx] = k1 - 1ull;
-        out.ord[idx] = ~tab.ordinv[n];
-        uint32_t c = tab.cnt[n];
-        out.cnt[idx] = c > 65535u ? 65535u : c;
+    for (uint32_t it = 0; it < MK_COMPACT_CHUNK / 64u; it++) {
+      const uint64_t n = base_slot + it * 64u + lane;
+      const unsigned long long k1 = n < S ? tab.key[n] : 0ull;
+      const bool occ = k1 != 0ull && !(drop_key0 && k1 == 1ull);
+      const uint64_t m = __ballot(occ);
+      if (occ) {
+        const uint64_t idx = base + mk_mbcnt(m);
+        if (idx < out.cap) {
+          out.key[idx] = k1 - 1ull;
+          out.ord[idx] = ~tab.ordinv[n];
+          const uint32_t c = tab.cnt[n];
+          out.cnt[idx] = c > 65535u ? 65535u : c;
+        }
       }
+      base += (unsigned long long)__popcll(m);
     }
   }
 }
