@@ -59,6 +59,10 @@ struct mk_engine {
   bool begun = false, compacted = false;
   uint64_t D = 0;
 
+  /* launch tuning (overridable through MK_SCAN_THREADS / MK_SCAN_CB for experiments) */
+  int tune_threads = 512;
+  uint32_t tune_cb = MK_MAX_CB;
+
   bool profiling = false;
   std::vector<mk_evpair> ev_scan, ev_clear, ev_finish, ev_pool;
   uint64_t prof_rows = 0, prof_bytes = 0;
@@ -191,6 +195,8 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   MK_HIP(e, hipHostMalloc((void **)&e->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   e->tab.err = (uint32_t *)(e->d_counters + 2);
   e->comps.resize((size_t)p->component_num);
+  if (const char *t = getenv("MK_SCAN_THREADS")) { int v = atoi(t); if (v == 256 || v == 512 || v == 768 || v == 1024) e->tune_threads = v; }
+  if (const char *t = getenv("MK_SCAN_CB")) { int v = atoi(t); if (v >= 16 && v <= MK_MAX_CB && v % 16 == 0) e->tune_cb = (uint32_t)v; }
   return MK_OK;
 }
 
@@ -280,16 +286,25 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
 }
 
 /* ---- scan launch -------------------------------------------------------------------------------------- */
-template <int K, bool V>
+template <int K, bool V, int T>
 static hipError_t mk_launch_scan_t(const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t r = hipFuncSetAttribute((const void *)mk_scan_kernel<K, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t r = hipFuncSetAttribute((const void *)mk_scan_kernel<K, V, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (r != hipSuccess) return r;
     configured = lds;
   }
-  hipLaunchKernelGGL((mk_scan_kernel<K, V>), grid, dim3(MK_SCAN_THREADS), lds, s, a);
+  hipLaunchKernelGGL((mk_scan_kernel<K, V, T>), grid, dim3(T), lds, s, a);
   return hipGetLastError();
+}
+template <int K, bool V>
+static hipError_t mk_launch_scan_k(int threads, const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
+  switch (threads) {
+    case 1024: return mk_launch_scan_t<K, V, 1024>(a, grid, lds, s);
+    case 768: return mk_launch_scan_t<K, V, 768>(a, grid, lds, s);
+    case 512: return mk_launch_scan_t<K, V, 512>(a, grid, lds, s);
+    default: return mk_launch_scan_t<K, V, 256>(a, grid, lds, s);
+  }
 }
 
 static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride, uint64_t nreads, uint64_t first_ord) {
@@ -297,11 +312,12 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   mk_scan_args a{};
   a.rows = rows_dev; a.nreads = nreads; a.first_ord = first_ord; a.stride = stride;
   const bool vec = (stride % 16u == 0) && (((uintptr_t)rows_dev & 15u) == 0);
-  /* column blocks: fewest blocks of at most MK_MAX_CB bytes, equal width, 16-byte (vec) / 4-byte granular */
+  /* column blocks: fewest blocks of at most max_cb bytes, equal width, 16-byte (vec) / 4-byte granular */
   const uint32_t g = vec ? 16u : 4u;
-  a.ncb = (stride + MK_MAX_CB - 1) / MK_MAX_CB;
+  const uint32_t max_cb = e->tune_cb;
+  a.ncb = (stride + max_cb - 1) / max_cb;
   a.CB = ((stride + a.ncb - 1) / a.ncb + g - 1) / g * g;
-  if (a.CB > MK_MAX_CB) { a.ncb++; a.CB = ((stride + a.ncb - 1) / a.ncb + g - 1) / g * g; }
+  if (a.CB > max_cb) { a.ncb++; a.CB = ((stride + a.ncb - 1) / a.ncb + g - 1) / g * g; }
   a.ncb = (stride + a.CB - 1) / a.CB;
   a.ppr = a.CB / g;
   a.ppr_inv = (1u << 20) / a.ppr + 1u;
@@ -313,10 +329,17 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   a.shuf = e->d_shuf;
   a.kp = e->kp;
   a.tab = e->tab;
-  const size_t lds = ((size_t)a.bm_words + (size_t)MK_SCAN_WAVES * a.wave_lds_dwords) * 4u;
+  /* workgroup size: as many waves as the LDS budget (filter + per-wave tile and queue) admits */
+  int threads = e->tune_threads;
+  size_t lds = 0;
+  for (;; threads -= 256) {
+    lds = ((size_t)a.bm_words + (size_t)(threads / 64) * a.wave_lds_dwords) * 4u;
+    if (lds <= 160u * 1024u || threads <= 256) break;
+  }
   if (lds > 160u * 1024u) return mk_fail(e, MK_ERR_ARG, "scan: LDS budget exceeded (%zu bytes)", lds);
+  const uint32_t waves = (uint32_t)threads / 64u;
   const uint64_t ntiles = (nreads + 63) / 64;
-  uint64_t blocks = (ntiles + MK_SCAN_WAVES - 1) / MK_SCAN_WAVES;
+  uint64_t blocks = (ntiles + waves - 1) / waves;
   if (blocks > (uint64_t)e->num_cu) blocks = (uint64_t)e->num_cu;
   dim3 grid((unsigned)blocks);
 
@@ -324,9 +347,9 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   hipError_t r;
   switch (e->P.k) {
-    case 11: r = vec ? mk_launch_scan_t<11, true>(a, grid, lds, e->stream) : mk_launch_scan_t<11, false>(a, grid, lds, e->stream); break;
-    case 10: r = vec ? mk_launch_scan_t<10, true>(a, grid, lds, e->stream) : mk_launch_scan_t<10, false>(a, grid, lds, e->stream); break;
-    default: r = vec ? mk_launch_scan_t<0, true>(a, grid, lds, e->stream) : mk_launch_scan_t<0, false>(a, grid, lds, e->stream); break;
+    case 11: r = vec ? mk_launch_scan_k<11, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<11, false>(threads, a, grid, lds, e->stream); break;
+    case 10: r = vec ? mk_launch_scan_k<10, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<10, false>(threads, a, grid, lds, e->stream); break;
+    default: r = vec ? mk_launch_scan_k<0, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<0, false>(threads, a, grid, lds, e->stream); break;
   }
   if (r != hipSuccess) return mk_fail(e, MK_ERR_HIP, "scan launch: %s", hipGetErrorString(r));
   if (e->profiling) {

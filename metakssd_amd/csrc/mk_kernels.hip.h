@@ -22,8 +22,6 @@
 #include "host/mk_host_internal.h"
 
 #define MK_WAVE 64
-#define MK_SCAN_THREADS 512            /* 8 waves per workgroup, one workgroup per CU */
-#define MK_SCAN_WAVES (MK_SCAN_THREADS / MK_WAVE)
 #define MK_QCAP 128                    /* candidate queue entries per wave (64 pending + one full push) */
 #define MK_MAX_CB 128                  /* widest column block staged per step, bytes */
 #define MK_MAX_PIECES 8                /* 16-byte pieces per lane per step = MK_MAX_CB/16 */
@@ -113,9 +111,13 @@ __device__ __forceinline__ void mk_upsert(const mk_table &tab, uint32_t S, uint6
   atomicOr(&tab.err[0], 1u); /* every slot taken by other keys */
 }
 
-/* exact accept test + upsert for up to 64 queued candidates (one per lane) */
-__device__ __forceinline__ void mk_drain(const mk_scan_args &a, const uint64_t *q_uni, const uint64_t *q_ord, uint32_t n,
-                                         uint32_t lane) {
+/* exact accept test + upsert for up to 64 queued candidates (one per lane).  Kept out of line: it is rare
+ * and bulky (two 64-bit modulo reductions); it reads the kernel's argument block through the kernarg
+ * segment pointer (taken in the kernel, where the builtin is valid), so calling it does not force the hot
+ * loop's parameters out of scalar registers into scratch. */
+__device__ __noinline__ void mk_drain(const mk_scan_args *ka, const uint64_t *q_uni, const uint64_t *q_ord, uint32_t n,
+                                      uint32_t lane) {
+  const mk_scan_args &a = *ka;
   if (lane < n) {
     uint64_t uni = q_uni[lane], ord = q_ord[lane];
     uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
@@ -133,21 +135,64 @@ __device__ __forceinline__ void mk_drain(const mk_scan_args &a, const uint64_t *
  * (every candidate is re-checked against the .shuf table in mk_drain). */
 __device__ __forceinline__ uint32_t mk_filter_mask(uint32_t x) { return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u)); }
 
+/* rolling forward / reverse-complement k-mer pair (iseq2comem.c:685-686).
+ * K == 0: geometry from runtime parameters, 64-bit arithmetic.
+ * K  > 8: geometry folded at compile time, the 4K-bit values kept as two 32-bit halves so that every
+ *         step is a 32-bit VALU op (v_lshl_or / v_alignbit), no 64-bit shifts. */
 template <int K>
-struct mk_kcfg {
-  /* K == 0: everything from runtime parameters; K > 0: k-mer geometry folded at compile time */
-  static __device__ __forceinline__ uint32_t TL(const mk_keyparams &kp) { return K ? 2u * K : kp.TL; }
-  static __device__ __forceinline__ uint32_t crv(const mk_keyparams &kp) { return K ? 4u * K - 2u : kp.crvsaddmove; }
-  static __device__ __forceinline__ uint64_t mask(const mk_keyparams &kp) {
-    return K ? (0xffffffffffffffffull >> (64 - 4 * (K ? K : 1))) : kp.tupmask;
+struct mk_kmer {
+  uint64_t f, r;
+  __device__ __forceinline__ void reset() { f = 0; r = 0; }
+  __device__ __forceinline__ void roll(uint32_t code, const mk_keyparams &kp) {
+    f = ((f << 2) | code) & kp.tupmask;
+    r = (r >> 2) | ((uint64_t)(code ^ 3u) << kp.crvsaddmove);
   }
+  __device__ __forceinline__ uint64_t uni() const { return f < r ? f : r; }
+  static __device__ __forceinline__ uint32_t dimx(uint64_t u, const mk_keyparams &kp, uint32_t dimmask) {
+    return (uint32_t)(u >> kp.out2) & dimmask;
+  }
+  static __device__ __forceinline__ uint32_t TL(const mk_keyparams &kp) { return kp.TL; }
 };
 
+template <>
+struct mk_kmer<11>; /* defined through the generic K > 8 template below */
 
-template <int K, bool VEC16>
-__global__ void __launch_bounds__(MK_SCAN_THREADS) mk_scan_kernel(const mk_scan_args a) {
+template <int K>
+struct mk_kmer_hi {
+  static_assert(K > 8 && K <= 16, "two-half representation needs 32 < 4K <= 64");
+  static constexpr uint32_t HMASK = (uint32_t)((1ull << (4 * K - 32)) - 1ull);
+  static constexpr uint32_t CRVHI = 4 * K - 2 - 32;
+  uint32_t flo, fhi, rlo, rhi;
+  __device__ __forceinline__ void reset() { flo = fhi = rlo = rhi = 0; }
+  __device__ __forceinline__ void roll(uint32_t code, const mk_keyparams &) {
+    const uint32_t nfhi = __builtin_amdgcn_alignbit(fhi, flo, 30) & HMASK;
+    flo = (flo << 2) | code;
+    fhi = nfhi;
+    const uint32_t nrlo = __builtin_amdgcn_alignbit(rhi, rlo, 2);
+    rhi = (rhi >> 2) | ((code ^ 3u) << CRVHI);
+    rlo = nrlo;
+  }
+  __device__ __forceinline__ uint64_t uni() const {
+    const uint64_t f = ((uint64_t)fhi << 32) | flo, r = ((uint64_t)rhi << 32) | rlo;
+    return f < r ? f : r;
+  }
+  static __device__ __forceinline__ uint32_t dimx(uint64_t u, const mk_keyparams &kp, uint32_t dimmask) {
+    /* out2 < 32 whenever K > 8 and subk < 8 would give more: guard with the generic shift */
+    return (uint32_t)(u >> kp.out2) & dimmask;
+  }
+  static __device__ __forceinline__ uint32_t TL(const mk_keyparams &) { return 2u * K; }
+};
+template <> struct mk_kmer<9> : mk_kmer_hi<9> {};
+template <> struct mk_kmer<10> : mk_kmer_hi<10> {};
+template <> struct mk_kmer<11> : mk_kmer_hi<11> {};
+template <> struct mk_kmer<12> : mk_kmer_hi<12> {};
+
+typedef __attribute__((address_space(3))) const uint32_t *mk_lds_cu32;
+
+template <int K, bool VEC16, int THREADS>
+__global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) {
   extern __shared__ __align__(16) uint32_t lds[];
-  using cfg = mk_kcfg<K>;
+  constexpr uint32_t WAVES = THREADS / 64;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t *bitmap = lds;
   uint32_t *tile = lds + a.bm_words + wave * a.wave_lds_dwords;
@@ -162,13 +207,16 @@ __global__ void __launch_bounds__(MK_SCAN_THREADS) mk_scan_kernel(const mk_scan_
   }
   __syncthreads();
 
-  const uint32_t TL = cfg::TL(a.kp), crv = cfg::crv(a.kp), out2 = a.kp.out2;
-  const uint64_t tupmask = cfg::mask(a.kp);
+  /* the filter sits at the start of the dynamic LDS; its byte address (a link-time constant) is added once
+   * to the index mask result by keeping it in a register */
+  const uint32_t filter_base = (uint32_t)(uintptr_t)(mk_lds_cu32)bitmap;
+  const mk_scan_args *ka = (const mk_scan_args *)__builtin_amdgcn_kernarg_segment_ptr();
+  const uint32_t TL = mk_kmer<K>::TL(a.kp);
   const uint32_t dimmask = a.dimmask;
   const uint32_t wmask4 = (a.bm_words - 1u) << 2;
   const uint64_t ntiles = (a.nreads + 63u) >> 6;
-  const uint64_t wave_global = (uint64_t)blockIdx.x * MK_SCAN_WAVES + wave;
-  const uint64_t nwaves = (uint64_t)gridDim.x * MK_SCAN_WAVES;
+  const uint64_t wave_global = (uint64_t)blockIdx.x * WAVES + wave;
+  const uint64_t nwaves = (uint64_t)gridDim.x * WAVES;
   if (wave_global >= ntiles) return;
   const uint64_t my_tiles = (ntiles - wave_global + nwaves - 1) / nwaves;
   const uint64_t nsteps = my_tiles * a.ncb;
@@ -215,11 +263,88 @@ __global__ void __launch_bounds__(MK_SCAN_THREADS) mk_scan_kernel(const mk_scan_
     }
   };
 
-  uint64_t fwd = 0, rc = 0;
+  mk_kmer<K> km;
+  km.reset();
   uint32_t run = 0;  /* valid bases since the last reset (the reference's base-1) */
   bool done = true;  /* this lane's row hit its '\n' (or does not exist) */
   uint32_t qn = 0;   /* queued candidates, wave-uniform */
   const uint32_t *myrow = tile + lane * a.rowdw;
+  uint64_t ord_row = 0;
+
+  /* ---- building blocks ------------------------------------------------------------------------------ */
+  struct quad { uint64_t u0, u1, u2, u3; uint32_t m0, m1, m2, m3, w0, w1, w2, w3; };
+
+  auto lookup = [&](uint64_t uni, uint32_t &mask, uint32_t &word) {
+    const uint32_t xx = mk_kmer<K>::dimx(uni, a.kp, dimmask);
+    word = *(mk_lds_cu32)(uintptr_t)(((xx >> 8) & wmask4) + filter_base);
+    mask = mk_filter_mask(xx);
+  };
+  /* four valid bases, every lane with a full window: roll, canonical k-mer, filter probe */
+  auto fast4 = [&](uint32_t codes, quad &q) {
+    km.roll(codes & 3u, a.kp);         q.u0 = km.uni(); lookup(q.u0, q.m0, q.w0);
+    km.roll((codes >> 8) & 3u, a.kp);  q.u1 = km.uni(); lookup(q.u1, q.m1, q.w1);
+    km.roll((codes >> 16) & 3u, a.kp); q.u2 = km.uni(); lookup(q.u2, q.m2, q.w2);
+    km.roll(codes >> 24, a.kp);        q.u3 = km.uni(); lookup(q.u3, q.m3, q.w3);
+  };
+  /* any four bytes: newline, N, ragged rows -- byte by byte, exactly iseq2comem.c:682-690 */
+  auto general4 = [&](uint32_t w, uint32_t codes, uint32_t x, quad &q) {
+    auto one = [&](uint32_t j, uint64_t &pu, uint32_t &pm, uint32_t &pw) {
+      const uint32_t ch = (w >> (8u * j)) & 0xffu;
+      const bool valid = ((x >> (8u * j)) & 0xffu) == 0u;
+      if (!done && ch == '\n') done = true;
+      const bool ok = valid && !done;
+      if (ok) { km.roll((codes >> (8u * j)) & 3u, a.kp); run++; }
+      else if (!done) run = 0; /* any other byte restarts the window (iseq2comem.c:688) */
+      pu = km.uni();
+      lookup(pu, pm, pw);
+      if (!(ok && run >= TL)) { pm = 1u; pw = 0u; } /* no complete k-mer here: never a hit */
+    };
+    one(0, q.u0, q.m0, q.w0); one(1, q.u1, q.m1, q.w1); one(2, q.u2, q.m2, q.w2); one(3, q.u3, q.m3, q.w3);
+  };
+  /* examine four probes; queue the candidates (rare) */
+  auto resolve4 = [&](const quad &q, uint32_t pos0) {
+    const uint32_t t0 = q.m0 & ~q.w0, t1 = q.m1 & ~q.w1, t2 = q.m2 & ~q.w2, t3 = q.m3 & ~q.w3;
+    const uint32_t mn = min(min(t0, t1), min(t2, t3));
+    if (__any(mn == 0u)) {
+#pragma unroll 1
+      for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t t = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : t3;
+        const uint64_t uni = j == 0 ? q.u0 : j == 1 ? q.u1 : j == 2 ? q.u2 : q.u3;
+        const bool hit = t == 0u;
+        const uint64_t m = __ballot(hit);
+        if (m == 0) continue;
+        const uint32_t off = qn + mk_mbcnt(m);
+        if (hit) { q_uni[off] = uni; q_ord[off] = ord_row | (uint64_t)(pos0 + j); }
+        qn = __builtin_amdgcn_readfirstlane(qn + (uint32_t)__popcll(m));
+        if (qn >= 64u) {
+          mk_wave_lds_fence();
+          mk_drain(ka, q_uni, q_ord, 64u, lane);
+          const uint64_t tu = q_uni[64u + lane], to = q_ord[64u + lane];
+          mk_wave_lds_fence();
+          q_uni[lane] = tu; q_ord[lane] = to;
+          mk_wave_lds_fence();
+          qn -= 64u;
+        }
+      }
+    }
+  };
+  auto decode = [&](uint32_t w, uint32_t &codes, uint32_t &x) {
+    codes = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
+    /* expected upper-case letter of each code, compared with the byte folded to upper case */
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u, codes);
+    x = (w & 0xDFDFDFDFu) ^ expect; /* byte j zero <=> byte j in ACGTacgt */
+  };
+  /* one dword outside the fast path */
+  auto slow_dword = [&](uint32_t w, uint32_t codes, uint32_t x, uint32_t pos0) {
+    if (__all(x == 0u && !done && run + 4u < TL)) { /* all valid, nobody completes a k-mer: roll only */
+      km.roll(codes & 3u, a.kp); km.roll((codes >> 8) & 3u, a.kp); km.roll((codes >> 16) & 3u, a.kp); km.roll(codes >> 24, a.kp);
+      run += 4u;
+    } else {
+      quad q;
+      general4(w, codes, x, q);
+      resolve4(q, pos0);
+    }
+  };
 
   issue_loads(0);
   for (uint64_t step = 0; step < nsteps; step++) {
@@ -232,112 +357,47 @@ __global__ void __launch_bounds__(MK_SCAN_THREADS) mk_scan_kernel(const mk_scan_
     if (step + 1 < nsteps) issue_loads(step + 1);
 
     if (cb == 0) {
-      fwd = 0; rc = 0; run = 0;
+      km.reset(); run = 0;
       done = row0 + lane >= a.nreads;
     }
     const uint32_t col0 = cb * a.CB;
     const uint32_t ndw = min(a.CB, a.stride - col0) >> 2;
-    const uint64_t ord_row = (a.first_ord + row0 + lane) << 12;
+    ord_row = (a.first_ord + row0 + lane) << 12;
     if (__all(done)) continue;
 
-    /* The four k-mers that end in dword d are looked up in the LDS filter while dword d is rolled; the
-     * results are examined one iteration later (LDS latency hidden behind the next dword's arithmetic).
-     * pu: canonical k-mers of the previous dword; pw and pm: their filter words and masks.  A base with no
-     * complete k-mer carries mask 1 / word 0, i.e. "no hit". */
-    uint64_t pu0 = 0, pu1 = 0, pu2 = 0, pu3 = 0;
-    uint32_t pm0 = 1, pm1 = 1, pm2 = 1, pm3 = 1, pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
-    bool pend = false;
-    uint32_t pend_pos0 = 0;
-
-    for (uint32_t d = 0; d <= ndw; d++) {
-      if (pend) {
-        const uint32_t t0 = pm0 & ~pw0, t1 = pm1 & ~pw1, t2 = pm2 & ~pw2, t3 = pm3 & ~pw3;
-        const uint32_t mn = min(min(t0, t1), min(t2, t3));
-        if (__any(mn == 0u)) { /* some lane has a filter hit among the four bases (rare) */
-#pragma unroll 1
-          for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t t = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : t3;
-            const uint64_t uni = j == 0 ? pu0 : j == 1 ? pu1 : j == 2 ? pu2 : pu3;
-            const bool hit = t == 0u;
-            const uint64_t m = __ballot(hit);
-            if (m == 0) continue;
-            const uint32_t off = qn + mk_mbcnt(m);
-            if (hit) { q_uni[off] = uni; q_ord[off] = ord_row | (uint64_t)(pend_pos0 + j); }
-            qn = __builtin_amdgcn_readfirstlane(qn + (uint32_t)__popcll(m));
-            if (qn >= 64u) {
-              mk_wave_lds_fence();
-              mk_drain(a, q_uni, q_ord, 64u, lane);
-              const uint64_t tu = q_uni[64u + lane], to = q_ord[64u + lane];
-              mk_wave_lds_fence();
-              q_uni[lane] = tu; q_ord[lane] = to;
-              mk_wave_lds_fence();
-              qn -= 64u;
-            }
-          }
-        }
-        pend = false;
-      }
-      if (d == ndw) break;
-
-      const uint32_t w = myrow[d];
-      const uint32_t tt = (w >> 1) ^ (w >> 2);
-      const uint32_t codes = tt & 0x03030303u;
-      /* expected upper-case letter of each code, compared with the byte folded to upper case */
-      const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u, codes);
-      const uint32_t x = (w & 0xDFDFDFDFu) ^ expect; /* byte j zero <=> byte j in ACGTacgt */
-
-      auto roll = [&](uint32_t code) {
-        fwd = ((fwd << 2) | code) & tupmask;
-        rc = (rc >> 2) | ((uint64_t)(code ^ 3u) << crv);
-      };
-      auto lookup = [&](uint64_t uni, uint32_t &mask, uint32_t &word) {
-        uint32_t xx = (uint32_t)(uni >> out2);
-        if (K == 0) xx &= dimmask;
-        word = *(const uint32_t *)((const char *)bitmap + ((xx >> 8) & wmask4));
-        mask = mk_filter_mask(xx);
-      };
-
-      if (__all(x == 0u && !done)) {
-        if (__all(run + 1u >= TL)) { /* every lane has a full window from the first base of this dword on */
-          roll(codes & 3u);          pu0 = fwd < rc ? fwd : rc; lookup(pu0, pm0, pw0);
-          roll((codes >> 8) & 3u);   pu1 = fwd < rc ? fwd : rc; lookup(pu1, pm1, pw1);
-          roll((codes >> 16) & 3u);  pu2 = fwd < rc ? fwd : rc; lookup(pu2, pm2, pw2);
-          roll((codes >> 24) & 3u);  pu3 = fwd < rc ? fwd : rc; lookup(pu3, pm3, pw3);
-          run += 4u;
-          pend = true;
-        } else if (__all(run + 4u < TL)) { /* no lane completes a k-mer in this dword: roll only */
-          roll(codes & 3u); roll((codes >> 8) & 3u); roll((codes >> 16) & 3u); roll((codes >> 24) & 3u);
-          run += 4u;
-        } else { /* all valid, some lanes still short of a full window */
-          roll(codes & 3u);          pu0 = fwd < rc ? fwd : rc; lookup(pu0, pm0, pw0); run++; if (run < TL) { pm0 = 1u; pw0 = 0u; }
-          roll((codes >> 8) & 3u);   pu1 = fwd < rc ? fwd : rc; lookup(pu1, pm1, pw1); run++; if (run < TL) { pm1 = 1u; pw1 = 0u; }
-          roll((codes >> 16) & 3u);  pu2 = fwd < rc ? fwd : rc; lookup(pu2, pm2, pw2); run++; if (run < TL) { pm2 = 1u; pw2 = 0u; }
-          roll((codes >> 24) & 3u);  pu3 = fwd < rc ? fwd : rc; lookup(pu3, pm3, pw3); run++; if (run < TL) { pm3 = 1u; pw3 = 0u; }
-          pend = true;
-        }
+    const uint32_t npairs = ndw >> 1;
+    uint32_t nw0 = myrow[0], nw1 = ndw > 1 ? myrow[1] : 0x0a0a0a0au;
+    for (uint32_t p = 0; p < npairs; p++) {
+      const uint32_t w0 = nw0, w1 = nw1;
+      if (p + 1 < npairs) { nw0 = myrow[2 * p + 2]; nw1 = myrow[2 * p + 3]; }
+      else if (ndw & 1u) nw0 = myrow[ndw - 1];
+      uint32_t c0, x0, c1, x1;
+      decode(w0, c0, x0);
+      decode(w1, c1, x1);
+      const uint32_t pos0 = col0 + 8u * p;
+      if (__all((x0 | x1) == 0u && !done && run + 1u >= TL)) {
+        /* 8 valid bases, every lane with a full window: two batches of four probes in flight */
+        quad qa, qb;
+        fast4(c0, qa);
+        fast4(c1, qb);
+        run += 8u;
+        resolve4(qa, pos0);
+        resolve4(qb, pos0 + 4u);
       } else {
-        /* general case: newline, N, ragged rows.  Byte by byte, exactly iseq2comem.c:682-690 */
-        auto general = [&](uint32_t j, uint64_t &pu, uint32_t &pm, uint32_t &pw) {
-          const uint32_t ch = (w >> (8u * j)) & 0xffu;
-          const bool valid = ((x >> (8u * j)) & 0xffu) == 0u;
-          if (!done && ch == '\n') done = true;
-          const bool ok = valid && !done;
-          if (ok) { roll((codes >> (8u * j)) & 3u); run++; }
-          else if (!done) run = 0; /* any other byte restarts the window (iseq2comem.c:688) */
-          pu = fwd < rc ? fwd : rc;
-          lookup(pu, pm, pw);
-          if (!(ok && run >= TL)) { pm = 1u; pw = 0u; }
-        };
-        general(0, pu0, pm0, pw0); general(1, pu1, pm1, pw1); general(2, pu2, pm2, pw2); general(3, pu3, pm3, pw3);
-        pend = true;
+        slow_dword(w0, c0, x0, pos0);
+        slow_dword(w1, c1, x1, pos0 + 4u);
+        if (__all(done)) break;
       }
-      pend_pos0 = col0 + 4u * d;
-      if (__all(done)) d = ndw - 1u; /* nothing left in this tile: resolve what is pending and stop */
+    }
+    if ((ndw & 1u) && !__all(done)) {
+      uint32_t c0, x0;
+      decode(nw0, c0, x0);
+      slow_dword(nw0, c0, x0, col0 + 4u * (ndw - 1u));
     }
   }
   if (qn) {
     mk_wave_lds_fence();
-    mk_drain(a, q_uni, q_ord, qn, lane);
+    mk_drain(ka, q_uni, q_ord, qn, lane);
   }
 }
 
