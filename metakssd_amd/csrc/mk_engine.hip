@@ -322,7 +322,7 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   a.ppr = a.CB / g;
   a.ppr_inv = (1u << 20) / a.ppr + 1u;
   a.rowdw = (a.CB / 4u) | 1u;
-  a.wave_lds_dwords = ((64u * a.rowdw + 1u) & ~1u) + 4u * MK_QCAP;
+  a.wave_lds_dwords = ((64u * a.rowdw + 1u) & ~1u) + 4u * MK_QCAP; /* queue follows the tile: 2+ dwords of read slack */
   a.bm_words = 1u << e->bm_bits;
   a.dimmask = (uint32_t)((1ull << (4 * e->P.subk)) - 1ull);
   a.accept = e->d_accept; a.n_accept = e->n_accept;
@@ -346,7 +346,7 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   hipError_t r;
-  switch (e->P.k) {
+  switch (e->P.subk == 6 ? e->P.k : 0) {
     case 11: r = vec ? mk_launch_scan_k<11, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<11, false>(threads, a, grid, lds, e->stream); break;
     case 10: r = vec ? mk_launch_scan_k<10, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<10, false>(threads, a, grid, lds, e->stream); break;
     default: r = vec ? mk_launch_scan_k<0, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<0, false>(threads, a, grid, lds, e->stream); break;
@@ -536,6 +536,7 @@ extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
       total += nc;
     }
     if ((uint32_t)(e->h_counters[2] & 0xffffffffu) & 2u) return mk_fail(e, MK_ERR_HIP, "layout kernel did not converge");
+    if ((uint32_t)(e->h_counters[2] & 0xffffffffu) & 4u) return mk_fail(e, MK_ERR_HIP, "scan kernel: LDS filter not at offset 0");
     if (total) {
       MK_HIP(e, hipMemcpyAsync(e->h_ids, e->d_out_ids, total * 4, hipMemcpyDeviceToHost, e->stream));
       if (koc) MK_HIP(e, hipMemcpyAsync(e->h_cnt, e->d_out_cnt, total * 2, hipMemcpyDeviceToHost, e->stream));

@@ -189,6 +189,11 @@ template <> struct mk_kmer<12> : mk_kmer_hi<12> {};
 
 typedef __attribute__((address_space(3))) const uint32_t *mk_lds_cu32;
 
+/* SWAR helpers on four bytes */
+__device__ __forceinline__ uint32_t mk_nonzero_bytes(uint32_t v) { /* bit 7 of byte j set <=> byte j != 0 */
+  return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
+}
+
 template <int K, bool VEC16, int THREADS>
 __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) {
   extern __shared__ __align__(16) uint32_t lds[];
@@ -207,9 +212,12 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   }
   __syncthreads();
 
-  /* the filter sits at the start of the dynamic LDS; its byte address (a link-time constant) is added once
-   * to the index mask result by keeping it in a register */
+  /* the filter sits at the start of the dynamic LDS (offset 0: the tuned loop addresses it absolutely) */
   const uint32_t filter_base = (uint32_t)(uintptr_t)(mk_lds_cu32)bitmap;
+  if (K != 0 && (filter_base != 0u || a.bm_words != 16384u)) {
+    if (threadIdx.x == 0) atomicOr(&a.tab.err[0], 4u);
+    return;
+  }
   const mk_scan_args *ka = (const mk_scan_args *)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t TL = mk_kmer<K>::TL(a.kp);
   const uint32_t dimmask = a.dimmask;
@@ -218,32 +226,41 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   const uint64_t wave_global = (uint64_t)blockIdx.x * WAVES + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * WAVES;
   if (wave_global >= ntiles) return;
-  const uint64_t my_tiles = (ntiles - wave_global + nwaves - 1) / nwaves;
-  const uint64_t nsteps = my_tiles * a.ncb;
 
+  /* ---- staging: global -> registers (one step ahead) -> LDS tile ------------------------------------------
+   * A step is one column block (CB bytes) of one tile (64 rows).  Piece i of this lane is row r_i, 16-byte
+   * (or 4-byte) column c_i of the block: both are the same for every step, so the global byte offset and
+   * the LDS dword index are computed once. */
   using piece_t = typename std::conditional<VEC16, uint4, uint32_t>::type;
   constexpr int NP = VEC16 ? MK_MAX_PIECES : MK_MAX_CB / 4;
+  constexpr uint32_t PW = VEC16 ? 16u : 4u;
   piece_t regs[NP];
-
-  /* piece q of a step: row r = q / ppr of the tile, piece c = q % ppr of the column block */
-  auto issue_loads = [&](uint64_t step) {
-    const uint64_t tile_id = wave_global + (step / a.ncb) * nwaves;
-    const uint32_t cb = (uint32_t)(step % a.ncb);
+  uint32_t goff[NP], loff[NP];
+#pragma unroll
+  for (int i = 0; i < NP; i++) {
+    const uint32_t q = lane + 64u * i;
+    const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr;
+    goff[i] = r * a.stride + c * PW;
+    loff[i] = r * a.rowdw + c * (PW / 4u);
+  }
+  auto issue_loads = [&](uint64_t tile_id, uint32_t cb) {
     const uint64_t row0 = tile_id << 6;
-    const uint32_t rows_here = (uint32_t)min((uint64_t)64, a.nreads - row0);
     const uint8_t *base = a.rows + row0 * a.stride + (uint64_t)cb * a.CB;
     const uint32_t cols_here = min(a.CB, a.stride - cb * a.CB);
-    const uint32_t pw = VEC16 ? 16u : 4u;
+    if (row0 + 64u <= a.nreads && cols_here == a.CB) { /* full tile, full block: no predicates */
 #pragma unroll
-    for (int i = 0; i < NP; i++) {
-      if ((uint32_t)i < a.ppr) {
-        uint32_t q = lane + 64u * i;
-        uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr;
-        piece_t v;
-        if constexpr (VEC16) v = make_uint4(0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au);
-        else v = 0x0a0a0a0au;
-        if (r < rows_here && c * pw < cols_here) v = *(const piece_t *)(base + (uint64_t)r * a.stride + c * pw);
-        regs[i] = v;
+      for (int i = 0; i < NP; i++)
+        if ((uint32_t)i < a.ppr) regs[i] = *(const piece_t *)(base + goff[i]);
+    } else {
+      const uint32_t rows_here = (uint32_t)(a.nreads - row0 < 64u ? a.nreads - row0 : 64u);
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        if ((uint32_t)i < a.ppr) {
+          const uint32_t q = lane + 64u * i;
+          const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr;
+          /* rows past the last read and columns past the stride are never looked at: do not load them */
+          if (r < rows_here && c * PW < cols_here) regs[i] = *(const piece_t *)(base + goff[i]);
+        }
       }
     }
   };
@@ -251,13 +268,11 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       if ((uint32_t)i < a.ppr) {
-        uint32_t q = lane + 64u * i;
-        uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr;
         if constexpr (VEC16) {
-          uint32_t *p = tile + r * a.rowdw + c * 4u;
+          uint32_t *p = tile + loff[i];
           p[0] = regs[i].x; p[1] = regs[i].y; p[2] = regs[i].z; p[3] = regs[i].w;
         } else {
-          tile[r * a.rowdw + c] = regs[i];
+          tile[loff[i]] = regs[i];
         }
       }
     }
@@ -278,6 +293,23 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     const uint32_t xx = mk_kmer<K>::dimx(uni, a.kp, dimmask);
     word = *(mk_lds_cu32)(uintptr_t)(((xx >> 8) & wmask4) + filter_base);
     mask = mk_filter_mask(xx);
+  };
+  /* queue the lanes flagged in `hit` (candidate k-mer `uni` ending at row position `pos`) */
+  auto push = [&](bool hit, uint64_t uni, uint32_t pos) {
+    const uint64_t m = __ballot(hit);
+    if (m == 0) return;
+    const uint32_t off = qn + mk_mbcnt(m);
+    if (hit) { q_uni[off] = uni; q_ord[off] = ord_row | (uint64_t)pos; }
+    qn = __builtin_amdgcn_readfirstlane(qn + (uint32_t)__popcll(m));
+    if (qn >= 64u) {
+      mk_wave_lds_fence();
+      mk_drain(ka, q_uni, q_ord, 64u, lane);
+      const uint64_t tu = q_uni[64u + lane], to = q_ord[64u + lane];
+      mk_wave_lds_fence();
+      q_uni[lane] = tu; q_ord[lane] = to;
+      mk_wave_lds_fence();
+      qn -= 64u;
+    }
   };
   /* four valid bases, every lane with a full window: roll, canonical k-mer, filter probe */
   auto fast4 = [&](uint32_t codes, quad &q) {
@@ -310,21 +342,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
       for (uint32_t j = 0; j < 4; j++) {
         const uint32_t t = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : t3;
         const uint64_t uni = j == 0 ? q.u0 : j == 1 ? q.u1 : j == 2 ? q.u2 : q.u3;
-        const bool hit = t == 0u;
-        const uint64_t m = __ballot(hit);
-        if (m == 0) continue;
-        const uint32_t off = qn + mk_mbcnt(m);
-        if (hit) { q_uni[off] = uni; q_ord[off] = ord_row | (uint64_t)(pos0 + j); }
-        qn = __builtin_amdgcn_readfirstlane(qn + (uint32_t)__popcll(m));
-        if (qn >= 64u) {
-          mk_wave_lds_fence();
-          mk_drain(ka, q_uni, q_ord, 64u, lane);
-          const uint64_t tu = q_uni[64u + lane], to = q_ord[64u + lane];
-          mk_wave_lds_fence();
-          q_uni[lane] = tu; q_ord[lane] = to;
-          mk_wave_lds_fence();
-          qn -= 64u;
-        }
+        push(t == 0u, uni, pos0 + j);
       }
     }
   };
@@ -334,65 +352,149 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u, codes);
     x = (w & 0xDFDFDFDFu) ^ expect; /* byte j zero <=> byte j in ACGTacgt */
   };
-  /* one dword outside the fast path */
+  /* One dword outside the fast path.
+   *  (1) all valid and nobody completes a k-mer        -> roll only (read heads)
+   *  (2) every lane in the same situation (same `run`, same valid/newline byte pattern: fixed-length
+   *      reads at their head and tail)                 -> scalar control flow, no per-lane predicates
+   *  (3) anything else (ragged rows, scattered N)      -> byte-wise predicated general4 */
   auto slow_dword = [&](uint32_t w, uint32_t codes, uint32_t x, uint32_t pos0) {
-    if (__all(x == 0u && !done && run + 4u < TL)) { /* all valid, nobody completes a k-mer: roll only */
+    if (__all(x == 0u && !done && run + 4u < TL)) {
       km.roll(codes & 3u, a.kp); km.roll((codes >> 8) & 3u, a.kp); km.roll((codes >> 16) & 3u, a.kp); km.roll(codes >> 24, a.kp);
       run += 4u;
-    } else {
-      quad q;
-      general4(w, codes, x, q);
-      resolve4(q, pos0);
+      return;
     }
+    const uint32_t inval = mk_nonzero_bytes(x);                       /* 0x80 in byte j: not ACGTacgt */
+    const uint32_t notnl = mk_nonzero_bytes(w ^ 0x0A0A0A0Au);         /* 0x80 in byte j: not '\n' */
+    const uint32_t pat = inval | (notnl >> 1);
+    const uint32_t pat0 = __builtin_amdgcn_readfirstlane(pat), run0 = __builtin_amdgcn_readfirstlane(run);
+    if (__all(pat == pat0 && run == run0 && !done)) {
+      uint32_t urun = run0; /* wave-uniform copy of run */
+#pragma unroll 1
+      for (uint32_t j = 0; j < 4; j++) {
+        if (!(pat0 & (0x40u << (8u * j)))) { done = true; break; }    /* '\n': every lane ends here */
+        if (pat0 & (0x80u << (8u * j))) { urun = 0; continue; }       /* invalid byte: window restarts */
+        km.roll((codes >> (8u * j)) & 3u, a.kp);
+        urun++;
+        if (urun >= TL) {
+          const uint64_t uni = km.uni();
+          uint32_t m, wd;
+          lookup(uni, m, wd);
+          push((m & ~wd) == 0u, uni, pos0 + j);
+        }
+      }
+      run = urun;
+      return;
+    }
+    quad q;
+    general4(w, codes, x, q);
+    resolve4(q, pos0);
   };
 
-  issue_loads(0);
-  for (uint64_t step = 0; step < nsteps; step++) {
-    const uint64_t tile_id = wave_global + (step / a.ncb) * nwaves;
-    const uint32_t cb = (uint32_t)(step % a.ncb);
+  uint64_t nt_tile = wave_global; /* next step to load */
+  uint32_t nt_cb = 0;
+  issue_loads(nt_tile, nt_cb);
+  for (uint64_t tile_id = wave_global; tile_id < ntiles; tile_id += nwaves) {
     const uint64_t row0 = tile_id << 6;
-    mk_wave_lds_fence();
-    commit();
-    mk_wave_lds_fence();
-    if (step + 1 < nsteps) issue_loads(step + 1);
-
-    if (cb == 0) {
-      km.reset(); run = 0;
-      done = row0 + lane >= a.nreads;
-    }
-    const uint32_t col0 = cb * a.CB;
-    const uint32_t ndw = min(a.CB, a.stride - col0) >> 2;
+    km.reset(); run = 0;
+    done = row0 + lane >= a.nreads;
     ord_row = (a.first_ord + row0 + lane) << 12;
-    if (__all(done)) continue;
+    for (uint32_t cb = 0; cb < a.ncb; cb++) {
+      mk_wave_lds_fence();
+      commit();
+      mk_wave_lds_fence();
+      if (++nt_cb == a.ncb) { nt_cb = 0; nt_tile += nwaves; }
+      if (nt_tile < ntiles) issue_loads(nt_tile, nt_cb);
+      if (__all(done)) continue;
 
-    const uint32_t npairs = ndw >> 1;
-    uint32_t nw0 = myrow[0], nw1 = ndw > 1 ? myrow[1] : 0x0a0a0a0au;
-    for (uint32_t p = 0; p < npairs; p++) {
-      const uint32_t w0 = nw0, w1 = nw1;
-      if (p + 1 < npairs) { nw0 = myrow[2 * p + 2]; nw1 = myrow[2 * p + 3]; }
-      else if (ndw & 1u) nw0 = myrow[ndw - 1];
-      uint32_t c0, x0, c1, x1;
-      decode(w0, c0, x0);
-      decode(w1, c1, x1);
-      const uint32_t pos0 = col0 + 8u * p;
-      if (__all((x0 | x1) == 0u && !done && run + 1u >= TL)) {
-        /* 8 valid bases, every lane with a full window: two batches of four probes in flight */
-        quad qa, qb;
-        fast4(c0, qa);
-        fast4(c1, qb);
-        run += 8u;
-        resolve4(qa, pos0);
-        resolve4(qb, pos0 + 4u);
+      const uint32_t col0 = cb * a.CB;
+      const uint32_t ndw = min(a.CB, a.stride - col0) >> 2;
+      const uint32_t npairs = ndw >> 1;
+      if constexpr (K != 0) {
+        /* ---- tuned loop (k-mer geometry and the 24-bit inner substring folded at compile time) --------
+         * all_ready (wave-uniform): no lane is past its newline and every lane already has a full window.
+         * While it holds, a pair of dwords needs ONE validity test and ONE filter-hit test; `run` is left
+         * stale (it only has to stay >= TL-1, which it does until a reset in the slow path). */
+        constexpr uint32_t OUT2 = 2u * (K - 6);
+        bool all_ready = __all(!done && run + 1u >= TL);
+        uint32_t nw0 = myrow[0], nw1 = myrow[1];
+        for (uint32_t p = 0; p < npairs; p++) {
+          const uint32_t w0 = nw0, w1 = nw1;
+          nw0 = myrow[2 * p + 2]; /* unconditional prefetch: at most 2 dwords past the row, inside the wave's LDS */
+          nw1 = myrow[2 * p + 3];
+          uint32_t c0, x0, c1, x1;
+          decode(w0, c0, x0);
+          decode(w1, c1, x1);
+          const uint32_t pos0 = col0 + 8u * p;
+          if (all_ready && __all((x0 | x1) == 0u)) {
+            quad qa, qb;
+            auto probe = [&](uint32_t code, uint64_t &u, uint32_t &m, uint32_t &wd) {
+              km.roll(code, a.kp);
+              const uint64_t f = ((uint64_t)km.fhi << 32) | km.flo, r = ((uint64_t)km.rhi << 32) | km.rlo;
+              const bool lt = f < r;
+              const uint32_t ulo = lt ? km.flo : km.rlo, uhi = lt ? km.fhi : km.rhi;
+              u = ((uint64_t)uhi << 32) | ulo;
+              const uint32_t xx = __builtin_amdgcn_alignbit(uhi, ulo, OUT2);
+              wd = *(mk_lds_cu32)(uintptr_t)((xx >> 8) & 0xFFFCu);
+              m = mk_filter_mask(xx);
+            };
+            probe(c0 & 3u, qa.u0, qa.m0, qa.w0);
+            probe(__builtin_amdgcn_ubfe(c0, 8, 2), qa.u1, qa.m1, qa.w1);
+            probe(__builtin_amdgcn_ubfe(c0, 16, 2), qa.u2, qa.m2, qa.w2);
+            probe(c0 >> 24, qa.u3, qa.m3, qa.w3);
+            probe(c1 & 3u, qb.u0, qb.m0, qb.w0);
+            probe(__builtin_amdgcn_ubfe(c1, 8, 2), qb.u1, qb.m1, qb.w1);
+            probe(__builtin_amdgcn_ubfe(c1, 16, 2), qb.u2, qb.m2, qb.w2);
+            probe(c1 >> 24, qb.u3, qb.m3, qb.w3);
+            __builtin_amdgcn_sched_barrier(0); /* keep all eight probes in flight before the first result is read */
+            const uint32_t ta = min(min(qa.m0 & ~qa.w0, qa.m1 & ~qa.w1), min(qa.m2 & ~qa.w2, qa.m3 & ~qa.w3));
+            const uint32_t tb = min(min(qb.m0 & ~qb.w0, qb.m1 & ~qb.w1), min(qb.m2 & ~qb.w2, qb.m3 & ~qb.w3));
+            if (__any(min(ta, tb) == 0u)) { /* rare: a filter hit among the 8 x 64 probes */
+              resolve4(qa, pos0);
+              resolve4(qb, pos0 + 4u);
+            }
+          } else {
+            slow_dword(w0, c0, x0, pos0);
+            slow_dword(w1, c1, x1, pos0 + 4u);
+            if (__all(done)) break;
+            all_ready = __all(!done && run + 1u >= TL);
+          }
+        }
+        if ((ndw & 1u) && !__all(done)) {
+          const uint32_t w = myrow[ndw - 1u];
+          uint32_t c0, x0;
+          decode(w, c0, x0);
+          slow_dword(w, c0, x0, col0 + 4u * (ndw - 1u));
+        }
       } else {
-        slow_dword(w0, c0, x0, pos0);
-        slow_dword(w1, c1, x1, pos0 + 4u);
-        if (__all(done)) break;
+        uint32_t nw0 = myrow[0], nw1 = ndw > 1 ? myrow[1] : 0x0a0a0a0au;
+        for (uint32_t p = 0; p < npairs; p++) {
+          const uint32_t w0 = nw0, w1 = nw1;
+          if (p + 1 < npairs) { nw0 = myrow[2 * p + 2]; nw1 = myrow[2 * p + 3]; }
+          else if (ndw & 1u) nw0 = myrow[ndw - 1];
+          uint32_t c0, x0, c1, x1;
+          decode(w0, c0, x0);
+          decode(w1, c1, x1);
+          const uint32_t pos0 = col0 + 8u * p;
+          if (__all((x0 | x1) == 0u && !done && run + 1u >= TL)) {
+            /* 8 valid bases, every lane with a full window: two batches of four probes in flight */
+            quad qa, qb;
+            fast4(c0, qa);
+            fast4(c1, qb);
+            run += 8u;
+            resolve4(qa, pos0);
+            resolve4(qb, pos0 + 4u);
+          } else {
+            slow_dword(w0, c0, x0, pos0);
+            slow_dword(w1, c1, x1, pos0 + 4u);
+            if (__all(done)) break;
+          }
+        }
+        if ((ndw & 1u) && !__all(done)) {
+          uint32_t c0, x0;
+          decode(nw0, c0, x0);
+          slow_dword(nw0, c0, x0, col0 + 4u * (ndw - 1u));
+        }
       }
-    }
-    if ((ndw & 1u) && !__all(done)) {
-      uint32_t c0, x0;
-      decode(nw0, c0, x0);
-      slow_dword(nw0, c0, x0, col0 + 4u * (ndw - 1u));
     }
   }
   if (qn) {
