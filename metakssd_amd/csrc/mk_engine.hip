@@ -159,12 +159,20 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   kp.dim_start = p->dim_start; kp.dim_end = p->dim_end;
   kp.S = p->hashsize;
 
-  /* .shuf table + the list of accepted inner substrings (iseq2comem.c:693-694) */
+  /* .shuf table + the filter list B = A u revcomp(A), A = accepted inner substrings (iseq2comem.c:693-694).
+   * The inner substring (2*subk bases) sits in the middle of the k-mer, so the reverse-complement k-mer's
+   * inner substring is the reverse complement of the forward one: see mk_kernels.hip.h, "LDS filter". */
   const uint64_t L = p->shuf_len;
   std::vector<uint32_t> acc;
+  const uint32_t dbits = 4u * (uint32_t)p->subk;
   for (uint64_t d = 0; d < L; d++) {
     int32_t v = p->shuf_table[d];
-    if (v >= p->dim_start && v < p->dim_end) acc.push_back((uint32_t)d);
+    if (v >= p->dim_start && v < p->dim_end) {
+      acc.push_back((uint32_t)d);
+      uint32_t n = ~(uint32_t)d, r = 0; /* reverse the 2-bit groups of the complement within dbits */
+      for (uint32_t i = 0; i < dbits; i += 2) r |= ((n >> i) & 3u) << (dbits - 2u - i);
+      acc.push_back(r);
+    }
   }
   e->n_accept = (uint32_t)acc.size();
   MK_HIP(e, hipMalloc(&e->d_shuf, L * sizeof(int32_t)));
@@ -374,7 +382,7 @@ extern "C" int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev
   int rc = mk_check_push(e, rows_dev, stride);
   if (rc) return rc;
   MK_HIP(e, hipSetDevice(e->device));
-  if ((first_read_ordinal + nreads) >> 52) return mk_fail(e, MK_ERR_ARG, "read ordinal too large");
+  if ((first_read_ordinal + nreads) >> 51) return mk_fail(e, MK_ERR_ARG, "read ordinal too large");
   return mk_launch_scan(e, rows_dev, stride, nreads, first_read_ordinal);
 }
 
@@ -383,7 +391,7 @@ extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t 
   int rc = mk_check_push(e, rows, stride);
   if (rc) return rc;
   MK_HIP(e, hipSetDevice(e->device));
-  if ((first_read_ordinal + nreads) >> 52) return mk_fail(e, MK_ERR_ARG, "read ordinal too large");
+  if ((first_read_ordinal + nreads) >> 51) return mk_fail(e, MK_ERR_ARG, "read ordinal too large");
   const size_t chunk_max = (size_t)64 << 20;
   if (!e->d_stage[0]) {
     e->stage_bytes = chunk_max;

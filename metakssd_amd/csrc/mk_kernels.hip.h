@@ -111,15 +111,29 @@ __device__ __forceinline__ void mk_upsert(const mk_table &tab, uint32_t S, uint6
   atomicOr(&tab.err[0], 1u); /* every slot taken by other keys */
 }
 
-/* exact accept test + upsert for up to 64 queued candidates (one per lane).  Kept out of line: it is rare
+/* reverse complement of a k-mer of `TL` bases held in the low 2*TL bits: reverse the 2-bit groups of the
+ * complement.  Equals the reference's incrementally built crvstuple (iseq2comem.c:686). */
+__device__ __forceinline__ uint64_t mk_revcomp(uint64_t f, uint32_t TL) {
+  uint64_t n = ~f;
+  n = ((n >> 2) & 0x3333333333333333ull) | ((n & 0x3333333333333333ull) << 2);
+  n = ((n >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((n & 0x0F0F0F0F0F0F0F0Full) << 4);
+  n = __builtin_bswap64(n);
+  return n >> (64u - 2u * TL);
+}
+
+/* exact accept test + upsert for up to 64 queued candidates (one per lane).  A candidate is the FORWARD
+ * k-mer whose inner substring passed the strand-symmetric LDS filter; here the canonical k-mer
+ * (iseq2comem.c:691) is formed and looked up in the .shuf table (:692-695).  Kept out of line: it is rare
  * and bulky (two 64-bit modulo reductions); it reads the kernel's argument block through the kernarg
  * segment pointer (taken in the kernel, where the builtin is valid), so calling it does not force the hot
  * loop's parameters out of scalar registers into scratch. */
-__device__ __noinline__ void mk_drain(const mk_scan_args *ka, const uint64_t *q_uni, const uint64_t *q_ord, uint32_t n,
+__device__ __noinline__ void mk_drain(const mk_scan_args *ka, const uint64_t *q_fwd, const uint64_t *q_ord, uint32_t n,
                                       uint32_t lane) {
   const mk_scan_args &a = *ka;
   if (lane < n) {
-    uint64_t uni = q_uni[lane], ord = q_ord[lane];
+    const uint64_t fwd = q_fwd[lane], ord = q_ord[lane];
+    const uint64_t rc = mk_revcomp(fwd, a.kp.TL);
+    const uint64_t uni = fwd < rc ? fwd : rc;
     uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
     int32_t pf = a.shuf[dim]; /* iseq2comem.c:693 */
     if (pf >= a.kp.dim_start && pf < a.kp.dim_end) {
@@ -129,56 +143,43 @@ __device__ __noinline__ void mk_drain(const mk_scan_args *ka, const uint64_t *q_
   }
 }
 
-/* LDS filter over the accepted inner substrings: a blocked Bloom filter, one 32-bit word per probe.
- * word = bits 10.. of the substring, the two bit positions = its bits 0-4 and 5-9.  With 4096 accepted
- * substrings in 16384 words the false-positive rate is about 0.07 %; correctness never depends on it
- * (every candidate is re-checked against the .shuf table in mk_drain). */
+/* LDS filter: a blocked Bloom filter over B = A u revcomp(A), A = the accepted inner substrings
+ * (dim_start <= shuf[d] < dim_end).  The inner substring lies symmetrically inside the k-mer, so the inner
+ * substring of the reverse-complement k-mer is the reverse complement of the forward one: a k-mer can only
+ * be accepted if its FORWARD inner substring is in B, whichever strand turns out to be canonical.  The hot
+ * loop therefore rolls and probes the forward strand only; canonicalisation happens for filter hits, in
+ * mk_drain.  One 32-bit word per probe: word = bits 10.. of the substring, two bit positions = its bits 0-4
+ * and 5-9.  8192 entries in 16384 words: about 0.15 % false positives; correctness never depends on it. */
 __device__ __forceinline__ uint32_t mk_filter_mask(uint32_t x) { return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u)); }
 
-/* rolling forward / reverse-complement k-mer pair (iseq2comem.c:685-686).
+/* rolling forward k-mer (iseq2comem.c:685).
  * K == 0: geometry from runtime parameters, 64-bit arithmetic.
- * K  > 8: geometry folded at compile time, the 4K-bit values kept as two 32-bit halves so that every
- *         step is a 32-bit VALU op (v_lshl_or / v_alignbit), no 64-bit shifts. */
+ * K  > 8: geometry folded at compile time, the 4K-bit value kept as two 32-bit halves so that every
+ *         step is a 32-bit VALU op (v_lshl_or / v_alignbit / v_and). */
 template <int K>
 struct mk_kmer {
-  uint64_t f, r;
-  __device__ __forceinline__ void reset() { f = 0; r = 0; }
-  __device__ __forceinline__ void roll(uint32_t code, const mk_keyparams &kp) {
-    f = ((f << 2) | code) & kp.tupmask;
-    r = (r >> 2) | ((uint64_t)(code ^ 3u) << kp.crvsaddmove);
-  }
-  __device__ __forceinline__ uint64_t uni() const { return f < r ? f : r; }
-  static __device__ __forceinline__ uint32_t dimx(uint64_t u, const mk_keyparams &kp, uint32_t dimmask) {
-    return (uint32_t)(u >> kp.out2) & dimmask;
-  }
+  uint64_t f;
+  __device__ __forceinline__ void reset() { f = 0; }
+  __device__ __forceinline__ void roll(uint32_t code, const mk_keyparams &kp) { f = ((f << 2) | code) & kp.tupmask; }
+  __device__ __forceinline__ uint64_t fwd() const { return f; }
+  __device__ __forceinline__ uint32_t dimx(const mk_keyparams &kp, uint32_t dimmask) const { return (uint32_t)(f >> kp.out2) & dimmask; }
   static __device__ __forceinline__ uint32_t TL(const mk_keyparams &kp) { return kp.TL; }
 };
-
-template <>
-struct mk_kmer<11>; /* defined through the generic K > 8 template below */
 
 template <int K>
 struct mk_kmer_hi {
   static_assert(K > 8 && K <= 16, "two-half representation needs 32 < 4K <= 64");
   static constexpr uint32_t HMASK = (uint32_t)((1ull << (4 * K - 32)) - 1ull);
-  static constexpr uint32_t CRVHI = 4 * K - 2 - 32;
-  uint32_t flo, fhi, rlo, rhi;
-  __device__ __forceinline__ void reset() { flo = fhi = rlo = rhi = 0; }
+  uint32_t flo, fhi;
+  __device__ __forceinline__ void reset() { flo = fhi = 0; }
   __device__ __forceinline__ void roll(uint32_t code, const mk_keyparams &) {
     const uint32_t nfhi = __builtin_amdgcn_alignbit(fhi, flo, 30) & HMASK;
     flo = (flo << 2) | code;
     fhi = nfhi;
-    const uint32_t nrlo = __builtin_amdgcn_alignbit(rhi, rlo, 2);
-    rhi = (rhi >> 2) | ((code ^ 3u) << CRVHI);
-    rlo = nrlo;
   }
-  __device__ __forceinline__ uint64_t uni() const {
-    const uint64_t f = ((uint64_t)fhi << 32) | flo, r = ((uint64_t)rhi << 32) | rlo;
-    return f < r ? f : r;
-  }
-  static __device__ __forceinline__ uint32_t dimx(uint64_t u, const mk_keyparams &kp, uint32_t dimmask) {
-    /* out2 < 32 whenever K > 8 and subk < 8 would give more: guard with the generic shift */
-    return (uint32_t)(u >> kp.out2) & dimmask;
+  __device__ __forceinline__ uint64_t fwd() const { return ((uint64_t)fhi << 32) | flo; }
+  __device__ __forceinline__ uint32_t dimx(const mk_keyparams &kp, uint32_t dimmask) const {
+    return (uint32_t)(fwd() >> kp.out2) & dimmask;
   }
   static __device__ __forceinline__ uint32_t TL(const mk_keyparams &) { return 2u * K; }
 };
@@ -289,12 +290,12 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   /* ---- building blocks ------------------------------------------------------------------------------ */
   struct quad { uint64_t u0, u1, u2, u3; uint32_t m0, m1, m2, m3, w0, w1, w2, w3; };
 
-  auto lookup = [&](uint64_t uni, uint32_t &mask, uint32_t &word) {
-    const uint32_t xx = mk_kmer<K>::dimx(uni, a.kp, dimmask);
+  auto lookup = [&](uint32_t &mask, uint32_t &word) { /* probe the current forward k-mer's inner substring */
+    const uint32_t xx = km.dimx(a.kp, dimmask);
     word = *(mk_lds_cu32)(uintptr_t)(((xx >> 8) & wmask4) + filter_base);
     mask = mk_filter_mask(xx);
   };
-  /* queue the lanes flagged in `hit` (candidate k-mer `uni` ending at row position `pos`) */
+  /* queue the lanes flagged in `hit` (forward k-mer `uni` ending at row position `pos`) */
   auto push = [&](bool hit, uint64_t uni, uint32_t pos) {
     const uint64_t m = __ballot(hit);
     if (m == 0) return;
@@ -313,10 +314,10 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   };
   /* four valid bases, every lane with a full window: roll, canonical k-mer, filter probe */
   auto fast4 = [&](uint32_t codes, quad &q) {
-    km.roll(codes & 3u, a.kp);         q.u0 = km.uni(); lookup(q.u0, q.m0, q.w0);
-    km.roll((codes >> 8) & 3u, a.kp);  q.u1 = km.uni(); lookup(q.u1, q.m1, q.w1);
-    km.roll((codes >> 16) & 3u, a.kp); q.u2 = km.uni(); lookup(q.u2, q.m2, q.w2);
-    km.roll(codes >> 24, a.kp);        q.u3 = km.uni(); lookup(q.u3, q.m3, q.w3);
+    km.roll(codes & 3u, a.kp);         q.u0 = km.fwd(); lookup(q.m0, q.w0);
+    km.roll((codes >> 8) & 3u, a.kp);  q.u1 = km.fwd(); lookup(q.m1, q.w1);
+    km.roll((codes >> 16) & 3u, a.kp); q.u2 = km.fwd(); lookup(q.m2, q.w2);
+    km.roll(codes >> 24, a.kp);        q.u3 = km.fwd(); lookup(q.m3, q.w3);
   };
   /* any four bytes: newline, N, ragged rows -- byte by byte, exactly iseq2comem.c:682-690 */
   auto general4 = [&](uint32_t w, uint32_t codes, uint32_t x, quad &q) {
@@ -327,24 +328,24 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
       const bool ok = valid && !done;
       if (ok) { km.roll((codes >> (8u * j)) & 3u, a.kp); run++; }
       else if (!done) run = 0; /* any other byte restarts the window (iseq2comem.c:688) */
-      pu = km.uni();
-      lookup(pu, pm, pw);
+      pu = km.fwd();
+      lookup(pm, pw);
       if (!(ok && run >= TL)) { pm = 1u; pw = 0u; } /* no complete k-mer here: never a hit */
     };
     one(0, q.u0, q.m0, q.w0); one(1, q.u1, q.m1, q.w1); one(2, q.u2, q.m2, q.w2); one(3, q.u3, q.m3, q.w3);
   };
-  /* examine four probes; queue the candidates (rare) */
+  /* examine four probes; queue the candidates (rare).  Unrolled: a base without a hit costs one compare
+   * and one scalar branch */
+  auto hits4 = [&](const quad &q, uint32_t pos0) {
+    push((q.m0 & ~q.w0) == 0u, q.u0, pos0);
+    push((q.m1 & ~q.w1) == 0u, q.u1, pos0 + 1u);
+    push((q.m2 & ~q.w2) == 0u, q.u2, pos0 + 2u);
+    push((q.m3 & ~q.w3) == 0u, q.u3, pos0 + 3u);
+  };
   auto resolve4 = [&](const quad &q, uint32_t pos0) {
     const uint32_t t0 = q.m0 & ~q.w0, t1 = q.m1 & ~q.w1, t2 = q.m2 & ~q.w2, t3 = q.m3 & ~q.w3;
     const uint32_t mn = min(min(t0, t1), min(t2, t3));
-    if (__any(mn == 0u)) {
-#pragma unroll 1
-      for (uint32_t j = 0; j < 4; j++) {
-        const uint32_t t = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : t3;
-        const uint64_t uni = j == 0 ? q.u0 : j == 1 ? q.u1 : j == 2 ? q.u2 : q.u3;
-        push(t == 0u, uni, pos0 + j);
-      }
-    }
+    if (__any(mn == 0u)) hits4(q, pos0);
   };
   auto decode = [&](uint32_t w, uint32_t &codes, uint32_t &x) {
     codes = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
@@ -376,10 +377,9 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
         km.roll((codes >> (8u * j)) & 3u, a.kp);
         urun++;
         if (urun >= TL) {
-          const uint64_t uni = km.uni();
           uint32_t m, wd;
-          lookup(uni, m, wd);
-          push((m & ~wd) == 0u, uni, pos0 + j);
+          lookup(m, wd);
+          push((m & ~wd) == 0u, km.fwd(), pos0 + j);
         }
       }
       run = urun;
@@ -399,11 +399,24 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     done = row0 + lane >= a.nreads;
     ord_row = (a.first_ord + row0 + lane) << 12;
     for (uint32_t cb = 0; cb < a.ncb; cb++) {
+#if defined(MK_ABLATE) && (MK_ABLATE == 2 || MK_ABLATE == 4)
+      if (tile_id == wave_global) { /* ablation: stage only the first tile, reuse it */
+#endif
       mk_wave_lds_fence();
       commit();
+#if defined(MK_ABLATE) && MK_ABLATE == 7
+      mk_wave_lds_fence(); commit(); /* marginal cost of one more LDS commit */
+#endif
       mk_wave_lds_fence();
       if (++nt_cb == a.ncb) { nt_cb = 0; nt_tile += nwaves; }
       if (nt_tile < ntiles) issue_loads(nt_tile, nt_cb);
+#if defined(MK_ABLATE) && MK_ABLATE == 8
+      __builtin_amdgcn_sched_barrier(0);
+      if (nt_tile < ntiles) issue_loads(nt_tile, nt_cb); /* marginal cost of one more set of global loads */
+#endif
+#if defined(MK_ABLATE) && (MK_ABLATE == 2 || MK_ABLATE == 4)
+      }
+#endif
       if (__all(done)) continue;
 
       const uint32_t col0 = cb * a.CB;
@@ -429,12 +442,13 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
             quad qa, qb;
             auto probe = [&](uint32_t code, uint64_t &u, uint32_t &m, uint32_t &wd) {
               km.roll(code, a.kp);
-              const uint64_t f = ((uint64_t)km.fhi << 32) | km.flo, r = ((uint64_t)km.rhi << 32) | km.rlo;
-              const bool lt = f < r;
-              const uint32_t ulo = lt ? km.flo : km.rlo, uhi = lt ? km.fhi : km.rhi;
-              u = ((uint64_t)uhi << 32) | ulo;
-              const uint32_t xx = __builtin_amdgcn_alignbit(uhi, ulo, OUT2);
+              u = km.fwd();
+              const uint32_t xx = __builtin_amdgcn_alignbit(km.fhi, km.flo, OUT2);
+#if defined(MK_ABLATE) && (MK_ABLATE == 1 || MK_ABLATE == 4)
+              wd = xx; /* ablation: no LDS probe */
+#else
               wd = *(mk_lds_cu32)(uintptr_t)((xx >> 8) & 0xFFFCu);
+#endif
               m = mk_filter_mask(xx);
             };
             probe(c0 & 3u, qa.u0, qa.m0, qa.w0);
@@ -448,9 +462,13 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
             __builtin_amdgcn_sched_barrier(0); /* keep all eight probes in flight before the first result is read */
             const uint32_t ta = min(min(qa.m0 & ~qa.w0, qa.m1 & ~qa.w1), min(qa.m2 & ~qa.w2, qa.m3 & ~qa.w3));
             const uint32_t tb = min(min(qb.m0 & ~qb.w0, qb.m1 & ~qb.w1), min(qb.m2 & ~qb.w2, qb.m3 & ~qb.w3));
+#if defined(MK_ABLATE) && MK_ABLATE == 3
+            if (__any(min(ta, tb) == 0xffffffffu)) { /* ablation: never enter the hit path */
+#else
             if (__any(min(ta, tb) == 0u)) { /* rare: a filter hit among the 8 x 64 probes */
-              resolve4(qa, pos0);
-              resolve4(qb, pos0 + 4u);
+#endif
+              hits4(qa, pos0);
+              hits4(qb, pos0 + 4u);
             }
           } else {
             slow_dword(w0, c0, x0, pos0);
