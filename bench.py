@@ -195,6 +195,7 @@ def main():
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms,
                          "launches": prof["scan_launches"]},
             "phases_ms_per_step": {"clear": prof["clear_ms"] / args.steps, "scan": prof["scan_ms"] / args.steps,
+                                   "resolve": prof["resolve_ms"] / args.steps,
                                    "finish": prof["finish_ms"] / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:

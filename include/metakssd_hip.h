@@ -108,6 +108,7 @@ typedef struct mk_result {
 typedef struct mk_profile {
   double scan_ms;        /* sum over scan-kernel launches since mk_profile_reset */
   uint64_t scan_launches;
+  double resolve_ms;     /* candidate resolution launches (canonical k-mer, exact .shuf check, upsert) */
   double clear_ms;       /* table clear in mk_sketch_begin */
   double finish_ms;      /* compaction + priority layout + ordered dump (device part of finish) */
   uint64_t bases_scanned; /* sum of nreads*stride handed to scan launches (row bytes, not bases) */

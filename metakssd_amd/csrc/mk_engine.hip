@@ -31,6 +31,10 @@ struct mk_engine {
   uint32_t *d_accept = nullptr;
   uint32_t n_accept = 0;
   uint32_t bm_bits = 0;
+  /* candidate append buffers: one slot per scan wave */
+  unsigned long long *d_cand_fwd = nullptr, *d_cand_ord = nullptr;
+  uint32_t *d_cand_count = nullptr;
+  uint32_t cand_slots = 0, cand_cap = 0;
 
   void *d_tab = nullptr; /* key[S] | ordinv[S] | cnt[S] */
   size_t tab_bytes = 0;
@@ -60,11 +64,11 @@ struct mk_engine {
   uint64_t D = 0;
 
   /* launch tuning (overridable through MK_SCAN_THREADS / MK_SCAN_CB for experiments) */
-  int tune_threads = 512;
+  int tune_threads = 1024;
   uint32_t tune_cb = MK_MAX_CB;
 
   bool profiling = false;
-  std::vector<mk_evpair> ev_scan, ev_clear, ev_finish, ev_pool;
+  std::vector<mk_evpair> ev_scan, ev_resolve, ev_clear, ev_finish, ev_pool;
   uint64_t prof_rows = 0, prof_bytes = 0;
 };
 
@@ -116,6 +120,7 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   if (!e) return MK_ERR_ARG;
   hipSetDevice(e->device);
   hipDeviceSynchronize();
+  hipFree(e->d_cand_fwd); hipFree(e->d_cand_ord); hipFree(e->d_cand_count);
   hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_tab); hipFree(e->d_slot);
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   hipFree(e->d_chunk); hipFree(e->d_counters); hipFree(e->d_out_ids); hipFree(e->d_out_cnt);
@@ -127,7 +132,7 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
     if (e->ev_copied[i]) hipEventDestroy(e->ev_copied[i]);
     if (e->ev_scanned[i]) hipEventDestroy(e->ev_scanned[i]);
   }
-  for (auto *v : {&e->ev_scan, &e->ev_clear, &e->ev_finish, &e->ev_pool})
+  for (auto *v : {&e->ev_scan, &e->ev_resolve, &e->ev_clear, &e->ev_finish, &e->ev_pool})
     for (auto &p : *v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   if (e->own_stream) hipStreamDestroy(e->own_stream);
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
@@ -203,7 +208,14 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   MK_HIP(e, hipHostMalloc((void **)&e->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   e->tab.err = (uint32_t *)(e->d_counters + 2);
   e->comps.resize((size_t)p->component_num);
-  if (const char *t = getenv("MK_SCAN_THREADS")) { int v = atoi(t); if (v == 256 || v == 512 || v == 768 || v == 1024) e->tune_threads = v; }
+  e->cand_slots = (uint32_t)e->num_cu * 16u; /* at most 16 waves per workgroup, one workgroup per CU */
+  e->cand_cap = 8192u;
+  if (const char *t = getenv("MK_CAND_CAP")) { int v = atoi(t); if (v >= 0) e->cand_cap = (uint32_t)v; }
+  MK_HIP(e, hipMalloc(&e->d_cand_fwd, (size_t)e->cand_slots * (e->cand_cap + 1) * 8));
+  MK_HIP(e, hipMalloc(&e->d_cand_ord, (size_t)e->cand_slots * (e->cand_cap + 1) * 8));
+  MK_HIP(e, hipMalloc(&e->d_cand_count, (size_t)e->cand_slots * sizeof(uint32_t)));
+  MK_HIP(e, hipMemset(e->d_cand_count, 0, (size_t)e->cand_slots * sizeof(uint32_t)));
+  if (const char *t = getenv("MK_SCAN_THREADS")) { int v = atoi(t); if (v == 512 || v == 768 || v == 1024) e->tune_threads = v; }
   if (const char *t = getenv("MK_SCAN_CB")) { int v = atoi(t); if (v >= 16 && v <= MK_MAX_CB && v % 16 == 0) e->tune_cb = (uint32_t)v; }
   return MK_OK;
 }
@@ -250,7 +262,7 @@ extern "C" int mk_profile_reset(mk_engine *e) {
   if (!e) return MK_ERR_ARG;
   MK_HIP(e, hipSetDevice(e->device));
   MK_HIP(e, hipStreamSynchronize(e->stream));
-  for (auto *v : {&e->ev_scan, &e->ev_clear, &e->ev_finish}) {
+  for (auto *v : {&e->ev_scan, &e->ev_resolve, &e->ev_clear, &e->ev_finish}) {
     for (auto &p : *v) e->ev_pool.push_back(p);
     v->clear();
   }
@@ -270,6 +282,7 @@ extern "C" int mk_profile_get(mk_engine *e, mk_profile *out) {
   };
   out->scan_ms = sum(e->ev_scan);
   out->scan_launches = e->ev_scan.size();
+  out->resolve_ms = sum(e->ev_resolve);
   out->clear_ms = sum(e->ev_clear);
   out->finish_ms = sum(e->ev_finish);
   out->rows_scanned = e->prof_rows;
@@ -294,24 +307,27 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
 }
 
 /* ---- scan launch -------------------------------------------------------------------------------------- */
-template <int K, bool V, int T>
+template <int K, bool V, int T, int NP>
 static hipError_t mk_launch_scan_t(const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t r = hipFuncSetAttribute((const void *)mk_scan_kernel<K, V, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t r = hipFuncSetAttribute((const void *)mk_scan_kernel<K, V, T, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (r != hipSuccess) return r;
     configured = lds;
   }
-  hipLaunchKernelGGL((mk_scan_kernel<K, V, T>), grid, dim3(T), lds, s, a);
+  hipLaunchKernelGGL((mk_scan_kernel<K, V, T, NP>), grid, dim3(T), lds, s, a);
   return hipGetLastError();
 }
 template <int K, bool V>
 static hipError_t mk_launch_scan_k(int threads, const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
+  /* piece registers: 16-byte path CB <= 80 -> 5 pieces, CB <= 128 -> 8; 4-byte path up to 32 */
+  constexpr int NPBIG = V ? MK_MAX_PIECES : MK_MAX_CB / 4;
+  constexpr int NPSMALL = V ? 5 : 20;
+  const bool small = a.ppr <= (uint32_t)NPSMALL;
   switch (threads) {
-    case 1024: return mk_launch_scan_t<K, V, 1024>(a, grid, lds, s);
-    case 768: return mk_launch_scan_t<K, V, 768>(a, grid, lds, s);
-    case 512: return mk_launch_scan_t<K, V, 512>(a, grid, lds, s);
-    default: return mk_launch_scan_t<K, V, 256>(a, grid, lds, s);
+    case 1024: return small ? mk_launch_scan_t<K, V, 1024, NPSMALL>(a, grid, lds, s) : mk_launch_scan_t<K, V, 1024, NPBIG>(a, grid, lds, s);
+    case 768: return small ? mk_launch_scan_t<K, V, 768, NPSMALL>(a, grid, lds, s) : mk_launch_scan_t<K, V, 768, NPBIG>(a, grid, lds, s);
+    default: return small ? mk_launch_scan_t<K, V, 512, NPSMALL>(a, grid, lds, s) : mk_launch_scan_t<K, V, 512, NPBIG>(a, grid, lds, s);
   }
 }
 
@@ -330,19 +346,20 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   a.ppr = a.CB / g;
   a.ppr_inv = (1u << 20) / a.ppr + 1u;
   a.rowdw = (a.CB / 4u) | 1u;
-  a.wave_lds_dwords = ((64u * a.rowdw + 1u) & ~1u) + 4u * MK_QCAP; /* queue follows the tile: 2+ dwords of read slack */
+  a.wave_lds_dwords = ((64u * a.rowdw + 1u) & ~1u) + 2u; /* +2: the unconditional word prefetch reads up to 2 dwords past a row */
   a.bm_words = 1u << e->bm_bits;
   a.dimmask = (uint32_t)((1ull << (4 * e->P.subk)) - 1ull);
   a.accept = e->d_accept; a.n_accept = e->n_accept;
   a.shuf = e->d_shuf;
   a.kp = e->kp;
   a.tab = e->tab;
+  a.cand_fwd = e->d_cand_fwd; a.cand_ord = e->d_cand_ord; a.cand_count = e->d_cand_count; a.cand_cap = e->cand_cap;
   /* workgroup size: as many waves as the LDS budget (filter + per-wave tile and queue) admits */
   int threads = e->tune_threads;
   size_t lds = 0;
   for (;; threads -= 256) {
     lds = ((size_t)a.bm_words + (size_t)(threads / 64) * a.wave_lds_dwords) * 4u;
-    if (lds <= 160u * 1024u || threads <= 256) break;
+    if (lds <= 160u * 1024u || threads <= 512) break;
   }
   if (lds > 160u * 1024u) return mk_fail(e, MK_ERR_ARG, "scan: LDS budget exceeded (%zu bytes)", lds);
   const uint32_t waves = (uint32_t)threads / 64u;
@@ -350,6 +367,11 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   uint64_t blocks = (ntiles + waves - 1) / waves;
   if (blocks > (uint64_t)e->num_cu) blocks = (uint64_t)e->num_cu;
   dim3 grid((unsigned)blocks);
+  if (getenv("MK_DEBUG")) {
+    static int once = 0;
+    if (!once++) fprintf(stderr, "scan cfg: threads %d blocks %llu CB %u ncb %u rowdw %u lds %zu B\n", threads,
+                         (unsigned long long)blocks, a.CB, a.ncb, a.rowdw, lds);
+  }
 
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
@@ -365,6 +387,15 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
     e->ev_scan.push_back(ev);
     e->prof_rows += nreads;
     e->prof_bytes += nreads * stride;
+  }
+  /* resolve the appended candidates: canonical k-mer, exact .shuf check, upsert */
+  {
+    const uint32_t used_slots = (uint32_t)blocks * waves;
+    mk_evpair ev2{};
+    if (e->profiling) { ev2 = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev2.a, e->stream)); }
+    hipLaunchKernelGGL(mk_resolve_kernel, dim3(used_slots), dim3(256), 0, e->stream, a, used_slots);
+    MK_HIP(e, hipGetLastError());
+    if (e->profiling) { MK_HIP(e, hipEventRecord(ev2.b, e->stream)); e->ev_resolve.push_back(ev2); }
   }
   e->compacted = false;
   return MK_OK;

@@ -22,7 +22,6 @@
 #include "host/mk_host_internal.h"
 
 #define MK_WAVE 64
-#define MK_QCAP 128                    /* candidate queue entries per wave (64 pending + one full push) */
 #define MK_MAX_CB 128                  /* widest column block staged per step, bytes */
 #define MK_MAX_PIECES 8                /* 16-byte pieces per lane per step = MK_MAX_CB/16 */
 #define MK_EMPTY32 0xFFFFFFFFu
@@ -58,6 +57,11 @@ struct mk_scan_args {
   const int32_t *shuf;
   mk_keyparams kp;
   mk_table tab;
+  /* filter hits ("candidates") leave the scan kernel through per-wave append buffers in HBM */
+  unsigned long long *cand_fwd; /* [nslots][cand_cap] forward k-mers */
+  unsigned long long *cand_ord; /* [nslots][cand_cap] ordinals */
+  uint32_t *cand_count;         /* [nslots] */
+  uint32_t cand_cap;
 };
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -121,25 +125,33 @@ __device__ __forceinline__ uint64_t mk_revcomp(uint64_t f, uint32_t TL) {
   return n >> (64u - 2u * TL);
 }
 
-/* exact accept test + upsert for up to 64 queued candidates (one per lane).  A candidate is the FORWARD
- * k-mer whose inner substring passed the strand-symmetric LDS filter; here the canonical k-mer
- * (iseq2comem.c:691) is formed and looked up in the .shuf table (:692-695).  Kept out of line: it is rare
- * and bulky (two 64-bit modulo reductions); it reads the kernel's argument block through the kernarg
- * segment pointer (taken in the kernel, where the builtin is valid), so calling it does not force the hot
- * loop's parameters out of scalar registers into scratch. */
-__device__ __noinline__ void mk_drain(const mk_scan_args *ka, const uint64_t *q_fwd, const uint64_t *q_ord, uint32_t n,
-                                      uint32_t lane) {
-  const mk_scan_args &a = *ka;
-  if (lane < n) {
-    const uint64_t fwd = q_fwd[lane], ord = q_ord[lane];
-    const uint64_t rc = mk_revcomp(fwd, a.kp.TL);
-    const uint64_t uni = fwd < rc ? fwd : rc;
-    uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
-    int32_t pf = a.shuf[dim]; /* iseq2comem.c:693 */
-    if (pf >= a.kp.dim_start && pf < a.kp.dim_end) {
-      uint64_t key = mk_reduce_key(a.kp, uni, (uint64_t)(pf - a.kp.dim_start));
-      mk_upsert(a.tab, a.kp.S, key, ord, 1u);
-    }
+/* One candidate = the FORWARD k-mer whose inner substring passed the strand-symmetric LDS filter.  Form the
+ * canonical k-mer (iseq2comem.c:691), look it up in the .shuf table (:692-695), reduce to the key (:696-699)
+ * and upsert. */
+__device__ __forceinline__ void mk_resolve_one(const mk_scan_args &a, uint64_t fwd, uint64_t ord) {
+  const uint64_t rc = mk_revcomp(fwd, a.kp.TL);
+  const uint64_t uni = fwd < rc ? fwd : rc;
+  const uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
+  const int32_t pf = a.shuf[dim];
+  if (pf >= a.kp.dim_start && pf < a.kp.dim_end) {
+    const uint64_t key = mk_reduce_key(a.kp, uni, (uint64_t)(pf - a.kp.dim_start));
+    mk_upsert(a.tab, a.kp.S, key, ord, 1u);
+  }
+}
+
+/* overflow path of the scan kernel (a wave's append buffer is full: dense accept-everything tables): resolve
+ * this base's hits on the spot.  Out of line; reads the argument block through the kernarg pointer so that
+ * the call does not push the hot loop's parameters into scratch. */
+__device__ __noinline__ void mk_resolve_inline(const mk_scan_args *ka, bool hit, uint64_t fwd, uint64_t ord) {
+  if (hit) mk_resolve_one(*ka, fwd, ord);
+}
+
+/* resolves the candidates the scan kernel appended: one workgroup per producer wave slot */
+__global__ void __launch_bounds__(256) mk_resolve_kernel(const mk_scan_args a, uint32_t nslots) {
+  for (uint32_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+    const uint32_t n = a.cand_count[slot];
+    const unsigned long long *f = a.cand_fwd + (size_t)slot * a.cand_cap, *o = a.cand_ord + (size_t)slot * a.cand_cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mk_resolve_one(a, f[i], o[i]);
   }
 }
 
@@ -195,15 +207,13 @@ __device__ __forceinline__ uint32_t mk_nonzero_bytes(uint32_t v) { /* bit 7 of b
   return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
 }
 
-template <int K, bool VEC16, int THREADS>
+template <int K, bool VEC16, int THREADS, int NPIECES>
 __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) {
   extern __shared__ __align__(16) uint32_t lds[];
   constexpr uint32_t WAVES = THREADS / 64;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t *bitmap = lds;
   uint32_t *tile = lds + a.bm_words + wave * a.wave_lds_dwords;
-  uint64_t *q_uni = (uint64_t *)(tile + ((64u * a.rowdw + 1u) & ~1u));
-  uint64_t *q_ord = q_uni + MK_QCAP;
 
   for (uint32_t i = threadIdx.x; i < a.bm_words; i += blockDim.x) bitmap[i] = 0u;
   __syncthreads();
@@ -226,14 +236,19 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   const uint64_t ntiles = (a.nreads + 63u) >> 6;
   const uint64_t wave_global = (uint64_t)blockIdx.x * WAVES + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * WAVES;
-  if (wave_global >= ntiles) return;
+  unsigned long long *const my_fwd = a.cand_fwd + (size_t)wave_global * a.cand_cap;
+  unsigned long long *const my_ord = a.cand_ord + (size_t)wave_global * a.cand_cap;
+  if (wave_global >= ntiles) {
+    if (lane == 0) a.cand_count[wave_global] = 0u;
+    return;
+  }
 
   /* ---- staging: global -> registers (one step ahead) -> LDS tile ------------------------------------------
    * A step is one column block (CB bytes) of one tile (64 rows).  Piece i of this lane is row r_i, 16-byte
    * (or 4-byte) column c_i of the block: both are the same for every step, so the global byte offset and
    * the LDS dword index are computed once. */
   using piece_t = typename std::conditional<VEC16, uint4, uint32_t>::type;
-  constexpr int NP = VEC16 ? MK_MAX_PIECES : MK_MAX_CB / 4;
+  constexpr int NP = NPIECES; /* pieces per lane per step: >= a.ppr (host picks the smallest instantiation) */
   constexpr uint32_t PW = VEC16 ? 16u : 4u;
   piece_t regs[NP];
   uint32_t goff[NP], loff[NP];
@@ -295,22 +310,22 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     word = *(mk_lds_cu32)(uintptr_t)(((xx >> 8) & wmask4) + filter_base);
     mask = mk_filter_mask(xx);
   };
-  /* queue the lanes flagged in `hit` (forward k-mer `uni` ending at row position `pos`) */
-  auto push = [&](bool hit, uint64_t uni, uint32_t pos) {
+  /* append the lanes flagged in `hit` (forward k-mer `fwd` ending at row position `pos`) to this wave's
+   * candidate buffer: plain stores, nothing to wait for */
+  auto push = [&](bool hit, uint64_t fwd, uint32_t pos) {
     const uint64_t m = __ballot(hit);
     if (m == 0) return;
-    const uint32_t off = qn + mk_mbcnt(m);
-    if (hit) { q_uni[off] = uni; q_ord[off] = ord_row | (uint64_t)pos; }
-    qn = __builtin_amdgcn_readfirstlane(qn + (uint32_t)__popcll(m));
-    if (qn >= 64u) {
-      mk_wave_lds_fence();
-      mk_drain(ka, q_uni, q_ord, 64u, lane);
-      const uint64_t tu = q_uni[64u + lane], to = q_ord[64u + lane];
-      mk_wave_lds_fence();
-      q_uni[lane] = tu; q_ord[lane] = to;
-      mk_wave_lds_fence();
-      qn -= 64u;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    if (qn + cnt > a.cand_cap) { /* buffer full (dense tables only): resolve right here */
+      mk_resolve_inline(ka, hit, fwd, ord_row | (uint64_t)pos);
+      return;
     }
+    if (hit) {
+      const uint32_t off = qn + mk_mbcnt(m);
+      my_fwd[off] = fwd;
+      my_ord[off] = ord_row | (uint64_t)pos;
+    }
+    qn = __builtin_amdgcn_readfirstlane(qn + cnt);
   };
   /* four valid bases, every lane with a full window: roll, canonical k-mer, filter probe */
   auto fast4 = [&](uint32_t codes, quad &q) {
@@ -460,15 +475,25 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
             probe(__builtin_amdgcn_ubfe(c1, 16, 2), qb.u2, qb.m2, qb.w2);
             probe(c1 >> 24, qb.u3, qb.m3, qb.w3);
             __builtin_amdgcn_sched_barrier(0); /* keep all eight probes in flight before the first result is read */
-            const uint32_t ta = min(min(qa.m0 & ~qa.w0, qa.m1 & ~qa.w1), min(qa.m2 & ~qa.w2, qa.m3 & ~qa.w3));
-            const uint32_t tb = min(min(qb.m0 & ~qb.w0, qb.m1 & ~qb.w1), min(qb.m2 & ~qb.w2, qb.m3 & ~qb.w3));
+            /* t == 0 <=> both filter bits set.  Binary descent over the min tree: a pair without hits costs one
+             * test, a single hit costs about six. */
+            const uint32_t a0 = qa.m0 & ~qa.w0, a1 = qa.m1 & ~qa.w1, a2 = qa.m2 & ~qa.w2, a3 = qa.m3 & ~qa.w3;
+            const uint32_t b0 = qb.m0 & ~qb.w0, b1 = qb.m1 & ~qb.w1, b2 = qb.m2 & ~qb.w2, b3 = qb.m3 & ~qb.w3;
+            const uint32_t a01 = min(a0, a1), a23 = min(a2, a3), b01 = min(b0, b1), b23 = min(b2, b3);
+            const uint32_t ta = min(a01, a23), tb = min(b01, b23);
 #if defined(MK_ABLATE) && MK_ABLATE == 3
             if (__any(min(ta, tb) == 0xffffffffu)) { /* ablation: never enter the hit path */
 #else
-            if (__any(min(ta, tb) == 0u)) { /* rare: a filter hit among the 8 x 64 probes */
+            if (__any(min(ta, tb) == 0u)) {
 #endif
-              hits4(qa, pos0);
-              hits4(qb, pos0 + 4u);
+              if (__any(ta == 0u)) {
+                if (__any(a01 == 0u)) { push(a0 == 0u, qa.u0, pos0); push(a1 == 0u, qa.u1, pos0 + 1u); }
+                if (__any(a23 == 0u)) { push(a2 == 0u, qa.u2, pos0 + 2u); push(a3 == 0u, qa.u3, pos0 + 3u); }
+              }
+              if (__any(tb == 0u)) {
+                if (__any(b01 == 0u)) { push(b0 == 0u, qb.u0, pos0 + 4u); push(b1 == 0u, qb.u1, pos0 + 5u); }
+                if (__any(b23 == 0u)) { push(b2 == 0u, qb.u2, pos0 + 6u); push(b3 == 0u, qb.u3, pos0 + 7u); }
+              }
             }
           } else {
             slow_dword(w0, c0, x0, pos0);
@@ -515,10 +540,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
       }
     }
   }
-  if (qn) {
-    mk_wave_lds_fence();
-    mk_drain(ka, q_uni, q_ord, qn, lane);
-  }
+  if (lane == 0) a.cand_count[wave_global] = qn;
 }
 
 /* ---- multi-GPU: fold an exported shard into this table -------------------------------------------- */

@@ -243,3 +243,34 @@ def test_device_resident_push_and_device_synth(capi, engine_for, shufs, oracle_f
     rc, want = oracle_for(shufs("L1K7")).koc_from_rows(host, stride)
     assert rc == 0
     assert_same(got, want)
+
+
+def test_candidate_buffer_overflow_path(capi, shufs, oracle_for, monkeypatch):
+    """a wave whose candidate append buffer is full resolves hits inline: force it with a zero-capacity buffer"""
+    monkeypatch.setenv("MK_CAND_CAP", "0")
+    eng = capi.Engine(shufs("L0K6"), 0)
+    monkeypatch.delenv("MK_CAND_CAP")
+    try:
+        rs = np.random.RandomState(12)
+        rows = ui.rows_from_seqs(ui.pool_reads(rs, 20000, 3000), 160)
+        got = run_koc(capi, eng, rows, 160)
+    finally:
+        eng.close()
+    rc, want = oracle_for(shufs("L0K6")).koc_from_rows(rows, 160)
+    assert rc == 0
+    assert_same(got, want)
+
+
+def test_candidate_buffer_partial_overflow(capi, shufs, oracle_for, monkeypatch):
+    """small buffer: some candidates go through the append buffer, the rest through the inline path"""
+    monkeypatch.setenv("MK_CAND_CAP", "100")
+    eng = capi.Engine(shufs("L0K6"), 0)
+    monkeypatch.delenv("MK_CAND_CAP")
+    try:
+        rows = capi.synth_rows_host(8, 0, 500, 150, 160)
+        got = run_koc(capi, eng, rows, 160)
+    finally:
+        eng.close()
+    rc, want = oracle_for(shufs("L0K6")).koc_from_rows(rows, 160)
+    assert rc == 0
+    assert_same(got, want)
