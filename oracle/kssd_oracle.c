@@ -184,6 +184,91 @@ int ko_koc_from_rows_omp(const ko_params *P, const int *shuf, const unsigned cha
   return KO_OK;
 }
 
+/* ---- shard-merge model (see kssd_oracle.h) ---- */
+int ko_partial_from_rows(const ko_params *P, const int *shuf, const unsigned char *rows, size_t stride, size_t nreads,
+                         ko_llong first_read_ordinal, ko_llong *keys, unsigned int *counts, ko_llong *ords, size_t cap,
+                         size_t *n_out) {
+  ko_llong S = P->hashsize;
+  ko_llong *co = calloc((size_t)S, sizeof(ko_llong));  /* key+1 */
+  ko_llong *cnt = calloc((size_t)S, sizeof(ko_llong));
+  ko_llong *first = calloc((size_t)S, sizeof(ko_llong));
+  if (!co || !cnt || !first) { free(co); free(cnt); free(first); return KO_ERR_IO; }
+  for (size_t t = 0; t < nreads; t++) {
+    const unsigned char *row = rows + t * stride;
+    int base = 1;
+    ko_llong tuple = 0, crvs = 0;
+    for (size_t pos = 0; pos < stride && row[pos] != '\n'; pos++) {
+      int b = ko_code(row[pos]);
+      if (b < 0) { base = 1; continue; }
+      tuple = ((tuple << 2) | (ko_llong)b) & P->tupmask;
+      crvs = (crvs >> 2) + (((ko_llong)b ^ 3ULL) << P->crvsaddmove);
+      base++;
+      if (base <= P->TL) continue;
+      ko_llong key;
+      if (!ko_reduce(P, shuf, tuple, crvs, &key)) continue;
+      for (ko_llong i = 0; i < S; i++) {
+        ko_llong n = ko_probe(key, i, S);
+        if (co[n] == 0) { co[n] = key + 1; cnt[n] = 1; first[n] = ((first_read_ordinal + t) << 12) | pos; break; }
+        if (co[n] == key + 1) { cnt[n]++; break; }
+      }
+    }
+  }
+  size_t n = 0;
+  int rc = KO_OK;
+  for (ko_llong s = 0; s < S; s++) {
+    if (!co[s]) continue;
+    if (n == cap) { rc = KO_ERR_ARG; break; }
+    keys[n] = co[s] - 1;
+    counts[n] = cnt[s] > 65535 ? 65535u : (unsigned int)cnt[s];
+    ords[n] = first[s];
+    n++;
+  }
+  *n_out = n;
+  free(co); free(cnt); free(first);
+  return rc;
+}
+
+typedef struct { ko_llong key, ord, cnt; } ko_rec;
+static int ko_cmp_key(const void *a, const void *b) {
+  const ko_rec *x = a, *y = b;
+  return x->key < y->key ? -1 : x->key > y->key ? 1 : x->ord < y->ord ? -1 : x->ord > y->ord;
+}
+static int ko_cmp_ord(const void *a, const void *b) {
+  const ko_rec *x = a, *y = b;
+  return x->ord < y->ord ? -1 : x->ord > y->ord;
+}
+int ko_layout_from_partials(const ko_params *P, int nparts, const ko_llong *const *keys, const unsigned int *const *counts,
+                            const ko_llong *const *ords, const size_t *n, ko_llong *co) {
+  size_t total = 0;
+  for (int p = 0; p < nparts; p++) total += n[p];
+  ko_rec *r = malloc((total + 1) * sizeof(ko_rec));
+  size_t m = 0;
+  for (int p = 0; p < nparts; p++)
+    for (size_t i = 0; i < n[p]; i++) { r[m].key = keys[p][i]; r[m].ord = ords[p][i]; r[m].cnt = counts[p][i]; m++; }
+  qsort(r, m, sizeof(ko_rec), ko_cmp_key);
+  size_t d = 0;
+  for (size_t i = 0; i < m; i++) { /* same key: counts add, first ordinal = min (sorted: the first one) */
+    if (d && r[d - 1].key == r[i].key) r[d - 1].cnt += r[i].cnt;
+    else r[d++] = r[i];
+  }
+  qsort(r, d, sizeof(ko_rec), ko_cmp_ord);
+  memset(co, 0, (size_t)P->hashsize * sizeof(ko_llong));
+  unsigned int keycount = 0;
+  int rc = KO_OK;
+  for (size_t i = 0; i < d && rc == KO_OK; i++) {
+    rc = ko_insert_koc(P, co, r[i].key, &keycount); /* first sighting: slot = (key<<16)+1 */
+    if (rc == KO_OK) {
+      ko_llong c = r[i].cnt > 65535 ? 65535 : r[i].cnt;
+      for (ko_llong j = 0; j < P->hashsize; j++) { /* set the merged, clamped count on the slot just taken */
+        ko_llong s = ko_probe(r[i].key, j, P->hashsize);
+        if ((co[s] >> KO_OCCRC_BIT) == r[i].key && co[s] != 0) { co[s] = (r[i].key << KO_OCCRC_BIT) + c; break; }
+      }
+    }
+  }
+  free(r);
+  return rc;
+}
+
 /* ---- fgets() over a memory stream, including the EOF indicator feof() reports ---- */
 typedef struct { const unsigned char *p, *end; int eof; } ko_ms;
 static unsigned char *ko_ms_gets(ko_ms *s, unsigned char *buf, int size) {

@@ -61,6 +61,18 @@ int ko_co_from_fasta_bytes(const ko_params *P, const int *shuf, const unsigned c
 /* wrt_co2cmpn_use_inn_subctx() (iseq2comem.c:625-652) into memory; same two-call protocol. */
 unsigned int ko_dump_co(const ko_params *P, const ko_llong *co, uint32_t **ids, size_t *n_out);
 
+/* ---- model of the multi-GPU shard merge (no reference counterpart: it is single-process) ----
+ * ko_partial_from_rows: the distinct keys of one contiguous read range as {key, min(count,65535), ordinal of the
+ *   first occurrence}, ordinal = (first_read_ordinal + row) << 12 | position of the k-mer's last base.
+ * ko_layout_from_partials: merges such lists (counts add then clamp, first ordinals take min) and inserts the keys
+ *   into co[] in first-ordinal order with the reference's insert (iseq2comem.c:701-718).  The claim the tests
+ *   check: this equals ko_koc_from_rows over the whole input, i.e. sharding does not change a byte. */
+int ko_partial_from_rows(const ko_params *P, const int *shuf, const unsigned char *rows, size_t stride, size_t nreads,
+                         ko_llong first_read_ordinal, ko_llong *keys, unsigned int *counts, ko_llong *ords, size_t cap,
+                         size_t *n_out);
+int ko_layout_from_partials(const ko_params *P, int nparts, const ko_llong *const *keys, const unsigned int *const *counts,
+                            const ko_llong *const *ords, const size_t *n, ko_llong *co);
+
 /* read_dim_shuffle_file() (command_shuffle.c:215-235) */
 int ko_shuf_read(const char *path, int header[4], int **table_out, size_t *len_out);
 

@@ -1,0 +1,65 @@
+"""worker for tests/test_dist_gloo.py: one rank of the sharded sketch over gloo (CPU tensors).
+
+Each rank sketches its contiguous read range with GLOBAL ordinals (here with the oracle's shard model, because the
+product's scan needs a GPU), the product's gather_partials() moves the lists to rank 0, rank 0 merges and lays out.
+Checked: (1) shard ranges tile the input, (2) the exchange delivers every list intact, (3) merged == sequential."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from metakssd_amd import capi
+    from metakssd_amd.shard import gather_partials, shard_range
+    from oracle_binding import Oracle
+    import util_inputs as ui
+
+    shuf = capi.Shuf.generate(6, 3, 0, 6)  # accept-everything table: the merge has real collisions to resolve
+    rs = np.random.RandomState(17)
+    seqs = ui.pool_reads(rs, 6000, 1201)   # odd count: uneven shards
+    rows = ui.rows_from_seqs(seqs, 160)
+    total = len(seqs)
+    lo, hi = shard_range(total, rank, world)
+    ranges = [shard_range(total, r, world) for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == total and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+
+    ora = Oracle(shuf.c.id, 6, 3, 0, shuf.table)
+    keys, cnts, ords = ora.partial_from_rows(rows[lo * 160:hi * 160], 160, lo)
+    tk = torch.from_numpy(keys.view(np.int64).copy())
+    tc = torch.from_numpy(cnts.view(np.int32).copy())
+    to = torch.from_numpy(ords.view(np.int64).copy())
+    got = gather_partials(tk, tc, to, len(keys), dst=0)
+    ok = True
+    if rank == 0:
+        parts = [(keys, cnts, ords)]
+        for (k, c, o) in got:
+            parts.append((k.numpy().view(np.uint64), c.numpy().view(np.uint32), o.numpy().view(np.uint64)))
+        assert len(parts) == world
+        # every received list must equal what that rank computed (recompute here)
+        for r in range(1, world):
+            rlo, rhi = ranges[r]
+            ek, ec, eo = Oracle(shuf.c.id, 6, 3, 0, shuf.table).partial_from_rows(rows[rlo * 160:rhi * 160], 160, rlo)
+            pk, pc, po = parts[r]
+            ok &= np.array_equal(pk, ek) and np.array_equal(pc, ec) and np.array_equal(po, eo)
+        merged = ora.layout_from_partials(parts)
+        rc, want = Oracle(shuf.c.id, 6, 3, 0, shuf.table).koc_from_rows(rows, 160)
+        ok &= rc == 0 and np.array_equal(merged[0][0], want[0][0]) and np.array_equal(merged[0][1], want[0][1])
+        ok &= len(want[0][0]) > 1000
+        open(os.environ["MK_DIST_RESULT"], "w").write("OK %d" % len(want[0][0]) if ok else "MISMATCH")
+    else:
+        assert got == []
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""tests/golden/make_golden.py -- regenerates the golden vectors with the REAL reference.
+
+Runs only in the build container (needs oracle/_ref/metakssd, compiled from /root/reference by
+`make -C oracle ref`).  For every case it runs `metakssd dist -L <shuf> [-A] [-u] -p 1 -o out <input>` and stores
+the payload files (combco.N, combco.N.a, combco.index.N) plus the decoded cofiles.stat fields under
+tests/golden/expected/<case>/.  Inputs are either committed (tests/golden/inputs/*.gz, written here from seeded
+numpy streams) or regenerated from a formula recorded in the manifest.  .shuf tables come from the product's
+seeded generator; their sha256 is recorded so that a generator change cannot go unnoticed.
+
+Nothing here is copied reference source: the outputs are data produced by executing the reference.
+"""
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import struct
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import util_inputs as ui  # noqa: E402
+from golden_cases import CASES, SHUF_SPECS, build_input, make_shuf  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "metakssd")
+
+
+def parse_stat(path):
+    b = open(path, "rb").read()
+    shuf_id, koc = struct.unpack_from("<IB", b, 0)
+    kmerlen, dim_rd_len, comp_num, infile_num, all_ctx = struct.unpack_from("<iiiiQ", b, 8)
+    cts = list(struct.unpack_from("<%dI" % infile_num, b, 32))
+    return dict(shuf_id=shuf_id, koc=koc, kmerlen=kmerlen, dim_rd_len=dim_rd_len, comp_num=comp_num,
+                infile_num=infile_num, all_ctx_ct=all_ctx, ctx_ct=cts)
+
+
+def main():
+    if not os.path.exists(REF):
+        raise SystemExit("oracle/_ref/metakssd missing: run `make -C oracle ref`")
+    exp_root = os.path.join(HERE, "expected")
+    shutil.rmtree(exp_root, ignore_errors=True)
+    os.makedirs(exp_root)
+    os.makedirs(os.path.join(HERE, "inputs"), exist_ok=True)
+    work = tempfile.mkdtemp(prefix="golden_")
+    manifest = {"shufs": {}, "cases": {}}
+    shuf_paths = {}
+    for name in sorted({c["shuf"] for c in CASES.values()}):
+        p = os.path.join(work, name + ".shuf")
+        make_shuf(name, p)
+        shuf_paths[name] = p
+        manifest["shufs"][name] = {"spec": SHUF_SPECS.get(name), "sha256": hashlib.sha256(open(p, "rb").read()).hexdigest()}
+    for case, c in CASES.items():
+        inp = build_input(case, work, write_committed=True)
+        out = os.path.join(work, case + ".out")
+        cmd = [REF, "dist", "-L", shuf_paths[c["shuf"]]] + c["flags"] + ["-p", "1", "-o", out, inp]
+        r = subprocess.run(cmd, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        err = r.stderr.decode(errors="replace")
+        aborted = "too crowd" in err and not os.path.exists(os.path.join(out, "cofiles.stat"))
+        entry = {"shuf": c["shuf"], "flags": c["flags"], "input": c["input"], "aborted": aborted}
+        if not aborted:
+            if r.returncode != 0:
+                raise SystemExit("reference failed on %s: %s" % (case, err[-300:]))
+            d = os.path.join(exp_root, case)
+            os.makedirs(d)
+            for f in sorted(os.listdir(out)):
+                if f.startswith("combco"):
+                    shutil.copy(os.path.join(out, f), os.path.join(d, f))
+            entry["stat"] = parse_stat(os.path.join(out, "cofiles.stat"))
+            entry["files"] = {f: hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest() for f in sorted(os.listdir(d))}
+        manifest["cases"][case] = entry
+        print("%-28s %s" % (case, "ABORT (too crowd)" if aborted else "distinct=%d" % entry["stat"]["all_ctx_ct"]))
+    json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+    shutil.rmtree(work, ignore_errors=True)
+    tot = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(HERE) for f in fs)
+    print("golden dir: %.1f KiB" % (tot / 1024))
+
+
+if __name__ == "__main__":
+    main()

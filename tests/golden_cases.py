@@ -1,0 +1,132 @@
+"""the golden cases: which .shuf, which flags, which input.  Shared by tests/golden/make_golden.py (runs the real
+reference, in the build container only) and by the tests (oracle CLI on CPU, product CLI on the GPU)."""
+import gzip
+import os
+
+import numpy as np
+
+import util_inputs as ui
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# name -> (k, subk, drlevel, seed); same as tests/conftest.py
+SHUF_SPECS = {
+    "L3K11": (11, 6, 3, 11), "L3K10": (10, 6, 3, 10), "L2K11": (11, 5, 2, 211),
+    "L3K9": (9, 6, 3, 9), "L0K6": (6, 3, 0, 6), "L1K7": (7, 4, 1, 7),
+}
+
+
+def make_shuf(name, path):
+    """write the .shuf `name` with the product's seeded generator (L0K6z: L0K6 with substring 0 -> 0)"""
+    from metakssd_amd import capi
+    base = name[:-1] if name.endswith("z") else name
+    k, subk, drl, seed = SHUF_SPECS[base]
+    s = capi.Shuf.generate(k, subk, drl, seed)
+    if name.endswith("z"):
+        t = s.table
+        j = int(np.nonzero(t == 0)[0][0])
+        t[j], t[0] = t[0], 0
+    s.write(path)
+
+
+def _committed(name):
+    return os.path.join(GOLDEN, "inputs", name)
+
+
+def _seqs(kind):
+    rs = np.random.RandomState({"dense": 101, "pool": 102, "ragged": 103, "homo": 0}[kind])
+    if kind == "dense":
+        return [ui.rand_seq(rs, 150) for _ in range(150)]
+    if kind == "pool":
+        return ui.pool_reads(rs, 8000, 2000)
+    if kind == "ragged":
+        return ui.ragged_reads(rs, 500)
+    return [b"A" * 150, b"C" * 150, b"G" * 150, b"T" * 150, b"AC" * 75, b"ACGT" * 37] * 20
+
+
+def _genome():
+    rs = np.random.RandomState(104)
+    g = ui.rand_seq(rs, 30000)
+    return [g[:20000], g[5000:12000], b"A" * 100 + g[500:900] + b"T" * 50, g[20000:20021], b"", g[20021:]]
+
+
+CASES = {
+    # BASELINE.json config 1/2: 100 k synthetic 150 bp reads, L3K11 -A (input regenerated from the formula)
+    "syn100k_L3K11": {"shuf": "L3K11", "flags": ["-A"], "input": "synth:seed=1,first=0,n=100000,len=150"},
+    "syn20k_L3K9": {"shuf": "L3K9", "flags": ["-A"], "input": "synth:seed=2,first=0,n=20000,len=150"},
+    # accept-everything table (131 071 slots): collision order decides the bytes
+    "dense150_L0K6": {"shuf": "L0K6", "flags": ["-A"], "input": "fq:dense"},
+    "pool2000_L0K6": {"shuf": "L0K6", "flags": ["-A"], "input": "fq:pool"},
+    "pool2000_L1K7": {"shuf": "L1K7", "flags": ["-A"], "input": "fq:pool"},
+    "pool2000_L2K11": {"shuf": "L2K11", "flags": ["-A"], "input": "fq:pool"},  # 16 components
+    "ragged500_L0K6": {"shuf": "L0K6", "flags": ["-A"], "input": "fq:ragged"},
+    "ragged500_L1K7": {"shuf": "L1K7", "flags": ["-A"], "input": "fq:ragged"},
+    "ragged500_crlf_L1K7": {"shuf": "L1K7", "flags": ["-A"], "input": "fq:ragged:crlf"},
+    "ragged500_trunc_L1K7": {"shuf": "L1K7", "flags": ["-A"], "input": "fq:ragged:trunc"},
+    "ragged500_nonl_L1K7": {"shuf": "L1K7", "flags": ["-A"], "input": "fq:ragged:nonl"},
+    "ragged500_gz_L1K7": {"shuf": "L1K7", "flags": ["-A"], "input": "fq:ragged:gz"},
+    "key0_L0K6z": {"shuf": "L0K6z", "flags": ["-A"], "input": "fq:homo"},
+    "saturate_L0K6": {"shuf": "L0K6", "flags": ["-A"], "input": "repeat:seed=9,len=150,times=70000"},
+    "crowded_L0K6": {"shuf": "L0K6", "flags": ["-A"], "input": "synth:seed=5,first=0,n=5000,len=150"},  # reference aborts
+    # FASTA (config 5 family)
+    "fasta_L0K6": {"shuf": "L0K6", "flags": [], "input": "fa:genome"},
+    "fasta_uniq_L0K6": {"shuf": "L0K6", "flags": ["-u"], "input": "fa:genome"},
+    "fasta_L0K6z": {"shuf": "L0K6z", "flags": [], "input": "fa:genome"},
+    "fasta_L1K7": {"shuf": "L1K7", "flags": [], "input": "fa:genome"},
+    "fasta_uniq_L1K7": {"shuf": "L1K7", "flags": ["-u"], "input": "fa:genome"},
+    "fasta_L3K10": {"shuf": "L3K10", "flags": [], "input": "fa:genome"},
+    "fasta_L2K11": {"shuf": "L2K11", "flags": [], "input": "fa:genome"},
+    "fasta_uniq_L2K11": {"shuf": "L2K11", "flags": ["-u"], "input": "fa:genome"},
+}
+
+
+def build_input(case, workdir, write_committed=False):
+    """materialise the input file of `case` in workdir; returns its path.  Committed inputs live gzip'ed under
+    tests/golden/inputs (written only by make_golden.py)."""
+    from metakssd_amd import capi
+    spec = CASES[case]["input"]
+    kind, _, rest = spec.partition(":")
+    if kind == "synth":
+        kv = dict(x.split("=") for x in rest.split(","))
+        path = os.path.join(workdir, case + ".fq")
+        rc = capi.lib.mk_synth_fastq_write(path.encode(), int(kv["seed"]), int(kv["first"]), int(kv["n"]), int(kv["len"]))
+        assert rc == 0
+        return path
+    if kind == "repeat":
+        kv = dict(x.split("=") for x in rest.split(","))
+        rs = np.random.RandomState(int(kv["seed"]))
+        one = ui.rand_seq(rs, int(kv["len"]))
+        path = os.path.join(workdir, case + ".fq")
+        rec = b"@r\n" + one + b"\n+\n" + b"I" * len(one) + b"\n"
+        with open(path, "wb") as f:
+            f.write(rec * int(kv["times"]))
+        return path
+    if kind == "fq":
+        parts = rest.split(":")
+        base, variant = parts[0], (parts[1] if len(parts) > 1 else "")
+        stored = _committed("fq_%s%s.fq.gz" % (base, "_" + variant if variant in ("crlf", "trunc", "nonl") else ""))
+        if write_committed:
+            seqs = _seqs(base)
+            data = ui.fastq_bytes(seqs, crlf=variant == "crlf", final_newline=variant != "nonl",
+                                  drop_last_qual=variant == "trunc")
+            with gzip.GzipFile(stored, "wb", mtime=0) as f:
+                f.write(data)
+        data = gzip.open(stored, "rb").read()
+        if variant == "gz":
+            path = os.path.join(workdir, case + ".fq.gz")
+            with gzip.GzipFile(path, "wb", mtime=0) as f:
+                f.write(data)
+            return path
+        path = os.path.join(workdir, case + ".fq")
+        open(path, "wb").write(data)
+        return path
+    if kind == "fa":
+        stored = _committed("fa_%s.fa.gz" % rest)
+        if write_committed:
+            with gzip.GzipFile(stored, "wb", mtime=0) as f:
+                f.write(ui.fasta_bytes(_genome()))
+        path = os.path.join(workdir, case + ".fa")
+        open(path, "wb").write(gzip.open(stored, "rb").read())
+        return path
+    raise ValueError(spec)

@@ -32,6 +32,9 @@ def load():
     lib.ko_co_from_fasta_bytes.argtypes = [C.POINTER(KoParams), vp, vp, C.c_size_t, vp, C.c_int]
     lib.ko_dump_co.argtypes = [C.POINTER(KoParams), vp, vp, vp]
     lib.ko_dump_co.restype = C.c_uint
+    lib.ko_partial_from_rows.argtypes = [C.POINTER(KoParams), vp, vp, C.c_size_t, C.c_size_t, C.c_ulonglong, vp, vp, vp,
+                                         C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.ko_layout_from_partials.argtypes = [C.POINTER(KoParams), C.c_int, vp, vp, vp, vp, vp]
     return lib
 
 
@@ -70,6 +73,7 @@ class Oracle:
         n = C.c_ulonglong(0)
         rc = self.lib.ko_koc_from_fastq_bytes(C.byref(self.P), self.table.ctypes.data, b.ctypes.data if len(b) else None,
                                               len(b), self.co.ctypes.data, C.byref(n))
+        self.last_nreads = n.value
         if rc:
             return rc, None
         return 0, self._dump(True)
@@ -96,3 +100,30 @@ class Oracle:
         if rc:
             return rc, None
         return 0, self._dump(False)
+
+
+    def partial_from_rows(self, rows, stride, first_read_ordinal):
+        """-> (keys u64, counts u32, ords u64) of the distinct keys of this read range"""
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        n = rows.size // stride
+        cap = int(self.P.hashlimit) + 1
+        keys, cnts, ords = np.zeros(cap, np.uint64), np.zeros(cap, np.uint32), np.zeros(cap, np.uint64)
+        m = C.c_size_t(0)
+        rc = self.lib.ko_partial_from_rows(C.byref(self.P), self.table.ctypes.data, rows.ctypes.data, stride, n,
+                                           first_read_ordinal, keys.ctypes.data, cnts.ctypes.data, ords.ctypes.data, cap,
+                                           C.byref(m))
+        assert rc == 0
+        return keys[:m.value].copy(), cnts[:m.value].copy(), ords[:m.value].copy()
+
+    def layout_from_partials(self, parts):
+        """parts: list of (keys, counts, ords) -> sketch after the merge, in reference slot order"""
+        k = [np.ascontiguousarray(p[0], np.uint64) for p in parts]
+        c = [np.ascontiguousarray(p[1], np.uint32) for p in parts]
+        o = [np.ascontiguousarray(p[2], np.uint64) for p in parts]
+        n = (C.c_size_t * len(parts))(*[len(x) for x in k])
+        pk = (C.c_void_p * len(parts))(*[x.ctypes.data for x in k])
+        pc = (C.c_void_p * len(parts))(*[x.ctypes.data for x in c])
+        po = (C.c_void_p * len(parts))(*[x.ctypes.data for x in o])
+        rc = self.lib.ko_layout_from_partials(C.byref(self.P), len(parts), pk, pc, po, n, self.co.ctypes.data)
+        assert rc == 0
+        return self._dump(True)

@@ -1,0 +1,186 @@
+"""host-side C layer (no GPU): .shuf format, derived parameters, FASTQ framing, FASTA windowing, sketch-dir writer"""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import util_inputs as ui
+from conftest import SHUF_SPECS
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from metakssd_amd import capi as c
+    return c
+
+
+def test_shuf_roundtrip_and_permutation(capi, tmp_path):
+    s = capi.Shuf.generate(9, 4, 2, 42)
+    t = s.table.copy()
+    assert sorted(t.tolist()) == list(range(16 ** 4))
+    p = str(tmp_path / "x.shuf")
+    s.write(p)
+    assert os.path.getsize(p) == 16 + 4 * 16 ** 4  # command_shuffle.c:205-206
+    hdr = struct.unpack("<4i", open(p, "rb").read(16))
+    assert hdr[1:] == (9, 4, 2)
+    r = capi.Shuf.read(p)
+    assert (r.c.id, r.c.k, r.c.subk, r.c.drlevel) == (s.c.id, 9, 4, 2)
+    assert np.array_equal(r.table, t)
+    with pytest.raises(capi.MkError):
+        capi.Shuf.read(str(tmp_path / "x.txt"))  # must end in .shuf (command_shuffle.c:217-219)
+    assert np.array_equal(capi.Shuf.generate(9, 4, 2, 42).table, t)       # deterministic
+    assert not np.array_equal(capi.Shuf.generate(9, 4, 2, 43).table, t)   # seeded
+
+
+@pytest.mark.parametrize("name", sorted(SHUF_SPECS))
+def test_params_match_oracle_and_survey_table(capi, name):
+    """mk_params_init == oracle's restatement of get_hashsz + seq2co_global_var_initial; spot values from SURVEY 8a"""
+    from oracle_binding import KoParams, load
+    k, subk, drl, seed = SHUF_SPECS[name]
+    sh = capi.Shuf.generate(k, subk, drl, seed) if subk < 6 else None
+    if sh is None:  # avoid generating 64 MiB tables here: build the params from a fake header
+        c = capi.ShufC(123, k, subk, drl, None, 16 ** subk)
+        dummy = (C.c_int32 * 1)()
+        c.table = C.cast(dummy, C.POINTER(C.c_int32))
+        p = capi.ParamsC()
+        assert capi.lib.mk_params_init(C.byref(c), C.byref(p)) == 0
+    else:
+        p = sh.params()
+    ko = KoParams()
+    assert load().ko_params_derive(123, k, subk, drl, C.byref(ko)) == 0
+    for f in ("half_outctx_len", "TL", "crvsaddmove", "component_num", "comp_code_bits", "dim_start", "dim_end",
+              "hashsize", "hashlimit", "tupmask", "domask", "undomask"):
+        assert getattr(p, f) == getattr(ko, f), f
+    if name == "L3K11":
+        assert (p.hashsize, p.hashlimit, p.component_num, p.dim_end, p.TL) == (33554393, 20132635, 1, 4096, 22)
+        assert p.tupmask == 2 ** 44 - 1 and p.domask == (2 ** 24 - 1) << 10 and p.undomask == (2 ** 10 - 1) << 34
+    if name == "L2K11":
+        assert (p.hashsize, p.component_num, p.comp_code_bits) == (536870909, 16, 4)
+    if name == "L3K10":
+        assert p.hashsize == 2097143
+
+
+def test_params_reject_out_of_range_primer_index(capi):
+    c = capi.ShufC(1, 5, 3, 2, None, 16 ** 3)  # 4*(5-2)-15 < 0 : the reference aborts (command_dist.c:291-303)
+    dummy = (C.c_int32 * 1)()
+    c.table = C.cast(dummy, C.POINTER(C.c_int32))
+    p = capi.ParamsC()
+    assert capi.lib.mk_params_init(C.byref(c), C.byref(p)) == capi.MK_ERR_FORMAT
+
+
+def test_synth_rows_formula(capi):
+    """read i, base b = "ACGT"[(mix64(mix64(seed ^ i) + b//32) >> 2*(b%32)) & 3]  (independent numpy restatement)"""
+    def mix64(z):
+        z = (z + 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        return z ^ (z >> 31)
+    rows = capi.synth_rows_host(77, 5, 3, 150, 160).reshape(3, 160)
+    for r in range(3):
+        want = bytearray()
+        for b in range(150):
+            w = mix64((mix64(77 ^ (5 + r)) + b // 32) & (2 ** 64 - 1))
+            want.append(b"ACGT"[(w >> (2 * (b % 32))) & 3])
+        assert bytes(rows[r, :150]) == bytes(want)
+        assert rows[r, 150] == 10 and not rows[r, 151:].any()
+
+
+def oracle_rows_result(oracle, rows, stride):
+    rc, res = oracle.koc_from_rows(rows, stride)
+    assert rc == 0
+    return res
+
+
+@pytest.mark.parametrize("variant", ["plain", "crlf", "trunc", "nonl"])
+def test_fastq_framing_equals_reference_reader(capi, shufs, oracle_for, variant):
+    """rows framed by mk_fastq_frame, walked by the oracle's per-read loop == the oracle's own 4x-fgets reader"""
+    rs = np.random.RandomState(3)
+    seqs = ui.ragged_reads(rs, 400)
+    data = ui.fastq_bytes(seqs, crlf=variant == "crlf", final_newline=variant != "nonl", drop_last_qual=variant == "trunc")
+    ora = oracle_for(shufs("L1K7"))
+    rc, want = ora.koc_from_fastq(data)
+    assert rc == 0
+    rows, n, used, rc = capi.fastq_frame(data, 304)
+    assert rc == 0 and used == len(data)
+    assert n == ora.last_nreads  # the records the reference's 4x-fgets reader keeps
+    assert n in (len(seqs), len(seqs) - 1)
+    got = oracle_rows_result(ora, rows, 304)
+    for (gi, gc_), (wi, wc) in zip(got, want):
+        assert np.array_equal(gi, wi) and np.array_equal(gc_, wc)
+
+
+def test_fastq_framing_streams_in_chunks(capi):
+    rs = np.random.RandomState(4)
+    seqs = ui.ragged_reads(rs, 300)
+    data = ui.fastq_bytes(seqs)
+    whole, n, _, rc = capi.fastq_frame(data, 304)
+    assert rc == 0
+    pieces, pos, buf = [], 0, b""
+    while pos < len(data) or buf:
+        take = data[pos:pos + 777]
+        pos += len(take)
+        buf += take
+        final = pos >= len(data)
+        rows, k, used, rc = capi.fastq_frame(buf, 304, final=final)
+        assert rc == 0
+        pieces.append(rows)
+        buf = buf[used:]
+        if final:
+            break
+    assert np.array_equal(np.concatenate(pieces), whole)
+
+
+def test_fastq_framing_stride_too_small_and_overlong_lines(capi):
+    data = ui.fastq_bytes([b"ACGT" * 10, b"A" * 200, b"ACGT"])
+    rows, n, used, rc = capi.fastq_frame(data, 64)
+    assert rc == capi.MK_ERR_ARG and n == 1          # caller re-frames from `used` with a wider stride
+    rows2, n2, used2, rc2 = capi.fastq_frame(data[used:], 256)
+    assert rc2 == 0 and n2 == 2
+    long_line = ui.fastq_bytes([b"A" * 4095])        # fgets(…,4096) would split it: outside the contract
+    assert capi.fastq_frame(long_line, 4096)[3] == capi.MK_ERR_FORMAT
+
+
+@pytest.mark.parametrize("stride,chunk", [(64, None), (256, 100), (4096, 7)])
+def test_fasta_windows_cover_every_kmer_once(capi, stride, chunk):
+    """rows overlap by TL-1 bases: concatenating row payloads minus the overlaps gives back the cleaned stream"""
+    rs = np.random.RandomState(5)
+    g = ui.rand_seq(rs, 3000)
+    fa = ui.fasta_bytes([g[:1000], g[1000:1010] + b"NN" + g[1012:2000], b"", g[2000:]], width=61)
+    TL = 14
+    rows = capi.fasta_windows(fa, TL, stride, chunk=chunk).reshape(-1, stride)
+    payloads = [bytes(r[: list(r).index(10)]) for r in rows]
+    rebuilt = payloads[0]
+    for p in payloads[1:]:
+        assert p[: TL - 1] == rebuilt[-(TL - 1):]
+        rebuilt += p[TL - 1:]
+    cleaned = b""
+    for line in fa.split(b"\n"):
+        cleaned += b">" if line.startswith(b">") else line
+    assert rebuilt == cleaned
+    assert all(len(p) == stride - 1 for p in payloads[:-1])
+
+
+def test_sketchdir_writer_layout(capi, tmp_path):
+    """combco.N / combco.index.N / combco.N.a / cofiles.stat exactly as run_stageI lays them out"""
+    sh = capi.Shuf.generate(7, 4, 1, 7)
+    p = sh.params()
+    out = str(tmp_path / "sk")
+    h = C.c_void_p()
+    assert capi.lib.mk_sketchdir_open(out.encode(), C.byref(p), 1, 2, C.byref(h)) == 0
+    for name, ids, cnt in (("a/x.fq", [5, 9, 7], [1, 2, 65535]), ("b/y.fq", [], [])):
+        ids_a = (C.c_uint32 * max(1, len(ids)))(*ids)
+        cnt_a = (C.c_uint16 * max(1, len(cnt)))(*cnt)
+        comp = capi.ComponentC(C.cast(ids_a, C.POINTER(C.c_uint32)), C.cast(cnt_a, C.POINTER(C.c_uint16)), len(ids))
+        res = capi.ResultC(1, len(ids), C.pointer(comp))
+        assert capi.lib.mk_sketchdir_add(h, name.encode(), C.byref(res)) == 0
+    assert capi.lib.mk_sketchdir_close(h) == 0
+    assert open(os.path.join(out, "combco.0"), "rb").read() == struct.pack("<3I", 5, 9, 7)
+    assert open(os.path.join(out, "combco.0.a"), "rb").read() == struct.pack("<3H", 1, 2, 65535)
+    assert open(os.path.join(out, "combco.index.0"), "rb").read() == struct.pack("<3Q", 0, 3, 3)
+    st = open(os.path.join(out, "cofiles.stat"), "rb").read()
+    assert len(st) == 32 + 2 * 4 + 2 * 256
+    assert struct.unpack_from("<IB3xiiiiQ", st, 0) == (sh.c.id & 0xffffffff, 1, 14, 2, 1, 2, 3)
+    assert struct.unpack_from("<2I", st, 32) == (3, 0)
+    assert st[40:40 + 256].rstrip(b"\0") == b"a/x.fq" and st[296:296 + 256].rstrip(b"\0") == b"b/y.fq"
