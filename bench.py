@@ -84,6 +84,11 @@ def main():
     ap.add_argument("--reads-per-gpu", type=int, default=50_000_000, help="BASELINE config 3: 50 M reads on one GPU")
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the measured configuration); gloo moves the lists through the host (debug)")
+    ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--verify", action="store_true",
+                    help="after timing, rank 0 re-sketches ALL ranks' reads on one engine and compares with the merged result")
     args = ap.parse_args()
 
     import torch
@@ -97,11 +102,17 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" %
                          (args.gpus, world, args.gpus))
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the exchanged lists live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     shuf = capi.Shuf.generate(11, 6, 3, 11)  # L3K11 = {k=11, subk=6, drlevel=3}, same bytes as the tests' table
     eng = capi.Engine(shuf, local_rank)
@@ -121,6 +132,7 @@ def main():
         po = torch.empty(cap, dtype=torch.int64, device=dev)
 
     result = {}
+    flags = {"keep": False}
 
     def step():
         eng.begin(capi.MK_MODE_KOC)
@@ -128,15 +140,22 @@ def main():
         if world > 1:
             if rank != 0:
                 m = eng.partial_export(pk.data_ptr(), pc.data_ptr(), po.data_ptr(), cap)
-                gather_partials(pk, pc, po, m, dst=0)
+                gather_partials(pk[:m].to(xdev), pc[:m].to(xdev), po[:m].to(xdev), m, dst=0)
             else:
-                for (k, c, o) in gather_partials(pk, pc, po, 0, dst=0):
+                empty = (pk[:0].to(xdev), pc[:0].to(xdev), po[:0].to(xdev))
+                for (k, c, o) in gather_partials(*empty, 0, dst=0):
+                    k, c, o = k.to(dev), c.to(dev), o.to(dev)
                     torch.cuda.current_stream().synchronize()
                     eng.partial_import(k.data_ptr(), c.data_ptr(), o.data_ptr(), k.numel())
+                    torch.cuda.current_stream().synchronize()  # k,c,o must outlive the import kernel
         if rank == 0:
-            r = eng.finish_raw()
-            result["distinct"] = int(r.total)
-            capi.lib.mk_result_release(eng.h, r)
+            if flags["keep"]:
+                result["sketch"] = eng.finish()
+                result["distinct"] = sum(len(x[0]) for x in result["sketch"])
+            else:
+                r = eng.finish_raw()
+                result["distinct"] = int(r.total)
+                capi.lib.mk_result_release(eng.h, r)
 
     def fence():
         torch.cuda.synchronize()
@@ -160,6 +179,22 @@ def main():
         dt = float(t.item())
     prof = eng.profile()
     eng.profile_enable(False)
+
+    verified = None
+    if args.verify:
+        flags["keep"] = True
+        step()
+        fence()
+        if rank == 0:
+            import numpy as np
+            allreads = torch.empty(world * n * STRIDE, dtype=torch.uint8, device=dev)
+            capi.synth_rows_device(local_rank, stream, SEED, 0, world * n, READ_LEN, STRIDE, allreads.data_ptr())
+            eng.begin(capi.MK_MODE_KOC)
+            eng.push_reads_device(allreads.data_ptr(), STRIDE, world * n, 0)
+            single = eng.finish()
+            verified = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(single, result["sketch"]))
+            del allreads
+        flags["keep"] = False
 
     if rank == 0:
         bases_per_step = float(world) * n * READ_LEN
@@ -198,6 +233,10 @@ def main():
                                    "resolve": prof["resolve_ms"] / args.steps,
                                    "finish": prof["finish_ms"] / args.steps},
         }
+        if verified is not None:
+            line["merged_equals_single_engine"] = bool(verified)
+        if args.backend != "nccl":
+            line["config"]["parallelism"] += " (debug transport: %s%s)" % (args.backend, ", same device" if args.same_device else "")
         if world == 1 and not args.no_cpu_baseline:
             m = min(args.cpu_sample_reads, n)
             eng.begin(capi.MK_MODE_KOC)

@@ -274,3 +274,23 @@ def test_candidate_buffer_partial_overflow(capi, shufs, oracle_for, monkeypatch)
     rc, want = oracle_for(shufs("L0K6")).koc_from_rows(rows, 160)
     assert rc == 0
     assert_same(got, want)
+
+
+def test_bench_two_rank_flow_merged_equals_single(capi):
+    """bench.py's N>1 code path (shard, export, exchange, import, finish) with two ranks on this one GPU and the
+    lists moved by gloo; the RCCL transport itself only runs on a multi-GPU node"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
+           "--reads-per-gpu", "1000000", "--steps", "1", "--warmup", "1", "--verify"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["merged_equals_single_engine"] is True
+    assert d["config"]["distinct_keys"] > 50000
