@@ -29,6 +29,7 @@ struct mk_engine {
 
   int32_t *d_shuf = nullptr;
   uint32_t *d_accept = nullptr;
+  uint32_t *d_accept_bits = nullptr;
   uint32_t n_accept = 0;
   uint32_t bm_bits = 0;
   /* candidate append buffers: one slot per scan wave */
@@ -36,7 +37,7 @@ struct mk_engine {
   uint32_t *d_cand_count = nullptr;
   uint32_t cand_slots = 0, cand_cap = 0;
 
-  void *d_tab = nullptr; /* key[S] | ordinv[S] | cnt[S] */
+  void *d_tab = nullptr; /* kc[S] | ordinv[S] */
   size_t tab_bytes = 0;
   mk_table tab{};
   uint32_t *d_slot = nullptr;
@@ -121,7 +122,7 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipSetDevice(e->device);
   hipDeviceSynchronize();
   hipFree(e->d_cand_fwd); hipFree(e->d_cand_ord); hipFree(e->d_cand_count);
-  hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_tab); hipFree(e->d_slot);
+  hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_accept_bits); hipFree(e->d_tab); hipFree(e->d_slot);
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   hipFree(e->d_chunk); hipFree(e->d_counters); hipFree(e->d_out_ids); hipFree(e->d_out_cnt);
   if (e->h_counters) hipHostFree(e->h_counters);
@@ -169,10 +170,12 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
    * inner substring is the reverse complement of the forward one: see mk_kernels.hip.h, "LDS filter". */
   const uint64_t L = p->shuf_len;
   std::vector<uint32_t> acc;
+  std::vector<uint32_t> bits((size_t)((L + 31) / 32), 0u);
   const uint32_t dbits = 4u * (uint32_t)p->subk;
   for (uint64_t d = 0; d < L; d++) {
     int32_t v = p->shuf_table[d];
     if (v >= p->dim_start && v < p->dim_end) {
+      bits[d >> 5] |= 1u << (d & 31u);
       acc.push_back((uint32_t)d);
       uint32_t n = ~(uint32_t)d, r = 0; /* reverse the 2-bit groups of the complement within dbits */
       for (uint32_t i = 0; i < dbits; i += 2) r |= ((n >> i) & 3u) << (dbits - 2u - i);
@@ -184,6 +187,8 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   MK_HIP(e, hipMemcpy(e->d_shuf, p->shuf_table, L * sizeof(int32_t), hipMemcpyHostToDevice));
   MK_HIP(e, hipMalloc(&e->d_accept, (acc.size() + 1) * sizeof(uint32_t)));
   if (!acc.empty()) MK_HIP(e, hipMemcpy(e->d_accept, acc.data(), acc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  MK_HIP(e, hipMalloc(&e->d_accept_bits, bits.size() * sizeof(uint32_t)));
+  MK_HIP(e, hipMemcpy(e->d_accept_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   /* LDS filter: 2^bm_bits words of 32 bits indexed by the inner substring's bits 10.. (at most 64 KiB) */
   {
     int wb = 4 * p->subk - 10;
@@ -191,11 +196,10 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   }
 
   const uint64_t S = p->hashsize;
-  e->tab_bytes = S * (8 + 8 + 4);
+  e->tab_bytes = S * (8 + 8);
   MK_HIP(e, hipMalloc(&e->d_tab, e->tab_bytes));
-  e->tab.key = (unsigned long long *)e->d_tab;
-  e->tab.ordinv = e->tab.key + S;
-  e->tab.cnt = (uint32_t *)(e->tab.ordinv + S);
+  e->tab.kc = (unsigned long long *)e->d_tab;
+  e->tab.ordinv = e->tab.kc + S;
   MK_HIP(e, hipMalloc(&e->d_slot, S * sizeof(uint32_t)));
   e->dist.cap = (uint64_t)p->hashlimit + 1;
   MK_HIP(e, hipMalloc(&e->dist.key, e->dist.cap * 8));
@@ -351,6 +355,7 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   a.dimmask = (uint32_t)((1ull << (4 * e->P.subk)) - 1ull);
   a.accept = e->d_accept; a.n_accept = e->n_accept;
   a.shuf = e->d_shuf;
+  a.accept_bits = e->d_accept_bits;
   a.kp = e->kp;
   a.tab = e->tab;
   a.cand_fwd = e->d_cand_fwd; a.cand_ord = e->d_cand_ord; a.cand_count = e->d_cand_count; a.cand_cap = e->cand_cap;
@@ -453,8 +458,9 @@ static int mk_compact(mk_engine *e) {
   if (e->compacted) return MK_OK;
   MK_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(unsigned long long), e->stream));
   const int drop0 = e->mode != MK_MODE_KOC; /* co[n]=0 stays "empty" in the set flavours: iseq2comem.c:300-302 */
-  const unsigned blocks = (unsigned)(e->num_cu * 8);
-  hipLaunchKernelGGL(mk_compact_kernel, dim3(blocks), dim3(256), 0, e->stream, e->tab, e->kp.S, e->dist, e->d_counters, drop0);
+  const unsigned blocks = (unsigned)(e->num_cu * 2);
+  hipLaunchKernelGGL(mk_compact_kernel, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
+                     e->d_counters, drop0);
   MK_HIP(e, hipGetLastError());
   MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
   MK_HIP(e, hipStreamSynchronize(e->stream));

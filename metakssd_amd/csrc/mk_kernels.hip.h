@@ -25,7 +25,9 @@
 #define MK_MAX_CB 128                  /* widest column block staged per step, bytes */
 #define MK_MAX_PIECES 8                /* 16-byte pieces per lane per step = MK_MAX_CB/16 */
 #define MK_EMPTY32 0xFFFFFFFFu
-#define MK_CNT_SAT 0x7FFFFFFFu         /* stop adding long before a u32 count could wrap */
+#define MK_CNT_BITS 24                 /* slot word = key << 24 | count (the reference's slot is key << 16 | count16) */
+#define MK_CNT_MASK 0xFFFFFFull
+#define MK_CNT_SAT 0xF00000ull         /* stop adding long before the count field could carry into the key */
 
 struct mk_keyparams {
   uint64_t tupmask, domask, undomask, lowmask;
@@ -35,10 +37,9 @@ struct mk_keyparams {
 };
 
 struct mk_table {
-  unsigned long long *key; /* key+1, 0 = empty                      [S] */
-  unsigned long long *ordinv; /* ~(first ordinal), max-combined     [S] */
-  uint32_t *cnt;           /* occurrences (not yet clamped)         [S] */
-  uint32_t *err;           /* [0] = table-full flag */
+  unsigned long long *kc;     /* key << 24 | occurrences (>= 1), 0 = empty   [S]  (keys are < 2^39) */
+  unsigned long long *ordinv; /* ~(first ordinal), max-combined              [S] */
+  uint32_t *err;              /* [0] = table-full flag */
 };
 
 struct mk_scan_args {
@@ -55,6 +56,7 @@ struct mk_scan_args {
   const uint32_t *accept; /* inner substrings d with dim_start <= shuf[d] < dim_end */
   uint32_t n_accept;
   const int32_t *shuf;
+  const uint32_t *accept_bits; /* bit d set <=> dim_start <= shuf[d] < dim_end (2 MiB at subk 6: stays in L2) */
   mk_keyparams kp;
   mk_table tab;
   /* filter hits ("candidates") leave the scan kernel through per-wave append buffers in HBM */
@@ -93,21 +95,23 @@ __device__ __forceinline__ uint64_t mk_reduce_key(const mk_keyparams &kp, uint64
 }
 
 /* counted upsert into the accumulation table (arrival order is irrelevant: counts add, first ordinals
- * combine by min; the reference-order layout is rebuilt afterwards by mk_layout_kernel) */
+ * combine by min; the reference-order layout is rebuilt afterwards by mk_layout_kernel).
+ * New key: one CAS (installs key with count `add`) + one atomicMax; known key: one atomicAdd + one atomicMax. */
 __device__ __forceinline__ void mk_upsert(const mk_table &tab, uint32_t S, uint64_t key, uint64_t ord, uint32_t add) {
   uint32_t n, h2;
   mk_probe_init(key, S, n, h2);
-  const unsigned long long want = key + 1ull;
+  const unsigned long long fresh = ((unsigned long long)key << MK_CNT_BITS) | add;
   for (uint32_t i = 0; i < S; i++) {
-    unsigned long long cur = __hip_atomic_load(&tab.key[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long cur = __hip_atomic_load(&tab.kc[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool mine = false;
     if (cur == 0ull) {
-      unsigned long long prev = atomicCAS(&tab.key[n], 0ull, want);
-      cur = prev == 0ull ? want : prev;
+      const unsigned long long prev = atomicCAS(&tab.kc[n], 0ull, fresh);
+      if (prev == 0ull) mine = true; /* installed with its first count */
+      else cur = prev;
     }
-    if (cur == want) {
+    if (mine || (cur >> MK_CNT_BITS) == key) {
+      if (!mine && (cur & MK_CNT_MASK) < MK_CNT_SAT) atomicAdd(&tab.kc[n], (unsigned long long)add);
       atomicMax(&tab.ordinv[n], ~(unsigned long long)ord);
-      uint32_t c = __hip_atomic_load(&tab.cnt[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (c < MK_CNT_SAT) atomicAdd(&tab.cnt[n], add);
       return;
     }
     n = mk_probe_next(n, h2, S);
@@ -132,6 +136,9 @@ __device__ __forceinline__ void mk_resolve_one(const mk_scan_args &a, uint64_t f
   const uint64_t rc = mk_revcomp(fwd, a.kp.TL);
   const uint64_t uni = fwd < rc ? fwd : rc;
   const uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
+  /* most candidates are filter false positives or wrong-strand mirrors: settle those on the small bitmap and
+   * touch the 4*16^subk-byte .shuf table only for the accepted ones */
+  if (!((a.accept_bits[dim >> 5] >> (dim & 31u)) & 1u)) return;
   const int32_t pf = a.shuf[dim];
   if (pf >= a.kp.dim_start && pf < a.kp.dim_end) {
     const uint64_t key = mk_reduce_key(a.kp, uni, (uint64_t)(pf - a.kp.dim_start));
@@ -558,44 +565,61 @@ struct mk_dist {
   uint64_t cap;
 };
 
-/* each wave owns a contiguous chunk of MK_COMPACT_CHUNK slots: pass 1 counts its occupied slots, one
- * atomicAdd per chunk reserves the output range, pass 2 (chunk still cache-hot) writes the entries */
-#define MK_COMPACT_CHUNK 4096u
-__global__ void __launch_bounds__(256) mk_compact_kernel(mk_table tab, uint32_t S, mk_dist out, unsigned long long *counter,
-                                                         int drop_key0) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t nchunks = ((uint64_t)S + MK_COMPACT_CHUNK - 1) / MK_COMPACT_CHUNK;
-  const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  for (uint64_t ch = wave0; ch < nchunks; ch += nw) {
-    const uint64_t base_slot = ch * MK_COMPACT_CHUNK;
-    uint32_t total = 0;
-    for (uint32_t it = 0; it < MK_COMPACT_CHUNK / 64u; it++) {
+/* Each wave owns MK_COMPACT_CHUNK consecutive slots (all loads of the chunk in flight together), a workgroup of
+ * 16 waves owns 16 consecutive chunks and reserves its output range with ONE atomicAdd (same-address atomics
+ * serialise at ~90 per microsecond on this chip, so there must be few of them). */
+#define MK_COMPACT_CHUNK 2048u
+#define MK_COMPACT_THREADS 1024
+__global__ void __launch_bounds__(MK_COMPACT_THREADS) mk_compact_kernel(mk_table tab, uint32_t S, mk_dist out,
+                                                                        unsigned long long *counter, int drop_key0) {
+  __shared__ uint32_t wtotal[MK_COMPACT_THREADS / 64];
+  __shared__ unsigned long long block_base;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  constexpr uint32_t WAVES = MK_COMPACT_THREADS / 64, ITER = MK_COMPACT_CHUNK / 64u;
+  const uint64_t nblockchunks = ((uint64_t)S + (uint64_t)MK_COMPACT_CHUNK * WAVES - 1) / ((uint64_t)MK_COMPACT_CHUNK * WAVES);
+  for (uint64_t bc = blockIdx.x; bc < nblockchunks; bc += gridDim.x) {
+    const uint64_t base_slot = (bc * WAVES + wave) * MK_COMPACT_CHUNK;
+    unsigned long long kc[ITER];
+#pragma unroll
+    for (uint32_t it = 0; it < ITER; it++) {
       const uint64_t n = base_slot + it * 64u + lane;
-      const unsigned long long k1 = n < S ? tab.key[n] : 0ull;
-      const bool occ = k1 != 0ull && !(drop_key0 && k1 == 1ull);
+      kc[it] = n < S ? tab.kc[n] : 0ull;
+    }
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t it = 0; it < ITER; it++) {
+      const bool occ = kc[it] != 0ull && !(drop_key0 && (kc[it] >> MK_CNT_BITS) == 0ull);
       total += (uint32_t)__popcll(__ballot(occ));
     }
-    if (total == 0) continue;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(counter, (unsigned long long)total);
-    base = __shfl(base, 0);
-    for (uint32_t it = 0; it < MK_COMPACT_CHUNK / 64u; it++) {
-      const uint64_t n = base_slot + it * 64u + lane;
-      const unsigned long long k1 = n < S ? tab.key[n] : 0ull;
-      const bool occ = k1 != 0ull && !(drop_key0 && k1 == 1ull);
-      const uint64_t m = __ballot(occ);
-      if (occ) {
-        const uint64_t idx = base + mk_mbcnt(m);
-        if (idx < out.cap) {
-          out.key[idx] = k1 - 1ull;
-          out.ord[idx] = ~tab.ordinv[n];
-          const uint32_t c = tab.cnt[n];
-          out.cnt[idx] = c > 65535u ? 65535u : c;
-        }
-      }
-      base += (unsigned long long)__popcll(m);
+    if (lane == 0) wtotal[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t sum = 0;
+      for (uint32_t w = 0; w < WAVES; w++) sum += wtotal[w];
+      block_base = sum ? atomicAdd(counter, (unsigned long long)sum) : 0ull;
     }
+    __syncthreads();
+    unsigned long long base = block_base;
+    for (uint32_t w = 0; w < wave; w++) base += wtotal[w];
+    if (total) {
+#pragma unroll
+      for (uint32_t it = 0; it < ITER; it++) {
+        const uint64_t n = base_slot + it * 64u + lane;
+        const bool occ = kc[it] != 0ull && !(drop_key0 && (kc[it] >> MK_CNT_BITS) == 0ull);
+        const uint64_t m = __ballot(occ);
+        if (occ) {
+          const uint64_t idx = base + mk_mbcnt(m);
+          if (idx < out.cap) {
+            out.key[idx] = kc[it] >> MK_CNT_BITS;
+            out.ord[idx] = ~tab.ordinv[n];
+            const uint32_t c = (uint32_t)(kc[it] & MK_CNT_MASK);
+            out.cnt[idx] = c > 65535u ? 65535u : c;
+          }
+        }
+        base += (unsigned long long)__popcll(m);
+      }
+    }
+    __syncthreads(); /* wtotal/block_base are reused by the next block-chunk */
   }
 }
 
