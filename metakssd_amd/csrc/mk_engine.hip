@@ -381,7 +381,8 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   hipError_t r;
-  switch (e->P.subk == 6 ? e->P.k : 0) {
+  /* tuned kernels: 24-bit inner substring (subk 6), k in {10,11}, every column block a whole number of 8-base pairs */
+  switch ((e->P.subk == 6 && stride % 8u == 0 && a.CB % 8u == 0) ? e->P.k : 0) {
     case 11: r = vec ? mk_launch_scan_k<11, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<11, false>(threads, a, grid, lds, e->stream); break;
     case 10: r = vec ? mk_launch_scan_k<10, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<10, false>(threads, a, grid, lds, e->stream); break;
     default: r = vec ? mk_launch_scan_k<0, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<0, false>(threads, a, grid, lds, e->stream); break;

@@ -303,6 +303,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
 
   mk_kmer<K> km;
   km.reset();
+  uint32_t h2 = 0, h3 = 0; /* tuned loop: low word of the forward k-mer at the two previous pair (8-base) boundaries */
   uint32_t run = 0;  /* valid bases since the last reset (the reference's base-1) */
   bool done = true;  /* this lane's row hit its '\n' (or does not exist) */
   uint32_t qn = 0;   /* queued candidates, wave-uniform */
@@ -417,7 +418,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   issue_loads(nt_tile, nt_cb);
   for (uint64_t tile_id = wave_global; tile_id < ntiles; tile_id += nwaves) {
     const uint64_t row0 = tile_id << 6;
-    km.reset(); run = 0;
+    km.reset(); run = 0; h2 = 0; h3 = 0;
     done = row0 + lane >= a.nreads;
     ord_row = (a.first_ord + row0 + lane) << 12;
     for (uint32_t cb = 0; cb < a.ncb; cb++) {
@@ -445,75 +446,98 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
       const uint32_t ndw = min(a.CB, a.stride - col0) >> 2;
       const uint32_t npairs = ndw >> 1;
       if constexpr (K != 0) {
-        /* ---- tuned loop (k-mer geometry and the 24-bit inner substring folded at compile time) --------
-         * all_ready (wave-uniform): no lane is past its newline and every lane already has a full window.
-         * While it holds, a pair of dwords needs ONE validity test and ONE filter-hit test; `run` is left
-         * stale (it only has to stay >= TL-1, which it does until a reset in the slow path). */
-        constexpr uint32_t OUT2 = 2u * (K - 6);
+        /* ---- tuned loop (K in 9..11, subk 6: geometry folded at compile time) --------------------------------
+         * The k-mer ending at base j has its 24-bit inner substring in bits SH..SH+23 of flo(j-1), the low word
+         * of the forward k-mer one base earlier.  While all_ready holds (no lane past its newline, every lane
+         * with a full window) the loop therefore rolls ONLY the low word: one validity test and one filter-hit
+         * test per 8 bases.  The high word is rebuilt on demand from h2/h3 = flo at the two previous pair ends
+         * (fhi(j) = flo(j-16) & HMASK): for the rare filter hits and when the slow path takes over. */
+        constexpr uint32_t SH = 2u * (K - 6) - 2u; /* out2 - 2 */
+        constexpr uint32_t HM = mk_kmer<K>::HMASK;
+        static_assert(SH + 24u <= 32u, "inner substring must lie inside flo(j-1)");
         bool all_ready = __all(!done && run + 1u >= TL);
         uint32_t nw0 = myrow[0], nw1 = myrow[1];
-        for (uint32_t p = 0; p < npairs; p++) {
-          const uint32_t w0 = nw0, w1 = nw1;
-          nw0 = myrow[2 * p + 2]; /* unconditional prefetch: at most 2 dwords past the row, inside the wave's LDS */
-          nw1 = myrow[2 * p + 3];
-          uint32_t c0, x0, c1, x1;
-          decode(w0, c0, x0);
-          decode(w1, c1, x1);
-          const uint32_t pos0 = col0 + 8u * p;
-          if (all_ready && __all((x0 | x1) == 0u)) {
-            quad qa, qb;
-            auto probe = [&](uint32_t code, uint64_t &u, uint32_t &m, uint32_t &wd) {
-              km.roll(code, a.kp);
-              u = km.fwd();
-              const uint32_t xx = __builtin_amdgcn_alignbit(km.fhi, km.flo, OUT2);
-#if defined(MK_ABLATE) && (MK_ABLATE == 1 || MK_ABLATE == 4)
-              wd = xx; /* ablation: no LDS probe */
-#else
-              wd = *(mk_lds_cu32)(uintptr_t)((xx >> 8) & 0xFFFCu);
-#endif
-              m = mk_filter_mask(xx);
-            };
-            probe(c0 & 3u, qa.u0, qa.m0, qa.w0);
-            probe(__builtin_amdgcn_ubfe(c0, 8, 2), qa.u1, qa.m1, qa.w1);
-            probe(__builtin_amdgcn_ubfe(c0, 16, 2), qa.u2, qa.m2, qa.w2);
-            probe(c0 >> 24, qa.u3, qa.m3, qa.w3);
-            probe(c1 & 3u, qb.u0, qb.m0, qb.w0);
-            probe(__builtin_amdgcn_ubfe(c1, 8, 2), qb.u1, qb.m1, qb.w1);
-            probe(__builtin_amdgcn_ubfe(c1, 16, 2), qb.u2, qb.m2, qb.w2);
-            probe(c1 >> 24, qb.u3, qb.m3, qb.w3);
-            __builtin_amdgcn_sched_barrier(0); /* keep all eight probes in flight before the first result is read */
-            /* t == 0 <=> both filter bits set.  Binary descent over the min tree: a pair without hits costs one
-             * test, a single hit costs about six. */
-            const uint32_t a0 = qa.m0 & ~qa.w0, a1 = qa.m1 & ~qa.w1, a2 = qa.m2 & ~qa.w2, a3 = qa.m3 & ~qa.w3;
-            const uint32_t b0 = qb.m0 & ~qb.w0, b1 = qb.m1 & ~qb.w1, b2 = qb.m2 & ~qb.w2, b3 = qb.m3 & ~qb.w3;
-            const uint32_t a01 = min(a0, a1), a23 = min(a2, a3), b01 = min(b0, b1), b23 = min(b2, b3);
-            const uint32_t ta = min(a01, a23), tb = min(b01, b23);
+        uint32_t p = 0;
+        while (p < npairs) {
+          uint32_t w0, w1, c0, x0, c1, x1;
+          bool have_pair = false;
+          if (all_ready) {
+            uint32_t flo = km.flo;
+            for (;;) { /* inner fast loop: leaves at a pair boundary */
+              w0 = nw0; w1 = nw1;
+              nw0 = myrow[2 * p + 2]; /* unconditional prefetch: at most 2 dwords past the row, inside the wave's LDS */
+              nw1 = myrow[2 * p + 3];
+              decode(w0, c0, x0);
+              decode(w1, c1, x1);
+              if (!__all((x0 | x1) == 0u)) { have_pair = true; break; }
+              const uint32_t fstart = flo;
+              uint32_t f0, f1, f2, f3, f4, f5, f6, f7, m0, m1, m2, m3, m4, m5, m6, m7, d0, d1, d2, d3, d4, d5, d6, d7;
+              auto probe = [&](uint32_t code, uint32_t &fl, uint32_t &m, uint32_t &wd) {
+                const uint32_t xx = flo >> SH;
+                wd = *(mk_lds_cu32)(uintptr_t)((flo >> (SH + 8u)) & 0xFFFCu);
+                m = mk_filter_mask(xx);
+                flo = (flo << 2) | code;
+                fl = flo;
+              };
+              probe(c0 & 3u, f0, m0, d0);
+              probe(__builtin_amdgcn_ubfe(c0, 8, 2), f1, m1, d1);
+              probe(__builtin_amdgcn_ubfe(c0, 16, 2), f2, m2, d2);
+              probe(c0 >> 24, f3, m3, d3);
+              probe(c1 & 3u, f4, m4, d4);
+              probe(__builtin_amdgcn_ubfe(c1, 8, 2), f5, m5, d5);
+              probe(__builtin_amdgcn_ubfe(c1, 16, 2), f6, m6, d6);
+              probe(c1 >> 24, f7, m7, d7);
+              __builtin_amdgcn_sched_barrier(0); /* all eight probes in flight before the first result is read */
+              /* t == 0 <=> both filter bits set.  Binary descent over the min tree: a pair without hits costs one
+               * test, a single hit about six. */
+              const uint32_t t0 = m0 & ~d0, t1 = m1 & ~d1, t2 = m2 & ~d2, t3 = m3 & ~d3;
+              const uint32_t t4 = m4 & ~d4, t5 = m5 & ~d5, t6 = m6 & ~d6, t7 = m7 & ~d7;
+              const uint32_t t01 = min(t0, t1), t23 = min(t2, t3), t45 = min(t4, t5), t67 = min(t6, t7);
+              const uint32_t ta = min(t01, t23), tb = min(t45, t67);
 #if defined(MK_ABLATE) && MK_ABLATE == 3
-            if (__any(min(ta, tb) == 0xffffffffu)) { /* ablation: never enter the hit path */
+              if (__any(min(ta, tb) == 0xffffffffu)) {
 #else
-            if (__any(min(ta, tb) == 0u)) {
+              if (__any(min(ta, tb) == 0u)) {
 #endif
-              if (__any(ta == 0u)) {
-                if (__any(a01 == 0u)) { push(a0 == 0u, qa.u0, pos0); push(a1 == 0u, qa.u1, pos0 + 1u); }
-                if (__any(a23 == 0u)) { push(a2 == 0u, qa.u2, pos0 + 2u); push(a3 == 0u, qa.u3, pos0 + 3u); }
+                const uint32_t pos0 = col0 + 8u * p;
+                /* forward k-mer ending at base j of this pair: low word fl, high word from flo(j-16), which lies
+                 * between h3 = flo(-17) and h2 = flo(-9):  flo(-17+d) = (h3 << 2d) | ((h2 & 0xFFFF) >> (16-2d)) */
+                auto hit = [&](uint32_t t, uint32_t fl, uint32_t j) {
+                  const uint32_t dd = 2u * (j + 1u);
+                  const uint32_t fhi = ((h3 << dd) | ((h2 & 0xFFFFu) >> (16u - dd))) & HM;
+                  push(t == 0u, ((uint64_t)fhi << 32) | fl, pos0 + j);
+                };
+                if (__any(ta == 0u)) {
+                  if (__any(t01 == 0u)) { hit(t0, f0, 0); hit(t1, f1, 1); }
+                  if (__any(t23 == 0u)) { hit(t2, f2, 2); hit(t3, f3, 3); }
+                }
+                if (__any(tb == 0u)) {
+                  if (__any(t45 == 0u)) { hit(t4, f4, 4); hit(t5, f5, 5); }
+                  if (__any(t67 == 0u)) { hit(t6, f6, 6); hit(t7, f7, 7); }
+                }
               }
-              if (__any(tb == 0u)) {
-                if (__any(b01 == 0u)) { push(b0 == 0u, qb.u0, pos0 + 4u); push(b1 == 0u, qb.u1, pos0 + 5u); }
-                if (__any(b23 == 0u)) { push(b2 == 0u, qb.u2, pos0 + 6u); push(b3 == 0u, qb.u3, pos0 + 7u); }
-              }
+              h3 = h2; h2 = fstart;
+              if (++p == npairs) break;
             }
+            km.flo = flo;
+            km.fhi = h3 & HM; /* = flo(-17) & HMASK at this pair boundary */
+            if (!have_pair) break;
           } else {
-            slow_dword(w0, c0, x0, pos0);
-            slow_dword(w1, c1, x1, pos0 + 4u);
-            if (__all(done)) break;
-            all_ready = __all(!done && run + 1u >= TL);
+            w0 = nw0; w1 = nw1;
+            nw0 = myrow[2 * p + 2];
+            nw1 = myrow[2 * p + 3];
+            decode(w0, c0, x0);
+            decode(w1, c1, x1);
           }
-        }
-        if ((ndw & 1u) && !__all(done)) {
-          const uint32_t w = myrow[ndw - 1u];
-          uint32_t c0, x0;
-          decode(w, c0, x0);
-          slow_dword(w, c0, x0, col0 + 4u * (ndw - 1u));
+          /* slow handling of one pair (full two-word roll) */
+          const uint32_t fstart = km.flo;
+          const uint32_t pos0 = col0 + 8u * p;
+          slow_dword(w0, c0, x0, pos0);
+          slow_dword(w1, c1, x1, pos0 + 4u);
+          h3 = h2; h2 = fstart;
+          p++;
+          if (__all(done)) break;
+          all_ready = __all(!done && run + 1u >= TL);
         }
       } else {
         uint32_t nw0 = myrow[0], nw1 = ndw > 1 ? myrow[1] : 0x0a0a0a0au;
