@@ -169,7 +169,14 @@ __global__ void __launch_bounds__(256) mk_resolve_kernel(const mk_scan_args a, u
  * loop therefore rolls and probes the forward strand only; canonicalisation happens for filter hits, in
  * mk_drain.  One 32-bit word per probe: word = bits 10.. of the substring, two bit positions = its bits 0-4
  * and 5-9.  8192 entries in 16384 words: about 0.15 % false positives; correctness never depends on it. */
-__device__ __forceinline__ uint32_t mk_filter_mask(uint32_t x) { return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u)); }
+__device__ __forceinline__ uint32_t mk_filter_mask(uint32_t x) {
+#if defined(MK_FILTER_BITS) && MK_FILTER_BITS == 2
+  return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u));
+#else
+  /* third position from bits 3..7 (overlaps the other two fields, still cuts false positives ~3x) */
+  return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u)) | (1u << ((x >> 3) & 31u));
+#endif
+}
 
 /* rolling forward k-mer (iseq2comem.c:685).
  * K == 0: geometry from runtime parameters, 64-bit arithmetic.
