@@ -174,7 +174,11 @@ __device__ __forceinline__ uint32_t mk_filter_mask(uint32_t x) {
   return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u));
 #else
   /* third position from bits 3..7 (overlaps the other two fields, still cuts false positives ~3x) */
+#if defined(MK_FILTER_BITS) && MK_FILTER_BITS == 4
+  return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u)) | (1u << ((x >> 3) & 31u)) | (1u << ((x >> 7) & 31u));
+#else
   return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u)) | (1u << ((x >> 3) & 31u));
+#endif
 #endif
 }
 
@@ -455,20 +459,24 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
       if constexpr (K != 0) {
         /* ---- tuned loop (K in 9..11, subk 6: geometry folded at compile time) --------------------------------
          * The k-mer ending at base j has its 24-bit inner substring in bits SH..SH+23 of flo(j-1), the low word
-         * of the forward k-mer one base earlier.  While all_ready holds (no lane past its newline, every lane
-         * with a full window) the loop therefore rolls ONLY the low word: one validity test and one filter-hit
-         * test per 8 bases.  The high word is rebuilt on demand from h2/h3 = flo at the two previous pair ends
-         * (fhi(j) = flo(j-16) & HMASK): for the rare filter hits and when the slow path takes over. */
+         * of the forward k-mer one base earlier, so the loop rolls ONLY the low word; the high word is rebuilt on
+         * demand from h2/h3 = flo at the two previous pair ends (fhi(j) = flo(j-16) & HMASK): for the rare filter
+         * hits and when the slow path takes over.
+         * The loop runs while the wave is UNIFORM: no lane past its newline and every lane with the same run
+         * length `urun` (fixed-length reads without N: always).  A pair of dwords (8 bases) then needs one
+         * validity test and one filter-hit test; k-mers that are not complete yet (read heads, j < jmin) or lie
+         * behind a common newline (read tails, j >= e) are probed like the others and discarded in the hit path. */
         constexpr uint32_t SH = 2u * (K - 6) - 2u; /* out2 - 2 */
         constexpr uint32_t HM = mk_kmer<K>::HMASK;
         static_assert(SH + 24u <= 32u, "inner substring must lie inside flo(j-1)");
-        bool all_ready = __all(!done && run + 1u >= TL);
+        uint32_t urun = __builtin_amdgcn_readfirstlane(run);
+        bool uniform = __all(!done && run == urun);
         uint32_t nw0 = myrow[0], nw1 = myrow[1];
         uint32_t p = 0;
         while (p < npairs) {
           uint32_t w0, w1, c0, x0, c1, x1;
           bool have_pair = false;
-          if (all_ready) {
+          if (uniform) {
             uint32_t flo = km.flo;
             for (;;) { /* inner fast loop: leaves at a pair boundary */
               w0 = nw0; w1 = nw1;
@@ -476,59 +484,90 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
               nw1 = myrow[2 * p + 3];
               decode(w0, c0, x0);
               decode(w1, c1, x1);
-              if (!__all((x0 | x1) == 0u)) { have_pair = true; break; }
+              uint32_t e = 8u; /* bases of this pair in front of the (common) newline */
+              if (!__all((x0 | x1) == 0u)) {
+                /* not eight valid bases everywhere: still fine if every lane has the same bytes-before-newline
+                 * pattern with only valid bases in front of it (the tail of fixed-length reads) */
+                const uint32_t nl0 = mk_nonzero_bytes(w0 ^ 0x0A0A0A0Au) ^ 0x80808080u; /* 0x80 where byte == '\n' */
+                const uint32_t nl1 = mk_nonzero_bytes(w1 ^ 0x0A0A0A0Au) ^ 0x80808080u;
+                const uint32_t s0 = __builtin_amdgcn_readfirstlane(nl0), s1 = __builtin_amdgcn_readfirstlane(nl1);
+                uint32_t ee = s0 ? (uint32_t)__builtin_ctz(s0) >> 3 : (s1 ? 4u + ((uint32_t)__builtin_ctz(s1) >> 3) : 8u);
+                /* bytes in front of position ee must be valid in every lane; the newline must be where lane 0 has it */
+                const uint64_t inval = ((uint64_t)mk_nonzero_bytes(x1) << 32) | mk_nonzero_bytes(x0);
+                const uint64_t front = ee >= 8u ? ~0ull : ((1ull << (8u * ee)) - 1ull);
+                const bool ok = ee < 8u && (inval & front) == 0ull && nl0 == s0 && nl1 == s1;
+                if (!__all(ok)) { have_pair = true; break; }
+                e = ee;
+              }
               const uint32_t fstart = flo;
-              uint32_t f0, f1, f2, f3, f4, f5, f6, f7, m0, m1, m2, m3, m4, m5, m6, m7, d0, d1, d2, d3, d4, d5, d6, d7;
-              auto probe = [&](uint32_t code, uint32_t &fl, uint32_t &m, uint32_t &wd) {
-                const uint32_t xx = flo >> SH;
-                wd = *(mk_lds_cu32)(uintptr_t)((flo >> (SH + 8u)) & 0xFFFCu);
-                m = mk_filter_mask(xx);
-                flo = (flo << 2) | code;
-                fl = flo;
-              };
-              probe(c0 & 3u, f0, m0, d0);
-              probe(__builtin_amdgcn_ubfe(c0, 8, 2), f1, m1, d1);
-              probe(__builtin_amdgcn_ubfe(c0, 16, 2), f2, m2, d2);
-              probe(c0 >> 24, f3, m3, d3);
-              probe(c1 & 3u, f4, m4, d4);
-              probe(__builtin_amdgcn_ubfe(c1, 8, 2), f5, m5, d5);
-              probe(__builtin_amdgcn_ubfe(c1, 16, 2), f6, m6, d6);
-              probe(c1 >> 24, f7, m7, d7);
-              __builtin_amdgcn_sched_barrier(0); /* all eight probes in flight before the first result is read */
-              /* t == 0 <=> both filter bits set.  Binary descent over the min tree: a pair without hits costs one
-               * test, a single hit about six. */
-              const uint32_t t0 = m0 & ~d0, t1 = m1 & ~d1, t2 = m2 & ~d2, t3 = m3 & ~d3;
-              const uint32_t t4 = m4 & ~d4, t5 = m5 & ~d5, t6 = m6 & ~d6, t7 = m7 & ~d7;
-              const uint32_t t01 = min(t0, t1), t23 = min(t2, t3), t45 = min(t4, t5), t67 = min(t6, t7);
-              const uint32_t ta = min(t01, t23), tb = min(t45, t67);
-#if defined(MK_ABLATE) && MK_ABLATE == 3
-              if (__any(min(ta, tb) == 0xffffffffu)) {
-#else
-              if (__any(min(ta, tb) == 0u)) {
-#endif
-                const uint32_t pos0 = col0 + 8u * p;
-                /* forward k-mer ending at base j of this pair: low word fl, high word from flo(j-16), which lies
-                 * between h3 = flo(-17) and h2 = flo(-9):  flo(-17+d) = (h3 << 2d) | ((h2 & 0xFFFF) >> (16-2d)) */
-                auto hit = [&](uint32_t t, uint32_t fl, uint32_t j) {
-                  const uint32_t dd = 2u * (j + 1u);
-                  const uint32_t fhi = ((h3 << dd) | ((h2 & 0xFFFFu) >> (16u - dd))) & HM;
-                  push(t == 0u, ((uint64_t)fhi << 32) | fl, pos0 + j);
+              if (urun + 8u < TL) { /* nobody completes a k-mer in this pair: roll only */
+                flo = (flo << 2) | (c0 & 3u);
+                flo = (flo << 2) | __builtin_amdgcn_ubfe(c0, 8, 2);
+                flo = (flo << 2) | __builtin_amdgcn_ubfe(c0, 16, 2);
+                flo = (flo << 2) | (c0 >> 24);
+                flo = (flo << 2) | (c1 & 3u);
+                flo = (flo << 2) | __builtin_amdgcn_ubfe(c1, 8, 2);
+                flo = (flo << 2) | __builtin_amdgcn_ubfe(c1, 16, 2);
+                flo = (flo << 2) | (c1 >> 24);
+              } else {
+                uint32_t f0, f1, f2, f3, f4, f5, f6, f7, m0, m1, m2, m3, m4, m5, m6, m7, d0, d1, d2, d3, d4, d5, d6, d7;
+                auto probe = [&](uint32_t code, uint32_t &fl, uint32_t &m, uint32_t &wd) {
+                  const uint32_t xx = flo >> SH;
+                  wd = *(mk_lds_cu32)(uintptr_t)((flo >> (SH + 8u)) & 0xFFFCu);
+                  m = mk_filter_mask(xx);
+                  flo = (flo << 2) | code;
+                  fl = flo;
                 };
-                if (__any(ta == 0u)) {
-                  if (__any(t01 == 0u)) { hit(t0, f0, 0); hit(t1, f1, 1); }
-                  if (__any(t23 == 0u)) { hit(t2, f2, 2); hit(t3, f3, 3); }
-                }
-                if (__any(tb == 0u)) {
-                  if (__any(t45 == 0u)) { hit(t4, f4, 4); hit(t5, f5, 5); }
-                  if (__any(t67 == 0u)) { hit(t6, f6, 6); hit(t7, f7, 7); }
+                probe(c0 & 3u, f0, m0, d0);
+                probe(__builtin_amdgcn_ubfe(c0, 8, 2), f1, m1, d1);
+                probe(__builtin_amdgcn_ubfe(c0, 16, 2), f2, m2, d2);
+                probe(c0 >> 24, f3, m3, d3);
+                probe(c1 & 3u, f4, m4, d4);
+                probe(__builtin_amdgcn_ubfe(c1, 8, 2), f5, m5, d5);
+                probe(__builtin_amdgcn_ubfe(c1, 16, 2), f6, m6, d6);
+                probe(c1 >> 24, f7, m7, d7);
+                __builtin_amdgcn_sched_barrier(0); /* all eight probes in flight before the first result is read */
+                /* t == 0 <=> all filter bits set.  Binary descent over the min tree: a pair without hits costs one
+                 * test, a single hit about six. */
+                const uint32_t t0 = m0 & ~d0, t1 = m1 & ~d1, t2 = m2 & ~d2, t3 = m3 & ~d3;
+                const uint32_t t4 = m4 & ~d4, t5 = m5 & ~d5, t6 = m6 & ~d6, t7 = m7 & ~d7;
+                const uint32_t t01 = min(t0, t1), t23 = min(t2, t3), t45 = min(t4, t5), t67 = min(t6, t7);
+                const uint32_t ta = min(t01, t23), tb = min(t45, t67);
+#if defined(MK_ABLATE) && MK_ABLATE == 3
+                if (__any(min(ta, tb) == 0xffffffffu)) {
+#else
+                if (__any(min(ta, tb) == 0u)) {
+#endif
+                  const uint32_t pos0 = col0 + 8u * p;
+                  const uint32_t jmin = urun + 1u >= TL ? 0u : TL - 1u - urun; /* first base with a complete k-mer */
+                  /* forward k-mer ending at base j of this pair: low word fl, high word from flo(j-16), which lies
+                   * between h3 = flo(-17) and h2 = flo(-9):  flo(-17+d) = (h3 << 2d) | ((h2 & 0xFFFF) >> (16-2d)) */
+                  auto hit = [&](uint32_t t, uint32_t fl, uint32_t j) {
+                    if (j < jmin || j >= e) return; /* wave-uniform: incomplete k-mer / behind the newline */
+                    const uint32_t dd = 2u * (j + 1u);
+                    const uint32_t fhi = ((h3 << dd) | ((h2 & 0xFFFFu) >> (16u - dd))) & HM;
+                    push(t == 0u, ((uint64_t)fhi << 32) | fl, pos0 + j);
+                  };
+                  if (__any(ta == 0u)) {
+                    if (__any(t01 == 0u)) { hit(t0, f0, 0); hit(t1, f1, 1); }
+                    if (__any(t23 == 0u)) { hit(t2, f2, 2); hit(t3, f3, 3); }
+                  }
+                  if (__any(tb == 0u)) {
+                    if (__any(t45 == 0u)) { hit(t4, f4, 4); hit(t5, f5, 5); }
+                    if (__any(t67 == 0u)) { hit(t6, f6, 6); hit(t7, f7, 7); }
+                  }
                 }
               }
               h3 = h2; h2 = fstart;
-              if (++p == npairs) break;
+              urun += e;
+              ++p;
+              if (e < 8u) { done = true; break; } /* the common newline: every lane is finished */
+              if (p == npairs) break;
             }
             km.flo = flo;
             km.fhi = h3 & HM; /* = flo(-17) & HMASK at this pair boundary */
-            if (!have_pair) break;
+            run = urun;
+            if (!have_pair) break; /* step exhausted or tile finished */
           } else {
             w0 = nw0; w1 = nw1;
             nw0 = myrow[2 * p + 2];
@@ -544,7 +583,8 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
           h3 = h2; h2 = fstart;
           p++;
           if (__all(done)) break;
-          all_ready = __all(!done && run + 1u >= TL);
+          urun = __builtin_amdgcn_readfirstlane(run);
+          uniform = __all(!done && run == urun);
         }
       } else {
         uint32_t nw0 = myrow[0], nw1 = ndw > 1 ? myrow[1] : 0x0a0a0a0au;
