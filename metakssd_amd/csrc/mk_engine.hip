@@ -66,6 +66,7 @@ struct mk_engine {
 
   /* launch tuning (overridable through MK_SCAN_THREADS / MK_SCAN_CB for experiments) */
   int tune_threads = 1024;
+  bool tune_onepass = true;
   uint32_t tune_cb = MK_MAX_CB;
 
   bool profiling = false;
@@ -220,6 +221,7 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   MK_HIP(e, hipMalloc(&e->d_cand_count, (size_t)e->cand_slots * sizeof(uint32_t)));
   MK_HIP(e, hipMemset(e->d_cand_count, 0, (size_t)e->cand_slots * sizeof(uint32_t)));
   if (const char *t = getenv("MK_SCAN_THREADS")) { int v = atoi(t); if (v == 512 || v == 768 || v == 1024) e->tune_threads = v; }
+  if (const char *t = getenv("MK_SCAN_ONEPASS")) e->tune_onepass = atoi(t) != 0;
   if (const char *t = getenv("MK_SCAN_CB")) { int v = atoi(t); if (v >= 16 && v <= MK_MAX_CB && v % 16 == 0) e->tune_cb = (uint32_t)v; }
   return MK_OK;
 }
@@ -311,27 +313,33 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
 }
 
 /* ---- scan launch -------------------------------------------------------------------------------------- */
-template <int K, bool V, int T, int NP>
+template <int K, bool V, int T, int NP, bool OP>
 static hipError_t mk_launch_scan_t(const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t r = hipFuncSetAttribute((const void *)mk_scan_kernel<K, V, T, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t r = hipFuncSetAttribute((const void *)mk_scan_kernel<K, V, T, NP, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (r != hipSuccess) return r;
     configured = lds;
   }
-  hipLaunchKernelGGL((mk_scan_kernel<K, V, T, NP>), grid, dim3(T), lds, s, a);
+  hipLaunchKernelGGL((mk_scan_kernel<K, V, T, NP, OP>), grid, dim3(T), lds, s, a);
   return hipGetLastError();
 }
 template <int K, bool V>
-static hipError_t mk_launch_scan_k(int threads, const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
+static hipError_t mk_launch_scan_k(int threads, bool onepass, const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
   /* piece registers: 16-byte path CB <= 80 -> 5 pieces, CB <= 128 -> 8; 4-byte path up to 32 */
   constexpr int NPBIG = V ? MK_MAX_PIECES : MK_MAX_CB / 4;
   constexpr int NPSMALL = V ? 5 : 20;
   const bool small = a.ppr <= (uint32_t)NPSMALL;
+  if constexpr (V) {
+    if (onepass && small) /* one-pass staging: 2 x 5 pieces live */
+      return threads >= 1024 ? mk_launch_scan_t<K, V, 1024, NPSMALL, true>(a, grid, lds, s)
+             : threads >= 768 ? mk_launch_scan_t<K, V, 768, NPSMALL, true>(a, grid, lds, s)
+                              : mk_launch_scan_t<K, V, 512, NPSMALL, true>(a, grid, lds, s);
+  }
   switch (threads) {
-    case 1024: return small ? mk_launch_scan_t<K, V, 1024, NPSMALL>(a, grid, lds, s) : mk_launch_scan_t<K, V, 1024, NPBIG>(a, grid, lds, s);
-    case 768: return small ? mk_launch_scan_t<K, V, 768, NPSMALL>(a, grid, lds, s) : mk_launch_scan_t<K, V, 768, NPBIG>(a, grid, lds, s);
-    default: return small ? mk_launch_scan_t<K, V, 512, NPSMALL>(a, grid, lds, s) : mk_launch_scan_t<K, V, 512, NPBIG>(a, grid, lds, s);
+    case 1024: return small ? mk_launch_scan_t<K, V, 1024, NPSMALL, false>(a, grid, lds, s) : mk_launch_scan_t<K, V, 1024, NPBIG, false>(a, grid, lds, s);
+    case 768: return small ? mk_launch_scan_t<K, V, 768, NPSMALL, false>(a, grid, lds, s) : mk_launch_scan_t<K, V, 768, NPBIG, false>(a, grid, lds, s);
+    default: return small ? mk_launch_scan_t<K, V, 512, NPSMALL, false>(a, grid, lds, s) : mk_launch_scan_t<K, V, 512, NPBIG, false>(a, grid, lds, s);
   }
 }
 
@@ -359,6 +367,8 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   a.kp = e->kp;
   a.tab = e->tab;
   a.cand_fwd = e->d_cand_fwd; a.cand_ord = e->d_cand_ord; a.cand_count = e->d_cand_count; a.cand_cap = e->cand_cap;
+  /* one-pass staging needs exactly two equal column blocks (stride == 2*CB) on the 16-byte path */
+  const bool onepass = e->tune_onepass && vec && a.ncb == 2 && stride == 2u * a.CB && a.ppr <= 5u;
   /* workgroup size: as many waves as the LDS budget (filter + per-wave tile and queue) admits */
   int threads = e->tune_threads;
   size_t lds = 0;
@@ -374,8 +384,8 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   dim3 grid((unsigned)blocks);
   if (getenv("MK_DEBUG")) {
     static int once = 0;
-    if (!once++) fprintf(stderr, "scan cfg: threads %d blocks %llu CB %u ncb %u rowdw %u lds %zu B\n", threads,
-                         (unsigned long long)blocks, a.CB, a.ncb, a.rowdw, lds);
+    if (!once++) fprintf(stderr, "scan cfg: threads %d blocks %llu CB %u ncb %u rowdw %u lds %zu B onepass %d\n", threads,
+                         (unsigned long long)blocks, a.CB, a.ncb, a.rowdw, lds, (int)onepass);
   }
 
   mk_evpair ev{};
@@ -383,9 +393,9 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   hipError_t r;
   /* tuned kernels: 24-bit inner substring (subk 6), k in {10,11}, every column block a whole number of 8-base pairs */
   switch ((e->P.subk == 6 && stride % 8u == 0 && a.CB % 8u == 0) ? e->P.k : 0) {
-    case 11: r = vec ? mk_launch_scan_k<11, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<11, false>(threads, a, grid, lds, e->stream); break;
-    case 10: r = vec ? mk_launch_scan_k<10, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<10, false>(threads, a, grid, lds, e->stream); break;
-    default: r = vec ? mk_launch_scan_k<0, true>(threads, a, grid, lds, e->stream) : mk_launch_scan_k<0, false>(threads, a, grid, lds, e->stream); break;
+    case 11: r = vec ? mk_launch_scan_k<11, true>(threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<11, false>(threads, false, a, grid, lds, e->stream); break;
+    case 10: r = vec ? mk_launch_scan_k<10, true>(threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<10, false>(threads, false, a, grid, lds, e->stream); break;
+    default: r = vec ? mk_launch_scan_k<0, true>(threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<0, false>(threads, false, a, grid, lds, e->stream); break;
   }
   if (r != hipSuccess) return mk_fail(e, MK_ERR_HIP, "scan launch: %s", hipGetErrorString(r));
   if (e->profiling) {

@@ -225,7 +225,10 @@ __device__ __forceinline__ uint32_t mk_nonzero_bytes(uint32_t v) { /* bit 7 of b
   return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
 }
 
-template <int K, bool VEC16, int THREADS, int NPIECES>
+/* ONEPASS (only with exactly two column blocks per row): the loads for BOTH blocks of a tile are issued together,
+ * so every 64-byte sector of the rows is requested once -- two separate 80-byte passes re-fetch the sector the
+ * halves share (+37 % HBM reads, tools/ubench_fetch.hip).  Costs NPIECES more piece registers. */
+template <int K, bool VEC16, int THREADS, int NPIECES, bool ONEPASS>
 __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) {
   extern __shared__ __align__(16) uint32_t lds[];
   constexpr uint32_t WAVES = THREADS / 64;
@@ -269,22 +272,36 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   constexpr int NP = NPIECES; /* pieces per lane per step: >= a.ppr (host picks the smallest instantiation) */
   constexpr uint32_t PW = VEC16 ? 16u : 4u;
   piece_t regs[NP];
-  uint32_t goff[NP], loff[NP];
-#pragma unroll
-  for (int i = 0; i < NP; i++) {
-    const uint32_t q = lane + 64u * i;
-    const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr;
-    goff[i] = r * a.stride + c * PW;
-    loff[i] = r * a.rowdw + c * (PW / 4u);
-  }
+  piece_t regs2[ONEPASS ? NP : 1]; /* second column block of the same tile */
+  /* row r_i and column c_i of piece i never change; the two offsets derived from them are recomputed where
+   * needed (a handful of ops per piece per step) rather than held in 2*NP registers */
+  auto goff_of = [&](int i) { const uint32_t q = lane + 64u * i; const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr; return r * a.stride + c * PW; };
+  auto loff_of = [&](int i) { const uint32_t q = lane + 64u * i; const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr; return r * a.rowdw + c * (PW / 4u); };
   auto issue_loads = [&](uint64_t tile_id, uint32_t cb) {
     const uint64_t row0 = tile_id << 6;
     const uint8_t *base = a.rows + row0 * a.stride + (uint64_t)cb * a.CB;
     const uint32_t cols_here = min(a.CB, a.stride - cb * a.CB);
-    if (row0 + 64u <= a.nreads && cols_here == a.CB) { /* full tile, full block: no predicates */
+    if constexpr (ONEPASS) {
+      /* host guarantees: ncb == 2, stride == 2*CB.  cb is 0 here. */
+      if (row0 + 64u <= a.nreads) {
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+          if ((uint32_t)i < a.ppr) { regs[i] = *(const piece_t *)(base + goff_of(i)); regs2[i] = *(const piece_t *)(base + a.CB + goff_of(i)); }
+      } else {
+        const uint32_t rows_here = (uint32_t)(a.nreads - row0);
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+          if ((uint32_t)i < a.ppr) {
+            const uint32_t q = lane + 64u * i;
+            const uint32_t r = (q * a.ppr_inv) >> 20;
+            if (r < rows_here) { regs[i] = *(const piece_t *)(base + goff_of(i)); regs2[i] = *(const piece_t *)(base + a.CB + goff_of(i)); }
+          }
+        }
+      }
+    } else if (row0 + 64u <= a.nreads && cols_here == a.CB) { /* full tile, full block: no predicates */
 #pragma unroll
       for (int i = 0; i < NP; i++)
-        if ((uint32_t)i < a.ppr) regs[i] = *(const piece_t *)(base + goff[i]);
+        if ((uint32_t)i < a.ppr) regs[i] = *(const piece_t *)(base + goff_of(i));
     } else {
       const uint32_t rows_here = (uint32_t)(a.nreads - row0 < 64u ? a.nreads - row0 : 64u);
 #pragma unroll
@@ -293,20 +310,26 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
           const uint32_t q = lane + 64u * i;
           const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr;
           /* rows past the last read and columns past the stride are never looked at: do not load them */
-          if (r < rows_here && c * PW < cols_here) regs[i] = *(const piece_t *)(base + goff[i]);
+          if (r < rows_here && c * PW < cols_here) regs[i] = *(const piece_t *)(base + goff_of(i));
         }
       }
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](uint32_t cb) {
+    (void)cb;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       if ((uint32_t)i < a.ppr) {
         if constexpr (VEC16) {
-          uint32_t *p = tile + loff[i];
-          p[0] = regs[i].x; p[1] = regs[i].y; p[2] = regs[i].z; p[3] = regs[i].w;
+          uint32_t *p = tile + loff_of(i);
+          if constexpr (ONEPASS) {
+            const piece_t v = cb ? regs2[i] : regs[i]; /* cb is wave-uniform */
+            p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+          } else {
+            p[0] = regs[i].x; p[1] = regs[i].y; p[2] = regs[i].z; p[3] = regs[i].w;
+          }
         } else {
-          tile[loff[i]] = regs[i];
+          tile[loff_of(i)] = regs[i];
         }
       }
     }
@@ -433,24 +456,16 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     done = row0 + lane >= a.nreads;
     ord_row = (a.first_ord + row0 + lane) << 12;
     for (uint32_t cb = 0; cb < a.ncb; cb++) {
-#if defined(MK_ABLATE) && (MK_ABLATE == 2 || MK_ABLATE == 4)
-      if (tile_id == wave_global) { /* ablation: stage only the first tile, reuse it */
-#endif
       mk_wave_lds_fence();
-      commit();
-#if defined(MK_ABLATE) && MK_ABLATE == 7
-      mk_wave_lds_fence(); commit(); /* marginal cost of one more LDS commit */
-#endif
+      commit(cb);
       mk_wave_lds_fence();
-      if (++nt_cb == a.ncb) { nt_cb = 0; nt_tile += nwaves; }
-      if (nt_tile < ntiles) issue_loads(nt_tile, nt_cb);
-#if defined(MK_ABLATE) && MK_ABLATE == 8
-      __builtin_amdgcn_sched_barrier(0);
-      if (nt_tile < ntiles) issue_loads(nt_tile, nt_cb); /* marginal cost of one more set of global loads */
-#endif
-#if defined(MK_ABLATE) && (MK_ABLATE == 2 || MK_ABLATE == 4)
+      if constexpr (ONEPASS) {
+        /* both halves of this tile are in registers; the next tile's loads go out once the second half is in LDS */
+        if (cb == 1u) { nt_tile += nwaves; if (nt_tile < ntiles) issue_loads(nt_tile, 0u); }
+      } else {
+        if (++nt_cb == a.ncb) { nt_cb = 0; nt_tile += nwaves; }
+        if (nt_tile < ntiles) issue_loads(nt_tile, nt_cb);
       }
-#endif
       if (__all(done)) continue;
 
       const uint32_t col0 = cb * a.CB;
