@@ -145,9 +145,11 @@ def main():
                 empty = (pk[:0].to(xdev), pc[:0].to(xdev), po[:0].to(xdev))
                 for (k, c, o) in gather_partials(*empty, 0, dst=0):
                     k, c, o = k.to(dev), c.to(dev), o.to(dev)
+                    # the engine runs on torch's current stream: the import is ordered after the receives/copies;
+                    # the tensors must outlive the import kernel, hence the engine-side sync before they are dropped
                     torch.cuda.current_stream().synchronize()
                     eng.partial_import(k.data_ptr(), c.data_ptr(), o.data_ptr(), k.numel())
-                    torch.cuda.current_stream().synchronize()  # k,c,o must outlive the import kernel
+                    eng.sync()
         if rank == 0:
             if flags["keep"]:
                 result["sketch"] = eng.finish()
@@ -189,10 +191,20 @@ def main():
             import numpy as np
             allreads = torch.empty(world * n * STRIDE, dtype=torch.uint8, device=dev)
             capi.synth_rows_device(local_rank, stream, SEED, 0, world * n, READ_LEN, STRIDE, allreads.data_ptr())
+            torch.cuda.synchronize()
             eng.begin(capi.MK_MODE_KOC)
             eng.push_reads_device(allreads.data_ptr(), STRIDE, world * n, 0)
             single = eng.finish()
             verified = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(single, result["sketch"]))
+            if not verified:
+                a, b = single[0], result["sketch"][0]
+                ka = np.sort(a[0].astype(np.uint64) << np.uint64(16) | a[1].astype(np.uint64))
+                kb = np.sort(b[0].astype(np.uint64) << np.uint64(16) | b[1].astype(np.uint64))
+                result["verify_detail"] = {"n_single": int(len(a[0])), "n_merged": int(len(b[0])),
+                                           "same_multiset": bool(len(ka) == len(kb) and np.array_equal(ka, kb)),
+                                           "first_diff": int(np.argmax(a[0][:min(len(a[0]), len(b[0]))] != b[0][:min(len(a[0]), len(b[0]))]))
+                                           if len(a[0]) and len(b[0]) else -1,
+                                           "only_single": int(len(np.setdiff1d(ka, kb))), "only_merged": int(len(np.setdiff1d(kb, ka)))}
             del allreads
         flags["keep"] = False
 
@@ -235,6 +247,8 @@ def main():
         }
         if verified is not None:
             line["merged_equals_single_engine"] = bool(verified)
+            if "verify_detail" in result:
+                line["verify_detail"] = result["verify_detail"]
         if args.backend != "nccl":
             line["config"]["parallelism"] += " (debug transport: %s%s)" % (args.backend, ", same device" if args.same_device else "")
         if world == 1 and not args.no_cpu_baseline:

@@ -118,8 +118,11 @@ typedef struct mk_profile {
 int mk_device_count(int *n);
 int mk_engine_create(const mk_params *p, int device, mk_engine **out);
 int mk_engine_destroy(mk_engine *e);
-/* run all engine work on a caller-owned hipStream_t (e.g. torch's current stream); NULL = engine's own */
+/* Run all engine work on a caller-owned hipStream_t (e.g. torch's current stream) so that it is ordered with the
+ * caller's own work on that stream.  NULL selects HIP's default stream (that is what torch.cuda.current_stream()
+ * normally is), NOT the engine's own stream: mk_engine_use_own_stream() goes back to that (the initial state). */
 int mk_engine_set_stream(mk_engine *e, void *hip_stream);
+int mk_engine_use_own_stream(mk_engine *e);
 const char *mk_last_error(const mk_engine *e); /* e may be NULL: last error of a failed create */
 
 int mk_sketch_begin(mk_engine *e, int mode);

@@ -76,6 +76,7 @@ def _load():
         "mk_engine_create": [C.POINTER(ParamsC), C.c_int, C.POINTER(vp)],
         "mk_engine_destroy": [vp],
         "mk_engine_set_stream": [vp, vp],
+        "mk_engine_use_own_stream": [vp],
         "mk_sketch_begin": [vp, C.c_int],
         "mk_sketch_push_reads": [vp, vp, u32, u64, u64],
         "mk_sketch_push_reads_device": [vp, vp, u32, u64, u64],
@@ -235,7 +236,11 @@ class Engine:
             pass
 
     def set_stream(self, stream_handle):
-        _check(lib.mk_engine_set_stream(self.h, C.c_void_p(stream_handle)), self.h)
+        """run the engine's work on this hipStream_t handle (0/None = HIP's default stream, e.g. torch's current stream)"""
+        _check(lib.mk_engine_set_stream(self.h, C.c_void_p(stream_handle or None)), self.h)
+
+    def use_own_stream(self):
+        _check(lib.mk_engine_use_own_stream(self.h), self.h)
 
     def begin(self, mode=MK_MODE_KOC):
         _check(lib.mk_sketch_begin(self.h, mode), self.h)

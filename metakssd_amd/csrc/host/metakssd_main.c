@@ -252,6 +252,7 @@ int main(int argc, char **argv) {
   if (files.n == 0) die("not valid raw seq format");
 
   double t0 = now_s();
+  const int dbg = getenv("MK_DEBUG") != NULL;
   mk_shuf sh;
   int rc = mk_shuf_read(shuf_path, &sh);
   if (rc != MK_OK) die("read_dim_shuffle_file(): cannot read %s (%d)", shuf_path, rc);
@@ -260,11 +261,14 @@ int main(int argc, char **argv) {
   if (rc != MK_OK) die("get_hashsz(): primer_ind out of range(0 ~ 24) for k=%d drlevel=%d (command_dist.c:291-303)", sh.k, sh.drlevel);
   if (!quiet) printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%u\thashlimit=%u\n", P.shuf_id, P.k, P.hashsize, P.hashlimit);
 
+  if (dbg) fprintf(stderr, "[t] shuf read + params: %.3f s\n", now_s() - t0);
   ctx_t c = {0};
   rc = mk_engine_create(&P, device, &c.eng);
   if (rc != MK_OK) die("mk_engine_create failed (%d): %s", rc, mk_last_error(NULL));
+  if (dbg) fprintf(stderr, "[t] + engine create: %.3f s\n", now_s() - t0);
   c.io = malloc(IOBUF);
   if (!c.io || mk_host_alloc((void **)&c.rows, ROWBUF) != MK_OK) die("out of memory");
+  if (dbg) fprintf(stderr, "[t] + host buffers: %.3f s\n", now_s() - t0);
 
   /* -A is switched off for good by the first non-FASTQ input (command_dist.c:389-392) */
   for (int i = 0; i < files.n; i++)
@@ -288,6 +292,7 @@ int main(int argc, char **argv) {
       CHECK(c.eng, mk_sketch_begin(c.eng, uniq ? MK_MODE_UNIQ_SET : MK_MODE_SET));
       sketch_fasta(&c, path, P.TL);
     }
+    if (dbg) fprintf(stderr, "[t] + framing/push of %s: %.3f s\n", path, now_s() - t0);
     mk_result res;
     rc = mk_sketch_finish(c.eng, &res);
     if (rc == MK_ERR_CROWDED) die("the context space is too crowd, try rerun the program using -k%d", P.k + 1);
@@ -298,12 +303,14 @@ int main(int argc, char **argv) {
     if (!quiet) printf("%d/%d decomposing %s\r", i + 1, files.n, path);
   }
   if (!quiet) printf("\n");
+  if (dbg) fprintf(stderr, "[t] + finish/write: %.3f s\n", now_s() - t0);
   rc = mk_sketchdir_close(sd);
   if (rc != MK_OK) die("closing sketch directory failed (%d)", rc);
   if (!quiet) printf("sketched %llu rows from %d file(s) in %.3f s\n", (unsigned long long)c.nrows_total, files.n, now_s() - t0);
   mk_host_free(c.rows);
   free(c.io);
   mk_engine_destroy(c.eng);
+  if (dbg) fprintf(stderr, "[t] + teardown: %.3f s\n", now_s() - t0);
   mk_shuf_free(&sh);
   return 0;
 }

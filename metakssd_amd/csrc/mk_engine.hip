@@ -250,7 +250,14 @@ extern "C" int mk_engine_create(const mk_params *p, int device, mk_engine **out)
 
 extern "C" int mk_engine_set_stream(mk_engine *e, void *hip_stream) {
   if (!e) return MK_ERR_ARG;
-  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  /* NULL is a real stream (HIP's default stream, which is what torch.cuda.current_stream() usually is): it must
+   * not mean "keep the engine's own stream", or caller-side ordering silently disappears */
+  e->stream = (hipStream_t)hip_stream;
+  return MK_OK;
+}
+extern "C" int mk_engine_use_own_stream(mk_engine *e) {
+  if (!e) return MK_ERR_ARG;
+  e->stream = e->own_stream;
   return MK_OK;
 }
 

@@ -542,6 +542,9 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                 probe(__builtin_amdgcn_ubfe(c1, 16, 2), f6, m6, d6);
                 probe(c1 >> 24, f7, m7, d7);
                 __builtin_amdgcn_sched_barrier(0); /* all eight probes in flight before the first result is read */
+#ifndef MK_NO_SINGLE_WAIT
+                __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) once, instead of a staggered wait per probe */
+#endif
                 /* t == 0 <=> all filter bits set.  Binary descent over the min tree: a pair without hits costs one
                  * test, a single hit about six. */
                 const uint32_t t0 = m0 & ~d0, t1 = m1 & ~d1, t2 = m2 & ~d2, t3 = m3 & ~d3;
@@ -720,18 +723,25 @@ __global__ void __launch_bounds__(256) mk_layout_kernel(mk_dist d, uint64_t D, u
     uint32_t n, h2;
     mk_probe_init(d.key[cur], S, n, h2);
     uint64_t guard = 0;
+    /* the first look at a slot is an L2-served load, which may be stale (per-XCD L2s are not coherent; the CAS
+     * itself executes memory-side and is authoritative): after a failed CAS continue from the value IT returned,
+     * never from a re-load.  A stale first look is harmless: occupants only ever get EARLIER, so "the occupant I
+     * saw is earlier than me" stays true, and "later than me / empty" is re-checked by the CAS. */
+    uint32_t old = __hip_atomic_load(&slot[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
       if (++guard > 8ull * S) { atomicOr(&err[0], 2u); break; }
-      uint32_t old = __hip_atomic_load(&slot[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old == MK_EMPTY32) {
-        if (atomicCAS(&slot[n], MK_EMPTY32, cur) == MK_EMPTY32) break;
-        continue; /* lost the race: look at the new occupant */
+      if (old != MK_EMPTY32 && d.ord[old] < ord) { /* an earlier key keeps the slot: next probe */
+        n = mk_probe_next(n, h2, S);
+        old = __hip_atomic_load(&slot[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
       }
-      if (d.ord[old] < ord) { n = mk_probe_next(n, h2, S); continue; } /* earlier key keeps the slot */
-      if (atomicCAS(&slot[n], old, cur) != old) continue;
-      cur = old; /* evicted: re-walk its own sequence (everything before this slot is held by earlier keys) */
+      const uint32_t prev = atomicCAS(&slot[n], old, cur);
+      if (prev != old) { old = prev; continue; } /* somebody else changed the slot: judge the real occupant */
+      if (old == MK_EMPTY32) break;              /* took an empty slot: done */
+      cur = old; /* evicted a later key: re-walk its own sequence (everything before this slot is held by earlier keys) */
       ord = d.ord[cur];
       mk_probe_init(d.key[cur], S, n, h2);
+      old = __hip_atomic_load(&slot[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
