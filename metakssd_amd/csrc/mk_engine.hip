@@ -437,7 +437,18 @@ extern "C" int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev
   if (rc) return rc;
   MK_HIP(e, hipSetDevice(e->device));
   if ((first_read_ordinal + nreads) >> 51) return mk_fail(e, MK_ERR_ARG, "read ordinal too large");
-  return mk_launch_scan(e, rows_dev, stride, nreads, first_read_ordinal);
+  /* one launch per at most `per` reads: every scan wave then sees few enough tiles that its candidate append
+   * buffer (cand_cap entries, ~9-16 candidates per 64-read tile at the usual 1/4096 accept rate) does not
+   * overflow into the slow inline path */
+  const uint64_t waves = (uint64_t)e->num_cu * (uint64_t)(e->tune_threads / 64);
+  uint64_t per = (uint64_t)(e->cand_cap / 32u) * 64u * waves;
+  if (per < 64u * waves) per = 64u * waves;
+  for (uint64_t done = 0; done < nreads; done += per) {
+    const uint64_t n = nreads - done < per ? nreads - done : per;
+    int rc2 = mk_launch_scan(e, rows_dev + done * stride, stride, n, first_read_ordinal + done);
+    if (rc2) return rc2;
+  }
+  return MK_OK;
 }
 
 extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t stride, uint64_t nreads,
