@@ -95,3 +95,53 @@ def test_product_cli_reproduces_reference_golden(case, shuf_files, tmp_path):
         return
     assert r.returncode == 0, r.stderr.decode()
     check_against_golden(case, out, inp)
+
+
+def _write_multi_inputs(d):
+    """three FASTA genomes + (separately) three FASTQ files, deterministic"""
+    import numpy as np
+    import util_inputs as ui
+    rs = np.random.RandomState(77)
+    fa, fq = [], []
+    os.makedirs(os.path.join(d, "genomes"))
+    os.makedirs(os.path.join(d, "reads"))
+    for i, n in enumerate((9000, 14000, 5000)):
+        g = ui.rand_seq(rs, n)
+        p = os.path.join(d, "genomes", "g%d.%s" % (i, ("fa", "fna", "fasta")[i]))
+        open(p, "wb").write(ui.fasta_bytes([g[: n // 2], g[n // 2:]], width=(60, 70, 80)[i]))
+        fa.append(p)
+    for i, n in enumerate((300, 1, 120)):
+        p = os.path.join(d, "reads", "s%d.fq" % i)
+        open(p, "wb").write(ui.fastq_bytes(ui.pool_reads(rs, 5000, n)))
+        fq.append(p)
+    return sorted(fa), sorted(fq)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,shuf,flags", [("fasta", "L1K7", []), ("fasta", "L1K7", ["-u"]), ("fasta", "L2K11", []),
+                                               ("fastq", "L1K7", ["-A"]), ("fastq", "L0K6", ["-A"])])
+def test_product_cli_multi_file_directory_equals_oracle(kind, shuf, flags, shuf_files, tmp_path):
+    """stage-I bookkeeping over several inputs (command_dist.c:408-500): per-file blocks in input order,
+    combco.index.N cumulative counts, cofiles.stat counts and names.  The product CLI expands a directory in sorted
+    order; the oracle CLI (pinned to the reference) gets the same files in that order."""
+    fa, fq = _write_multi_inputs(str(tmp_path))
+    files = fa if kind == "fasta" else fq
+    dir_arg = os.path.dirname(files[0])
+    out_p, out_o = str(tmp_path / "out_product"), str(tmp_path / "out_oracle")
+    r = subprocess.run([PRODUCT_CLI, "dist", "-L", shuf_files(shuf)] + flags + ["-o", out_p, dir_arg],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    r = subprocess.run([ORACLE_CLI, "-L", shuf_files(shuf)] + flags + ["-o", out_o] + files,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    names_p = sorted(f for f in os.listdir(out_p) if f.startswith("combco"))
+    names_o = sorted(f for f in os.listdir(out_o) if f.startswith("combco"))
+    assert names_p == names_o and names_p
+    for f in names_p:
+        assert filecmp.cmp(os.path.join(out_p, f), os.path.join(out_o, f), shallow=False), f
+    sp, np_ = parse_stat(os.path.join(out_p, "cofiles.stat"))
+    so, no_ = parse_stat(os.path.join(out_o, "cofiles.stat"))
+    assert sp == so and np_ == no_ == files
+    assert sp["infile_num"] == 3 and sum(sp["ctx_ct"]) == sp["all_ctx_ct"]
+    idx = struct.unpack("<4Q", open(os.path.join(out_p, "combco.index.0"), "rb").read())
+    assert idx[0] == 0 and list(idx) == sorted(idx)
