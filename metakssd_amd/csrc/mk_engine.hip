@@ -42,8 +42,9 @@ struct mk_engine {
   mk_table tab{};
   uint32_t *d_slot = nullptr;
   mk_dist dist{};
-  uint32_t *d_chunk = nullptr;
+  uint32_t *d_chunk = nullptr; /* [component][chunk] */
   uint32_t nchunks = 0;
+  unsigned long long *d_comp_totals = nullptr, *h_comp_totals = nullptr; /* [component] */
   unsigned long long *d_counters = nullptr; /* [0]=distinct, [1]=dump total, [2..3]=err flags (as u32) */
   unsigned long long *h_counters = nullptr; /* pinned mirror */
   uint32_t *d_out_ids = nullptr;
@@ -125,7 +126,8 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipFree(e->d_cand_fwd); hipFree(e->d_cand_ord); hipFree(e->d_cand_count);
   hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_accept_bits); hipFree(e->d_tab); hipFree(e->d_slot);
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
-  hipFree(e->d_chunk); hipFree(e->d_counters); hipFree(e->d_out_ids); hipFree(e->d_out_cnt);
+  hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters);
+  if (e->h_comp_totals) hipHostFree(e->h_comp_totals); hipFree(e->d_out_ids); hipFree(e->d_out_cnt);
   if (e->h_counters) hipHostFree(e->h_counters);
   if (e->h_ids) hipHostFree(e->h_ids);
   if (e->h_cnt) hipHostFree(e->h_cnt);
@@ -207,7 +209,10 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   MK_HIP(e, hipMalloc(&e->dist.ord, e->dist.cap * 8));
   MK_HIP(e, hipMalloc(&e->dist.cnt, e->dist.cap * 4));
   e->nchunks = (uint32_t)((S + MK_DUMP_CHUNK - 1) / MK_DUMP_CHUNK);
-  MK_HIP(e, hipMalloc(&e->d_chunk, (size_t)e->nchunks * sizeof(uint32_t)));
+  if (p->component_num > (int)MK_MAX_COMP) return mk_fail(e, MK_ERR_ARG, "component_num %d > %u", p->component_num, MK_MAX_COMP);
+  MK_HIP(e, hipMalloc(&e->d_chunk, (size_t)e->nchunks * (size_t)p->component_num * sizeof(uint32_t)));
+  MK_HIP(e, hipMalloc(&e->d_comp_totals, MK_MAX_COMP * sizeof(unsigned long long)));
+  MK_HIP(e, hipHostMalloc((void **)&e->h_comp_totals, MK_MAX_COMP * sizeof(unsigned long long), hipHostMallocDefault));
   MK_HIP(e, hipMalloc(&e->d_counters, 8 * sizeof(unsigned long long)));
   MK_HIP(e, hipMemset(e->d_counters, 0, 8 * sizeof(unsigned long long)));
   MK_HIP(e, hipHostMalloc((void **)&e->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -593,21 +598,39 @@ extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
     da.uniq_only = e->mode == MK_MODE_UNIQ_SET;
     da.nchunks = e->nchunks;
     const unsigned dblocks = (e->nchunks + 3) / 4; /* 4 waves (chunks) per 256-thread block */
-    for (int c = 0; c < C; c++) {
-      da.comp = (uint32_t)c;
+    if (C == 1) {
+      da.comp = 0;
       hipLaunchKernelGGL(mk_dump_count_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, e->d_chunk);
       hipLaunchKernelGGL(mk_dump_scan_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_chunk, e->nchunks, e->d_counters + 1);
       hipLaunchKernelGGL(mk_dump_write_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, (const uint32_t *)e->d_chunk,
-                         e->d_out_ids + total, koc ? e->d_out_cnt + total : nullptr);
+                         e->d_out_ids, koc ? e->d_out_cnt : nullptr);
       MK_HIP(e, hipGetLastError());
       MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
       MK_HIP(e, hipStreamSynchronize(e->stream));
       const uint64_t nc = e->h_counters[1];
-      if (total + nc > D) return mk_fail(e, MK_ERR_HIP, "dump produced more entries than distinct keys");
-      e->comps[c].n = nc;
-      e->comps[c].ids = e->h_ids + total;
-      e->comps[c].counts = koc ? e->h_cnt + total : nullptr;
-      total += nc;
+      if (nc > D) return mk_fail(e, MK_ERR_HIP, "dump produced more entries than distinct keys");
+      e->comps[0].n = nc;
+      e->comps[0].ids = e->h_ids;
+      e->comps[0].counts = koc ? e->h_cnt : nullptr;
+      total = nc;
+    } else {
+      /* all components in one count pass and one write pass; components back to back in the output */
+      hipLaunchKernelGGL(mk_dumpc_count_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, e->d_chunk);
+      hipLaunchKernelGGL(mk_dumpc_scan_kernel, dim3((unsigned)C), dim3(1024), 0, e->stream, e->d_chunk, e->nchunks, e->d_comp_totals);
+      hipLaunchKernelGGL(mk_dumpc_write_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, (const uint32_t *)e->d_chunk,
+                         (const unsigned long long *)e->d_comp_totals, e->d_out_ids, koc ? e->d_out_cnt : nullptr);
+      MK_HIP(e, hipGetLastError());
+      MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+      MK_HIP(e, hipMemcpyAsync(e->h_comp_totals, e->d_comp_totals, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+      MK_HIP(e, hipStreamSynchronize(e->stream));
+      for (int c = 0; c < C; c++) {
+        const uint64_t nc = e->h_comp_totals[c];
+        if (total + nc > D) return mk_fail(e, MK_ERR_HIP, "dump produced more entries than distinct keys");
+        e->comps[c].n = nc;
+        e->comps[c].ids = e->h_ids + total;
+        e->comps[c].counts = koc ? e->h_cnt + total : nullptr;
+        total += nc;
+      }
     }
     if ((uint32_t)(e->h_counters[2] & 0xffffffffu) & 2u) return mk_fail(e, MK_ERR_HIP, "layout kernel did not converge");
     if ((uint32_t)(e->h_counters[2] & 0xffffffffu) & 4u) return mk_fail(e, MK_ERR_HIP, "scan kernel: LDS filter not at offset 0");

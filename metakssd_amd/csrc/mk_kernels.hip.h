@@ -827,6 +827,102 @@ __global__ void __launch_bounds__(256) mk_dump_write_kernel(mk_dump_args a, cons
   }
 }
 
+/* ---- slot-order dump for several components in ONE pass over the layout table (component_num is 16 whenever it
+ * is not 1: 4(k-drlevel) <= 39 bits caps k-drlevel at 9).  Same chunking as above; chunk_count is [comp][chunk]. */
+#define MK_MAX_COMP 16u
+__device__ __forceinline__ bool mk_dumpc_pred(const mk_dump_args &a, uint64_t n, uint32_t &idx, uint32_t &comp) {
+  idx = n < a.S ? a.slot[n] : MK_EMPTY32;
+  comp = 0;
+  if (idx == MK_EMPTY32) return false;
+  if (a.uniq_only && a.d.cnt[idx] != 1u) return false;
+  comp = (uint32_t)(a.d.key[idx] % a.comp_num);
+  return true;
+}
+
+__global__ void __launch_bounds__(256) mk_dumpc_count_kernel(mk_dump_args a, uint32_t *chunk_count) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (chunk >= a.nchunks) return;
+  uint32_t mine = 0; /* lane c (< comp_num) accumulates component c */
+  for (uint32_t it = 0; it < MK_DUMP_CHUNK / 64u; it++) {
+    uint32_t idx, comp;
+    const bool p = mk_dumpc_pred(a, (uint64_t)chunk * MK_DUMP_CHUNK + it * 64u + lane, idx, comp);
+    uint64_t rest = __ballot(p);
+    while (rest) { /* one round per distinct component present among the 64 slots */
+      const uint32_t c = __shfl(comp, (int)__builtin_ctzll(rest));
+      const uint64_t m = __ballot(p && comp == c);
+      if (lane == c) mine += (uint32_t)__popcll(m);
+      rest &= ~m;
+    }
+  }
+  if (lane < a.comp_num) chunk_count[(size_t)lane * a.nchunks + chunk] = mine;
+}
+
+/* one workgroup per component: exclusive scan of that component's chunk counts; totals[c] = its size */
+__global__ void __launch_bounds__(1024) mk_dumpc_scan_kernel(uint32_t *chunk_count, uint32_t nchunks, unsigned long long *totals) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long carry_s;
+  uint32_t *cc = chunk_count + (size_t)blockIdx.x * nchunks;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nchunks; base += 1024u) {
+    const uint32_t i = base + threadIdx.x;
+    unsigned long long v = i < nchunks ? cc[i] : 0ull, incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      unsigned long long t = __shfl_up(incl, o);
+      if ((int)lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned long long woff = 0;
+    for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
+    const unsigned long long carry = carry_s;
+    if (i < nchunks) cc[i] = (uint32_t)(carry + woff + incl - v);
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+/* out_ids/out_cnt hold the components back to back: component c starts at sum(totals[0..c)) */
+__global__ void __launch_bounds__(256) mk_dumpc_write_kernel(mk_dump_args a, const uint32_t *chunk_off,
+                                                             const unsigned long long *totals, uint32_t *out_ids,
+                                                             uint16_t *out_cnt) {
+  __shared__ uint32_t wbase[4][MK_MAX_COMP];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (chunk >= a.nchunks) return;
+  if (lane < a.comp_num) {
+    unsigned long long start = 0;
+    for (uint32_t c = 0; c < lane; c++) start += totals[c];
+    wbase[wave][lane] = (uint32_t)start + chunk_off[(size_t)lane * a.nchunks + chunk];
+  }
+  mk_wave_lds_fence();
+  for (uint32_t it = 0; it < MK_DUMP_CHUNK / 64u; it++) {
+    uint32_t idx, comp;
+    const bool p = mk_dumpc_pred(a, (uint64_t)chunk * MK_DUMP_CHUNK + it * 64u + lane, idx, comp);
+    uint64_t rest = __ballot(p);
+    while (rest) {
+      const uint32_t c = __shfl(comp, (int)__builtin_ctzll(rest));
+      const bool sel = p && comp == c;
+      const uint64_t m = __ballot(sel);
+      const uint32_t base = wbase[wave][c];
+      if (sel) {
+        const uint32_t o = base + mk_mbcnt(m);
+        out_ids[o] = (uint32_t)(a.d.key[idx] >> a.comp_code_bits);
+        if (out_cnt) out_cnt[o] = (uint16_t)a.d.cnt[idx];
+      }
+      mk_wave_lds_fence();
+      if (lane == 0) wbase[wave][c] = base + (uint32_t)__popcll(m);
+      mk_wave_lds_fence();
+      rest &= ~m;
+    }
+  }
+}
+
 /* ---- synthetic reads: 16 bytes of one row per thread ------------------------------------------------- */
 __global__ void __launch_bounds__(256) mk_synth_kernel(uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len,
                                                        uint32_t stride, uint8_t *rows) {
