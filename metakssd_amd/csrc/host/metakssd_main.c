@@ -9,14 +9,15 @@
  *
  * Differences, all documented in DESIGN.md: inputs are processed in discovery order (the reference
  * applies a time-seeded shuffle, command_dist.c:215); FASTQ without -A (the 4-bit -n/-Q path,
- * fastq2co) and every non-sketching mode of `dist` are not part of this build; -p is accepted and
- * ignored (the GPU does the work); --device selects the GPU.
+ * fastq2co) and every non-sketching mode of `dist` are not part of this build; -p N sets the number of host
+ * threads that read and frame/window input files ahead of the GPU (default 8); --device selects the GPU.
  */
 #define _GNU_SOURCE
 #include "metakssd_hip.h"
 
 #include <dirent.h>
 #include <errno.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -196,6 +197,105 @@ static void sketch_fasta(ctx_t *c, const char *path, int TL) {
   if (is_pipe) pclose(f); else fclose(f);
 }
 
+/* ---- parallel front end for many small inputs (genome directories, many small FASTQ files) ---------------
+ * The reference parallelises stage I over FILES (command_dist.c:363-366).  Here worker threads read and frame /
+ * window whole files into pinned row buffers ahead of the main thread, which pushes and finishes them strictly
+ * in input order (the order defines the sketch directory).  A file whose rows do not fit one buffer is left to
+ * the main thread's streaming path.  Buffers are handed out in file order, so the pipeline cannot deadlock. */
+#define PF_MAX_BUFS 16
+typedef struct {
+  int ready, too_big, err;   /* err: MK_ERR_* from framing */
+  int buf;                   /* pinned buffer index, -1 = none */
+  uint64_t nrows;
+  uint32_t stride;
+} pf_slot;
+typedef struct {
+  strlist *files;
+  int TL;
+  int nbufs;
+  uint8_t *bufs[PF_MAX_BUFS];
+  int free_bufs[PF_MAX_BUFS], nfree;
+  int next;                  /* next file index to prepare */
+  pf_slot *slots;
+  pthread_mutex_t mu;
+  pthread_cond_t cv_buf, cv_ready;
+} pf_t;
+
+static uint8_t *slurp(const char *path, size_t *n_out, size_t limit, int *too_big) {
+  int is_pipe;
+  FILE *f = open_input(path, &is_pipe);
+  if (!f) return NULL;
+  size_t cap = (size_t)8 << 20, n = 0;
+  uint8_t *b = malloc(cap);
+  for (;;) {
+    if (n == cap) {
+      if (cap >= limit) { *too_big = 1; break; }
+      cap *= 2;
+      b = realloc(b, cap);
+    }
+    size_t r = fread(b + n, 1, cap - n, f);
+    if (r == 0) break;
+    n += r;
+  }
+  if (is_pipe) pclose(f); else fclose(f);
+  *n_out = n;
+  return b;
+}
+
+static void *pf_worker(void *arg) {
+  pf_t *pf = arg;
+  for (;;) {
+    pthread_mutex_lock(&pf->mu);
+    while (pf->next < pf->files->n && pf->nfree == 0) pthread_cond_wait(&pf->cv_buf, &pf->mu);
+    if (pf->next >= pf->files->n) { pthread_mutex_unlock(&pf->mu); return NULL; }
+    const int i = pf->next++;
+    const int b = pf->free_bufs[--pf->nfree];
+    pthread_mutex_unlock(&pf->mu);
+
+    pf_slot s = {0};
+    s.buf = b;
+    const char *path = pf->files->v[i];
+    size_t n = 0;
+    int too_big = 0;
+    uint8_t *text = slurp(path, &n, ROWBUF, &too_big);
+    if (!text) s.err = MK_ERR_IO;
+    else if (too_big) s.too_big = 1;
+    else if (is_fastq(path)) {
+      uint32_t stride = 160;
+      for (;;) {
+        uint64_t nrows = 0;
+        size_t used = 0;
+        int rc = mk_fastq_frame(text, n, 1, pf->bufs[b], stride, ROWBUF / stride, &nrows, &used);
+        if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : stride * 2; continue; }
+        if (rc != MK_OK) s.err = rc;
+        else if (used < n) s.too_big = 1; /* more rows than one buffer holds */
+        s.nrows = nrows; s.stride = stride;
+        break;
+      }
+    } else {
+      mk_fasta_state st;
+      const uint32_t stride = 512;
+      uint64_t nrows = 0;
+      size_t used = 0;
+      if (n == 0) s.err = MK_ERR_FORMAT;
+      else {
+        mk_fasta_window_init(&st, pf->TL);
+        int rc = mk_fasta_window(&st, text, n, 1, pf->bufs[b], stride, ROWBUF / stride, &nrows, &used);
+        if (rc != MK_OK) s.err = rc;
+        else if (used < n || st.fresh) s.too_big = 1;
+        s.nrows = nrows; s.stride = stride;
+      }
+    }
+    free(text);
+    pthread_mutex_lock(&pf->mu);
+    if (s.too_big || s.err) { pf->free_bufs[pf->nfree++] = b; s.buf = -1; pthread_cond_broadcast(&pf->cv_buf); }
+    s.ready = 1;
+    pf->slots[i] = s;
+    pthread_cond_broadcast(&pf->cv_ready);
+    pthread_mutex_unlock(&pf->mu);
+  }
+}
+
 static void usage(void) {
   fprintf(stderr,
           "usage: metakssd dist -L <file.shuf> [-A] [-u] [-o outdir] [-p N] [--device D] <fastq|fasta|dir>...\n"
@@ -232,12 +332,12 @@ int main(int argc, char **argv) {
   if (strcmp(argv[1], "dist") != 0) die("only the `dist` sketching path and `shuffle` are part of this build (got `%s`)", argv[1]);
 
   const char *shuf_path = NULL, *outdir = ".";
-  int abundance = 0, uniq = 0, device = 0, quiet = 0;
+  int abundance = 0, uniq = 0, device = 0, quiet = 0, nthreads = 8;
   strlist args = {0};
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "-L") && i + 1 < argc) shuf_path = argv[++i];
     else if (!strcmp(argv[i], "-o") && i + 1 < argc) outdir = argv[++i];
-    else if (!strcmp(argv[i], "-p") && i + 1 < argc) ++i; /* accepted, unused */
+    else if (!strcmp(argv[i], "-p") && i + 1 < argc) nthreads = atoi(argv[++i]); /* host front-end threads */
     else if (!strcmp(argv[i], "-A")) abundance = 1;
     else if (!strcmp(argv[i], "-u")) uniq = 1;
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
@@ -280,17 +380,57 @@ int main(int argc, char **argv) {
   rc = mk_sketchdir_open(outdir, &P, abundance, files.n, &sd);
   if (rc != MK_OK) die("cannot create sketch directory %s (%d)", outdir, rc);
 
+  /* worker threads prepare files ahead when there are several inputs */
+  pf_t pf;
+  memset(&pf, 0, sizeof pf);
+  pthread_t workers[PF_MAX_BUFS];
+  int nworkers = 0;
+  if (files.n > 1 && nthreads > 1) {
+    pf.files = &files; pf.TL = P.TL;
+    pf.nbufs = nthreads < PF_MAX_BUFS ? nthreads : PF_MAX_BUFS;
+    if (pf.nbufs > files.n) pf.nbufs = files.n;
+    pf.slots = calloc(files.n, sizeof(pf_slot));
+    pthread_mutex_init(&pf.mu, NULL);
+    pthread_cond_init(&pf.cv_buf, NULL);
+    pthread_cond_init(&pf.cv_ready, NULL);
+    for (int b = 0; b < pf.nbufs; b++) {
+      if (mk_host_alloc((void **)&pf.bufs[b], ROWBUF) != MK_OK) { pf.nbufs = b; break; }
+      pf.free_bufs[pf.nfree++] = b;
+    }
+    for (int t = 0; t < pf.nbufs; t++)
+      if (pthread_create(&workers[nworkers], NULL, pf_worker, &pf) == 0) nworkers++;
+    if (nworkers == 0) { free(pf.slots); pf.slots = NULL; }
+  }
+
   for (int i = 0; i < files.n; i++) {
     const char *path = files.v[i];
     c.next_ordinal = 0;
-    if (is_fastq(path)) {
-      if (!abundance) die("%s: FASTQ without -A (fastq2co, -n/-Q 4-bit counts) is not built yet", path);
-      if (!quiet) printf("running mt_shortreads2koc()\n");
-      CHECK(c.eng, mk_sketch_begin(c.eng, MK_MODE_KOC));
-      sketch_fastq(&c, path);
-    } else {
-      CHECK(c.eng, mk_sketch_begin(c.eng, uniq ? MK_MODE_UNIQ_SET : MK_MODE_SET));
-      sketch_fasta(&c, path, P.TL);
+    const int fq = is_fastq(path);
+    if (fq && !abundance) die("%s: FASTQ without -A (fastq2co, -n/-Q 4-bit counts) is not built yet", path);
+    if (fq && !quiet) printf("running mt_shortreads2koc()\n");
+    CHECK(c.eng, mk_sketch_begin(c.eng, fq ? MK_MODE_KOC : (uniq ? MK_MODE_UNIQ_SET : MK_MODE_SET)));
+    int handled = 0;
+    if (nworkers) {
+      pthread_mutex_lock(&pf.mu);
+      while (!pf.slots[i].ready) pthread_cond_wait(&pf.cv_ready, &pf.mu);
+      pf_slot sl = pf.slots[i];
+      pthread_mutex_unlock(&pf.mu);
+      if (sl.err == MK_ERR_IO) die("%s: cannot open", path);
+      if (sl.err == MK_ERR_FORMAT && !fq) die("fastco():eof or fread error file=%s", path);
+      if (sl.err) die("%s: sequence or header line of 4095+ characters: outside the FASTQ framing contract (iseq2comem.c:656,673)", path);
+      if (!sl.too_big) {
+        if (sl.nrows) CHECK(c.eng, mk_sketch_push_reads(c.eng, pf.bufs[sl.buf], sl.stride, sl.nrows, 0));
+        c.nrows_total += sl.nrows;
+        pthread_mutex_lock(&pf.mu); /* push returned: the buffer has been copied to the device */
+        pf.free_bufs[pf.nfree++] = sl.buf;
+        pthread_cond_broadcast(&pf.cv_buf);
+        pthread_mutex_unlock(&pf.mu);
+        handled = 1;
+      }
+    }
+    if (!handled) {
+      if (fq) sketch_fastq(&c, path);
+      else sketch_fasta(&c, path, P.TL);
     }
     if (dbg) fprintf(stderr, "[t] + framing/push of %s: %.3f s\n", path, now_s() - t0);
     mk_result res;
