@@ -2,9 +2,10 @@
  * mk_kernels.hip.h -- device code of the MI355X sketch engine (gfx950, wave64).
  *
  * Kernels (DESIGN.md has the data layout and the roofline of each):
- *   mk_scan_kernel      rows of ASCII bases -> rolling canonical k-mer -> LDS filter of the accepted
- *                       inner-substring subspace -> exact .shuf check -> key -> counted upsert.
- *                       Restates the per-read loop of mt_shortreads2koc(), iseq2comem.c:676-720
+ *   mk_scan_kernel      rows of ASCII bases -> rolling forward k-mer -> strand-symmetric LDS filter of the
+ *                       accepted inner-substring subspace -> candidates appended to per-wave HBM buffers.
+ *   mk_resolve_kernel   candidates -> canonical k-mer -> exact .shuf check -> key -> counted upsert.
+ *                       Together they restate the per-read loop of mt_shortreads2koc(), iseq2comem.c:676-720
  *                       (and of fasta2co(), :248-311, on overlapped windows).
  *   mk_import_kernel    fold another shard's {key,count,first ordinal} list into the table (multi-GPU).
  *   mk_compact_kernel   table -> dense list of distinct keys.
@@ -167,8 +168,9 @@ __global__ void __launch_bounds__(256) mk_resolve_kernel(const mk_scan_args a, u
  * substring of the reverse-complement k-mer is the reverse complement of the forward one: a k-mer can only
  * be accepted if its FORWARD inner substring is in B, whichever strand turns out to be canonical.  The hot
  * loop therefore rolls and probes the forward strand only; canonicalisation happens for filter hits, in
- * mk_drain.  One 32-bit word per probe: word = bits 10.. of the substring, two bit positions = its bits 0-4
- * and 5-9.  8192 entries in 16384 words: about 0.15 % false positives; correctness never depends on it. */
+ * mk_resolve_one.  One 32-bit word per probe: word = bits 10.. of the substring, three bit positions = its bits
+ * 0-4, 5-9 and 3-7.  8192 entries in 16384 words: about 0.06 % false positives; correctness never depends on
+ * it (every candidate is re-checked against the accept bitmap / .shuf table). */
 __device__ __forceinline__ uint32_t mk_filter_mask(uint32_t x) {
 #if defined(MK_FILTER_BITS) && MK_FILTER_BITS == 2
   return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u));
@@ -340,7 +342,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   uint32_t h2 = 0, h3 = 0; /* tuned loop: low word of the forward k-mer at the two previous pair (8-base) boundaries */
   uint32_t run = 0;  /* valid bases since the last reset (the reference's base-1) */
   bool done = true;  /* this lane's row hit its '\n' (or does not exist) */
-  uint32_t qn = 0;   /* queued candidates, wave-uniform */
+  uint32_t qn = 0;   /* candidates appended to this wave's buffer so far (wave-uniform) */
   const uint32_t *myrow = tile + lane * a.rowdw;
   uint64_t ord_row = 0;
 
