@@ -172,15 +172,13 @@ __global__ void __launch_bounds__(256) mk_resolve_kernel(const mk_scan_args a, u
  * 0-4, 5-9 and 3-7.  8192 entries in 16384 words: about 0.06 % false positives; correctness never depends on
  * it (every candidate is re-checked against the accept bitmap / .shuf table). */
 __device__ __forceinline__ uint32_t mk_filter_mask(uint32_t x) {
-#if defined(MK_FILTER_BITS) && MK_FILTER_BITS == 2
-  return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u));
-#else
-  /* third position from bits 3..7 (overlaps the other two fields, still cuts false positives ~3x) */
-#if defined(MK_FILTER_BITS) && MK_FILTER_BITS == 4
-  return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u)) | (1u << ((x >> 3) & 31u)) | (1u << ((x >> 7) & 31u));
-#else
+#if defined(MK_FILTER_OLD)
   return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u)) | (1u << ((x >> 3) & 31u));
-#endif
+#else
+  /* bit positions = the 5-bit fields at offsets 0, 2 and 6 of the substring.  EVEN offsets on purpose: the
+   * substring slides by one base (2 bits) per step, so field 2k of this base's substring is the low 5 bits of
+   * the substring k bases earlier -- in the tuned loop those are already in registers (no extra shifts). */
+  return (1u << (x & 31u)) | (1u << ((x >> 2) & 31u)) | (1u << ((x >> 6) & 31u));
 #endif
 }
 
@@ -528,6 +526,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                 flo = (flo << 2) | (c1 >> 24);
               } else {
                 uint32_t f0, f1, f2, f3, f4, f5, f6, f7, m0, m1, m2, m3, m4, m5, m6, m7, d0, d1, d2, d3, d4, d5, d6, d7;
+#if defined(MK_FILTER_OLD)
                 auto probe = [&](uint32_t code, uint32_t &fl, uint32_t &m, uint32_t &wd) {
                   const uint32_t xx = flo >> SH;
                   wd = *(mk_lds_cu32)(uintptr_t)((flo >> (SH + 8u)) & 0xFFFCu);
@@ -535,6 +534,19 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                   flo = (flo << 2) | code;
                   fl = flo;
                 };
+#else
+                /* substrings of the three previous bases (x_{j-1} = x_j >> 2): their low 5 bits are this base's
+                 * filter fields at offsets 2, 4, 6 */
+                uint32_t xm1 = flo >> (SH + 2u), xm2 = flo >> (SH + 4u), xm3 = flo >> (SH + 6u);
+                auto probe = [&](uint32_t code, uint32_t &fl, uint32_t &m, uint32_t &wd) {
+                  const uint32_t xx = flo >> SH;
+                  wd = *(mk_lds_cu32)(uintptr_t)((flo >> (SH + 8u)) & 0xFFFCu);
+                  m = (1u << (xx & 31u)) | (1u << (xm1 & 31u)) | (1u << (xm3 & 31u));
+                  xm3 = xm2; xm2 = xm1; xm1 = xx;
+                  flo = (flo << 2) | code;
+                  fl = flo;
+                };
+#endif
                 probe(c0 & 3u, f0, m0, d0);
                 probe(__builtin_amdgcn_ubfe(c0, 8, 2), f1, m1, d1);
                 probe(__builtin_amdgcn_ubfe(c0, 16, 2), f2, m2, d2);
