@@ -15,10 +15,12 @@
  *   CO[tid]=malloc(hashsize*8)   command_dist.c:344-348      mk_engine_create / mk_engine_destroy
  *   memset(co,0,..)              iseq2comem.c:663            mk_sketch_begin
  *   mt_shortreads2koc() loop     iseq2comem.c:675-721        mk_sketch_push_reads[_device]  (MK_MODE_KOC)
+ *   fastq2co() loop              iseq2comem.c:349-413        mk_sketch_begin_occ + same push (MK_MODE_OCC_SET)
  *   fasta2co()/uniq_fasta2co()   iseq2comem.c:218-315,729-828  same entry points on overlapped windows
  *                                                            (MK_MODE_SET / MK_MODE_UNIQ_SET)
  *   write_fqkoc2files()          iseq2comem.c:516-562     }  mk_sketch_finish -> mk_result
  *   wrt_co2cmpn_use_inn_subctx() iseq2comem.c:625-652     }
+ *   write_fqco2file()            iseq2comem.c:596-621     }
  *   err(errno,"...too crowd")    iseq2comem.c:708-709        MK_ERR_CROWDED (never exit() in here)
  *   -- (no counterpart: single process) --                   mk_partial_count/export/import (multi-GPU merge)
  *
@@ -54,7 +56,9 @@ enum {
 enum {
   MK_MODE_KOC = 0,     /* -A FASTQ: mt_shortreads2koc + write_fqkoc2files: ids + 16-bit counts      */
   MK_MODE_SET = 1,     /* FASTA:    fasta2co + wrt_co2cmpn_use_inn_subctx: ids, key 0 never stored  */
-  MK_MODE_UNIQ_SET = 2 /* FASTA -u: uniq_fasta2co: keys seen more than once are dropped at the dump */
+  MK_MODE_UNIQ_SET = 2, /* FASTA -u: uniq_fasta2co: keys seen more than once are dropped at the dump */
+  MK_MODE_OCC_SET = 3   /* FASTQ without -A: fastq2co + write_fqco2file: ids of the keys seen at least
+                           min_occurrence times (-n), key 0 kept; see mk_sketch_begin_occ            */
 };
 
 /* ---- .shuf (command_shuffle.h:4-16) -------------------------------------------------------- */
@@ -125,7 +129,12 @@ int mk_engine_set_stream(mk_engine *e, void *hip_stream);
 int mk_engine_use_own_stream(mk_engine *e);
 const char *mk_last_error(const mk_engine *e); /* e may be NULL: last error of a failed create */
 
-int mk_sketch_begin(mk_engine *e, int mode);
+int mk_sketch_begin(mk_engine *e, int mode); /* MK_MODE_OCC_SET here means min_occurrence 1 */
+/* fastq2co(…, Q, M) (iseq2comem.c:323-419): MK_MODE_OCC_SET with M = min_occurrence, 1 <= M < 15 (:325; the CLI
+ * clamps -n to 1..7, command_dist_wrapper.c:169-180).  The quality threshold Q is applied by the front end
+ * (mk_fastq_frame_q).  fastq2co() never advances its key counter (:404), so it does not abort at hashlimit: this
+ * flavour reports MK_ERR_CROWDED only when the table itself is full (distinct keys >= hashsize). */
+int mk_sketch_begin_occ(mk_engine *e, int min_occurrence);
 /* Fixed-stride rows, each an ASCII sequence line terminated by '\n' (the layout of the reference's
  * fq_buff[l][FQ_LEN], iseq2comem.c:659,673); a row without '\n' ends at `stride`.  stride % 4 == 0,
  * 4 <= stride <= 4096.  Read i of this call has global ordinal first_read_ordinal + i: ordinals define
@@ -173,6 +182,17 @@ int mk_synth_fastq_write(const char *path, uint64_t seed, uint64_t first_read, u
  * *consumed (so a caller can stream).  final!=0 means `buf` ends the file. */
 int mk_fastq_frame(const uint8_t *buf, size_t n, int final, uint8_t *rows, uint32_t stride, uint64_t max_rows,
                    uint64_t *nrows, size_t *consumed);
+/* FASTQ framing of fastq2co's reader (iseq2comem.c:343-363, fgets width 20000) for MK_MODE_OCC_SET: like
+ * mk_fastq_frame, plus (a) bases whose quality byte (signed char, raw code) is below qmin (-Q) are written as 'N',
+ * which resets the k-mer window exactly like the reference's test at :367; a quality line shorter than its
+ * sequence counts as quality 0 there (the reference reads the previous record's bytes); (b) the record rule of that
+ * reader: a record missing a line, or whose 4th line lacks its '\n', is not walked, except the first record of
+ * the file (records_before == 0), which is walked whenever its sequence line exists; (c) a sequence longer than
+ * stride-1 is cut into rows overlapping by TL-1 bases once stride is 4096 (MK_ERR_ARG below that: widen and
+ * call again from *consumed).  *nrecords counts records, *nrows rows. */
+int mk_fastq_frame_q(const uint8_t *buf, size_t n, int final, int32_t qmin, int32_t TL, uint64_t records_before,
+                     uint8_t *rows, uint32_t stride, uint64_t max_rows, uint64_t *nrows, uint64_t *nrecords,
+                     size_t *consumed);
 /* FASTA front end of fasta2co (iseq2comem.c:240-279): strips line breaks, maps headers/invalid bytes to
  * window resets and cuts the base stream into rows of `stride` bytes overlapping by TL-1 bases so that
  * every k-mer lies in exactly one row.  Call mk_fasta_window_init once per file, then feed the file in

@@ -5,4 +5,4 @@ metakssd_amd/csrc) and the C command line (metakssd_amd/bin/metakssd).  This pac
 ctypes binding used by tests and bench.py; importing it requires the built library.
 """
 from . import capi  # noqa: F401
-from .capi import Engine, Shuf, MkError, CrowdedError, MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET  # noqa: F401
+from .capi import Engine, Shuf, MkError, CrowdedError, MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET, MK_MODE_OCC_SET  # noqa: F401

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmetakssd_hip.so")
 MK_OK = 0
 MK_ERR_ARG, MK_ERR_NO_DEVICE, MK_ERR_HIP, MK_ERR_CROWDED = -1, -2, -3, -4
 MK_ERR_STATE, MK_ERR_IO, MK_ERR_FORMAT, MK_ERR_NOMEM = -5, -6, -7, -8
-MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET = 0, 1, 2
+MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET, MK_MODE_OCC_SET = 0, 1, 2, 3
 
 
 class MkError(RuntimeError):
@@ -78,6 +78,7 @@ def _load():
         "mk_engine_set_stream": [vp, vp],
         "mk_engine_use_own_stream": [vp],
         "mk_sketch_begin": [vp, C.c_int],
+        "mk_sketch_begin_occ": [vp, C.c_int],
         "mk_sketch_push_reads": [vp, vp, u32, u64, u64],
         "mk_sketch_push_reads_device": [vp, vp, u32, u64, u64],
         "mk_sketch_finish": [vp, C.POINTER(ResultC)],
@@ -95,6 +96,8 @@ def _load():
         "mk_synth_rows_device": [C.c_int, vp, u64, u64, u64, u32, u32, vp],
         "mk_synth_fastq_write": [C.c_char_p, u64, u64, u64, u32],
         "mk_fastq_frame": [vp, C.c_size_t, C.c_int, vp, u32, u64, C.POINTER(u64), C.POINTER(C.c_size_t)],
+        "mk_fastq_frame_q": [vp, C.c_size_t, C.c_int, i32, i32, u64, vp, u32, u64, C.POINTER(u64), C.POINTER(u64),
+                             C.POINTER(C.c_size_t)],
         "mk_fasta_window_init": [C.POINTER(FastaStateC), i32],
         "mk_fasta_window": [C.POINTER(FastaStateC), vp, C.c_size_t, C.c_int, vp, u32, u64, C.POINTER(u64),
                             C.POINTER(C.c_size_t)],
@@ -183,6 +186,18 @@ def fastq_frame(buf, stride, final=True, max_rows=None):
     return rows[: n.value * stride], n.value, used.value, rc
 
 
+def fastq_frame_q(buf, stride, TL, qmin=0, final=True, records_before=0, max_rows=None):
+    """FASTQ bytes -> rows the way fastq2co() reads them (quality mask, record rule, long-read windows);
+    returns (rows, nrows, nrecords, consumed, rc)"""
+    b = np.frombuffer(buf, dtype=np.uint8)
+    max_rows = max_rows if max_rows is not None else len(b) // 4 + len(b) // max(1, stride - TL) + 2
+    rows = np.zeros(max(1, max_rows) * stride, dtype=np.uint8)
+    n, nrec, used = C.c_uint64(0), C.c_uint64(0), C.c_size_t(0)
+    rc = lib.mk_fastq_frame_q(b.ctypes.data if len(b) else None, len(b), 1 if final else 0, qmin, TL, records_before,
+                              rows.ctypes.data, stride, max_rows, C.byref(n), C.byref(nrec), C.byref(used))
+    return rows[: n.value * stride], n.value, nrec.value, used.value, rc
+
+
 def fasta_windows(buf, TL, stride, chunk=None):
     """FASTA bytes -> overlapped fixed-stride rows; `chunk` feeds the input in pieces of that many bytes"""
     b = np.frombuffer(buf, dtype=np.uint8)
@@ -244,6 +259,10 @@ class Engine:
 
     def begin(self, mode=MK_MODE_KOC):
         _check(lib.mk_sketch_begin(self.h, mode), self.h)
+
+    def begin_occ(self, min_occurrence=1):
+        """FASTQ without -A (fastq2co): ids of keys seen at least min_occurrence times"""
+        _check(lib.mk_sketch_begin_occ(self.h, min_occurrence), self.h)
 
     def push_reads(self, rows, stride, first_read_ordinal=0):
         """rows: host numpy u8 array of nreads*stride bytes"""

@@ -110,6 +110,8 @@ typedef struct {
   uint8_t *rows; /* pinned rows */
   uint64_t next_ordinal;
   uint64_t nrows_total;
+  int occ;      /* FASTQ without -A: fastq2co()'s reader (quality mask, its record rule) */
+  int qmin, TL; /* -Q, k-mer length */
 } ctx_t;
 
 #define CHECK(e, call)                                                  \
@@ -138,6 +140,7 @@ static void sketch_fastq(ctx_t *c, const char *path) {
   uint32_t stride = 160;
   size_t have = 0;
   int eof = 0;
+  uint64_t records = 0;
   while (!eof || have) {
     if (!eof) {
       size_t r = fread(c->io + have, 1, IOBUF - have, f);
@@ -148,7 +151,11 @@ static void sketch_fastq(ctx_t *c, const char *path) {
     for (;;) {
       uint64_t nrows = 0;
       size_t used = 0;
-      int rc = mk_fastq_frame(c->io + off, have - off, eof, c->rows, stride, ROWBUF / stride, &nrows, &used);
+      uint64_t nrec = 0;
+      int rc = c->occ ? mk_fastq_frame_q(c->io + off, have - off, eof, c->qmin, c->TL, records, c->rows, stride, ROWBUF / stride,
+                                         &nrows, &nrec, &used)
+                      : mk_fastq_frame(c->io + off, have - off, eof, c->rows, stride, ROWBUF / stride, &nrows, &used);
+      records += nrec;
       if (nrows) {
         CHECK(c->eng, mk_sketch_push_reads(c->eng, c->rows, stride, nrows, c->next_ordinal));
         c->next_ordinal += nrows;
@@ -157,7 +164,8 @@ static void sketch_fastq(ctx_t *c, const char *path) {
       off += used;
       if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : stride * 2; continue; } /* longer read: widen rows */
       if (rc == MK_ERR_ARG || rc == MK_ERR_FORMAT)
-        die("%s: sequence or header line of 4095+ characters: outside the FASTQ framing contract (iseq2comem.c:656,673)", path);
+        die("%s: FASTQ line longer than the reference's fgets() width (%s): outside the framing contract", path,
+            c->occ ? "19998 characters, iseq2comem.c:319,343" : "4094 characters, iseq2comem.c:656,673");
       if (rc != MK_OK) die("mk_fastq_frame failed (%d)", rc);
       if (nrows == 0 || off >= have) break;
     }
@@ -212,6 +220,7 @@ typedef struct {
 typedef struct {
   strlist *files;
   int TL;
+  int occ, qmin; /* FASTQ without -A */
   int nbufs;
   uint8_t *bufs[PF_MAX_BUFS];
   int free_bufs[PF_MAX_BUFS], nfree;
@@ -265,7 +274,9 @@ static void *pf_worker(void *arg) {
       for (;;) {
         uint64_t nrows = 0;
         size_t used = 0;
-        int rc = mk_fastq_frame(text, n, 1, pf->bufs[b], stride, ROWBUF / stride, &nrows, &used);
+        uint64_t nrec = 0;
+        int rc = pf->occ ? mk_fastq_frame_q(text, n, 1, pf->qmin, pf->TL, 0, pf->bufs[b], stride, ROWBUF / stride, &nrows, &nrec, &used)
+                         : mk_fastq_frame(text, n, 1, pf->bufs[b], stride, ROWBUF / stride, &nrows, &used);
         if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : stride * 2; continue; }
         if (rc != MK_OK) s.err = rc;
         else if (used < n) s.too_big = 1; /* more rows than one buffer holds */
@@ -298,7 +309,7 @@ static void *pf_worker(void *arg) {
 
 static void usage(void) {
   fprintf(stderr,
-          "usage: metakssd dist -L <file.shuf> [-A] [-u] [-o outdir] [-p N] [--device D] <fastq|fasta|dir>...\n"
+          "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D] <fastq|fasta|dir>...\n"
           "       metakssd shuffle -k <halfK> -s <halfSubK> -l <level> [--seed N] -o <prefix>\n");
   exit(2);
 }
@@ -333,6 +344,7 @@ int main(int argc, char **argv) {
 
   const char *shuf_path = NULL, *outdir = ".";
   int abundance = 0, uniq = 0, device = 0, quiet = 0, nthreads = 8;
+  int kmerocrs = 1, kmerqlty = 0; /* command_dist_wrapper.c:79-80 */
   strlist args = {0};
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "-L") && i + 1 < argc) shuf_path = argv[++i];
@@ -340,6 +352,13 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "-p") && i + 1 < argc) nthreads = atoi(argv[++i]); /* host front-end threads */
     else if (!strcmp(argv[i], "-A")) abundance = 1;
     else if (!strcmp(argv[i], "-u")) uniq = 1;
+    else if (!strcmp(argv[i], "-n") && i + 1 < argc) { /* command_dist_wrapper.c:169-180 */
+      int v = atoi(argv[++i]);
+      if (v > 7) { fprintf(stderr, "metakssd: -n argument is larger than Max, it has been set to 7, ignorned -n %d \n", v); v = 7; }
+      else if (v < 1) { fprintf(stderr, "metakssd: -n argument is smaller than Min, it has been set to 1, ignorned -n %d \n", v); v = 1; }
+      kmerocrs = v;
+    }
+    else if (!strcmp(argv[i], "-Q") && i + 1 < argc) kmerqlty = atoi(argv[++i]); /* :182-185 */
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--quiet")) quiet = 1;
     else if (argv[i][0] == '-' && argv[i][1]) die("option %s is not part of the sketching path built here", argv[i]);
@@ -387,6 +406,7 @@ int main(int argc, char **argv) {
   int nworkers = 0;
   if (files.n > 1 && nthreads > 1) {
     pf.files = &files; pf.TL = P.TL;
+    pf.occ = !abundance; pf.qmin = kmerqlty;
     pf.nbufs = nthreads < PF_MAX_BUFS ? nthreads : PF_MAX_BUFS;
     if (pf.nbufs > files.n) pf.nbufs = files.n;
     pf.slots = calloc(files.n, sizeof(pf_slot));
@@ -406,9 +426,10 @@ int main(int argc, char **argv) {
     const char *path = files.v[i];
     c.next_ordinal = 0;
     const int fq = is_fastq(path);
-    if (fq && !abundance) die("%s: FASTQ without -A (fastq2co, -n/-Q 4-bit counts) is not built yet", path);
-    if (fq && !quiet) printf("running mt_shortreads2koc()\n");
-    CHECK(c.eng, mk_sketch_begin(c.eng, fq ? MK_MODE_KOC : (uniq ? MK_MODE_UNIQ_SET : MK_MODE_SET)));
+    if (fq && abundance && !quiet) printf("running mt_shortreads2koc()\n");
+    if (fq && !abundance) CHECK(c.eng, mk_sketch_begin_occ(c.eng, kmerocrs)); /* command_dist.c:385-386 */
+    else CHECK(c.eng, mk_sketch_begin(c.eng, fq ? MK_MODE_KOC : (uniq ? MK_MODE_UNIQ_SET : MK_MODE_SET)));
+    c.occ = fq && !abundance; c.qmin = kmerqlty; c.TL = P.TL;
     int handled = 0;
     if (nworkers) {
       pthread_mutex_lock(&pf.mu);

@@ -101,6 +101,80 @@ int mk_fastq_frame(const uint8_t *buf, size_t n, int final, uint8_t *rows, uint3
   return rc;
 }
 
+#define MK_FQCO_LEN 20000 /* iseq2comem.c:319: fastq2co()'s fgets() width */
+
+/* rows one sequence payload of L bytes needs at this stride (windows overlap by TL-1 bases) */
+static uint64_t mk_rows_for(size_t L, uint32_t cap, uint32_t TL) {
+  if (L <= cap) return 1;
+  const size_t step = cap - (TL - 1);
+  return 1 + (L - cap + step - 1) / step;
+}
+
+int mk_fastq_frame_q(const uint8_t *buf, size_t n, int final, int32_t qmin, int32_t TL, uint64_t records_before,
+                     uint8_t *rows, uint32_t stride, uint64_t max_rows, uint64_t *nrows, uint64_t *nrecords,
+                     size_t *consumed) {
+  if ((!buf && n) || !rows || !nrows || !nrecords || !consumed || stride > 4096 || (stride & 3) || TL < 2 || TL > 32 ||
+      stride < 2u * (uint32_t)TL + 4)
+    return MK_ERR_ARG;
+  const uint8_t *p = buf, *end = buf + n;
+  const uint32_t cap = stride - 1;
+  uint64_t r = 0, rec = 0;
+  int rc = MK_OK;
+  while (p < end) {
+    const uint8_t *ln[4];
+    size_t len[4] = {0, 0, 0, 0};
+    const uint8_t *q = p;
+    int have = 0;
+    for (; have < 4 && q < end; have++) {
+      len[have] = mk_line(q, end, final);
+      if (!len[have]) break;
+      ln[have] = q;
+      q += len[have];
+    }
+    if (have < 4 && !final) break; /* record still arriving */
+    /* fastq2co() reads the NEXT record at the end of the current one and walks it only if those four fgets()
+     * did not touch end-of-file (iseq2comem.c:351-362): a record with a missing line, or whose last line has
+     * no '\n', is read but never walked.  The first record is read before the loop and always walked (:343-349). */
+    const int whole = have == 4 && ln[3][len[3] - 1] == '\n';
+    if (!whole && !(records_before + rec == 0 && have >= 2)) { p = end; break; }
+    for (int i = 0; i < have; i++)
+      if (len[i] >= MK_FQCO_LEN - 1) rc = MK_ERR_FORMAT; /* fgets(…,LEN,…) would split the line */
+    if (rc) break;
+    size_t L = len[1];
+    if (L && ln[1][L - 1] == '\n') L--;
+    if (L > cap && stride < 4096) { rc = MK_ERR_ARG; break; } /* caller re-frames from here with wider rows */
+    const uint64_t need = mk_rows_for(L, cap, (uint32_t)TL);
+    if (r + need > max_rows) {
+      if (r == 0) rc = MK_ERR_ARG;
+      break;
+    }
+    const uint8_t *sq = ln[1], *ql = have == 4 ? ln[3] : NULL;
+    const size_t qn = have == 4 ? len[3] : 0;
+    size_t at = 0;
+    for (uint64_t w = 0; w < need; w++) {
+      uint8_t *row = rows + (r + w) * (uint64_t)stride;
+      size_t m = L - at < cap ? L - at : cap;
+      if (qmin <= -128) memcpy(row, sq + at, m); /* every signed quality byte passes */
+      else /* a base whose quality byte is below -Q resets the window exactly like a non-ACGT byte (:367-379) */
+        for (size_t i = 0; i < m; i++) {
+          const int qv = at + i < qn ? (int)(signed char)ql[at + i] : 0;
+          row[i] = qv >= qmin ? sq[at + i] : (uint8_t)'N';
+        }
+      row[m] = '\n';
+      if (m + 1 < stride) memset(row + m + 1, 0, stride - m - 1);
+      at += m;
+      if (w + 1 < need) at -= (size_t)(TL - 1);
+    }
+    r += need;
+    rec++;
+    p = q;
+  }
+  *nrows = r;
+  *nrecords = rec;
+  *consumed = (size_t)(p - buf);
+  return rc;
+}
+
 int mk_fasta_window_init(mk_fasta_state *st, int32_t TL) {
   if (!st || TL < 2 || TL > 32) return MK_ERR_ARG;
   memset(st, 0, sizeof *st);

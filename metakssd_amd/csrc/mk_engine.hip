@@ -62,6 +62,7 @@ struct mk_engine {
   int stage_next = 0;
 
   int mode = -1;
+  uint32_t min_occ = 1; /* MK_MODE_OCC_SET: dump keys seen at least this often */
   bool begun = false, compacted = false;
   uint64_t D = 0;
 
@@ -204,7 +205,7 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   e->tab.kc = (unsigned long long *)e->d_tab;
   e->tab.ordinv = e->tab.kc + S;
   MK_HIP(e, hipMalloc(&e->d_slot, S * sizeof(uint32_t)));
-  e->dist.cap = (uint64_t)p->hashlimit + 1;
+  e->dist.cap = S; /* hashlimit+1 entries suffice for KOC/SET; MK_MODE_OCC_SET may fill the table (fastq2co never aborts) */
   MK_HIP(e, hipMalloc(&e->dist.key, e->dist.cap * 8));
   MK_HIP(e, hipMalloc(&e->dist.ord, e->dist.cap * 8));
   MK_HIP(e, hipMalloc(&e->dist.cnt, e->dist.cap * 4));
@@ -308,8 +309,17 @@ extern "C" int mk_profile_get(mk_engine *e, mk_profile *out) {
   return MK_OK;
 }
 
+extern "C" int mk_sketch_begin_occ(mk_engine *e, int min_occurrence) {
+  if (!e) return MK_ERR_ARG;
+  if (min_occurrence < 1 || min_occurrence >= 15) /* iseq2comem.c:325 */
+    return mk_fail(e, MK_ERR_ARG, "fastq2co(): Occurence num should be 1..14 (got %d)", min_occurrence);
+  int rc = mk_sketch_begin(e, MK_MODE_OCC_SET);
+  if (rc == MK_OK) e->min_occ = (uint32_t)min_occurrence;
+  return rc;
+}
+
 extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
-  if (!e || mode < MK_MODE_KOC || mode > MK_MODE_UNIQ_SET) return MK_ERR_ARG;
+  if (!e || mode < MK_MODE_KOC || mode > MK_MODE_OCC_SET) return MK_ERR_ARG;
   MK_HIP(e, hipSetDevice(e->device));
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
@@ -318,6 +328,7 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   MK_HIP(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->stream));
   if (e->profiling) { MK_HIP(e, hipEventRecord(ev.b, e->stream)); e->ev_clear.push_back(ev); }
   e->mode = mode;
+  e->min_occ = 1;
   e->begun = true;
   e->compacted = false;
   e->D = 0;
@@ -491,7 +502,11 @@ extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t 
 static int mk_compact(mk_engine *e) {
   if (e->compacted) return MK_OK;
   MK_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(unsigned long long), e->stream));
-  const int drop0 = e->mode != MK_MODE_KOC; /* co[n]=0 stays "empty" in the set flavours: iseq2comem.c:300-302 */
+  /* co[n]=0 stays "empty" in the FASTA set flavours (iseq2comem.c:300-302); the FASTQ slot words carry a count
+   * field, so key 0 is an ordinary key there (:398-399, :704-705) */
+  const int drop0 = e->mode == MK_MODE_SET || e->mode == MK_MODE_UNIQ_SET;
+  /* fastq2co() tests `keycount > hashlimit` but never advances keycount (:404): only a full table stops it */
+  const uint64_t limit = e->mode == MK_MODE_OCC_SET ? (uint64_t)e->kp.S - 1 : (uint64_t)e->P.hashlimit;
   const unsigned blocks = (unsigned)(e->num_cu * 2);
   hipLaunchKernelGGL(mk_compact_kernel, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
                      e->d_counters, drop0);
@@ -500,9 +515,9 @@ static int mk_compact(mk_engine *e) {
   MK_HIP(e, hipStreamSynchronize(e->stream));
   const uint32_t errflags = (uint32_t)(e->h_counters[2] & 0xffffffffu);
   e->D = e->h_counters[0];
-  if ((errflags & 1u) || e->D > e->P.hashlimit)
-    return mk_fail(e, MK_ERR_CROWDED, "the context space is too crowd (%llu distinct keys > hashlimit %u), try k=%d",
-                   (unsigned long long)e->D, e->P.hashlimit, e->P.k + 1);
+  if ((errflags & 1u) || e->D > limit)
+    return mk_fail(e, MK_ERR_CROWDED, "the context space is too crowd (%llu distinct keys > limit %llu), try k=%d",
+                   (unsigned long long)e->D, (unsigned long long)limit, e->P.k + 1);
   e->compacted = true;
   return MK_OK;
 }
@@ -595,7 +610,8 @@ extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
     mk_dump_args da{};
     da.slot = e->d_slot; da.S = S; da.d = e->dist;
     da.comp_num = (uint32_t)C; da.comp_code_bits = (uint32_t)e->P.comp_code_bits;
-    da.uniq_only = e->mode == MK_MODE_UNIQ_SET;
+    da.cnt_lo = e->mode == MK_MODE_OCC_SET ? e->min_occ : 1u; /* write_fqco2file(): marked keys only (iseq2comem.c:611) */
+    da.cnt_hi = e->mode == MK_MODE_UNIQ_SET ? 1u : 0xffffffffu;  /* uniq_fasta2co(): repeated keys dropped */
     da.nchunks = e->nchunks;
     const unsigned dblocks = (e->nchunks + 3) / 4; /* 4 waves (chunks) per 256-thread block */
     if (C == 1) {

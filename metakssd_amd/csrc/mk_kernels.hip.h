@@ -769,7 +769,7 @@ struct mk_dump_args {
   uint32_t S;
   mk_dist d;
   uint32_t comp_num, comp, comp_code_bits;
-  int uniq_only; /* MK_MODE_UNIQ_SET: keep keys seen exactly once */
+  uint32_t cnt_lo, cnt_hi; /* keep keys whose (clamped) count lies in [cnt_lo, cnt_hi] */
   uint32_t nchunks;
 };
 
@@ -777,7 +777,10 @@ __device__ __forceinline__ bool mk_dump_pred(const mk_dump_args &a, uint64_t n, 
   idx = n < a.S ? a.slot[n] : MK_EMPTY32;
   if (idx == MK_EMPTY32) return false;
   if (a.comp_num > 1 && (uint32_t)(a.d.key[idx] % a.comp_num) != a.comp) return false;
-  if (a.uniq_only && a.d.cnt[idx] != 1u) return false;
+  if (a.cnt_lo > 1u || a.cnt_hi != 0xffffffffu) {
+    const uint32_t c = a.d.cnt[idx];
+    if (c < a.cnt_lo || c > a.cnt_hi) return false;
+  }
   return true;
 }
 
@@ -848,7 +851,10 @@ __device__ __forceinline__ bool mk_dumpc_pred(const mk_dump_args &a, uint64_t n,
   idx = n < a.S ? a.slot[n] : MK_EMPTY32;
   comp = 0;
   if (idx == MK_EMPTY32) return false;
-  if (a.uniq_only && a.d.cnt[idx] != 1u) return false;
+  if (a.cnt_lo > 1u || a.cnt_hi != 0xffffffffu) {
+    const uint32_t c = a.d.cnt[idx];
+    if (c < a.cnt_lo || c > a.cnt_hi) return false;
+  }
   comp = (uint32_t)(a.d.key[idx] % a.comp_num);
   return true;
 }

@@ -91,11 +91,11 @@ def revcomp(s):
     return s.translate(RC)[::-1]
 
 
-def write_fq(path, seqs, crlf=False, final_newline=True, drop_last_qual=False):
+def write_fq(path, seqs, crlf=False, final_newline=True, drop_last_qual=False, quals=None):
     nl = "\r\n" if crlf else "\n"
     out = []
     for i, s in enumerate(seqs):
-        rec = ["@r%d" % i, s, "+", "I" * len(s)]
+        rec = ["@r%d" % i, s, "+", quals[i] if quals else "I" * len(s)]
         if drop_last_qual and i == len(seqs) - 1:
             rec = rec[:3]
         out.append(nl.join(rec) + nl)
@@ -251,6 +251,50 @@ def main():
     case("L3K9_ragged_gz", "L3K9", [fq3 + ".gz"], ["-A"])
     # 16 components
     case("L2K11_pool60k", "L2K11", [fq2], ["-A"])
+
+    # ---- FASTQ without -A: fastq2co() + write_fqco2file() (-n minimum occurrence, -Q quality byte) ------------
+    case("L3K11_syn100k_set", "L3K11", [fq], [])
+    for n in ("1", "2", "3", "7", "9", "0"):           # 9 clamps to 7, 0 clamps to 1 (command_dist_wrapper.c:169-180)
+        case("L3K9_pool60k_n%s" % n, "L3K9", [fq2], ["-n", n])
+        case("L1K7_pool_n%s" % n, "L1K7", [fq10], ["-n", n])
+    fq16 = os.path.join(work, "lowcov.fq")      # ~3x coverage with both strands: occurrence counts spread over 1..10
+    lc = [pool[a:a + 150] for a in (rng.randrange(0, 60000) for _ in range(1200))]
+    write_fq(fq16, [revcomp(x) if rng.random() < 0.5 else x for x in lc])
+    for n in range(1, 8):
+        case("L0K6_lowcov_n%d" % n, "L0K6", [fq16], ["-n", str(n)])
+        case("L1K7_lowcov_n%d" % n, "L1K7", [fq16], ["-n", str(n)])
+    case("L2K11_pool60k_n2", "L2K11", [fq2], ["-n", "2"])
+    case("L3K9_ragged_set", "L3K9", [fq3], [])
+    case("L3K9_ragged_crlf_set", "L3K9", [fq4], ["-n", "2"])
+    case("L3K9_trunc_last_set", "L3K9", [fq5], [])
+    case("L3K9_no_final_nl_set", "L3K9", [fq6], [])      # last record is read but never walked (iseq2comem.c:357)
+    fq12 = os.path.join(work, "one_nonl.fq")
+    write_fq(fq12, [rand_seq(rng, 300)], final_newline=False)   # ... except when it is the first record (:343-349)
+    case("L1K7_one_record_no_nl_set", "L1K7", [fq12], [])
+    case("L3K9_saturate_n7", "L3K9", [fq7], ["-n", "7"])
+    case("L0K6z_key0_set", "L0K6z", [fq8], ["-n", "2"])
+    case("L0K6_dense400_set", "L0K6", [fq9], [])
+    case("L0K6_pool_n3", "L0K6", [fq10], ["-n", "3"])
+    # fastq2co never advances its key counter (:404): no abort above hashlimit (78642 of 131071 slots here)
+    fq13 = os.path.join(work, "dense700.fq")
+    write_fq(fq13, [rand_seq(rng, 150) for _ in range(700)])
+    case("L0K6_dense700_load0.73_set", "L0K6", [fq13], [])
+    # per-base qualities: Phred+33 characters '#'..'I', threshold is the raw character code
+    qseqs = [pool[a:a + 150] for a in (rng.randrange(0, 60000) for _ in range(20000))]
+    quals = ["".join(rng.choice("#+5?I") if rng.random() < 0.08 else "I" for _ in range(150)) for _ in qseqs]
+    fq14 = os.path.join(work, "qual.fq")
+    write_fq(fq14, qseqs, quals=quals)
+    for Q in ("0", "36", "54", "64", "73", "74"):
+        case("L3K9_qual_Q%s" % Q, "L3K9", [fq14], ["-Q", Q])
+        case("L1K7_qual_Q%s_n2" % Q, "L1K7", [fq14], ["-Q", Q, "-n", "2"])
+    # long reads (fgets width 20000 there): one row each in the oracle, windows in the product
+    lseqs = [rand_seq(rng, L) for L in (4094, 4095, 4096, 5000, 8191, 12000, 19997, 150, 0, 7000)]
+    fq15 = os.path.join(work, "long.fq")
+    write_fq(fq15, lseqs)
+    case("L3K9_long_reads_set", "L3K9", [fq15], [])
+    case("L1K7_long_reads_n1", "L1K7", [fq15], [])
+    subprocess.check_call("gzip -kf %s" % fq14, shell=True)
+    case("L3K10_qual_gz_Q54", "L3K10", [fq14 + ".gz"], ["-Q", "54"])
 
     # ---- FASTA cases (config 5 family): single file each so the reference's random file order is moot --
     def write_fa(path, contigs, width=70):

@@ -325,6 +325,77 @@ unsigned int ko_dump_koc(const ko_params *P, const ko_llong *co, uint32_t **ids,
   return wr;
 }
 
+/* ---- FASTQ without -A: fastq2co() (iseq2comem.c:323-419) + write_fqco2file() (:596-621) ---- */
+#define KO_FQCO_LEN 20000     /* iseq2comem.c:319 */
+#define KO_CT_BIT 4           /* :320 */
+#define KO_CT_MAX 0xfULL      /* :321 */
+int ko_co_from_fastq_bytes(const ko_params *P, const int *shuf, const unsigned char *fq, size_t n, int Q, int M,
+                           ko_llong *co, ko_llong *nlines_out) {
+  if ((ko_llong)M >= KO_CT_MAX) return KO_ERR_ARG; /* :325 */
+  ko_llong S = P->hashsize, tuple = 0, crvs = 0;
+  memset(co, 0, (size_t)S * sizeof(ko_llong)); /* :328 */
+  ko_ms s = {fq, fq + n, 0};
+  /* the reference's two line buffers live across records, so a quality line shorter than its sequence line
+   * exposes the previous record's bytes; kept (zero-filled at start where the reference has malloc garbage) */
+  unsigned char *seq = calloc(KO_FQCO_LEN + 10, 1), *qual = calloc(KO_FQCO_LEN + 10, 1);
+  if (!seq || !qual) { free(seq); free(qual); return KO_ERR_IO; }
+  ko_ms_gets(&s, seq, KO_FQCO_LEN); ko_ms_gets(&s, seq, KO_FQCO_LEN);   /* :343 */
+  ko_ms_gets(&s, qual, KO_FQCO_LEN); ko_ms_gets(&s, qual, KO_FQCO_LEN); /* :344 */
+  ko_llong base = 1, line_num = 0;
+  int rc = KO_OK;
+  int sl = (int)strlen((char *)seq);
+  for (int pos = 0; pos < sl; pos++) {
+    if (seq[pos] == '\n') { /* :350-363: next record is read here; it is walked only if that did not touch EOF */
+      ko_ms_gets(&s, seq, KO_FQCO_LEN); ko_ms_gets(&s, seq, KO_FQCO_LEN);
+      ko_ms_gets(&s, qual, KO_FQCO_LEN); ko_ms_gets(&s, qual, KO_FQCO_LEN);
+      sl = (int)strlen((char *)seq);
+      line_num += 4;
+      if (s.eof) break;
+      base = 1;
+      pos = -1;
+      continue;
+    }
+    int b = ko_code(seq[pos]);
+    if (b < 0 || (int)(signed char)qual[pos] < Q) { base = 1; continue; } /* :367-379 */
+    tuple = ((tuple << 2) | (ko_llong)b) & P->tupmask;
+    crvs = (crvs >> 2) + (((ko_llong)b ^ 3ULL) << P->crvsaddmove);
+    base++;
+    if (base <= P->TL) continue; /* :382 */
+    ko_llong key;
+    if (!ko_reduce(P, shuf, tuple, crvs, &key)) continue;
+    for (ko_llong i = 0; i < S; i++) { /* :393-411; keycount is never advanced there, so no crowding abort */
+      ko_llong slot = ko_probe(key, i, S);
+      if (co[slot] == 0) {
+        co[slot] = M == 1 ? ((key << KO_CT_BIT) | KO_CT_MAX) : ((key << KO_CT_BIT) + 1ULL);
+        break;
+      } else if ((co[slot] >> KO_CT_BIT) == key) {
+        if ((co[slot] & KO_CT_MAX) == KO_CT_MAX) break;
+        co[slot] += 1ULL;
+        if (!((long long)(co[slot] & KO_CT_MAX) < (long long)M)) co[slot] |= KO_CT_MAX;
+        break;
+      }
+    }
+  }
+  if (sl > 0 && !s.eof && seq[sl - 1] != '\n') rc = KO_ERR_CONTRACT; /* line of LEN-1 chars or more: walk stops short */
+  if (nlines_out) *nlines_out = line_num;
+  free(seq); free(qual);
+  return rc;
+}
+
+unsigned int ko_dump_fqco(const ko_params *P, const ko_llong *co, uint32_t **ids, size_t *n_out) {
+  /* write_fqco2file(): slots whose 4-bit count field is saturated, in slot order */
+  unsigned int wr = 0;
+  for (int c = 0; c < P->component_num; c++) n_out[c] = 0;
+  for (ko_llong s = 0; s < P->hashsize; s++) {
+    if ((co[s] & KO_CT_MAX) != KO_CT_MAX) continue;
+    int c = (int)((co[s] >> KO_CT_BIT) % (ko_llong)P->component_num);
+    if (ids) ids[c][n_out[c]] = (uint32_t)(co[s] >> (P->comp_code_bits + KO_CT_BIT));
+    n_out[c]++;
+    wr++;
+  }
+  return wr;
+}
+
 int ko_co_from_fasta_bytes(const ko_params *P, const int *shuf, const unsigned char *fa, size_t n, ko_llong *co, int uniq) {
   /* fasta2co(): iseq2comem.c:218-315; uniq_fasta2co(): :729-828.  The 64 KiB refill window is
    * transparent to the result except for the header-skip loop reading buff[-1] right after a refill
@@ -439,6 +510,10 @@ static unsigned char *ko_slurp_zcat(const char *path, size_t *n_out) {
 }
 
 int ko_dist_stage1(const char *shuf_path, int abundance, int uniq, const char *outdir, int nfiles, const char **files) {
+  return ko_dist_stage1_ex(shuf_path, abundance, uniq, 0, 1, outdir, nfiles, files); /* defaults: command_dist_wrapper.c:79-80 */
+}
+int ko_dist_stage1_ex(const char *shuf_path, int abundance, int uniq, int Q, int M, const char *outdir, int nfiles,
+                      const char **files) {
   int header[4], *shuf = NULL;
   size_t shuf_len = 0;
   int rc = ko_shuf_read(shuf_path, header, &shuf, &shuf_len);
@@ -480,7 +555,12 @@ int ko_dist_stage1(const char *shuf_path, int abundance, int uniq, const char *o
         ctx_ct[i] = ko_dump_koc(&P, co, ids, cnts, nout);
       }
     } else if (is_fq) {
-      rc = KO_ERR_ARG; /* fastq2co 4-bit path (-n/-Q): not restated */
+      rc = ko_co_from_fastq_bytes(&P, shuf, bytes, n, Q, M, co, NULL); /* command_dist.c:385-386 */
+      if (rc == KO_OK) {
+        ko_dump_fqco(&P, co, NULL, nout);
+        for (int c = 0; c < C; c++) { ids[c] = malloc(4 * (nout[c] + 1)); cnts[c] = NULL; }
+        ctx_ct[i] = ko_dump_fqco(&P, co, ids, nout);
+      }
     } else {
       if (abundance) abundance = 0; /* command_dist.c:389-392: -A is switched off for good by the first FASTA */
       rc = ko_co_from_fasta_bytes(&P, shuf, bytes, n, co, uniq);

@@ -56,6 +56,14 @@ int ko_koc_from_rows_omp(const ko_params *P, const int *shuf, const unsigned cha
  * call once with ids==NULL to size (n_out filled), then again. */
 unsigned int ko_dump_koc(const ko_params *P, const ko_llong *co, uint32_t **ids, uint16_t **cnts, size_t *n_out);
 
+/* FASTQ without -A: fastq2co() (iseq2comem.c:323-419): 4-bit occurrence field, a key is marked (field = 0xf) once it
+ * was seen M times (M = -n, 1..7) over bases whose quality byte is >= Q (-Q, raw character code).  The last record of a
+ * file whose final line lacks its newline is NOT walked (:357: the record is read, feof() is already set). */
+int ko_co_from_fastq_bytes(const ko_params *P, const int *shuf, const unsigned char *fq, size_t n, int Q, int M,
+                           ko_llong *co, ko_llong *nlines_out);
+/* write_fqco2file() (iseq2comem.c:596-621) into memory; two-call protocol like ko_dump_koc. */
+unsigned int ko_dump_fqco(const ko_params *P, const ko_llong *co, uint32_t **ids, size_t *n_out);
+
 /* FASTA path: fasta2co() (iseq2comem.c:218-315) / uniq_fasta2co() (:729-828) over a byte stream. */
 int ko_co_from_fasta_bytes(const ko_params *P, const int *shuf, const unsigned char *fa, size_t n, ko_llong *co, int uniq);
 /* wrt_co2cmpn_use_inn_subctx() (iseq2comem.c:625-652) into memory; same two-call protocol. */
@@ -80,6 +88,9 @@ int ko_shuf_read(const char *path, int header[4], int **table_out, size_t *len_o
  * (the reference permutes them with a time-seeded shuffle, command_dist.c:215) :
  * run_stageI() command_dist.c:341-500.  cofiles.stat padding and post-NUL path bytes are zeroed. */
 int ko_dist_stage1(const char *shuf_path, int abundance, int uniq, const char *outdir, int nfiles, const char **files);
+/* same with -Q / -n (used by the FASTQ-without--A path only; defaults 0 / 1, command_dist_wrapper.c:79-80,169-185) */
+int ko_dist_stage1_ex(const char *shuf_path, int abundance, int uniq, int Q, int M, const char *outdir, int nfiles,
+                      const char **files);
 
 #ifdef __cplusplus
 }

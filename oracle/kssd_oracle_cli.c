@@ -1,25 +1,32 @@
 /* kssd_oracle_cli.c -- TEST INFRASTRUCTURE ONLY: command-line face of the oracle restatement.
- * usage: kssd_oracle_cli -L x.shuf [-A] [-u] -o outdir file...   (mirrors `metakssd dist`, -p 1, given file order) */
+ * usage: kssd_oracle_cli -L x.shuf [-A] [-u] [-n M] [-Q q] -o outdir file...   (mirrors `metakssd dist`, -p 1, given file order) */
 #include "kssd_oracle.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 int main(int argc, char **argv) {
   const char *shuf = NULL, *out = NULL;
-  int A = 0, u = 0, nf = 0;
+  int A = 0, u = 0, nf = 0, Q = 0, M = 1;
   const char *files[4096];
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "-L") && i + 1 < argc) shuf = argv[++i];
     else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
     else if (!strcmp(argv[i], "-A")) A = 1;
     else if (!strcmp(argv[i], "-u")) u = 1;
+    else if (!strcmp(argv[i], "-Q") && i + 1 < argc) Q = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-n") && i + 1 < argc) { /* command_dist_wrapper.c:169-180 clamps to 1..7 */
+      M = atoi(argv[++i]);
+      if (M > 7) M = 7;
+      if (M < 1) M = 1;
+    }
     else if (nf < 4096) files[nf++] = argv[i];
   }
   if (!shuf || !out || nf == 0) {
     fprintf(stderr, "usage: %s -L x.shuf [-A] [-u] -o outdir file...\n", argv[0]);
     return 2;
   }
-  int rc = ko_dist_stage1(shuf, A, u, out, nf, files);
+  int rc = ko_dist_stage1_ex(shuf, A, u, Q, M, out, nf, files);
   if (rc) fprintf(stderr, "kssd_oracle_cli: error %d\n", rc);
   return rc ? 1 : 0;
 }

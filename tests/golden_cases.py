@@ -35,7 +35,12 @@ def _committed(name):
 
 
 def _seqs(kind):
-    rs = np.random.RandomState({"dense": 101, "pool": 102, "ragged": 103, "homo": 0}[kind])
+    rs = np.random.RandomState({"dense": 101, "pool": 102, "ragged": 103, "homo": 0, "lowcov": 105, "qual": 106,
+                                "long": 107}[kind])
+    if kind in ("lowcov", "qual"):   # ~3x coverage of a 60 kb pool, both strands: occurrence counts spread over 1..10
+        return ui.pool_reads(rs, 60000, 1200, p_n=0.0 if kind == "qual" else 0.05)
+    if kind == "long":               # fastq2co()'s fgets width is 20000: reads beyond the 4096-byte row limit
+        return [ui.rand_seq(rs, L) for L in (4094, 4095, 4096, 5000, 8191, 12000, 19997, 150, 0, 7000)]
     if kind == "dense":
         return [ui.rand_seq(rs, 150) for _ in range(150)]
     if kind == "pool":
@@ -69,6 +74,28 @@ CASES = {
     "key0_L0K6z": {"shuf": "L0K6z", "flags": ["-A"], "input": "fq:homo"},
     "saturate_L0K6": {"shuf": "L0K6", "flags": ["-A"], "input": "repeat:seed=9,len=150,times=70000"},
     "crowded_L0K6": {"shuf": "L0K6", "flags": ["-A"], "input": "synth:seed=5,first=0,n=5000,len=150"},  # reference aborts
+    # FASTQ without -A: fastq2co + write_fqco2file (-n minimum occurrence, -Q minimum quality byte)
+    "syn100k_set_L3K11": {"shuf": "L3K11", "flags": [], "input": "synth:seed=1,first=0,n=100000,len=150"},
+    "lowcov_n1_L0K6": {"shuf": "L0K6", "flags": [], "input": "fq:lowcov"},
+    "lowcov_n2_L0K6": {"shuf": "L0K6", "flags": ["-n", "2"], "input": "fq:lowcov"},
+    "lowcov_n4_L1K7": {"shuf": "L1K7", "flags": ["-n", "4"], "input": "fq:lowcov"},
+    "lowcov_n7_L0K6": {"shuf": "L0K6", "flags": ["-n", "7"], "input": "fq:lowcov"},
+    "lowcov_n9_L1K7": {"shuf": "L1K7", "flags": ["-n", "9"], "input": "fq:lowcov"},  # clamps to 7
+    "lowcov_n3_L2K11": {"shuf": "L2K11", "flags": ["-n", "3"], "input": "fq:lowcov"},  # 16 components
+    "ragged500_set_L1K7": {"shuf": "L1K7", "flags": [], "input": "fq:ragged"},
+    "ragged500_crlf_set_L1K7": {"shuf": "L1K7", "flags": [], "input": "fq:ragged:crlf"},
+    "ragged500_trunc_set_L1K7": {"shuf": "L1K7", "flags": [], "input": "fq:ragged:trunc"},
+    "ragged500_nonl_set_L1K7": {"shuf": "L1K7", "flags": [], "input": "fq:ragged:nonl"},  # last record not walked
+    "key0_n2_L0K6z": {"shuf": "L0K6z", "flags": ["-n", "2"], "input": "fq:homo"},
+    "qual_Q0_L1K7": {"shuf": "L1K7", "flags": ["-Q", "0"], "input": "fq:qual"},
+    "qual_Q54_L1K7": {"shuf": "L1K7", "flags": ["-Q", "54"], "input": "fq:qual"},
+    "qual_Q54_n2_L0K6": {"shuf": "L0K6", "flags": ["-Q", "54", "-n", "2"], "input": "fq:qual"},
+    "qual_Q73_L0K6": {"shuf": "L0K6", "flags": ["-Q", "73"], "input": "fq:qual"},
+    "qual_Q74_L1K7": {"shuf": "L1K7", "flags": ["-Q", "74"], "input": "fq:qual"},  # nothing passes
+    "long_set_L1K7": {"shuf": "L1K7", "flags": [], "input": "fq:long"},
+    "long_n2_L0K6": {"shuf": "L0K6", "flags": ["-n", "2"], "input": "fq:long"},
+    # 97 k distinct keys in 131 071 slots, above hashlimit 78 642: fastq2co never advances its key counter, no abort
+    "dense700_set_L0K6": {"shuf": "L0K6", "flags": [], "input": "synth:seed=6,first=0,n=700,len=150"},
     # FASTA (config 5 family)
     "fasta_L0K6": {"shuf": "L0K6", "flags": [], "input": "fa:genome"},
     "fasta_uniq_L0K6": {"shuf": "L0K6", "flags": ["-u"], "input": "fa:genome"},
@@ -108,8 +135,9 @@ def build_input(case, workdir, write_committed=False):
         stored = _committed("fq_%s%s.fq.gz" % (base, "_" + variant if variant in ("crlf", "trunc", "nonl") else ""))
         if write_committed:
             seqs = _seqs(base)
+            quals = ui.random_quals(np.random.RandomState(206), seqs) if base == "qual" else None
             data = ui.fastq_bytes(seqs, crlf=variant == "crlf", final_newline=variant != "nonl",
-                                  drop_last_qual=variant == "trunc")
+                                  drop_last_qual=variant == "trunc", quals=quals)
             with gzip.GzipFile(stored, "wb", mtime=0) as f:
                 f.write(data)
         data = gzip.open(stored, "rb").read()

@@ -29,6 +29,10 @@ def load():
     lib.ko_koc_from_rows_omp.argtypes = [C.POINTER(KoParams), vp, vp, C.c_size_t, C.c_size_t, vp, C.c_int, C.c_int]
     lib.ko_dump_koc.argtypes = [C.POINTER(KoParams), vp, vp, vp, vp]
     lib.ko_dump_koc.restype = C.c_uint
+    lib.ko_co_from_fastq_bytes.argtypes = [C.POINTER(KoParams), vp, vp, C.c_size_t, C.c_int, C.c_int, vp,
+                                           C.POINTER(C.c_ulonglong)]
+    lib.ko_dump_fqco.argtypes = [C.POINTER(KoParams), vp, vp, vp]
+    lib.ko_dump_fqco.restype = C.c_uint
     lib.ko_co_from_fasta_bytes.argtypes = [C.POINTER(KoParams), vp, vp, C.c_size_t, vp, C.c_int]
     lib.ko_dump_co.argtypes = [C.POINTER(KoParams), vp, vp, vp]
     lib.ko_dump_co.restype = C.c_uint
@@ -92,6 +96,23 @@ class Oracle:
         n = rows.size // stride
         return self.lib.ko_koc_from_rows_omp(C.byref(self.P), self.table.ctypes.data, rows.ctypes.data, stride, n,
                                              self.co.ctypes.data, 1, nthreads)
+
+    def co_from_fastq(self, data, Q=0, M=1):
+        """fastq2co(Q, M) + write_fqco2file: [(ids, None)] per component"""
+        b = np.frombuffer(data, dtype=np.uint8)
+        nl = C.c_ulonglong(0)
+        rc = self.lib.ko_co_from_fastq_bytes(C.byref(self.P), self.table.ctypes.data, b.ctypes.data if len(b) else None,
+                                             len(b), Q, M, self.co.ctypes.data, C.byref(nl))
+        self.last_nlines = nl.value
+        if rc:
+            return rc, None
+        Cn = self.P.component_num
+        nout = (C.c_size_t * Cn)()
+        self.lib.ko_dump_fqco(C.byref(self.P), self.co.ctypes.data, None, nout)
+        ids = [np.zeros(nout[c], np.uint32) for c in range(Cn)]
+        pi = (C.c_void_p * Cn)(*[a.ctypes.data for a in ids])
+        self.lib.ko_dump_fqco(C.byref(self.P), self.co.ctypes.data, pi, nout)
+        return 0, [(ids[c], None) for c in range(Cn)]
 
     def co_from_fasta(self, data, uniq=False):
         b = np.frombuffer(data, dtype=np.uint8)

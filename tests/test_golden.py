@@ -18,7 +18,7 @@ ROOT = gc.ROOT
 MANIFEST = json.load(open(os.path.join(gc.GOLDEN, "manifest.json")))
 ORACLE_CLI = os.path.join(ROOT, "oracle", "kssd_oracle_cli")
 PRODUCT_CLI = os.path.join(ROOT, "metakssd_amd", "bin", "metakssd")
-HEAVY = {"pool2000_L2K11", "fasta_L2K11", "fasta_uniq_L2K11"}  # 4.3 GB oracle table each
+HEAVY = {"pool2000_L2K11", "fasta_L2K11", "fasta_uniq_L2K11", "lowcov_n3_L2K11"}  # 4.3 GB oracle table each
 
 
 def parse_stat(path):

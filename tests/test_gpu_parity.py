@@ -294,3 +294,149 @@ def test_bench_two_rank_flow_merged_equals_single(capi):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["merged_equals_single_engine"] is True
     assert d["config"]["distinct_keys"] > 50000
+
+
+# ---- FASTQ without -A: fastq2co + write_fqco2file through MK_MODE_OCC_SET -----------------------
+def run_occ(capi, eng, data, TL, M, Q=0, stride=304, pushes=1):
+    rows, n, nrec, used, rc = capi.fastq_frame_q(data, stride, TL, qmin=Q)
+    assert rc == 0 and used == len(data)
+    eng.begin_occ(M)
+    per = (n + pushes - 1) // pushes if n else 0
+    done = 0
+    while done < n:
+        m = min(per, n - done)
+        eng.push_reads(rows[done * stride:(done + m) * stride], stride, done)
+        done += m
+    return eng.finish()
+
+
+@pytest.mark.parametrize("M", [1, 2, 4, 7, 14])
+@pytest.mark.parametrize("name", ["L0K6", "L1K7", "L3K9", "L2K11"])
+def test_fastq_set_min_occurrence(capi, engine_for, shufs, oracle_for, name, M):
+    """~3x coverage of a pool with both strands, N and lower case: keys seen >= M times, reference slot order"""
+    if name == "L2K11" and M not in (1, 4):
+        pytest.skip("4.3 GB oracle table: two values of M are enough for the 16-component dump")
+    rs = np.random.RandomState(51)
+    seqs = ui.pool_reads(rs, 60000, 1200) + ui.ragged_reads(rs, 100)
+    data = ui.fastq_bytes(seqs)
+    rc, want = oracle_for(shufs(name)).co_from_fastq(data, Q=0, M=M)
+    assert rc == 0
+    got = run_occ(capi, engine_for(name), data, 2 * shufs(name).c.k, M, pushes=3 if M == 2 else 1)
+    assert all(g[1] is None for g in got)
+    if name in ("L0K6", "L1K7") and M <= 7:
+        assert sum(len(w[0]) for w in want) > 0
+    assert_same(got, want, "%s M=%d" % (name, M))
+
+
+@pytest.mark.parametrize("Q", [0, 36, 54, 73, 74])
+def test_fastq_set_quality_threshold(capi, engine_for, shufs, oracle_for, Q):
+    rs = np.random.RandomState(52)
+    seqs = ui.pool_reads(rs, 60000, 1500, p_n=0.0)
+    data = ui.fastq_bytes(seqs, quals=ui.random_quals(rs, seqs))
+    for name, M in (("L0K6", 2), ("L1K7", 1)):
+        rc, want = oracle_for(shufs(name)).co_from_fastq(data, Q=Q, M=M)
+        assert rc == 0
+        got = run_occ(capi, engine_for(name), data, 2 * shufs(name).c.k, M, Q=Q)
+        assert (sum(len(w[0]) for w in want) == 0) == (Q == 74)
+        assert_same(got, want, "%s Q=%d" % (name, Q))
+
+
+@pytest.mark.parametrize("variant", ["crlf", "trunc", "nonl", "one_nonl", "long", "empty"])
+def test_fastq_set_reader_edge_cases(capi, engine_for, shufs, oracle_for, variant):
+    """fastq2co()'s record rule (last record unterminated: read, not walked; first record always walked), CRLF,
+    reads beyond the 4096-byte row (windows overlapping by TL-1), a file of one empty read"""
+    rs = np.random.RandomState(53)
+    stride = 304
+    if variant == "one_nonl":
+        seqs = [ui.rand_seq(rs, 300)]
+    elif variant == "long":
+        seqs = [ui.rand_seq(rs, L) for L in (4094, 4095, 4096, 5000, 8191, 12000, 19997, 150, 0, 7000)]
+        stride = 4096
+    elif variant == "empty":
+        seqs = [b""]
+    else:
+        seqs = ui.ragged_reads(rs, 400)
+    data = ui.fastq_bytes(seqs, crlf=variant == "crlf", final_newline=variant not in ("nonl", "one_nonl"),
+                          drop_last_qual=variant == "trunc")
+    for name in ("L0K6", "L1K7"):
+        if name == "L0K6" and variant == "long":
+            continue  # 70 k random bases of 12-mers fit, but leave the dense table to the other cases
+        rc, want = oracle_for(shufs(name)).co_from_fastq(data, Q=0, M=1)
+        assert rc == 0
+        got = run_occ(capi, engine_for(name), data, 2 * shufs(name).c.k, 1, stride=stride)
+        assert_same(got, want, "%s %s" % (name, variant))
+
+
+def test_fastq_set_key_zero_is_kept(capi, engine_for, shufs, oracle_for):
+    """the 4-bit count field makes the slot word of key 0 non-zero (iseq2comem.c:398-399): unlike the FASTA set
+    flavours, key 0 is an ordinary key here"""
+    seqs = [b"A" * 150, b"C" * 150, b"G" * 150, b"T" * 150, b"AC" * 75, b"ACGT" * 37] * 3
+    data = ui.fastq_bytes(seqs)
+    for M in (1, 2, 7):
+        rc, want = oracle_for(shufs("L0K6z")).co_from_fastq(data, Q=0, M=M)
+        assert rc == 0
+        assert M > 2 or 0 in want[0][0].tolist()
+        got = run_occ(capi, engine_for("L0K6z"), data, 12, M)
+        assert_same(got, want, "M=%d" % M)
+
+
+def test_fastq_set_does_not_abort_above_hashlimit(capi, engine_for, shufs, oracle_for):
+    """fastq2co() never advances keycount (iseq2comem.c:404): 97 k distinct keys in 131 071 slots (hashlimit 78 642)
+    is a result there, not an abort; only a full table is an error here"""
+    rows = capi.synth_rows_host(6, 0, 700, 150, 160)
+    data = b"".join(b"@r\n" + bytes(rows[i * 160:i * 160 + 150]) + b"\n+\n" + b"I" * 150 + b"\n" for i in range(700))
+    ora = oracle_for(shufs("L0K6"))
+    rc, want = ora.co_from_fastq(data, Q=0, M=1)
+    assert rc == 0 and len(want[0][0]) > ora.P.hashlimit
+    eng = engine_for("L0K6")
+    got = run_occ(capi, eng, data, 12, 1, stride=160)
+    assert_same(got, want)
+    eng.begin(capi.MK_MODE_KOC)       # the counted flavour still aborts there (iseq2comem.c:708-709)
+    eng.push_reads(rows, 160, 0)
+    with pytest.raises(capi.CrowdedError):
+        eng.finish()
+    big = capi.synth_rows_host(5, 0, 5000, 150, 160)  # ~600 k distinct keys: more than the table has slots
+    eng.begin_occ(1)
+    eng.push_reads(big, 160, 0)
+    with pytest.raises(capi.CrowdedError):
+        eng.finish()
+    with pytest.raises(capi.MkError):
+        eng.begin_occ(15)             # iseq2comem.c:325
+    with pytest.raises(capi.MkError):
+        eng.begin_occ(0)
+
+
+def test_fastq_set_shard_merge(capi, shufs, oracle_for):
+    """the multi-GPU merge carries counts, so the occurrence filter applies to the merged counts"""
+    import ctypes as C
+    shuf = shufs("L1K7")
+    rs = np.random.RandomState(54)
+    seqs = ui.pool_reads(rs, 60000, 1500)
+    data = ui.fastq_bytes(seqs)
+    rows, n, nrec, used, rc = capi.fastq_frame_q(data, 160, 14)
+    assert rc == 0 and n == 1500
+    cut = 700
+    e0, e1 = capi.Engine(shuf, 0), capi.Engine(shuf, 0)
+    try:
+        e0.begin_occ(3)
+        e1.begin_occ(3)
+        e0.push_reads(rows[:cut * 160], 160, 0)
+        e1.push_reads(rows[cut * 160:], 160, cut)
+        d1 = e1.partial_count()
+        hip = C.CDLL("libamdhip64.so")
+        bufs = []
+        for nbytes in (8 * d1, 4 * d1, 8 * d1):
+            p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+            bufs.append(p)
+        assert e1.partial_export(bufs[0].value, bufs[1].value, bufs[2].value, d1) == d1
+        e0.partial_import(bufs[0].value, bufs[1].value, bufs[2].value, d1)
+        merged = e0.finish()
+        for p in bufs:
+            hip.hipFree(p)
+    finally:
+        e0.close()
+        e1.close()
+    rc, want = oracle_for(shuf).co_from_fastq(data, Q=0, M=3)
+    assert rc == 0 and len(want[0][0]) > 0
+    assert_same(merged, want)

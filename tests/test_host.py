@@ -142,6 +142,77 @@ def test_fastq_framing_stride_too_small_and_overlong_lines(capi):
     assert capi.fastq_frame(long_line, 4096)[3] == capi.MK_ERR_FORMAT
 
 
+def _occ_via_rows(ora, rows, stride, M):
+    """ids of the keys seen >= M times, in slot order, from the oracle's counted per-read loop over framed rows:
+    fastq2co inserts every key at first sight exactly like the counted loop, so the layouts coincide"""
+    rc, res = ora.koc_from_rows(rows, stride)
+    assert rc == 0
+    return [ids[cnt >= M] for ids, cnt in res]
+
+
+@pytest.mark.parametrize("variant", ["plain", "crlf", "trunc", "nonl", "qual", "one_nonl", "long"])
+@pytest.mark.parametrize("M", [1, 3])
+def test_fastq_frame_q_equals_fastq2co_reader(capi, shufs, oracle_for, variant, M):
+    """rows framed by mk_fastq_frame_q (quality mask, record rule, long-read windows), walked by the oracle's per-read
+    loop and filtered by count >= M == the oracle's restatement of fastq2co()+write_fqco2file() on the file bytes"""
+    rs = np.random.RandomState(8)
+    quals, Q, stride = None, 0, 304
+    if variant == "qual":
+        seqs = ui.pool_reads(rs, 3000, 150, p_n=0.0)
+        quals, Q = ui.random_quals(rs, seqs), 54
+    elif variant == "one_nonl":
+        seqs = [ui.rand_seq(rs, 250)]
+    elif variant == "long":
+        seqs = [ui.rand_seq(rs, L) for L in (4094, 4095, 4096, 9000, 150, 19997)]
+        seqs = seqs + seqs[:2] + seqs[:2]
+        stride = 4096
+    else:
+        seqs = ui.pool_reads(rs, 3000, 150) + ui.ragged_reads(rs, 150)
+    data = ui.fastq_bytes(seqs, crlf=variant == "crlf", final_newline=variant not in ("nonl", "one_nonl"),
+                          drop_last_qual=variant == "trunc", quals=quals)
+    sh = shufs("L1K7")
+    ora = oracle_for(sh)
+    rc, want = ora.co_from_fastq(data, Q=Q, M=M)
+    assert rc == 0
+    rows, n, nrec, used, rc = capi.fastq_frame_q(data, stride, 2 * sh.c.k, qmin=Q)
+    assert rc == 0 and used == len(data)
+    walked = len(seqs) - (1 if variant in ("trunc", "nonl") else 0)
+    assert nrec == walked
+    assert (n > nrec) == (variant == "long")
+    got = _occ_via_rows(ora, rows, stride, M)
+    assert sum(len(w[0]) for w in want) > 0 or (variant == "one_nonl" and M > 1)
+    for g, (w, _) in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_fastq_frame_q_streams_in_chunks_and_widens(capi):
+    rs = np.random.RandomState(9)
+    seqs = ui.ragged_reads(rs, 200)
+    quals = ui.random_quals(rs, seqs)
+    data = ui.fastq_bytes(seqs, quals=quals)
+    whole, n, nrec, used, rc = capi.fastq_frame_q(data, 304, 14, qmin=54)
+    assert rc == 0 and nrec == len(seqs) and used == len(data)
+    pieces, pos, buf, recs = [], 0, b"", 0
+    while True:
+        take = data[pos:pos + 555]
+        pos += len(take)
+        buf += take
+        final = pos >= len(data)
+        rows, k, r, used, rc = capi.fastq_frame_q(buf, 304, 14, qmin=54, final=final, records_before=recs)
+        assert rc == 0
+        pieces.append(rows)
+        recs += r
+        buf = buf[used:]
+        if final:
+            break
+    assert recs == len(seqs) and np.array_equal(np.concatenate(pieces), whole)
+    # a read longer than the row: MK_ERR_ARG until the stride is 4096, then it is windowed
+    data = ui.fastq_bytes([b"ACGT" * 10, b"A" * 500])
+    rows, n, nrec, used, rc = capi.fastq_frame_q(data, 64, 14)
+    assert rc == capi.MK_ERR_ARG and nrec == 1
+    assert capi.fastq_frame_q(ui.fastq_bytes([b"A" * 19999]), 4096, 14)[4] == capi.MK_ERR_FORMAT
+
+
 @pytest.mark.parametrize("stride,chunk", [(64, None), (256, 100), (4096, 7)])
 def test_fasta_windows_cover_every_kmer_once(capi, stride, chunk):
     """rows overlap by TL-1 bases: concatenating row payloads minus the overlaps gives back the cleaned stream"""

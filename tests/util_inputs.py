@@ -24,11 +24,11 @@ def rows_from_seqs(seqs, stride):
     return rows
 
 
-def fastq_bytes(seqs, crlf=False, final_newline=True, drop_last_qual=False):
+def fastq_bytes(seqs, crlf=False, final_newline=True, drop_last_qual=False, quals=None):
     nl = b"\r\n" if crlf else b"\n"
     out = []
     for i, s in enumerate(seqs):
-        rec = [b"@r%d" % i, s, b"+", b"I" * len(s)]
+        rec = [b"@r%d" % i, s, b"+", quals[i] if quals is not None else b"I" * len(s)]
         if drop_last_qual and i == len(seqs) - 1:
             rec = rec[:3]
         out.append(nl.join(rec) + nl)
@@ -76,3 +76,15 @@ def ragged_reads(rs, nreads, lens=(0, 1, 21, 22, 23, 50, 100, 150, 151, 250, 300
             s = s[:j] + b"NNN" + s[j + 3:]
         seqs.append(s)
     return seqs
+
+
+def random_quals(rs, seqs, p_low=0.08, low=b"#+5?", high=b"I"):
+    """per-base quality bytes: mostly `high`, a fraction p_low drawn from `low`"""
+    lo = np.frombuffer(low, np.uint8)
+    out = []
+    for s in seqs:
+        q = np.full(len(s), high[0], np.uint8)
+        m = rs.rand(len(s)) < p_low
+        q[m] = lo[rs.randint(0, len(lo), size=int(m.sum()))]
+        out.append(q.tobytes())
+    return out
