@@ -130,10 +130,21 @@ __device__ __forceinline__ uint64_t mk_revcomp(uint64_t f, uint32_t TL) {
   return n >> (64u - 2u * TL);
 }
 
+/* The scan kernel's 2-bit code of a base is (byte >> 1) & 3: A=0 C=1 T=2 G=3 -- two VALU ops per four bases
+ * cheaper than the reference's A=0 C=1 G=2 T=3 (Basemap, global_basic.c:62-69).  The two codings differ by the
+ * Gray map c ^ (c >> 1), which is its own inverse on 2 bits; the LDS filter is built over re-coded substrings
+ * and every candidate k-mer is re-coded once here, before anything reference-defined is computed from it. */
+#ifdef MK_STD_CODES
+__device__ __forceinline__ uint64_t mk_scan_to_ref_codes(uint64_t k) { return k; }
+#else
+__device__ __forceinline__ uint64_t mk_scan_to_ref_codes(uint64_t k) { return k ^ ((k >> 1) & 0x5555555555555555ull); }
+#endif
+
 /* One candidate = the FORWARD k-mer whose inner substring passed the strand-symmetric LDS filter.  Form the
  * canonical k-mer (iseq2comem.c:691), look it up in the .shuf table (:692-695), reduce to the key (:696-699)
  * and upsert. */
-__device__ __forceinline__ void mk_resolve_one(const mk_scan_args &a, uint64_t fwd, uint64_t ord) {
+__device__ __forceinline__ void mk_resolve_one(const mk_scan_args &a, uint64_t scan_fwd, uint64_t ord) {
+  const uint64_t fwd = mk_scan_to_ref_codes(scan_fwd);
   const uint64_t rc = mk_revcomp(fwd, a.kp.TL);
   const uint64_t uni = fwd < rc ? fwd : rc;
   const uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
@@ -239,7 +250,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   for (uint32_t i = threadIdx.x; i < a.bm_words; i += blockDim.x) bitmap[i] = 0u;
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < a.n_accept; i += blockDim.x) {
-    const uint32_t d = a.accept[i];
+    const uint32_t d = (uint32_t)mk_scan_to_ref_codes(a.accept[i]); /* reference coding -> scan coding (same map) */
     atomicOr(&bitmap[(d >> 10) & (a.bm_words - 1u)], mk_filter_mask(d));
   }
   __syncthreads();
@@ -405,9 +416,14 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     if (__any(mn == 0u)) hits4(q, pos0);
   };
   auto decode = [&](uint32_t w, uint32_t &codes, uint32_t &x) {
+#ifdef MK_STD_CODES
     codes = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
-    /* expected upper-case letter of each code, compared with the byte folded to upper case */
     const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u, codes);
+#else
+    codes = (w >> 1) & 0x03030303u; /* scan coding A0 C1 T2 G3, see mk_scan_to_ref_codes */
+    /* expected upper-case letter of each code, compared with the byte folded to upper case */
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, codes);
+#endif
     x = (w & 0xDFDFDFDFu) ^ expect; /* byte j zero <=> byte j in ACGTacgt */
   };
   /* One dword outside the fast path.
