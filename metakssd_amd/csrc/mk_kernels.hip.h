@@ -179,18 +179,18 @@ __global__ void __launch_bounds__(256) mk_resolve_kernel(const mk_scan_args a, u
  * substring of the reverse-complement k-mer is the reverse complement of the forward one: a k-mer can only
  * be accepted if its FORWARD inner substring is in B, whichever strand turns out to be canonical.  The hot
  * loop therefore rolls and probes the forward strand only; canonicalisation happens for filter hits, in
- * mk_resolve_one.  One 32-bit word per probe: word = bits 10.. of the substring, three bit positions = its bits
- * 0-4, 5-9 and 3-7.  8192 entries in 16384 words: about 0.06 % false positives; correctness never depends on
+ * mk_resolve_one.  One 32-bit word per probe: word = bits 10.. of the substring, three bit positions = its 5-bit
+ * fields at bit offsets 0, 2 and 6.  8192 entries in 16384 words: about 0.1 % false positives; correctness never depends on
  * it (every candidate is re-checked against the accept bitmap / .shuf table). */
 __device__ __forceinline__ uint32_t mk_filter_mask(uint32_t x) {
-#if defined(MK_FILTER_OLD)
-  return (1u << (x & 31u)) | (1u << ((x >> 5) & 31u)) | (1u << ((x >> 3) & 31u));
-#else
   /* bit positions = the 5-bit fields at offsets 0, 2 and 6 of the substring.  EVEN offsets on purpose: the
    * substring slides by one base (2 bits) per step, so field 2k of this base's substring is the low 5 bits of
    * the substring k bases earlier -- in the tuned loop those are already in registers (no extra shifts). */
+  /* (a fourth field at offset 4 would be free in the loop -- v_or3_b32 -- but measured MORE false positives:
+   * the overlapping fields are too correlated) */
+  /* (other even offsets measured worse: (0,4,6) +1 %, (0,2,4) +6 %, anything using offset 8 +13..25 % -- those
+   * bits also pick the word) */
   return (1u << (x & 31u)) | (1u << ((x >> 2) & 31u)) | (1u << ((x >> 6) & 31u));
-#endif
 }
 
 /* rolling forward k-mer (iseq2comem.c:685).
@@ -230,6 +230,27 @@ template <> struct mk_kmer<11> : mk_kmer_hi<11> {};
 template <> struct mk_kmer<12> : mk_kmer_hi<12> {};
 
 typedef __attribute__((address_space(3))) const uint32_t *mk_lds_cu32;
+
+/* scan code of byte J of a raw dword: (byte >> 1) & 3 in one instruction */
+template <int J>
+__device__ __forceinline__ uint32_t mk_code_of(uint32_t w) {
+  uint32_t r;
+  asm("v_bfe_u32 %0, %1, %2, 2" : "=v"(r) : "v"(w), "n"(8 * J + 1));
+  return r;
+}
+
+/* 1 << ((flo >> SH) & 31).  For SH == 8 (k = 11) the shift amount is byte 1 of flo, which SDWA selects for free. */
+template <uint32_t SH>
+__device__ __forceinline__ uint32_t mk_onehot_at(uint32_t flo) {
+  if constexpr (SH == 8u) {
+    uint32_t r;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
+        : "=v"(r) : "v"(flo), "s"(1u));
+    return r;
+  } else {
+    return 1u << ((flo >> SH) & 31u);
+  }
+}
 
 /* SWAR helpers on four bytes */
 __device__ __forceinline__ uint32_t mk_nonzero_bytes(uint32_t v) { /* bit 7 of byte j set <=> byte j != 0 */
@@ -366,20 +387,22 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   /* append the lanes flagged in `hit` (forward k-mer `fwd` ending at row position `pos`) to this wave's
    * candidate buffer: plain stores, nothing to wait for */
   auto push = [&](bool hit, uint64_t fwd, uint32_t pos) {
+    const uint64_t ord = ord_row | (uint64_t)pos;
     const uint64_t m = __ballot(hit);
     if (m == 0) return;
     const uint32_t cnt = (uint32_t)__popcll(m);
     if (qn + cnt > a.cand_cap) { /* buffer full (dense tables only): resolve right here */
-      mk_resolve_inline(ka, hit, fwd, ord_row | (uint64_t)pos);
+      mk_resolve_inline(ka, hit, fwd, ord);
       return;
     }
     if (hit) {
       const uint32_t off = qn + mk_mbcnt(m);
       my_fwd[off] = fwd;
-      my_ord[off] = ord_row | (uint64_t)pos;
+      my_ord[off] = ord;
     }
     qn = __builtin_amdgcn_readfirstlane(qn + cnt);
   };
+
   /* four valid bases, every lane with a full window: roll, canonical k-mer, filter probe */
   auto fast4 = [&](uint32_t codes, quad &q) {
     km.roll(codes & 3u, a.kp);         q.u0 = km.fwd(); lookup(q.m0, q.w0);
@@ -509,6 +532,12 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
           bool have_pair = false;
           if (uniform) {
             uint32_t flo = km.flo;
+            /* one-hot filter words of the three previous bases' substrings (see probe below) */
+            uint32_t oh1, oh2, oh3;
+            auto oh_init = [&]() {
+              oh1 = 1u << ((flo >> (SH + 2u)) & 31u); oh2 = 1u << ((flo >> (SH + 4u)) & 31u); oh3 = 1u << ((flo >> (SH + 6u)) & 31u);
+            };
+            oh_init();
             for (;;) { /* inner fast loop: leaves at a pair boundary */
               w0 = nw0; w1 = nw1;
               nw0 = myrow[2 * p + 2]; /* unconditional prefetch: at most 2 dwords past the row, inside the wave's LDS */
@@ -516,61 +545,60 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
               decode(w0, c0, x0);
               decode(w1, c1, x1);
               uint32_t e = 8u; /* bases of this pair in front of the (common) newline */
-              if (!__all((x0 | x1) == 0u)) {
-                /* not eight valid bases everywhere: still fine if every lane has the same bytes-before-newline
-                 * pattern with only valid bases in front of it (the tail of fixed-length reads) */
+              const uint32_t bad = x0 | x1; /* non-zero: a byte of this lane's pair is not ACGTacgt */
+              /* Not eight valid bases everywhere: still fine if every lane has the same bytes-before-newline pattern
+               * with only valid bases in front of it (the tail of fixed-length reads).  Returns false when the pair
+               * has to go to the slow path; sets e otherwise. */
+              auto common_newline = [&]() -> bool {
                 const uint32_t nl0 = mk_nonzero_bytes(w0 ^ 0x0A0A0A0Au) ^ 0x80808080u; /* 0x80 where byte == '\n' */
                 const uint32_t nl1 = mk_nonzero_bytes(w1 ^ 0x0A0A0A0Au) ^ 0x80808080u;
                 const uint32_t s0 = __builtin_amdgcn_readfirstlane(nl0), s1 = __builtin_amdgcn_readfirstlane(nl1);
-                uint32_t ee = s0 ? (uint32_t)__builtin_ctz(s0) >> 3 : (s1 ? 4u + ((uint32_t)__builtin_ctz(s1) >> 3) : 8u);
+                const uint32_t ee = s0 ? (uint32_t)__builtin_ctz(s0) >> 3 : (s1 ? 4u + ((uint32_t)__builtin_ctz(s1) >> 3) : 8u);
                 /* bytes in front of position ee must be valid in every lane; the newline must be where lane 0 has it */
                 const uint64_t inval = ((uint64_t)mk_nonzero_bytes(x1) << 32) | mk_nonzero_bytes(x0);
                 const uint64_t front = ee >= 8u ? ~0ull : ((1ull << (8u * ee)) - 1ull);
                 const bool ok = ee < 8u && (inval & front) == 0ull && nl0 == s0 && nl1 == s1;
-                if (!__all(ok)) { have_pair = true; break; }
+                if (!__all(ok)) return false;
                 e = ee;
-              }
+                return true;
+              };
+              /* tested BEFORE the probes go out: folding this test into the hit test (one branch per pair, probes
+               * issued speculatively) measured 4 % slower */
+              if (!__all(bad == 0u) && !common_newline()) { have_pair = true; break; }
               const uint32_t fstart = flo;
               if (urun + 8u < TL) { /* nobody completes a k-mer in this pair: roll only */
-                flo = (flo << 2) | (c0 & 3u);
-                flo = (flo << 2) | __builtin_amdgcn_ubfe(c0, 8, 2);
-                flo = (flo << 2) | __builtin_amdgcn_ubfe(c0, 16, 2);
-                flo = (flo << 2) | (c0 >> 24);
-                flo = (flo << 2) | (c1 & 3u);
-                flo = (flo << 2) | __builtin_amdgcn_ubfe(c1, 8, 2);
-                flo = (flo << 2) | __builtin_amdgcn_ubfe(c1, 16, 2);
-                flo = (flo << 2) | (c1 >> 24);
+                flo = (flo << 2) | mk_code_of<0>(w0);
+                flo = (flo << 2) | mk_code_of<1>(w0);
+                flo = (flo << 2) | mk_code_of<2>(w0);
+                flo = (flo << 2) | mk_code_of<3>(w0);
+                flo = (flo << 2) | mk_code_of<0>(w1);
+                flo = (flo << 2) | mk_code_of<1>(w1);
+                flo = (flo << 2) | mk_code_of<2>(w1);
+                flo = (flo << 2) | mk_code_of<3>(w1);
+                oh_init();
               } else {
                 uint32_t f0, f1, f2, f3, f4, f5, f6, f7, m0, m1, m2, m3, m4, m5, m6, m7, d0, d1, d2, d3, d4, d5, d6, d7;
-#if defined(MK_FILTER_OLD)
+                /* Filter fields at offsets 0, 2, 6 of the substring x_j: because x_{j-1} = x_j >> 2, the three bits of
+                 * base j are the one-hot words of the low 5 bits of x_j, x_{j-1} and x_{j-3} -- one new one-hot per
+                 * base, the other two are carried (across pairs too: oh1..oh3). */
                 auto probe = [&](uint32_t code, uint32_t &fl, uint32_t &m, uint32_t &wd) {
-                  const uint32_t xx = flo >> SH;
                   wd = *(mk_lds_cu32)(uintptr_t)((flo >> (SH + 8u)) & 0xFFFCu);
-                  m = mk_filter_mask(xx);
+                  const uint32_t oh = mk_onehot_at<SH>(flo);
+                  m = oh | oh1 | oh3;
+                  oh3 = oh2; oh2 = oh1; oh1 = oh;
                   flo = (flo << 2) | code;
                   fl = flo;
                 };
-#else
-                /* substrings of the three previous bases (x_{j-1} = x_j >> 2): their low 5 bits are this base's
-                 * filter fields at offsets 2, 4, 6 */
-                uint32_t xm1 = flo >> (SH + 2u), xm2 = flo >> (SH + 4u), xm3 = flo >> (SH + 6u);
-                auto probe = [&](uint32_t code, uint32_t &fl, uint32_t &m, uint32_t &wd) {
-                  const uint32_t xx = flo >> SH;
-                  wd = *(mk_lds_cu32)(uintptr_t)((flo >> (SH + 8u)) & 0xFFFCu);
-                  m = (1u << (xx & 31u)) | (1u << (xm1 & 31u)) | (1u << (xm3 & 31u));
-                  xm3 = xm2; xm2 = xm1; xm1 = xx;
-                  flo = (flo << 2) | code;
-                  fl = flo;
-                };
-#endif
-                probe(c0 & 3u, f0, m0, d0);
-                probe(__builtin_amdgcn_ubfe(c0, 8, 2), f1, m1, d1);
-                probe(__builtin_amdgcn_ubfe(c0, 16, 2), f2, m2, d2);
-                probe(c0 >> 24, f3, m3, d3);
-                probe(c1 & 3u, f4, m4, d4);
-                probe(__builtin_amdgcn_ubfe(c1, 8, 2), f5, m5, d5);
-                probe(__builtin_amdgcn_ubfe(c1, 16, 2), f6, m6, d6);
-                probe(c1 >> 24, f7, m7, d7);
+                /* code j straight from the raw dword with one v_bfe_u32 (left to itself the compiler shifts, then
+                 * uses v_and_or_b32) */
+                probe(mk_code_of<0>(w0), f0, m0, d0);
+                probe(mk_code_of<1>(w0), f1, m1, d1);
+                probe(mk_code_of<2>(w0), f2, m2, d2);
+                probe(mk_code_of<3>(w0), f3, m3, d3);
+                probe(mk_code_of<0>(w1), f4, m4, d4);
+                probe(mk_code_of<1>(w1), f5, m5, d5);
+                probe(mk_code_of<2>(w1), f6, m6, d6);
+                probe(mk_code_of<3>(w1), f7, m7, d7);
                 __builtin_amdgcn_sched_barrier(0); /* all eight probes in flight before the first result is read */
 #ifndef MK_NO_SINGLE_WAIT
                 __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) once, instead of a staggered wait per probe */
