@@ -432,7 +432,7 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
     const uint32_t used_slots = (uint32_t)blocks * waves;
     mk_evpair ev2{};
     if (e->profiling) { ev2 = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev2.a, e->stream)); }
-    hipLaunchKernelGGL(mk_resolve_kernel, dim3(used_slots), dim3(256), 0, e->stream, a, used_slots);
+    hipLaunchKernelGGL(mk_resolve_kernel, dim3(used_slots), dim3(MK_RESOLVE_THREADS), 0, e->stream, a, used_slots);
     MK_HIP(e, hipGetLastError());
     if (e->profiling) { MK_HIP(e, hipEventRecord(ev2.b, e->stream)); e->ev_resolve.push_back(ev2); }
   }

@@ -103,6 +103,8 @@ __device__ __forceinline__ void mk_upsert(const mk_table &tab, uint32_t S, uint6
   mk_probe_init(key, S, n, h2);
   const unsigned long long fresh = ((unsigned long long)key << MK_CNT_BITS) | add;
   for (uint32_t i = 0; i < S; i++) {
+    /* load, then CAS only on an empty slot (CAS-first measured the same on all-distinct input and costs a failed
+     * atomic per occurrence on repeat-heavy input) */
     unsigned long long cur = __hip_atomic_load(&tab.kc[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool mine = false;
     if (cur == 0ull) {
@@ -166,7 +168,8 @@ __device__ __noinline__ void mk_resolve_inline(const mk_scan_args *ka, bool hit,
 }
 
 /* resolves the candidates the scan kernel appended: one workgroup per producer wave slot */
-__global__ void __launch_bounds__(256) mk_resolve_kernel(const mk_scan_args a, uint32_t nslots) {
+#define MK_RESOLVE_THREADS 1024 /* measured 256: 0.233 ms, 512: 0.230, 1024: 0.212 (50 M reads, 7 M candidates) */
+__global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk_scan_args a, uint32_t nslots) {
   for (uint32_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
     const uint32_t n = a.cand_count[slot];
     const unsigned long long *f = a.cand_fwd + (size_t)slot * a.cand_cap, *o = a.cand_ord + (size_t)slot * a.cand_cap;
