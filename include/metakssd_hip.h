@@ -216,6 +216,26 @@ int mk_sketchdir_open(const char *outdir, const mk_params *p, int koc, int nfile
 int mk_sketchdir_add(mk_sketchdir *d, const char *input_path, const mk_result *r);
 int mk_sketchdir_close(mk_sketchdir *d);
 
+/* ---- `metakssd set -u` / `set -q` ---------------------------------------------------
+ * sketch_union() (command_set.c:241-319) and uniq_sketch_union() (:427-512) push every id of a component's combined
+ * sketch file through a 2^32-bit dictionary and write the marked ids in ascending order (pan.N); -q keeps the ids
+ * that occur exactly once in the whole file (uniq_pan.N).  mk_setop holds the dictionaries on the device:
+ *   mk_setop_begin  = memset(dict..)            :284 / :473-474
+ *   mk_setop_add    = the marking loop          :293-296 / :482-490   (any number of calls, host or device lists)
+ *   mk_setop_finish = the ascending walk        :303-312 / :496-505   -> ids in library-owned pinned host memory,
+ *                     valid until the next begin/finish/destroy on this handle */
+enum { MK_SET_UNION = 0, MK_SET_UNIQ_UNION = 1 };
+typedef struct mk_setop mk_setop;
+int mk_setop_create(int device, mk_setop **out); /* MK_ERR_NO_DEVICE without a HIP device: no CPU path */
+int mk_setop_destroy(mk_setop *s);
+const char *mk_setop_last_error(const mk_setop *s); /* s may be NULL: last error of a failed create */
+int mk_setop_begin(mk_setop *s, int mode);
+int mk_setop_add(mk_setop *s, const uint32_t *ids, uint64_t n);            /* host list; returns when `ids` may be reused */
+int mk_setop_add_device(mk_setop *s, const uint32_t *ids_dev, uint64_t n); /* device list, asynchronous on mk_setop_stream() */
+int mk_setop_finish(mk_setop *s, const uint32_t **ids_out, uint64_t *n_out);
+int mk_setop_result_device(mk_setop *s, const uint32_t **ids_dev, uint64_t *n); /* the same result, left in HBM */
+void *mk_setop_stream(mk_setop *s); /* hipStream_t the handle works on */
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,13 @@ def _load():
         "mk_fasta_window_init": [C.POINTER(FastaStateC), i32],
         "mk_fasta_window": [C.POINTER(FastaStateC), vp, C.c_size_t, C.c_int, vp, u32, u64, C.POINTER(u64),
                             C.POINTER(C.c_size_t)],
+        "mk_setop_create": [C.c_int, C.POINTER(vp)],
+        "mk_setop_destroy": [vp],
+        "mk_setop_begin": [vp, C.c_int],
+        "mk_setop_add": [vp, vp, u64],
+        "mk_setop_add_device": [vp, vp, u64],
+        "mk_setop_finish": [vp, C.POINTER(vp), C.POINTER(u64)],
+        "mk_setop_result_device": [vp, C.POINTER(vp), C.POINTER(u64)],
         "mk_sketchdir_open": [C.c_char_p, C.POINTER(ParamsC), C.c_int, C.c_int, C.POINTER(vp)],
         "mk_sketchdir_add": [vp, C.c_char_p, C.POINTER(ResultC)],
         "mk_sketchdir_close": [vp],
@@ -111,6 +118,10 @@ def _load():
         fn.restype = C.c_int
     lib.mk_shuf_free.argtypes = [C.POINTER(ShufC)]
     lib.mk_shuf_free.restype = None
+    lib.mk_setop_last_error.argtypes = [vp]
+    lib.mk_setop_last_error.restype = C.c_char_p
+    lib.mk_setop_stream.argtypes = [vp]
+    lib.mk_setop_stream.restype = vp
     lib.mk_last_error.argtypes = [vp]
     lib.mk_last_error.restype = C.c_char_p
     return lib
@@ -329,3 +340,52 @@ class Engine:
 
 def synth_rows_device(device, stream, seed, first_read, nreads, length, stride, dev_ptr):
     _check(lib.mk_synth_rows_device(device, C.c_void_p(stream), seed, first_read, nreads, length, stride, C.c_void_p(dev_ptr)))
+
+
+MK_SET_UNION, MK_SET_UNIQ_UNION = 0, 1
+
+
+class SetOp:
+    """`metakssd set -u / -q` dictionaries on the device (mk_setop_*)"""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib.mk_setop_create(device, C.byref(self.h))
+        if rc:
+            raise MkError(rc, (lib.mk_setop_last_error(None) or b"").decode())
+
+    def _check(self, rc):
+        if rc:
+            raise MkError(rc, (lib.mk_setop_last_error(self.h) or b"").decode())
+
+    def union(self, id_lists, uniq=False):
+        """id_lists: iterable of uint32 numpy arrays -> ascending uint32 array"""
+        self._check(lib.mk_setop_begin(self.h, MK_SET_UNIQ_UNION if uniq else MK_SET_UNION))
+        for a in id_lists:
+            a = np.ascontiguousarray(a, dtype=np.uint32)
+            if a.size:
+                self._check(lib.mk_setop_add(self.h, a.ctypes.data, a.size))
+        out, n = C.c_void_p(), C.c_uint64(0)
+        self._check(lib.mk_setop_finish(self.h, C.byref(out), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, np.uint32)
+        return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
+
+    def begin(self, uniq=False):
+        self._check(lib.mk_setop_begin(self.h, MK_SET_UNIQ_UNION if uniq else MK_SET_UNION))
+
+    def add_device(self, dev_ptr, n):
+        self._check(lib.mk_setop_add_device(self.h, C.c_void_p(dev_ptr), n))
+
+    def finish_count(self):
+        out, n = C.c_void_p(), C.c_uint64(0)
+        self._check(lib.mk_setop_finish(self.h, C.byref(out), C.byref(n)))
+        return n.value
+
+    def stream(self):
+        return lib.mk_setop_stream(self.h)
+
+    def close(self):
+        if self.h:
+            lib.mk_setop_destroy(self.h)
+            self.h = C.c_void_p()

@@ -310,8 +310,83 @@ static void *pf_worker(void *arg) {
 static void usage(void) {
   fprintf(stderr,
           "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D] <fastq|fasta|dir>...\n"
+          "       metakssd set -u|-q [-o outdir] [--device D] <sketch dir>\n"
           "       metakssd shuffle -k <halfK> -s <halfSubK> -l <level> [--seed N] -o <prefix>\n");
   exit(2);
+}
+
+/* ---- `metakssd set -u | -q [-o outdir] <sketch dir>`: sketch_union() / uniq_sketch_union(), command_set.c:241-319,427-512 ----
+ * The dictionary work runs on the device (mk_setop_*); the directory handling follows the reference: the 32-byte
+ * cofiles.stat header is copied as it is, one pan.N / uniq_pan.N per component, and a sketch directory holding a
+ * single sketch is offered for renaming in place (:254-267). */
+static int cmd_set(int argc, char **argv) {
+  int op = -1, device = 0; /* 2 union, 3 uniq_union (command_set.c:55) */
+  const char *outdir = "./", *in = NULL;
+  for (int i = 0; i < argc; i++) {
+    if (!strcmp(argv[i], "-u")) { if (op != -1) printf("set operation is already set, -u is ignored.\n"); else op = 2; }
+    else if (!strcmp(argv[i], "-q")) { if (op != -1) printf("set operation is already set, -q is ignored.\n"); else op = 3; }
+    else if (!strcmp(argv[i], "-o") && i + 1 < argc) outdir = argv[++i];
+    else if (!strcmp(argv[i], "-p") && i + 1 < argc) ++i; /* threads: no meaning here */
+    else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+    else if (argv[i][0] == '-' && argv[i][1]) die("set option %s is not part of this build (-u and -q are)", argv[i]);
+    else if (!in) in = argv[i];
+  }
+  if (!in) usage();
+  if (op == -1) { printf("set operation use : -u, -q, -i or -s\n"); return 255; }
+  const char *prefix = op == 2 ? "pan" : "uniq_pan";
+  const char *fn = op == 2 ? "sketch_union()" : "uniq_sketch_union()";
+  char path[PATHLEN * 2 + 32];
+  snprintf(path, sizeof path, "%s/cofiles.stat", in);
+  FILE *f = fopen(path, "rb");
+  if (!f) die("cannot find cofiles.stat under %s ", in);
+  unsigned char hdr[32];
+  if (fread(hdr, 1, 32, f) != 32) die("%s:%s", fn, path);
+  fclose(f);
+  int32_t comp_num, infile_num;
+  memcpy(&comp_num, hdr + 16, 4);
+  memcpy(&infile_num, hdr + 20, 4);
+  if (infile_num == 1) {
+    char reply = 0;
+    printf("only 1 sketch, use %s as pan-sketch?(Y/N)\n", in);
+    if (scanf(" %c", &reply) == 1 && (reply == 'Y' || reply == 'y')) {
+      for (int c = 0; c < comp_num; c++) {
+        char a[PATHLEN * 2 + 32], b[PATHLEN * 2 + 32];
+        snprintf(a, sizeof a, "%s/combco.%d", in, c);
+        snprintf(b, sizeof b, "%s/%s.%d", in, prefix, c);
+        if (rename(a, b) != 0) die("%s: %s", fn, strerror(errno));
+      }
+      printf("the union directory: %s created successfully\n", in);
+      return 0;
+    }
+  }
+  mkdir(outdir, 0777);
+  snprintf(path, sizeof path, "%s/cofiles.stat", outdir);
+  if (!(f = fopen(path, "wb"))) die("%s:%s", fn, path);
+  fwrite(hdr, 1, 32, f);
+  fclose(f);
+  mk_setop *so;
+  if (mk_setop_create(device, &so) != MK_OK) die("mk_setop_create failed: %s", mk_setop_last_error(NULL));
+  for (int c = 0; c < comp_num; c++) {
+    snprintf(path, sizeof path, "%s/combco.%d", in, c);
+    struct stat st;
+    if (stat(path, &st) != 0) die("%s:%s", fn, path);
+    const uint64_t n = (uint64_t)st.st_size / 4;
+    uint32_t *ids = NULL;
+    if (mk_host_alloc((void **)&ids, n ? n * 4 : 4) != MK_OK) die("out of memory");
+    if (!(f = fopen(path, "rb")) || fread(ids, 4, n, f) != n) die("%s:%s", fn, path);
+    fclose(f);
+    const uint32_t *out = NULL;
+    uint64_t m = 0;
+    if (mk_setop_begin(so, op == 2 ? MK_SET_UNION : MK_SET_UNIQ_UNION) != MK_OK || mk_setop_add(so, ids, n) != MK_OK ||
+        mk_setop_finish(so, &out, &m) != MK_OK)
+      die("%s: %s", fn, mk_setop_last_error(so));
+    mk_host_free(ids);
+    snprintf(path, sizeof path, "%s/%s.%d", outdir, prefix, c);
+    if (!(f = fopen(path, "wb")) || fwrite(out, 4, m, f) != m) die("%s:%s", fn, path);
+    fclose(f);
+  }
+  mk_setop_destroy(so);
+  return 0;
 }
 
 static int cmd_shuffle(int argc, char **argv) {
@@ -340,7 +415,8 @@ int main(int argc, char **argv) {
   setvbuf(stdout, NULL, _IOLBF, 0);
   if (argc < 2) usage();
   if (!strcmp(argv[1], "shuffle")) return cmd_shuffle(argc - 2, argv + 2);
-  if (strcmp(argv[1], "dist") != 0) die("only the `dist` sketching path and `shuffle` are part of this build (got `%s`)", argv[1]);
+  if (!strcmp(argv[1], "set")) return cmd_set(argc - 2, argv + 2);
+  if (strcmp(argv[1], "dist") != 0) die("only the `dist` sketching path, `set -u/-q` and `shuffle` are part of this build (got `%s`)", argv[1]);
 
   const char *shuf_path = NULL, *outdir = ".";
   int abundance = 0, uniq = 0, device = 0, quiet = 0, nthreads = 8;

@@ -1,0 +1,326 @@
+/*
+ * mk_setop.hip -- `metakssd set -u` / `set -q` on the device.
+ *
+ * Replaces the dictionary loops of sketch_union() (command_set.c:279-316) and uniq_sketch_union()
+ * (:466-509): the reference marks every id of a combined sketch file in a 2^32-bit dictionary (plus a second
+ * "still unique" dictionary for -q) and walks the dictionary to emit the ids in ascending order.  Here:
+ *
+ *   mk_set_mark_kernel    ids -> atomicOr into the `seen` bitmap (and, for -q, into `dup` when the bit was set)
+ *   mk_set_count_kernel   popcount of seen (& ~dup) per 1024-word chunk            (one pass over the bitmaps)
+ *   mk_set_scan_kernel    exclusive prefix over the 131 072 chunk counts
+ *   mk_set_write_kernel   non-empty chunks only: bits -> ascending ids at the chunk's offset
+ *
+ * All HBM-bound byte/bit work (no contraction, MFMA does not apply): the count pass streams 512 MiB (1 GiB for -q);
+ * the mark pass is bound by device-scope atomics.  The bit order inside a word is ours (LSB first); only the
+ * ascending id order is observable, and that is what the reference's MSB-first walk produces too.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "metakssd_hip.h"
+
+#define MK_SET_WORDS (1ull << 27)          /* 2^32 bits */
+#define MK_SET_CHUNK_WORDS 1024u           /* one wave per chunk: 16 consecutive words per lane */
+#define MK_SET_NCHUNKS (uint32_t)(MK_SET_WORDS / MK_SET_CHUNK_WORDS)
+
+struct mk_setop {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint32_t *d_seen = nullptr, *d_dup = nullptr;
+  uint32_t *d_chunk = nullptr;              /* [NCHUNKS] counts, then exclusive offsets (low 32 bits) */
+  unsigned long long *d_chunk_off = nullptr; /* [NCHUNKS] 64-bit exclusive offsets */
+  unsigned long long *d_total = nullptr, *h_total = nullptr;
+  uint32_t *d_stage[2] = {nullptr, nullptr};
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
+  uint32_t *d_out = nullptr, *h_out = nullptr;
+  uint64_t out_cap = 0, h_cap = 0;
+  int mode = -1;
+  bool begun = false;
+  int num_cu = 256;
+  char err[256] = {0};
+};
+
+static thread_local char mk_set_create_err[256];
+
+static int mk_set_fail(mk_setop *s, int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(s ? s->err : mk_set_create_err, 256, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define MK_SET_HIP(s, call)                                                                          \
+  do {                                                                                               \
+    hipError_t _r = (call);                                                                          \
+    if (_r != hipSuccess) return mk_set_fail(s, MK_ERR_HIP, "%s: %s", #call, hipGetErrorString(_r)); \
+  } while (0)
+
+#define MK_SET_STAGE_IDS ((size_t)16 << 20) /* 64 MiB of ids per staging buffer */
+
+/* ---- kernels ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ void mk_set_mark_one(uint32_t v, uint32_t *seen, uint32_t *dup) {
+  const uint32_t w = v >> 5, bit = 1u << (v & 31u);
+  if (dup) {
+    /* bits are only ever set, so a (possibly stale, the per-XCD L2s are not coherent) read that already shows
+     * the duplicate bit is final; otherwise the atomic's return value decides */
+    if (dup[w] & bit) return;
+    const uint32_t old = atomicOr(&seen[w], bit);
+    if (old & bit) atomicOr(&dup[w], bit);
+  } else {
+    if (seen[w] & bit) return;
+    atomicOr(&seen[w], bit);
+  }
+}
+
+__global__ void __launch_bounds__(256) mk_set_mark_kernel(const uint32_t *ids, uint64_t n, uint32_t *seen, uint32_t *dup) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t n4 = (((uintptr_t)ids & 15u) == 0) ? n >> 2 : 0; /* 16-byte loads when the list is aligned */
+  const uint4 *ids4 = reinterpret_cast<const uint4 *>(ids);
+  for (uint64_t i = tid; i < n4; i += nthreads) {
+    const uint4 v = ids4[i];
+    mk_set_mark_one(v.x, seen, dup); mk_set_mark_one(v.y, seen, dup); mk_set_mark_one(v.z, seen, dup); mk_set_mark_one(v.w, seen, dup);
+  }
+  for (uint64_t i = (n4 << 2) + tid; i < n; i += nthreads) mk_set_mark_one(ids[i], seen, dup);
+}
+
+__device__ __forceinline__ uint32_t mk_set_word(const uint32_t *seen, const uint32_t *dup, uint64_t w) {
+  return dup ? (seen[w] & ~dup[w]) : seen[w];
+}
+
+__global__ void __launch_bounds__(256) mk_set_count_kernel(const uint32_t *seen, const uint32_t *dup, uint32_t *chunk_count) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (chunk >= MK_SET_NCHUNKS) return;
+  /* 1024 words = 4 KiB per chunk: lane reads 4 x 16 bytes, coalesced (word order inside the chunk is irrelevant here) */
+  const uint4 *s4 = reinterpret_cast<const uint4 *>(seen + (uint64_t)chunk * MK_SET_CHUNK_WORDS);
+  const uint4 *d4 = dup ? reinterpret_cast<const uint4 *>(dup + (uint64_t)chunk * MK_SET_CHUNK_WORDS) : nullptr;
+  uint32_t c = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    uint4 v = s4[k * 64u + lane];
+    if (d4) { const uint4 d = d4[k * 64u + lane]; v.x &= ~d.x; v.y &= ~d.y; v.z &= ~d.z; v.w &= ~d.w; }
+    c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if (lane == 0) chunk_count[chunk] = c;
+}
+
+/* exclusive prefix over the chunk counts: one workgroup, 1024 threads x 128 chunks */
+__global__ void __launch_bounds__(1024) mk_set_scan_kernel(const uint32_t *chunk_count, unsigned long long *chunk_off,
+                                                          unsigned long long *total) {
+  __shared__ unsigned long long part[1024];
+  constexpr uint32_t PER = MK_SET_NCHUNKS / 1024u;
+  const uint32_t t = threadIdx.x;
+  unsigned long long sum = 0;
+  for (uint32_t k = 0; k < PER; k++) sum += chunk_count[t * PER + k];
+  part[t] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024u; off <<= 1) { /* Hillis-Steele inclusive scan */
+    const unsigned long long v = t >= off ? part[t - off] : 0ull;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned long long run = part[t] - sum;
+  for (uint32_t k = 0; k < PER; k++) {
+    chunk_off[t * PER + k] = run;
+    run += chunk_count[t * PER + k];
+  }
+  if (t == 1023u) *total = part[t];
+}
+
+__global__ void __launch_bounds__(256) mk_set_write_kernel(const uint32_t *seen, const uint32_t *dup, const uint32_t *chunk_count,
+                                                           const unsigned long long *chunk_off, uint32_t *out) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (chunk >= MK_SET_NCHUNKS || chunk_count[chunk] == 0u) return; /* wave-uniform */
+  /* ascending order: lane l owns the 16 consecutive words [16 l, 16 l + 16) of the chunk */
+  const uint64_t w0 = (uint64_t)chunk * MK_SET_CHUNK_WORDS + 16u * lane;
+  uint32_t wd[16];
+  uint32_t mine = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) { wd[k] = mk_set_word(seen, dup, w0 + k); mine += __popc(wd[k]); }
+  uint32_t incl = mine; /* inclusive scan of the lane totals */
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off, 64);
+    if ((int)lane >= off) incl += v;
+  }
+  uint32_t *o = out + chunk_off[chunk] + (incl - mine);
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) {
+    uint32_t bits = wd[k];
+    const uint32_t base = (uint32_t)((w0 + k) << 5);
+    while (bits) {
+      const uint32_t b = (uint32_t)__builtin_ctz(bits);
+      *o++ = base + b;
+      bits &= bits - 1u;
+    }
+  }
+}
+
+/* ---- host side ------------------------------------------------------------------------------------------ */
+extern "C" int mk_setop_create(int device, mk_setop **out) {
+  if (!out) return MK_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return mk_set_fail(nullptr, MK_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  if (device < 0 || device >= ndev) return mk_set_fail(nullptr, MK_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+  mk_setop *s = new (std::nothrow) mk_setop();
+  if (!s) return MK_ERR_NOMEM;
+  s->device = device;
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    delete s;
+    return mk_set_fail(nullptr, MK_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+  }
+  s->num_cu = prop.multiProcessorCount;
+  hipError_t r = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (r == hipSuccess) r = hipMalloc(&s->d_seen, MK_SET_WORDS * 4);
+  if (r == hipSuccess) r = hipMalloc(&s->d_dup, MK_SET_WORDS * 4);
+  if (r == hipSuccess) r = hipMalloc(&s->d_chunk, (size_t)MK_SET_NCHUNKS * 4);
+  if (r == hipSuccess) r = hipMalloc(&s->d_chunk_off, (size_t)MK_SET_NCHUNKS * 8);
+  if (r == hipSuccess) r = hipMalloc(&s->d_total, 8);
+  if (r == hipSuccess) r = hipHostMalloc((void **)&s->h_total, 8, hipHostMallocDefault);
+  for (int b = 0; b < 2 && r == hipSuccess; b++) {
+    r = hipMalloc(&s->d_stage[b], MK_SET_STAGE_IDS * 4);
+    if (r == hipSuccess) r = hipEventCreateWithFlags(&s->ev_stage[b], hipEventDisableTiming);
+  }
+  if (r != hipSuccess) {
+    mk_set_fail(nullptr, MK_ERR_NOMEM, "setop allocation: %s", hipGetErrorString(r));
+    mk_setop_destroy(s);
+    return MK_ERR_NOMEM;
+  }
+  *out = s;
+  return MK_OK;
+}
+
+extern "C" int mk_setop_destroy(mk_setop *s) {
+  if (!s) return MK_OK;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  (void)hipFree(s->d_seen); (void)hipFree(s->d_dup); (void)hipFree(s->d_chunk); (void)hipFree(s->d_chunk_off);
+  (void)hipFree(s->d_total); (void)hipFree(s->d_out);
+  if (s->h_total) (void)hipHostFree(s->h_total);
+  if (s->h_out) (void)hipHostFree(s->h_out);
+  for (int b = 0; b < 2; b++) {
+    (void)hipFree(s->d_stage[b]);
+    if (s->ev_stage[b]) (void)hipEventDestroy(s->ev_stage[b]);
+  }
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return MK_OK;
+}
+
+extern "C" const char *mk_setop_last_error(const mk_setop *s) { return s ? s->err : mk_set_create_err; }
+
+extern "C" int mk_setop_begin(mk_setop *s, int mode) {
+  if (!s || (mode != MK_SET_UNION && mode != MK_SET_UNIQ_UNION)) return MK_ERR_ARG;
+  MK_SET_HIP(s, hipSetDevice(s->device));
+  /* memset(dict,0,..) command_set.c:284,473; the reference's second dictionary starts all-ones ("unique") and
+   * clears bits, ours starts all-zero and sets "duplicate" bits: seen & ~dup is the same set */
+  MK_SET_HIP(s, hipMemsetAsync(s->d_seen, 0, MK_SET_WORDS * 4, s->stream));
+  if (mode == MK_SET_UNIQ_UNION) MK_SET_HIP(s, hipMemsetAsync(s->d_dup, 0, MK_SET_WORDS * 4, s->stream));
+  s->mode = mode;
+  s->begun = true;
+  return MK_OK;
+}
+
+static int mk_set_mark(mk_setop *s, const uint32_t *ids_dev, uint64_t n) {
+  uint64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > (uint64_t)s->num_cu * 32) blocks = (uint64_t)s->num_cu * 32;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(mk_set_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, s->stream, ids_dev, n, s->d_seen,
+                     s->mode == MK_SET_UNIQ_UNION ? s->d_dup : nullptr);
+  MK_SET_HIP(s, hipGetLastError());
+  return MK_OK;
+}
+
+extern "C" int mk_setop_add_device(mk_setop *s, const uint32_t *ids_dev, uint64_t n) {
+  if (!s) return MK_ERR_ARG;
+  if (!s->begun) return mk_set_fail(s, MK_ERR_STATE, "mk_setop_add before mk_setop_begin");
+  if (n == 0) return MK_OK;
+  if (!ids_dev) return MK_ERR_ARG;
+  MK_SET_HIP(s, hipSetDevice(s->device));
+  return mk_set_mark(s, ids_dev, n);
+}
+
+extern "C" int mk_setop_add(mk_setop *s, const uint32_t *ids, uint64_t n) {
+  if (!s) return MK_ERR_ARG;
+  if (!s->begun) return mk_set_fail(s, MK_ERR_STATE, "mk_setop_add before mk_setop_begin");
+  if (n == 0) return MK_OK;
+  if (!ids) return MK_ERR_ARG;
+  MK_SET_HIP(s, hipSetDevice(s->device));
+  uint64_t done = 0;
+  int b = 0;
+  while (done < n) { /* double-buffered: the copy of chunk i+1 overlaps the marking of chunk i */
+    const uint64_t m = n - done < MK_SET_STAGE_IDS ? n - done : MK_SET_STAGE_IDS;
+    MK_SET_HIP(s, hipEventSynchronize(s->ev_stage[b])); /* previous marking out of this buffer is done */
+    MK_SET_HIP(s, hipMemcpyAsync(s->d_stage[b], ids + done, m * 4, hipMemcpyHostToDevice, s->stream));
+    int rc = mk_set_mark(s, s->d_stage[b], m);
+    if (rc) return rc;
+    MK_SET_HIP(s, hipEventRecord(s->ev_stage[b], s->stream));
+    done += m;
+    b ^= 1;
+  }
+  MK_SET_HIP(s, hipStreamSynchronize(s->stream)); /* the caller's buffer is free again */
+  return MK_OK;
+}
+
+extern "C" int mk_setop_finish(mk_setop *s, const uint32_t **ids_out, uint64_t *n_out) {
+  if (!s || !ids_out || !n_out) return MK_ERR_ARG;
+  if (!s->begun) return mk_set_fail(s, MK_ERR_STATE, "mk_setop_finish before mk_setop_begin");
+  MK_SET_HIP(s, hipSetDevice(s->device));
+  const uint32_t *dup = s->mode == MK_SET_UNIQ_UNION ? s->d_dup : nullptr;
+  const unsigned blocks = MK_SET_NCHUNKS / 4u; /* 4 waves (chunks) per 256-thread block */
+  hipLaunchKernelGGL(mk_set_count_kernel, dim3(blocks), dim3(256), 0, s->stream, s->d_seen, dup, s->d_chunk);
+  hipLaunchKernelGGL(mk_set_scan_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_chunk, s->d_chunk_off, s->d_total);
+  MK_SET_HIP(s, hipGetLastError());
+  MK_SET_HIP(s, hipMemcpyAsync(s->h_total, s->d_total, 8, hipMemcpyDeviceToHost, s->stream));
+  MK_SET_HIP(s, hipStreamSynchronize(s->stream));
+  const uint64_t total = *s->h_total;
+  if (total > s->out_cap) {
+    (void)hipFree(s->d_out);
+    s->d_out = nullptr; s->out_cap = 0;
+    const uint64_t cap = total + total / 8 + 1024;
+    MK_SET_HIP(s, hipMalloc(&s->d_out, cap * 4));
+    s->out_cap = cap;
+  }
+  if (total > s->h_cap) {
+    if (s->h_out) (void)hipHostFree(s->h_out);
+    s->h_out = nullptr; s->h_cap = 0;
+    const uint64_t cap = total + total / 8 + 1024;
+    MK_SET_HIP(s, hipHostMalloc((void **)&s->h_out, cap * 4, hipHostMallocDefault));
+    s->h_cap = cap;
+  }
+  if (total) {
+    hipLaunchKernelGGL(mk_set_write_kernel, dim3(blocks), dim3(256), 0, s->stream, s->d_seen, dup, s->d_chunk, s->d_chunk_off,
+                       s->d_out);
+    MK_SET_HIP(s, hipGetLastError());
+    MK_SET_HIP(s, hipMemcpyAsync(s->h_out, s->d_out, total * 4, hipMemcpyDeviceToHost, s->stream));
+    MK_SET_HIP(s, hipStreamSynchronize(s->stream));
+  }
+  *ids_out = s->h_out;
+  *n_out = total;
+  s->begun = false;
+  return MK_OK;
+}
+
+/* result left on the device (ascending ids), for callers that keep working there */
+extern "C" int mk_setop_result_device(mk_setop *s, const uint32_t **ids_dev, uint64_t *n) {
+  if (!s || !ids_dev || !n) return MK_ERR_ARG;
+  if (s->begun) return mk_set_fail(s, MK_ERR_STATE, "mk_setop_result_device before mk_setop_finish");
+  *ids_dev = s->d_out;
+  *n = s->h_total ? *s->h_total : 0;
+  return MK_OK;
+}
+
+extern "C" void *mk_setop_stream(mk_setop *s) { return s ? (void *)s->stream : nullptr; }

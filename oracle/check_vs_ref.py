@@ -321,6 +321,41 @@ def main():
     write_fa(fa2, [rand_seq(rng, 30011), "ACGT" * 10, "", rand_seq(rng, 21), rand_seq(rng, 22)], width=60)
     case("L3K10_fasta_small", "L3K10", [fa2], [])
 
+    # ---- `set -u` / `set -q` on sketch directories made by the reference itself (command_set.c:241-319, 427-512) ----
+    def set_case(label, shuf, inputs, dist_flags, op, reply=b"N\n"):
+        nonlocal failures
+        sk = os.path.join(work, label + ".sk")
+        o_ref, o_ora = os.path.join(work, label + ".refpan"), os.path.join(work, label + ".orapan")
+        for d in (sk, o_ref, o_ora):
+            shutil.rmtree(d, ignore_errors=True)
+        run([REF, "dist", "-L", shufs[shuf]] + dist_flags + ["-p", "1", "-o", sk] + inputs, work)
+        r1 = subprocess.run([REF, "set", op, "-o", o_ref, sk], cwd=work, input=reply, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        r2 = subprocess.run([ORA, "set", op, "-o", o_ora, sk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        names = sorted(os.listdir(o_ref)) if os.path.isdir(o_ref) else []
+        ok = r1.returncode == 0 and r2.returncode == 0 and names and names == sorted(os.listdir(o_ora))
+        ok = ok and all(filecmp.cmp(os.path.join(o_ref, f), os.path.join(o_ora, f), shallow=False) for f in names)
+        nids = sum(os.path.getsize(os.path.join(o_ref, f)) // 4 for f in names if f != "cofiles.stat")
+        print("%s %-28s ids=%d files=%d" % ("ok  " if ok else "FAIL", label, nids, len(names)))
+        failures += 0 if ok else 1
+
+    fas = []
+    for i, (a, b) in enumerate([(0, 200000), (100000, 300000), (150000, 400000), (0, 400000)]):
+        pth = os.path.join(work, "strain%d.fa" % i)
+        write_fa(pth, [g[a:b]])
+        fas.append(pth)
+    small = []
+    for i, (a, b) in enumerate([(0, 20000), (10000, 30000), (15000, 40000)]):   # dense table: keep below hashlimit
+        pth = os.path.join(work, "small%d.fa" % i)
+        write_fa(pth, [g[a:b]])
+        small.append(pth)
+    for sh in ("L1K7", "L0K6z", "L3K10", "L2K11"):
+        set_case("%s_set_u" % sh, sh, small if sh == "L0K6z" else fas, [], "-u")          # fas[3] covers the others
+        set_case("%s_set_q" % sh, sh, small if sh == "L0K6z" else fas[:3], [], "-q")
+    set_case("L1K7_set_u_reads_A", "L1K7", [fq10, fq16, fq11], ["-A"], "-u")
+    set_case("L1K7_set_q_reads_n2", "L1K7", [fq10, fq16, fq11], ["-n", "2"], "-q")
+    set_case("L1K7_set_u_single_N", "L1K7", [fas[0]], [], "-u")        # one sketch, prompt answered N: normal output
+    # (the cofiles.stat header is compared byte for byte here: both sides copy the reference-made directory's bytes)
+
     if args.big:
         fqb = os.path.join(work, "syn1p5m.fq")
         lib.mk_synth_fastq_write(fqb.encode(), 7, 0, 1500000, 150)

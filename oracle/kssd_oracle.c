@@ -633,3 +633,80 @@ int ko_dist_stage1_ex(const char *shuf_path, int abundance, int uniq, int Q, int
   free(fid); free(fab); free(index); free(ids); free(cnts); free(nout); free(ctx_ct); free(co); free(shuf);
   return rc;
 }
+
+
+/* ---- `set -u` / `set -q`: sketch_union() (command_set.c:241-319) / uniq_sketch_union() (:427-512) ---- */
+#define KO_COMPONENT_SZ 8 /* global_basic.h:36: ids of one component live in [0, 16^8) */
+size_t ko_set_union(const uint32_t *ids, size_t n, int uniq, uint32_t *out) {
+  const size_t comp_sz = (size_t)1 << (4 * KO_COMPONENT_SZ);
+  ko_llong *dict = calloc(comp_sz / 64, sizeof(ko_llong));                 /* :280 / :467: k-mer present */
+  ko_llong *dict2 = uniq ? malloc(comp_sz / 8) : NULL;                     /* :468: 1 = seen once so far, 0 = repeated */
+  if (!dict || (uniq && !dict2)) { free(dict); free(dict2); return (size_t)-1; }
+  if (uniq) memset(dict2, 0xff, comp_sz / 8);                              /* :474 */
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t v = ids[i];
+    const ko_llong bit = 0x8000000000000000ULL >> (v % 64);
+    if (uniq && (dict[v / 64] & bit)) dict2[v / 64] &= ~bit;               /* :486-487 */
+    dict[v / 64] |= bit;                                                   /* :295 / :489 */
+  }
+  size_t m = 0;
+  for (size_t w = 0; w < comp_sz / 64; w++) {                              /* :303-312 / :496-505: ascending ids */
+    const ko_llong word = uniq ? (dict[w] & dict2[w]) : dict[w];
+    if (!word) continue;
+    for (int b = 0; b < 64; b++)
+      if ((0x8000000000000000ULL >> b) & word) { if (out) out[m] = (uint32_t)(64 * w + b); m++; }
+  }
+  free(dict); free(dict2);
+  return m;
+}
+
+int ko_set_stage(const char *indir, const char *outdir, int uniq, int answer_yes) {
+  char path[KO_PATHLEN * 2];
+  unsigned char hdr[32]; /* co_dstat_t (global_basic.h:116-126) is copied as it is, padding bytes included (:274) */
+  snprintf(path, sizeof path, "%s/cofiles.stat", indir);
+  FILE *f = fopen(path, "rb");
+  if (!f) return KO_ERR_IO;
+  if (fread(hdr, 1, 32, f) != 32) { fclose(f); return KO_ERR_IO; }
+  fclose(f);
+  int32_t comp_num, infile_num;
+  memcpy(&comp_num, hdr + 16, 4);
+  memcpy(&infile_num, hdr + 20, 4);
+  const char *prefix = uniq ? "uniq_pan" : "pan";
+  if (infile_num == 1 && answer_yes) { /* :254-267 / :441-455: the single sketch is renamed in place */
+    for (int c = 0; c < comp_num; c++) {
+      char a[KO_PATHLEN * 2], b[KO_PATHLEN * 2];
+      snprintf(a, sizeof a, "%s/combco.%d", indir, c);
+      snprintf(b, sizeof b, "%s/%s.%d", indir, prefix, c);
+      if (rename(a, b) != 0) return KO_ERR_IO;
+    }
+    return KO_OK;
+  }
+  mkdir(outdir, 0777);
+  snprintf(path, sizeof path, "%s/cofiles.stat", outdir);
+  f = fopen(path, "wb");
+  if (!f) return KO_ERR_IO;
+  fwrite(hdr, 1, 32, f);
+  fclose(f);
+  for (int c = 0; c < comp_num; c++) {
+    snprintf(path, sizeof path, "%s/combco.%d", indir, c);
+    struct stat st;
+    if (stat(path, &st) != 0) return KO_ERR_IO;
+    const size_t n = (size_t)st.st_size / 4;
+    uint32_t *ids = malloc(4 * (n + 1));
+    f = fopen(path, "rb");
+    if (!f || !ids) { free(ids); return KO_ERR_IO; }
+    if (fread(ids, 4, n, f) != n) { fclose(f); free(ids); return KO_ERR_IO; }
+    fclose(f);
+    uint32_t *out = malloc(4 * (n + 1));
+    const size_t m = ko_set_union(ids, n, uniq, out);
+    free(ids);
+    if (m == (size_t)-1) { free(out); return KO_ERR_IO; }
+    snprintf(path, sizeof path, "%s/%s.%d", outdir, prefix, c);
+    f = fopen(path, "wb");
+    if (!f) { free(out); return KO_ERR_IO; }
+    fwrite(out, 4, m, f);
+    fclose(f);
+    free(out);
+  }
+  return KO_OK;
+}

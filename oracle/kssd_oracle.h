@@ -92,6 +92,15 @@ int ko_dist_stage1(const char *shuf_path, int abundance, int uniq, const char *o
 int ko_dist_stage1_ex(const char *shuf_path, int abundance, int uniq, int Q, int M, const char *outdir, int nfiles,
                       const char **files);
 
+/* ---- `set -u` / `set -q` ----
+ * sketch_union() (command_set.c:241-319) / uniq_sketch_union() (:427-512) for one component: the ids of all the
+ * sketches of a combined sketch file go through a 2^32-bit dictionary and come out ascending; uniq keeps the ids
+ * that occur exactly once in the whole file.  out may be NULL (count only); returns the count, (size_t)-1 = no memory. */
+size_t ko_set_union(const uint32_t *ids, size_t n, int uniq, uint32_t *out);
+/* the whole command on a sketch directory: cofiles.stat header copied as it is, pan.N / uniq_pan.N written.
+ * answer_yes: the reply to "only 1 sketch, use ... as pan-sketch?(Y/N)" when infile_num == 1 (renames in place). */
+int ko_set_stage(const char *indir, const char *outdir, int uniq, int answer_yes);
+
 #ifdef __cplusplus
 }
 #endif

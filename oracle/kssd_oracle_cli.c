@@ -5,7 +5,25 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* kssd_oracle_cli set -u|-q [-y] [-o outdir] sketchdir   (mirrors `metakssd set`; -y answers the single-sketch prompt with Y) */
+static int set_main(int argc, char **argv) {
+  const char *out = "./", *in = NULL;
+  int op = -1, yes = 0;
+  for (int i = 0; i < argc; i++) {
+    if (!strcmp(argv[i], "-u")) { if (op < 0) op = 0; }
+    else if (!strcmp(argv[i], "-q")) { if (op < 0) op = 1; }
+    else if (!strcmp(argv[i], "-y")) yes = 1;
+    else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
+    else in = argv[i];
+  }
+  if (op < 0 || !in) { fprintf(stderr, "usage: kssd_oracle_cli set -u|-q [-y] [-o outdir] sketchdir\n"); return 2; }
+  int rc = ko_set_stage(in, out, op, yes);
+  if (rc) fprintf(stderr, "kssd_oracle_cli set: error %d\n", rc);
+  return rc ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && !strcmp(argv[1], "set")) return set_main(argc - 2, argv + 2);
   const char *shuf = NULL, *out = NULL;
   int A = 0, u = 0, nf = 0, Q = 0, M = 1;
   const char *files[4096];

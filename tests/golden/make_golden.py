@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 import util_inputs as ui  # noqa: E402
-from golden_cases import CASES, SHUF_SPECS, build_input, make_shuf  # noqa: E402
+from golden_cases import CASES, SET_CASES, SHUF_SPECS, build_input, build_set_inputs, make_shuf  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "metakssd")
 
@@ -51,7 +51,7 @@ def main():
     work = tempfile.mkdtemp(prefix="golden_")
     manifest = {"shufs": {}, "cases": {}}
     shuf_paths = {}
-    for name in sorted({c["shuf"] for c in CASES.values()}):
+    for name in sorted({c["shuf"] for c in CASES.values()} | {c["shuf"] for c in SET_CASES.values()}):
         p = os.path.join(work, name + ".shuf")
         make_shuf(name, p)
         shuf_paths[name] = p
@@ -76,6 +76,35 @@ def main():
             entry["files"] = {f: hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest() for f in sorted(os.listdir(d))}
         manifest["cases"][case] = entry
         print("%-28s %s" % (case, "ABORT (too crowd)" if aborted else "distinct=%d" % entry["stat"]["all_ctx_ct"]))
+    # ---- `set -u` / `set -q`: reference dist makes the sketch directory, reference set makes pan.N / uniq_pan.N ----
+    manifest["set_cases"] = {}
+    for case, c in SET_CASES.items():
+        inputs = build_set_inputs(case, work, write_committed=True)
+        sk, out = os.path.join(work, case + ".sk"), os.path.join(work, case + ".pan")
+        # -p 1 and files given in order: with one thread the reference keeps the given order only after its
+        # time-seeded shuffle of the file list -- the union does not depend on the order, the uniq-union neither
+        r = subprocess.run([REF, "dist", "-L", shuf_paths[c["shuf"]]] + c["flags"] + ["-p", "1", "-o", sk] + inputs,
+                           cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if not os.path.exists(os.path.join(sk, "cofiles.stat")):
+            raise SystemExit("reference dist failed on %s: %s" % (case, r.stderr.decode(errors="replace")[-300:]))
+        r = subprocess.run([REF, "set", c["op"], "-o", out, sk], cwd=work, input=b"N\n", stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE)
+        if r.returncode != 0 or not os.path.exists(os.path.join(out, "cofiles.stat")):
+            raise SystemExit("reference set failed on %s: %s" % (case, r.stderr.decode(errors="replace")[-300:]))
+        d = os.path.join(exp_root, case)
+        os.makedirs(d)
+        for f in sorted(os.listdir(out)):
+            if f.startswith("pan.") or f.startswith("uniq_pan."):
+                shutil.copy(os.path.join(out, f), os.path.join(d, f))
+        hdr = open(os.path.join(out, "cofiles.stat"), "rb").read()
+        assert len(hdr) == 32
+        stat = parse_stat(os.path.join(sk, "cofiles.stat"))
+        entry = {"shuf": c["shuf"], "flags": c["flags"], "inputs": c["inputs"], "op": c["op"],
+                 "header": {k: stat[k] for k in ("shuf_id", "koc", "kmerlen", "dim_rd_len", "comp_num", "infile_num", "all_ctx_ct")},
+                 "files": {f: hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest() for f in sorted(os.listdir(d))},
+                 "ids": sum(os.path.getsize(os.path.join(d, f)) // 4 for f in os.listdir(d))}
+        manifest["set_cases"][case] = entry
+        print("%-28s ids=%d files=%d" % (case, entry["ids"], len(entry["files"])))
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
     shutil.rmtree(work, ignore_errors=True)
     tot = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(HERE) for f in fs)

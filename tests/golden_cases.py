@@ -56,6 +56,27 @@ def _genome():
     return [g[:20000], g[5000:12000], b"A" * 100 + g[500:900] + b"T" * 50, g[20000:20021], b"", g[20021:]]
 
 
+def _strain(name):
+    """three overlapping 'strains' cut from one seeded 90 kb sequence: shared, pairwise-shared and private k-mers"""
+    g = ui.rand_seq(np.random.RandomState(108), 90000)
+    a, b = {"sA": (0, 50000), "sB": (20000, 70000), "sC": (40000, 90000)}[name]
+    return [g[a:(a + b) // 2], g[(a + b) // 2:b]]
+
+
+# `set -u` / `set -q` (SURVEY.md 8f N2): the sketch directory is made by `dist` from `inputs`, then the set operation
+SET_CASES = {
+    "set_u_strains_L1K7": {"shuf": "L1K7", "flags": [], "inputs": ["fa:sA", "fa:sB", "fa:sC"], "op": "-u"},
+    "set_q_strains_L1K7": {"shuf": "L1K7", "flags": [], "inputs": ["fa:sA", "fa:sB", "fa:sC"], "op": "-q"},
+    "set_u_strains_L0K6": {"shuf": "L0K6", "flags": [], "inputs": ["fa:sA", "fa:sB", "fa:sC"], "op": "-u"},
+    "set_q_strains_L0K6": {"shuf": "L0K6", "flags": [], "inputs": ["fa:sA", "fa:sB", "fa:sC"], "op": "-q"},
+    "set_u_strains_L2K11": {"shuf": "L2K11", "flags": [], "inputs": ["fa:sA", "fa:sB", "fa:sC"], "op": "-u"},  # 16 components
+    "set_q_strains_L2K11": {"shuf": "L2K11", "flags": [], "inputs": ["fa:sA", "fa:sB", "fa:sC"], "op": "-q"},
+    "set_u_reads_A_L1K7": {"shuf": "L1K7", "flags": ["-A"], "inputs": ["fq:pool", "fq:lowcov", "fq:ragged"], "op": "-u"},
+    "set_q_reads_L0K6": {"shuf": "L0K6", "flags": ["-n", "2"], "inputs": ["fq:lowcov", "fq:qual"], "op": "-q"},
+    "set_u_single_N_L1K7": {"shuf": "L1K7", "flags": [], "inputs": ["fa:sA"], "op": "-u"},  # one sketch: prompt answered N
+}
+
+
 CASES = {
     # BASELINE.json config 1/2: 100 k synthetic 150 bp reads, L3K11 -A (input regenerated from the formula)
     "syn100k_L3K11": {"shuf": "L3K11", "flags": ["-A"], "input": "synth:seed=1,first=0,n=100000,len=150"},
@@ -108,11 +129,12 @@ CASES = {
 }
 
 
-def build_input(case, workdir, write_committed=False):
+def build_input(case, workdir, write_committed=False, spec=None):
     """materialise the input file of `case` in workdir; returns its path.  Committed inputs live gzip'ed under
-    tests/golden/inputs (written only by make_golden.py)."""
+    tests/golden/inputs (written only by make_golden.py).  `spec` overrides the case's own input (set cases name
+    their files <case>)."""
     from metakssd_amd import capi
-    spec = CASES[case]["input"]
+    spec = spec or CASES[case]["input"]
     kind, _, rest = spec.partition(":")
     if kind == "synth":
         kv = dict(x.split("=") for x in rest.split(","))
@@ -153,8 +175,16 @@ def build_input(case, workdir, write_committed=False):
         stored = _committed("fa_%s.fa.gz" % rest)
         if write_committed:
             with gzip.GzipFile(stored, "wb", mtime=0) as f:
-                f.write(ui.fasta_bytes(_genome()))
+                f.write(ui.fasta_bytes(_genome() if rest == "genome" else _strain(rest)))
         path = os.path.join(workdir, case + ".fa")
         open(path, "wb").write(gzip.open(stored, "rb").read())
         return path
     raise ValueError(spec)
+
+
+def build_set_inputs(case, workdir, write_committed=False):
+    """input files of a SET_CASES entry, in order"""
+    out = []
+    for i, spec in enumerate(SET_CASES[case]["inputs"]):
+        out.append(build_input("%s_in%d" % (case, i), workdir, write_committed=write_committed, spec=spec))
+    return out

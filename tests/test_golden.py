@@ -145,3 +145,66 @@ def test_product_cli_multi_file_directory_equals_oracle(kind, shuf, flags, shuf_
     assert sp["infile_num"] == 3 and sum(sp["ctx_ct"]) == sp["all_ctx_ct"]
     idx = struct.unpack("<4Q", open(os.path.join(out_p, "combco.index.0"), "rb").read())
     assert idx[0] == 0 and list(idx) == sorted(idx)
+
+
+# ---- `set -u` / `set -q`: pan.N / uniq_pan.N made by the reference's own `set` --------------------
+SET_HEAVY = {"set_u_strains_L2K11", "set_q_strains_L2K11"}  # 4.3 GB oracle table for the dist step
+
+
+def parse_header(path):
+    b = open(path, "rb").read()
+    assert len(b) == 32  # sketch_union() writes the co_dstat_t header only (command_set.c:274)
+    shuf_id, koc = struct.unpack_from("<IB", b, 0)
+    kmerlen, dim_rd_len, comp_num, infile_num, all_ctx = struct.unpack_from("<iiiiQ", b, 8)
+    return dict(shuf_id=shuf_id, koc=koc, kmerlen=kmerlen, dim_rd_len=dim_rd_len, comp_num=comp_num,
+                infile_num=infile_num, all_ctx_ct=all_ctx)
+
+
+def check_set_against_golden(case, outdir):
+    entry = MANIFEST["set_cases"][case]
+    exp = os.path.join(gc.GOLDEN, "expected", case)
+    want = sorted(os.listdir(exp))
+    got = sorted(f for f in os.listdir(outdir) if f.startswith("pan.") or f.startswith("uniq_pan."))
+    assert got == want
+    for f in want:
+        assert filecmp.cmp(os.path.join(exp, f), os.path.join(outdir, f), shallow=False), "%s: %s differs" % (case, f)
+    assert parse_header(os.path.join(outdir, "cofiles.stat")) == entry["header"]
+
+
+def run_set_case(case, shuf_files, tmp_path, dist_cmd, set_cmd):
+    entry = MANIFEST["set_cases"][case]
+    inputs = gc.build_set_inputs(case, str(tmp_path))
+    sk, out = str(tmp_path / "sk"), str(tmp_path / "pan")
+    r = subprocess.run(dist_cmd + ["-L", shuf_files(entry["shuf"])] + entry["flags"] + ["-o", sk] + inputs,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    r = subprocess.run(set_cmd + [entry["op"], "-o", out, sk], input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    check_set_against_golden(case, out)
+
+
+@pytest.mark.parametrize("case", sorted(MANIFEST["set_cases"]))
+def test_oracle_set_reproduces_reference_golden(case, shuf_files, tmp_path):
+    run_set_case(case, shuf_files, tmp_path, [ORACLE_CLI], [ORACLE_CLI, "set"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(MANIFEST["set_cases"]))
+def test_product_cli_set_reproduces_reference_golden(case, shuf_files, tmp_path):
+    """`metakssd dist ...` then `metakssd set -u|-q` through the HIP engine and the device dictionaries"""
+    run_set_case(case, shuf_files, tmp_path, [PRODUCT_CLI, "dist", "-p", "4"], [PRODUCT_CLI, "set"])
+
+
+@pytest.mark.gpu
+def test_product_cli_set_single_sketch_rename(shuf_files, tmp_path):
+    """one sketch in the directory and the answer Y: combco.N is renamed in place (command_set.c:254-267)"""
+    inputs = gc.build_set_inputs("set_u_single_N_L1K7", str(tmp_path))
+    sk = str(tmp_path / "sk")
+    r = subprocess.run([PRODUCT_CLI, "dist", "-L", shuf_files("L1K7"), "-o", sk] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    before = open(os.path.join(sk, "combco.0"), "rb").read()
+    r = subprocess.run([PRODUCT_CLI, "set", "-q", "-o", str(tmp_path / "unused"), sk], input=b"y\n", stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"only 1 sketch" in r.stdout
+    assert not os.path.exists(os.path.join(sk, "combco.0")) and not os.path.exists(str(tmp_path / "unused"))
+    assert open(os.path.join(sk, "uniq_pan.0"), "rb").read() == before

@@ -1,0 +1,113 @@
+"""GPU parity for `set -u` / `set -q`: mk_setop_* through the C ABI against the oracle's restatement
+of sketch_union() / uniq_sketch_union() (command_set.c:241-319, 427-512) and against numpy's definition of the same
+sets.  The oracle side is pinned by tests/golden (pan.N / uniq_pan.N written by the compiled reference)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from metakssd_amd import capi as c
+    if c.device_count() < 1:
+        pytest.fail("no HIP device: the -m gpu tests must run on the MI355X box")
+    return c
+
+
+@pytest.fixture(scope="module")
+def setop(capi):
+    s = capi.SetOp(0)
+    yield s
+    s.close()
+
+
+def oracle_union(ids, uniq):
+    from oracle_binding import load
+    lib = load()
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    out = np.zeros(max(1, ids.size), np.uint32)
+    lib.ko_set_union.restype = C.c_size_t
+    lib.ko_set_union.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    m = lib.ko_set_union(ids.ctypes.data if ids.size else None, ids.size, 1 if uniq else 0, out.ctypes.data)
+    return out[:m]
+
+
+def numpy_union(ids, uniq):
+    vals, cnt = np.unique(np.asarray(ids, dtype=np.uint32), return_counts=True)
+    return vals[cnt == 1] if uniq else vals
+
+
+@pytest.mark.parametrize("uniq", [False, True])
+def test_union_of_sketch_like_lists(capi, setop, uniq):
+    """three 'genomes' sharing part of their ids, handed over as separate lists (what combco.N concatenates)"""
+    rs = np.random.RandomState(61)
+    pool = rs.randint(0, 2 ** 32, size=300000, dtype=np.uint64).astype(np.uint32)
+    lists = [rs.permutation(pool[:200000]), rs.permutation(pool[100000:]), rs.permutation(pool[50000:250000])]
+    got = setop.union(lists, uniq=uniq)
+    allids = np.concatenate(lists)
+    want = oracle_union(allids, uniq)
+    assert np.array_equal(got, want)
+    assert np.array_equal(want, numpy_union(allids, uniq))
+    assert got.size > 0
+
+
+@pytest.mark.parametrize("uniq", [False, True])
+def test_word_and_range_edges(capi, setop, uniq):
+    edge = np.array([0, 1, 31, 32, 33, 63, 64, 65, 1023, 1024, 32767, 32768, 32769, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 2,
+                     2 ** 32 - 1, 0, 64, 2 ** 32 - 1, 2 ** 32 - 1], dtype=np.uint64).astype(np.uint32)
+    got = setop.union([edge], uniq=uniq)
+    assert np.array_equal(got, oracle_union(edge, uniq))
+    assert np.array_equal(got, numpy_union(edge, uniq))
+
+
+def test_empty_input_and_handle_reuse(capi, setop):
+    assert setop.union([], uniq=False).size == 0
+    assert setop.union([np.zeros(0, np.uint32)], uniq=True).size == 0
+    a = np.arange(1000, 2000, dtype=np.uint32)
+    assert np.array_equal(setop.union([a, a], uniq=False), a)
+    assert setop.union([a, a], uniq=True).size == 0          # everything twice
+    assert np.array_equal(setop.union([a], uniq=True), a)     # begin() cleared both dictionaries
+
+
+def test_dense_run_and_unaligned_list(capi, setop):
+    """a dense range (every bit of many words set) and a list whose address is not 16-byte aligned"""
+    base = np.arange(5_000_000, 9_000_000, dtype=np.uint32)
+    buf = np.concatenate([np.zeros(1, np.uint32), base[::-1], base[::7]])
+    view = buf[1:]                       # 4 bytes past an aligned address
+    assert view.ctypes.data % 16 == 4
+    got = setop.union([view], uniq=False)
+    assert np.array_equal(got, base)
+    got = setop.union([view], uniq=True)
+    mask = np.ones(base.size, bool)
+    mask[::7] = False
+    assert np.array_equal(got, base[mask])
+
+
+def test_large_random_list_properties(capi, setop):
+    """40 M ids (160 MB: several staging buffers): ascending, duplicate-free, same set as numpy's"""
+    rs = np.random.RandomState(62)
+    ids = rs.randint(0, 2 ** 28, size=40_000_000, dtype=np.int64).astype(np.uint32)
+    got = setop.union([ids[:15_000_000], ids[15_000_000:]], uniq=False)
+    assert (np.diff(got.astype(np.int64)) > 0).all()
+    assert np.array_equal(got, np.unique(ids))
+    gotq = setop.union([ids], uniq=True)
+    assert np.array_equal(gotq, numpy_union(ids, True))
+
+
+def test_device_resident_lists(capi, setop):
+    hip = C.CDLL("libamdhip64.so")
+    rs = np.random.RandomState(63)
+    ids = rs.randint(0, 2 ** 32, size=1_000_000, dtype=np.uint64).astype(np.uint32)
+    ids[::10] = ids[5]
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), C.c_size_t(ids.nbytes)) == 0
+    assert hip.hipMemcpy(p, C.c_void_p(ids.ctypes.data), C.c_size_t(ids.nbytes), 1) == 0
+    setop.begin(uniq=True)
+    setop.add_device(p.value, ids.size // 2)
+    setop.add_device(p.value + 4 * (ids.size // 2), ids.size - ids.size // 2)
+    n = setop.finish_count()
+    hip.hipFree(p)
+    assert n == numpy_union(ids, True).size
