@@ -234,6 +234,13 @@ int mk_setop_add(mk_setop *s, const uint32_t *ids, uint64_t n);            /* ho
 int mk_setop_add_device(mk_setop *s, const uint32_t *ids_dev, uint64_t n); /* device list, asynchronous on mk_setop_stream() */
 int mk_setop_finish(mk_setop *s, const uint32_t **ids_out, uint64_t *n_out);
 int mk_setop_result_device(mk_setop *s, const uint32_t **ids_dev, uint64_t *n); /* the same result, left in HBM */
+/* `set -i <pan>` / `set -s <pan>`: sketch_operate() (command_set.c:321-425).  With the pan ids in the dictionary
+ * (mk_setop_begin(MK_SET_UNION) + mk_setop_add: the indexing loop :374-377), keep -- in input order -- the ids of a
+ * combined sketch file that are (keep_members != 0, -i) / are not (-s) in it: the loop :392-405.  bounds[0..nb) are
+ * positions into `ids` (combco.index.N); bounds_out[j] receives the number of kept ids in front of position bounds[j]
+ * (the output's combco.index.N).  The dictionary stays valid for further calls.  Result memory as for mk_setop_finish. */
+int mk_setop_filter(mk_setop *s, int keep_members, const uint32_t *ids, uint64_t n, const uint64_t *bounds, uint32_t nb,
+                    const uint32_t **ids_out, uint64_t *n_out, uint64_t *bounds_out);
 void *mk_setop_stream(mk_setop *s); /* hipStream_t the handle works on */
 
 #ifdef __cplusplus

@@ -310,29 +310,134 @@ static void *pf_worker(void *arg) {
 static void usage(void) {
   fprintf(stderr,
           "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D] <fastq|fasta|dir>...\n"
-          "       metakssd set -u|-q [-o outdir] [--device D] <sketch dir>\n"
+          "       metakssd set -u|-q|-i <pan dir>|-s <pan dir>|-P [-o outdir] [--device D] <sketch dir>\n"
           "       metakssd shuffle -k <halfK> -s <halfSubK> -l <level> [--seed N] -o <prefix>\n");
   exit(2);
 }
 
-/* ---- `metakssd set -u | -q [-o outdir] <sketch dir>`: sketch_union() / uniq_sketch_union(), command_set.c:241-319,427-512 ----
+static uint8_t *read_whole(const char *path, size_t *n_out) {
+  struct stat st;
+  if (stat(path, &st) != 0) return NULL;
+  FILE *f = fopen(path, "rb");
+  if (!f) return NULL;
+  uint8_t *b = malloc((size_t)st.st_size + 8);
+  if (b && fread(b, 1, (size_t)st.st_size, f) != (size_t)st.st_size) { free(b); b = NULL; }
+  fclose(f);
+  *n_out = (size_t)st.st_size;
+  return b;
+}
+
+/* `set -P`: print_gnames(), command_set.c:610-631 */
+static int set_print_names(const char *in) {
+  char path[PATHLEN * 2 + 32];
+  snprintf(path, sizeof path, "%s/cofiles.stat", in);
+  size_t n = 0;
+  uint8_t *st = read_whole(path, &n);
+  if (!st || n < 32) die("cannot find cofiles.stat under %s ", in);
+  int32_t infile_num;
+  memcpy(&infile_num, st + 20, 4);
+  if (n < 32 + (size_t)infile_num * (4 + PATHLEN)) die("sketch_union():%s", path);
+  for (int i = 0; i < infile_num; i++) {
+    uint32_t ct;
+    memcpy(&ct, st + 32 + 4 * (size_t)i, 4);
+    printf("%d\t%.*s\n", (int)ct, PATHLEN, (const char *)st + 32 + 4 * (size_t)infile_num + (size_t)PATHLEN * i);
+  }
+  free(st);
+  return 0;
+}
+
+/* `set -i <pan>` / `set -s <pan>`: sketch_operate(), command_set.c:321-425.  Dictionary of the pan ids and the ordered
+ * filter on the device (mk_setop_filter); files, per-file recount and the untouched header fields as in the reference. */
+static int set_operate(const char *in, const char *pan, const char *outdir, int intersect, int device) {
+  char path[PATHLEN * 2 + 32];
+  size_t pn = 0, sn = 0;
+  snprintf(path, sizeof path, "%s/cofiles.stat", pan);
+  uint8_t *pst = read_whole(path, &pn);
+  if (!pst || pn < 32) die("cannot find cofiles.stat under %s ", pan);
+  snprintf(path, sizeof path, "%s/cofiles.stat", in);
+  uint8_t *st = read_whole(path, &sn);
+  if (!st || sn < 32) die("cannot find cofiles.stat under %s ", in);
+  uint32_t pan_id, in_id;
+  int32_t pan_comp, infile_num;
+  memcpy(&pan_id, pst, 4); memcpy(&in_id, st, 4);
+  memcpy(&pan_comp, pst + 16, 4);
+  memcpy(&infile_num, st + 20, 4);
+  free(pst);
+  if (pan_id != in_id) die("sketcing id not match(%d Vs. %d)", (int)in_id, (int)pan_id);
+  if (sn < 32 + 4 * (size_t)infile_num) die("sketch_operate():%s", path);
+  uint32_t *ctx_ct = (uint32_t *)(st + 32);
+  memset(ctx_ct, 0, 4 * (size_t)infile_num); /* :344-345: recounted below; all_ctx_ct stays as it was */
+  mkdir(outdir, 0777);
+  mk_setop *so;
+  if (mk_setop_create(device, &so) != MK_OK) die("mk_setop_create failed: %s", mk_setop_last_error(NULL));
+  uint64_t *post = malloc(8 * ((size_t)infile_num + 1));
+  for (int c = 0; c < pan_comp; c++) {
+    size_t nb = 0, ib = 0, cb = 0;
+    snprintf(path, sizeof path, "%s/pan.%d", pan, c);
+    uint8_t *pids = read_whole(path, &nb);
+    if (!pids) { snprintf(path, sizeof path, "%s/uniq_pan.%d", pan, c); pids = read_whole(path, &nb); } /* :369-372 */
+    if (!pids) die("sketch_operate():%s", path);
+    snprintf(path, sizeof path, "%s/combco.index.%d", in, c);
+    uint8_t *idx = read_whole(path, &ib);
+    if (!idx || ib < 8 * ((size_t)infile_num + 1)) die("sketch_operate():%s", path);
+    snprintf(path, sizeof path, "%s/combco.%d", in, c);
+    uint8_t *co = read_whole(path, &cb);
+    if (!co) die("sketch_operate():%s", path);
+    const uint64_t *pos = (const uint64_t *)idx;
+    const uint64_t n = pos[infile_num];
+    if (n * 4 > cb) die("sketch_operate():%s is shorter than its index says", path);
+    const uint32_t *out = NULL;
+    uint64_t m = 0;
+    if (mk_setop_begin(so, MK_SET_UNION) != MK_OK || mk_setop_add(so, (const uint32_t *)pids, nb / 4) != MK_OK ||
+        mk_setop_filter(so, intersect, (const uint32_t *)co, n, pos, (uint32_t)infile_num + 1, &out, &m, post) != MK_OK)
+      die("sketch_operate(): %s", mk_setop_last_error(so));
+    for (int i = 0; i < infile_num; i++) ctx_ct[i] += (uint32_t)(post[i + 1] - post[i]);
+    FILE *f;
+    snprintf(path, sizeof path, "%s/combco.%d", outdir, c);
+    if (!(f = fopen(path, "wb")) || fwrite(out, 4, m, f) != m) die("sketch_operate():%s", path);
+    fclose(f);
+    snprintf(path, sizeof path, "%s/combco.index.%d", outdir, c);
+    if (!(f = fopen(path, "wb")) || fwrite(post, 8, (size_t)infile_num + 1, f) != (size_t)infile_num + 1) die("sketch_operate():%s", path);
+    fclose(f);
+    free(pids); free(idx); free(co);
+  }
+  free(post);
+  mk_setop_destroy(so);
+  snprintf(path, sizeof path, "%s/cofiles.stat", outdir);
+  FILE *f = fopen(path, "wb");
+  if (!f || fwrite(st, 1, sn, f) != sn) die("sketch_operate():%s", path);
+  fclose(f);
+  free(st);
+  return 0;
+}
+
+/* ---- `metakssd set`: -u / -q (sketch_union / uniq_sketch_union, command_set.c:241-319,427-512), -i / -s <pan>
+ * (sketch_operate, :321-425), -P (print_gnames, :610-631) ----
  * The dictionary work runs on the device (mk_setop_*); the directory handling follows the reference: the 32-byte
  * cofiles.stat header is copied as it is, one pan.N / uniq_pan.N per component, and a sketch directory holding a
  * single sketch is offered for renaming in place (:254-267). */
 static int cmd_set(int argc, char **argv) {
-  int op = -1, device = 0; /* 2 union, 3 uniq_union (command_set.c:55) */
-  const char *outdir = "./", *in = NULL;
+  int op = -1, device = 0, print = 0; /* 0 subtract, 1 intersect, 2 union, 3 uniq_union (command_set.c:55) */
+  const char *outdir = "./", *in = NULL, *panpath = NULL;
   for (int i = 0; i < argc; i++) {
     if (!strcmp(argv[i], "-u")) { if (op != -1) printf("set operation is already set, -u is ignored.\n"); else op = 2; }
     else if (!strcmp(argv[i], "-q")) { if (op != -1) printf("set operation is already set, -q is ignored.\n"); else op = 3; }
+    else if (!strcmp(argv[i], "-s") && i + 1 < argc) { if (op != -1) printf("set operation is already set, -s is ignored.\n"); else { op = 0; panpath = argv[i + 1]; } i++; }
+    else if (!strcmp(argv[i], "-i") && i + 1 < argc) { if (op != -1) printf("set operation is already set, -i is ignored.\n"); else { op = 1; panpath = argv[i + 1]; } i++; }
+    else if (!strcmp(argv[i], "-P")) print = 1;
     else if (!strcmp(argv[i], "-o") && i + 1 < argc) outdir = argv[++i];
     else if (!strcmp(argv[i], "-p") && i + 1 < argc) ++i; /* threads: no meaning here */
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
-    else if (argv[i][0] == '-' && argv[i][1]) die("set option %s is not part of this build (-u and -q are)", argv[i]);
+    else if (argv[i][0] == '-' && argv[i][1]) die("set option %s is not part of this build (-u -q -i -s -P are)", argv[i]);
     else if (!in) in = argv[i];
   }
   if (!in) usage();
-  if (op == -1) { printf("set operation use : -u, -q, -i or -s\n"); return 255; }
+  if (op == 0 || op == 1) return set_operate(in, panpath, outdir, op == 1, device);
+  if (op == -1) {
+    if (print) return set_print_names(in);
+    printf("set operation use : -u, -q, -i or -s\n");
+    return 255;
+  }
   const char *prefix = op == 2 ? "pan" : "uniq_pan";
   const char *fn = op == 2 ? "sketch_union()" : "uniq_sketch_union()";
   char path[PATHLEN * 2 + 32];
@@ -416,7 +521,7 @@ int main(int argc, char **argv) {
   if (argc < 2) usage();
   if (!strcmp(argv[1], "shuffle")) return cmd_shuffle(argc - 2, argv + 2);
   if (!strcmp(argv[1], "set")) return cmd_set(argc - 2, argv + 2);
-  if (strcmp(argv[1], "dist") != 0) die("only the `dist` sketching path, `set -u/-q` and `shuffle` are part of this build (got `%s`)", argv[1]);
+  if (strcmp(argv[1], "dist") != 0) die("only the `dist` sketching path, `set -u/-q/-i/-s/-P` and `shuffle` are part of this build (got `%s`)", argv[1]);
 
   const char *shuf_path = NULL, *outdir = ".";
   int abundance = 0, uniq = 0, device = 0, quiet = 0, nthreads = 8;

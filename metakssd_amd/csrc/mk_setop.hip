@@ -39,6 +39,14 @@ struct mk_setop {
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   uint32_t *d_out = nullptr, *h_out = nullptr;
   uint64_t out_cap = 0, h_cap = 0;
+  /* mk_setop_filter: the list being filtered, its per-chunk counts / offsets, the boundary positions */
+  uint32_t *d_in = nullptr;
+  uint64_t in_cap = 0;
+  uint32_t *d_fcount = nullptr;
+  unsigned long long *d_foff = nullptr;
+  uint64_t fchunk_cap = 0;
+  unsigned long long *d_bounds = nullptr, *d_bounds_out = nullptr;
+  uint64_t bounds_cap = 0;
   int mode = -1;
   bool begun = false;
   int num_cu = 256;
@@ -166,6 +174,94 @@ __global__ void __launch_bounds__(256) mk_set_write_kernel(const uint32_t *seen,
   }
 }
 
+/* ---- set -i / -s: ordered filter of an id list by dictionary membership (sketch_operate, command_set.c:392-405) ---- */
+#define MK_SET_FCHUNK 1024u /* ids per wave: lane l owns the 16 consecutive ids [16 l, 16 l + 16) of the chunk */
+
+__device__ __forceinline__ uint32_t mk_set_keep16(const uint32_t *ids, uint64_t i0, uint64_t n, const uint32_t *seen, uint32_t keep,
+                                                 uint32_t v[16]) {
+  uint32_t flags = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) {
+    const uint64_t i = i0 + k;
+    v[k] = i < n ? ids[i] : 0u;
+    const uint32_t member = i < n ? (seen[v[k] >> 5] >> (v[k] & 31u)) & 1u : (keep ^ 1u); /* past the end: never kept */
+    flags |= (member == keep ? 1u : 0u) << k;
+  }
+  return flags;
+}
+
+__global__ void __launch_bounds__(256) mk_set_fcount_kernel(const uint32_t *ids, uint64_t n, const uint32_t *seen, uint32_t keep,
+                                                            uint64_t nchunks, uint32_t *chunk_count) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (chunk >= nchunks) return;
+  uint32_t v[16];
+  uint32_t c = __popc(mk_set_keep16(ids, chunk * MK_SET_FCHUNK + 16u * lane, n, seen, keep, v));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if (lane == 0) chunk_count[chunk] = c;
+}
+
+/* exclusive prefix over any number of chunk counts: one workgroup, each thread a contiguous slice */
+__global__ void __launch_bounds__(1024) mk_set_scan_n_kernel(const uint32_t *count, uint64_t nchunks, unsigned long long *off,
+                                                            unsigned long long *total) {
+  __shared__ unsigned long long part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint64_t per = (nchunks + 1023u) / 1024u, lo = (uint64_t)t * per, hi = lo + per < nchunks ? lo + per : nchunks;
+  unsigned long long sum = 0;
+  for (uint64_t k = lo; k < hi; k++) sum += count[k];
+  part[t] = sum;
+  __syncthreads();
+  for (uint32_t o = 1; o < 1024u; o <<= 1) {
+    const unsigned long long v = t >= o ? part[t - o] : 0ull;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned long long run = part[t] - sum;
+  for (uint64_t k = lo; k < hi; k++) { off[k] = run; run += count[k]; }
+  if (t == 1023u) *total = part[t];
+}
+
+__global__ void __launch_bounds__(256) mk_set_fwrite_kernel(const uint32_t *ids, uint64_t n, const uint32_t *seen, uint32_t keep,
+                                                            uint64_t nchunks, const uint32_t *chunk_count,
+                                                            const unsigned long long *chunk_off, uint32_t *out) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (chunk >= nchunks || chunk_count[chunk] == 0u) return; /* wave-uniform */
+  uint32_t v[16];
+  const uint32_t flags = mk_set_keep16(ids, chunk * MK_SET_FCHUNK + 16u * lane, n, seen, keep, v);
+  const uint32_t mine = __popc(flags);
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(incl, off, 64);
+    if ((int)lane >= off) incl += u;
+  }
+  uint32_t *o = out + chunk_off[chunk] + (incl - mine);
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++)
+    if ((flags >> k) & 1u) *o++ = v[k];
+}
+
+/* kept ids in front of each boundary position (combco.index.N -> the output's index) */
+__global__ void __launch_bounds__(256) mk_set_bounds_kernel(const uint32_t *ids, uint64_t n, const uint32_t *seen, uint32_t keep,
+                                                            uint64_t nchunks, const unsigned long long *chunk_off,
+                                                            const unsigned long long *total, const unsigned long long *bounds,
+                                                            uint32_t nb, unsigned long long *out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nb) return;
+  uint64_t b = bounds[j];
+  if (b > n) b = n;
+  const uint64_t c = b / MK_SET_FCHUNK;
+  unsigned long long acc = c < nchunks ? chunk_off[c] : *total;
+  for (uint64_t i = c * MK_SET_FCHUNK; i < b; i++) {
+    const uint32_t v = ids[i];
+    acc += (((seen[v >> 5] >> (v & 31u)) & 1u) == keep) ? 1u : 0u;
+  }
+  out[j] = acc;
+}
+
 /* ---- host side ------------------------------------------------------------------------------------------ */
 extern "C" int mk_setop_create(int device, mk_setop **out) {
   if (!out) return MK_ERR_ARG;
@@ -209,6 +305,7 @@ extern "C" int mk_setop_destroy(mk_setop *s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   (void)hipFree(s->d_seen); (void)hipFree(s->d_dup); (void)hipFree(s->d_chunk); (void)hipFree(s->d_chunk_off);
   (void)hipFree(s->d_total); (void)hipFree(s->d_out);
+  (void)hipFree(s->d_in); (void)hipFree(s->d_fcount); (void)hipFree(s->d_foff); (void)hipFree(s->d_bounds); (void)hipFree(s->d_bounds_out);
   if (s->h_total) (void)hipHostFree(s->h_total);
   if (s->h_out) (void)hipHostFree(s->h_out);
   for (int b = 0; b < 2; b++) {
@@ -311,6 +408,77 @@ extern "C" int mk_setop_finish(mk_setop *s, const uint32_t **ids_out, uint64_t *
   *ids_out = s->h_out;
   *n_out = total;
   s->begun = false;
+  return MK_OK;
+}
+
+static int mk_set_grow(mk_setop *s, void **p, uint64_t *cap, uint64_t need, size_t elem) {
+  if (need <= *cap) return MK_OK;
+  (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  const uint64_t c = need + need / 8 + 1024;
+  MK_SET_HIP(s, hipMalloc(p, c * elem));
+  *cap = c;
+  return MK_OK;
+}
+
+extern "C" int mk_setop_filter(mk_setop *s, int keep_members, const uint32_t *ids, uint64_t n, const uint64_t *bounds, uint32_t nb,
+                               const uint32_t **ids_out, uint64_t *n_out, uint64_t *bounds_out) {
+  if (!s || !ids_out || !n_out || (n && !ids) || (nb && (!bounds || !bounds_out))) return MK_ERR_ARG;
+  if (!s->begun || s->mode != MK_SET_UNION) return mk_set_fail(s, MK_ERR_STATE, "mk_setop_filter needs a union dictionary (begin + add of the pan ids)");
+  MK_SET_HIP(s, hipSetDevice(s->device));
+  const uint32_t keep = keep_members ? 1u : 0u;
+  const uint64_t nchunks = (n + MK_SET_FCHUNK - 1) / MK_SET_FCHUNK;
+  int rc;
+  if ((rc = mk_set_grow(s, (void **)&s->d_in, &s->in_cap, n, 4))) return rc;
+  if ((rc = mk_set_grow(s, (void **)&s->d_out, &s->out_cap, n, 4))) return rc;
+  { /* counts and offsets share one capacity */
+    uint64_t c1 = s->fchunk_cap, c2 = s->fchunk_cap;
+    if ((rc = mk_set_grow(s, (void **)&s->d_fcount, &c1, nchunks, 4))) return rc;
+    if ((rc = mk_set_grow(s, (void **)&s->d_foff, &c2, nchunks, 8))) return rc;
+    s->fchunk_cap = c1 < c2 ? c1 : c2;
+  }
+  {
+    uint64_t c1 = s->bounds_cap, c2 = s->bounds_cap;
+    if ((rc = mk_set_grow(s, (void **)&s->d_bounds, &c1, nb, 8))) return rc;
+    if ((rc = mk_set_grow(s, (void **)&s->d_bounds_out, &c2, nb, 8))) return rc;
+    s->bounds_cap = c1 < c2 ? c1 : c2;
+  }
+  uint64_t total = 0;
+  if (n) {
+    MK_SET_HIP(s, hipMemcpyAsync(s->d_in, ids, n * 4, hipMemcpyHostToDevice, s->stream));
+    const unsigned blocks = (unsigned)((nchunks + 3) / 4);
+    hipLaunchKernelGGL(mk_set_fcount_kernel, dim3(blocks), dim3(256), 0, s->stream, s->d_in, n, s->d_seen, keep, nchunks, s->d_fcount);
+    hipLaunchKernelGGL(mk_set_scan_n_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_fcount, nchunks, s->d_foff, s->d_total);
+    hipLaunchKernelGGL(mk_set_fwrite_kernel, dim3(blocks), dim3(256), 0, s->stream, s->d_in, n, s->d_seen, keep, nchunks, s->d_fcount,
+                       s->d_foff, s->d_out);
+    MK_SET_HIP(s, hipGetLastError());
+    MK_SET_HIP(s, hipMemcpyAsync(s->h_total, s->d_total, 8, hipMemcpyDeviceToHost, s->stream));
+    if (nb) {
+      MK_SET_HIP(s, hipMemcpyAsync(s->d_bounds, bounds, (size_t)nb * 8, hipMemcpyHostToDevice, s->stream));
+      hipLaunchKernelGGL(mk_set_bounds_kernel, dim3((nb + 255) / 256), dim3(256), 0, s->stream, s->d_in, n, s->d_seen, keep, nchunks,
+                         s->d_foff, s->d_total, s->d_bounds, nb, s->d_bounds_out);
+      MK_SET_HIP(s, hipGetLastError());
+      MK_SET_HIP(s, hipMemcpyAsync(bounds_out, s->d_bounds_out, (size_t)nb * 8, hipMemcpyDeviceToHost, s->stream));
+    }
+    MK_SET_HIP(s, hipStreamSynchronize(s->stream));
+    total = *s->h_total;
+  } else {
+    for (uint32_t j = 0; j < nb; j++) bounds_out[j] = 0;
+    *s->h_total = 0;
+  }
+  if (total > s->h_cap) {
+    if (s->h_out) (void)hipHostFree(s->h_out);
+    s->h_out = nullptr; s->h_cap = 0;
+    const uint64_t cap = total + total / 8 + 1024;
+    MK_SET_HIP(s, hipHostMalloc((void **)&s->h_out, cap * 4, hipHostMallocDefault));
+    s->h_cap = cap;
+  }
+  if (total) {
+    MK_SET_HIP(s, hipMemcpyAsync(s->h_out, s->d_out, total * 4, hipMemcpyDeviceToHost, s->stream));
+    MK_SET_HIP(s, hipStreamSynchronize(s->stream));
+  }
+  *ids_out = s->h_out;
+  *n_out = total;
   return MK_OK;
 }
 

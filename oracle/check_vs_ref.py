@@ -354,6 +354,27 @@ def main():
     set_case("L1K7_set_u_reads_A", "L1K7", [fq10, fq16, fq11], ["-A"], "-u")
     set_case("L1K7_set_q_reads_n2", "L1K7", [fq10, fq16, fq11], ["-n", "2"], "-q")
     set_case("L1K7_set_u_single_N", "L1K7", [fas[0]], [], "-u")        # one sketch, prompt answered N: normal output
+
+    # `set -i <pan>` / `set -s <pan>` (sketch_operate, :321-425): pan directories from the runs above
+    def operate_case(label, sk_label, pan_label, op):
+        nonlocal failures
+        sk, pan = os.path.join(work, sk_label + ".sk"), os.path.join(work, pan_label + ".refpan")
+        o_ref, o_ora = os.path.join(work, label + ".refop"), os.path.join(work, label + ".oraop")
+        for d in (o_ref, o_ora):
+            shutil.rmtree(d, ignore_errors=True)
+        r1 = subprocess.run([REF, "set", op, pan, "-o", o_ref, sk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        r2 = subprocess.run([ORA, "set", op, pan, "-o", o_ora, sk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        names = sorted(os.listdir(o_ref)) if os.path.isdir(o_ref) else []
+        ok = r1.returncode == 0 and r2.returncode == 0 and names and names == sorted(os.listdir(o_ora))
+        ok = ok and all(filecmp.cmp(os.path.join(o_ref, f), os.path.join(o_ora, f), shallow=False) for f in names)
+        nids = sum(os.path.getsize(os.path.join(o_ref, f)) // 4 for f in names if f.startswith("combco.") and ".index." not in f)
+        print("%s %-28s ids=%d files=%d" % ("ok  " if ok else "FAIL", label, nids, len(names)))
+        failures += 0 if ok else 1
+
+    for sh in ("L1K7", "L0K6z", "L2K11"):
+        operate_case("%s_set_i_q" % sh, "%s_set_u" % sh, "%s_set_q" % sh, "-i")   # sketches of _set_u x pan of _set_q
+        operate_case("%s_set_s_q" % sh, "%s_set_u" % sh, "%s_set_q" % sh, "-s")
+    operate_case("L1K7_set_s_reads_A", "L1K7_set_u_reads_A", "L1K7_set_q_reads_n2", "-s")   # koc=1 input, uniq_pan.N as pan
     # (the cofiles.stat header is compared byte for byte here: both sides copy the reference-made directory's bytes)
 
     if args.big:

@@ -710,3 +710,92 @@ int ko_set_stage(const char *indir, const char *outdir, int uniq, int answer_yes
   }
   return KO_OK;
 }
+
+
+/* ---- `set -i <pan>` / `set -s <pan>`: sketch_operate() (command_set.c:321-425) ---- */
+size_t ko_set_filter(const uint32_t *pan, size_t npan, int keep_members, const uint32_t *ids, size_t n, uint32_t *out) {
+  const size_t comp_sz = (size_t)1 << (4 * KO_COMPONENT_SZ);
+  ko_llong *dict = calloc(comp_sz / 64, sizeof(ko_llong)); /* :361,364 */
+  if (!dict) return (size_t)-1;
+  for (size_t i = 0; i < npan; i++) dict[pan[i] / 64] |= 0x8000000000000000ULL >> (pan[i] % 64); /* :374-377 */
+  size_t m = 0;
+  for (size_t i = 0; i < n; i++) { /* :394-404: order kept */
+    const int member = (dict[ids[i] / 64] & (0x8000000000000000ULL >> (ids[i] % 64))) > 0;
+    if (keep_members == member) out[m++] = ids[i];
+  }
+  free(dict);
+  return m;
+}
+
+static unsigned char *ko_slurp(const char *path, size_t *n_out) {
+  struct stat st;
+  if (stat(path, &st) != 0) return NULL;
+  FILE *f = fopen(path, "rb");
+  if (!f) return NULL;
+  unsigned char *b = malloc((size_t)st.st_size + 8);
+  if (b && fread(b, 1, (size_t)st.st_size, f) != (size_t)st.st_size) { free(b); b = NULL; }
+  fclose(f);
+  *n_out = (size_t)st.st_size;
+  return b;
+}
+
+int ko_set_operate(const char *indir, const char *pandir, const char *outdir, int intersect) {
+  char path[KO_PATHLEN * 2];
+  size_t pan_stat_n = 0, stat_n = 0;
+  snprintf(path, sizeof path, "%s/cofiles.stat", pandir);
+  unsigned char *pan_stat = ko_slurp(path, &pan_stat_n);
+  snprintf(path, sizeof path, "%s/cofiles.stat", indir);
+  unsigned char *stat_mem = ko_slurp(path, &stat_n); /* :336-340: the whole file, rewritten at the end */
+  if (!pan_stat || !stat_mem || pan_stat_n < 32 || stat_n < 32) { free(pan_stat); free(stat_mem); return KO_ERR_IO; }
+  uint32_t pan_id, in_id;
+  int32_t pan_comp, infile_num;
+  memcpy(&pan_id, pan_stat, 4); memcpy(&in_id, stat_mem, 4);
+  memcpy(&pan_comp, pan_stat + 16, 4);
+  memcpy(&infile_num, stat_mem + 20, 4);
+  free(pan_stat);
+  if (pan_id != in_id) { free(stat_mem); return KO_ERR_ARG; } /* :341 */
+  uint32_t *ctx_ct = (uint32_t *)(stat_mem + 32);
+  memset(ctx_ct, 0, (size_t)infile_num * 4); /* :344-345; all_ctx_ct in the header is left as it was */
+  mkdir(outdir, 0777);
+  size_t *pos = malloc(sizeof(size_t) * ((size_t)infile_num + 1)), *post = malloc(sizeof(size_t) * ((size_t)infile_num + 1));
+  int rc = KO_OK;
+  for (int c = 0; c < pan_comp && rc == KO_OK; c++) { /* :365: the PAN directory's component count drives the loop */
+    size_t nb = 0, ib = 0, cb = 0;
+    snprintf(path, sizeof path, "%s/pan.%d", pandir, c);
+    unsigned char *pan = ko_slurp(path, &nb);
+    if (!pan) { snprintf(path, sizeof path, "%s/uniq_pan.%d", pandir, c); pan = ko_slurp(path, &nb); } /* :369-372 */
+    snprintf(path, sizeof path, "%s/combco.index.%d", indir, c);
+    unsigned char *idx = ko_slurp(path, &ib);
+    snprintf(path, sizeof path, "%s/combco.%d", indir, c);
+    unsigned char *co = ko_slurp(path, &cb);
+    if (!pan || !idx || !co || ib < sizeof(size_t) * ((size_t)infile_num + 1)) { free(pan); free(idx); free(co); rc = KO_ERR_IO; break; }
+    memcpy(pos, idx, sizeof(size_t) * ((size_t)infile_num + 1));
+    const uint32_t *ids = (const uint32_t *)co;
+    uint32_t *out = malloc(4 * (pos[infile_num] + 1));
+    size_t m = 0;
+    post[0] = 0;
+    for (int i = 0; i < infile_num; i++) { /* :392-405, one file at a time through the same dictionary */
+      const size_t k = ko_set_filter((const uint32_t *)pan, nb / 4, intersect, ids + pos[i], pos[i + 1] - pos[i], out + m);
+      if (k == (size_t)-1) { rc = KO_ERR_IO; break; }
+      m += k;
+      post[i + 1] = m;
+      ctx_ct[i] += (uint32_t)k;
+    }
+    if (rc == KO_OK) {
+      snprintf(path, sizeof path, "%s/combco.%d", outdir, c);
+      FILE *f = fopen(path, "wb");
+      if (f) { fwrite(out, 4, m, f); fclose(f); } else rc = KO_ERR_IO;
+      snprintf(path, sizeof path, "%s/combco.index.%d", outdir, c);
+      f = fopen(path, "wb");
+      if (f) { fwrite(post, sizeof(size_t), (size_t)infile_num + 1, f); fclose(f); } else rc = KO_ERR_IO;
+    }
+    free(out); free(pan); free(idx); free(co);
+  }
+  if (rc == KO_OK) {
+    snprintf(path, sizeof path, "%s/cofiles.stat", outdir);
+    FILE *f = fopen(path, "wb");
+    if (f) { fwrite(stat_mem, 1, stat_n, f); fclose(f); } else rc = KO_ERR_IO; /* :415-418 */
+  }
+  free(pos); free(post); free(stat_mem);
+  return rc;
+}

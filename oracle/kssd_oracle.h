@@ -100,6 +100,12 @@ size_t ko_set_union(const uint32_t *ids, size_t n, int uniq, uint32_t *out);
 /* the whole command on a sketch directory: cofiles.stat header copied as it is, pan.N / uniq_pan.N written.
  * answer_yes: the reply to "only 1 sketch, use ... as pan-sketch?(Y/N)" when infile_num == 1 (renames in place). */
 int ko_set_stage(const char *indir, const char *outdir, int uniq, int answer_yes);
+/* `set -i <pan>` / `set -s <pan>`: sketch_operate() (command_set.c:321-425).  ko_set_filter: the ids that are
+ * (keep_members=1) / are not (0) in the dictionary built from `pan`, input order kept; returns the count.
+ * ko_set_operate: the whole command (combco.N, combco.index.N, cofiles.stat with recounted per-file sizes; the header's
+ * all_ctx_ct and koc are left untouched and no .a files are written, exactly like the reference). */
+size_t ko_set_filter(const uint32_t *pan, size_t npan, int keep_members, const uint32_t *ids, size_t n, uint32_t *out);
+int ko_set_operate(const char *indir, const char *pandir, const char *outdir, int intersect);
 
 #ifdef __cplusplus
 }

@@ -87,22 +87,34 @@ def main():
                            cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         if not os.path.exists(os.path.join(sk, "cofiles.stat")):
             raise SystemExit("reference dist failed on %s: %s" % (case, r.stderr.decode(errors="replace")[-300:]))
-        r = subprocess.run([REF, "set", c["op"], "-o", out, sk], cwd=work, input=b"N\n", stdout=subprocess.PIPE,
+        op_args = [c["op"]]
+        if "pan" in c:  # the pan directory: reference dist on the pan inputs, then reference set -u/-q
+            pc = c["pan"]
+            pin = build_set_inputs(case, work, write_committed=True, pan=True)
+            psk, pdir = os.path.join(work, case + ".psk"), os.path.join(work, case + ".pdir")
+            subprocess.run([REF, "dist", "-L", shuf_paths[c["shuf"]]] + pc["flags"] + ["-p", "1", "-o", psk] + pin, cwd=work,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            subprocess.run([REF, "set", pc["op"], "-o", pdir, psk], cwd=work, input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            if not os.path.exists(os.path.join(pdir, "cofiles.stat")):
+                raise SystemExit("reference pan step failed on %s" % case)
+            op_args = [c["op"], pdir]
+        r = subprocess.run([REF, "set"] + op_args + ["-o", out, sk], cwd=work, input=b"N\n", stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE)
         if r.returncode != 0 or not os.path.exists(os.path.join(out, "cofiles.stat")):
             raise SystemExit("reference set failed on %s: %s" % (case, r.stderr.decode(errors="replace")[-300:]))
         d = os.path.join(exp_root, case)
         os.makedirs(d)
         for f in sorted(os.listdir(out)):
-            if f.startswith("pan.") or f.startswith("uniq_pan."):
+            if f.startswith("pan.") or f.startswith("uniq_pan.") or f.startswith("combco"):
                 shutil.copy(os.path.join(out, f), os.path.join(d, f))
-        hdr = open(os.path.join(out, "cofiles.stat"), "rb").read()
-        assert len(hdr) == 32
         stat = parse_stat(os.path.join(sk, "cofiles.stat"))
         entry = {"shuf": c["shuf"], "flags": c["flags"], "inputs": c["inputs"], "op": c["op"],
                  "header": {k: stat[k] for k in ("shuf_id", "koc", "kmerlen", "dim_rd_len", "comp_num", "infile_num", "all_ctx_ct")},
                  "files": {f: hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest() for f in sorted(os.listdir(d))},
-                 "ids": sum(os.path.getsize(os.path.join(d, f)) // 4 for f in os.listdir(d))}
+                 "ids": sum(os.path.getsize(os.path.join(d, f)) // 4 for f in os.listdir(d) if ".index." not in f)}
+        if "pan" in c:
+            entry["pan"] = c["pan"]
+            entry["stat"] = parse_stat(os.path.join(out, "cofiles.stat"))  # full stat file: recounted ctx_ct, old all_ctx_ct
         manifest["set_cases"][case] = entry
         print("%-28s ids=%d files=%d" % (case, entry["ids"], len(entry["files"])))
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)

@@ -74,6 +74,17 @@ SET_CASES = {
     "set_u_reads_A_L1K7": {"shuf": "L1K7", "flags": ["-A"], "inputs": ["fq:pool", "fq:lowcov", "fq:ragged"], "op": "-u"},
     "set_q_reads_L0K6": {"shuf": "L0K6", "flags": ["-n", "2"], "inputs": ["fq:lowcov", "fq:qual"], "op": "-q"},
     "set_u_single_N_L1K7": {"shuf": "L1K7", "flags": [], "inputs": ["fa:sA"], "op": "-u"},  # one sketch: prompt answered N
+    # `set -i <pan>` / `set -s <pan>` (sketch_operate): the pan directory is made by dist + set from "pan"
+    "set_i_markers_L1K7": {"shuf": "L1K7", "flags": [], "inputs": ["fa:sA", "fa:sB", "fa:sC"], "op": "-i",
+                           "pan": {"flags": [], "inputs": ["fa:sA", "fa:sB", "fa:sC"], "op": "-q"}},  # README.md:98-103
+    "set_s_private_L1K7": {"shuf": "L1K7", "flags": [], "inputs": ["fa:sA", "fa:sB", "fa:sC"], "op": "-s",
+                           "pan": {"flags": [], "inputs": ["fa:sA", "fa:sB"], "op": "-u"}},
+    "set_i_dense_L0K6": {"shuf": "L0K6", "flags": [], "inputs": ["fa:sC", "fa:sA", "fa:sB"], "op": "-i",
+                         "pan": {"flags": [], "inputs": ["fa:sB", "fa:sC"], "op": "-q"}},
+    "set_s_reads_A_L1K7": {"shuf": "L1K7", "flags": ["-A"], "inputs": ["fq:pool", "fq:lowcov"], "op": "-s",
+                           "pan": {"flags": ["-A"], "inputs": ["fq:ragged", "fq:pool"], "op": "-u"}},  # koc stays 1, no .a written
+    "set_i_strains_L2K11": {"shuf": "L2K11", "flags": [], "inputs": ["fa:sA", "fa:sB", "fa:sC"], "op": "-i",
+                            "pan": {"flags": [], "inputs": ["fa:sB", "fa:sC"], "op": "-u"}},  # 16 components
 }
 
 
@@ -182,9 +193,10 @@ def build_input(case, workdir, write_committed=False, spec=None):
     raise ValueError(spec)
 
 
-def build_set_inputs(case, workdir, write_committed=False):
-    """input files of a SET_CASES entry, in order"""
+def build_set_inputs(case, workdir, write_committed=False, pan=False):
+    """input files of a SET_CASES entry (or of its "pan" part), in order"""
     out = []
-    for i, spec in enumerate(SET_CASES[case]["inputs"]):
-        out.append(build_input("%s_in%d" % (case, i), workdir, write_committed=write_committed, spec=spec))
+    specs = SET_CASES[case]["pan"]["inputs"] if pan else SET_CASES[case]["inputs"]
+    for i, spec in enumerate(specs):
+        out.append(build_input("%s_%s%d" % (case, "pan" if pan else "in", i), workdir, write_committed=write_committed, spec=spec))
     return out

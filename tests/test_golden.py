@@ -148,7 +148,6 @@ def test_product_cli_multi_file_directory_equals_oracle(kind, shuf, flags, shuf_
 
 
 # ---- `set -u` / `set -q`: pan.N / uniq_pan.N made by the reference's own `set` --------------------
-SET_HEAVY = {"set_u_strains_L2K11", "set_q_strains_L2K11"}  # 4.3 GB oracle table for the dist step
 
 
 def parse_header(path):
@@ -160,15 +159,20 @@ def parse_header(path):
                 infile_num=infile_num, all_ctx_ct=all_ctx)
 
 
-def check_set_against_golden(case, outdir):
+def check_set_against_golden(case, outdir, inputs):
     entry = MANIFEST["set_cases"][case]
     exp = os.path.join(gc.GOLDEN, "expected", case)
     want = sorted(os.listdir(exp))
-    got = sorted(f for f in os.listdir(outdir) if f.startswith("pan.") or f.startswith("uniq_pan."))
-    assert got == want
+    got = sorted(f for f in os.listdir(outdir) if f != "cofiles.stat")
+    assert got == want  # in particular: no combco.N.a after -i / -s even when the header says koc (command_set.c:321-425)
     for f in want:
         assert filecmp.cmp(os.path.join(exp, f), os.path.join(outdir, f), shallow=False), "%s: %s differs" % (case, f)
-    assert parse_header(os.path.join(outdir, "cofiles.stat")) == entry["header"]
+    if "stat" in entry:  # -i / -s: the whole stat file of the input directory with recounted per-file sizes
+        stat, names = parse_stat(os.path.join(outdir, "cofiles.stat"))
+        assert stat == entry["stat"] and names == inputs
+        assert sum(stat["ctx_ct"]) != stat["all_ctx_ct"] or entry["ids"] == stat["all_ctx_ct"]  # header total is NOT recounted
+    else:
+        assert parse_header(os.path.join(outdir, "cofiles.stat")) == entry["header"]
 
 
 def run_set_case(case, shuf_files, tmp_path, dist_cmd, set_cmd):
@@ -178,9 +182,19 @@ def run_set_case(case, shuf_files, tmp_path, dist_cmd, set_cmd):
     r = subprocess.run(dist_cmd + ["-L", shuf_files(entry["shuf"])] + entry["flags"] + ["-o", sk] + inputs,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()
-    r = subprocess.run(set_cmd + [entry["op"], "-o", out, sk], input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    op_args = [entry["op"]]
+    if "pan" in entry:
+        pin = gc.build_set_inputs(case, str(tmp_path), pan=True)
+        psk, pdir = str(tmp_path / "psk"), str(tmp_path / "pdir")
+        r = subprocess.run(dist_cmd + ["-L", shuf_files(entry["shuf"])] + entry["pan"]["flags"] + ["-o", psk] + pin,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        r = subprocess.run(set_cmd + [entry["pan"]["op"], "-o", pdir, psk], input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        op_args = [entry["op"], pdir]
+    r = subprocess.run(set_cmd + op_args + ["-o", out, sk], input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()
-    check_set_against_golden(case, out)
+    check_set_against_golden(case, out, inputs)
 
 
 @pytest.mark.parametrize("case", sorted(MANIFEST["set_cases"]))
@@ -208,3 +222,22 @@ def test_product_cli_set_single_sketch_rename(shuf_files, tmp_path):
     assert r.returncode == 0 and b"only 1 sketch" in r.stdout
     assert not os.path.exists(os.path.join(sk, "combco.0")) and not os.path.exists(str(tmp_path / "unused"))
     assert open(os.path.join(sk, "uniq_pan.0"), "rb").read() == before
+
+
+@pytest.mark.gpu
+def test_product_cli_set_print_names_and_id_mismatch(shuf_files, tmp_path):
+    """-P prints "<count>\\t<name>" per sketch (command_set.c:610-631); -i with a pan of another .shuf id is refused (:341)"""
+    inputs = gc.build_set_inputs("set_u_strains_L1K7", str(tmp_path))
+    sk, sk2 = str(tmp_path / "sk"), str(tmp_path / "sk2")
+    for d, sh in ((sk, "L1K7"), (sk2, "L0K6")):
+        r = subprocess.run([PRODUCT_CLI, "dist", "-L", shuf_files(sh), "-o", d] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+    stat, names = parse_stat(os.path.join(sk, "cofiles.stat"))
+    r = subprocess.run([PRODUCT_CLI, "set", "-P", sk], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0
+    assert r.stdout.decode().splitlines() == ["%d\t%s" % (c, n) for c, n in zip(stat["ctx_ct"], names)]
+    pan2 = str(tmp_path / "pan2")
+    r = subprocess.run([PRODUCT_CLI, "set", "-u", "-o", pan2, sk2], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0
+    r = subprocess.run([PRODUCT_CLI, "set", "-i", pan2, "-o", str(tmp_path / "x"), sk], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"sketcing id not match" in r.stderr

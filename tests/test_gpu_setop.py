@@ -111,3 +111,67 @@ def test_device_resident_lists(capi, setop):
     n = setop.finish_count()
     hip.hipFree(p)
     assert n == numpy_union(ids, True).size
+
+
+# ---- set -i / -s: ordered filter by dictionary membership (sketch_operate, command_set.c:392-405) --------------------
+def oracle_filter(pan, keep, ids):
+    from oracle_binding import load
+    lib = load()
+    lib.ko_set_filter.restype = C.c_size_t
+    lib.ko_set_filter.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    pan = np.ascontiguousarray(pan, np.uint32)
+    ids = np.ascontiguousarray(ids, np.uint32)
+    out = np.zeros(max(1, ids.size), np.uint32)
+    m = lib.ko_set_filter(pan.ctypes.data if pan.size else None, pan.size, keep, ids.ctypes.data if ids.size else None, ids.size,
+                          out.ctypes.data)
+    return out[:m]
+
+
+def product_filter(capi, setop, pan, keep, ids, bounds):
+    lib = capi.lib
+    lib.mk_setop_filter.restype = C.c_int
+    lib.mk_setop_filter.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_uint64), C.c_void_p]
+    pan = np.ascontiguousarray(pan, np.uint32)
+    ids = np.ascontiguousarray(ids, np.uint32)
+    bounds = np.ascontiguousarray(bounds, np.uint64)
+    bout = np.zeros(bounds.size, np.uint64)
+    setop.begin(uniq=False)
+    if pan.size:
+        assert lib.mk_setop_add(setop.h, pan.ctypes.data, pan.size) == 0
+    out, n = C.c_void_p(), C.c_uint64(0)
+    rc = lib.mk_setop_filter(setop.h, keep, ids.ctypes.data if ids.size else None, ids.size, bounds.ctypes.data if bounds.size else None,
+                             bounds.size, C.byref(out), C.byref(n), bout.ctypes.data if bounds.size else None)
+    assert rc == 0, lib.mk_setop_last_error(setop.h)
+    got = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint32)), shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint32)
+    return got, bout
+
+
+@pytest.mark.parametrize("keep", [1, 0])
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 1023, 1024, 1025, 300001])
+def test_filter_keeps_order_and_reports_boundaries(capi, setop, keep, n):
+    rs = np.random.RandomState(70 + n % 97)
+    universe = rs.randint(0, 2 ** 32, size=50000, dtype=np.uint64).astype(np.uint32)
+    pan = universe[::2]
+    ids = universe[rs.randint(0, universe.size, size=n)] if n else np.zeros(0, np.uint32)   # repeats, arbitrary order
+    cuts = np.unique(np.concatenate([[0, n], rs.randint(0, n + 1, size=7)])).astype(np.uint64)
+    got, bout = product_filter(capi, setop, pan, keep, ids, cuts)
+    want = oracle_filter(pan, keep, ids)
+    assert np.array_equal(got, want)
+    member = np.isin(ids, pan)
+    kept = member if keep else ~member
+    assert np.array_equal(want, ids[kept])
+    assert np.array_equal(bout, np.concatenate([[0], np.cumsum(kept)])[cuts.astype(np.int64)].astype(np.uint64))
+
+
+def test_filter_empty_dictionary_and_state_errors(capi, setop):
+    ids = np.arange(10, 5000, 3, dtype=np.uint32)
+    got, _ = product_filter(capi, setop, np.zeros(0, np.uint32), 0, ids, np.zeros(0, np.uint64))
+    assert np.array_equal(got, ids)                      # nothing is a member: -s keeps all
+    got, _ = product_filter(capi, setop, np.zeros(0, np.uint32), 1, ids, np.zeros(0, np.uint64))
+    assert got.size == 0                                 # ... and -i keeps none
+    setop.begin(uniq=True)                               # a uniq dictionary is not a membership dictionary
+    out, n = C.c_void_p(), C.c_uint64(0)
+    rc = capi.lib.mk_setop_filter(setop.h, 1, ids.ctypes.data, ids.size, None, 0, C.byref(out), C.byref(n), None)
+    assert rc == capi.MK_ERR_STATE
+    setop.finish_count()
