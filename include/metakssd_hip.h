@@ -243,6 +243,14 @@ int mk_setop_filter(mk_setop *s, int keep_members, const uint32_t *ids, uint64_t
                     const uint32_t **ids_out, uint64_t *n_out, uint64_t *bounds_out);
 void *mk_setop_stream(mk_setop *s); /* hipStream_t the handle works on */
 
+/* `set -g <file.tsv>`: the per-taxon table of grouping_genomes() (command_set.c:866-915).  `ids` = the id lists of the
+ * taxon's genomes concatenated in the order of the category file; they go through an FCFS double-hashing table of
+ * `table_size` slots (HASH() in 32-bit unsigned arithmetic, id 0 never stored, an id without a place after table_size
+ * probes dropped) and come back in slot order.  mk_setop_group_table_size(total ids) is the size the reference picks
+ * (:867-872).  Independent of the dictionary state; result memory as for mk_setop_finish. */
+int mk_setop_group(mk_setop *s, const uint32_t *ids, uint64_t n, uint32_t table_size, const uint32_t **ids_out, uint64_t *n_out);
+uint32_t mk_setop_group_table_size(uint64_t total_ids);
+
 #ifdef __cplusplus
 }
 #endif

@@ -310,7 +310,7 @@ static void *pf_worker(void *arg) {
 static void usage(void) {
   fprintf(stderr,
           "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D] <fastq|fasta|dir>...\n"
-          "       metakssd set -u|-q|-i <pan dir>|-s <pan dir>|-P [-o outdir] [--device D] <sketch dir>\n"
+          "       metakssd set -u|-q|-i <pan dir>|-s <pan dir>|-g <tax.tsv>|-P [-o outdir] [--device D] <sketch dir>\n"
           "       metakssd shuffle -k <halfK> -s <halfSubK> -l <level> [--seed N] -o <prefix>\n");
   exit(2);
 }
@@ -411,6 +411,161 @@ static int set_operate(const char *in, const char *pan, const char *outdir, int 
   return 0;
 }
 
+/* `set -g <file.tsv>`: grouping_genomes() (command_set.c:831-974) on top of organize_taxf() (:635-705).
+ * Line i of the category file ("<taxid>[TAB<name>]") classifies sketch i.  The taxa are visited in the slot order of the
+ * reference's hash of taxids (table of nextPrime(lines / 0.6) slots, double hashing) -- that order is part of the output.
+ * Per taxon and component the concatenated id lists of its sketches go through mk_setop_group. */
+typedef struct { int taxid; char *name; int *gids; int ng; } taxon_t;
+
+static int next_prime_from(int n) { /* global_basic.c:453-475 */
+  for (;; n++) {
+    int composite = 0;
+    for (int j = 2; (long long)j * j <= n; j++)
+      if (n % j == 0) { composite = 1; break; }
+    if (!composite) return n;
+  }
+}
+
+static int set_group(const char *in, const char *taxfile, const char *outdir, int device) {
+  size_t tn = 0;
+  uint8_t *txt = read_whole(taxfile, &tn);
+  if (!txt) die("%s: %s", taxfile, strerror(errno));
+  int nlines = 0;
+  for (size_t i = 0; i < tn; i++) nlines += txt[i] == '\n';
+  const int tsz = next_prime_from((int)((double)nlines / 0.6)); /* LD_FCTR */
+  taxon_t *slots = calloc((size_t)tsz, sizeof *slots);
+  for (int i = 0; i < tsz; i++) slots[i].taxid = -1;
+  int ntax = 0;
+  size_t at = 0;
+  for (int i = 0; i < nlines; i++) {
+    size_t e = at;
+    while (txt[e] != '\n') e++;
+    if (e - at + 1 >= PATHLEN) die("organize_taxf(): %dth line %.40s is not full read, exceed PATHLEN %d ", i, (char *)txt + at, PATHLEN);
+    txt[e] = 0;
+    char *save = NULL;
+    char *tok = strtok_r((char *)txt + at, "\t", &save);
+    at = e + 1;
+    if (!tok) die("organize_taxf(): %dth line of %s is empty", i, taxfile);
+    const int taxid = atoi(tok);
+    const char *name = strtok_r(NULL, "\t", &save);
+    if (taxid < 0) die("organize_taxf(): negative taxid %d in %dth line", taxid, i);
+    for (int n = 0; n < tsz; n++) {
+      const int hv = (taxid % tsz + n * (1 + taxid % (tsz - 1))) % tsz;
+      if (hv < 0) die("organize_taxf(): taxid %d overflows the category hash", taxid);
+      taxon_t *t = &slots[hv];
+      if (t->taxid == -1) {
+        t->taxid = taxid; t->name = name ? strdup(name) : NULL;
+        t->gids = malloc(sizeof(int)); t->gids[0] = i; t->ng = 1;
+        ntax++;
+        break;
+      }
+      if (t->taxid == taxid) {
+        if ((t->name == NULL) != (name == NULL) || (name && strcmp(t->name, name) != 0))
+          die("organize_taxf() abort!: taxid %d has different taxnames in %dth and %dth lines", taxid, t->gids[0], i);
+        t->gids = realloc(t->gids, sizeof(int) * (size_t)(t->ng + 1));
+        t->gids[t->ng++] = i;
+        break;
+      }
+    }
+  }
+  taxon_t *tax = malloc(sizeof *tax * (size_t)(ntax + 1));
+  int k = 0;
+  for (int i = 0; i < tsz; i++)
+    if (slots[i].taxid != -1) tax[k++] = slots[i];
+  free(slots);
+
+  char path[PATHLEN * 2 + 32];
+  size_t sn = 0;
+  snprintf(path, sizeof path, "%s/cofiles.stat", in);
+  uint8_t *st = read_whole(path, &sn);
+  if (!st || sn < 32) die("cannot find cofiles.stat under %s ", in);
+  int32_t comp_num, infile_num;
+  memcpy(&comp_num, st + 16, 4);
+  memcpy(&infile_num, st + 20, 4);
+  if (infile_num != nlines)
+    die("grouping_genomes():%s's genome number %d not matches %s's genome number %d", path, infile_num, taxfile, nlines);
+  mkdir(outdir, 0777);
+  mk_setop *so;
+  if (mk_setop_create(device, &so) != MK_OK) die("mk_setop_create failed: %s", mk_setop_last_error(NULL));
+  uint32_t *ctx_ct = calloc((size_t)ntax + 1, 4);
+  uint64_t *outidx = malloc(8 * ((size_t)ntax + 1));
+  uint64_t all_ctx_ct = 0;
+  int outfn = 0;
+  for (int c = 0; c < comp_num; c++) {
+    size_t cb = 0, ib = 0;
+    snprintf(path, sizeof path, "%s/combco.%d", in, c);
+    uint8_t *co = read_whole(path, &cb);
+    if (!co) die("grouping_genomes():%s", path);
+    snprintf(path, sizeof path, "%s/combco.index.%d", in, c);
+    uint8_t *idx = read_whole(path, &ib);
+    if (!idx || ib < 8 * ((size_t)infile_num + 1)) die("grouping_genomes():%s", path);
+    const uint32_t *ids = (const uint32_t *)co;
+    const uint64_t *pos = (const uint64_t *)idx;
+    snprintf(path, sizeof path, "%s/combco.%d", outdir, c);
+    FILE *f = fopen(path, "wb");
+    if (!f) die("grouping_genomes():%s", path);
+    uint32_t *cat = NULL;
+    uint64_t cat_cap = 0, offset = 0;
+    outfn = 0;
+    outidx[0] = 0;
+    for (int t = 0; t < ntax; t++) {
+      if (tax[t].taxid == 0) continue; /* taxid 0 = leave these sketches out (:866) */
+      uint64_t total = 0;
+      for (int g = 0; g < tax[t].ng; g++) total += pos[tax[t].gids[g] + 1] - pos[tax[t].gids[g]];
+      if (total == 0) die("grouping_genomes(): taxid %d has no k-mer in component %d (LOG2(0) in the reference)", tax[t].taxid, c);
+      if (total > cat_cap) {
+        if (cat) mk_host_free(cat);
+        cat_cap = total + total / 4 + 1024;
+        if (mk_host_alloc((void **)&cat, cat_cap * 4) != MK_OK) die("out of memory");
+      }
+      uint64_t w = 0;
+      for (int g = 0; g < tax[t].ng; g++) {
+        const uint64_t a = pos[tax[t].gids[g]], b = pos[tax[t].gids[g] + 1];
+        memcpy(cat + w, ids + a, (b - a) * 4);
+        w += b - a;
+      }
+      const uint32_t *out = NULL;
+      uint64_t m = 0;
+      if (mk_setop_group(so, cat, total, mk_setop_group_table_size(total), &out, &m) != MK_OK)
+        die("grouping_genomes(): %s", mk_setop_last_error(so));
+      if (fwrite(out, 4, m, f) != m) die("grouping_genomes():%s", path);
+      offset += m; all_ctx_ct += m; ctx_ct[outfn] += (uint32_t)m;
+      outidx[++outfn] = offset;
+      printf("%d/%d species pangenome grouped\r", t, ntax);
+    }
+    printf("\n");
+    fclose(f);
+    if (cat) mk_host_free(cat);
+    snprintf(path, sizeof path, "%s/combco.index.%d", outdir, c);
+    if (!(f = fopen(path, "wb")) || fwrite(outidx, 8, (size_t)outfn + 1, f) != (size_t)outfn + 1) die("grouping_genomes():%s", path);
+    fclose(f);
+    free(co); free(idx);
+  }
+  mk_setop_destroy(so);
+  /* cofiles.stat: the input's header with the new sketch count, koc = 0 and the new total (:929-966) */
+  int32_t v = outfn;
+  memcpy(st + 20, &v, 4);
+  st[4] = 0;
+  memcpy(st + 24, &all_ctx_ct, 8);
+  snprintf(path, sizeof path, "%s/cofiles.stat", outdir);
+  FILE *f = fopen(path, "wb");
+  if (!f) die("grouping_genomes():%s", path);
+  fwrite(st, 1, 32, f);
+  fwrite(ctx_ct, 4, (size_t)outfn, f);
+  for (int t = 0; t < ntax; t++) {
+    if (tax[t].taxid == 0) continue;
+    char name[PATHLEN];
+    memset(name, 0, sizeof name);
+    if (tax[t].name) snprintf(name, sizeof name, "%d_%s", tax[t].taxid, tax[t].name);
+    else snprintf(name, sizeof name, "%d", tax[t].taxid);
+    fwrite(name, 1, PATHLEN, f);
+  }
+  fclose(f);
+  for (int t = 0; t < ntax; t++) { free(tax[t].name); free(tax[t].gids); }
+  free(tax); free(st); free(ctx_ct); free(outidx); free(txt);
+  return 0;
+}
+
 /* ---- `metakssd set`: -u / -q (sketch_union / uniq_sketch_union, command_set.c:241-319,427-512), -i / -s <pan>
  * (sketch_operate, :321-425), -P (print_gnames, :610-631) ----
  * The dictionary work runs on the device (mk_setop_*); the directory handling follows the reference: the 32-byte
@@ -418,23 +573,25 @@ static int set_operate(const char *in, const char *pan, const char *outdir, int 
  * single sketch is offered for renaming in place (:254-267). */
 static int cmd_set(int argc, char **argv) {
   int op = -1, device = 0, print = 0; /* 0 subtract, 1 intersect, 2 union, 3 uniq_union (command_set.c:55) */
-  const char *outdir = "./", *in = NULL, *panpath = NULL;
+  const char *outdir = "./", *in = NULL, *panpath = NULL, *taxfile = NULL;
   for (int i = 0; i < argc; i++) {
     if (!strcmp(argv[i], "-u")) { if (op != -1) printf("set operation is already set, -u is ignored.\n"); else op = 2; }
     else if (!strcmp(argv[i], "-q")) { if (op != -1) printf("set operation is already set, -q is ignored.\n"); else op = 3; }
     else if (!strcmp(argv[i], "-s") && i + 1 < argc) { if (op != -1) printf("set operation is already set, -s is ignored.\n"); else { op = 0; panpath = argv[i + 1]; } i++; }
     else if (!strcmp(argv[i], "-i") && i + 1 < argc) { if (op != -1) printf("set operation is already set, -i is ignored.\n"); else { op = 1; panpath = argv[i + 1]; } i++; }
     else if (!strcmp(argv[i], "-P")) print = 1;
+    else if (!strcmp(argv[i], "-g") && i + 1 < argc) taxfile = argv[++i];
     else if (!strcmp(argv[i], "-o") && i + 1 < argc) outdir = argv[++i];
     else if (!strcmp(argv[i], "-p") && i + 1 < argc) ++i; /* threads: no meaning here */
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
-    else if (argv[i][0] == '-' && argv[i][1]) die("set option %s is not part of this build (-u -q -i -s -P are)", argv[i]);
+    else if (argv[i][0] == '-' && argv[i][1]) die("set option %s is not part of this build (-u -q -i -s -g -P are)", argv[i]);
     else if (!in) in = argv[i];
   }
   if (!in) usage();
   if (op == 0 || op == 1) return set_operate(in, panpath, outdir, op == 1, device);
   if (op == -1) {
     if (print) return set_print_names(in);
+    if (taxfile) return set_group(in, taxfile, outdir, device); /* looked at only without -u/-q/-i/-s (command_set.c:227-231) */
     printf("set operation use : -u, -q, -i or -s\n");
     return 255;
   }

@@ -47,6 +47,13 @@ struct mk_setop {
   uint64_t fchunk_cap = 0;
   unsigned long long *d_bounds = nullptr, *d_bounds_out = nullptr;
   uint64_t bounds_cap = 0;
+  /* mk_setop_group: auxiliary first-position table, first-occurrence list, the taxon's slot table */
+  unsigned long long *d_aux = nullptr;
+  uint64_t aux_cap = 0;
+  uint32_t *d_first = nullptr;
+  uint64_t first_cap = 0;
+  uint32_t *d_slot = nullptr;
+  uint64_t slot_cap = 0;
   int mode = -1;
   bool begun = false;
   int num_cu = 256;
@@ -177,26 +184,36 @@ __global__ void __launch_bounds__(256) mk_set_write_kernel(const uint32_t *seen,
 /* ---- set -i / -s: ordered filter of an id list by dictionary membership (sketch_operate, command_set.c:392-405) ---- */
 #define MK_SET_FCHUNK 1024u /* ids per wave: lane l owns the 16 consecutive ids [16 l, 16 l + 16) of the chunk */
 
-__device__ __forceinline__ uint32_t mk_set_keep16(const uint32_t *ids, uint64_t i0, uint64_t n, const uint32_t *seen, uint32_t keep,
-                                                 uint32_t v[16]) {
+/* Ordered stream compaction shared by -i / -s (membership), and by -g (first occurrences; occupied table slots): a
+ * predicate P maps an input position to {keep?, value}.  Pass 1 counts per chunk, pass 2 (after the prefix) rewrites:
+ * lane l owns the 16 consecutive positions [16 l, 16 l + 16) of its wave's chunk, so the output keeps the input order. */
+struct mk_pred_member { /* ids[i] kept iff its dictionary bit == keep */
+  const uint32_t *ids, *seen;
+  uint32_t keep;
+  __device__ __forceinline__ bool operator()(uint64_t i, uint32_t &v) const {
+    v = ids[i];
+    return ((seen[v >> 5] >> (v & 31u)) & 1u) == keep;
+  }
+};
+
+template <class P>
+__device__ __forceinline__ uint32_t mk_set_keep16(const P &p, uint64_t i0, uint64_t n, uint32_t v[16]) {
   uint32_t flags = 0;
 #pragma unroll
   for (uint32_t k = 0; k < 16; k++) {
-    const uint64_t i = i0 + k;
-    v[k] = i < n ? ids[i] : 0u;
-    const uint32_t member = i < n ? (seen[v[k] >> 5] >> (v[k] & 31u)) & 1u : (keep ^ 1u); /* past the end: never kept */
-    flags |= (member == keep ? 1u : 0u) << k;
+    v[k] = 0u;
+    if (i0 + k < n && p(i0 + k, v[k])) flags |= 1u << k;
   }
   return flags;
 }
 
-__global__ void __launch_bounds__(256) mk_set_fcount_kernel(const uint32_t *ids, uint64_t n, const uint32_t *seen, uint32_t keep,
-                                                            uint64_t nchunks, uint32_t *chunk_count) {
+template <class P>
+__global__ void __launch_bounds__(256) mk_set_fcount_kernel(const P p, uint64_t n, uint64_t nchunks, uint32_t *chunk_count) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (chunk >= nchunks) return;
   uint32_t v[16];
-  uint32_t c = __popc(mk_set_keep16(ids, chunk * MK_SET_FCHUNK + 16u * lane, n, seen, keep, v));
+  uint32_t c = __popc(mk_set_keep16(p, chunk * MK_SET_FCHUNK + 16u * lane, n, v));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
   if (lane == 0) chunk_count[chunk] = c;
@@ -207,7 +224,8 @@ __global__ void __launch_bounds__(1024) mk_set_scan_n_kernel(const uint32_t *cou
                                                             unsigned long long *total) {
   __shared__ unsigned long long part[1024];
   const uint32_t t = threadIdx.x;
-  const uint64_t per = (nchunks + 1023u) / 1024u, lo = (uint64_t)t * per, hi = lo + per < nchunks ? lo + per : nchunks;
+  const uint64_t per = (nchunks + 1023u) / 1024u, lo = (uint64_t)t * per < nchunks ? (uint64_t)t * per : nchunks,
+                 hi = lo + per < nchunks ? lo + per : nchunks;
   unsigned long long sum = 0;
   for (uint64_t k = lo; k < hi; k++) sum += count[k];
   part[t] = sum;
@@ -223,14 +241,14 @@ __global__ void __launch_bounds__(1024) mk_set_scan_n_kernel(const uint32_t *cou
   if (t == 1023u) *total = part[t];
 }
 
-__global__ void __launch_bounds__(256) mk_set_fwrite_kernel(const uint32_t *ids, uint64_t n, const uint32_t *seen, uint32_t keep,
-                                                            uint64_t nchunks, const uint32_t *chunk_count,
+template <class P>
+__global__ void __launch_bounds__(256) mk_set_fwrite_kernel(const P p, uint64_t n, uint64_t nchunks, const uint32_t *chunk_count,
                                                             const unsigned long long *chunk_off, uint32_t *out) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (chunk >= nchunks || chunk_count[chunk] == 0u) return; /* wave-uniform */
   uint32_t v[16];
-  const uint32_t flags = mk_set_keep16(ids, chunk * MK_SET_FCHUNK + 16u * lane, n, seen, keep, v);
+  const uint32_t flags = mk_set_keep16(p, chunk * MK_SET_FCHUNK + 16u * lane, n, v);
   const uint32_t mine = __popc(flags);
   uint32_t incl = mine;
 #pragma unroll
@@ -242,6 +260,89 @@ __global__ void __launch_bounds__(256) mk_set_fwrite_kernel(const uint32_t *ids,
 #pragma unroll
   for (uint32_t k = 0; k < 16; k++)
     if ((flags >> k) & 1u) *o++ = v[k];
+}
+
+/* ---- set -g: one taxon's table of grouping_genomes() (command_set.c:874-915) ------------------------------------------
+ * The reference inserts the taxon's ids one by one (genome order, file order) into an FCFS double-hashing table and
+ * dumps the table in slot order, so the bytes encode the order of FIRST occurrences.  On the device:
+ *   mk_grp_insert_kernel   id -> (id, smallest position) in an auxiliary table (any order, atomicMin)
+ *   ordered compaction     positions that are the first occurrence of their id -> list L in first-occurrence order
+ *   mk_grp_layout_kernel   priority insertion of L into the reference's table geometry: rank = index in L; a key takes a
+ *                          slot from a later-ranked occupant (which restarts its own walk) and walks past earlier ones;
+ *                          the fixed point is the sequential FCFS layout.  Probe arithmetic is the reference's 32-bit
+ *                          unsigned HASH(unsigned,int,int) (global_basic.h:282-284); a key that finds no place in
+ *                          table_size probes is dropped, id 0 is never stored (:886, :909)
+ *   ordered compaction     occupied slots -> ids in slot order */
+#define MK_GRP_EMPTY 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ uint32_t mk_grp_mix(uint32_t k) { /* auxiliary table only: any hash will do */
+  k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16;
+  return k;
+}
+
+__global__ void __launch_bounds__(256) mk_grp_insert_kernel(const uint32_t *ids, uint64_t n, unsigned long long *aux, uint32_t amask) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t key = ids[i];
+    if (key == 0u) continue;
+    const unsigned long long entry = ((unsigned long long)key << 32) | (uint32_t)i;
+    uint32_t h = mk_grp_mix(key) & amask;
+    for (;;) {
+      unsigned long long cur = __hip_atomic_load(&aux[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == MK_GRP_EMPTY) {
+        const unsigned long long prev = atomicCAS(&aux[h], MK_GRP_EMPTY, entry);
+        if (prev == MK_GRP_EMPTY) break;
+        cur = prev;
+      }
+      if ((uint32_t)(cur >> 32) == key) { atomicMin(&aux[h], entry); break; }
+      h = (h + 1u) & amask;
+    }
+  }
+}
+
+struct mk_pred_first { /* position i kept iff it is the first occurrence of ids[i] (and ids[i] != 0) */
+  const uint32_t *ids;
+  const unsigned long long *aux;
+  uint32_t amask;
+  __device__ __forceinline__ bool operator()(uint64_t i, uint32_t &v) const {
+    v = ids[i];
+    if (v == 0u) return false;
+    uint32_t h = mk_grp_mix(v) & amask;
+    for (;;) {
+      const unsigned long long cur = aux[h];
+      if ((uint32_t)(cur >> 32) == v && cur != MK_GRP_EMPTY) return (uint32_t)cur == (uint32_t)i;
+      h = (h + 1u) & amask;
+    }
+  }
+};
+
+struct mk_pred_slot { /* slot s kept iff occupied; value = the id whose rank it holds */
+  const uint32_t *slot, *L;
+  __device__ __forceinline__ bool operator()(uint64_t s, uint32_t &v) const {
+    const uint32_t r = slot[s];
+    if (r == 0xFFFFFFFFu) return false;
+    v = L[r];
+    return true;
+  }
+};
+
+__global__ void __launch_bounds__(256) mk_grp_layout_kernel(const uint32_t *L, uint32_t D, uint32_t *slot, uint32_t S) {
+  for (uint32_t r0 = blockIdx.x * blockDim.x + threadIdx.x; r0 < D; r0 += gridDim.x * blockDim.x) {
+    uint32_t cur = r0, key = L[cur], h1 = key % S, h2 = 1u + key % (S - 1u), x = 0;
+    while (x < S) {
+      const uint32_t y = (h1 + x * h2) % S; /* unsigned 32-bit wrap-around included, as the reference computes it */
+      uint32_t occ = __hip_atomic_load(&slot[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (occ == 0xFFFFFFFFu) {
+        occ = atomicCAS(&slot[y], 0xFFFFFFFFu, cur);
+        if (occ == 0xFFFFFFFFu) break; /* settled */
+      }
+      if (occ > cur) { /* a later first occurrence holds the slot: take it, the evicted key starts over */
+        const uint32_t prev = atomicCAS(&slot[y], occ, cur);
+        if (prev == occ) { cur = occ; key = L[cur]; h1 = key % S; h2 = 1u + key % (S - 1u); x = 0; }
+        /* else: the slot changed under us -- look at it again */
+      } else {
+        x++; /* an earlier first occurrence: walk on */
+      }
+    }
+  }
 }
 
 /* kept ids in front of each boundary position (combco.index.N -> the output's index) */
@@ -305,6 +406,7 @@ extern "C" int mk_setop_destroy(mk_setop *s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   (void)hipFree(s->d_seen); (void)hipFree(s->d_dup); (void)hipFree(s->d_chunk); (void)hipFree(s->d_chunk_off);
   (void)hipFree(s->d_total); (void)hipFree(s->d_out);
+  (void)hipFree(s->d_aux); (void)hipFree(s->d_first); (void)hipFree(s->d_slot);
   (void)hipFree(s->d_in); (void)hipFree(s->d_fcount); (void)hipFree(s->d_foff); (void)hipFree(s->d_bounds); (void)hipFree(s->d_bounds_out);
   if (s->h_total) (void)hipHostFree(s->h_total);
   if (s->h_out) (void)hipHostFree(s->h_out);
@@ -411,6 +513,8 @@ extern "C" int mk_setop_finish(mk_setop *s, const uint32_t **ids_out, uint64_t *
   return MK_OK;
 }
 
+static int mk_set_result_to_host(mk_setop *s, uint64_t total);
+
 static int mk_set_grow(mk_setop *s, void **p, uint64_t *cap, uint64_t need, size_t elem) {
   if (need <= *cap) return MK_OK;
   (void)hipFree(*p);
@@ -447,9 +551,10 @@ extern "C" int mk_setop_filter(mk_setop *s, int keep_members, const uint32_t *id
   if (n) {
     MK_SET_HIP(s, hipMemcpyAsync(s->d_in, ids, n * 4, hipMemcpyHostToDevice, s->stream));
     const unsigned blocks = (unsigned)((nchunks + 3) / 4);
-    hipLaunchKernelGGL(mk_set_fcount_kernel, dim3(blocks), dim3(256), 0, s->stream, s->d_in, n, s->d_seen, keep, nchunks, s->d_fcount);
+    const mk_pred_member pm{s->d_in, s->d_seen, keep};
+    hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_member>, dim3(blocks), dim3(256), 0, s->stream, pm, n, nchunks, s->d_fcount);
     hipLaunchKernelGGL(mk_set_scan_n_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_fcount, nchunks, s->d_foff, s->d_total);
-    hipLaunchKernelGGL(mk_set_fwrite_kernel, dim3(blocks), dim3(256), 0, s->stream, s->d_in, n, s->d_seen, keep, nchunks, s->d_fcount,
+    hipLaunchKernelGGL(mk_set_fwrite_kernel<mk_pred_member>, dim3(blocks), dim3(256), 0, s->stream, pm, n, nchunks, s->d_fcount,
                        s->d_foff, s->d_out);
     MK_SET_HIP(s, hipGetLastError());
     MK_SET_HIP(s, hipMemcpyAsync(s->h_total, s->d_total, 8, hipMemcpyDeviceToHost, s->stream));
@@ -466,6 +571,13 @@ extern "C" int mk_setop_filter(mk_setop *s, int keep_members, const uint32_t *id
     for (uint32_t j = 0; j < nb; j++) bounds_out[j] = 0;
     *s->h_total = 0;
   }
+  if ((rc = mk_set_result_to_host(s, total))) return rc;
+  *ids_out = s->h_out;
+  *n_out = total;
+  return MK_OK;
+}
+
+static int mk_set_result_to_host(mk_setop *s, uint64_t total) {
   if (total > s->h_cap) {
     if (s->h_out) (void)hipHostFree(s->h_out);
     s->h_out = nullptr; s->h_cap = 0;
@@ -477,9 +589,80 @@ extern "C" int mk_setop_filter(mk_setop *s, int keep_members, const uint32_t *id
     MK_SET_HIP(s, hipMemcpyAsync(s->h_out, s->d_out, total * 4, hipMemcpyDeviceToHost, s->stream));
     MK_SET_HIP(s, hipStreamSynchronize(s->stream));
   }
+  return MK_OK;
+}
+
+extern "C" int mk_setop_group(mk_setop *s, const uint32_t *ids, uint64_t n, uint32_t table_size, const uint32_t **ids_out,
+                              uint64_t *n_out) {
+  if (!s || !ids_out || !n_out || (n && !ids) || table_size < 3u) return MK_ERR_ARG;
+  if (n >= 0xFFFFFFFFull) return mk_set_fail(s, MK_ERR_ARG, "mk_setop_group: more than 2^32-2 ids in one taxon");
+  MK_SET_HIP(s, hipSetDevice(s->device));
+  *ids_out = s->h_out;
+  *n_out = 0;
+  if (n == 0) return MK_OK;
+  int rc;
+  uint64_t asize = 1024;
+  while (asize < 2 * n) asize <<= 1;
+  const uint64_t nchunks = (n + MK_SET_FCHUNK - 1) / MK_SET_FCHUNK, schunks = ((uint64_t)table_size + MK_SET_FCHUNK - 1) / MK_SET_FCHUNK;
+  const uint64_t maxchunks = nchunks > schunks ? nchunks : schunks;
+  if ((rc = mk_set_grow(s, (void **)&s->d_in, &s->in_cap, n, 4))) return rc;
+  if ((rc = mk_set_grow(s, (void **)&s->d_first, &s->first_cap, n, 4))) return rc;
+  if ((rc = mk_set_grow(s, (void **)&s->d_out, &s->out_cap, n, 4))) return rc;
+  if ((rc = mk_set_grow(s, (void **)&s->d_aux, &s->aux_cap, asize, 8))) return rc;
+  if ((rc = mk_set_grow(s, (void **)&s->d_slot, &s->slot_cap, table_size, 4))) return rc;
+  {
+    uint64_t c1 = s->fchunk_cap, c2 = s->fchunk_cap;
+    if ((rc = mk_set_grow(s, (void **)&s->d_fcount, &c1, maxchunks, 4))) return rc;
+    if ((rc = mk_set_grow(s, (void **)&s->d_foff, &c2, maxchunks, 8))) return rc;
+    s->fchunk_cap = c1 < c2 ? c1 : c2;
+  }
+  MK_SET_HIP(s, hipMemcpyAsync(s->d_in, ids, n * 4, hipMemcpyHostToDevice, s->stream));
+  MK_SET_HIP(s, hipMemsetAsync(s->d_aux, 0xFF, asize * 8, s->stream));
+  MK_SET_HIP(s, hipMemsetAsync(s->d_slot, 0xFF, (size_t)table_size * 4, s->stream));
+  uint64_t ib = (n + 255) / 256;
+  if (ib > (uint64_t)s->num_cu * 16) ib = (uint64_t)s->num_cu * 16;
+  hipLaunchKernelGGL(mk_grp_insert_kernel, dim3((unsigned)ib), dim3(256), 0, s->stream, s->d_in, n, s->d_aux, (uint32_t)(asize - 1));
+  /* first occurrences, in input order */
+  const mk_pred_first pf{s->d_in, s->d_aux, (uint32_t)(asize - 1)};
+  const unsigned fb = (unsigned)((nchunks + 3) / 4);
+  hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_first>, dim3(fb), dim3(256), 0, s->stream, pf, n, nchunks, s->d_fcount);
+  hipLaunchKernelGGL(mk_set_scan_n_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_fcount, nchunks, s->d_foff, s->d_total);
+  hipLaunchKernelGGL(mk_set_fwrite_kernel<mk_pred_first>, dim3(fb), dim3(256), 0, s->stream, pf, n, nchunks, s->d_fcount, s->d_foff,
+                     s->d_first);
+  MK_SET_HIP(s, hipGetLastError());
+  MK_SET_HIP(s, hipMemcpyAsync(s->h_total, s->d_total, 8, hipMemcpyDeviceToHost, s->stream));
+  MK_SET_HIP(s, hipStreamSynchronize(s->stream));
+  const uint64_t D = *s->h_total;
+  if (D) {
+    uint64_t lb = (D + 255) / 256;
+    if (lb > (uint64_t)s->num_cu * 16) lb = (uint64_t)s->num_cu * 16;
+    hipLaunchKernelGGL(mk_grp_layout_kernel, dim3((unsigned)lb), dim3(256), 0, s->stream, s->d_first, (uint32_t)D, s->d_slot, table_size);
+    const mk_pred_slot ps{s->d_slot, s->d_first};
+    const unsigned sb = (unsigned)((schunks + 3) / 4);
+    hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_slot>, dim3(sb), dim3(256), 0, s->stream, ps, (uint64_t)table_size, schunks, s->d_fcount);
+    hipLaunchKernelGGL(mk_set_scan_n_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_fcount, schunks, s->d_foff, s->d_total);
+    hipLaunchKernelGGL(mk_set_fwrite_kernel<mk_pred_slot>, dim3(sb), dim3(256), 0, s->stream, ps, (uint64_t)table_size, schunks, s->d_fcount,
+                       s->d_foff, s->d_out);
+    MK_SET_HIP(s, hipGetLastError());
+    MK_SET_HIP(s, hipMemcpyAsync(s->h_total, s->d_total, 8, hipMemcpyDeviceToHost, s->stream));
+    MK_SET_HIP(s, hipStreamSynchronize(s->stream));
+  }
+  const uint64_t total = D ? *s->h_total : 0;
+  if ((rc = mk_set_result_to_host(s, total))) return rc;
   *ids_out = s->h_out;
   *n_out = total;
   return MK_OK;
+}
+
+/* primer[LOG2(hashsize * 1.5) - 7] (command_set.c:871-872, global_basic.c:75-82): the table a taxon of `total_ids` ids gets */
+extern "C" uint32_t mk_setop_group_table_size(uint64_t total_ids) {
+  static const uint32_t primes[25] = {251u, 509u, 1021u, 2039u, 4093u, 8191u, 16381u, 32749u, 65521u, 131071u, 262139u, 524287u,
+                                      1048573u, 2097143u, 4194301u, 8388593u, 16777213u, 33554393u, 67108859u, 134217689u,
+                                      268435399u, 536870909u, 1073741789u, 2147483647u, 4294967291u};
+  const unsigned long long v = (unsigned long long)((double)(int)total_ids * 1.5); /* `int hashsize` there */
+  if (v == 0) return primes[0];
+  const unsigned ind = 63u - (unsigned)__builtin_clzll(v);
+  return ind > 7u ? primes[ind - 7u > 24u ? 24u : ind - 7u] : primes[0];
 }
 
 /* result left on the device (ascending ids), for callers that keep working there */

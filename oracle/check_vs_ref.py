@@ -377,6 +377,34 @@ def main():
     operate_case("L1K7_set_s_reads_A", "L1K7_set_u_reads_A", "L1K7_set_q_reads_n2", "-s")   # koc=1 input, uniq_pan.N as pan
     # (the cofiles.stat header is compared byte for byte here: both sides copy the reference-made directory's bytes)
 
+    # `set -g <tax.tsv>` (grouping_genomes, :831-974): both sides read the same reference-made directory; the category file
+    # follows that directory's (time-shuffled) sketch order only in the sense that line i classifies sketch i
+    def group_case(label, sk_label, tax_lines):
+        nonlocal failures
+        sk = os.path.join(work, sk_label + ".sk")
+        taxf = os.path.join(work, label + ".tsv")
+        open(taxf, "w").write("".join(t + "\n" for t in tax_lines))
+        o_ref, o_ora = os.path.join(work, label + ".refgrp"), os.path.join(work, label + ".oragrp")
+        for d in (o_ref, o_ora):
+            shutil.rmtree(d, ignore_errors=True)
+        r1 = subprocess.run([REF, "set", "-g", taxf, "-o", o_ref, sk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        r2 = subprocess.run([ORA, "set", "-g", taxf, "-o", o_ora, sk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        names = sorted(os.listdir(o_ref)) if os.path.isdir(o_ref) else []
+        ok = r1.returncode == 0 and r2.returncode == 0 and names and names == sorted(os.listdir(o_ora))
+        for f in names:
+            if f == "cofiles.stat":  # names: the reference leaves the bytes behind each NUL uninitialised
+                ok = ok and parse_stat(os.path.join(o_ref, f)) == parse_stat(os.path.join(o_ora, f))
+            else:
+                ok = ok and filecmp.cmp(os.path.join(o_ref, f), os.path.join(o_ora, f), shallow=False)
+        st = parse_stat(os.path.join(o_ref, "cofiles.stat")) if names else {}
+        print("%s %-28s ids=%s taxa=%s" % ("ok  " if ok else "FAIL", label, st.get("all_ctx"), st.get("names")))
+        failures += 0 if ok else 1
+
+    group_case("L1K7_set_g", "L1K7_set_u", ["562\tEscherichia coli", "1280", "562\tEscherichia coli", "0\tskip me"])
+    group_case("L0K6z_set_g", "L0K6z_set_u", ["5\tfive", "5\tfive", "6"])
+    group_case("L2K11_set_g", "L2K11_set_u", ["77\ta b c", "78\td", "77\ta b c", "78\td"])
+    group_case("L1K7_set_g_reads_A", "L1K7_set_u_reads_A", ["9", "9", "10\tten"])
+
     if args.big:
         fqb = os.path.join(work, "syn1p5m.fq")
         lib.mk_synth_fastq_write(fqb.encode(), 7, 0, 1500000, 150)

@@ -11,6 +11,7 @@
 #include "kssd_oracle.h"
 
 #include <errno.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -797,5 +798,181 @@ int ko_set_operate(const char *indir, const char *pandir, const char *outdir, in
     if (f) { fwrite(stat_mem, 1, stat_n, f); fclose(f); } else rc = KO_ERR_IO; /* :415-418 */
   }
   free(pos); free(post); free(stat_mem);
+  return rc;
+}
+
+
+/* ---- `set -g <file.tsv>`: organize_taxf() (command_set.c:635-705) + grouping_genomes() (:831-974) ---- */
+static const unsigned int ko_primer[25] = { /* global_basic.c:75-82 */
+  251, 509, 1021, 2039, 4093, 8191, 16381, 32749, 65521, 131071, 262139, 524287, 1048573, 2097143, 4194301, 8388593,
+  16777213, 33554393, 67108859, 134217689, 268435399, 536870909, 1073741789, 2147483647, 4294967291u};
+
+static int ko_next_prime(int n) { /* global_basic.c:453-475 */
+  for (;;) {
+    int composite = 0;
+    for (int j = 2; j <= (int)sqrt((double)n); j++)
+      if (n % j == 0) { composite = 1; break; }
+    if (!composite) return n;
+    n++;
+  }
+}
+
+/* the per-taxon table of grouping_genomes() (:874-897): ids in the given order, FCFS double hashing in 32-bit
+ * unsigned arithmetic exactly as HASH(unsigned, int, int) evaluates (global_basic.h:282-284), id 0 never stored,
+ * an id that finds no place in `table_size` probes is dropped; dump in slot order (:907-915) */
+size_t ko_group_layout(const uint32_t *ids, size_t n, uint32_t table_size, uint32_t *out) {
+  uint32_t *tab = calloc(table_size, 4);
+  if (!tab) return (size_t)-1;
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t key = ids[i];
+    for (int x = 0; x < (int)table_size; x++) {
+      const uint32_t y = (key % table_size + (uint32_t)x * (1u + key % (table_size - 1u))) % table_size;
+      if (tab[y] == 0) { tab[y] = key; break; }
+      if (tab[y] == key) break;
+    }
+  }
+  size_t m = 0;
+  for (uint32_t x = 0; x < table_size; x++)
+    if (tab[x] != 0) out[m++] = tab[x];
+  free(tab);
+  return m;
+}
+
+uint32_t ko_group_table_size(uint64_t total_ids) { /* :867-872: int hashsize; LOG2(hashsize * 1.5); primer[ind - 7] */
+  const unsigned long long v = (unsigned long long)((double)(int)total_ids * 1.5);
+  const unsigned ind = (unsigned)(63 - __builtin_clzll(v));
+  return ind > 7 ? ko_primer[ind - 7] : ko_primer[0];
+}
+
+typedef struct { int taxid; char *name; int *gids; int ng; } ko_taxon;
+
+int ko_set_group(const char *indir, const char *taxfile, const char *outdir) {
+  /* ---- organize_taxf(): line i = genome i: "<taxid>[\t<name>]"; taxa come out in the slot order of a hash of taxids ---- */
+  size_t tn = 0;
+  unsigned char *txt = ko_slurp(taxfile, &tn);
+  if (!txt) return KO_ERR_IO;
+  int ln = 0;
+  for (size_t i = 0; i < tn; i++) ln += txt[i] == '\n';
+  const int hashsz = ko_next_prime((int)((double)ln / 0.6)); /* LD_FCTR, global_basic.h:44 */
+  ko_taxon *hs = calloc((size_t)hashsz, sizeof(ko_taxon));
+  for (int i = 0; i < hashsz; i++) hs[i].taxid = -1;
+  int tax_count = 0, rc = KO_OK;
+  size_t at = 0;
+  for (int i = 0; i < ln && rc == KO_OK; i++) {
+    size_t e = at;
+    while (txt[e] != '\n') e++;
+    if (e - at + 1 >= KO_PATHLEN) { rc = KO_ERR_CONTRACT; break; } /* fgets(…,PATHLEN,…) would split the line (:657-659) */
+    txt[e] = 0;
+    char *line = (char *)txt + at;
+    at = e + 1;
+    char *tok = strtok(line, "\t");
+    if (!tok) { rc = KO_ERR_CONTRACT; break; } /* the reference dereferences NULL here */
+    const int taxid = atoi(tok);
+    char *name = strtok(NULL, "\t");
+    for (int n = 0; n < hashsz; n++) {
+      const int hv = (taxid % hashsz + n * (1 + taxid % (hashsz - 1))) % hashsz; /* HASH() in int arithmetic */
+      if (hv < 0) { rc = KO_ERR_CONTRACT; break; }
+      if (hs[hv].taxid == -1) {
+        hs[hv].taxid = taxid;
+        hs[hv].name = name ? strdup(name) : NULL;
+        hs[hv].gids = malloc(sizeof(int));
+        hs[hv].gids[0] = i;
+        hs[hv].ng = 1;
+        tax_count++;
+        break;
+      } else if (hs[hv].taxid == taxid) {
+        if ((hs[hv].name == NULL) != (name == NULL) || (name && strcmp(hs[hv].name, name) != 0)) { rc = KO_ERR_ARG; break; } /* :680-683 */
+        hs[hv].gids = realloc(hs[hv].gids, sizeof(int) * (size_t)(hs[hv].ng + 1));
+        hs[hv].gids[hs[hv].ng++] = i;
+        break;
+      }
+    }
+  }
+  free(txt);
+  ko_taxon *tax = malloc(sizeof(ko_taxon) * (size_t)(tax_count + 1));
+  int taxn = 0;
+  for (int n = 0; n < hashsz; n++)
+    if (hs[n].taxid != -1) tax[taxn++] = hs[n];
+  free(hs);
+  /* ---- grouping_genomes() ---- */
+  char path[KO_PATHLEN * 2];
+  size_t sn = 0;
+  snprintf(path, sizeof path, "%s/cofiles.stat", indir);
+  unsigned char *st = rc == KO_OK ? ko_slurp(path, &sn) : NULL;
+  if (rc == KO_OK && (!st || sn < 32)) rc = KO_ERR_IO;
+  int32_t comp_num = 0, infile_num = 0;
+  if (rc == KO_OK) {
+    memcpy(&comp_num, st + 16, 4);
+    memcpy(&infile_num, st + 20, 4);
+    if (infile_num != ln) rc = KO_ERR_ARG; /* :845-846 */
+  }
+  if (rc == KO_OK) mkdir(outdir, 0777);
+  uint32_t *ctx_ct = calloc((size_t)taxn + 1, 4);
+  size_t *outidx = malloc(sizeof(size_t) * ((size_t)taxn + 1));
+  ko_llong all_ctx_ct = 0;
+  int outfn = 0;
+  for (int c = 0; c < comp_num && rc == KO_OK; c++) {
+    size_t cb = 0, ib = 0;
+    snprintf(path, sizeof path, "%s/combco.%d", indir, c);
+    unsigned char *co = ko_slurp(path, &cb);
+    snprintf(path, sizeof path, "%s/combco.index.%d", indir, c);
+    unsigned char *idx = ko_slurp(path, &ib);
+    if (!co || !idx) { free(co); free(idx); rc = KO_ERR_IO; break; }
+    const uint32_t *ids = (const uint32_t *)co;
+    const size_t *pos = (const size_t *)idx;
+    snprintf(path, sizeof path, "%s/combco.%d", outdir, c);
+    FILE *f = fopen(path, "wb");
+    if (!f) { free(co); free(idx); rc = KO_ERR_IO; break; }
+    outfn = 0;
+    size_t offset = 0;
+    outidx[0] = 0;
+    for (int t = 0; t < taxn; t++) {
+      if (tax[t].taxid == 0) continue; /* :866, :906 */
+      size_t total = 0;
+      for (int g = 0; g < tax[t].ng; g++) total += pos[tax[t].gids[g] + 1] - pos[tax[t].gids[g]];
+      if (total == 0) { rc = KO_ERR_CONTRACT; break; } /* LOG2(0): undefined in the reference */
+      uint32_t *cat = malloc(4 * total), *out = malloc(4 * total);
+      size_t k = 0;
+      for (int g = 0; g < tax[t].ng; g++)
+        for (size_t i = pos[tax[t].gids[g]]; i < pos[tax[t].gids[g] + 1]; i++) cat[k++] = ids[i];
+      const size_t m = ko_group_layout(cat, total, ko_group_table_size(total), out);
+      fwrite(out, 4, m, f);
+      offset += m; all_ctx_ct += m; ctx_ct[outfn] += (uint32_t)m;
+      outfn++;
+      outidx[outfn] = offset;
+      free(cat); free(out);
+    }
+    fclose(f);
+    if (rc == KO_OK) {
+      snprintf(path, sizeof path, "%s/combco.index.%d", outdir, c);
+      f = fopen(path, "wb");
+      if (f) { fwrite(outidx, sizeof(size_t), (size_t)outfn + 1, f); fclose(f); } else rc = KO_ERR_IO;
+    }
+    free(co); free(idx);
+  }
+  if (rc == KO_OK) { /* :935-966: header with the new count, koc = 0, the new total; names "<taxid>_<name>" or "<taxid>" */
+    int32_t v = outfn;
+    memcpy(st + 20, &v, 4);
+    st[4] = 0;
+    memcpy(st + 24, &all_ctx_ct, 8);
+    snprintf(path, sizeof path, "%s/cofiles.stat", outdir);
+    FILE *f = fopen(path, "wb");
+    if (!f) rc = KO_ERR_IO;
+    else {
+      fwrite(st, 1, 32, f);
+      fwrite(ctx_ct, 4, (size_t)outfn, f);
+      for (int t = 0; t < taxn; t++) {
+        if (tax[t].taxid == 0) continue;
+        char name[KO_PATHLEN];
+        memset(name, 0, sizeof name); /* the reference leaves the bytes after the NUL uninitialised */
+        if (tax[t].name) snprintf(name, sizeof name, "%d_%s", tax[t].taxid, tax[t].name);
+        else snprintf(name, sizeof name, "%d", tax[t].taxid);
+        fwrite(name, 1, KO_PATHLEN, f);
+      }
+      fclose(f);
+    }
+  }
+  for (int t = 0; t < taxn; t++) { free(tax[t].name); free(tax[t].gids); }
+  free(tax); free(st); free(ctx_ct); free(outidx);
   return rc;
 }

@@ -106,6 +106,13 @@ int ko_set_stage(const char *indir, const char *outdir, int uniq, int answer_yes
  * all_ctx_ct and koc are left untouched and no .a files are written, exactly like the reference). */
 size_t ko_set_filter(const uint32_t *pan, size_t npan, int keep_members, const uint32_t *ids, size_t n, uint32_t *out);
 int ko_set_operate(const char *indir, const char *pandir, const char *outdir, int intersect);
+/* `set -g <file.tsv>`: grouping_genomes() (command_set.c:831-974) with organize_taxf() (:635-705).  Per taxon the ids of its
+ * genomes (file order) go through an FCFS double-hashing table of ko_group_table_size(total ids) slots and come out in
+ * slot order; ko_group_layout is that table (32-bit unsigned probe arithmetic, id 0 never stored, ids that find no
+ * place within table_size probes are dropped -- the table can be SMALLER than the id count, see :871). */
+size_t ko_group_layout(const uint32_t *ids, size_t n, uint32_t table_size, uint32_t *out);
+uint32_t ko_group_table_size(uint64_t total_ids);
+int ko_set_group(const char *indir, const char *taxfile, const char *outdir);
 
 #ifdef __cplusplus
 }

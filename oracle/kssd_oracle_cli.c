@@ -7,16 +7,22 @@
 
 /* kssd_oracle_cli set -u|-q [-y] [-o outdir] sketchdir   (mirrors `metakssd set`; -y answers the single-sketch prompt with Y) */
 static int set_main(int argc, char **argv) {
-  const char *out = "./", *in = NULL, *pan = NULL;
+  const char *out = "./", *in = NULL, *pan = NULL, *tax = NULL;
   int op = -1, yes = 0;
   for (int i = 0; i < argc; i++) {
     if (!strcmp(argv[i], "-u")) { if (op < 0) op = 0; }
     else if (!strcmp(argv[i], "-i") && i + 1 < argc) { if (op < 0) { op = 3; pan = argv[i + 1]; } i++; }
     else if (!strcmp(argv[i], "-s") && i + 1 < argc) { if (op < 0) { op = 2; pan = argv[i + 1]; } i++; }
+    else if (!strcmp(argv[i], "-g") && i + 1 < argc) tax = argv[++i];
     else if (!strcmp(argv[i], "-q")) { if (op < 0) op = 1; }
     else if (!strcmp(argv[i], "-y")) yes = 1;
     else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
     else in = argv[i];
+  }
+  if (op < 0 && tax && in) { /* cmd_set(): -g is looked at only when no operation was chosen (command_set.c:227-231) */
+    int rc = ko_set_group(in, tax, out);
+    if (rc) fprintf(stderr, "kssd_oracle_cli set -g: error %d\n", rc);
+    return rc ? 1 : 0;
   }
   if (op < 0 || !in) { fprintf(stderr, "usage: kssd_oracle_cli set -u|-q|-i pan|-s pan [-y] [-o outdir] sketchdir\n"); return 2; }
   int rc = op >= 2 ? ko_set_operate(in, pan, out, op == 3) : ko_set_stage(in, out, op, yes);

@@ -30,6 +30,7 @@ import util_inputs as ui  # noqa: E402
 from golden_cases import CASES, SET_CASES, SHUF_SPECS, build_input, build_set_inputs, make_shuf  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "metakssd")
+ORA = os.path.join(ROOT, "oracle", "kssd_oracle_cli")  # only to lay out sketch directories in a given order (set -g cases)
 
 
 def parse_stat(path):
@@ -81,9 +82,35 @@ def main():
     for case, c in SET_CASES.items():
         inputs = build_set_inputs(case, work, write_committed=True)
         sk, out = os.path.join(work, case + ".sk"), os.path.join(work, case + ".pan")
-        # -p 1 and files given in order: with one thread the reference keeps the given order only after its
-        # time-seeded shuffle of the file list -- the union does not depend on the order, the uniq-union neither
-        r = subprocess.run([REF, "dist", "-L", shuf_paths[c["shuf"]]] + c["flags"] + ["-p", "1", "-o", sk] + inputs,
+        if c["op"] == "-g":
+            r = subprocess.run([ORA, "-L", shuf_paths[c["shuf"]]] + c["flags"] + ["-o", sk] + inputs, cwd=work,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            taxf = os.path.join(work, case + ".tsv")
+            open(taxf, "w").write("".join(t + "\n" for t in c["tax"]))
+            r = subprocess.run([REF, "set", "-g", taxf, "-o", out, sk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            if r.returncode != 0 or not os.path.exists(os.path.join(out, "cofiles.stat")):
+                raise SystemExit("reference set -g failed on %s: %s" % (case, r.stderr.decode(errors="replace")[-300:]))
+            d = os.path.join(exp_root, case)
+            os.makedirs(d)
+            for f in sorted(os.listdir(out)):
+                if f.startswith("combco"):
+                    shutil.copy(os.path.join(out, f), os.path.join(d, f))
+            b = open(os.path.join(out, "cofiles.stat"), "rb").read()
+            st = parse_stat(os.path.join(out, "cofiles.stat"))
+            n = st["infile_num"]
+            names = [b[32 + 4 * n + 256 * i: 32 + 4 * n + 256 * (i + 1)].split(b"\0", 1)[0].decode() for i in range(n)]
+            manifest["set_cases"][case] = {
+                "shuf": c["shuf"], "flags": c["flags"], "inputs": c["inputs"], "op": "-g", "tax": c["tax"], "stat": st, "names": names,
+                "files": {f: hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest() for f in sorted(os.listdir(d))},
+                "ids": sum(os.path.getsize(os.path.join(d, f)) // 4 for f in os.listdir(d) if ".index." not in f)}
+            print("%-28s ids=%d taxa=%s" % (case, manifest["set_cases"][case]["ids"], names))
+            continue
+        # The reference's dist permutes its input list with a time-seeded shuffle (command_dist.c:215,
+        # command_shuffle.c:143): fine for -u / -q (order-free), but -i / -s write one block per sketch in directory
+        # order, so THEIR sketch directory is laid out by the pinned oracle CLI in the given order (as for -g) and only
+        # the set operation itself is the reference's.
+        dist_bin = [ORA] if "pan" in c else [REF, "dist", "-p", "1"]
+        r = subprocess.run(dist_bin + ["-L", shuf_paths[c["shuf"]]] + c["flags"] + ["-o", sk] + inputs,
                            cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         if not os.path.exists(os.path.join(sk, "cofiles.stat")):
             raise SystemExit("reference dist failed on %s: %s" % (case, r.stderr.decode(errors="replace")[-300:]))

@@ -85,6 +85,20 @@ SET_CASES = {
                            "pan": {"flags": ["-A"], "inputs": ["fq:ragged", "fq:pool"], "op": "-u"}},  # koc stays 1, no .a written
     "set_i_strains_L2K11": {"shuf": "L2K11", "flags": [], "inputs": ["fa:sA", "fa:sB", "fa:sC"], "op": "-i",
                             "pan": {"flags": [], "inputs": ["fa:sB", "fa:sC"], "op": "-u"}},  # 16 components
+    # `set -g <tax.tsv>` (grouping_genomes): line i classifies sketch i, so the sketch directory is made in the GIVEN
+    # order (the reference's dist permutes its inputs with a time seed): make_golden builds it with the pinned oracle
+    # CLI and runs the reference's `set -g` on it.  taxid 0 = left out; one taxon without a name.
+    "set_g_taxa_L1K7": {"shuf": "L1K7", "flags": [], "op": "-g",
+                        "inputs": ["fa:sA", "fa:sB", "fa:genome", "fa:sC", "fa:sB", "fa:sA"],
+                        "tax": ["562\tEscherichia coli", "28901\tSalmonella enterica", "0\tunclassified", "562\tEscherichia coli",
+                                "1280", "28901\tSalmonella enterica"]},
+    "set_g_taxa_L0K6": {"shuf": "L0K6", "flags": [], "op": "-g",
+                        "inputs": ["fa:sC", "fa:sA", "fa:sB", "fa:genome"],
+                        "tax": ["9\tnine", "7", "9\tnine", "131567\tcellular organisms"]},
+    "set_g_reads_A_L1K7": {"shuf": "L1K7", "flags": ["-A"], "op": "-g", "inputs": ["fq:pool", "fq:lowcov", "fq:ragged"],
+                           "tax": ["3\tthree", "3\tthree", "4\tfour"]},  # koc becomes 0 in the grouped directory
+    "set_g_taxa_L2K11": {"shuf": "L2K11", "flags": [], "op": "-g", "inputs": ["fa:sA", "fa:sB", "fa:sC"],
+                         "tax": ["11\televen", "12\ttwelve", "11\televen"]},  # 16 components
 }
 
 

@@ -167,7 +167,11 @@ def check_set_against_golden(case, outdir, inputs):
     assert got == want  # in particular: no combco.N.a after -i / -s even when the header says koc (command_set.c:321-425)
     for f in want:
         assert filecmp.cmp(os.path.join(exp, f), os.path.join(outdir, f), shallow=False), "%s: %s differs" % (case, f)
-    if "stat" in entry:  # -i / -s: the whole stat file of the input directory with recounted per-file sizes
+    if entry["op"] == "-g":  # grouped directory: new header, per-taxon counts, "<taxid>_<name>" names (command_set.c:929-966)
+        stat, names = parse_stat(os.path.join(outdir, "cofiles.stat"))
+        assert stat == entry["stat"] and names == entry["names"]
+        assert stat["koc"] == 0 and sum(stat["ctx_ct"]) == stat["all_ctx_ct"]
+    elif "stat" in entry:  # -i / -s: the whole stat file of the input directory with recounted per-file sizes
         stat, names = parse_stat(os.path.join(outdir, "cofiles.stat"))
         assert stat == entry["stat"] and names == inputs
         assert sum(stat["ctx_ct"]) != stat["all_ctx_ct"] or entry["ids"] == stat["all_ctx_ct"]  # header total is NOT recounted
@@ -183,6 +187,10 @@ def run_set_case(case, shuf_files, tmp_path, dist_cmd, set_cmd):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()
     op_args = [entry["op"]]
+    if entry["op"] == "-g":
+        taxf = str(tmp_path / "tax.tsv")
+        open(taxf, "w").write("".join(t + "\n" for t in entry["tax"]))
+        op_args = ["-g", taxf]
     if "pan" in entry:
         pin = gc.build_set_inputs(case, str(tmp_path), pan=True)
         psk, pdir = str(tmp_path / "psk"), str(tmp_path / "pdir")

@@ -175,3 +175,85 @@ def test_filter_empty_dictionary_and_state_errors(capi, setop):
     rc = capi.lib.mk_setop_filter(setop.h, 1, ids.ctypes.data, ids.size, None, 0, C.byref(out), C.byref(n), None)
     assert rc == capi.MK_ERR_STATE
     setop.finish_count()
+
+
+# ---- set -g: the per-taxon FCFS table of grouping_genomes() (command_set.c:866-915) ------------------------------------
+def oracle_group(ids, table_size):
+    from oracle_binding import load
+    lib = load()
+    lib.ko_group_layout.restype = C.c_size_t
+    lib.ko_group_layout.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+    ids = np.ascontiguousarray(ids, np.uint32)
+    out = np.zeros(max(1, ids.size), np.uint32)
+    m = lib.ko_group_layout(ids.ctypes.data if ids.size else None, ids.size, table_size, out.ctypes.data)
+    return out[:m]
+
+
+def product_group(capi, setop, ids, table_size):
+    lib = capi.lib
+    lib.mk_setop_group.restype = C.c_int
+    lib.mk_setop_group.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    ids = np.ascontiguousarray(ids, np.uint32)
+    out, n = C.c_void_p(), C.c_uint64(0)
+    rc = lib.mk_setop_group(setop.h, ids.ctypes.data if ids.size else None, ids.size, table_size, C.byref(out), C.byref(n))
+    assert rc == 0, lib.mk_setop_last_error(setop.h)
+    return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint32)), shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint32)
+
+
+def table_size_for(capi, n):
+    capi.lib.mk_setop_group_table_size.restype = C.c_uint32
+    capi.lib.mk_setop_group_table_size.argtypes = [C.c_uint64]
+    return capi.lib.mk_setop_group_table_size(n)
+
+
+def test_group_table_size_matches_reference_formula(capi):
+    from oracle_binding import load
+    lib = load()
+    lib.ko_group_table_size.restype = C.c_uint32
+    lib.ko_group_table_size.argtypes = [C.c_uint64]
+    for n in [1, 2, 85, 86, 170, 171, 341, 342, 1000, 1365, 1366, 43690, 43691, 10 ** 6, 10 ** 7, 3 * 10 ** 8, 14 * 10 ** 8]:
+        assert table_size_for(capi, n) == lib.ko_group_table_size(n), n
+    assert table_size_for(capi, 1000) == 2039 and table_size_for(capi, 100) == 251  # primer[LOG2(1.5 n) - 7]
+
+
+@pytest.mark.parametrize("n,dup", [(1, 1), (17, 2), (1000, 3), (1365, 1), (50000, 4), (400000, 3)])
+def test_group_layout_equals_sequential_fcfs_table(capi, setop, n, dup):
+    """a taxon of `dup` genomes sharing ids: slot-order dump of the FCFS table == the oracle's sequential insert"""
+    rs = np.random.RandomState(80 + n % 89)
+    base = rs.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    base[rs.randint(0, n, size=max(1, n // 50))] = 0                      # id 0 is never stored
+    parts = [base] + [base[rs.permutation(n)[: max(1, n // 2)]] for _ in range(dup - 1)]
+    ids = np.concatenate(parts)
+    S = table_size_for(capi, ids.size)
+    got = product_group(capi, setop, ids, S)
+    want = oracle_group(ids, S)
+    assert np.array_equal(got, want)
+    assert set(got.tolist()) == set(np.unique(ids).tolist()) - {0}
+
+
+def test_group_dense_and_overfull_tables(capi, setop):
+    """tables the reference would never choose: load 0.97, then more distinct ids than slots (ids without a place after
+    table_size probes are dropped, 32-bit probe arithmetic wraps for the long walks) -- still the sequential result"""
+    rs = np.random.RandomState(81)
+    ids = rs.randint(1, 2 ** 32, size=4000, dtype=np.uint64).astype(np.uint32)
+    for S in (4093, 2039, 1021):
+        got = product_group(capi, setop, ids, S)
+        want = oracle_group(ids, S)
+        assert np.array_equal(got, want), S
+        assert got.size == min(S, np.unique(ids).size)
+    big = rs.randint(1, 2 ** 32, size=133000, dtype=np.uint64).astype(np.uint32)
+    got = product_group(capi, setop, big, 131071)
+    assert np.array_equal(got, oracle_group(big, 131071))
+
+
+def test_group_is_independent_of_dictionary_state(capi, setop):
+    rs = np.random.RandomState(82)
+    ids = rs.randint(0, 2 ** 20, size=30000, dtype=np.uint64).astype(np.uint32)
+    S = table_size_for(capi, ids.size)
+    a = product_group(capi, setop, ids, S)
+    setop.begin(uniq=True)
+    b = product_group(capi, setop, ids, S)
+    setop.finish_count()
+    assert np.array_equal(a, b) and np.array_equal(a, oracle_group(ids, S))
+    assert product_group(capi, setop, np.zeros(0, np.uint32), 251).size == 0
+    assert product_group(capi, setop, np.zeros(5, np.uint32), 251).size == 0       # only id 0: nothing stored
