@@ -251,6 +251,16 @@ void *mk_setop_stream(mk_setop *s); /* hipStream_t the handle works on */
 int mk_setop_group(mk_setop *s, const uint32_t *ids, uint64_t n, uint32_t table_size, const uint32_t **ids_out, uint64_t *n_out);
 uint32_t mk_setop_group_table_size(uint64_t total_ids);
 
+/* ---- `metakssd composite -r <ref> -q <qry>`: the join of get_species_abundance() ----------------------
+ * command_composite.c:525-553 builds a k-mer -> position dictionary of one query sketch (one component) and, for every
+ * reference sketch, collects the query's counts (combco.N.a) of the k-mers the two share.  mk_setop_join does both for a
+ * whole reference component: counts_out = the query's count for every reference position whose id occurs in the query, in
+ * reference order; bounds / bounds_out as in mk_setop_filter (combco.index.N of the reference -> one segment of
+ * counts_out per reference sketch).  Independent of the dictionary state; result memory as for mk_setop_finish. */
+int mk_setop_join(mk_setop *s, const uint32_t *qry_ids, const uint16_t *qry_counts, uint64_t nq, const uint32_t *ref_ids,
+                  uint64_t nref, const uint64_t *bounds, uint32_t nb, const uint32_t **counts_out, uint64_t *n_out,
+                  uint64_t *bounds_out);
+
 #ifdef __cplusplus
 }
 #endif

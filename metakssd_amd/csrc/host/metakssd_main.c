@@ -311,6 +311,7 @@ static void usage(void) {
   fprintf(stderr,
           "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D] <fastq|fasta|dir>...\n"
           "       metakssd set -u|-q|-i <pan dir>|-s <pan dir>|-g <tax.tsv>|-P [-o outdir] [--device D] <sketch dir>\n"
+          "       metakssd composite -r <marker db dir> -q <-A sketch dir> [-b] [-o outdir] [--device D]\n"
           "       metakssd shuffle -k <halfK> -s <halfSubK> -l <level> [--seed N] -o <prefix>\n");
   exit(2);
 }
@@ -651,6 +652,148 @@ static int cmd_set(int argc, char **argv) {
   return 0;
 }
 
+/* ---- `metakssd composite -r <ref> -q <qry> [-b] [-o outdir]`: get_species_abundance(), command_composite.c:446-649 ----
+ * The join (query k-mer dictionary, lookup of every reference k-mer, :525-553) runs on the device, one mk_setop_join per
+ * query and component; the order statistics over each reference's handful of counts and the report stay on the host,
+ * in the reference's float arithmetic. */
+static int cmp_int_asc(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+
+static int cmd_composite(int argc, char **argv) {
+  const char *refdir = NULL, *qrydir = NULL, *outdir = "./";
+  int binvec = 0, device = 0;
+  for (int i = 0; i < argc; i++) {
+    if (!strcmp(argv[i], "-r") && i + 1 < argc) refdir = argv[++i];
+    else if (!strcmp(argv[i], "-q") && i + 1 < argc) qrydir = argv[++i];
+    else if (!strcmp(argv[i], "-o") && i + 1 < argc) outdir = argv[++i];
+    else if (!strcmp(argv[i], "-p") && i + 1 < argc) ++i;
+    else if (!strcmp(argv[i], "-b")) binvec = 1;
+    else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+    else die("composite option %s is not part of this build (-r -q -b -o are)", argv[i]);
+  }
+  if (!refdir || !qrydir || !strcmp(refdir, qrydir)) die("get_species_abundance(): refdir or qrydir is not initialized");
+  char path[PATHLEN * 3 + 64];
+  size_t rsn = 0, qsn = 0;
+  snprintf(path, sizeof path, "%s/cofiles.stat", refdir);
+  uint8_t *rst = read_whole(path, &rsn);
+  if (!rst || rsn < 32) die("cannot find cofiles.stat under %s ", refdir);
+  snprintf(path, sizeof path, "%s/cofiles.stat", qrydir);
+  uint8_t *qst = read_whole(path, &qsn);
+  if (!qst || qsn < 32) die("cannot find cofiles.stat under %s ", qrydir);
+  uint32_t ref_id, qry_id;
+  int32_t ref_n, qry_n, comp_num;
+  memcpy(&ref_id, rst, 4); memcpy(&qry_id, qst, 4);
+  memcpy(&comp_num, rst + 16, 4);
+  memcpy(&ref_n, rst + 20, 4); memcpy(&qry_n, qst + 20, 4);
+  if (!qst[4]) die("get_species_abundance(): query has not abundance");
+  if (qry_id != ref_id) printf("get_species_abundance(): qry shuf_id %u not match ref shuf_id: %u\n", qry_id, ref_id);
+  if (rsn < 32 + (size_t)ref_n * (4 + PATHLEN) || qsn < 32 + (size_t)qry_n * (4 + PATHLEN)) die("get_species_abundance(): truncated cofiles.stat");
+  const char *refname = (const char *)rst + 32 + 4 * (size_t)ref_n, *qryname = (const char *)qst + 32 + 4 * (size_t)qry_n;
+
+  mk_setop *so;
+  if (mk_setop_create(device, &so) != MK_OK) die("mk_setop_create failed: %s", mk_setop_last_error(NULL));
+  int **vals = calloc((size_t)ref_n, sizeof(int *)); /* per reference sketch: the query's counts of the shared k-mers */
+  int *nval = calloc((size_t)ref_n, sizeof(int)), *cap = calloc((size_t)ref_n, sizeof(int));
+  uint64_t *seg = malloc(8 * ((size_t)ref_n + 1));
+  int *order = malloc(sizeof(int) * (size_t)ref_n), *tmp = malloc(sizeof(int) * (size_t)ref_n);
+  struct { int ref_idx; float pct; } *vec = malloc(8 * ((size_t)ref_n + 1));
+
+  for (int q = 0; q < qry_n; q++) {
+    for (int r = 0; r < ref_n; r++) nval[r] = 0;
+    for (int c = 0; c < comp_num; c++) {
+      size_t n1, n2, n3, n4, n5;
+      snprintf(path, sizeof path, "%s/combco.%d", refdir, c);
+      uint8_t *rco = read_whole(path, &n1);
+      if (!rco) die("get_species_abundance():%s", path);
+      snprintf(path, sizeof path, "%s/combco.index.%d", refdir, c);
+      uint8_t *ridx = read_whole(path, &n2);
+      if (!ridx || n2 < 8 * ((size_t)ref_n + 1)) die("get_species_abundance():%s", path);
+      snprintf(path, sizeof path, "%s/combco.%d", qrydir, c);
+      uint8_t *qco = read_whole(path, &n3);
+      if (!qco) die("get_species_abundance():%s", path);
+      snprintf(path, sizeof path, "%s/combco.index.%d", qrydir, c);
+      uint8_t *qidx = read_whole(path, &n4);
+      if (!qidx || n4 < 8 * ((size_t)qry_n + 1)) die("get_species_abundance():%s", path);
+      snprintf(path, sizeof path, "%s/combco.%d.a", qrydir, c);
+      uint8_t *qab = read_whole(path, &n5);
+      if (!qab) die("get_species_abundance():%s", path);
+      const uint64_t *rpos = (const uint64_t *)ridx, *qpos = (const uint64_t *)qidx;
+      if (rpos[ref_n] * 4 > n1 || qpos[qry_n] * 4 > n3 || qpos[qry_n] * 2 > n5) die("get_species_abundance(): component %d is shorter than its index says", c);
+      const uint32_t *counts = NULL;
+      uint64_t m = 0;
+      if (mk_setop_join(so, (const uint32_t *)qco + qpos[q], (const uint16_t *)qab + qpos[q], qpos[q + 1] - qpos[q], (const uint32_t *)rco,
+                        rpos[ref_n], rpos, (uint32_t)ref_n + 1, &counts, &m, seg) != MK_OK)
+        die("get_species_abundance(): %s", mk_setop_last_error(so));
+      for (int r = 0; r < ref_n; r++) {
+        const int k = (int)(seg[r + 1] - seg[r]);
+        if (nval[r] + k > cap[r]) {
+          cap[r] = (nval[r] + k) * 2 + 8;
+          vals[r] = realloc(vals[r], sizeof(int) * (size_t)cap[r]);
+        }
+        for (int j = 0; j < k; j++) vals[r][nval[r] + j] = (int)counts[seg[r] + (uint64_t)j];
+        nval[r] += k;
+      }
+      free(rco); free(ridx); free(qco); free(qidx); free(qab);
+    }
+    /* references by decreasing number of shared k-mers; ties keep their index order (what glibc's merge-sort qsort gives
+     * the reference, :568-570): bottom-up merge sort */
+    for (int i = 0; i < ref_n; i++) order[i] = i;
+    for (int w = 1; w < ref_n; w *= 2) {
+      for (int lo = 0; lo < ref_n; lo += 2 * w) {
+        const int mid = lo + w < ref_n ? lo + w : ref_n, hi = lo + 2 * w < ref_n ? lo + 2 * w : ref_n;
+        int a = lo, b = mid, k = lo;
+        while (a < mid && b < hi) tmp[k++] = nval[order[b]] > nval[order[a]] ? order[b++] : order[a++];
+        while (a < mid) tmp[k++] = order[a++];
+        while (b < hi) tmp[k++] = order[b++];
+      }
+      memcpy(order, tmp, sizeof(int) * (size_t)ref_n);
+    }
+    FILE *vf = NULL;
+    if (binvec) { /* :573-581 */
+      char dir[PATHLEN * 2 + 32], qn[PATHLEN + 1];
+      if (strlen(outdir) < 3) snprintf(dir, sizeof dir, "%s/abundance_Vec", refdir);
+      else snprintf(dir, sizeof dir, "%s", outdir);
+      mkdir(dir, 0777);
+      snprintf(qn, sizeof qn, "%.*s", PATHLEN, qryname + (size_t)PATHLEN * q);
+      const char *base = strrchr(qn, '/');
+      snprintf(path, sizeof path, "%s/%s.abv", dir, base ? base + 1 : qn);
+      if (!(vf = fopen(path, "wb"))) die("get_species_abundance():%s", path);
+    }
+    int num_pass = 0;
+    float vecsum = 0;
+    for (int i = 0; i < ref_n; i++) {
+      const int r = order[i], kmer_num = nval[r];
+      if (kmer_num < 6) break; /* MIN_KM_S */
+      int *v = vals[r] - 1;    /* 1-based like the reference's ref_abund[r][1..kmer_num] */
+      qsort(vals[r], (size_t)kmer_num, sizeof(int), cmp_int_asc);
+      int sum = 0;
+      for (int n = 1; n <= kmer_num; n++) sum += v[n];
+      const int median_idx = kmer_num / 2, pct_idx = kmer_num * 0.98; /* ST_PCTL */
+      int lastsum = 0, lastn = 0;
+      for (int n = pct_idx; n <= kmer_num * 0.99; n++) { lastsum += v[n]; lastn++; } /* ED_PCTL */
+      if (binvec) {
+        if (v[median_idx] > 1 && kmer_num > 7) {
+          vec[num_pass].ref_idx = r;
+          vec[num_pass].pct = (float)lastsum / lastn;
+          vecsum += vec[num_pass].pct;
+          num_pass++;
+        }
+      } else {
+        printf("%.*s\t%.*s\t%d\t%f\t%f\t%d\t%d\n", PATHLEN, qryname + (size_t)PATHLEN * q, PATHLEN, refname + (size_t)PATHLEN * r, kmer_num,
+               (float)sum / kmer_num, (float)lastsum / lastn, v[median_idx], v[kmer_num]);
+      }
+    }
+    if (vf) {
+      for (int i = 0; i < num_pass; i++) vec[i].pct = (vec[i].pct - 1) * 100 / (vecsum - num_pass);
+      fwrite(vec, 8, (size_t)num_pass, vf);
+      fclose(vf);
+    }
+  }
+  mk_setop_destroy(so);
+  for (int r = 0; r < ref_n; r++) free(vals[r]);
+  free(vals); free(nval); free(cap); free(seg); free(order); free(tmp); free(vec); free(rst); free(qst);
+  return 0;
+}
+
 static int cmd_shuffle(int argc, char **argv) {
   int k = 8, s = 5, l = 2;
   unsigned long long seed = 1;
@@ -678,7 +821,8 @@ int main(int argc, char **argv) {
   if (argc < 2) usage();
   if (!strcmp(argv[1], "shuffle")) return cmd_shuffle(argc - 2, argv + 2);
   if (!strcmp(argv[1], "set")) return cmd_set(argc - 2, argv + 2);
-  if (strcmp(argv[1], "dist") != 0) die("only the `dist` sketching path, `set -u/-q/-i/-s/-P` and `shuffle` are part of this build (got `%s`)", argv[1]);
+  if (!strcmp(argv[1], "composite")) return cmd_composite(argc - 2, argv + 2);
+  if (strcmp(argv[1], "dist") != 0) die("only the `dist` sketching path, `set`, `composite -q` and `shuffle` are part of this build (got `%s`)", argv[1]);
 
   const char *shuf_path = NULL, *outdir = ".";
   int abundance = 0, uniq = 0, device = 0, quiet = 0, nthreads = 8;

@@ -54,6 +54,11 @@ struct mk_setop {
   uint64_t first_cap = 0;
   uint32_t *d_slot = nullptr;
   uint64_t slot_cap = 0;
+  /* mk_setop_join: the query's ids and counts */
+  uint32_t *d_qids = nullptr;
+  uint64_t qids_cap = 0;
+  uint16_t *d_qab = nullptr;
+  uint64_t qab_cap = 0;
   int mode = -1;
   bool begun = false;
   int num_cu = 256;
@@ -279,10 +284,11 @@ __device__ __forceinline__ uint32_t mk_grp_mix(uint32_t k) { /* auxiliary table 
   return k;
 }
 
-__global__ void __launch_bounds__(256) mk_grp_insert_kernel(const uint32_t *ids, uint64_t n, unsigned long long *aux, uint32_t amask) {
+__global__ void __launch_bounds__(256) mk_grp_insert_kernel(const uint32_t *ids, uint64_t n, unsigned long long *aux, uint32_t amask,
+                                                            int skip_zero) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t key = ids[i];
-    if (key == 0u) continue;
+    if (skip_zero && key == 0u) continue;
     const unsigned long long entry = ((unsigned long long)key << 32) | (uint32_t)i;
     uint32_t h = mk_grp_mix(key) & amask;
     for (;;) {
@@ -324,6 +330,25 @@ struct mk_pred_slot { /* slot s kept iff occupied; value = the id whose rank it 
   }
 };
 
+/* composite -q (command_composite.c:537-553): reference position i kept iff its id occurs among the query's ids; value =
+ * the query's count of that k-mer (of its first occurrence, which is what the reference's dictionary returns) */
+struct mk_pred_join {
+  const uint32_t *ref_ids;
+  const unsigned long long *aux; /* query id -> smallest query position */
+  uint32_t amask;
+  const uint16_t *qry_abund;
+  __device__ __forceinline__ bool operator()(uint64_t i, uint32_t &v) const {
+    const uint32_t key = ref_ids[i];
+    uint32_t h = mk_grp_mix(key) & amask;
+    for (;;) {
+      const unsigned long long cur = aux[h];
+      if (cur == MK_GRP_EMPTY) return false;
+      if ((uint32_t)(cur >> 32) == key) { v = qry_abund[(uint32_t)cur]; return true; }
+      h = (h + 1u) & amask;
+    }
+  }
+};
+
 __global__ void __launch_bounds__(256) mk_grp_layout_kernel(const uint32_t *L, uint32_t D, uint32_t *slot, uint32_t S) {
   for (uint32_t r0 = blockIdx.x * blockDim.x + threadIdx.x; r0 < D; r0 += gridDim.x * blockDim.x) {
     uint32_t cur = r0, key = L[cur], h1 = key % S, h2 = 1u + key % (S - 1u), x = 0;
@@ -345,9 +370,9 @@ __global__ void __launch_bounds__(256) mk_grp_layout_kernel(const uint32_t *L, u
   }
 }
 
-/* kept ids in front of each boundary position (combco.index.N -> the output's index) */
-__global__ void __launch_bounds__(256) mk_set_bounds_kernel(const uint32_t *ids, uint64_t n, const uint32_t *seen, uint32_t keep,
-                                                            uint64_t nchunks, const unsigned long long *chunk_off,
+/* kept entries in front of each boundary position (combco.index.N -> the output's index) */
+template <class P>
+__global__ void __launch_bounds__(256) mk_set_bounds_kernel(const P p, uint64_t n, uint64_t nchunks, const unsigned long long *chunk_off,
                                                             const unsigned long long *total, const unsigned long long *bounds,
                                                             uint32_t nb, unsigned long long *out) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,8 +382,8 @@ __global__ void __launch_bounds__(256) mk_set_bounds_kernel(const uint32_t *ids,
   const uint64_t c = b / MK_SET_FCHUNK;
   unsigned long long acc = c < nchunks ? chunk_off[c] : *total;
   for (uint64_t i = c * MK_SET_FCHUNK; i < b; i++) {
-    const uint32_t v = ids[i];
-    acc += (((seen[v >> 5] >> (v & 31u)) & 1u) == keep) ? 1u : 0u;
+    uint32_t v;
+    acc += p(i, v) ? 1u : 0u;
   }
   out[j] = acc;
 }
@@ -406,7 +431,7 @@ extern "C" int mk_setop_destroy(mk_setop *s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   (void)hipFree(s->d_seen); (void)hipFree(s->d_dup); (void)hipFree(s->d_chunk); (void)hipFree(s->d_chunk_off);
   (void)hipFree(s->d_total); (void)hipFree(s->d_out);
-  (void)hipFree(s->d_aux); (void)hipFree(s->d_first); (void)hipFree(s->d_slot);
+  (void)hipFree(s->d_aux); (void)hipFree(s->d_first); (void)hipFree(s->d_slot); (void)hipFree(s->d_qids); (void)hipFree(s->d_qab);
   (void)hipFree(s->d_in); (void)hipFree(s->d_fcount); (void)hipFree(s->d_foff); (void)hipFree(s->d_bounds); (void)hipFree(s->d_bounds_out);
   if (s->h_total) (void)hipHostFree(s->h_total);
   if (s->h_out) (void)hipHostFree(s->h_out);
@@ -560,7 +585,7 @@ extern "C" int mk_setop_filter(mk_setop *s, int keep_members, const uint32_t *id
     MK_SET_HIP(s, hipMemcpyAsync(s->h_total, s->d_total, 8, hipMemcpyDeviceToHost, s->stream));
     if (nb) {
       MK_SET_HIP(s, hipMemcpyAsync(s->d_bounds, bounds, (size_t)nb * 8, hipMemcpyHostToDevice, s->stream));
-      hipLaunchKernelGGL(mk_set_bounds_kernel, dim3((nb + 255) / 256), dim3(256), 0, s->stream, s->d_in, n, s->d_seen, keep, nchunks,
+      hipLaunchKernelGGL(mk_set_bounds_kernel<mk_pred_member>, dim3((nb + 255) / 256), dim3(256), 0, s->stream, pm, n, nchunks,
                          s->d_foff, s->d_total, s->d_bounds, nb, s->d_bounds_out);
       MK_SET_HIP(s, hipGetLastError());
       MK_SET_HIP(s, hipMemcpyAsync(bounds_out, s->d_bounds_out, (size_t)nb * 8, hipMemcpyDeviceToHost, s->stream));
@@ -621,7 +646,7 @@ extern "C" int mk_setop_group(mk_setop *s, const uint32_t *ids, uint64_t n, uint
   MK_SET_HIP(s, hipMemsetAsync(s->d_slot, 0xFF, (size_t)table_size * 4, s->stream));
   uint64_t ib = (n + 255) / 256;
   if (ib > (uint64_t)s->num_cu * 16) ib = (uint64_t)s->num_cu * 16;
-  hipLaunchKernelGGL(mk_grp_insert_kernel, dim3((unsigned)ib), dim3(256), 0, s->stream, s->d_in, n, s->d_aux, (uint32_t)(asize - 1));
+  hipLaunchKernelGGL(mk_grp_insert_kernel, dim3((unsigned)ib), dim3(256), 0, s->stream, s->d_in, n, s->d_aux, (uint32_t)(asize - 1), 1);
   /* first occurrences, in input order */
   const mk_pred_first pf{s->d_in, s->d_aux, (uint32_t)(asize - 1)};
   const unsigned fb = (unsigned)((nchunks + 3) / 4);
@@ -650,6 +675,68 @@ extern "C" int mk_setop_group(mk_setop *s, const uint32_t *ids, uint64_t n, uint
   const uint64_t total = D ? *s->h_total : 0;
   if ((rc = mk_set_result_to_host(s, total))) return rc;
   *ids_out = s->h_out;
+  *n_out = total;
+  return MK_OK;
+}
+
+extern "C" int mk_setop_join(mk_setop *s, const uint32_t *qry_ids, const uint16_t *qry_counts, uint64_t nq, const uint32_t *ref_ids,
+                             uint64_t nref, const uint64_t *bounds, uint32_t nb, const uint32_t **counts_out, uint64_t *n_out,
+                             uint64_t *bounds_out) {
+  if (!s || !counts_out || !n_out || (nq && (!qry_ids || !qry_counts)) || (nref && !ref_ids) || (nb && (!bounds || !bounds_out)))
+    return MK_ERR_ARG;
+  if (nq >= 0xFFFFFFFFull) return mk_set_fail(s, MK_ERR_ARG, "mk_setop_join: more than 2^32-2 query ids");
+  MK_SET_HIP(s, hipSetDevice(s->device));
+  *counts_out = s->h_out;
+  *n_out = 0;
+  for (uint32_t j = 0; j < nb; j++) bounds_out[j] = 0;
+  if (nq == 0 || nref == 0) return MK_OK;
+  int rc;
+  uint64_t asize = 1024;
+  while (asize < 2 * nq) asize <<= 1;
+  const uint64_t nchunks = (nref + MK_SET_FCHUNK - 1) / MK_SET_FCHUNK;
+  if ((rc = mk_set_grow(s, (void **)&s->d_qids, &s->qids_cap, nq, 4))) return rc;
+  if ((rc = mk_set_grow(s, (void **)&s->d_qab, &s->qab_cap, nq, 2))) return rc;
+  if ((rc = mk_set_grow(s, (void **)&s->d_aux, &s->aux_cap, asize, 8))) return rc;
+  if ((rc = mk_set_grow(s, (void **)&s->d_in, &s->in_cap, nref, 4))) return rc;
+  if ((rc = mk_set_grow(s, (void **)&s->d_out, &s->out_cap, nref, 4))) return rc;
+  {
+    uint64_t c1 = s->fchunk_cap, c2 = s->fchunk_cap;
+    if ((rc = mk_set_grow(s, (void **)&s->d_fcount, &c1, nchunks, 4))) return rc;
+    if ((rc = mk_set_grow(s, (void **)&s->d_foff, &c2, nchunks, 8))) return rc;
+    s->fchunk_cap = c1 < c2 ? c1 : c2;
+  }
+  {
+    uint64_t c1 = s->bounds_cap, c2 = s->bounds_cap;
+    if ((rc = mk_set_grow(s, (void **)&s->d_bounds, &c1, nb, 8))) return rc;
+    if ((rc = mk_set_grow(s, (void **)&s->d_bounds_out, &c2, nb, 8))) return rc;
+    s->bounds_cap = c1 < c2 ? c1 : c2;
+  }
+  MK_SET_HIP(s, hipMemcpyAsync(s->d_qids, qry_ids, nq * 4, hipMemcpyHostToDevice, s->stream));
+  MK_SET_HIP(s, hipMemcpyAsync(s->d_qab, qry_counts, nq * 2, hipMemcpyHostToDevice, s->stream));
+  MK_SET_HIP(s, hipMemcpyAsync(s->d_in, ref_ids, nref * 4, hipMemcpyHostToDevice, s->stream));
+  MK_SET_HIP(s, hipMemsetAsync(s->d_aux, 0xFF, asize * 8, s->stream));
+  uint64_t ib = (nq + 255) / 256;
+  if (ib > (uint64_t)s->num_cu * 16) ib = (uint64_t)s->num_cu * 16;
+  hipLaunchKernelGGL(mk_grp_insert_kernel, dim3((unsigned)ib), dim3(256), 0, s->stream, s->d_qids, nq, s->d_aux, (uint32_t)(asize - 1), 0);
+  const mk_pred_join pj{s->d_in, s->d_aux, (uint32_t)(asize - 1), s->d_qab};
+  const unsigned fb = (unsigned)((nchunks + 3) / 4);
+  hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_join>, dim3(fb), dim3(256), 0, s->stream, pj, nref, nchunks, s->d_fcount);
+  hipLaunchKernelGGL(mk_set_scan_n_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_fcount, nchunks, s->d_foff, s->d_total);
+  hipLaunchKernelGGL(mk_set_fwrite_kernel<mk_pred_join>, dim3(fb), dim3(256), 0, s->stream, pj, nref, nchunks, s->d_fcount, s->d_foff,
+                     s->d_out);
+  MK_SET_HIP(s, hipGetLastError());
+  MK_SET_HIP(s, hipMemcpyAsync(s->h_total, s->d_total, 8, hipMemcpyDeviceToHost, s->stream));
+  if (nb) {
+    MK_SET_HIP(s, hipMemcpyAsync(s->d_bounds, bounds, (size_t)nb * 8, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(mk_set_bounds_kernel<mk_pred_join>, dim3((nb + 255) / 256), dim3(256), 0, s->stream, pj, nref, nchunks, s->d_foff,
+                       s->d_total, s->d_bounds, nb, s->d_bounds_out);
+    MK_SET_HIP(s, hipGetLastError());
+    MK_SET_HIP(s, hipMemcpyAsync(bounds_out, s->d_bounds_out, (size_t)nb * 8, hipMemcpyDeviceToHost, s->stream));
+  }
+  MK_SET_HIP(s, hipStreamSynchronize(s->stream));
+  const uint64_t total = *s->h_total;
+  if ((rc = mk_set_result_to_host(s, total))) return rc;
+  *counts_out = s->h_out;
   *n_out = total;
   return MK_OK;
 }

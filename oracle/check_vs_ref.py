@@ -405,6 +405,38 @@ def main():
     group_case("L2K11_set_g", "L2K11_set_u", ["77\ta b c", "78\td", "77\ta b c", "78\td"])
     group_case("L1K7_set_g_reads_A", "L1K7_set_u_reads_A", ["9", "9", "10\tten"])
 
+    # `composite -r <db> -q <qry> [-b]` (get_species_abundance, command_composite.c:446-649): marker db from the grouped
+    # directory above by the reference's set -q / -i, queries = the three -A read sketches; stdout and .abv compared
+    def composite_case(label, grp_label, qry_label):
+        nonlocal failures
+        grp, qsk = os.path.join(work, grp_label + ".refgrp"), os.path.join(work, qry_label + ".sk")
+        uq, db = os.path.join(work, label + ".uq"), os.path.join(work, label + ".db")
+        for d in (uq, db, os.path.join(work, label + ".abv_ref"), os.path.join(work, label + ".abv_ora")):
+            shutil.rmtree(d, ignore_errors=True)
+        subprocess.run([REF, "set", "-q", "-o", uq, grp], cwd=work, input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        subprocess.run([REF, "set", "-i", uq, "-o", db, grp], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        r1 = subprocess.run([REF, "composite", "-r", db, "-q", qsk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        r2 = subprocess.run([ORA, "composite", "-r", db, "-q", qsk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        ok = r1.returncode == 0 and r2.returncode == 0 and r1.stdout == r2.stdout and len(r1.stdout) > 0
+        a_ref, a_ora = os.path.join(work, label + ".abv_ref"), os.path.join(work, label + ".abv_ora")
+        subprocess.run([REF, "composite", "-r", db, "-q", qsk, "-b", "-o", a_ref], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        subprocess.run([ORA, "composite", "-r", db, "-q", qsk, "-b", "-o", a_ora], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        names = sorted(os.listdir(a_ref)) if os.path.isdir(a_ref) else []
+        ok = ok and names and names == sorted(os.listdir(a_ora))
+        ok = ok and all(filecmp.cmp(os.path.join(a_ref, f), os.path.join(a_ora, f), shallow=False) for f in names)
+        print("%s %-28s lines=%d abv=%d" % ("ok  " if ok else "FAIL", label, len(r1.stdout.splitlines()), len(names)))
+        failures += 0 if ok else 1
+
+    # reads of fq10 / fq16 were drawn from `pool`, not from the strains: make a db whose taxa ARE those read sets' sources
+    pfa = []
+    for i, (a, b) in enumerate([(0, 30000), (20000, 60000)]):
+        pth = os.path.join(work, "poolpart%d.fa" % i)
+        write_fa(pth, [pool[a:b]])
+        pfa.append(pth)
+    run([REF, "dist", "-L", shufs["L1K7"], "-p", "1", "-o", os.path.join(work, "L1K7_pooldb.sk")] + pfa, work)
+    group_case("L1K7_pooldb", "L1K7_pooldb", ["1\tfirst", "2\tsecond"])
+    composite_case("L1K7_composite", "L1K7_pooldb", "L1K7_set_u_reads_A")
+
     if args.big:
         fqb = os.path.join(work, "syn1p5m.fq")
         lib.mk_synth_fastq_write(fqb.encode(), 7, 0, 1500000, 150)

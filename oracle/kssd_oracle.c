@@ -976,3 +976,120 @@ int ko_set_group(const char *indir, const char *taxfile, const char *outdir) {
   free(tax); free(st); free(ctx_ct); free(outidx);
   return rc;
 }
+
+
+/* ---- `composite -r <ref> -q <qry> [-b]`: get_species_abundance() (command_composite.c:446-649) ---- */
+static int ko_cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; } /* :657-659 */
+
+int ko_composite(const char *refdir, const char *qrydir, const char *outdir, int binvec, FILE *out) {
+  char path[KO_PATHLEN * 2];
+  size_t rn_bytes = 0, qn_bytes = 0;
+  snprintf(path, sizeof path, "%s/cofiles.stat", refdir);
+  unsigned char *rst = ko_slurp(path, &rn_bytes);
+  snprintf(path, sizeof path, "%s/cofiles.stat", qrydir);
+  unsigned char *qst = ko_slurp(path, &qn_bytes);
+  if (!rst || !qst || rn_bytes < 32 || qn_bytes < 32) { free(rst); free(qst); return KO_ERR_IO; }
+  int32_t ref_n, qry_n, comp_num;
+  memcpy(&ref_n, rst + 20, 4); memcpy(&qry_n, qst + 20, 4); memcpy(&comp_num, rst + 16, 4);
+  if (!qst[4]) { free(rst); free(qst); return KO_ERR_ARG; } /* :467 "query has not abundance" */
+  const char *refname = (const char *)rst + 32 + 4 * (size_t)ref_n, *qryname = (const char *)qst + 32 + 4 * (size_t)qry_n;
+  int **ab = malloc(sizeof(int *) * (size_t)ref_n); /* ab[r][0] = matches, ab[r][1..] = the query's counts of them (:491-492) */
+  size_t *cap = malloc(sizeof(size_t) * (size_t)ref_n);
+  for (int r = 0; r < ref_n; r++) { cap[r] = 8; ab[r] = malloc(sizeof(int) * 8); }
+  int rc = KO_OK;
+  for (int q = 0; q < qry_n && rc == KO_OK; q++) {
+    for (int r = 0; r < ref_n; r++) ab[r][0] = 0;
+    for (int c = 0; c < comp_num && rc == KO_OK; c++) {
+      size_t a1, a2, a3, a4, a5;
+      snprintf(path, sizeof path, "%s/combco.%d", refdir, c);
+      uint32_t *rco = (uint32_t *)ko_slurp(path, &a1);
+      snprintf(path, sizeof path, "%s/combco.index.%d", refdir, c);
+      size_t *ridx = (size_t *)ko_slurp(path, &a2);
+      snprintf(path, sizeof path, "%s/combco.%d", qrydir, c);
+      uint32_t *qco = (uint32_t *)ko_slurp(path, &a3);
+      snprintf(path, sizeof path, "%s/combco.index.%d", qrydir, c);
+      size_t *qidx = (size_t *)ko_slurp(path, &a4);
+      snprintf(path, sizeof path, "%s/combco.%d.a", qrydir, c);
+      uint16_t *qab = (uint16_t *)ko_slurp(path, &a5);
+      if (!rco || !ridx || !qco || !qidx || !qab) rc = KO_ERR_IO;
+      if (rc == KO_OK) {
+        /* :525-536: k-mer -> position dictionary of this query: double hashing in 32-bit unsigned arithmetic, no duplicate test */
+        const int hash_sz = ko_next_prime((int)((double)(qidx[q + 1] - qidx[q]) / 0.6));
+        size_t *dict = calloc((size_t)hash_sz + 1, sizeof(size_t));
+        for (size_t idx = qidx[q]; idx < qidx[q + 1]; idx++)
+          for (int i = 0; i < hash_sz; i++) {
+            const unsigned hv = (qco[idx] % (unsigned)hash_sz + (unsigned)i * (1u + qco[idx] % (unsigned)(hash_sz - 1))) % (unsigned)hash_sz;
+            if (dict[hv] == 0) { dict[hv] = idx + 1; break; }
+          }
+        for (int r = 0; r < ref_n; r++) /* :537-553 */
+          for (size_t ri = ridx[r]; ri < ridx[r + 1]; ri++)
+            for (int i = 0; i < hash_sz; i++) {
+              const unsigned hv = (rco[ri] % (unsigned)hash_sz + (unsigned)i * (1u + rco[ri] % (unsigned)(hash_sz - 1))) % (unsigned)hash_sz;
+              if (dict[hv] == 0) break;
+              if (qco[dict[hv] - 1] == rco[ri]) {
+                if ((size_t)ab[r][0] + 2 > cap[r]) { cap[r] *= 2; ab[r] = realloc(ab[r], sizeof(int) * cap[r]); }
+                ab[r][++ab[r][0]] = qab[dict[hv] - 1];
+                break;
+              }
+            }
+        free(dict);
+      }
+      free(rco); free(ridx); free(qco); free(qidx); free(qab);
+    }
+    if (rc) break;
+    /* :568-570: references by decreasing number of matches; qsort() of glibc <= 2.36 is a stable merge sort, i.e. ties
+     * stay in index order -- restated as an insertion sort with that property */
+    int *order = malloc(sizeof(int) * (size_t)ref_n);
+    for (int i = 0; i < ref_n; i++) {
+      int j = i;
+      while (j > 0 && ab[order[j - 1]][0] < ab[i][0]) { order[j] = order[j - 1]; j--; }
+      order[j] = i;
+    }
+    FILE *vf = NULL;
+    struct { int ref_idx; float pct; } *vec = malloc(8 * ((size_t)ref_n + 1));
+    int num_pass = 0;
+    float vecsum = 0;
+    if (binvec) { /* :573-581 */
+      char dir[KO_PATHLEN * 2], qn[KO_PATHLEN + 1], vpath[KO_PATHLEN * 4];
+      if (strlen(outdir) < 3) snprintf(dir, sizeof dir, "%s/abundance_Vec", refdir);
+      else snprintf(dir, sizeof dir, "%s", outdir);
+      mkdir(dir, 0777);
+      snprintf(qn, sizeof qn, "%.*s", KO_PATHLEN, qryname + (size_t)KO_PATHLEN * q);
+      const char *base = strrchr(qn, '/');
+      snprintf(vpath, sizeof vpath, "%s/%s.abv", dir, base ? base + 1 : qn);
+      vf = fopen(vpath, "wb");
+      if (!vf) rc = KO_ERR_IO;
+    }
+    for (int i = 0; i < ref_n && rc == KO_OK; i++) {
+      int *a = ab[order[i]];
+      const int kmer_num = a[0];
+      if (kmer_num < 6) break; /* MIN_KM_S */
+      qsort(a + 1, (size_t)kmer_num, sizeof(int), ko_cmp_int);
+      int sum = 0;
+      for (int n = 1; n <= kmer_num; n++) sum += a[n];
+      const int median_idx = kmer_num / 2, pct_idx = kmer_num * 0.98;
+      int lastsum = 0, lastn = 0;
+      for (int n = pct_idx; n <= kmer_num * 0.99; n++) { lastsum += a[n]; lastn++; }
+      if (binvec) {
+        if (a[median_idx] > 1 && kmer_num > 7) {
+          vec[num_pass].ref_idx = order[i];
+          vec[num_pass].pct = (float)lastsum / lastn;
+          vecsum += vec[num_pass].pct;
+          num_pass++;
+        }
+      } else {
+        fprintf(out, "%s\t%s\t%d\t%f\t%f\t%d\t%d\n", qryname + (size_t)KO_PATHLEN * q, refname + (size_t)KO_PATHLEN * order[i], kmer_num,
+                (float)sum / kmer_num, (float)lastsum / lastn, a[median_idx], a[kmer_num]);
+      }
+    }
+    if (binvec && vf) {
+      for (int i = 0; i < num_pass; i++) vec[i].pct = (vec[i].pct - 1) * 100 / (vecsum - num_pass); /* :623 */
+      fwrite(vec, 8, (size_t)num_pass, vf);
+      fclose(vf);
+    }
+    free(vec); free(order);
+  }
+  for (int r = 0; r < ref_n; r++) free(ab[r]);
+  free(ab); free(cap); free(rst); free(qst);
+  return rc;
+}

@@ -114,6 +114,13 @@ size_t ko_group_layout(const uint32_t *ids, size_t n, uint32_t table_size, uint3
 uint32_t ko_group_table_size(uint64_t total_ids);
 int ko_set_group(const char *indir, const char *taxfile, const char *outdir);
 
+/* ---- `composite -r <ref> -q <qry> [-b] [-o dir]`: get_species_abundance() (command_composite.c:446-649).
+ * For every query sketch and reference sketch: the query's counts of the k-mers they share, then per reference (by
+ * decreasing number of shared k-mers, at least 6) the line "<qry>\t<ref>\t<n>\t<mean>\t<98-99 percentile mean>\t<median>\t<max>"
+ * on `out`, or with binvec the normalised .abv vector file.  float arithmetic as in the reference. */
+#include <stdio.h>
+int ko_composite(const char *refdir, const char *qrydir, const char *outdir, int binvec, FILE *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,8 +30,25 @@ static int set_main(int argc, char **argv) {
   return rc ? 1 : 0;
 }
 
+/* kssd_oracle_cli composite -r refdir -q qrydir [-b] [-o outdir] */
+static int composite_main(int argc, char **argv) {
+  const char *ref = NULL, *qry = NULL, *out = "./";
+  int b = 0;
+  for (int i = 0; i < argc; i++) {
+    if (!strcmp(argv[i], "-r") && i + 1 < argc) ref = argv[++i];
+    else if (!strcmp(argv[i], "-q") && i + 1 < argc) qry = argv[++i];
+    else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
+    else if (!strcmp(argv[i], "-b")) b = 1;
+  }
+  if (!ref || !qry) { fprintf(stderr, "usage: kssd_oracle_cli composite -r refdir -q qrydir [-b] [-o outdir]\n"); return 2; }
+  int rc = ko_composite(ref, qry, out, b, stdout);
+  if (rc) fprintf(stderr, "kssd_oracle_cli composite: error %d\n", rc);
+  return rc ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && !strcmp(argv[1], "set")) return set_main(argc - 2, argv + 2);
+  if (argc > 1 && !strcmp(argv[1], "composite")) return composite_main(argc - 2, argv + 2);
   const char *shuf = NULL, *out = NULL;
   int A = 0, u = 0, nf = 0, Q = 0, M = 1;
   const char *files[4096];

@@ -27,7 +27,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 import util_inputs as ui  # noqa: E402
-from golden_cases import CASES, SET_CASES, SHUF_SPECS, build_input, build_set_inputs, make_shuf  # noqa: E402
+from golden_cases import (CASES, COMPOSITE_CASES, SET_CASES, SHUF_SPECS, build_composite_inputs, build_input,  # noqa: E402
+                          build_set_inputs, make_shuf)
 
 REF = os.path.join(ROOT, "oracle", "_ref", "metakssd")
 ORA = os.path.join(ROOT, "oracle", "kssd_oracle_cli")  # only to lay out sketch directories in a given order (set -g cases)
@@ -52,7 +53,8 @@ def main():
     work = tempfile.mkdtemp(prefix="golden_")
     manifest = {"shufs": {}, "cases": {}}
     shuf_paths = {}
-    for name in sorted({c["shuf"] for c in CASES.values()} | {c["shuf"] for c in SET_CASES.values()}):
+    for name in sorted({c["shuf"] for c in CASES.values()} | {c["shuf"] for c in SET_CASES.values()} |
+                       {c["shuf"] for c in COMPOSITE_CASES.values()}):
         p = os.path.join(work, name + ".shuf")
         make_shuf(name, p)
         shuf_paths[name] = p
@@ -144,6 +146,40 @@ def main():
             entry["stat"] = parse_stat(os.path.join(out, "cofiles.stat"))  # full stat file: recounted ctx_ct, old all_ctx_ct
         manifest["set_cases"][case] = entry
         print("%-28s ids=%d files=%d" % (case, entry["ids"], len(entry["files"])))
+    # ---- composite: marker database by the reference's set -g / -q / -i, then the reference's composite -q (text and -b) ----
+    manifest["composite_cases"] = {}
+    for case, c in COMPOSITE_CASES.items():
+        refs, qry = build_composite_inputs(case, work, write_committed=True)
+        sk, grp, uq, db, qsk = (os.path.join(work, case + sfx) for sfx in (".sk", ".grp", ".uq", ".db", ".qsk"))
+        taxf = os.path.join(work, case + ".tsv")
+        open(taxf, "w").write("".join(t + "\n" for t in c["tax"]))
+        steps = [[ORA, "-L", shuf_paths[c["shuf"]], "-o", sk] + refs,
+                 [REF, "set", "-g", taxf, "-o", grp, sk], [REF, "set", "-q", "-o", uq, grp], [REF, "set", "-i", uq, "-o", db, grp],
+                 [ORA, "-L", shuf_paths[c["shuf"]], "-A", "-o", qsk] + qry]
+        for cmd in steps:
+            r = subprocess.run(cmd, cwd=work, input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            if r.returncode != 0:
+                raise SystemExit("%s: step failed: %s\n%s" % (case, " ".join(cmd), r.stderr.decode(errors="replace")[-300:]))
+        r = subprocess.run([REF, "composite", "-r", db, "-q", qsk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            raise SystemExit("reference composite failed on %s" % case)
+        lines = []
+        for ln in r.stdout.decode().splitlines():
+            f = ln.split("\t")
+            f[0] = os.path.basename(f[0])  # the query's path is whatever the test's tmp dir is
+            lines.append("\t".join(f))
+        d = os.path.join(exp_root, case)
+        os.makedirs(d)
+        open(os.path.join(d, "composite.tsv"), "w").write("".join(x + "\n" for x in lines))
+        abv = os.path.join(work, case + ".abv")
+        r = subprocess.run([REF, "composite", "-r", db, "-q", qsk, "-b", "-o", abv], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        for f in sorted(os.listdir(abv)):
+            shutil.copy(os.path.join(abv, f), os.path.join(d, f))
+        manifest["composite_cases"][case] = {"shuf": c["shuf"], "refs": c["refs"], "tax": c["tax"], "query": c["query"], "lines": len(lines),
+                                             "files": sorted(os.listdir(d))}
+        print("%-28s lines=%d files=%s" % (case, len(lines), sorted(os.listdir(d))))
+        for x in lines[:3]:
+            print("    " + x)
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
     shutil.rmtree(work, ignore_errors=True)
     tot = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(HERE) for f in fs)

@@ -36,9 +36,20 @@ def _committed(name):
 
 def _seqs(kind):
     rs = np.random.RandomState({"dense": 101, "pool": 102, "ragged": 103, "homo": 0, "lowcov": 105, "qual": 106,
-                                "long": 107}[kind])
+                                "long": 107, "mix": 109, "mixs": 109}[kind])
     if kind in ("lowcov", "qual"):   # ~3x coverage of a 60 kb pool, both strands: occurrence counts spread over 1..10
         return ui.pool_reads(rs, 60000, 1200, p_n=0.0 if kind == "qual" else 0.05)
+    if kind == "mixs":               # a small version for the accept-everything table (131 071 slots)
+        return _seqs("mix")[:400]
+    if kind == "mix":                # metagenome-like reads: 70 % from strain sA, 30 % from strain sC (composite cases)
+        ga, gc_ = b"".join(_strain("sA")), b"".join(_strain("sC"))
+        out = []
+        for _ in range(4000):
+            g = ga if rs.rand() < 0.7 else gc_
+            a = rs.randint(0, len(g) - 150)
+            r = g[a:a + 150]
+            out.append(ui.revcomp(r) if rs.rand() < 0.5 else r)
+        return out
     if kind == "long":               # fastq2co()'s fgets width is 20000: reads beyond the 4096-byte row limit
         return [ui.rand_seq(rs, L) for L in (4094, 4095, 4096, 5000, 8191, 12000, 19997, 150, 0, 7000)]
     if kind == "dense":
@@ -99,6 +110,20 @@ SET_CASES = {
                            "tax": ["3\tthree", "3\tthree", "4\tfour"]},  # koc becomes 0 in the grouped directory
     "set_g_taxa_L2K11": {"shuf": "L2K11", "flags": [], "op": "-g", "inputs": ["fa:sA", "fa:sB", "fa:sC"],
                          "tax": ["11\televen", "12\ttwelve", "11\televen"]},  # 16 components
+}
+
+
+# `composite -r <markers> -q <qry>`.  The marker database is built the way the reference's README does
+# (:80-104): dist (sketch directory in the given order, laid out by the pinned oracle CLI) -> set -g tax -> set -q -> set -i;
+# the query is the -A sketch of "query".  All set steps and composite itself are run by the reference in make_golden.
+COMPOSITE_CASES = {
+    "composite_mix_L1K7": {"shuf": "L1K7", "refs": ["fa:sA", "fa:sB", "fa:sC", "fa:genome"],
+                           "tax": ["1\tstrain A", "2\tstrain B", "3\tstrain C", "4"], "query": ["fq:mix"]},
+    "composite_two_queries_L1K7": {"shuf": "L1K7", "refs": ["fa:sA", "fa:sB", "fa:sC"],
+                                   "tax": ["10\tten", "10\tten", "30\tthirty"], "query": ["fq:mix", "fq:lowcov", "fq:mixs"]},
+    "composite_small_L0K6": {"shuf": "L0K6", "refs": ["fa:sA", "fa:sC"], "tax": ["5\tfive", "6"], "query": ["fq:mixs"]},
+    "composite_mix_L2K11": {"shuf": "L2K11", "refs": ["fa:sA", "fa:sB", "fa:sC"],
+                            "tax": ["1\tA", "2\tB", "3\tC"], "query": ["fq:mix"]},  # 16 components
 }
 
 
@@ -214,3 +239,10 @@ def build_set_inputs(case, workdir, write_committed=False, pan=False):
     for i, spec in enumerate(specs):
         out.append(build_input("%s_%s%d" % (case, "pan" if pan else "in", i), workdir, write_committed=write_committed, spec=spec))
     return out
+
+
+def build_composite_inputs(case, workdir, write_committed=False):
+    c = COMPOSITE_CASES[case]
+    refs = [build_input("%s_ref%d" % (case, i), workdir, write_committed=write_committed, spec=sp) for i, sp in enumerate(c["refs"])]
+    qry = [build_input("%s_qry%d" % (case, i), workdir, write_committed=write_committed, spec=sp) for i, sp in enumerate(c["query"])]
+    return refs, qry

@@ -249,3 +249,46 @@ def test_product_cli_set_print_names_and_id_mismatch(shuf_files, tmp_path):
     assert r.returncode == 0
     r = subprocess.run([PRODUCT_CLI, "set", "-i", pan2, "-o", str(tmp_path / "x"), sk], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"sketcing id not match" in r.stderr
+
+
+# ---- composite -q: marker database by set -g / -q / -i, then the abundance report ------------------
+def run_composite_case(case, shuf_files, tmp_path, dist_cmd, set_cmd, comp_cmd):
+    entry = MANIFEST["composite_cases"][case]
+    refs, qry = gc.build_composite_inputs(case, str(tmp_path))
+    sk, grp, uq, db, qsk = (str(tmp_path / n) for n in ("sk", "grp", "uq", "db", "qsk"))
+    taxf = str(tmp_path / "tax.tsv")
+    open(taxf, "w").write("".join(t + "\n" for t in entry["tax"]))
+    for cmd in (dist_cmd + ["-L", shuf_files(entry["shuf"]), "-o", sk] + refs,
+                set_cmd + ["-g", taxf, "-o", grp, sk], set_cmd + ["-q", "-o", uq, grp], set_cmd + ["-i", uq, "-o", db, grp],
+                dist_cmd + ["-L", shuf_files(entry["shuf"]), "-A", "-o", qsk] + qry):
+        r = subprocess.run(cmd, input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, (cmd, r.stderr.decode())
+    exp = os.path.join(gc.GOLDEN, "expected", case)
+    r = subprocess.run(comp_cmd + ["-r", db, "-q", qsk], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    got = []
+    for ln in r.stdout.decode().splitlines():
+        f = ln.split("\t")
+        f[0] = os.path.basename(f[0])
+        got.append("\t".join(f))
+    assert got == open(os.path.join(exp, "composite.tsv")).read().splitlines()
+    assert len(got) == entry["lines"] and len(got) > 0
+    abv = str(tmp_path / "abv")
+    r = subprocess.run(comp_cmd + ["-r", db, "-q", qsk, "-b", "-o", abv], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    want_abv = sorted(f for f in os.listdir(exp) if f.endswith(".abv"))
+    assert sorted(os.listdir(abv)) == want_abv
+    for f in want_abv:
+        assert filecmp.cmp(os.path.join(exp, f), os.path.join(abv, f), shallow=False), f
+
+
+@pytest.mark.parametrize("case", sorted(MANIFEST["composite_cases"]))
+def test_oracle_composite_reproduces_reference_golden(case, shuf_files, tmp_path):
+    run_composite_case(case, shuf_files, tmp_path, [ORACLE_CLI], [ORACLE_CLI, "set"], [ORACLE_CLI, "composite"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(MANIFEST["composite_cases"]))
+def test_product_cli_composite_reproduces_reference_golden(case, shuf_files, tmp_path):
+    """the README's MarkerDB recipe and the profiling step, every stage on the device build"""
+    run_composite_case(case, shuf_files, tmp_path, [PRODUCT_CLI, "dist", "-p", "4"], [PRODUCT_CLI, "set"], [PRODUCT_CLI, "composite"])

@@ -257,3 +257,53 @@ def test_group_is_independent_of_dictionary_state(capi, setop):
     assert np.array_equal(a, b) and np.array_equal(a, oracle_group(ids, S))
     assert product_group(capi, setop, np.zeros(0, np.uint32), 251).size == 0
     assert product_group(capi, setop, np.zeros(5, np.uint32), 251).size == 0       # only id 0: nothing stored
+
+
+# ---- composite -q: the join of get_species_abundance() (command_composite.c:525-553) ------------------------------------
+def product_join(capi, setop, qids, qab, rids, bounds):
+    lib = capi.lib
+    lib.mk_setop_join.restype = C.c_int
+    lib.mk_setop_join.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
+                                  C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]
+    qids = np.ascontiguousarray(qids, np.uint32)
+    qab = np.ascontiguousarray(qab, np.uint16)
+    rids = np.ascontiguousarray(rids, np.uint32)
+    bounds = np.ascontiguousarray(bounds, np.uint64)
+    bout = np.zeros(bounds.size, np.uint64)
+    out, n = C.c_void_p(), C.c_uint64(0)
+    rc = lib.mk_setop_join(setop.h, qids.ctypes.data if qids.size else None, qab.ctypes.data if qab.size else None, qids.size,
+                           rids.ctypes.data if rids.size else None, rids.size, bounds.ctypes.data if bounds.size else None, bounds.size,
+                           C.byref(out), C.byref(n), bout.ctypes.data if bounds.size else None)
+    assert rc == 0, lib.mk_setop_last_error(setop.h)
+    got = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint32)), shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint32)
+    return got, bout
+
+
+@pytest.mark.parametrize("nq,nref", [(0, 100), (100, 0), (1, 1), (1000, 5000), (200000, 1500000)])
+def test_join_returns_query_counts_in_reference_order(capi, setop, nq, nref):
+    """query = distinct ids with counts (a -A sketch), reference = blocks of ids (ids may repeat across blocks): for every
+    reference position whose id is in the query, the query's count, in reference order, with the per-block boundaries"""
+    rs = np.random.RandomState(90 + nq % 83)
+    universe = np.unique(rs.randint(0, 2 ** 32, size=max(4, 2 * nq), dtype=np.uint64).astype(np.uint32))
+    if nq:
+        universe[0] = 0                                           # id 0 is an ordinary id here (the dictionary stores idx + 1)
+    qids = rs.permutation(universe)[:nq]
+    qab = rs.randint(1, 65536, size=nq).astype(np.uint16)
+    rids = universe[rs.randint(0, universe.size, size=nref)] if nref else np.zeros(0, np.uint32)
+    cuts = np.unique(np.concatenate([[0, nref], rs.randint(0, nref + 1, size=9)])).astype(np.uint64)
+    got, bout = product_join(capi, setop, qids, qab, rids, cuts)
+    lut = dict(zip(qids.tolist(), qab.tolist()))
+    hit = np.array([r in lut for r in rids.tolist()], dtype=bool) if nref else np.zeros(0, bool)
+    want = np.array([lut[r] for r in rids[hit].tolist()], dtype=np.uint32)
+    assert np.array_equal(got, want)
+    assert np.array_equal(bout, np.concatenate([[0], np.cumsum(hit)])[cuts.astype(np.int64)].astype(np.uint64))
+    if nq and nref > 1:
+        assert got.size > 0
+
+
+def test_join_duplicate_query_ids_take_the_first_occurrence(capi, setop):
+    """not produced by dist (sketch ids are distinct), but defined by the reference's dictionary: the first inserted wins"""
+    qids = np.array([7, 9, 7, 11, 9], np.uint32)
+    qab = np.array([70, 90, 71, 110, 91], np.uint16)
+    got, _ = product_join(capi, setop, qids, qab, np.array([9, 7, 5, 11, 7], np.uint32), np.zeros(0, np.uint64))
+    assert got.tolist() == [90, 70, 110, 70]
