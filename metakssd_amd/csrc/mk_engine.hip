@@ -338,11 +338,14 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
 /* ---- scan launch -------------------------------------------------------------------------------------- */
 template <int K, bool V, int T, int NP, bool OP>
 static hipError_t mk_launch_scan_t(const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
-  static size_t configured = 0;
-  if (lds > configured) {
+  /* the dynamic-LDS limit is a per-device attribute of the kernel: remember what each device was given */
+  static size_t configured[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (lds > configured[dev]) {
     hipError_t r = hipFuncSetAttribute((const void *)mk_scan_kernel<K, V, T, NP, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (r != hipSuccess) return r;
-    configured = lds;
+    configured[dev] = lds;
   }
   hipLaunchKernelGGL((mk_scan_kernel<K, V, T, NP, OP>), grid, dim3(T), lds, s, a);
   return hipGetLastError();
