@@ -193,6 +193,12 @@ int mk_fastq_frame(const uint8_t *buf, size_t n, int final, uint8_t *rows, uint3
 int mk_fastq_frame_q(const uint8_t *buf, size_t n, int final, int32_t qmin, int32_t TL, uint64_t records_before,
                      uint8_t *rows, uint32_t stride, uint64_t max_rows, uint64_t *nrows, uint64_t *nrecords,
                      size_t *consumed);
+/* mk_fastq_frame (occ == 0) or mk_fastq_frame_q (occ != 0) on `nthreads` host threads: the buffer is cut at record
+ * boundaries (every fourth line start, counted from the start of `buf`, which must be a record boundary) and the slices
+ * are framed concurrently into their places in `rows`; same rows, counts and *consumed as the serial call. */
+int mk_fastq_frame_mt(const uint8_t *buf, size_t n, int final, int occ, int32_t qmin, int32_t TL, uint64_t records_before,
+                      uint8_t *rows, uint32_t stride, uint64_t max_rows, int nthreads, uint64_t *nrows, uint64_t *nrecords,
+                      size_t *consumed);
 /* FASTA front end of fasta2co (iseq2comem.c:240-279): strips line breaks, maps headers/invalid bytes to
  * window resets and cuts the base stream into rows of `stride` bytes overlapping by TL-1 bases so that
  * every k-mer lies in exactly one row.  Call mk_fasta_window_init once per file, then feed the file in

@@ -98,6 +98,8 @@ def _load():
         "mk_fastq_frame": [vp, C.c_size_t, C.c_int, vp, u32, u64, C.POINTER(u64), C.POINTER(C.c_size_t)],
         "mk_fastq_frame_q": [vp, C.c_size_t, C.c_int, i32, i32, u64, vp, u32, u64, C.POINTER(u64), C.POINTER(u64),
                              C.POINTER(C.c_size_t)],
+        "mk_fastq_frame_mt": [vp, C.c_size_t, C.c_int, C.c_int, i32, i32, u64, vp, u32, u64, C.c_int, C.POINTER(u64), C.POINTER(u64),
+                              C.POINTER(C.c_size_t)],
         "mk_fasta_window_init": [C.POINTER(FastaStateC), i32],
         "mk_fasta_window": [C.POINTER(FastaStateC), vp, C.c_size_t, C.c_int, vp, u32, u64, C.POINTER(u64),
                             C.POINTER(C.c_size_t)],
@@ -206,6 +208,17 @@ def fastq_frame_q(buf, stride, TL, qmin=0, final=True, records_before=0, max_row
     n, nrec, used = C.c_uint64(0), C.c_uint64(0), C.c_size_t(0)
     rc = lib.mk_fastq_frame_q(b.ctypes.data if len(b) else None, len(b), 1 if final else 0, qmin, TL, records_before,
                               rows.ctypes.data, stride, max_rows, C.byref(n), C.byref(nrec), C.byref(used))
+    return rows[: n.value * stride], n.value, nrec.value, used.value, rc
+
+
+def fastq_frame_mt(buf, stride, nthreads, occ=False, TL=22, qmin=0, final=True, records_before=0, max_rows=None):
+    """the threaded framer; returns (rows, nrows, nrecords, consumed, rc)"""
+    b = np.frombuffer(buf, dtype=np.uint8)
+    max_rows = max_rows if max_rows is not None else len(b) // 4 + len(b) // max(1, stride - TL) + 2
+    rows = np.zeros(max(1, max_rows) * stride, dtype=np.uint8)
+    n, nrec, used = C.c_uint64(0), C.c_uint64(0), C.c_size_t(0)
+    rc = lib.mk_fastq_frame_mt(b.ctypes.data if len(b) else None, len(b), 1 if final else 0, 1 if occ else 0, qmin, TL, records_before,
+                               rows.ctypes.data, stride, max_rows, nthreads, C.byref(n), C.byref(nrec), C.byref(used))
     return rows[: n.value * stride], n.value, nrec.value, used.value, rc
 
 

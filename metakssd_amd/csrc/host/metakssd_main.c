@@ -22,8 +22,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
+#include <unistd.h>
 
 #define PATHLEN 256 /* global_basic.h:32 */
 
@@ -112,6 +115,7 @@ typedef struct {
   uint64_t nrows_total;
   int occ;      /* FASTQ without -A: fastq2co()'s reader (quality mask, its record rule) */
   int qmin, TL; /* -Q, k-mer length */
+  int nthreads; /* host threads for framing one big FASTQ (mk_fastq_frame_mt) */
 } ctx_t;
 
 #define CHECK(e, call)                                                  \
@@ -133,7 +137,52 @@ static FILE *open_input(const char *path, int *is_pipe) {
   return fopen(path, "rb");
 }
 
+/* an uncompressed regular file is framed straight out of its page-cache mapping: no copy into the I/O buffer (that copy,
+ * not the framing, is what bounds a single-threaded read loop), the framing threads fault the pages in concurrently */
+static int sketch_fastq_mapped(ctx_t *c, const char *path) {
+  if (is_compressed(path)) return 0;
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return 0;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) { close(fd); return 0; }
+  const size_t size = (size_t)st.st_size;
+  const uint8_t *map = mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (map == MAP_FAILED) return 0;
+  madvise((void *)map, size, MADV_SEQUENTIAL);
+  uint32_t stride = 160;
+  uint64_t records = 0;
+  size_t off = 0;
+  while (off < size) {
+    const size_t win = size - off < IOBUF ? size - off : IOBUF;
+    const int final = off + win == size;
+    uint64_t nrows = 0, nrec = 0;
+    size_t used = 0;
+    int rc = mk_fastq_frame_mt(map + off, win, final, c->occ, c->qmin, c->TL, records, c->rows, stride, ROWBUF / stride, c->nthreads,
+                               &nrows, &nrec, &used);
+    records += nrec;
+    if (nrows) {
+      CHECK(c->eng, mk_sketch_push_reads(c->eng, c->rows, stride, nrows, c->next_ordinal));
+      c->next_ordinal += nrows;
+      c->nrows_total += nrows;
+    }
+    off += used;
+    if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : stride * 2; continue; }
+    if (rc == MK_ERR_ARG || rc == MK_ERR_FORMAT)
+      die("%s: FASTQ line longer than the reference's fgets() width (%s): outside the framing contract", path,
+          c->occ ? "19998 characters, iseq2comem.c:319,343" : "4094 characters, iseq2comem.c:656,673");
+    if (rc != MK_OK) die("mk_fastq_frame failed (%d)", rc);
+    if (used == 0) {
+      if (final) break; /* trailing partial record: dropped like the reference does */
+      if (win == IOBUF) die("%s: a single FASTQ record exceeds the %zu-byte window", path, IOBUF);
+    }
+  }
+  munmap((void *)map, size);
+  return 1;
+}
+
 static void sketch_fastq(ctx_t *c, const char *path) {
+  if (sketch_fastq_mapped(c, path)) return;
   int is_pipe;
   FILE *f = open_input(path, &is_pipe);
   if (!f) die("mtfastq2koc():%s: %s", path, strerror(errno));
@@ -152,9 +201,10 @@ static void sketch_fastq(ctx_t *c, const char *path) {
       uint64_t nrows = 0;
       size_t used = 0;
       uint64_t nrec = 0;
-      int rc = c->occ ? mk_fastq_frame_q(c->io + off, have - off, eof, c->qmin, c->TL, records, c->rows, stride, ROWBUF / stride,
-                                         &nrows, &nrec, &used)
-                      : mk_fastq_frame(c->io + off, have - off, eof, c->rows, stride, ROWBUF / stride, &nrows, &used);
+      /* every call starts at a record boundary (what is left of the buffer is moved to its front), which is what the
+       * threaded framer needs */
+      int rc = mk_fastq_frame_mt(c->io + off, have - off, eof, c->occ, c->qmin, c->TL, records, c->rows, stride, ROWBUF / stride,
+                                 c->nthreads, &nrows, &nrec, &used);
       records += nrec;
       if (nrows) {
         CHECK(c->eng, mk_sketch_push_reads(c->eng, c->rows, stride, nrows, c->next_ordinal));
@@ -911,7 +961,7 @@ int main(int argc, char **argv) {
     if (fq && abundance && !quiet) printf("running mt_shortreads2koc()\n");
     if (fq && !abundance) CHECK(c.eng, mk_sketch_begin_occ(c.eng, kmerocrs)); /* command_dist.c:385-386 */
     else CHECK(c.eng, mk_sketch_begin(c.eng, fq ? MK_MODE_KOC : (uniq ? MK_MODE_UNIQ_SET : MK_MODE_SET)));
-    c.occ = fq && !abundance; c.qmin = kmerqlty; c.TL = P.TL;
+    c.occ = fq && !abundance; c.qmin = kmerqlty; c.TL = P.TL; c.nthreads = nthreads;
     int handled = 0;
     if (nworkers) {
       pthread_mutex_lock(&pf.mu);

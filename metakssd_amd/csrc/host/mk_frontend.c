@@ -11,6 +11,7 @@
 #include "metakssd_hip.h"
 #include "mk_host_internal.h"
 
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -173,6 +174,154 @@ int mk_fastq_frame_q(const uint8_t *buf, size_t n, int final, int32_t qmin, int3
   *nrecords = rec;
   *consumed = (size_t)(p - buf);
   return rc;
+}
+
+/* ---- the same two framers on several threads -----------------------------------------------------------------------
+ * Records are groups of four lines counted from the start of the buffer (which the caller keeps at a record boundary),
+ * whatever the lines contain -- exactly what the serial framers (and the reference's 4x fgets) do.  So: count the
+ * newlines of T slices in parallel, prefix the counts, cut the buffer at the line starts whose index is a multiple of
+ * four, and let every thread run the SERIAL framer over its own whole records, writing at the row index its first
+ * record has.  The tail behind the last complete record goes through the serial framer with the caller's `final`. */
+typedef struct {
+  const uint8_t *buf;
+  size_t lo, hi;        /* phase 1: slice; phase 2: whole records [lo, hi) */
+  uint64_t lines;       /* phase 1 out */
+  int occ, qmin, TL;    /* phase 2 in */
+  uint64_t records_before;
+  uint8_t *rows;
+  uint32_t stride;
+  uint64_t want_rows;   /* records in [lo, hi) */
+  int rc;
+  uint64_t nrows, nrec;
+  size_t used;
+} mk_frame_job;
+
+static void *mk_count_lines(void *arg) {
+  mk_frame_job *j = arg;
+  uint64_t c = 0;
+  const uint8_t *p = j->buf + j->lo, *end = j->buf + j->hi;
+  while (p < end) {
+    const uint8_t *nl = memchr(p, '\n', (size_t)(end - p));
+    if (!nl) break;
+    c++;
+    p = nl + 1;
+  }
+  j->lines = c;
+  return NULL;
+}
+
+static void *mk_frame_slice(void *arg) {
+  mk_frame_job *j = arg;
+  if (j->occ)
+    j->rc = mk_fastq_frame_q(j->buf + j->lo, j->hi - j->lo, 0, j->qmin, j->TL, j->records_before, j->rows, j->stride, j->want_rows,
+                             &j->nrows, &j->nrec, &j->used);
+  else {
+    j->rc = mk_fastq_frame(j->buf + j->lo, j->hi - j->lo, 0, j->rows, j->stride, j->want_rows, &j->nrows, &j->used);
+    j->nrec = j->nrows;
+  }
+  return NULL;
+}
+
+/* byte offset of the start of line number `k` (0-based, counted from `from`, which is a line start) */
+static size_t mk_skip_lines(const uint8_t *buf, size_t from, size_t n, uint64_t k) {
+  size_t at = from;
+  while (k--) {
+    const uint8_t *nl = memchr(buf + at, '\n', n - at);
+    if (!nl) return n;
+    at = (size_t)(nl - buf) + 1;
+  }
+  return at;
+}
+
+int mk_fastq_frame_mt(const uint8_t *buf, size_t n, int final, int occ, int32_t qmin, int32_t TL, uint64_t records_before,
+                      uint8_t *rows, uint32_t stride, uint64_t max_rows, int nthreads, uint64_t *nrows, uint64_t *nrecords,
+                      size_t *consumed) {
+  if ((!buf && n) || !rows || !nrows || !nrecords || !consumed) return MK_ERR_ARG;
+  enum { MAXT = 64 };
+  int T = nthreads < 1 ? 1 : nthreads > MAXT ? MAXT : nthreads;
+  if (n < ((size_t)1 << 20)) T = 1; /* not worth the threads */
+  *nrows = *nrecords = 0;
+  *consumed = 0;
+  uint64_t done_rows = 0, done_rec = 0;
+  size_t at = 0;
+  if (T > 1) {
+    mk_frame_job job[MAXT];
+    pthread_t th[MAXT];
+    memset(job, 0, sizeof job);
+    for (int t = 0; t < T; t++) { job[t].buf = buf; job[t].lo = n / (size_t)T * (size_t)t; job[t].hi = t + 1 == T ? n : n / (size_t)T * (size_t)(t + 1); }
+    for (int t = 1; t < T; t++) pthread_create(&th[t], NULL, mk_count_lines, &job[t]);
+    mk_count_lines(&job[0]);
+    for (int t = 1; t < T; t++) pthread_join(th[t], NULL);
+    /* cut points: for every slice the first record boundary (line start whose index is a multiple of four) at or behind
+     * its first byte; they come out in non-decreasing order, duplicates are dropped */
+    size_t cut[MAXT + 1];
+    uint64_t cutline[MAXT + 1];
+    uint64_t before = 0; /* newlines in front of slice t */
+    int nc = 0;
+    for (int t = 0; t < T; t++) {
+      size_t ls = job[t].lo;
+      uint64_t idx = before;
+      before += job[t].lines;
+      if (t > 0 && buf[ls - 1] != '\n') { /* slice starts inside a line: the next line start */
+        const uint8_t *nl = memchr(buf + ls, '\n', n - ls);
+        if (!nl) continue;
+        ls = (size_t)(nl - buf) + 1;
+        idx++;
+      }
+      const uint64_t skip = (4u - (idx & 3u)) & 3u;
+      const size_t c = mk_skip_lines(buf, ls, n, skip);
+      if (c >= n) continue;
+      if (nc && c <= cut[nc - 1]) continue;
+      cut[nc] = c; cutline[nc] = idx + skip; nc++;
+    }
+    const uint64_t total_lines = before;
+    uint64_t R = total_lines / 4u; /* complete records in the buffer */
+    if (R > max_rows) R = max_rows;
+    /* a read longer than the row is cut into several rows in the occ flavour at the maximal stride: rows != records there,
+     * so such buffers stay serial */
+    if (nc >= 2 && cut[0] == 0 && R >= (uint64_t)nc && !(occ && stride == 4096u)) {
+      int last = nc - 1;
+      while (last > 0 && cutline[last] >= 4u * R) last--;
+      const size_t endcut = mk_skip_lines(buf, cut[last], n, 4u * R - cutline[last]); /* start of line 4R */
+      int J = 0;
+      for (int i = 0; i <= last; i++) {
+        const size_t hi = i == last ? endcut : cut[i + 1];
+        const uint64_t hiline = i == last ? 4u * R : cutline[i + 1];
+        mk_frame_job *j = &job[J++];
+        memset(j, 0, sizeof *j);
+        j->buf = buf; j->lo = cut[i]; j->hi = hi; j->occ = occ; j->qmin = qmin; j->TL = TL;
+        j->records_before = records_before + cutline[i] / 4u;
+        j->rows = rows + (cutline[i] / 4u) * (uint64_t)stride; j->stride = stride;
+        j->want_rows = (hiline - cutline[i]) / 4u;
+      }
+      for (int t = 1; t < J; t++) pthread_create(&th[t], NULL, mk_frame_slice, &job[t]);
+      mk_frame_slice(&job[0]);
+      for (int t = 1; t < J; t++) pthread_join(th[t], NULL);
+      for (int t = 0; t < J; t++) {
+        if (job[t].rc != MK_OK) return job[t].rc; /* MK_ERR_ARG: widen the rows and call again; nothing reported as consumed */
+        if (job[t].nrows != job[t].want_rows || job[t].used != job[t].hi - job[t].lo) return MK_ERR_FORMAT; /* cannot happen */
+      }
+      done_rows = done_rec = R;
+      at = endcut;
+    }
+  }
+  /* the rest (everything when not split): serial, with the caller's `final` */
+  if (at < n || n == 0) {
+    uint64_t r = 0, rec = 0;
+    size_t used = 0;
+    int rc;
+    if (occ) rc = mk_fastq_frame_q(buf + at, n - at, final, qmin, TL, records_before + done_rec, rows + done_rows * (uint64_t)stride, stride,
+                                   max_rows - done_rows, &r, &rec, &used);
+    else { rc = mk_fastq_frame(buf + at, n - at, final, rows + done_rows * (uint64_t)stride, stride, max_rows - done_rows, &r, &used); rec = r; }
+    if (rc != MK_OK && done_rows == 0) { *nrows = r; *nrecords = rec; *consumed = used; return rc; }
+    if (rc == MK_OK || r) { done_rows += r; done_rec += rec; at += used; }
+    if (rc != MK_OK && rc != MK_ERR_ARG) return rc;
+    /* MK_ERR_ARG after some parallel progress: report the progress; the caller comes back with the remainder */
+  }
+  *nrows = done_rows;
+  *nrecords = done_rec;
+  *consumed = at;
+  return MK_OK;
 }
 
 int mk_fasta_window_init(mk_fasta_state *st, int32_t TL) {

@@ -213,6 +213,68 @@ def test_fastq_frame_q_streams_in_chunks_and_widens(capi):
     assert capi.fastq_frame_q(ui.fastq_bytes([b"A" * 19999]), 4096, 14)[4] == capi.MK_ERR_FORMAT
 
 
+@pytest.mark.parametrize("variant", ["plain", "ragged", "crlf", "trunc", "nonl", "long_headers"])
+@pytest.mark.parametrize("occ", [False, True])
+def test_threaded_framing_equals_serial(capi, variant, occ):
+    """mk_fastq_frame_mt cuts the buffer at every fourth line start and frames the slices concurrently: same rows, counts and
+    consumed bytes as the serial framers, for any thread count"""
+    rs = np.random.RandomState(11)
+    if variant == "plain":
+        seqs = [ui.rand_seq(rs, 150) for _ in range(9000)]
+    elif variant == "long_headers":
+        seqs = [ui.rand_seq(rs, 40) for _ in range(20000)]
+    else:
+        seqs = ui.ragged_reads(rs, 12000)
+    quals = ui.random_quals(rs, seqs) if occ else None
+    data = ui.fastq_bytes(seqs, crlf=variant == "crlf", final_newline=variant != "nonl", drop_last_qual=variant == "trunc", quals=quals)
+    if variant == "long_headers":  # header lines much longer than the reads: slices start in the middle of long lines
+        data = data.replace(b"@r", b"@" + b"x" * 700 + b"r")
+    assert len(data) > (1 << 20)
+    stride = 304
+    if occ:
+        want = capi.fastq_frame_q(data, stride, 14, qmin=54)
+        want = (want[0], want[1], want[2], want[3], want[4])
+    else:
+        r = capi.fastq_frame(data, stride)
+        want = (r[0], r[1], r[1], r[2], r[3])
+    assert want[4] == 0
+    for T in (1, 2, 3, 8, 17):
+        got = capi.fastq_frame_mt(data, stride, T, occ=occ, TL=14, qmin=54)
+        assert got[4] == 0 and got[1:4] == want[1:4], T
+        assert np.array_equal(got[0], want[0]), T
+    # not the last chunk of a stream: stops at the last complete record, like the serial call
+    cutoff = len(data) - 777
+    if occ:
+        w2 = capi.fastq_frame_q(data[:cutoff], stride, 14, qmin=54, final=False)
+        w2 = (w2[0], w2[1], w2[2], w2[3], w2[4])
+    else:
+        r = capi.fastq_frame(data[:cutoff], stride, final=False)
+        w2 = (r[0], r[1], r[1], r[2], r[3])
+    g2 = capi.fastq_frame_mt(data[:cutoff], stride, 5, occ=occ, TL=14, qmin=54, final=False)
+    assert g2[4] == 0 and g2[1:4] == w2[1:4] and np.array_equal(g2[0], w2[0])
+    # fewer row slots than records: the first max_rows records, consumed up to there
+    g3 = capi.fastq_frame_mt(data, stride, 4, occ=occ, TL=14, qmin=54, max_rows=5000)
+    assert g3[4] == 0 and g3[1] == 5000 and np.array_equal(g3[0], want[0][: 5000 * stride])
+    g4 = capi.fastq_frame_mt(data[g3[3]:], stride, 4, occ=occ, TL=14, qmin=54, records_before=g3[2])
+    assert g4[4] == 0 and g3[1] + g4[1] == want[1] and np.array_equal(np.concatenate([g3[0], g4[0]]), want[0])
+
+
+def test_threaded_framing_reports_narrow_rows_and_long_lines(capi):
+    rs = np.random.RandomState(12)
+    seqs = [ui.rand_seq(rs, 150) for _ in range(8000)]
+    seqs[5000] = ui.rand_seq(rs, 600)
+    data = ui.fastq_bytes(seqs)
+    assert capi.fastq_frame_mt(data, 304, 6)[4] == capi.MK_ERR_ARG          # caller widens the rows and calls again
+    r = capi.fastq_frame_mt(data, 1024, 6)
+    assert r[4] == 0 and r[1] == 8000 and np.array_equal(r[0], capi.fastq_frame(data, 1024)[0])
+    seqs[5000] = ui.rand_seq(rs, 4100)
+    assert capi.fastq_frame_mt(ui.fastq_bytes(seqs), 4096, 6)[4] == capi.MK_ERR_FORMAT
+    # occ flavour at the maximal stride windows long reads (rows != records): the threaded call falls back to one thread
+    r = capi.fastq_frame_mt(ui.fastq_bytes(seqs), 4096, 6, occ=True, TL=14)
+    w = capi.fastq_frame_q(ui.fastq_bytes(seqs), 4096, 14)
+    assert r[4] == 0 and r[1] == w[1] == 8001 and r[2] == 8000 and np.array_equal(r[0], w[0])
+
+
 @pytest.mark.parametrize("stride,chunk", [(64, None), (256, 100), (4096, 7)])
 def test_fasta_windows_cover_every_kmer_once(capi, stride, chunk):
     """rows overlap by TL-1 bases: concatenating row payloads minus the overlaps gives back the cleaned stream"""
