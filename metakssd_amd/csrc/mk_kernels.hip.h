@@ -569,39 +569,33 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                * issued speculatively) measured 4 % slower */
               if (!__all(bad == 0u) && !common_newline()) { have_pair = true; break; }
               const uint32_t fstart = flo;
+              /* the eight codes of the pair packed big-endian into the top 16 bits of `lo` (one v_dot4_u32_u8 per dword:
+               * weights 64,16,4,1; one v_perm_b32 to place the two bytes): the low word after base j is then ONE funnel
+               * shift of {fstart, lo} -- no eight-long dependent roll chain */
+              const uint32_t lo = __builtin_amdgcn_perm(__builtin_amdgcn_udot4(c0, 0x01041040u, 0u, false),
+                                                        __builtin_amdgcn_udot4(c1, 0x01041040u, 0u, false), 0x04000C0Cu);
               if (urun + 8u < TL) { /* nobody completes a k-mer in this pair: roll only */
-                flo = (flo << 2) | mk_code_of<0>(w0);
-                flo = (flo << 2) | mk_code_of<1>(w0);
-                flo = (flo << 2) | mk_code_of<2>(w0);
-                flo = (flo << 2) | mk_code_of<3>(w0);
-                flo = (flo << 2) | mk_code_of<0>(w1);
-                flo = (flo << 2) | mk_code_of<1>(w1);
-                flo = (flo << 2) | mk_code_of<2>(w1);
-                flo = (flo << 2) | mk_code_of<3>(w1);
+                flo = __builtin_amdgcn_alignbit(fstart, lo, 16);
                 oh_init();
               } else {
                 uint32_t f0, f1, f2, f3, f4, f5, f6, f7, m0, m1, m2, m3, m4, m5, m6, m7, d0, d1, d2, d3, d4, d5, d6, d7;
+                f0 = __builtin_amdgcn_alignbit(fstart, lo, 30); f1 = __builtin_amdgcn_alignbit(fstart, lo, 28);
+                f2 = __builtin_amdgcn_alignbit(fstart, lo, 26); f3 = __builtin_amdgcn_alignbit(fstart, lo, 24);
+                f4 = __builtin_amdgcn_alignbit(fstart, lo, 22); f5 = __builtin_amdgcn_alignbit(fstart, lo, 20);
+                f6 = __builtin_amdgcn_alignbit(fstart, lo, 18); f7 = __builtin_amdgcn_alignbit(fstart, lo, 16);
                 /* Filter fields at offsets 0, 2, 6 of the substring x_j: because x_{j-1} = x_j >> 2, the three bits of
                  * base j are the one-hot words of the low 5 bits of x_j, x_{j-1} and x_{j-3} -- one new one-hot per
-                 * base, the other two are carried (across pairs too: oh1..oh3). */
-                auto probe = [&](uint32_t code, uint32_t &fl, uint32_t &m, uint32_t &wd) {
-                  wd = *(mk_lds_cu32)(uintptr_t)((flo >> (SH + 8u)) & 0xFFFCu);
-                  const uint32_t oh = mk_onehot_at<SH>(flo);
+                 * base, the other two are carried (across pairs too: oh1..oh3).  The substring of base j sits in the
+                 * low word BEFORE base j is rolled in. */
+                auto probe = [&](uint32_t before, uint32_t &m, uint32_t &wd) {
+                  wd = *(mk_lds_cu32)(uintptr_t)((before >> (SH + 8u)) & 0xFFFCu);
+                  const uint32_t oh = mk_onehot_at<SH>(before);
                   m = oh | oh1 | oh3;
                   oh3 = oh2; oh2 = oh1; oh1 = oh;
-                  flo = (flo << 2) | code;
-                  fl = flo;
                 };
-                /* code j straight from the raw dword with one v_bfe_u32 (left to itself the compiler shifts, then
-                 * uses v_and_or_b32) */
-                probe(mk_code_of<0>(w0), f0, m0, d0);
-                probe(mk_code_of<1>(w0), f1, m1, d1);
-                probe(mk_code_of<2>(w0), f2, m2, d2);
-                probe(mk_code_of<3>(w0), f3, m3, d3);
-                probe(mk_code_of<0>(w1), f4, m4, d4);
-                probe(mk_code_of<1>(w1), f5, m5, d5);
-                probe(mk_code_of<2>(w1), f6, m6, d6);
-                probe(mk_code_of<3>(w1), f7, m7, d7);
+                probe(fstart, m0, d0); probe(f0, m1, d1); probe(f1, m2, d2); probe(f2, m3, d3);
+                probe(f3, m4, d4); probe(f4, m5, d5); probe(f5, m6, d6); probe(f6, m7, d7);
+                flo = f7;
                 __builtin_amdgcn_sched_barrier(0); /* all eight probes in flight before the first result is read */
 #ifndef MK_NO_SINGLE_WAIT
                 __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) once, instead of a staggered wait per probe */
@@ -610,12 +604,12 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                  * test, a single hit about six. */
                 const uint32_t t0 = m0 & ~d0, t1 = m1 & ~d1, t2 = m2 & ~d2, t3 = m3 & ~d3;
                 const uint32_t t4 = m4 & ~d4, t5 = m5 & ~d5, t6 = m6 & ~d6, t7 = m7 & ~d7;
-                const uint32_t t01 = min(t0, t1), t23 = min(t2, t3), t45 = min(t4, t5), t67 = min(t6, t7);
-                const uint32_t ta = min(t01, t23), tb = min(t45, t67);
+                /* groups of 3, 3, 2: v_min3_u32 */
+                const uint32_t ta = min(min(t0, t1), t2), tb = min(min(t3, t4), t5), tc = min(t6, t7);
 #if defined(MK_ABLATE) && MK_ABLATE == 3
-                if (__any(min(ta, tb) == 0xffffffffu)) {
+                if (__any(min(min(ta, tb), tc) == 0xffffffffu)) {
 #else
-                if (__any(min(ta, tb) == 0u)) {
+                if (__any(min(min(ta, tb), tc) == 0u)) {
 #endif
                   const uint32_t pos0 = col0 + 8u * p;
                   const uint32_t jmin = urun + 1u >= TL ? 0u : TL - 1u - urun; /* first base with a complete k-mer */
@@ -627,14 +621,9 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                     const uint32_t fhi = ((h3 << dd) | ((h2 & 0xFFFFu) >> (16u - dd))) & HM;
                     push(t == 0u, ((uint64_t)fhi << 32) | fl, pos0 + j);
                   };
-                  if (__any(ta == 0u)) {
-                    if (__any(t01 == 0u)) { hit(t0, f0, 0); hit(t1, f1, 1); }
-                    if (__any(t23 == 0u)) { hit(t2, f2, 2); hit(t3, f3, 3); }
-                  }
-                  if (__any(tb == 0u)) {
-                    if (__any(t45 == 0u)) { hit(t4, f4, 4); hit(t5, f5, 5); }
-                    if (__any(t67 == 0u)) { hit(t6, f6, 6); hit(t7, f7, 7); }
-                  }
+                  if (__any(ta == 0u)) { hit(t0, f0, 0); hit(t1, f1, 1); hit(t2, f2, 2); }
+                  if (__any(tb == 0u)) { hit(t3, f3, 3); hit(t4, f4, 4); hit(t5, f5, 5); }
+                  if (__any(tc == 0u)) { hit(t6, f6, 6); hit(t7, f7, 7); }
                 }
               }
               h3 = h2; h2 = fstart;
