@@ -510,7 +510,10 @@ static int mk_compact(mk_engine *e) {
   const int drop0 = e->mode == MK_MODE_SET || e->mode == MK_MODE_UNIQ_SET;
   /* fastq2co() tests `keycount > hashlimit` but never advances keycount (:404): only a full table stops it */
   const uint64_t limit = e->mode == MK_MODE_OCC_SET ? (uint64_t)e->kp.S - 1 : (uint64_t)e->P.hashlimit;
-  const unsigned blocks = (unsigned)(e->num_cu * 2);
+#ifndef MK_COMPACT_BLOCKS_PER_CU
+#define MK_COMPACT_BLOCKS_PER_CU 2
+#endif
+  const unsigned blocks = (unsigned)(e->num_cu * MK_COMPACT_BLOCKS_PER_CU);
   hipLaunchKernelGGL(mk_compact_kernel, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
                      e->d_counters, drop0);
   MK_HIP(e, hipGetLastError());

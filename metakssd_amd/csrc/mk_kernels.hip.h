@@ -707,7 +707,9 @@ struct mk_dist {
 /* Each wave owns MK_COMPACT_CHUNK consecutive slots (all loads of the chunk in flight together), a workgroup of
  * 16 waves owns 16 consecutive chunks and reserves its output range with ONE atomicAdd (same-address atomics
  * serialise at ~90 per microsecond on this chip, so there must be few of them). */
+#ifndef MK_COMPACT_CHUNK
 #define MK_COMPACT_CHUNK 2048u
+#endif
 #define MK_COMPACT_THREADS 1024
 __global__ void __launch_bounds__(MK_COMPACT_THREADS) mk_compact_kernel(mk_table tab, uint32_t S, mk_dist out,
                                                                         unsigned long long *counter, int drop_key0) {

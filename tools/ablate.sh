@@ -14,7 +14,7 @@ for v in "${VS[@]}"; do
     cp /tmp/lib_orig.so ../lib/libmetakssd_hip.so
   fi
   cd $GRAFT_REPO_ROOT
-  python bench.py --steps 4 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('variant [$v] scan_ms', round(d['roofline']['avg_launch_ms'],3), 'resolve', round(d['phases_ms_per_step']['resolve'],3), 'Gb/s', round(d['value'],1), 'distinct', d['config']['distinct_keys'])"
+  python bench.py --steps 4 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('variant [$v] scan_ms', round(d['roofline']['avg_launch_ms'],3), 'resolve', round(d['phases_ms_per_step']['resolve'],3), 'finish', round(d['phases_ms_per_step']['finish'],3), 'Gb/s', round(d['value'],1), 'distinct', d['config']['distinct_keys'])"
   cd metakssd_amd/csrc
 done
 cp /tmp/lib_orig.so ../lib/libmetakssd_hip.so
