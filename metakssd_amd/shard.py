@@ -46,3 +46,56 @@ def gather_partials(keys, counts, ords, n, dst=0, group=None):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return out
+
+
+# ---- config 5: whole input files are the unit -- no reduction, only a gather in file order -----------
+def shard_files(nfiles, rank, world):
+    """indices of the files `rank` sketches: contiguous blocks, so that rank order == file order"""
+    lo, hi = shard_range(nfiles, rank, world)
+    return list(range(lo, hi))
+
+
+def gather_file_sketches(mine, ncomp, dst=0, group=None, device=None):
+    """mine: list of per-file sketches of this rank, each a list over components of uint32 numpy arrays (ids).
+    Returns on `dst` the list of ALL files' sketches in rank order (= file order with shard_files); [] elsewhere.
+    One exchange: all_gather of the per-file, per-component lengths, then one id buffer per sending rank."""
+    import numpy as np
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device or torch.device("cpu")
+    lens = np.array([[len(c) for c in f] for f in mine], dtype=np.int64).reshape(-1, ncomp)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([lens.shape[0]], dtype=torch.int64, device=dev), group=group)
+    counts = [int(c.item()) for c in counts]
+    maxf = max(counts) if counts else 0
+    pad = torch.zeros(max(1, maxf) * ncomp, dtype=torch.int64, device=dev)
+    pad[: lens.size] = torch.from_numpy(lens.reshape(-1)).to(dev)
+    all_lens = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(all_lens, pad, group=group)
+    flat = np.concatenate([c for f in mine for c in f]).astype(np.uint32) if lens.size and lens.sum() else np.zeros(0, np.uint32)
+    ops, bufs = [], {}
+    if rank == dst:
+        for r in range(world):
+            n = int(all_lens[r][: counts[r] * ncomp].sum().item())
+            if r != dst and n:
+                bufs[r] = torch.empty(n, dtype=torch.int32, device=dev)
+                ops.append(dist.P2POp(dist.irecv, bufs[r], r, group))
+    elif flat.size:
+        ops.append(dist.P2POp(dist.isend, torch.from_numpy(flat.view(np.int32).copy()).to(dev), dst, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank != dst:
+        return []
+    out = []
+    for r in range(world):
+        data = flat if r == dst else (bufs[r].cpu().numpy().view(np.uint32) if r in bufs else np.zeros(0, np.uint32))
+        ll = all_lens[r][: counts[r] * ncomp].cpu().numpy().reshape(-1, ncomp)
+        at = 0
+        for f in range(counts[r]):
+            comps = []
+            for c in range(ncomp):
+                comps.append(data[at: at + int(ll[f, c])].copy())
+                at += int(ll[f, c])
+            out.append(comps)
+    return out

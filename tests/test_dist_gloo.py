@@ -20,6 +20,20 @@ def test_sharded_sketch_merge_over_gloo(world, tmp_path):
     assert open(result).read().startswith("OK")
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_file_sharded_sketches_gather_in_file_order_over_gloo(world, tmp_path):
+    """config 5: whole files are the unit, no reduction: rank 0 receives every file's per-component id
+    arrays in file order"""
+    result = str(tmp_path / "result.txt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MK_DIST_RESULT=result)
+    port = 31500 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_files_worker.py")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    assert open(result).read() == "OK"
+
+
 def test_shard_ranges_cover_and_order():
     sys.path.insert(0, ROOT)
     from metakssd_amd.shard import shard_range

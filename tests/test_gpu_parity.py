@@ -440,3 +440,38 @@ def test_fastq_set_shard_merge(capi, shufs, oracle_for):
     rc, want = oracle_for(shuf).co_from_fastq(data, Q=0, M=3)
     assert rc == 0 and len(want[0][0]) > 0
     assert_same(merged, want)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_genome_directory_sharded_by_file_equals_cli(capi, shufs, tmp_path, world):
+    """config 5's multi-GPU shape: files sharded across ranks (here 2 ranks on the one GPU, lists through gloo),
+    per-file sketches gathered in file order: the sketch directory is byte-identical to the single-process CLI's"""
+    import filecmp
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rs = np.random.RandomState(71)
+    gd = tmp_path / "genomes"
+    gd.mkdir()
+    for i, n in enumerate((30000, 9000, 52000, 700, 21000)):
+        g = ui.rand_seq(rs, n)
+        (gd / ("g%d.%s" % (i, ("fa", "fna", "fasta")[i % 3]))).write_bytes(ui.fasta_bytes([g[: n // 3], g[n // 3:]], width=60 + i))
+    sp = str(tmp_path / "L1K7.shuf")
+    shufs("L1K7").write(sp)
+    out_cli, out_multi = str(tmp_path / "cli"), str(tmp_path / "multi")
+    r = subprocess.run([os.path.join(root, "metakssd_amd", "bin", "metakssd"), "dist", "-L", sp, "-o", out_cli, str(gd)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    tool = os.path.join(root, "tools", "dist_genomes_multi.py")
+    if world == 1:
+        cmd = [sys.executable, tool, "-L", sp, "-o", out_multi, str(gd)]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(32500 + os.getpid() % 2000), tool, "-L", sp, "-o", out_multi, "--backend", "gloo", "--same-device", str(gd)]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    names = sorted(os.listdir(out_cli))
+    assert names == sorted(os.listdir(out_multi)) and "cofiles.stat" in names
+    for f in names:
+        assert filecmp.cmp(os.path.join(out_cli, f), os.path.join(out_multi, f), shallow=False), f
