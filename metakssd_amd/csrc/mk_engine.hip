@@ -39,6 +39,11 @@ struct mk_engine {
 
   void *d_tab = nullptr; /* kc[S] | ordinv[S] */
   size_t tab_bytes = 0;
+  /* sparse bookkeeping (large tables): dirty-block bitmaps of the accumulation and the layout table, the lists made of
+   * them, and whether both tables are known to be all-empty outside the marked blocks */
+  bool sparse = false, tables_tracked = false;
+  uint32_t *d_dirty_acc = nullptr, *d_dirty_slot = nullptr, *d_list_acc = nullptr, *d_list_slot = nullptr, *d_nlist = nullptr;
+  uint32_t acc_words = 0, slot_words = 0, acc_blocks = 0;
   mk_table tab{};
   uint32_t *d_slot = nullptr;
   mk_dist dist{};
@@ -126,6 +131,7 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipDeviceSynchronize();
   hipFree(e->d_cand_fwd); hipFree(e->d_cand_ord); hipFree(e->d_cand_count);
   hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_accept_bits); hipFree(e->d_tab); hipFree(e->d_slot);
+  hipFree(e->d_dirty_acc); hipFree(e->d_dirty_slot); hipFree(e->d_list_acc); hipFree(e->d_list_slot); hipFree(e->d_nlist);
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters);
   if (e->h_comp_totals) hipHostFree(e->h_comp_totals); hipFree(e->d_out_ids); hipFree(e->d_out_cnt);
@@ -205,6 +211,23 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   e->tab.kc = (unsigned long long *)e->d_tab;
   e->tab.ordinv = e->tab.kc + S;
   MK_HIP(e, hipMalloc(&e->d_slot, S * sizeof(uint32_t)));
+  /* sparse bookkeeping from 2^26 slots up (L2K11: 537 M slots for a genome's few thousand keys); MK_SPARSE=0/1 forces it
+   * off/on (the tests run the small tables both ways) */
+  e->sparse = S >= (1ull << 26);
+  if (const char *t = getenv("MK_SPARSE")) e->sparse = atoi(t) != 0;
+  if (e->sparse) {
+    e->acc_blocks = (uint32_t)((S + MK_SPARSE_BLOCK - 1) / MK_SPARSE_BLOCK);
+    e->acc_words = (e->acc_blocks + 31u) / 32u;
+    const uint32_t nch = (uint32_t)((S + MK_DUMP_CHUNK - 1) / MK_DUMP_CHUNK);
+    e->slot_words = (nch + 31u) / 32u;
+    MK_HIP(e, hipMalloc(&e->d_dirty_acc, (size_t)e->acc_words * 4));
+    MK_HIP(e, hipMalloc(&e->d_dirty_slot, (size_t)e->slot_words * 4));
+    MK_HIP(e, hipMalloc(&e->d_list_acc, (size_t)e->acc_words * 32 * 4));
+    MK_HIP(e, hipMalloc(&e->d_list_slot, (size_t)e->slot_words * 32 * 4));
+    MK_HIP(e, hipMalloc(&e->d_nlist, 4 * sizeof(uint32_t)));
+    e->tab.dirty = e->d_dirty_acc;
+    e->tab.dirty_shift = MK_SPARSE_SHIFT;
+  }
   e->dist.cap = S; /* hashlimit+1 entries suffice for KOC/SET; MK_MODE_OCC_SET may fill the table (fastq2co never aborts) */
   MK_HIP(e, hipMalloc(&e->dist.key, e->dist.cap * 8));
   MK_HIP(e, hipMalloc(&e->dist.ord, e->dist.cap * 8));
@@ -324,7 +347,23 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   /* the table clear the reference does with memset(co,0,..) (iseq2comem.c:223,663) */
-  MK_HIP(e, hipMemsetAsync(e->d_tab, 0, e->tab_bytes, e->stream));
+  if (e->sparse && e->tables_tracked) {
+    /* both tables are empty except in the blocks the last sketch marked: clear those, and the marks */
+    hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_acc, e->acc_words, e->d_list_acc, e->d_nlist, 1);
+    hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_slot, e->slot_words, e->d_list_slot, e->d_nlist + 1, 1);
+    hipLaunchKernelGGL(mk_dirty_clear_kernel, dim3((unsigned)e->num_cu * 8u), dim3(256), 0, e->stream, e->tab.kc, e->tab.ordinv, e->kp.S,
+                       (const uint32_t *)e->d_list_acc, (const uint32_t *)e->d_nlist, (uint32_t)MK_SPARSE_SHIFT, e->d_slot,
+                       (const uint32_t *)e->d_list_slot, (const uint32_t *)(e->d_nlist + 1), (uint32_t)MK_DUMP_SHIFT);
+    MK_HIP(e, hipGetLastError());
+  } else {
+    MK_HIP(e, hipMemsetAsync(e->d_tab, 0, e->tab_bytes, e->stream));
+    if (e->sparse) {
+      MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)e->kp.S * sizeof(uint32_t), e->stream));
+      MK_HIP(e, hipMemsetAsync(e->d_dirty_acc, 0, (size_t)e->acc_words * 4, e->stream));
+      MK_HIP(e, hipMemsetAsync(e->d_dirty_slot, 0, (size_t)e->slot_words * 4, e->stream));
+      e->tables_tracked = true;
+    }
+  }
   MK_HIP(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->stream));
   if (e->profiling) { MK_HIP(e, hipEventRecord(ev.b, e->stream)); e->ev_clear.push_back(ev); }
   e->mode = mode;
@@ -514,8 +553,14 @@ static int mk_compact(mk_engine *e) {
 #define MK_COMPACT_BLOCKS_PER_CU 2
 #endif
   const unsigned blocks = (unsigned)(e->num_cu * MK_COMPACT_BLOCKS_PER_CU);
-  hipLaunchKernelGGL(mk_compact_kernel, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
-                     e->d_counters, drop0);
+  if (e->sparse) { /* only the blocks somebody installed a key in */
+    hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_acc, e->acc_words, e->d_list_acc, e->d_nlist + 2, 0);
+    hipLaunchKernelGGL(mk_compact_kernel<MK_SPARSE_BLOCK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
+                       e->d_counters, drop0, (const uint32_t *)e->d_list_acc, (const uint32_t *)(e->d_nlist + 2));
+  } else {
+    hipLaunchKernelGGL(mk_compact_kernel<MK_COMPACT_CHUNK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
+                       e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+  }
   MK_HIP(e, hipGetLastError());
   MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
   MK_HIP(e, hipStreamSynchronize(e->stream));
@@ -607,14 +652,16 @@ extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
 
   uint64_t total = 0;
   if (D > 0) {
-    MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), e->stream));
+    if (!e->sparse) MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), e->stream)); /* sparse: kept empty by begin */
     uint64_t lb = (D + 255) / 256;
     if (lb > (uint64_t)e->num_cu * 16) lb = (uint64_t)e->num_cu * 16;
-    hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)lb), dim3(256), 0, e->stream, e->dist, D, e->d_slot, S, e->tab.err);
+    hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)lb), dim3(256), 0, e->stream, e->dist, D, e->d_slot, S, e->tab.err,
+                       e->sparse ? e->d_dirty_slot : nullptr, (uint32_t)MK_DUMP_SHIFT);
     MK_HIP(e, hipGetLastError());
 
     mk_dump_args da{};
     da.slot = e->d_slot; da.S = S; da.d = e->dist;
+    da.dirty_slot = e->sparse ? e->d_dirty_slot : nullptr;
     da.comp_num = (uint32_t)C; da.comp_code_bits = (uint32_t)e->P.comp_code_bits;
     da.cnt_lo = e->mode == MK_MODE_OCC_SET ? e->min_occ : 1u; /* write_fqco2file(): marked keys only (iseq2comem.c:611) */
     da.cnt_hi = e->mode == MK_MODE_UNIQ_SET ? 1u : 0xffffffffu;  /* uniq_fasta2co(): repeated keys dropped */

@@ -41,6 +41,11 @@ struct mk_table {
   unsigned long long *kc;     /* key << 24 | occurrences (>= 1), 0 = empty   [S]  (keys are < 2^39) */
   unsigned long long *ordinv; /* ~(first ordinal), max-combined              [S] */
   uint32_t *err;              /* [0] = table-full flag */
+  /* Large tables (S >= 2^26, e.g. L2K11's 537 M slots for a genome's few thousand keys): one bit per block of
+   * 1 << dirty_shift slots, set by whoever installs a key, so that clearing, compaction and the dump touch only the
+   * blocks that were used.  NULL = dense bookkeeping (every pass walks all S slots). */
+  uint32_t *dirty;
+  uint32_t dirty_shift;
 };
 
 struct mk_scan_args {
@@ -115,6 +120,10 @@ __device__ __forceinline__ void mk_upsert(const mk_table &tab, uint32_t S, uint6
     if (mine || (cur >> MK_CNT_BITS) == key) {
       if (!mine && (cur & MK_CNT_MASK) < MK_CNT_SAT) atomicAdd(&tab.kc[n], (unsigned long long)add);
       atomicMax(&tab.ordinv[n], ~(unsigned long long)ord);
+      if (mine && tab.dirty) { /* the only place a slot ever becomes non-zero */
+        const uint32_t b = n >> tab.dirty_shift;
+        atomicOr(&tab.dirty[b >> 5], 1u << (b & 31u));
+      }
       return;
     }
     n = mk_probe_next(n, h2, S);
@@ -704,6 +713,48 @@ struct mk_dist {
   uint64_t cap;
 };
 
+/* ---- sparse bookkeeping for large tables --------------------------------------------------------------------------
+ * mk_dirty_list_kernel: bitmap -> list of set block indices (any order), one workgroup.
+ * mk_dirty_clear_kernel: re-establishes "all empty" on the listed blocks of the accumulation table (zero) and, with the
+ * second list, of the layout table (0xFFFFFFFF). */
+__global__ void __launch_bounds__(1024) mk_dirty_list_kernel(uint32_t *bitmap, uint32_t nwords, uint32_t *list, uint32_t *count,
+                                                            int clear_bitmap) {
+  __shared__ uint32_t base_s;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (uint32_t w0 = 0; w0 < nwords; w0 += 1024u) {
+    const uint32_t w = w0 + threadIdx.x;
+    uint32_t bits = w < nwords ? bitmap[w] : 0u;
+    if (bits && clear_bitmap) bitmap[w] = 0u;
+    uint32_t off = bits ? atomicAdd(&base_s, (uint32_t)__popc(bits)) : 0u;
+    while (bits) {
+      list[off++] = (w << 5) + (uint32_t)__builtin_ctz(bits);
+      bits &= bits - 1u;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *count = base_s;
+}
+
+__global__ void __launch_bounds__(256) mk_dirty_clear_kernel(unsigned long long *kc, unsigned long long *ordinv, uint32_t S,
+                                                             const uint32_t *list, const uint32_t *nlist, uint32_t shift,
+                                                             uint32_t *slot, const uint32_t *slist, const uint32_t *nslist,
+                                                             uint32_t sshift) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  const uint32_t n = *nlist, ns = slot ? *nslist : 0u;
+  for (uint64_t i = wave; i < n; i += nwaves) {
+    const uint64_t b0 = (uint64_t)list[i] << shift;
+    for (uint32_t k = lane; k < (1u << shift); k += 64u)
+      if (b0 + k < S) { kc[b0 + k] = 0ull; ordinv[b0 + k] = 0ull; }
+  }
+  for (uint64_t i = wave; i < ns; i += nwaves) {
+    const uint64_t b0 = (uint64_t)slist[i] << sshift;
+    for (uint32_t k = lane; k < (1u << sshift); k += 64u)
+      if (b0 + k < S) slot[b0 + k] = MK_EMPTY32;
+  }
+}
+
 /* Each wave owns MK_COMPACT_CHUNK consecutive slots (all loads of the chunk in flight together), a workgroup of
  * 16 waves owns 16 consecutive chunks and reserves its output range with ONE atomicAdd (same-address atomics
  * serialise at ~90 per microsecond on this chip, so there must be few of them). */
@@ -711,15 +762,21 @@ struct mk_dist {
 #define MK_COMPACT_CHUNK 2048u
 #endif
 #define MK_COMPACT_THREADS 1024
+/* CHUNK slots per wave.  Dense: the chunks tile the table.  Sparse (list != NULL): chunk i is the dirty block list[i]
+ * (CHUNK == block size), *nlist of them. */
+template <uint32_t CHUNK>
 __global__ void __launch_bounds__(MK_COMPACT_THREADS) mk_compact_kernel(mk_table tab, uint32_t S, mk_dist out,
-                                                                        unsigned long long *counter, int drop_key0) {
+                                                                        unsigned long long *counter, int drop_key0,
+                                                                        const uint32_t *list, const uint32_t *nlist) {
   __shared__ uint32_t wtotal[MK_COMPACT_THREADS / 64];
   __shared__ unsigned long long block_base;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  constexpr uint32_t WAVES = MK_COMPACT_THREADS / 64, ITER = MK_COMPACT_CHUNK / 64u;
-  const uint64_t nblockchunks = ((uint64_t)S + (uint64_t)MK_COMPACT_CHUNK * WAVES - 1) / ((uint64_t)MK_COMPACT_CHUNK * WAVES);
+  constexpr uint32_t WAVES = MK_COMPACT_THREADS / 64, ITER = CHUNK / 64u;
+  const uint64_t nchunks = list ? (uint64_t)*nlist : ((uint64_t)S + CHUNK - 1) / CHUNK;
+  const uint64_t nblockchunks = (nchunks + WAVES - 1) / WAVES;
   for (uint64_t bc = blockIdx.x; bc < nblockchunks; bc += gridDim.x) {
-    const uint64_t base_slot = (bc * WAVES + wave) * MK_COMPACT_CHUNK;
+    const uint64_t ci = bc * WAVES + wave;
+    const uint64_t base_slot = ci < nchunks ? (list ? (uint64_t)list[ci] : ci) * CHUNK : (uint64_t)S;
     unsigned long long kc[ITER];
 #pragma unroll
     for (uint32_t it = 0; it < ITER; it++) {
@@ -768,7 +825,8 @@ __global__ void __launch_bounds__(MK_COMPACT_THREADS) mk_compact_kernel(mk_table
  * Sequential FCFS insertion puts key K in the first slot of its probe sequence that no EARLIER key holds.
  * That fixed point is unique, so it can be reached in any order: a walking key takes a slot from a later
  * occupant and the evicted key resumes from the start of its own sequence. */
-__global__ void __launch_bounds__(256) mk_layout_kernel(mk_dist d, uint64_t D, uint32_t *slot, uint32_t S, uint32_t *err) {
+__global__ void __launch_bounds__(256) mk_layout_kernel(mk_dist d, uint64_t D, uint32_t *slot, uint32_t S, uint32_t *err,
+                                                        uint32_t *dirty_slot, uint32_t dirty_slot_shift) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += (uint64_t)gridDim.x * blockDim.x) {
     uint32_t cur = (uint32_t)i;
     unsigned long long ord = d.ord[cur];
@@ -789,7 +847,13 @@ __global__ void __launch_bounds__(256) mk_layout_kernel(mk_dist d, uint64_t D, u
       }
       const uint32_t prev = atomicCAS(&slot[n], old, cur);
       if (prev != old) { old = prev; continue; } /* somebody else changed the slot: judge the real occupant */
-      if (old == MK_EMPTY32) break;              /* took an empty slot: done */
+      if (old == MK_EMPTY32) {                   /* took an empty slot: done */
+        if (dirty_slot) {
+          const uint32_t b = n >> dirty_slot_shift;
+          atomicOr(&dirty_slot[b >> 5], 1u << (b & 31u));
+        }
+        break;
+      }
       cur = old; /* evicted a later key: re-walk its own sequence (everything before this slot is held by earlier keys) */
       ord = d.ord[cur];
       mk_probe_init(d.key[cur], S, n, h2);
@@ -801,6 +865,9 @@ __global__ void __launch_bounds__(256) mk_layout_kernel(mk_dist d, uint64_t D, u
 /* ---- slot-order dump, one component at a time ----------------------------------------------------------
  * each wave owns a contiguous chunk of MK_DUMP_CHUNK slots */
 #define MK_DUMP_CHUNK 4096u
+#define MK_DUMP_SHIFT 12u
+#define MK_SPARSE_SHIFT 9u                    /* accumulation-table blocks of 512 slots (8 KiB of kc) */
+#define MK_SPARSE_BLOCK (1u << MK_SPARSE_SHIFT)
 
 struct mk_dump_args {
   const uint32_t *slot;
@@ -808,6 +875,7 @@ struct mk_dump_args {
   mk_dist d;
   uint32_t comp_num, comp, comp_code_bits;
   uint32_t cnt_lo, cnt_hi; /* keep keys whose (clamped) count lies in [cnt_lo, cnt_hi] */
+  const uint32_t *dirty_slot; /* sparse bookkeeping: one bit per MK_DUMP_CHUNK slots of the layout table, NULL = all chunks */
   uint32_t nchunks;
 };
 
@@ -826,6 +894,10 @@ __global__ void __launch_bounds__(256) mk_dump_count_kernel(mk_dump_args a, uint
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (chunk >= a.nchunks) return;
+  if (a.dirty_slot && !((a.dirty_slot[chunk >> 5] >> (chunk & 31u)) & 1u)) { /* untouched chunk of a large table */
+    if (lane == 0) chunk_count[chunk] = 0u;
+    return;
+  }
   uint32_t total = 0;
   for (uint32_t it = 0; it < MK_DUMP_CHUNK / 64u; it++) {
     uint32_t idx;
@@ -868,6 +940,7 @@ __global__ void __launch_bounds__(256) mk_dump_write_kernel(mk_dump_args a, cons
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (chunk >= a.nchunks) return;
+  if (a.dirty_slot && !((a.dirty_slot[chunk >> 5] >> (chunk & 31u)) & 1u)) return;
   uint32_t off = chunk_off[chunk];
   for (uint32_t it = 0; it < MK_DUMP_CHUNK / 64u; it++) {
     uint32_t idx;
@@ -901,6 +974,10 @@ __global__ void __launch_bounds__(256) mk_dumpc_count_kernel(mk_dump_args a, uin
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (chunk >= a.nchunks) return;
+  if (a.dirty_slot && !((a.dirty_slot[chunk >> 5] >> (chunk & 31u)) & 1u)) {
+    if (lane < a.comp_num) chunk_count[(size_t)lane * a.nchunks + chunk] = 0u;
+    return;
+  }
   uint32_t mine = 0; /* lane c (< comp_num) accumulates component c */
   for (uint32_t it = 0; it < MK_DUMP_CHUNK / 64u; it++) {
     uint32_t idx, comp;
@@ -953,6 +1030,7 @@ __global__ void __launch_bounds__(256) mk_dumpc_write_kernel(mk_dump_args a, con
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (chunk >= a.nchunks) return;
+  if (a.dirty_slot && !((a.dirty_slot[chunk >> 5] >> (chunk & 31u)) & 1u)) return; /* wave-uniform */
   if (lane < a.comp_num) {
     unsigned long long start = 0;
     for (uint32_t c = 0; c < lane; c++) start += totals[c];
