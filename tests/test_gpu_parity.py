@@ -475,3 +475,39 @@ def test_genome_directory_sharded_by_file_equals_cli(capi, shufs, tmp_path, worl
     assert names == sorted(os.listdir(out_multi)) and "cofiles.stat" in names
     for f in names:
         assert filecmp.cmp(os.path.join(out_cli, f), os.path.join(out_multi, f), shallow=False), f
+
+
+@pytest.mark.parametrize("name", ["L0K6", "L1K7", "L0K6z"])
+def test_sparse_bookkeeping_over_a_sequence_of_sketches(capi, shufs, oracle_for, monkeypatch, name):
+    """tables of 2^26+ slots track which blocks were touched and clear / compact / dump only those (mk_table::dirty);
+    MK_SPARSE=1 forces that on a small dense table, where one engine then runs sketches of very different sizes and
+    flavours back to back -- every one must equal the oracle, i.e. nothing of an earlier sketch may survive a clear"""
+    monkeypatch.setenv("MK_SPARSE", "1")
+    eng = capi.Engine(shufs(name), 0)
+    monkeypatch.delenv("MK_SPARSE")
+    ora = oracle_for(shufs(name))
+    rs = np.random.RandomState(91)
+    try:
+        for step, nreads in enumerate([300, 3, 0, 450, 1, 200]):
+            seqs = ui.pool_reads(rs, 30000, nreads) if nreads else []
+            rows = ui.rows_from_seqs(seqs, 160) if nreads else np.zeros(0, np.uint8)
+            got = run_koc(capi, eng, rows, 160, pushes=1 + step % 3)
+            rc, want = ora.koc_from_rows(rows, 160) if nreads else (0, [(np.zeros(0, np.uint32), np.zeros(0, np.uint16))])
+            assert rc == 0
+            assert_same(got, want, "%s step %d" % (name, step))
+            if step == 1:  # a crowded sketch in between: error, then the engine must still come back clean
+                big = capi.synth_rows_host(5, 0, 30000 if name == "L1K7" else 5000, 150, 160)  # L1K7 accepts 1 k-mer in 16
+                eng.begin(capi.MK_MODE_KOC)
+                eng.push_reads(big, 160, 0)
+                with pytest.raises(capi.CrowdedError):
+                    eng.finish()
+            if step == 3:  # a FASTA set sketch on the same engine
+                fa = ui.fasta_bytes([ui.rand_seq(rs, 9000), ui.rand_seq(rs, 4000)])
+                eng.begin(capi.MK_MODE_SET)
+                eng.push_reads(capi.fasta_windows(fa, 2 * shufs(name).c.k, 256), 256, 0)
+                got = eng.finish()
+                rc, want = ora.co_from_fasta(fa)
+                assert rc == 0
+                assert_same(got, want, "%s fasta" % name)
+    finally:
+        eng.close()
