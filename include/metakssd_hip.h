@@ -23,6 +23,10 @@
  *   write_fqco2file()            iseq2comem.c:596-621     }
  *   err(errno,"...too crowd")    iseq2comem.c:708-709        MK_ERR_CROWDED (never exit() in here)
  *   -- (no counterpart: single process) --                   mk_partial_count/export/import (multi-GPU merge)
+ *   sketch_union()/uniq_sketch_union() dictionaries  command_set.c:279-316,466-509   mk_setop_begin/add/finish
+ *   sketch_operate() membership filter               command_set.c:361-405           mk_setop_filter
+ *   grouping_genomes() per-taxon table               command_set.c:866-915           mk_setop_group
+ *   get_species_abundance() dictionary + lookups     command_composite.c:525-553     mk_setop_join
  *
  * Conventions: plain pointers and sizes only; every function returns MK_OK (0) or a negative
  * MK_ERR_* code and never calls exit(); mk_last_error() gives the text.  One engine per GPU;

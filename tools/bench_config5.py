@@ -31,7 +31,7 @@ for name, (k, s, l, seed) in {"L3K10": (10, 6, 3, 10), "L2K11": (11, 5, 2, 211)}
     sp = os.path.join(d, name + ".shuf"); capi.Shuf.generate(k, s, l, seed).write(sp)
     for rep in range(2):
         t0 = time.perf_counter()
-        subprocess.check_call([cli, "dist", "-L", sp, "-o", os.path.join(d, "out_%s_%d" % (name, rep)), "--quiet", gd])
+        subprocess.check_call([cli, "dist", "-L", sp, "-p", os.environ.get("THREADS", "8"), "-o", os.path.join(d, "out_%s_%d" % (name, rep)), "--quiet", gd])
         dt = time.perf_counter() - t0
         print("%s product CLI rep %d: %.2f s for %d genomes = %.1f genomes/s, %.2f Gbases/s" % (name, rep, dt, G, G / dt, G * MB / 1e3 / dt))
     if os.path.exists(ref):
