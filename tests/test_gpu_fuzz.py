@@ -1,0 +1,18 @@
+"""a slice of tools/fuzz_parity.py in the GPU suite: random geometries, flavours, strides, pushes and dirty reads, engine vs
+oracle bit for bit (the tool itself has been run over thousands of cases per seed; see its docstring)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed,sparse", [(11, "0"), (12, "1")])
+def test_randomized_engine_vs_oracle(seed, sparse):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--cases", "250", "--seed", str(seed)],
+                       env=dict(os.environ, MK_SPARSE=sparse), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "250 cases, 0 mismatches" in out, out[-1500:]

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""tools/fuzz_parity.py -- randomized differential test of the HIP engine against the CPU oracle (GPU box only).
+
+    python tools/fuzz_parity.py [--cases 200] [--seed 1]
+
+Every case draws a .shuf geometry, a sketch flavour (-A counted / FASTA set / FASTA -u / FASTQ occurrence set), a row stride,
+a number of pushes and reads with random lengths, strands, lower case, N runs and odd bytes, and compares the engine's
+sketch with the oracle's, bit for bit.  Exits non-zero on the first difference and prints how to reproduce it."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import util_inputs as ui  # noqa: E402
+
+GEOM = [(6, 3, 0), (7, 4, 1), (8, 4, 2), (8, 5, 2), (9, 5, 2), (9, 6, 3), (10, 6, 3), (10, 5, 2), (11, 6, 3), (7, 3, 0)]
+
+
+def random_reads(rs, n, dense):
+    pool = ui.rand_seq(rs, int(rs.choice([2000, 20000, 200000])))
+    out = []
+    for _ in range(n):
+        L = int(rs.choice([0, 1, 11, 12, 13, 21, 22, 23, 50, 100, 150, 151, 152, 250, 301]))
+        if L > len(pool):
+            L = len(pool)
+        a = rs.randint(0, len(pool) - L + 1)
+        s = pool[a:a + L]
+        r = rs.rand()
+        if r < 0.4:
+            s = ui.revcomp(s)
+        if rs.rand() < 0.2:
+            s = s.lower()
+        if L > 4 and rs.rand() < 0.25:
+            j = rs.randint(0, L - 2)
+            s = s[:j] + bytes(rs.choice([78, 110, 45, 42, 85, 0x80 if False else 88], size=rs.randint(1, 3)).astype(np.uint8)) + s[j + 2:]
+            s = s[:L]
+        out.append(s)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    from metakssd_amd import capi
+    from oracle_binding import Oracle
+    engines, oracles, shufs = {}, {}, {}
+    bad = 0
+    nonempty = total_ids = crowded = 0
+    for case in range(a.cases):
+        rs = np.random.RandomState(a.seed * 100003 + case)
+        k, subk, drl = GEOM[rs.randint(0, len(GEOM))]
+        key = (k, subk, drl)
+        if key not in shufs:
+            shufs[key] = capi.Shuf.generate(k, subk, drl, 1000 + k * 100 + subk * 10 + drl)
+            engines[key] = capi.Engine(shufs[key], 0)
+            oracles[key] = Oracle(shufs[key].c.id, k, subk, drl, shufs[key].table)
+        eng, ora, P = engines[key], oracles[key], shufs[key].params()
+        dense = P.dim_end - P.dim_start >= 16 ** subk  # accept-everything tables crowd quickly
+        flavour = ["koc", "set", "uniq", "occ"][rs.randint(0, 4)]
+        budget = int(P.hashlimit * (0.5 if flavour != "occ" else 0.8))
+        per_read = 100 * (1.0 if dense else max(1.0 / 16 ** drl, 1e-4))
+        nreads = int(min(rs.choice([1, 7, 64, 65, 300, 2000]), max(1, budget / max(per_read, 1e-9) / 2)))
+        desc = "case %d seed %d: k=%d subk=%d drlevel=%d %s nreads=%d" % (case, a.seed, k, subk, drl, flavour, nreads)
+        seqs = random_reads(rs, nreads, dense)
+        if flavour in ("koc",):
+            stride = int(rs.choice([304, 308, 320, 512, 4096]))
+            rows = ui.rows_from_seqs(seqs, stride)
+            rc, want = ora.koc_from_rows(rows, stride)
+            eng.begin(capi.MK_MODE_KOC)
+            pushes = int(rs.choice([1, 2, 5]))
+            n = len(seqs)
+            per = (n + pushes - 1) // pushes
+            for s0 in range(0, n, per):
+                eng.push_reads(rows[s0 * stride:(s0 + per) * stride], stride, s0)
+        elif flavour == "occ":
+            M, Q = int(rs.choice([1, 2, 3, 7])), int(rs.choice([0, 40, 54]))
+            quals = ui.random_quals(rs, seqs)
+            data = ui.fastq_bytes(seqs, quals=quals, final_newline=bool(rs.rand() < 0.8))
+            rc, want = ora.co_from_fastq(data, Q=Q, M=M)
+            stride = int(rs.choice([304, 512]))
+            rows, nrows, nrec, used, frc = capi.fastq_frame_q(data, stride, P.TL, qmin=Q)
+            assert frc == 0 and used == len(data), desc
+            eng.begin_occ(M)
+            eng.push_reads(rows, stride, 0)
+            desc += " M=%d Q=%d" % (M, Q)
+        else:
+            fa = ui.fasta_bytes([s for s in seqs if len(s) > 0] or [b"ACGT"], width=int(rs.choice([60, 70, 80, 1000])))
+            rc, want = ora.co_from_fasta(fa, uniq=flavour == "uniq")
+            stride = int(rs.choice([64, 256, 512, 4096]))
+            if stride < 2 * P.TL + 4:
+                stride = 256
+            rows = capi.fasta_windows(fa, P.TL, stride, chunk=int(rs.choice([0, 100, 5000])) or None)
+            eng.begin(capi.MK_MODE_UNIQ_SET if flavour == "uniq" else capi.MK_MODE_SET)
+            eng.push_reads(rows, stride, 0)
+        try:
+            got = eng.finish()
+            grc = 0
+        except capi.CrowdedError:
+            grc, got = -2, None
+        if rc != 0 or grc != 0:
+            ok = (rc != 0) == (grc != 0)
+            crowded += 1
+        else:
+            n_ids = sum(len(w[0]) for w in want)
+            nonempty += n_ids > 0
+            total_ids += n_ids
+            ok = len(got) == len(want) and all(np.array_equal(g[0], w[0]) and (w[1] is None or np.array_equal(g[1], w[1])) for g, w in zip(got, want))
+        if not ok:
+            bad += 1
+            print("MISMATCH", desc, "oracle rc", rc, "engine rc", grc)
+            break
+    print("%d cases, %d mismatches; %d with a non-empty sketch (%d ids compared), %d crowded on both sides" %
+          (case + 1, bad, nonempty, total_ids, crowded))
+    for e in engines.values():
+        e.close()
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
