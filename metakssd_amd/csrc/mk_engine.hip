@@ -640,7 +640,7 @@ extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
     MK_HIP(e, hipMalloc(&e->d_out_cnt, cap * 2));
     e->out_cap = cap;
   }
-  if (D > e->h_cap) {
+  if (D > e->h_cap || !e->h_ids) { /* also for an empty first result: mk_component pointers are never NULL where promised */
     if (e->h_ids) hipHostFree(e->h_ids);
     if (e->h_cnt) hipHostFree(e->h_cnt);
     e->h_ids = nullptr; e->h_cnt = nullptr;
