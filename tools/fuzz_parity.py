@@ -23,8 +23,10 @@ GEOM = [(6, 3, 0), (7, 4, 1), (8, 4, 2), (8, 5, 2), (9, 5, 2), (9, 6, 3), (10, 6
 def random_reads(rs, n, dense):
     pool = ui.rand_seq(rs, int(rs.choice([2000, 20000, 200000])))
     out = []
+    lens = [[0, 1, 11, 12, 13, 21, 22, 23, 50, 100, 150, 151, 152, 250, 301], [150], [0, 22, 23, 60, 63, 95, 127, 150, 159],
+            [100, 101, 150]][rs.randint(0, 4)]  # sometimes fixed-length or short reads: the narrow-row (one-pass staging) kernels
     for _ in range(n):
-        L = int(rs.choice([0, 1, 11, 12, 13, 21, 22, 23, 50, 100, 150, 151, 152, 250, 301]))
+        L = int(rs.choice(lens))
         if L > len(pool):
             L = len(pool)
         a = rs.randint(0, len(pool) - L + 1)
@@ -69,9 +71,11 @@ def main():
         desc = "case %d seed %d: k=%d subk=%d drlevel=%d %s nreads=%d" % (case, a.seed, k, subk, drl, flavour, nreads)
         seqs = random_reads(rs, nreads, dense)
         if flavour in ("koc",):
-            stride = int(rs.choice([304, 308, 320, 512, 4096]))
+            need = max([len(x) for x in seqs] + [0]) + 1
+            stride = int(rs.choice([x for x in (64, 96, 128, 152, 160, 164, 176, 304, 308, 320, 512, 4096) if x >= need]))
             rows = ui.rows_from_seqs(seqs, stride)
             rc, want = ora.koc_from_rows(rows, stride)
+            desc += " stride=%d" % stride
             eng.begin(capi.MK_MODE_KOC)
             pushes = int(rs.choice([1, 2, 5]))
             n = len(seqs)
