@@ -16,3 +16,12 @@ def test_randomized_engine_vs_oracle(seed, sparse):
                        env=dict(os.environ, MK_SPARSE=sparse), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and "250 cases, 0 mismatches" in out, out[-1500:]
+
+
+def test_randomized_setop_vs_numpy_and_oracle():
+    """mk_setop_* (set -u/-q/-i/-s/-g, composite join) on random id lists around the chunk boundaries, with duplicates, zeros and
+    the top of the 32-bit range: numpy's definition of the sets, the oracle's per-taxon table (also over-full ones)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_setop.py"), "--cases", "500", "--seed", "41"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "500 cases, 0 mismatches" in out, out[-1500:]
