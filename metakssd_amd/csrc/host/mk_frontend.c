@@ -65,7 +65,7 @@ static size_t mk_line(const uint8_t *p, const uint8_t *end, int final) {
 
 int mk_fastq_frame(const uint8_t *buf, size_t n, int final, uint8_t *rows, uint32_t stride, uint64_t max_rows,
                    uint64_t *nrows, size_t *consumed) {
-  if (!buf || !rows || !nrows || !consumed || stride < 4 || stride > 4096 || (stride & 3)) return MK_ERR_ARG;
+  if ((!buf && n) || !rows || !nrows || !consumed || stride < 4 || stride > 4096 || (stride & 3)) return MK_ERR_ARG;
   const uint8_t *p = buf, *end = buf + n;
   uint64_t r = 0;
   int rc = MK_OK;

@@ -317,3 +317,14 @@ def test_sketchdir_writer_layout(capi, tmp_path):
     assert struct.unpack_from("<IB3xiiiiQ", st, 0) == (sh.c.id & 0xffffffff, 1, 14, 2, 1, 2, 3)
     assert struct.unpack_from("<2I", st, 32) == (3, 0)
     assert st[40:40 + 256].rstrip(b"\0") == b"a/x.fq" and st[296:296 + 256].rstrip(b"\0") == b"b/y.fq"
+
+
+def test_randomized_fastq_text_against_both_reference_readers():
+    """tools/fuzz_framing.py: random, partly malformed FASTQ-like text (blank lines, missing lines, CRLF, no final newline)
+    through the product's framers vs the oracle's restatements of mt_shortreads2koc's and fastq2co's readers"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_framing.py"), "--cases", "600", "--seed", "7"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"600 cases, 0 mismatches" in r.stdout, r.stdout.decode(errors="replace")[-800:]
