@@ -207,7 +207,8 @@ int mk_fastq_frame_mt(const uint8_t *buf, size_t n, int final, int occ, int32_t 
  * window resets and cuts the base stream into rows of `stride` bytes overlapping by TL-1 bases so that
  * every k-mer lies in exactly one row.  Call mk_fasta_window_init once per file, then feed the file in
  * any chunking; when *consumed < n (max_rows reached) call again with the rest; pass final!=0 with
- * the last chunk (n may be 0) to flush the pending row. */
+ * the last chunk (n may be 0) to flush the pending row.  MK_ERR_FORMAT: the input ends inside a '>' line (no newline
+ * behind the last header), where the reference aborts (iseq2comem.c:259-271). */
 typedef struct mk_fasta_state {
   uint32_t TL;        /* k-mer length in bases (2k) */
   uint32_t in_header; /* inside a '>' line */

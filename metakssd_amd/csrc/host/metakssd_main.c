@@ -242,7 +242,9 @@ static void sketch_fasta(ctx_t *c, const char *path, int TL) {
     do {
       uint64_t nrows = 0;
       size_t used = 0;
-      CHECK(c->eng, mk_fasta_window(&st, c->io + off, have - off, eof, c->rows, stride, ROWBUF / stride, &nrows, &used));
+      const int wrc = mk_fasta_window(&st, c->io + off, have - off, eof, c->rows, stride, ROWBUF / stride, &nrows, &used);
+      if (wrc == MK_ERR_FORMAT) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", path); /* iseq2comem.c:269 */
+      if (wrc != MK_OK) die("mk_fasta_window failed (%d)", wrc);
       if (nrows) {
         CHECK(c->eng, mk_sketch_push_reads(c->eng, c->rows, stride, nrows, c->next_ordinal));
         c->next_ordinal += nrows;
@@ -338,7 +340,7 @@ static void *pf_worker(void *arg) {
       const uint32_t stride = 512;
       uint64_t nrows = 0;
       size_t used = 0;
-      if (n == 0) s.err = MK_ERR_FORMAT;
+      if (n == 0) s.err = MK_ERR_STATE; /* empty input: the reference's "eof or fread error" (iseq2comem.c:235) */
       else {
         mk_fasta_window_init(&st, pf->TL);
         int rc = mk_fasta_window(&st, text, n, 1, pf->bufs[b], stride, ROWBUF / stride, &nrows, &used);
@@ -969,7 +971,8 @@ int main(int argc, char **argv) {
       pf_slot sl = pf.slots[i];
       pthread_mutex_unlock(&pf.mu);
       if (sl.err == MK_ERR_IO) die("%s: cannot open", path);
-      if (sl.err == MK_ERR_FORMAT && !fq) die("fastco():eof or fread error file=%s", path);
+      if (sl.err == MK_ERR_STATE && !fq) die("fastco():eof or fread error file=%s", path);
+      if (sl.err == MK_ERR_FORMAT && !fq) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", path);
       if (sl.err) die("%s: sequence or header line of 4095+ characters: outside the FASTQ framing contract (iseq2comem.c:656,673)", path);
       if (!sl.too_big) {
         if (sl.nrows) CHECK(c.eng, mk_sketch_push_reads(c.eng, pf.bufs[sl.buf], sl.stride, sl.nrows, 0));

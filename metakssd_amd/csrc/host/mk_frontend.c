@@ -364,6 +364,12 @@ int mk_fasta_window(mk_fasta_state *st, const uint8_t *buf, size_t n, int final,
     st->pending[st->fill++] = ch; /* ACGTacgt roll in the kernel; any other byte resets (iseq2comem.c:258,275-279) */
     st->fresh++;
   }
+  if (final && pos >= n && st->in_header) { /* a '>' line that the file ends in without a newline: the reference gives up
+                                               * ("can not find seqences head start from '>'", iseq2comem.c:259-271) */
+    *nrows = r;
+    *consumed = pos;
+    return MK_ERR_FORMAT;
+  }
   if (final && pos >= n && st->fresh > 0 && r < max_rows) mk_fasta_emit(st, rows + r++ * (uint64_t)stride, stride);
   *nrows = r;
   *consumed = pos;

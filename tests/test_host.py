@@ -295,6 +295,20 @@ def test_fasta_windows_cover_every_kmer_once(capi, stride, chunk):
     assert all(len(p) == stride - 1 for p in payloads[:-1])
 
 
+def test_fasta_input_ending_inside_a_header_is_an_error(capi):
+    """the reference gives up when the stream ends inside a '>' line (iseq2comem.c:259-271); with the newline it is fine"""
+    rs = np.random.RandomState(14)
+    body = ui.fasta_bytes([ui.rand_seq(rs, 500)])
+    with pytest.raises(capi.MkError) as ei:
+        capi.fasta_windows(body + b">tail header without newline", 14, 256)
+    assert ei.value.code == capi.MK_ERR_FORMAT
+    with pytest.raises(capi.MkError):
+        capi.fasta_windows(body + b">tail header without newline", 14, 256, chunk=37)
+    rows_ok = capi.fasta_windows(body + b">tail header with newline\n", 14, 256)  # fine: the '>' stays as one reset byte
+    plain = capi.fasta_windows(body, 14, 256)
+    assert rows_ok.size == plain.size and (rows_ok != plain).sum() <= 2
+
+
 def test_sketchdir_writer_layout(capi, tmp_path):
     """combco.N / combco.index.N / combco.N.a / cofiles.stat exactly as run_stageI lays them out"""
     sh = capi.Shuf.generate(7, 4, 1, 7)

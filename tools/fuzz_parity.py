@@ -95,13 +95,39 @@ def main():
             desc += " M=%d Q=%d" % (M, Q)
         else:
             fa = ui.fasta_bytes([s for s in seqs if len(s) > 0] or [b"ACGT"], width=int(rs.choice([60, 70, 80, 1000])))
+            if rs.rand() < 0.5:  # rougher text: CRLF, blank lines, '>' inside a sequence line, a header without sequence
+                lines = fa.split(b"\n")
+                for _ in range(int(rs.randint(1, 6))):
+                    j = int(rs.randint(0, len(lines)))
+                    what = rs.randint(0, 5)
+                    if what == 0:
+                        lines.insert(j, b"")
+                    elif what == 1 and lines[j] and not lines[j].startswith(b">"):
+                        cut = int(rs.randint(0, len(lines[j]) + 1))
+                        lines[j] = lines[j][:cut] + b">" + lines[j][cut:]
+                    elif what == 2:
+                        lines.insert(j, b">only a header " + bytes(rs.randint(32, 127, size=int(rs.randint(0, 90))).astype(np.uint8)).replace(b"\n", b" "))
+                    elif what == 3:
+                        lines[j] = lines[j] + b"\r"
+                    else:
+                        lines[j] = lines[j].replace(b"A", b"a", 3)
+                fa = b"\n".join(lines)
+                if rs.rand() < 0.3 and fa.endswith(b"\n"):
+                    fa = fa[:-1]
             rc, want = ora.co_from_fasta(fa, uniq=flavour == "uniq")
             stride = int(rs.choice([64, 256, 512, 4096]))
             if stride < 2 * P.TL + 4:
                 stride = 256
-            rows = capi.fasta_windows(fa, P.TL, stride, chunk=int(rs.choice([0, 100, 5000])) or None)
             eng.begin(capi.MK_MODE_UNIQ_SET if flavour == "uniq" else capi.MK_MODE_SET)
-            eng.push_reads(rows, stride, 0)
+            try:
+                rows = capi.fasta_windows(fa, P.TL, stride, chunk=int(rs.choice([0, 100, 5000])) or None)
+                eng.push_reads(rows, stride, 0)
+            except capi.MkError as ex:  # input ends inside a '>' line: the reference aborts there, the oracle says KO_ERR_CONTRACT
+                if ex.code != capi.MK_ERR_FORMAT or rc != -5:
+                    raise
+                eng.finish()
+                crowded += 1
+                continue
         try:
             got = eng.finish()
             grc = 0
