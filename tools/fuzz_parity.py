@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import util_inputs as ui  # noqa: E402
 
 GEOM = [(6, 3, 0), (7, 4, 1), (8, 4, 2), (8, 5, 2), (9, 5, 2), (9, 6, 3), (10, 6, 3), (10, 5, 2), (11, 6, 3), (7, 3, 0)]
+GEOM_BIG = (11, 5, 2)  # 16 components, 537 M slots (4.3 GB oracle table, sparse bookkeeping in the engine): drawn rarely
 
 
 def random_reads(rs, n, dense):
@@ -48,6 +49,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="also draw the 16-component L2K11 geometry (slow oracle)")
     a = ap.parse_args()
     from metakssd_amd import capi
     from oracle_binding import Oracle
@@ -56,7 +58,7 @@ def main():
     nonempty = total_ids = crowded = 0
     for case in range(a.cases):
         rs = np.random.RandomState(a.seed * 100003 + case)
-        k, subk, drl = GEOM[rs.randint(0, len(GEOM))]
+        k, subk, drl = GEOM_BIG if (a.big and rs.rand() < 0.08) else GEOM[rs.randint(0, len(GEOM))]
         key = (k, subk, drl)
         if key not in shufs:
             shufs[key] = capi.Shuf.generate(k, subk, drl, 1000 + k * 100 + subk * 10 + drl)
