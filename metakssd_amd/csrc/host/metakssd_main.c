@@ -364,6 +364,7 @@ static void usage(void) {
           "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D] <fastq|fasta|dir>...\n"
           "       metakssd set -u|-q|-i <pan dir>|-s <pan dir>|-g <tax.tsv>|-P [-o outdir] [--device D] <sketch dir>\n"
           "       metakssd composite -r <marker db dir> -q <-A sketch dir> [-b] [-o outdir] [--device D]\n"
+          "       metakssd composite -d <x.abv>...\n"
           "       metakssd shuffle -k <halfK> -s <halfSubK> -l <level> [--seed N] -o <prefix>\n");
   exit(2);
 }
@@ -710,9 +711,45 @@ static int cmd_set(int argc, char **argv) {
  * in the reference's float arithmetic. */
 static int cmp_int_asc(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
 
+/* `composite -d <x.abv>...`: read_abv(), command_composite.c:186-210 -- prints the (reference index, percentage) pairs of
+ * the vector files `composite -b` writes.  Host only. */
+static int composite_read_abv(int nfiles, char **files) {
+  for (int i = 0; i < nfiles; i++) {
+    const char *ext = strrchr(files[i], '.');
+    if (!ext || strcmp(ext + 1, "abv") != 0) {
+      printf("%dth argument %s is not a .abv file, skipped\n", i, files[i]);
+      continue;
+    }
+    size_t n = 0;
+    uint8_t *b = read_whole(files[i], &n);
+    if (!b) die("read_abv():%s", files[i]);
+    for (size_t l = 0; l + 8 <= n || l < n; l += 8) { /* the reference loops while l < st_size */
+      int32_t idx = 0;
+      float pct = 0;
+      if (l + 8 <= n) { memcpy(&idx, b + l, 4); memcpy(&pct, b + l + 4, 4); }
+      printf("%d\t%f\n", idx, pct);
+    }
+    free(b);
+  }
+  return 1;
+}
+
 static int cmd_composite(int argc, char **argv) {
   const char *refdir = NULL, *qrydir = NULL, *outdir = "./";
   int binvec = 0, device = 0;
+  for (int i = 0; i < argc; i++)
+    if (!strcmp(argv[i], "-d")) { /* cmd_composite(): -d is looked at only without -r (command_composite.c:179-182) */
+      int has_r = 0;
+      for (int j = 0; j < argc; j++) has_r |= !strcmp(argv[j], "-r");
+      if (!has_r) {
+        char *files[4096];
+        int nf = 0;
+        for (int j = 0; j < argc && nf < 4096; j++)
+          if (argv[j][0] != '-') files[nf++] = argv[j];
+        if (nf < 1) { printf("\vUsage: kssd composite -d <query.abv>\n\v"); return 0; }
+        return composite_read_abv(nf, files) == 1 ? 0 : 1;
+      }
+    }
   for (int i = 0; i < argc; i++) {
     if (!strcmp(argv[i], "-r") && i + 1 < argc) refdir = argv[++i];
     else if (!strcmp(argv[i], "-q") && i + 1 < argc) qrydir = argv[++i];
@@ -720,7 +757,7 @@ static int cmd_composite(int argc, char **argv) {
     else if (!strcmp(argv[i], "-p") && i + 1 < argc) ++i;
     else if (!strcmp(argv[i], "-b")) binvec = 1;
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
-    else die("composite option %s is not part of this build (-r -q -b -o are)", argv[i]);
+    else die("composite option %s is not part of this build (-r -q -b -o and -d are)", argv[i]);
   }
   if (!refdir || !qrydir || !strcmp(refdir, qrydir)) die("get_species_abundance(): refdir or qrydir is not initialized");
   char path[PATHLEN * 3 + 64];

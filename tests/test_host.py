@@ -342,3 +342,19 @@ def test_randomized_fastq_text_against_both_reference_readers():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_framing.py"), "--cases", "600", "--seed", "7"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and b"600 cases, 0 mismatches" in r.stdout, r.stdout.decode(errors="replace")[-800:]
+
+
+def test_cli_composite_d_prints_abv_vectors(tmp_path):
+    """`composite -d x.abv` (read_abv, command_composite.c:186-210): host only, runs without a GPU.  The golden .abv files were
+    written by the reference's `composite -b`; the expected text is its "%d\\t%f" of the stored (index, float) pairs."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "metakssd_amd", "bin", "metakssd")
+    abv = os.path.join(root, "tests", "golden", "expected", "composite_two_queries_L1K7", "composite_two_queries_L1K7_qry0.fq.abv")
+    raw = open(abv, "rb").read()
+    want = "".join("%d\t%s\n" % (i, "%f" % struct.unpack("<f", struct.pack("<f", p))[0])
+                   for i, p in struct.iter_unpack("<if", raw))
+    r = subprocess.run([cli, "composite", "-d", "not_a_vector.txt", abv], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == "0th argument not_a_vector.txt is not a .abv file, skipped\n" + want and len(raw) >= 16
