@@ -362,7 +362,7 @@ static void *pf_worker(void *arg) {
 static void usage(void) {
   fprintf(stderr,
           "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D] <fastq|fasta|dir>...\n"
-          "       metakssd set -u|-q|-i <pan dir>|-s <pan dir>|-g <tax.tsv>|-P [-o outdir] [--device D] <sketch dir>\n"
+          "       metakssd set -u|-q|-i <pan dir>|-s <pan dir>|-g <tax.tsv>|-c|-P [-o outdir] [--device D] <sketch dir>\n"
           "       metakssd composite -r <marker db dir> -q <-A sketch dir> [-b] [-o outdir] [--device D]\n"
           "       metakssd composite -d <x.abv>...\n"
           "       metakssd shuffle -k <halfK> -s <halfSubK> -l <level> [--seed N] -o <prefix>\n");
@@ -620,6 +620,77 @@ static int set_group(const char *in, const char *taxfile, const char *outdir, in
   return 0;
 }
 
+/* `set -c <pan dir>...`: combin_pans(), command_set.c:515-608 -- the pan.N (or uniq_pan.N) files of several pan directories
+ * become the blocks of one combined sketch directory.  File shuffling only, no device work.  The reference writes 256 bytes
+ * starting at each argument string as the name record (whatever follows the NUL in argv); here the rest is zero. */
+static int set_combine(int ndirs, char **dirs, const char *outdir) {
+  char path[PATHLEN * 2 + 32];
+  size_t n0 = 0;
+  snprintf(path, sizeof path, "%s/cofiles.stat", dirs[0]);
+  uint8_t *hdr = read_whole(path, &n0);
+  if (!hdr || n0 < 32) die("combin_pans():%s", path);
+  uint32_t id0;
+  int32_t comp_num;
+  memcpy(&id0, hdr, 4);
+  memcpy(&comp_num, hdr + 16, 4);
+  mkdir(outdir, 0777);
+  uint32_t *ctx_ct = calloc((size_t)ndirs, 4);
+  uint64_t all_ctx_ct = 0;
+  FILE **co = malloc(sizeof(FILE *) * (size_t)comp_num), **ix = malloc(sizeof(FILE *) * (size_t)comp_num);
+  uint64_t *off = calloc((size_t)comp_num, 8);
+  for (int c = 0; c < comp_num; c++) {
+    snprintf(path, sizeof path, "%s/combco.%d", outdir, c);
+    if (!(co[c] = fopen(path, "wb"))) die("%s", path);
+    snprintf(path, sizeof path, "%s/combco.index.%d", outdir, c);
+    if (!(ix[c] = fopen(path, "wb"))) die("%s", path);
+    fwrite(&off[c], 8, 1, ix[c]);
+  }
+  for (int i = 0; i < ndirs; i++) {
+    size_t ni = 0;
+    snprintf(path, sizeof path, "%s/cofiles.stat", dirs[i]);
+    uint8_t *h = read_whole(path, &ni);
+    if (!h || ni < 32) die("combin_pans():%s", path);
+    uint32_t idi;
+    int32_t ci;
+    memcpy(&idi, h, 4);
+    memcpy(&ci, h + 16, 4);
+    free(h);
+    if (idi != id0) die("combin_pans(): %dth shuf_id: %u not match 0th shuf_id: %u", i, idi, id0);
+    if (ci != comp_num) die("combin_pans(): %dth comp_num: %u not match 0th comp_num: %u", i, (unsigned)ci, (unsigned)comp_num);
+    for (int c = 0; c < comp_num; c++) {
+      size_t nb = 0;
+      snprintf(path, sizeof path, "%s/pan.%d", dirs[i], c);
+      uint8_t *ids = read_whole(path, &nb);
+      if (!ids) { snprintf(path, sizeof path, "%s/uniq_pan.%d", dirs[i], c); ids = read_whole(path, &nb); }
+      if (!ids) die("%s", path);
+      fwrite(ids, 1, nb, co[c]);
+      off[c] += nb / 4;
+      fwrite(&off[c], 8, 1, ix[c]);
+      ctx_ct[i] += (uint32_t)(nb / 4);
+      free(ids);
+    }
+    all_ctx_ct += ctx_ct[i];
+  }
+  for (int c = 0; c < comp_num; c++) { fclose(co[c]); fclose(ix[c]); }
+  int32_t v = ndirs;
+  memcpy(hdr + 20, &v, 4);
+  memcpy(hdr + 24, &all_ctx_ct, 8);
+  snprintf(path, sizeof path, "%s/cofiles.stat", outdir);
+  FILE *f = fopen(path, "wb");
+  if (!f) die("%s", path);
+  fwrite(hdr, 1, 32, f);
+  fwrite(ctx_ct, 4, (size_t)ndirs, f);
+  for (int i = 0; i < ndirs; i++) {
+    char name[PATHLEN];
+    memset(name, 0, sizeof name);
+    snprintf(name, sizeof name, "%s", dirs[i]);
+    fwrite(name, 1, PATHLEN, f);
+  }
+  fclose(f);
+  free(hdr); free(ctx_ct); free(co); free(ix); free(off);
+  return 0;
+}
+
 /* ---- `metakssd set`: -u / -q (sketch_union / uniq_sketch_union, command_set.c:241-319,427-512), -i / -s <pan>
  * (sketch_operate, :321-425), -P (print_gnames, :610-631) ----
  * The dictionary work runs on the device (mk_setop_*); the directory handling follows the reference: the 32-byte
@@ -633,15 +704,25 @@ static int cmd_set(int argc, char **argv) {
     else if (!strcmp(argv[i], "-q")) { if (op != -1) printf("set operation is already set, -q is ignored.\n"); else op = 3; }
     else if (!strcmp(argv[i], "-s") && i + 1 < argc) { if (op != -1) printf("set operation is already set, -s is ignored.\n"); else { op = 0; panpath = argv[i + 1]; } i++; }
     else if (!strcmp(argv[i], "-i") && i + 1 < argc) { if (op != -1) printf("set operation is already set, -i is ignored.\n"); else { op = 1; panpath = argv[i + 1]; } i++; }
+    else if (!strcmp(argv[i], "-c")) { if (op != -1) printf("set operation is already set, -c is ignored.\n"); else op = 4; }
     else if (!strcmp(argv[i], "-P")) print = 1;
     else if (!strcmp(argv[i], "-g") && i + 1 < argc) taxfile = argv[++i];
     else if (!strcmp(argv[i], "-o") && i + 1 < argc) outdir = argv[++i];
     else if (!strcmp(argv[i], "-p") && i + 1 < argc) ++i; /* threads: no meaning here */
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
-    else if (argv[i][0] == '-' && argv[i][1]) die("set option %s is not part of this build (-u -q -i -s -g -P are)", argv[i]);
+    else if (argv[i][0] == '-' && argv[i][1]) die("set option %s is not part of this build (-u -q -i -s -g -c -P are)", argv[i]);
     else if (!in) in = argv[i];
   }
   if (!in) usage();
+  if (op == 4) { /* every non-option argument is a pan directory */
+    char *dirs[4096];
+    int nd = 0;
+    for (int i = 0; i < argc && nd < 4096; i++) {
+      if (!strcmp(argv[i], "-o") || !strcmp(argv[i], "-p") || !strcmp(argv[i], "--device")) { i++; continue; }
+      if (argv[i][0] != '-') dirs[nd++] = argv[i];
+    }
+    return set_combine(nd, dirs, outdir);
+  }
   if (op == 0 || op == 1) return set_operate(in, panpath, outdir, op == 1, device);
   if (op == -1) {
     if (print) return set_print_names(in);

@@ -358,3 +358,38 @@ def test_cli_composite_d_prints_abv_vectors(tmp_path):
     r = subprocess.run([cli, "composite", "-d", "not_a_vector.txt", abv], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout.decode() == "0th argument not_a_vector.txt is not a .abv file, skipped\n" + want and len(raw) >= 16
+
+
+def test_cli_set_c_combines_pan_directories(tmp_path):
+    """`set -c <pan dir>...` (combin_pans, command_set.c:515-608): host only.  Two golden pan directories (written by the
+    reference's set -u / -q) become the two blocks of one combined sketch directory."""
+    import shutil
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "metakssd_amd", "bin", "metakssd")
+    exp = os.path.join(root, "tests", "golden", "expected")
+    hdr = struct.pack("<IB3xiiiiQ", 77, 0, 14, 2, 1, 3, 999)
+    dirs = []
+    for name, src, pref in (("u", "set_u_strains_L1K7", "pan.0"), ("q", "set_q_strains_L1K7", "uniq_pan.0")):
+        d = tmp_path / name
+        d.mkdir()
+        shutil.copy(os.path.join(exp, src, pref), str(d / pref))
+        (d / "cofiles.stat").write_bytes(hdr)
+        dirs.append(str(d))
+    out = str(tmp_path / "combined")
+    r = subprocess.run([cli, "set", "-c", "-o", out] + dirs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    a = open(os.path.join(exp, "set_u_strains_L1K7", "pan.0"), "rb").read()
+    b = open(os.path.join(exp, "set_q_strains_L1K7", "uniq_pan.0"), "rb").read()
+    assert open(os.path.join(out, "combco.0"), "rb").read() == a + b
+    assert struct.unpack("<3Q", open(os.path.join(out, "combco.index.0"), "rb").read()) == (0, len(a) // 4, (len(a) + len(b)) // 4)
+    st = open(os.path.join(out, "cofiles.stat"), "rb").read()
+    assert len(st) == 32 + 2 * 4 + 2 * 256
+    assert struct.unpack_from("<iiQ", st, 16) == (1, 2, (len(a) + len(b)) // 4)          # comp_num, infile_num, all_ctx_ct
+    assert struct.unpack_from("<2I", st, 32) == (len(a) // 4, len(b) // 4)
+    assert st[40:40 + 256].split(b"\0")[0].decode() == dirs[0]
+    # a pan directory of another .shuf id is refused (:556-559)
+    (tmp_path / "q" / "cofiles.stat").write_bytes(struct.pack("<IB3xiiiiQ", 78, 0, 14, 2, 1, 3, 999))
+    r = subprocess.run([cli, "set", "-c", "-o", out] + dirs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"not match 0th shuf_id" in r.stderr
