@@ -66,8 +66,13 @@ struct mk_scan_args {
   mk_keyparams kp;
   mk_table tab;
   /* filter hits ("candidates") leave the scan kernel through per-wave append buffers in HBM */
-  unsigned long long *cand_fwd; /* [nslots][cand_cap] forward k-mers */
-  unsigned long long *cand_ord; /* [nslots][cand_cap] ordinals */
+  /* [nslots][cand_cap] 16-byte candidate records:
+   *   single k-mer (slow paths, generic kernel): {fwd lo, fwd hi, ord lo, ord hi | 0x80000000}
+   *   pair (tuned loop: some base of this lane's 8-base pair passed the LDS filter):
+   *       {flo at the pair start, packed codes << 16 | e << 12 | jmin << 9 | pos0 >> 3, h2 & 0xFFFF | h3 << 16, row index}
+   * The resolve kernel holds the same LDS filter, finds the base(s) that passed and rebuilds their k-mers, so the scan
+   * kernel's hit path is one ballot and one 16-byte store. */
+  uint4 *cand;
   uint32_t *cand_count;         /* [nslots] */
   uint32_t cand_cap;
 };
@@ -169,20 +174,57 @@ __device__ __forceinline__ void mk_resolve_one(const mk_scan_args &a, uint64_t s
   }
 }
 
-/* overflow path of the scan kernel (a wave's append buffer is full: dense accept-everything tables): resolve
- * this base's hits on the spot.  Out of line; reads the argument block through the kernarg pointer so that
- * the call does not push the hot loop's parameters into scratch. */
-__device__ __noinline__ void mk_resolve_inline(const mk_scan_args *ka, bool hit, uint64_t fwd, uint64_t ord) {
-  if (hit) mk_resolve_one(*ka, fwd, ord);
+typedef __attribute__((address_space(3))) const uint32_t *mk_lds_cu32;
+__device__ __forceinline__ uint32_t mk_filter_mask(uint32_t x);
+
+/* expands one candidate record; `filter` = the LDS filter (same contents in the scan and the resolve kernel) */
+__device__ __forceinline__ void mk_resolve_record(const mk_scan_args &a, const uint4 r, const uint32_t *filter) {
+  if (r.w & 0x80000000u) { /* single k-mer */
+    mk_resolve_one(a, ((uint64_t)r.y << 32) | r.x, ((uint64_t)(r.w & 0x7FFFFFFFu) << 32) | r.z);
+    return;
+  }
+  const uint32_t K = a.kp.TL >> 1, SH = 2u * (K - 6u) - 2u;
+  const uint32_t hm = (uint32_t)((1ull << (2u * a.kp.TL - 32u)) - 1ull); /* mk_kmer_hi<K>::HMASK */
+  const uint32_t pos0 = (r.y & 0x1FFu) << 3, jmin = (r.y >> 9) & 7u, e = (r.y >> 12) & 15u;
+  const uint32_t lo = r.y & 0xFFFF0000u, h2 = r.z & 0xFFFFu, h3 = r.z >> 16;
+  const uint64_t ord0 = ((a.first_ord + (uint64_t)r.w) << 12) | pos0;
+  /* first every base of the pair against the LDS filter (no global memory), then only the bases that passed -- one per
+   * round, so that the dependent global accesses of mk_resolve_one are not repeated for the seven bases that did not */
+  uint32_t before = r.x, hits = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 8; j++) {
+    const uint32_t x = (before >> SH) & 0xFFFFFFu;
+    if (j >= jmin && j < e && (mk_filter_mask(x) & ~filter[(x >> 10) & (a.bm_words - 1u)]) == 0u) hits |= 1u << j;
+    before = __builtin_amdgcn_alignbit(r.x, lo, 30u - 2u * j);
+  }
+  while (hits) {
+    const uint32_t j = (uint32_t)__builtin_ctz(hits);
+    hits &= hits - 1u;
+    const uint32_t dd = 2u * (j + 1u);
+    const uint32_t fl = __builtin_amdgcn_alignbit(r.x, lo, 30u - 2u * j);
+    const uint32_t fhi = ((h3 << dd) | (h2 >> (16u - dd))) & hm;
+    mk_resolve_one(a, ((uint64_t)fhi << 32) | fl, ord0 + j);
+  }
 }
 
-/* resolves the candidates the scan kernel appended: one workgroup per producer wave slot */
+/* overflow path of the scan kernel (a wave's append buffer is full: dense accept-everything tables): resolve
+ * this lane's record on the spot.  Out of line; reads the argument block through the kernarg pointer so that
+ * the call does not push the hot loop's parameters into scratch. */
+__device__ __noinline__ void mk_resolve_inline(const mk_scan_args *ka, bool hit, uint4 r, const uint32_t *filter) {
+  if (hit) mk_resolve_record(*ka, r, filter);
+}
+
+__device__ __forceinline__ void mk_build_filter(uint32_t *bitmap, const mk_scan_args &a);
+
+/* resolves the candidates the scan kernel appended: a workgroup builds the LDS filter once and then walks producer slots */
 #define MK_RESOLVE_THREADS 1024 /* measured 256: 0.233 ms, 512: 0.230, 1024: 0.212 (50 M reads, 7 M candidates) */
 __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk_scan_args a, uint32_t nslots) {
+  extern __shared__ __align__(16) uint32_t rlds[];
+  mk_build_filter(rlds, a);
   for (uint32_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
     const uint32_t n = a.cand_count[slot];
-    const unsigned long long *f = a.cand_fwd + (size_t)slot * a.cand_cap, *o = a.cand_ord + (size_t)slot * a.cand_cap;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mk_resolve_one(a, f[i], o[i]);
+    const uint4 *c = a.cand + (size_t)slot * a.cand_cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mk_resolve_record(a, c[i], rlds);
   }
 }
 
@@ -241,7 +283,7 @@ template <> struct mk_kmer<10> : mk_kmer_hi<10> {};
 template <> struct mk_kmer<11> : mk_kmer_hi<11> {};
 template <> struct mk_kmer<12> : mk_kmer_hi<12> {};
 
-typedef __attribute__((address_space(3))) const uint32_t *mk_lds_cu32;
+
 
 /* scan code of byte J of a raw dword: (byte >> 1) & 3 in one instruction */
 template <int J>
@@ -269,6 +311,16 @@ __device__ __forceinline__ uint32_t mk_nonzero_bytes(uint32_t v) { /* bit 7 of b
   return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
 }
 
+__device__ __forceinline__ void mk_build_filter(uint32_t *bitmap, const mk_scan_args &a) {
+  for (uint32_t i = threadIdx.x; i < a.bm_words; i += blockDim.x) bitmap[i] = 0u;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < a.n_accept; i += blockDim.x) {
+    const uint32_t d = (uint32_t)mk_scan_to_ref_codes(a.accept[i]); /* reference coding -> scan coding (same map) */
+    atomicOr(&bitmap[(d >> 10) & (a.bm_words - 1u)], mk_filter_mask(d));
+  }
+  __syncthreads();
+}
+
 /* ONEPASS (only with exactly two column blocks per row): the loads for BOTH blocks of a tile are issued together,
  * so every 64-byte sector of the rows is requested once -- two separate 80-byte passes re-fetch the sector the
  * halves share (+37 % HBM reads, tools/ubench_fetch.hip).  Costs NPIECES more piece registers. */
@@ -280,13 +332,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   uint32_t *bitmap = lds;
   uint32_t *tile = lds + a.bm_words + wave * a.wave_lds_dwords;
 
-  for (uint32_t i = threadIdx.x; i < a.bm_words; i += blockDim.x) bitmap[i] = 0u;
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < a.n_accept; i += blockDim.x) {
-    const uint32_t d = (uint32_t)mk_scan_to_ref_codes(a.accept[i]); /* reference coding -> scan coding (same map) */
-    atomicOr(&bitmap[(d >> 10) & (a.bm_words - 1u)], mk_filter_mask(d));
-  }
-  __syncthreads();
+  mk_build_filter(bitmap, a);
 
   /* the filter sits at the start of the dynamic LDS (offset 0: the tuned loop addresses it absolutely) */
   const uint32_t filter_base = (uint32_t)(uintptr_t)(mk_lds_cu32)bitmap;
@@ -301,8 +347,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   const uint64_t ntiles = (a.nreads + 63u) >> 6;
   const uint64_t wave_global = (uint64_t)blockIdx.x * WAVES + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * WAVES;
-  unsigned long long *const my_fwd = a.cand_fwd + (size_t)wave_global * a.cand_cap;
-  unsigned long long *const my_ord = a.cand_ord + (size_t)wave_global * a.cand_cap;
+  uint4 *const my_cand = a.cand + (size_t)wave_global * a.cand_cap;
   if (wave_global >= ntiles) {
     if (lane == 0) a.cand_count[wave_global] = 0u;
     return;
@@ -398,21 +443,20 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   };
   /* append the lanes flagged in `hit` (forward k-mer `fwd` ending at row position `pos`) to this wave's
    * candidate buffer: plain stores, nothing to wait for */
-  auto push = [&](bool hit, uint64_t fwd, uint32_t pos) {
-    const uint64_t ord = ord_row | (uint64_t)pos;
+  auto push_record = [&](bool hit, const uint4 r) {
     const uint64_t m = __ballot(hit);
     if (m == 0) return;
     const uint32_t cnt = (uint32_t)__popcll(m);
     if (qn + cnt > a.cand_cap) { /* buffer full (dense tables only): resolve right here */
-      mk_resolve_inline(ka, hit, fwd, ord);
+      mk_resolve_inline(ka, hit, r, bitmap);
       return;
     }
-    if (hit) {
-      const uint32_t off = qn + mk_mbcnt(m);
-      my_fwd[off] = fwd;
-      my_ord[off] = ord;
-    }
+    if (hit) my_cand[qn + mk_mbcnt(m)] = r;
     qn = __builtin_amdgcn_readfirstlane(qn + cnt);
+  };
+  auto push = [&](bool hit, uint64_t fwd, uint32_t pos) { /* one k-mer: slow paths, generic kernel */
+    const uint64_t ord = ord_row | (uint64_t)pos;
+    push_record(hit, make_uint4((uint32_t)fwd, (uint32_t)(fwd >> 32), (uint32_t)ord, (uint32_t)(ord >> 32) | 0x80000000u));
   };
 
   /* four valid bases, every lane with a full window: roll, canonical k-mer, filter probe */
@@ -587,11 +631,11 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                 flo = __builtin_amdgcn_alignbit(fstart, lo, 16);
                 oh_init();
               } else {
-                uint32_t f0, f1, f2, f3, f4, f5, f6, f7, m0, m1, m2, m3, m4, m5, m6, m7, d0, d1, d2, d3, d4, d5, d6, d7;
-                f0 = __builtin_amdgcn_alignbit(fstart, lo, 30); f1 = __builtin_amdgcn_alignbit(fstart, lo, 28);
-                f2 = __builtin_amdgcn_alignbit(fstart, lo, 26); f3 = __builtin_amdgcn_alignbit(fstart, lo, 24);
-                f4 = __builtin_amdgcn_alignbit(fstart, lo, 22); f5 = __builtin_amdgcn_alignbit(fstart, lo, 20);
-                f6 = __builtin_amdgcn_alignbit(fstart, lo, 18); f7 = __builtin_amdgcn_alignbit(fstart, lo, 16);
+                uint32_t m0, m1, m2, m3, m4, m5, m6, m7, d0, d1, d2, d3, d4, d5, d6, d7;
+                const uint32_t f0 = __builtin_amdgcn_alignbit(fstart, lo, 30), f1 = __builtin_amdgcn_alignbit(fstart, lo, 28);
+                const uint32_t f2 = __builtin_amdgcn_alignbit(fstart, lo, 26), f3 = __builtin_amdgcn_alignbit(fstart, lo, 24);
+                const uint32_t f4 = __builtin_amdgcn_alignbit(fstart, lo, 22), f5 = __builtin_amdgcn_alignbit(fstart, lo, 20);
+                const uint32_t f6 = __builtin_amdgcn_alignbit(fstart, lo, 18), f7 = __builtin_amdgcn_alignbit(fstart, lo, 16);
                 /* Filter fields at offsets 0, 2, 6 of the substring x_j: because x_{j-1} = x_j >> 2, the three bits of
                  * base j are the one-hot words of the low 5 bits of x_j, x_{j-1} and x_{j-3} -- one new one-hot per
                  * base, the other two are carried (across pairs too: oh1..oh3).  The substring of base j sits in the
@@ -620,19 +664,13 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
 #else
                 if (__any(min(min(ta, tb), tc) == 0u)) {
 #endif
-                  const uint32_t pos0 = col0 + 8u * p;
-                  const uint32_t jmin = urun + 1u >= TL ? 0u : TL - 1u - urun; /* first base with a complete k-mer */
-                  /* forward k-mer ending at base j of this pair: low word fl, high word from flo(j-16), which lies
-                   * between h3 = flo(-17) and h2 = flo(-9):  flo(-17+d) = (h3 << 2d) | ((h2 & 0xFFFF) >> (16-2d)) */
-                  auto hit = [&](uint32_t t, uint32_t fl, uint32_t j) {
-                    if (j < jmin || j >= e) return; /* wave-uniform: incomplete k-mer / behind the newline */
-                    const uint32_t dd = 2u * (j + 1u);
-                    const uint32_t fhi = ((h3 << dd) | ((h2 & 0xFFFFu) >> (16u - dd))) & HM;
-                    push(t == 0u, ((uint64_t)fhi << 32) | fl, pos0 + j);
-                  };
-                  if (__any(ta == 0u)) { hit(t0, f0, 0); hit(t1, f1, 1); hit(t2, f2, 2); }
-                  if (__any(tb == 0u)) { hit(t3, f3, 3); hit(t4, f4, 4); hit(t5, f5, 5); }
-                  if (__any(tc == 0u)) { hit(t6, f6, 6); hit(t7, f7, 7); }
+                  /* some lane's filter test fired somewhere in this pair: those lanes append one pair record and the
+                   * resolve kernel, which holds the same filter, finds the base.  jmin = first base with a complete
+                   * k-mer (< 8 here), e = bases in front of the common newline (1..8). */
+                  const uint32_t jmin = urun + 1u >= TL ? 0u : TL - 1u - urun;
+                  const uint32_t meta = ((col0 + 8u * p) >> 3) | (jmin << 9) | (e << 12);
+                  push_record(min(min(ta, tb), tc) == 0u,
+                              make_uint4(fstart, (lo & 0xFFFF0000u) | meta, (h2 & 0xFFFFu) | (h3 << 16), (uint32_t)(row0 + lane)));
                 }
               }
               h3 = h2; h2 = fstart;
