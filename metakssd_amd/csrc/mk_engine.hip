@@ -409,6 +409,7 @@ static hipError_t mk_launch_scan_k(int threads, bool onepass, const mk_scan_args
 
 static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride, uint64_t nreads, uint64_t first_ord) {
   if (nreads == 0) return MK_OK;
+  if (nreads >= (1ull << 31)) return mk_fail(e, MK_ERR_ARG, "scan launch of %llu reads: the caller splits pushes below 2^31", (unsigned long long)nreads);
   mk_scan_args a{};
   a.rows = rows_dev; a.nreads = nreads; a.first_ord = first_ord; a.stride = stride;
   const bool vec = (stride % 16u == 0) && (((uintptr_t)rows_dev & 15u) == 0);
@@ -503,6 +504,7 @@ extern "C" int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev
   const uint64_t waves = (uint64_t)e->num_cu * (uint64_t)(e->tune_threads / 64);
   uint64_t per = (uint64_t)(e->cand_cap / 32u) * 64u * waves;
   if (per < 64u * waves) per = 64u * waves;
+  if (per > (1ull << 30)) per = 1ull << 30; /* 32-bit tile and row indices inside a launch */
   for (uint64_t done = 0; done < nreads; done += per) {
     const uint64_t n = nreads - done < per ? nreads - done : per;
     int rc2 = mk_launch_scan(e, rows_dev + done * stride, stride, n, first_read_ordinal + done);

@@ -344,9 +344,10 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   const uint32_t TL = mk_kmer<K>::TL(a.kp);
   const uint32_t dimmask = a.dimmask;
   const uint32_t wmask4 = (a.bm_words - 1u) << 2;
-  const uint64_t ntiles = (a.nreads + 63u) >> 6;
-  const uint64_t wave_global = (uint64_t)blockIdx.x * WAVES + wave;
-  const uint64_t nwaves = (uint64_t)gridDim.x * WAVES;
+  /* a launch covers fewer than 2^31 reads (the engine splits larger pushes), so tile and row indices are 32-bit */
+  const uint32_t ntiles = (uint32_t)((a.nreads + 63u) >> 6);
+  const uint32_t wave_global = blockIdx.x * WAVES + wave;
+  const uint32_t nwaves = gridDim.x * WAVES;
   uint4 *const my_cand = a.cand + (size_t)wave_global * a.cand_cap;
   if (wave_global >= ntiles) {
     if (lane == 0) a.cand_count[wave_global] = 0u;
@@ -366,9 +367,9 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
    * needed (a handful of ops per piece per step) rather than held in 2*NP registers */
   auto goff_of = [&](int i) { const uint32_t q = lane + 64u * i; const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr; return r * a.stride + c * PW; };
   auto loff_of = [&](int i) { const uint32_t q = lane + 64u * i; const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr; return r * a.rowdw + c * (PW / 4u); };
-  auto issue_loads = [&](uint64_t tile_id, uint32_t cb) {
-    const uint64_t row0 = tile_id << 6;
-    const uint8_t *base = a.rows + row0 * a.stride + (uint64_t)cb * a.CB;
+  auto issue_loads = [&](uint32_t tile_id, uint32_t cb) {
+    const uint32_t row0 = tile_id << 6;
+    const uint8_t *base = a.rows + (uint64_t)row0 * a.stride + (uint64_t)cb * a.CB;
     const uint32_t cols_here = min(a.CB, a.stride - cb * a.CB);
     if constexpr (ONEPASS) {
       /* host guarantees: ncb == 2, stride == 2*CB.  cb is 0 here. */
@@ -542,11 +543,11 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     resolve4(q, pos0);
   };
 
-  uint64_t nt_tile = wave_global; /* next step to load */
+  uint32_t nt_tile = wave_global; /* next step to load */
   uint32_t nt_cb = 0;
   issue_loads(nt_tile, nt_cb);
-  for (uint64_t tile_id = wave_global; tile_id < ntiles; tile_id += nwaves) {
-    const uint64_t row0 = tile_id << 6;
+  for (uint32_t tile_id = wave_global; tile_id < ntiles; tile_id += nwaves) {
+    const uint32_t row0 = tile_id << 6;
     km.reset(); run = 0; h2 = 0; h3 = 0;
     done = row0 + lane >= a.nreads;
     ord_row = (a.first_ord + row0 + lane) << 12;
