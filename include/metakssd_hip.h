@@ -27,6 +27,9 @@
  *   sketch_operate() membership filter               command_set.c:361-405           mk_setop_filter
  *   grouping_genomes() per-taxon table               command_set.c:866-915           mk_setop_group
  *   get_species_abundance() dictionary + lookups     command_composite.c:525-553     mk_setop_join
+ *   combco2mco() inverted index                      co2mco.c:37-66                  mk_mco_build / mk_mco_index_rows
+ *   mco_cbdco_nobin_dist() counting loop             command_dist.c:1033-1049        mk_mco_count_begin/add/finish
+ *   dist_print_nobin() / output_ctrl()               command_dist.c:1531-1690        mk_dist_print
  *
  * Conventions: plain pointers and sizes only; every function returns MK_OK (0) or a negative
  * MK_ERR_* code and never calls exit(); mk_last_error() gives the text.  One engine per GPU;
@@ -271,6 +274,51 @@ uint32_t mk_setop_group_table_size(uint64_t total_ids);
 int mk_setop_join(mk_setop *s, const uint32_t *qry_ids, const uint16_t *qry_counts, uint64_t nq, const uint32_t *ref_ids,
                   uint64_t nref, const uint64_t *bounds, uint32_t nb, const uint32_t **counts_out, uint64_t *n_out,
                   uint64_t *bounds_out);
+
+/* ---- stage II and the reference-database search ---------------------------------------------
+ * combco2mco() (co2mco.c:12-87) turns a component's combined sketch file (genome-major: combco.N + combco.index.N) into
+ * the inverted index (k-mer-id-major): mco.N = for every k-mer id in ascending order the numbers of the genomes that
+ * hold it, in genome order; mco.index.N = 2^32 cumulative row ends (32 GiB).  mco_cbdco_nobin_dist()
+ * (command_dist.c:902-1079) then counts, for every query sketch and reference genome, the k-mer ids they share
+ * (loop :1033-1049) into sharedk_ct.dat, and dist_print_nobin()/output_ctrl() (:1531-1690) print distance.out.
+ *   mk_mco_build        = the append loop + prefix sum    co2mco.c:37-59     (stable sort of (id, genome) by id)
+ *   mk_mco_index_rows   = the dense index, a slab of rows co2mco.c:59-66     (filled on the device from the row table)
+ *   mk_mco_count_*      = the shared-k-mer counting loop  command_dist.c:1033-1049
+ *   mk_dist_print       = dist_print_nobin + output_ctrl  command_dist.c:1531-1690  (host: libm + snprintf)
+ * Result pointers are library-owned pinned host memory, valid until the next build / destroy on the handle. */
+typedef struct mk_mco mk_mco;
+int mk_mco_create(int device, mk_mco **out); /* MK_ERR_NO_DEVICE without a HIP device: no CPU path */
+int mk_mco_destroy(mk_mco *m);
+const char *mk_mco_last_error(const mk_mco *m); /* m may be NULL: last error of a failed create */
+/* ids[index[cofnum]], index[cofnum + 1] = one component of a sketch directory.  gids[*n]: mco.N; row_ids / row_ends
+ * [*nrows]: the non-empty rows (ascending ids) and their cumulative ends.  The row table also stays on the device. */
+int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *index, uint32_t cofnum, const uint32_t **gids, uint64_t *n,
+                 const uint32_t **row_ids, const uint64_t **row_ends, uint64_t *nrows);
+/* rows [row0, row0 + nrows) of the dense mco.index.N of the last build (nrows <= 2^27 per call) into out[] (host) */
+int mk_mco_index_rows(mk_mco *m, uint64_t row0, uint64_t nrows, uint64_t *out);
+/* counting: begin zeroes a qry_num x ref_num matrix in HBM; every add handles one component; finish adds the matrix
+ * into ct[qry_num * ref_num] (host).  For an add, gids[ngids] is the component's mco.N (NULL: the lists of the last
+ * mk_mco_build, still on the device); the row of query id i is gids[ext_start[i] .. ext_end[i]) -- what the reference
+ * reads from the mmap'ed index (:1040-1041) -- or, with ext_start == NULL, is looked up on the device in the row table
+ * of the last build from qry_ids[i].  Sketches with qry_ctx_ct[k] == 0 are skipped (:1035). */
+int mk_mco_count_begin(mk_mco *m, uint32_t ref_num, uint32_t qry_num);
+int mk_mco_count_add(mk_mco *m, const uint32_t *gids, uint64_t ngids, const uint32_t *qry_ids, const uint64_t *ext_start,
+                     const uint64_t *ext_end, const uint64_t *qry_index, const uint32_t *qry_ctx_ct);
+int mk_mco_count_finish(mk_mco *m, uint32_t *ct);
+
+/* distance.out (host).  Options as command_dist_wrapper.c:83-92. */
+typedef struct mk_dist_opts {
+  int32_t metric;     /* -M: 0 Jaccard / MashD, 1 containment / AafD */
+  int32_t outfields;  /* -O: 0 distance, 1 + P-value and FDR, 2 + confidence intervals (default) */
+  int32_t correction; /* --correction */
+  int32_t num_neigb;  /* -N: the N best references per query, 0 = all */
+  double dthreshold;  /* -D: lines with a larger distance are dropped (default 1) */
+} mk_dist_opts;
+/* names: 256-byte records as in cofiles.stat / mcofiles.stat.  `out` is a FILE*.  MK_ERR_ARG: -N above 1024 or above
+ * ref_num (the reference gives up there, :1574), metric / outfields out of range. */
+int mk_dist_print(void *out, const mk_dist_opts *o, int32_t kmerlen, int32_t dim_rd_len, uint32_t ref_num, uint32_t qry_num,
+                  const uint32_t *ref_ctx_ct, const uint32_t *qry_ctx_ct, const char *refnames, const char *qrynames,
+                  const uint32_t *ct);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,11 @@ class FastaStateC(C.Structure):
                 ("pending", C.c_uint8 * 4096)]
 
 
+class DistOptsC(C.Structure):
+    _fields_ = [("metric", C.c_int32), ("outfields", C.c_int32), ("correction", C.c_int32), ("num_neigb", C.c_int32),
+                ("dthreshold", C.c_double)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -110,6 +115,14 @@ def _load():
         "mk_setop_add_device": [vp, vp, u64],
         "mk_setop_finish": [vp, C.POINTER(vp), C.POINTER(u64)],
         "mk_setop_result_device": [vp, C.POINTER(vp), C.POINTER(u64)],
+        "mk_mco_create": [C.c_int, C.POINTER(vp)],
+        "mk_mco_destroy": [vp],
+        "mk_mco_build": [vp, vp, vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
+        "mk_mco_index_rows": [vp, u64, u64, vp],
+        "mk_mco_count_begin": [vp, u32, u32],
+        "mk_mco_count_add": [vp, vp, u64, vp, vp, vp, vp, vp],
+        "mk_mco_count_finish": [vp, vp],
+        "mk_dist_print": [vp, C.POINTER(DistOptsC), i32, i32, u32, u32, vp, vp, vp, vp, vp],
         "mk_sketchdir_open": [C.c_char_p, C.POINTER(ParamsC), C.c_int, C.c_int, C.POINTER(vp)],
         "mk_sketchdir_add": [vp, C.c_char_p, C.POINTER(ResultC)],
         "mk_sketchdir_close": [vp],
@@ -122,6 +135,8 @@ def _load():
     lib.mk_shuf_free.restype = None
     lib.mk_setop_last_error.argtypes = [vp]
     lib.mk_setop_last_error.restype = C.c_char_p
+    lib.mk_mco_last_error.argtypes = [vp]
+    lib.mk_mco_last_error.restype = C.c_char_p
     lib.mk_setop_stream.argtypes = [vp]
     lib.mk_setop_stream.restype = vp
     lib.mk_last_error.argtypes = [vp]
@@ -402,3 +417,92 @@ class SetOp:
         if self.h:
             lib.mk_setop_destroy(self.h)
             self.h = C.c_void_p()
+
+
+class Mco:
+    """stage II inverted index and shared-k-mer counting on the device (mk_mco_*)"""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib.mk_mco_create(device, C.byref(self.h))
+        if rc:
+            raise MkError(rc, (lib.mk_mco_last_error(None) or b"").decode())
+
+    def _check(self, rc):
+        if rc:
+            raise MkError(rc, (lib.mk_mco_last_error(self.h) or b"").decode())
+
+    def build(self, ids, index):
+        """ids: uint32 (one component's combco.N), index: uint64[cofnum + 1] -> (gids, row_ids, row_ends)"""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        index = np.ascontiguousarray(index, dtype=np.uint64)
+        g, ri, re_ = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n, nr = C.c_uint64(0), C.c_uint64(0)
+        self._check(lib.mk_mco_build(self.h, ids.ctypes.data if ids.size else None, index.ctypes.data, index.size - 1, C.byref(g),
+                                     C.byref(n), C.byref(ri), C.byref(re_), C.byref(nr)))
+
+        def arr(p, ct, k):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(k,)).copy() if k else np.zeros(0, ct)
+        return arr(g, C.c_uint32, n.value), arr(ri, C.c_uint32, nr.value), arr(re_, C.c_uint64, nr.value)
+
+    def index_rows(self, row0, nrows):
+        out = np.empty(nrows, np.uint64)
+        self._check(lib.mk_mco_index_rows(self.h, row0, nrows, out.ctypes.data if nrows else None))
+        return out
+
+    def count(self, ref_num, qry_index, qry_ctx_ct, components):
+        """components: iterable of dicts {gids (or None: last build), qry_ids, ext_start, ext_end (or None: device row table)};
+        qry_index per component inside the dict.  Returns the qry_num x ref_num uint32 matrix."""
+        qry_num = len(qry_ctx_ct)
+        self._check(lib.mk_mco_count_begin(self.h, ref_num, qry_num))
+        ctx = np.ascontiguousarray(qry_ctx_ct, dtype=np.uint32)
+        for comp in components:
+            qi = np.ascontiguousarray(comp.get("qry_index", qry_index), dtype=np.uint64)
+            gids = comp.get("gids")
+            gids = None if gids is None else np.ascontiguousarray(gids, dtype=np.uint32)
+            qids = comp.get("qry_ids")
+            qids = None if qids is None else np.ascontiguousarray(qids, dtype=np.uint32)
+            es, ee = comp.get("ext_start"), comp.get("ext_end")
+            es = None if es is None else np.ascontiguousarray(es, dtype=np.uint64)
+            ee = None if ee is None else np.ascontiguousarray(ee, dtype=np.uint64)
+            self._check(lib.mk_mco_count_add(self.h, gids.ctypes.data if gids is not None and gids.size else (None if gids is None else 0),
+                                             0 if gids is None else gids.size,
+                                             qids.ctypes.data if qids is not None and qids.size else None,
+                                             es.ctypes.data if es is not None else None, ee.ctypes.data if ee is not None else None,
+                                             qi.ctypes.data, ctx.ctypes.data if ctx.size else None))
+        ct = np.zeros((qry_num, ref_num), np.uint32)
+        if ct.size:
+            self._check(lib.mk_mco_count_finish(self.h, ct.ctypes.data))
+        return ct
+
+    def close(self):
+        if self.h:
+            lib.mk_mco_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def dist_print(path, ref_ctx_ct, qry_ctx_ct, refnames, qrynames, ct, kmerlen, dim_rd_len, metric=0, outfields=2, correction=0,
+               num_neigb=0, dthreshold=1.0):
+    """write distance.out through mk_dist_print (host code: needs no GPU); names: lists of str"""
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+
+    def pack(names):
+        b = bytearray(256 * len(names))
+        for i, nm in enumerate(names):
+            e = nm.encode()[:255]
+            b[256 * i:256 * i + len(e)] = e
+        return bytes(b)
+    rn, qn = pack(refnames), pack(qrynames)
+    rc_, qc_ = np.ascontiguousarray(ref_ctx_ct, dtype=np.uint32), np.ascontiguousarray(qry_ctx_ct, dtype=np.uint32)
+    ct = np.ascontiguousarray(ct, dtype=np.uint32)
+    o = DistOptsC(metric, outfields, correction, num_neigb, dthreshold)
+    fp = libc.fopen(path.encode(), b"w")
+    if not fp:
+        raise OSError("cannot open %s" % path)
+    rc = lib.mk_dist_print(fp, C.byref(o), kmerlen, dim_rd_len, rc_.size, qc_.size, rc_.ctypes.data if rc_.size else None,
+                           qc_.ctypes.data if qc_.size else None, rn, qn, ct.ctypes.data if ct.size else None)
+    libc.fclose(fp)
+    return rc

@@ -362,6 +362,9 @@ static void *pf_worker(void *arg) {
 static void usage(void) {
   fprintf(stderr,
           "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D] <fastq|fasta|dir>...\n"
+          "       metakssd dist -o <mco dir> <sketch dir>                      (stage II: inverted index)\n"
+          "       metakssd dist -L <file.shuf> -r <genomes> -o <db dir>         (stage I + II)\n"
+          "       metakssd dist -r <mco dir> -o <outdir> [-M 0|1] [-O 0|1|2] [-N n] [-D d] [--correction 0|1] [--keepskf] [-f skf] <sketch dir>\n"
           "       metakssd set -u|-q|-i <pan dir>|-s <pan dir>|-g <tax.tsv>|-c|-P [-o outdir] [--device D] <sketch dir>\n"
           "       metakssd composite -r <marker db dir> -q <-A sketch dir> [-b] [-o outdir] [--device D]\n"
           "       metakssd composite -d <x.abv>...\n"
@@ -986,6 +989,203 @@ static int cmd_shuffle(int argc, char **argv) {
   return 0;
 }
 
+
+/* ---- stage II and `dist -r` ---------------------------------------------------------------------- */
+static int dir_has(const char *dir, const char *name) { /* test_get_fullpath(), command_dist.c:318-338 */
+  char path[PATHLEN * 2 + 32];
+  struct stat st;
+  if (stat(dir, &st) != 0 || !S_ISDIR(st.st_mode)) return 0;
+  snprintf(path, sizeof path, "%s/%s", dir, name);
+  FILE *f = fopen(path, "rb");
+  if (!f) return 0;
+  fclose(f);
+  return 1;
+}
+
+/* run_stageII() + combco2mco() (command_dist.c:504-552, co2mco.c:12-87): mcofiles.stat, mco.N, mco.index.N */
+static int run_stage2(const char *codir, const char *mcodir, int device, int quiet) {
+  char path[PATHLEN * 2 + 32];
+  size_t sn = 0;
+  snprintf(path, sizeof path, "%s/cofiles.stat", codir);
+  uint8_t *st = read_whole(path, &sn);
+  if (!st || sn < 32) die("run_stageII(():%s", path);
+  int32_t comp_num, cofnum;
+  memcpy(&comp_num, st + 16, 4); memcpy(&cofnum, st + 20, 4);
+  if (sn < 32 + (size_t)cofnum * (4 + PATHLEN)) die("run_stageII(():%s", path);
+  if (mkdir(mcodir, 0700)) {
+    if (errno == EEXIST) printf("Warning: write mco file to an exists outdir:%s\n", mcodir);
+    else die("run_stageII(): mkdir %s error", mcodir);
+  }
+  snprintf(path, sizeof path, "%s/mcofiles.stat", mcodir);
+  FILE *f = fopen(path, "wb");
+  if (!f) die("run_stageII(():%s", path);
+  fwrite(st, 4, 1, f);                                   /* mco_dstat_t: shuf_id, */
+  fwrite(st + 8, 4, 4, f);                               /* kmerlen, dim_rd_len, comp_num, infile_num (command_dist.h:66-75) */
+  fwrite(st + 32, 1, (size_t)cofnum * (4 + PATHLEN), f); /* per-sketch k-mer counts, names */
+  if (fclose(f)) die("run_stageII(():%s", path);
+  mk_mco *m;
+  if (mk_mco_create(device, &m) != MK_OK) die("mk_mco_create failed: %s", mk_mco_last_error(NULL));
+  const uint64_t slab = 1ull << 27;
+  uint64_t *rows = malloc(slab * 8);
+  if (!rows) die("out of memory");
+  for (int c = 0; c < comp_num; c++) {
+    size_t nb = 0, ib = 0;
+    snprintf(path, sizeof path, "%s/combco.index.%d", codir, c);
+    uint8_t *idx = read_whole(path, &ib);
+    if (!idx || ib < 8 * ((size_t)cofnum + 1)) die("%s", path);
+    snprintf(path, sizeof path, "%s/combco.%d", codir, c);
+    uint8_t *ids = read_whole(path, &nb);
+    if (!ids || nb / 4 < ((const uint64_t *)idx)[cofnum]) die("%s", path);
+    const uint32_t *gids, *row_ids;
+    const uint64_t *row_ends;
+    uint64_t n, nrows;
+    int rc = mk_mco_build(m, (const uint32_t *)ids, (const uint64_t *)idx, (uint32_t)cofnum, &gids, &n, &row_ids, &row_ends, &nrows);
+    if (rc != MK_OK) die("mk_mco_build failed (%d): %s", rc, mk_mco_last_error(m));
+    free(ids); free(idx);
+    snprintf(path, sizeof path, "%s/mco.index.%d", mcodir, c);
+    f = fopen(path, "wb");
+    if (!f) die("%s", path);
+    for (uint64_t r0 = 0; r0 < (1ull << 32); r0 += slab) { /* 1LLU << 4*COMPONENT_SZ rows, co2mco.c:19, 63-66 */
+      rc = mk_mco_index_rows(m, r0, slab, rows);
+      if (rc != MK_OK) die("mk_mco_index_rows failed (%d): %s", rc, mk_mco_last_error(m));
+      if (fwrite(rows, 8, slab, f) != slab) die("%s: write failed", path);
+    }
+    if (fclose(f)) die("%s: write failed", path);
+    snprintf(path, sizeof path, "%s/mco.%d", mcodir, c);
+    f = fopen(path, "wb");
+    if (!f) die("combco2mco()::%s", path);
+    if (n && fwrite(gids, 4, n, f) != n) die("%s: write failed", path);
+    if (fclose(f)) die("%s: write failed", path);
+    if (!quiet) printf("component %d: %llu ids in %llu rows\n", c, (unsigned long long)n, (unsigned long long)nrows);
+  }
+  free(rows); free(st);
+  mk_mco_destroy(m);
+  return 0;
+}
+
+static void *map_whole(const char *path, size_t *n) {
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return NULL;
+  struct stat st;
+  if (fstat(fd, &st) != 0) { close(fd); return NULL; }
+  *n = (size_t)st.st_size;
+  void *p = st.st_size ? mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : NULL;
+  close(fd);
+  return p == MAP_FAILED ? NULL : p;
+}
+
+typedef struct {
+  const uint64_t *index;
+  const uint32_t *ids;
+  uint64_t *es, *ee;
+  uint64_t lo, hi;
+} extent_job;
+
+static void *extent_worker(void *arg) { /* command_dist.c:1040-1041: the row of k-mer id `ind` in the mmap'ed index */
+  extent_job *j = arg;
+  for (uint64_t i = j->lo; i < j->hi; i++) {
+    const uint32_t ind = j->ids[i];
+    j->es[i] = ind > 0 ? j->index[ind - 1] : 0;
+    j->ee[i] = j->index[ind];
+  }
+  return NULL;
+}
+
+/* mco_cbdco_nobin_dist() (command_dist.c:902-1079): `dist -r <mco dir> -o <outdir> <sketch dir>` */
+static int run_search(const char *refdir, const char *qrydir, const char *outdir, const mk_dist_opts *o, int keep_shared, const char *skf,
+                      int device, int nthreads, int quiet) {
+  char path[PATHLEN * 2 + 32];
+  size_t rn = 0, qn = 0;
+  mkdir(outdir, 0700);
+  snprintf(path, sizeof path, "%s/mcofiles.stat", refdir);
+  uint8_t *rst = read_whole(path, &rn);
+  if (!rst || rn < 20) die("need provied mco dir path for mco_co_dist() arg 1. refmco_dstat_fpath");
+  snprintf(path, sizeof path, "%s/cofiles.stat", qrydir);
+  uint8_t *qst = read_whole(path, &qn);
+  if (!qst || qn < 32) die("need provied co dir path for mco_co_dist() arg 2.  qryco_dstat_fpath");
+  uint32_t r_shuf, q_shuf;
+  int32_t r_comp, ref_num, q_k, q_dr, q_comp, qry_num;
+  memcpy(&r_shuf, rst, 4); memcpy(&r_comp, rst + 12, 4); memcpy(&ref_num, rst + 16, 4);
+  memcpy(&q_shuf, qst, 4); memcpy(&q_k, qst + 8, 4); memcpy(&q_dr, qst + 12, 4); memcpy(&q_comp, qst + 16, 4); memcpy(&qry_num, qst + 20, 4);
+  if (q_shuf != r_shuf) die("qry shuf_id: %d not match ref shuf_id: %d\ntry regenerate .co dir and feed -s the .shuffile used to generated ref database", q_shuf, r_shuf);
+  if (q_comp != r_comp) die("qry comp_num: %d not match ref comp_num: %d", q_comp, r_comp);
+  if (rn < 20 + (size_t)ref_num * (4 + PATHLEN) || qn < 32 + (size_t)qry_num * (4 + PATHLEN)) die("truncated stat file under %s or %s", refdir, qrydir);
+  const uint32_t *ref_ct = (const uint32_t *)(rst + 20), *qry_ct = (const uint32_t *)(qst + 32);
+  const char *refnames = (const char *)rst + 20 + 4 * (size_t)ref_num, *qrynames = (const char *)qst + 32 + 4 * (size_t)qry_num;
+  const size_t cells = (size_t)ref_num * (size_t)qry_num;
+  char skpath[PATHLEN * 2 + 32];
+  snprintf(skpath, sizeof skpath, "%s/sharedk_ct.dat", outdir);
+  uint32_t *ct = NULL;
+  if (skf && skf[0]) { /* -f: print from an earlier run's counts (:987-990) */
+    size_t sb = 0;
+    snprintf(skpath, sizeof skpath, "%s", skf);
+    ct = (uint32_t *)read_whole(skpath, &sb);
+    if (!ct || sb < cells * 4) die("open %s failed", skpath);
+  } else {
+    FILE *probe = fopen(skpath, "rb");
+    if (probe) { fclose(probe); die(" mco_cbdco_nobin_dist():%s: File exists", skpath); } /* :954-960 */
+    ct = calloc(cells + 1, 4);
+    if (!ct) die("out of memory");
+    if (!quiet) printf("disf_sz=%lu\trefnum=%d\tqrynum=%d\tnum_mapping_distf=%d\tbatch_qrynum=%d\t%lu\t%lu\n", (unsigned long)(cells * 4), ref_num,
+                       qry_num, 0, qry_num, (unsigned long)(cells * 4), 0ul);
+    mk_mco *m;
+    if (mk_mco_create(device, &m) != MK_OK) die("mk_mco_create failed: %s", mk_mco_last_error(NULL));
+    int rc = mk_mco_count_begin(m, (uint32_t)ref_num, (uint32_t)qry_num);
+    if (rc != MK_OK) die("mk_mco_count_begin failed (%d): %s", rc, mk_mco_last_error(m));
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    for (int c = 0; c < r_comp; c++) {
+      size_t gb = 0, xb = 0, ib = 0, cb = 0;
+      snprintf(path, sizeof path, "%s/mco.index.%d", refdir, c);
+      const uint64_t *index = map_whole(path, &xb);
+      if (!index || xb != (8ull << 32)) die("%s: not a 2^32-row index", path);
+      snprintf(path, sizeof path, "%s/mco.%d", refdir, c);
+      const uint32_t *gids = map_whole(path, &gb);
+      if (!gids && gb) die("%s", path);
+      snprintf(path, sizeof path, "%s/combco.index.%d", qrydir, c);
+      uint8_t *qidx = read_whole(path, &ib);
+      if (!qidx || ib < 8 * ((size_t)qry_num + 1)) die("%s", path);
+      snprintf(path, sizeof path, "%s/combco.%d", qrydir, c);
+      uint8_t *qids = read_whole(path, &cb);
+      const uint64_t nq = ((const uint64_t *)qidx)[qry_num];
+      if (!qids || cb / 4 < nq) die("%s", path);
+      uint64_t *es = malloc(8 * (nq + 1)), *ee = malloc(8 * (nq + 1));
+      if (!es || !ee) die("out of memory");
+      pthread_t th[64];
+      extent_job jobs[64];
+      int started = 0;
+      for (int t = 0; t < nthreads; t++) {
+        jobs[t] = (extent_job){index, (const uint32_t *)qids, es, ee, nq * (uint64_t)t / (uint64_t)nthreads, nq * (uint64_t)(t + 1) / (uint64_t)nthreads};
+        if (t + 1 == nthreads || pthread_create(&th[started], NULL, extent_worker, &jobs[t]) != 0) extent_worker(&jobs[t]);
+        else started++;
+      }
+      for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+      rc = mk_mco_count_add(m, gids, gb / 4, NULL, es, ee, (const uint64_t *)qidx, qry_ct);
+      if (rc != MK_OK) die("mk_mco_count_add failed (%d): %s", rc, mk_mco_last_error(m));
+      free(es); free(ee); free(qids); free(qidx);
+      munmap((void *)index, xb);
+      if (gids) munmap((void *)gids, gb);
+    }
+    rc = mk_mco_count_finish(m, ct);
+    if (rc != MK_OK) die("mk_mco_count_finish failed (%d): %s", rc, mk_mco_last_error(m));
+    mk_mco_destroy(m);
+    FILE *sk = fopen(skpath, "wb");
+    if (!sk) die(" mco_cbdco_nobin_dist()::%s", skpath);
+    if (cells && fwrite(ct, 4, cells, sk) != cells) die("%s: write failed", skpath);
+    if (fclose(sk)) die("%s: write failed", skpath);
+  }
+  snprintf(path, sizeof path, "%s/distance.out", outdir);
+  FILE *fp = fopen(path, "w");
+  if (!fp) die("dist_print_nobin():%s", path);
+  if (o->num_neigb > 1024 || o->num_neigb > ref_num) die("neighborN_max %d should smaller than NREF %d and ref_num %d", o->num_neigb, 1024, ref_num);
+  int rc = mk_dist_print(fp, o, q_k, q_dr, (uint32_t)ref_num, (uint32_t)qry_num, ref_ct, qry_ct, refnames, qrynames, ct);
+  if (rc != MK_OK) die("mk_dist_print failed (%d)", rc);
+  if (fclose(fp)) die("%s: write failed", path);
+  if (!keep_shared) remove(skpath); /* :1633 (also a file given with -f) */
+  free(ct); free(rst); free(qst);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   setvbuf(stdout, NULL, _IOLBF, 0);
   if (argc < 2) usage();
@@ -997,6 +1197,9 @@ int main(int argc, char **argv) {
   const char *shuf_path = NULL, *outdir = ".";
   int abundance = 0, uniq = 0, device = 0, quiet = 0, nthreads = 8;
   int kmerocrs = 1, kmerqlty = 0; /* command_dist_wrapper.c:79-80 */
+  const char *refpath = NULL, *skf = NULL;
+  mk_dist_opts dopt = {0, 2, 0, 0, 1.0}; /* command_dist_wrapper.c:83-87 */
+  int keep_shared = 0, stage2_after = 0;
   strlist args = {0};
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "-L") && i + 1 < argc) shuf_path = argv[++i];
@@ -1013,8 +1216,38 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "-Q") && i + 1 < argc) kmerqlty = atoi(argv[++i]); /* :182-185 */
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--quiet")) quiet = 1;
+    else if (!strcmp(argv[i], "-r") && i + 1 < argc) refpath = argv[++i];
+    else if (!strcmp(argv[i], "-M") && i + 1 < argc) dopt.metric = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-O") && i + 1 < argc) dopt.outfields = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-N") && i + 1 < argc) dopt.num_neigb = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-D") && i + 1 < argc) dopt.dthreshold = atof(argv[++i]);
+    else if (!strcmp(argv[i], "--correction") && i + 1 < argc) dopt.correction = atoi(argv[++i]);
+    else if (!strncmp(argv[i], "--correction=", 13)) dopt.correction = atoi(argv[i] + 13);
+    else if (!strcmp(argv[i], "--keepskf")) keep_shared = 1;
+    else if (!strcmp(argv[i], "-f") && i + 1 < argc) skf = argv[++i];
     else if (argv[i][0] == '-' && argv[i][1]) die("option %s is not part of the sketching path built here", argv[i]);
     else sl_push(&args, argv[i]);
+  }
+  /* dist_dispatch(), command_dist.c:49-250: what the arguments are decides the mode */
+  if (refpath) {
+    if (dopt.metric < 0 || dopt.metric > 1 || dopt.outfields < 0 || dopt.outfields > 2) die("-M takes 0/1 and -O 0/1/2");
+    const int ref_co = dir_has(refpath, "cofiles.stat"), ref_mco = dir_has(refpath, "mcofiles.stat");
+    if (ref_co && !ref_mco) run_stage2(refpath, refpath, device, quiet); /* :119-122: the index goes next to the sketches */
+    if (ref_co || ref_mco) {
+      if (args.n == 0) return 0;
+      if (dir_has(args.v[0], "mcofiles.stat") && !dir_has(args.v[0], "cofiles.stat"))
+        die("when -r specified, the query sould not be .mco format, the valid query format shoulde be .fas/.fq file or .co");
+      if (!dir_has(args.v[0], "cofiles.stat")) die("please specify valid query genomes seq or .co file for database search");
+      return run_search(refpath, args.v[0], outdir, &dopt, keep_shared, skf, device, nthreads, quiet);
+    }
+    /* raw sequences: stage I into outdir (no abundances, :111), then stage II in place (:112-114) */
+    args.n = 0;
+    sl_push(&args, refpath);
+    abundance = 0;
+    stage2_after = 1;
+  } else if (args.n >= 1 && dir_has(args.v[0], "cofiles.stat")) {
+    if (args.n > 1) die("combining several sketch directories (combine_queries) is not part of this build");
+    return run_stage2(args.v[0], outdir, device, quiet); /* :187-190 */
   }
   if (!shuf_path) die("-L <file.shuf> is required (numeric levels generate a time-seeded table in the reference; use `metakssd shuffle`)");
   if (args.n == 0) die("please specify the input/query files");
@@ -1126,5 +1359,6 @@ int main(int argc, char **argv) {
   mk_engine_destroy(c.eng);
   if (dbg) fprintf(stderr, "[t] + teardown: %.3f s\n", now_s() - t0);
   mk_shuf_free(&sh);
+  if (stage2_after) return run_stage2(outdir, outdir, device, quiet);
   return 0;
 }

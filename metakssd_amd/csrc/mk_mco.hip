@@ -1,0 +1,520 @@
+/*
+ * mk_mco.hip -- stage II (inverted index) and the reference-database search on the device.
+ *
+ * combco2mco() (co2mco.c:12-87) appends, genome after genome, the genome's number to the row of every k-mer id it holds
+ * and writes the rows in id order; mco_cbdco_nobin_dist() (command_dist.c:1033-1049) walks, for every id of a query
+ * sketch, the id's row and bumps ct[query][genome].  Both are byte/integer work with no contraction: HBM- and
+ * atomic-bound, MFMA does not apply.
+ *
+ *   mk_mco_gid_kernel       position in combco.N -> genome number (binary search in combco.index.N)
+ *   rocprim::radix_sort_pairs   (id, genome) by id, stable: a row keeps the genome order in which the reference appends.
+ *                           The sort is the one library primitive on this path (a plain LSD radix sort, like a plain
+ *                           GEMM would go to hipBLASLt); everything around it is written here
+ *   mk_mco_rowcount / rowscan / rowwrite   ordered compaction of the row ends: the non-empty rows and their cumulative ends
+ *   mk_mco_index_kernel     a slab of the dense 2^32-entry mco.index.N filled from the row table
+ *   mk_mco_extent_kernel    query id -> its row's extent (device row table; the CLI takes extents from the mmap'ed index)
+ *   mk_mco_count_kernel     the counting loop: one workgroup per slice of a query sketch, counters in LDS (one per
+ *                           reference genome, up to 32 768) flushed once per slice; global atomics above that
+ */
+#include <hip/hip_runtime.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "metakssd_hip.h"
+
+#define MK_MCO_CHUNK 1024u          /* positions per wave in the compaction passes: 16 per lane */
+#define MK_MCO_SLAB_ROWS (1ull << 27) /* dense-index rows per mk_mco_index_rows call (1 GiB) */
+#define MK_MCO_LDS_REFS 32768u      /* reference genomes whose counters fit in LDS (128 KiB) */
+#define MK_MCO_SLICE 16384u         /* query ids per work item */
+
+struct mk_mco_item {
+  unsigned long long a; /* first position in the component's query id list */
+  uint32_t len, k;      /* ids in the slice; query sketch */
+};
+
+struct mk_mco {
+  int device = 0, num_cu = 256;
+  hipStream_t stream = nullptr;
+  /* build */
+  uint32_t *d_key[2] = {nullptr, nullptr}, *d_val[2] = {nullptr, nullptr};
+  uint64_t pair_cap = 0;
+  void *d_tmp = nullptr;
+  size_t tmp_cap = 0;
+  unsigned long long *d_index = nullptr;
+  uint64_t index_cap = 0;
+  uint32_t *d_chunk = nullptr;
+  unsigned long long *d_chunk_off = nullptr, *d_total = nullptr, *h_total = nullptr;
+  uint64_t chunk_cap = 0;
+  uint32_t *d_row_ids = nullptr;
+  unsigned long long *d_row_ends = nullptr;
+  uint64_t row_cap = 0, nrows = 0, n = 0;
+  bool built = false;
+  uint32_t *h_gids = nullptr, *h_row_ids = nullptr;
+  unsigned long long *h_row_ends = nullptr;
+  uint64_t h_gid_cap = 0, h_row_cap = 0;
+  unsigned long long *d_slab = nullptr;
+  /* count */
+  uint32_t *d_ct = nullptr;
+  uint64_t ct_cap = 0;
+  uint32_t ref_num = 0, qry_num = 0;
+  bool counting = false;
+  uint32_t *d_gids = nullptr;
+  uint64_t gids_cap = 0;
+  uint32_t *d_qids = nullptr;
+  unsigned long long *d_es = nullptr, *d_ee = nullptr;
+  uint64_t q_cap = 0;
+  mk_mco_item *d_items = nullptr;
+  uint64_t item_cap = 0;
+  bool lds_configured = false;
+  char err[256] = {0};
+};
+
+static thread_local char mk_mco_create_err[256];
+
+static int mk_mco_fail(mk_mco *m, int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(m ? m->err : mk_mco_create_err, 256, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define MK_MCO_HIP(m, call)                                                                          \
+  do {                                                                                               \
+    hipError_t _r = (call);                                                                          \
+    if (_r != hipSuccess) return mk_mco_fail(m, MK_ERR_HIP, "%s: %s", #call, hipGetErrorString(_r)); \
+  } while (0)
+
+template <class T>
+static int mk_mco_grow(mk_mco *m, T **p, uint64_t *cap, uint64_t need) {
+  if (need <= *cap && *p) return MK_OK;
+  (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  const uint64_t c = need + need / 8 + 1024;
+  MK_MCO_HIP(m, hipMalloc((void **)p, c * sizeof(T)));
+  *cap = c;
+  return MK_OK;
+}
+
+/* ---- kernels ------------------------------------------------------------------------------------------ */
+
+/* number of entries of a[0..n) that are <= x */
+template <class T, class X>
+__device__ __forceinline__ uint64_t mk_mco_upper(const T *a, uint64_t lo, uint64_t hi, X x) {
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if ((X)a[mid] <= x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+/* co2mco.c:37-39: position k of the combined file belongs to genome j with index[j] <= k < index[j+1] */
+__global__ void __launch_bounds__(256) mk_mco_gid_kernel(const unsigned long long *index, uint32_t cofnum, uint64_t n, uint32_t *gid) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    gid[i] = (uint32_t)(mk_mco_upper(index, 0, (uint64_t)cofnum + 1, (unsigned long long)i) - 1);
+}
+
+__device__ __forceinline__ uint32_t mk_mco_ends16(const uint32_t *key, uint64_t i0, uint64_t n) {
+  uint32_t flags = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) {
+    const uint64_t i = i0 + k;
+    if (i < n && (i + 1 == n || key[i] != key[i + 1])) flags |= 1u << k;
+  }
+  return flags;
+}
+
+__global__ void __launch_bounds__(256) mk_mco_rowcount_kernel(const uint32_t *key, uint64_t n, uint64_t nchunks, uint32_t *chunk_count) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (chunk >= nchunks) return;
+  uint32_t c = __popc(mk_mco_ends16(key, chunk * MK_MCO_CHUNK + 16u * lane, n));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if (lane == 0) chunk_count[chunk] = c;
+}
+
+/* exclusive prefix over the chunk counts: one workgroup, each thread a contiguous slice */
+__global__ void __launch_bounds__(1024) mk_mco_rowscan_kernel(const uint32_t *count, uint64_t nchunks, unsigned long long *off,
+                                                             unsigned long long *total) {
+  __shared__ unsigned long long part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint64_t per = (nchunks + 1023u) / 1024u, lo = (uint64_t)t * per < nchunks ? (uint64_t)t * per : nchunks,
+                 hi = lo + per < nchunks ? lo + per : nchunks;
+  unsigned long long sum = 0;
+  for (uint64_t k = lo; k < hi; k++) sum += count[k];
+  part[t] = sum;
+  __syncthreads();
+  for (uint32_t o = 1; o < 1024u; o <<= 1) {
+    const unsigned long long v = t >= o ? part[t - o] : 0ull;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned long long run = part[t] - sum;
+  for (uint64_t k = lo; k < hi; k++) { off[k] = run; run += count[k]; }
+  if (t == 1023u) *total = part[t];
+}
+
+/* co2mco.c:59: the cumulative row ends, kept only where a row ends */
+__global__ void __launch_bounds__(256) mk_mco_rowwrite_kernel(const uint32_t *key, uint64_t n, uint64_t nchunks, const uint32_t *chunk_count,
+                                                              const unsigned long long *chunk_off, uint32_t *row_ids,
+                                                              unsigned long long *row_ends) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (chunk >= nchunks || chunk_count[chunk] == 0u) return; /* wave-uniform */
+  const uint64_t i0 = chunk * MK_MCO_CHUNK + 16u * lane;
+  const uint32_t flags = mk_mco_ends16(key, i0, n);
+  const uint32_t mine = __popc(flags);
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(incl, off, 64);
+    if ((int)lane >= off) incl += u;
+  }
+  uint64_t o = chunk_off[chunk] + (incl - mine);
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++)
+    if ((flags >> k) & 1u) { row_ids[o] = key[i0 + k]; row_ends[o] = i0 + k + 1; o++; }
+}
+
+/* co2mco.c:59-66: out[r - row0] = cumulative end of the last non-empty row <= r (0 before the first one) */
+__global__ void __launch_bounds__(256) mk_mco_index_kernel(const uint32_t *row_ids, const unsigned long long *row_ends, uint64_t nrows_tab,
+                                                           uint64_t row0, uint64_t nrows, unsigned long long *out) {
+  const uint64_t b0 = (uint64_t)blockIdx.x * blockDim.x;
+  if (b0 >= nrows) return;
+  const uint64_t last = b0 + blockDim.x - 1 < nrows ? b0 + blockDim.x - 1 : nrows - 1;
+  /* the block's rows see table positions [lo, hi]: both searches run on block-uniform values */
+  const uint64_t lo = mk_mco_upper(row_ids, 0, nrows_tab, (uint64_t)(row0 + b0));
+  const uint64_t hi = mk_mco_upper(row_ids, lo, nrows_tab, (uint64_t)(row0 + last));
+  const uint64_t r = b0 + threadIdx.x;
+  if (r >= nrows) return;
+  const uint64_t u = mk_mco_upper(row_ids, lo ? lo - 1 : 0, hi, (uint64_t)(row0 + r));
+  out[r] = u ? row_ends[u - 1] : 0ull;
+}
+
+/* command_dist.c:1040-1041 from the row table instead of the dense index */
+__global__ void __launch_bounds__(256) mk_mco_extent_kernel(const uint32_t *qids, uint64_t nq, const uint32_t *row_ids,
+                                                            const unsigned long long *row_ends, uint64_t nrows_tab,
+                                                            unsigned long long *es, unsigned long long *ee) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t id = qids[i];
+    const uint64_t u = mk_mco_upper(row_ids, 0, nrows_tab, (uint64_t)id); /* rows <= id */
+    unsigned long long s = 0, e = 0;
+    if (u && row_ids[u - 1] == id) { e = row_ends[u - 1]; s = u > 1 ? row_ends[u - 2] : 0ull; }
+    es[i] = s; ee[i] = e;
+  }
+}
+
+/* command_dist.c:1038-1045: for every id of the slice, every genome of its row: ct[query][genome]++ */
+template <bool LDS>
+__global__ void __launch_bounds__(1024) mk_mco_count_kernel(const mk_mco_item *items, uint32_t nitems, const uint32_t *gids,
+                                                            const unsigned long long *es, const unsigned long long *ee, uint32_t R,
+                                                            uint32_t *ct) {
+  extern __shared__ uint32_t mk_mco_acc[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+    const mk_mco_item item = items[it];
+    uint32_t *dst = ct + (size_t)item.k * R;
+    if (LDS) {
+      for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) mk_mco_acc[r] = 0u;
+      __syncthreads();
+    }
+    uint32_t *tgt = LDS ? mk_mco_acc : dst;
+    const unsigned long long end = item.a + item.len;
+    for (unsigned long long base = item.a + (unsigned long long)wave * 64u; base < end; base += (unsigned long long)nwaves * 64u) {
+      const unsigned long long i = base + lane;
+      unsigned long long s = 0, e = 0;
+      if (i < end) { s = es[i]; e = ee[i]; }
+      const bool wide = e - s > 32ull;
+      if (!wide)
+        for (unsigned long long g = s; g < e; g++) { /* short row: the lane walks it */
+          const uint32_t r = gids[g];
+          if (r < R) atomicAdd(&tgt[r], 1u);
+        }
+      unsigned long long m = __ballot(wide);
+      while (m) { /* long row: the wave walks it together */
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const unsigned long long ws = __shfl(s, l, 64), we = __shfl(e, l, 64);
+        for (unsigned long long g = ws + lane; g < we; g += 64u) {
+          const uint32_t r = gids[g];
+          if (r < R) atomicAdd(&tgt[r], 1u);
+        }
+      }
+    }
+    if (LDS) {
+      __syncthreads();
+      for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) {
+        const uint32_t c = mk_mco_acc[r];
+        if (c) atomicAdd(&dst[r], c);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+/* ---- host side ---------------------------------------------------------------------------------------- */
+
+extern "C" int mk_mco_create(int device, mk_mco **out) {
+  if (!out) return MK_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return mk_mco_fail(nullptr, MK_ERR_NO_DEVICE, "no HIP device: mk_mco has no CPU path");
+  if (device < 0 || device >= ndev) return mk_mco_fail(nullptr, MK_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, ndev - 1);
+  mk_mco *m = new (std::nothrow) mk_mco();
+  if (!m) return MK_ERR_NOMEM;
+  m->device = device;
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    delete m;
+    return mk_mco_fail(nullptr, MK_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device);
+  }
+  m->num_cu = prop.multiProcessorCount;
+  hipError_t r = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (r == hipSuccess) r = hipMalloc(&m->d_total, 8);
+  if (r == hipSuccess) r = hipHostMalloc((void **)&m->h_total, 8, hipHostMallocDefault);
+  if (r != hipSuccess) {
+    mk_mco_fail(nullptr, MK_ERR_NOMEM, "mco allocation: %s", hipGetErrorString(r));
+    mk_mco_destroy(m);
+    return MK_ERR_NOMEM;
+  }
+  *out = m;
+  return MK_OK;
+}
+
+extern "C" int mk_mco_destroy(mk_mco *m) {
+  if (!m) return MK_OK;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  for (int b = 0; b < 2; b++) { (void)hipFree(m->d_key[b]); (void)hipFree(m->d_val[b]); }
+  (void)hipFree(m->d_tmp); (void)hipFree(m->d_index); (void)hipFree(m->d_chunk); (void)hipFree(m->d_chunk_off);
+  (void)hipFree(m->d_total); (void)hipFree(m->d_row_ids); (void)hipFree(m->d_row_ends); (void)hipFree(m->d_slab);
+  (void)hipFree(m->d_ct); (void)hipFree(m->d_gids); (void)hipFree(m->d_qids); (void)hipFree(m->d_es); (void)hipFree(m->d_ee);
+  (void)hipFree(m->d_items);
+  if (m->h_total) (void)hipHostFree(m->h_total);
+  if (m->h_gids) (void)hipHostFree(m->h_gids);
+  if (m->h_row_ids) (void)hipHostFree(m->h_row_ids);
+  if (m->h_row_ends) (void)hipHostFree(m->h_row_ends);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+  return MK_OK;
+}
+
+extern "C" const char *mk_mco_last_error(const mk_mco *m) { return m ? m->err : mk_mco_create_err; }
+
+static unsigned mk_mco_blocks(const mk_mco *m, uint64_t n, unsigned per_block) {
+  uint64_t b = (n + per_block - 1) / per_block;
+  const uint64_t cap = (uint64_t)m->num_cu * 32u;
+  if (b > cap) b = cap;
+  return b ? (unsigned)b : 1u;
+}
+
+extern "C" int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *index, uint32_t cofnum, const uint32_t **gids, uint64_t *n_out,
+                            const uint32_t **row_ids, const uint64_t **row_ends, uint64_t *nrows_out) {
+  if (!m || !index || !gids || !n_out || !row_ids || !row_ends || !nrows_out) return MK_ERR_ARG;
+  const uint64_t n = index[cofnum];
+  if (n && !ids) return MK_ERR_ARG;
+  for (uint32_t j = 0; j < cofnum; j++)
+    if (index[j] > index[j + 1]) return mk_mco_fail(m, MK_ERR_ARG, "combco.index not ascending at sketch %u", j);
+  MK_MCO_HIP(m, hipSetDevice(m->device));
+  m->built = false;
+  m->n = n; m->nrows = 0;
+  int rc;
+  /* the result buffers exist even for an empty component */
+  if (n > m->h_gid_cap || !m->h_gids) {
+    if (m->h_gids) (void)hipHostFree(m->h_gids);
+    m->h_gids = nullptr; m->h_gid_cap = 0;
+    const uint64_t c = n + n / 8 + 1024;
+    MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_gids, c * 4, hipHostMallocDefault));
+    m->h_gid_cap = c;
+  }
+  uint64_t total = 0;
+  if (n) {
+    uint64_t cap = m->pair_cap;
+    for (int b = 0; b < 2; b++) {
+      cap = m->pair_cap;
+      if ((rc = mk_mco_grow(m, &m->d_key[b], &cap, n))) return rc;
+      cap = m->pair_cap;
+      if ((rc = mk_mco_grow(m, &m->d_val[b], &cap, n))) return rc;
+    }
+    m->pair_cap = cap;
+    if ((rc = mk_mco_grow(m, &m->d_index, &m->index_cap, (uint64_t)cofnum + 1))) return rc;
+    MK_MCO_HIP(m, hipMemcpyAsync(m->d_key[0], ids, n * 4, hipMemcpyHostToDevice, m->stream));
+    MK_MCO_HIP(m, hipMemcpyAsync(m->d_index, index, ((size_t)cofnum + 1) * 8, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(mk_mco_gid_kernel, dim3(mk_mco_blocks(m, n, 256)), dim3(256), 0, m->stream, m->d_index, cofnum, n, m->d_val[0]);
+    MK_MCO_HIP(m, hipGetLastError());
+    size_t tmp_bytes = 0;
+    MK_MCO_HIP(m, rocprim::radix_sort_pairs(nullptr, tmp_bytes, m->d_key[0], m->d_key[1], m->d_val[0], m->d_val[1], (size_t)n, 0u, 32u,
+                                            m->stream));
+    if (tmp_bytes > m->tmp_cap || !m->d_tmp) {
+      (void)hipFree(m->d_tmp);
+      m->d_tmp = nullptr; m->tmp_cap = 0;
+      MK_MCO_HIP(m, hipMalloc(&m->d_tmp, tmp_bytes + 256));
+      m->tmp_cap = tmp_bytes + 256;
+    }
+    MK_MCO_HIP(m, rocprim::radix_sort_pairs(m->d_tmp, tmp_bytes, m->d_key[0], m->d_key[1], m->d_val[0], m->d_val[1], (size_t)n, 0u, 32u,
+                                            m->stream));
+    /* row ends */
+    const uint64_t nchunks = (n + MK_MCO_CHUNK - 1) / MK_MCO_CHUNK;
+    cap = m->chunk_cap;
+    if ((rc = mk_mco_grow(m, &m->d_chunk, &cap, nchunks))) return rc;
+    if ((rc = mk_mco_grow(m, &m->d_chunk_off, &m->chunk_cap, nchunks))) return rc;
+    const unsigned cblocks = (unsigned)((nchunks + 3) / 4);
+    hipLaunchKernelGGL(mk_mco_rowcount_kernel, dim3(cblocks), dim3(256), 0, m->stream, m->d_key[1], n, nchunks, m->d_chunk);
+    hipLaunchKernelGGL(mk_mco_rowscan_kernel, dim3(1), dim3(1024), 0, m->stream, m->d_chunk, nchunks, m->d_chunk_off, m->d_total);
+    MK_MCO_HIP(m, hipGetLastError());
+    MK_MCO_HIP(m, hipMemcpyAsync(m->h_total, m->d_total, 8, hipMemcpyDeviceToHost, m->stream));
+    MK_MCO_HIP(m, hipStreamSynchronize(m->stream));
+    total = *m->h_total;
+    cap = m->row_cap;
+    if ((rc = mk_mco_grow(m, &m->d_row_ids, &cap, total))) return rc;
+    if ((rc = mk_mco_grow(m, &m->d_row_ends, &m->row_cap, total))) return rc;
+    hipLaunchKernelGGL(mk_mco_rowwrite_kernel, dim3(cblocks), dim3(256), 0, m->stream, m->d_key[1], n, nchunks, m->d_chunk,
+                       m->d_chunk_off, m->d_row_ids, m->d_row_ends);
+    MK_MCO_HIP(m, hipGetLastError());
+  }
+  if (total > m->h_row_cap || !m->h_row_ids) {
+    if (m->h_row_ids) (void)hipHostFree(m->h_row_ids);
+    if (m->h_row_ends) (void)hipHostFree(m->h_row_ends);
+    m->h_row_ids = nullptr; m->h_row_ends = nullptr; m->h_row_cap = 0;
+    const uint64_t c = total + total / 8 + 1024;
+    MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_row_ids, c * 4, hipHostMallocDefault));
+    MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_row_ends, c * 8, hipHostMallocDefault));
+    m->h_row_cap = c;
+  }
+  if (n) {
+    MK_MCO_HIP(m, hipMemcpyAsync(m->h_gids, m->d_val[1], n * 4, hipMemcpyDeviceToHost, m->stream));
+    MK_MCO_HIP(m, hipMemcpyAsync(m->h_row_ids, m->d_row_ids, total * 4, hipMemcpyDeviceToHost, m->stream));
+    MK_MCO_HIP(m, hipMemcpyAsync(m->h_row_ends, m->d_row_ends, total * 8, hipMemcpyDeviceToHost, m->stream));
+    MK_MCO_HIP(m, hipStreamSynchronize(m->stream));
+  }
+  m->nrows = total;
+  m->built = true;
+  *gids = m->h_gids; *n_out = n;
+  *row_ids = m->h_row_ids; *row_ends = (const uint64_t *)m->h_row_ends; *nrows_out = total;
+  return MK_OK;
+}
+
+extern "C" int mk_mco_index_rows(mk_mco *m, uint64_t row0, uint64_t nrows, uint64_t *out) {
+  if (!m || (nrows && !out)) return MK_ERR_ARG;
+  if (!m->built) return mk_mco_fail(m, MK_ERR_STATE, "mk_mco_index_rows before mk_mco_build");
+  if (nrows > MK_MCO_SLAB_ROWS || row0 + nrows > (1ull << 32)) return mk_mco_fail(m, MK_ERR_ARG, "row range out of bounds");
+  if (nrows == 0) return MK_OK;
+  MK_MCO_HIP(m, hipSetDevice(m->device));
+  if (!m->d_slab) MK_MCO_HIP(m, hipMalloc((void **)&m->d_slab, MK_MCO_SLAB_ROWS * 8));
+  hipLaunchKernelGGL(mk_mco_index_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, m->stream, m->d_row_ids, m->d_row_ends,
+                     m->nrows, row0, nrows, m->d_slab);
+  MK_MCO_HIP(m, hipGetLastError());
+  MK_MCO_HIP(m, hipMemcpyAsync(out, m->d_slab, nrows * 8, hipMemcpyDeviceToHost, m->stream));
+  MK_MCO_HIP(m, hipStreamSynchronize(m->stream));
+  return MK_OK;
+}
+
+extern "C" int mk_mco_count_begin(mk_mco *m, uint32_t ref_num, uint32_t qry_num) {
+  if (!m) return MK_ERR_ARG;
+  MK_MCO_HIP(m, hipSetDevice(m->device));
+  const uint64_t cells = (uint64_t)ref_num * qry_num;
+  int rc = mk_mco_grow(m, &m->d_ct, &m->ct_cap, cells ? cells : 1);
+  if (rc) return rc;
+  MK_MCO_HIP(m, hipMemsetAsync(m->d_ct, 0, (cells ? cells : 1) * 4, m->stream));
+  m->ref_num = ref_num; m->qry_num = qry_num;
+  m->counting = true;
+  return MK_OK;
+}
+
+extern "C" int mk_mco_count_add(mk_mco *m, const uint32_t *gids, uint64_t ngids, const uint32_t *qry_ids, const uint64_t *ext_start,
+                                const uint64_t *ext_end, const uint64_t *qry_index, const uint32_t *qry_ctx_ct) {
+  if (!m || !qry_index || !qry_ctx_ct) return MK_ERR_ARG;
+  if (!m->counting) return mk_mco_fail(m, MK_ERR_STATE, "mk_mco_count_add before mk_mco_count_begin");
+  if ((ext_start == nullptr) != (ext_end == nullptr)) return MK_ERR_ARG;
+  if (!gids && !m->built) return mk_mco_fail(m, MK_ERR_STATE, "no gid lists: pass them or call mk_mco_build first");
+  if (!ext_start && !m->built) return mk_mco_fail(m, MK_ERR_STATE, "no row table: pass extents or call mk_mco_build first");
+  const uint64_t nq = qry_index[m->qry_num];
+  if (nq == 0 || m->ref_num == 0) return MK_OK;
+  if (!ext_start && !qry_ids) return MK_ERR_ARG;
+  MK_MCO_HIP(m, hipSetDevice(m->device));
+  int rc;
+  const uint32_t *d_lists = m->d_val[1];
+  uint64_t nlists = m->n;
+  if (gids) {
+    if ((rc = mk_mco_grow(m, &m->d_gids, &m->gids_cap, ngids ? ngids : 1))) return rc;
+    MK_MCO_HIP(m, hipMemcpyAsync(m->d_gids, gids, ngids * 4, hipMemcpyHostToDevice, m->stream));
+    d_lists = m->d_gids;
+    nlists = ngids;
+  }
+  uint64_t cap = m->q_cap;
+  if ((rc = mk_mco_grow(m, &m->d_qids, &cap, nq))) return rc;
+  cap = m->q_cap;
+  if ((rc = mk_mco_grow(m, &m->d_es, &cap, nq))) return rc;
+  if ((rc = mk_mco_grow(m, &m->d_ee, &m->q_cap, nq))) return rc;
+  if (ext_start) {
+    for (uint64_t i = 0; i < nq; i++) /* a corrupt index must not send the kernel out of the lists */
+      if (ext_start[i] > ext_end[i] || ext_end[i] > nlists) return mk_mco_fail(m, MK_ERR_ARG, "row extent %llu out of the gid lists", (unsigned long long)i);
+    MK_MCO_HIP(m, hipMemcpyAsync(m->d_es, ext_start, nq * 8, hipMemcpyHostToDevice, m->stream));
+    MK_MCO_HIP(m, hipMemcpyAsync(m->d_ee, ext_end, nq * 8, hipMemcpyHostToDevice, m->stream));
+  } else {
+    MK_MCO_HIP(m, hipMemcpyAsync(m->d_qids, qry_ids, nq * 4, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(mk_mco_extent_kernel, dim3(mk_mco_blocks(m, nq, 256)), dim3(256), 0, m->stream, m->d_qids, nq, m->d_row_ids,
+                       m->d_row_ends, m->nrows, m->d_es, m->d_ee);
+    MK_MCO_HIP(m, hipGetLastError());
+  }
+  /* work items: slices of the sketches that count (command_dist.c:1035) */
+  std::vector<mk_mco_item> items;
+  for (uint32_t k = 0; k < m->qry_num; k++) {
+    if (qry_index[k] > qry_index[k + 1] || qry_index[k + 1] > nq) return mk_mco_fail(m, MK_ERR_ARG, "query index not ascending at sketch %u", k);
+    if (qry_ctx_ct[k] == 0) continue;
+    for (uint64_t a = qry_index[k]; a < qry_index[k + 1]; a += MK_MCO_SLICE) {
+      const uint64_t len = qry_index[k + 1] - a < MK_MCO_SLICE ? qry_index[k + 1] - a : MK_MCO_SLICE;
+      items.push_back(mk_mco_item{a, (uint32_t)len, k});
+    }
+  }
+  if (items.empty()) return MK_OK;
+  if (items.size() > 0xFFFFFFFFull) return mk_mco_fail(m, MK_ERR_ARG, "too many query slices");
+  if ((rc = mk_mco_grow(m, &m->d_items, &m->item_cap, items.size()))) return rc;
+  MK_MCO_HIP(m, hipMemcpyAsync(m->d_items, items.data(), items.size() * sizeof(mk_mco_item), hipMemcpyHostToDevice, m->stream));
+  MK_MCO_HIP(m, hipStreamSynchronize(m->stream)); /* `items` leaves scope */
+  const uint32_t nitems = (uint32_t)items.size(), R = m->ref_num;
+  /* LDS counters pay when a slice brings more increments than the R-counter zero + flush costs */
+  const bool lds = R <= MK_MCO_LDS_REFS && nq / nitems >= R / 16u;
+  if (lds) {
+    if (!m->lds_configured) {
+      MK_MCO_HIP(m, hipFuncSetAttribute((const void *)mk_mco_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(MK_MCO_LDS_REFS * 4u)));
+      m->lds_configured = true;
+    }
+    const unsigned grid = nitems < (unsigned)m->num_cu * 2u ? nitems : (unsigned)m->num_cu * 2u;
+    hipLaunchKernelGGL(mk_mco_count_kernel<true>, dim3(grid), dim3(1024), (size_t)R * 4u, m->stream, m->d_items, nitems, d_lists, m->d_es,
+                       m->d_ee, R, m->d_ct);
+  } else {
+    const unsigned grid = nitems < (unsigned)m->num_cu * 8u ? nitems : (unsigned)m->num_cu * 8u;
+    hipLaunchKernelGGL(mk_mco_count_kernel<false>, dim3(grid), dim3(1024), 0, m->stream, m->d_items, nitems, d_lists, m->d_es, m->d_ee, R,
+                       m->d_ct);
+  }
+  MK_MCO_HIP(m, hipGetLastError());
+  MK_MCO_HIP(m, hipStreamSynchronize(m->stream)); /* the caller's buffers are free again */
+  return MK_OK;
+}
+
+extern "C" int mk_mco_count_finish(mk_mco *m, uint32_t *ct) {
+  if (!m || !ct) return MK_ERR_ARG;
+  if (!m->counting) return mk_mco_fail(m, MK_ERR_STATE, "mk_mco_count_finish before mk_mco_count_begin");
+  MK_MCO_HIP(m, hipSetDevice(m->device));
+  const uint64_t cells = (uint64_t)m->ref_num * m->qry_num;
+  m->counting = false;
+  if (cells == 0) return MK_OK;
+  std::vector<uint32_t> tmp;
+  try { tmp.resize(cells); } catch (...) { return mk_mco_fail(m, MK_ERR_NOMEM, "no host memory for %llu counters", (unsigned long long)cells); }
+  MK_MCO_HIP(m, hipMemcpyAsync(tmp.data(), m->d_ct, cells * 4, hipMemcpyDeviceToHost, m->stream));
+  MK_MCO_HIP(m, hipStreamSynchronize(m->stream));
+  for (uint64_t i = 0; i < cells; i++) ct[i] += tmp[i];
+  return MK_OK;
+}

@@ -1093,3 +1093,301 @@ int ko_composite(const char *refdir, const char *qrydir, const char *outdir, int
   free(ab); free(cap); free(rst); free(qst);
   return rc;
 }
+
+
+/* ======== SURVEY.md 8f N4: stage II (`combco2mco`, co2mco.c:12-87) and `dist -r <mco> <co>` (command_dist.c:902-1079,
+ * 1531-1690) ======== */
+#include <fcntl.h>
+#include <math.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+typedef struct { uint32_t id, gid; } ko_pair;
+
+/* stable merge sort by id: a row's genome numbers come out in the order the reference appends them (co2mco.c:37-56:
+ * genomes ascending, positions ascending inside a genome) */
+static void ko_pair_msort(ko_pair *a, ko_pair *tmp, size_t n) {
+  if (n < 2) return;
+  size_t h = n / 2;
+  ko_pair_msort(a, tmp, h);
+  ko_pair_msort(a + h, tmp, n - h);
+  size_t i = 0, j = h, o = 0;
+  while (i < h && j < n) tmp[o++] = a[j].id < a[i].id ? a[j++] : a[i++];
+  while (i < h) tmp[o++] = a[i++];
+  while (j < n) tmp[o++] = a[j++];
+  memcpy(a, tmp, n * sizeof *a);
+}
+
+int ko_mco_build(const uint32_t *ids, const uint64_t *index, int cofnum, uint32_t *gids_out, uint32_t **row_ids,
+                 uint64_t **row_ends, size_t *nrows) {
+  size_t n = cofnum > 0 ? (size_t)index[cofnum] : 0, o = 0;
+  ko_pair *p = malloc(sizeof *p * (n + 1)), *t = malloc(sizeof *t * (n + 1));
+  if (!p || !t) { free(p); free(t); return KO_ERR_ARG; }
+  for (int j = 0; j < cofnum; j++)                                   /* co2mco.c:37 */
+    for (size_t k = (size_t)index[j]; k < (size_t)index[j + 1]; k++) /* :39 */
+      p[o++] = (ko_pair){ids[k], (uint32_t)j};                       /* :41, :55 */
+  ko_pair_msort(p, t, n);
+  size_t d = 0;
+  for (size_t i = 0; i < n; i++) d += i + 1 == n || p[i].id != p[i + 1].id;
+  uint32_t *ri = malloc(4 * (d + 1));
+  uint64_t *re = malloc(8 * (d + 1));
+  d = 0;
+  for (size_t i = 0; i < n; i++) {
+    gids_out[i] = p[i].gid;                                          /* :74-80: rows ascending, each row as appended */
+    if (i + 1 == n || p[i].id != p[i + 1].id) { ri[d] = p[i].id; re[d++] = i + 1; } /* :59: cumulative row ends */
+  }
+  free(p); free(t);
+  *row_ids = ri; *row_ends = re; *nrows = d;
+  return KO_OK;
+}
+
+/* mco.index.N as the reference writes it (:59-66): 2^32 cumulative row ends, 32 GiB */
+static int ko_write_dense_index(const char *path, const uint32_t *row_ids, const uint64_t *row_ends, size_t nrows) {
+  FILE *f = fopen(path, "wb");
+  if (!f) return KO_ERR_IO;
+  const size_t B = 1u << 20;
+  uint64_t *buf = malloc(8 * B);
+  size_t d = 0;
+  uint64_t cur = 0;
+  for (uint64_t r0 = 0; r0 < (1ull << 32); r0 += B) {
+    for (uint64_t r = r0; r < r0 + B; r++) {
+      if (d < nrows && row_ids[d] == r) cur = row_ends[d++];
+      buf[r - r0] = cur;
+    }
+    if (fwrite(buf, 8, B, f) != B) { fclose(f); free(buf); return KO_ERR_IO; }
+  }
+  free(buf);
+  return fclose(f) ? KO_ERR_IO : KO_OK;
+}
+
+/* run_stageII() (command_dist.c:504-552) + combco2mco(); dense_index = 0 leaves mco.index.N out (tests that cannot
+ * afford 32 GiB per component) */
+int ko_stage2(const char *codir, const char *mcodir, int dense_index) {
+  char path[KO_PATHLEN * 2];
+  size_t sn = 0;
+  snprintf(path, sizeof path, "%s/cofiles.stat", codir);
+  unsigned char *st = ko_slurp(path, &sn);
+  if (!st || sn < 32) { free(st); return KO_ERR_IO; }
+  int32_t comp_num, cofnum;
+  memcpy(&comp_num, st + 16, 4); memcpy(&cofnum, st + 20, 4);
+  mkdir(mcodir, 0700); /* :506 (an existing directory only earns a warning) */
+  snprintf(path, sizeof path, "%s/mcofiles.stat", mcodir);
+  FILE *f = fopen(path, "wb");
+  if (!f) { free(st); return KO_ERR_IO; }
+  fwrite(st, 4, 1, f);                                      /* shuf_id :527 */
+  fwrite(st + 8, 4, 4, f);                                  /* kmerlen, dim_rd_len, comp_num, infile_num :528-531 */
+  fwrite(st + 32, 1, (size_t)cofnum * (4 + KO_PATHLEN), f); /* ctx_ct list and names :534-539 */
+  fclose(f);
+  int rc = KO_OK;
+  for (int c = 0; c < comp_num && rc == KO_OK; c++) {
+    size_t nb = 0, ib = 0;
+    snprintf(path, sizeof path, "%s/combco.%d", codir, c);
+    uint32_t *ids = (uint32_t *)ko_slurp(path, &nb);
+    snprintf(path, sizeof path, "%s/combco.index.%d", codir, c);
+    uint64_t *idx = (uint64_t *)ko_slurp(path, &ib);
+    if (!ids || !idx || ib < 8 * ((size_t)cofnum + 1)) { free(ids); free(idx); rc = KO_ERR_IO; break; }
+    uint32_t *gids = malloc(4 * (nb / 4 + 1)), *ri = NULL;
+    uint64_t *re = NULL;
+    size_t nr = 0;
+    rc = ko_mco_build(ids, idx, cofnum, gids, &ri, &re, &nr);
+    if (rc == KO_OK) {
+      snprintf(path, sizeof path, "%s/mco.%d", mcodir, c);
+      f = fopen(path, "wb");
+      if (!f) rc = KO_ERR_IO;
+      else { fwrite(gids, 4, (size_t)idx[cofnum], f); fclose(f); }
+      snprintf(path, sizeof path, "%s/mco.index.%d", mcodir, c);
+      if (rc == KO_OK && dense_index) rc = ko_write_dense_index(path, ri, re, nr);
+    }
+    free(ids); free(idx); free(gids); free(ri); free(re);
+  }
+  free(st);
+  return rc;
+}
+
+/* the counting loop of mco_cbdco_nobin_dist() (command_dist.c:1033-1049) for one component; row extents either from the
+ * reference's dense index (dense != NULL: `s = ind > 0 ? index[ind-1] : 0 .. index[ind]`) or from the sparse row table */
+void ko_mco_count(const uint32_t *gids, const uint64_t *dense, const uint32_t *row_ids, const uint64_t *row_ends, size_t nrows,
+                  const uint32_t *qry_ids, const uint64_t *qry_index, int qry_num, const uint32_t *qry_ctx_ct, int ref_num,
+                  uint32_t *ct) {
+  for (int k = 0; k < qry_num; k++) {
+    if (qry_ctx_ct[k] == 0) continue;                            /* :1035 */
+    uint32_t *row = ct + (size_t)k * (size_t)ref_num;            /* :1037 */
+    for (size_t n = (size_t)qry_index[k]; n < (size_t)qry_index[k + 1]; n++) {
+      uint32_t ind = qry_ids[n];
+      uint64_t s, e;
+      if (dense) { s = ind > 0 ? dense[ind - 1] : 0; e = dense[ind]; } /* :1040-1041 */
+      else {
+        size_t lo = 0, hi = nrows;
+        while (lo < hi) { size_t m = (lo + hi) / 2; if (row_ids[m] < ind) lo = m + 1; else hi = m; }
+        if (lo == nrows || row_ids[lo] != ind) continue;
+        s = lo ? row_ends[lo - 1] : 0; e = row_ends[lo];
+      }
+      for (uint64_t g = s; g < e; g++) row[gids[g]]++;           /* :1043-1044 */
+    }
+  }
+}
+
+/* output_ctrl() (command_dist.c:1637-1680): one line of distance.out, or nothing when the distance is above the
+ * threshold.  Returns the line length (0 = suppressed). */
+static int ko_dist_line(char *line, size_t cap, const ko_dist_opts *o, int kmerlen, int dim_rd_len, long long cmprsn,
+                        const char *qname, const char *rname, unsigned X, unsigned Y, unsigned XnY) {
+  double rs = 0;
+  if (o->correction) {                                                  /* :1639-1646 */
+    unsigned xr = X - XnY, yr = Y - XnY;
+    double base = 1 - 1 / pow(4, (kmerlen - dim_rd_len));
+    double px = 1 - pow(base, xr), py = 1 - pow(base, yr);
+    rs = px * py * (xr + yr) / (px + py - 2 * px * py);
+  }
+  unsigned denom = o->metric == 0 ? X + Y - XnY : (X < Y ? X : Y);      /* :1648-1649 */
+  double metric = ((double)XnY - rs) / denom;
+  double dist = log(o->metric == 0 ? 1 / (2 * metric) + 0.5 : 1 / metric) / kmerlen; /* :1636, :1651 */
+  if (dist > 1) dist = 1;
+  if (dist > o->dthreshold) return 0;                                   /* :1653 */
+  int len = snprintf(line, cap, "%s\t%s\t%u-%u|%u|%u\t%.6lf\t%.6lf", qname, rname, XnY, (unsigned)rs, X, Y, metric, dist);
+  if (o->outfields > 0) {                                               /* :1657-1670 */
+    double sd = pow(metric * (1 - metric) / denom, 0.5);
+    double pv = 0.5 * erfc(metric / sd * pow(0.5, 0.5));
+    len += snprintf(line + len, cap - (size_t)len, "\t%E\t%E", pv, pv * cmprsn);
+    if (o->outfields > 1) {
+      double m1 = metric - 1.96 * sd, m2 = metric + 1.96 * sd;
+      double d1 = log(o->metric == 0 ? 1 / (2 * m2) + 0.5 : 1 / m2) / kmerlen;
+      double d2 = log(o->metric == 0 ? 1 / (2 * m1) + 0.5 : 1 / m1) / kmerlen;
+      len += snprintf(line + len, cap - (size_t)len, "\t[%.6lf,%.6lf]\t[%.6lf,%.6lf]", m1, m2, d1, d2);
+    }
+  }
+  len += snprintf(line + len, cap - (size_t)len, "\n");
+  return len;
+}
+
+/* dist_print_nobin() (command_dist.c:1531-1634) */
+int ko_dist_print(FILE *fp, const ko_dist_opts *o, int kmerlen, int dim_rd_len, int ref_num, int qry_num,
+                  const uint32_t *ref_ctx_ct, const uint32_t *qry_ctx_ct, const char *refnames, const char *qrynames,
+                  const uint32_t *ct) {
+  static const char *hdr[2][3] = {{"Jaccard\tMashD", "P-value(J)\tFDR(J)", "Jaccard_CI\tMashD_CI"},
+                                  {"ContainmentM\tAafD", "P-value(C)\tFDR(C)", "ContainmentM_CI\tAafD_CI"}};
+  if (o->metric < 0 || o->metric > 1 || o->outfields < 0 || o->outfields > 2) return KO_ERR_ARG;
+  fprintf(fp, "Qry\tRef\tShared_k|Ref_s|Qry_s");                        /* :1567-1570 */
+  for (int i = 0; i <= o->outfields; i++) fprintf(fp, "\t%s", hdr[o->metric][i]);
+  fprintf(fp, "\n");
+  int N = o->num_neigb;
+  if (N > 1024 || N > ref_num) return KO_ERR_ARG;                       /* :1574 */
+  long long cmprsn = (long long)((unsigned)ref_num * (unsigned)qry_num); /* :1562: unsigned product */
+  char line[1024];
+  struct { double m; int rid; } best[1025];
+  for (int q = 0; q < qry_num; q++) {
+    unsigned Y = qry_ctx_ct[q];
+    const uint32_t *row = ct + (size_t)q * (size_t)ref_num;
+    const char *qn = qrynames + (size_t)q * KO_PATHLEN;
+    if (N) {                                                            /* :1591-1618 */
+      for (int i = 0; i < N; i++) { best[i].m = 0; best[i].rid = -1; }
+      for (int r = 0; r < ref_num; r++) {
+        unsigned X = ref_ctx_ct[r], XnY = row[r];
+        double m = o->metric == 1 ? (double)XnY / (X < Y ? X : Y) : (double)XnY / (X + Y - XnY);
+        for (int i = N - 1; i >= 0; i--) {
+          if (m > best[i].m) { best[i + 1] = best[i]; best[i].m = m; best[i].rid = r; }
+          else break;
+        }
+      }
+      for (int i = 0; i < N; i++) {
+        if (best[i].rid < 0) continue;
+        int len = ko_dist_line(line, sizeof line, o, kmerlen, dim_rd_len, cmprsn, qn, refnames + (size_t)best[i].rid * KO_PATHLEN,
+                               ref_ctx_ct[best[i].rid], Y, row[best[i].rid]);
+        if (len > 1) fwrite(line, 1, (size_t)len, fp);
+      }
+    } else {
+      for (int r = 0; r < ref_num; r++) {                               /* :1620-1626 */
+        int len = ko_dist_line(line, sizeof line, o, kmerlen, dim_rd_len, cmprsn, qn, refnames + (size_t)r * KO_PATHLEN,
+                               ref_ctx_ct[r], Y, row[r]);
+        if (len > 1) fwrite(line, 1, (size_t)len, fp);
+      }
+    }
+  }
+  return KO_OK;
+}
+
+static void *ko_map_file(const char *path, size_t *n) {
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return NULL;
+  struct stat s;
+  fstat(fd, &s);
+  *n = (size_t)s.st_size;
+  void *p = s.st_size ? mmap(NULL, (size_t)s.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : NULL;
+  close(fd);
+  return p == MAP_FAILED ? NULL : p;
+}
+
+/* mco_cbdco_nobin_dist(): `dist -r <refdir> -o <outdir> <qrydir>`.  refdir holds mcofiles.stat + mco.N + the dense
+ * mco.index.N (ref_is_co = 0), or is a sketch directory whose inverted index is built in memory (ref_is_co = 1: same
+ * numbers without the 32 GiB files).  Writes distance.out and, with keep_shared, sharedk_ct.dat. */
+int ko_dist_search(const char *refdir, int ref_is_co, const char *qrydir, const char *outdir, const ko_dist_opts *o) {
+  char path[KO_PATHLEN * 2];
+  size_t rn = 0, qn = 0;
+  snprintf(path, sizeof path, "%s/%s", refdir, ref_is_co ? "cofiles.stat" : "mcofiles.stat");
+  unsigned char *rst = ko_slurp(path, &rn);
+  snprintf(path, sizeof path, "%s/cofiles.stat", qrydir);
+  unsigned char *qst = ko_slurp(path, &qn);
+  if (!rst || !qst || qn < 32 || rn < 32) { free(rst); free(qst); return KO_ERR_IO; }
+  const size_t rh = ref_is_co ? 32 : 20; /* sizeof(co_dstat_t) / sizeof(mco_dstat_t) */
+  int32_t r_shuf, r_k, r_dr, r_comp, ref_num, q_shuf, q_k, q_dr, q_comp, qry_num;
+  memcpy(&r_shuf, rst, 4);
+  memcpy(&r_k, rst + (ref_is_co ? 8 : 4), 4); memcpy(&r_dr, rst + (ref_is_co ? 12 : 8), 4);
+  memcpy(&r_comp, rst + (ref_is_co ? 16 : 12), 4); memcpy(&ref_num, rst + (ref_is_co ? 20 : 16), 4);
+  memcpy(&q_shuf, qst, 4); memcpy(&q_k, qst + 8, 4); memcpy(&q_dr, qst + 12, 4); memcpy(&q_comp, qst + 16, 4);
+  memcpy(&qry_num, qst + 20, 4);
+  (void)r_k; (void)r_dr;
+  if (r_comp != q_comp || r_shuf != q_shuf) { free(rst); free(qst); return KO_ERR_ARG; } /* :944-949 */
+  const uint32_t *ref_ct = (const uint32_t *)(rst + rh), *qry_ct = (const uint32_t *)(qst + 32);
+  const char *refnames = (const char *)rst + rh + 4 * (size_t)ref_num, *qrynames = (const char *)qst + 32 + 4 * (size_t)qry_num;
+  mkdir(outdir, 0700);
+  uint32_t *ct = calloc((size_t)ref_num * (size_t)qry_num + 1, 4);
+  int rc = KO_OK;
+  for (int c = 0; c < r_comp && rc == KO_OK; c++) {
+    size_t a = 0, b = 0, g = 0, x = 0;
+    snprintf(path, sizeof path, "%s/combco.%d", qrydir, c);
+    uint32_t *qids = (uint32_t *)ko_slurp(path, &a);
+    snprintf(path, sizeof path, "%s/combco.index.%d", qrydir, c);
+    uint64_t *qidx = (uint64_t *)ko_slurp(path, &b);
+    if (!qids || !qidx) { free(qids); free(qidx); rc = KO_ERR_IO; break; }
+    if (ref_is_co) {
+      snprintf(path, sizeof path, "%s/combco.%d", refdir, c);
+      uint32_t *rids = (uint32_t *)ko_slurp(path, &g);
+      snprintf(path, sizeof path, "%s/combco.index.%d", refdir, c);
+      uint64_t *ridx = (uint64_t *)ko_slurp(path, &x);
+      if (!rids || !ridx) { free(rids); free(ridx); free(qids); free(qidx); rc = KO_ERR_IO; break; }
+      uint32_t *gids = malloc(g + 4), *ri = NULL;
+      uint64_t *re = NULL;
+      size_t nr = 0;
+      rc = ko_mco_build(rids, ridx, ref_num, gids, &ri, &re, &nr);
+      if (rc == KO_OK) ko_mco_count(gids, NULL, ri, re, nr, qids, qidx, qry_num, qry_ct, ref_num, ct);
+      free(rids); free(ridx); free(gids); free(ri); free(re);
+    } else {
+      snprintf(path, sizeof path, "%s/mco.%d", refdir, c);
+      const uint32_t *gids = ko_map_file(path, &g);
+      snprintf(path, sizeof path, "%s/mco.index.%d", refdir, c);
+      const uint64_t *dense = ko_map_file(path, &x);
+      if (!dense || x != (8ull << 32)) rc = KO_ERR_IO;
+      else ko_mco_count(gids, dense, NULL, NULL, 0, qids, qidx, qry_num, qry_ct, ref_num, ct);
+      if (gids) munmap((void *)gids, g);
+      if (dense) munmap((void *)dense, x);
+    }
+    free(qids); free(qidx);
+  }
+  if (rc == KO_OK) {
+    snprintf(path, sizeof path, "%s/distance.out", outdir);
+    FILE *fp = fopen(path, "w");
+    if (!fp) rc = KO_ERR_IO;
+    else {
+      rc = ko_dist_print(fp, o, q_k, q_dr, ref_num, qry_num, ref_ct, qry_ct, refnames, qrynames, ct); /* :972-973: the QUERY's k */
+      fclose(fp);
+    }
+    if (rc == KO_OK && o->keep_shared) {                                /* :1633 removes the file otherwise */
+      snprintf(path, sizeof path, "%s/sharedk_ct.dat", outdir);
+      fp = fopen(path, "wb");
+      if (!fp) rc = KO_ERR_IO;
+      else { fwrite(ct, 4, (size_t)ref_num * (size_t)qry_num, fp); fclose(fp); }
+    }
+  }
+  free(ct); free(rst); free(qst);
+  return rc;
+}

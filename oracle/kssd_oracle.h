@@ -121,6 +121,31 @@ int ko_set_group(const char *indir, const char *taxfile, const char *outdir);
 #include <stdio.h>
 int ko_composite(const char *refdir, const char *qrydir, const char *outdir, int binvec, FILE *out);
 
+/* ---- stage II (combco2mco, co2mco.c:12-87) and the `dist -r <mco> <co>` search (command_dist.c:902-1079,
+ * output :1531-1690).  ko_mco_build: the inverted index of one component -- gids_out[index[cofnum]] = the genome numbers
+ * row by row (rows = k-mer ids ascending, a row in genome order), row_ids / row_ends (malloc'ed) = the non-empty rows and
+ * their cumulative ends, i.e. the places where the reference's dense 2^32-entry mco.index.N changes value. */
+int ko_mco_build(const uint32_t *ids, const uint64_t *index, int cofnum, uint32_t *gids_out, uint32_t **row_ids,
+                 uint64_t **row_ends, size_t *nrows);
+/* run_stageII(): mcofiles.stat, mco.N and (dense_index != 0) the 32 GiB mco.index.N per component */
+int ko_stage2(const char *codir, const char *mcodir, int dense_index);
+/* ct[qry_num x ref_num] += shared k-mer counts of one component; `dense` (the reference's index) or the sparse rows */
+void ko_mco_count(const uint32_t *gids, const uint64_t *dense, const uint32_t *row_ids, const uint64_t *row_ends, size_t nrows,
+                  const uint32_t *qry_ids, const uint64_t *qry_index, int qry_num, const uint32_t *qry_ctx_ct, int ref_num,
+                  uint32_t *ct);
+typedef struct ko_dist_opts {
+  int metric;        /* -M 0 Jaccard / 1 containment            (command_dist_wrapper.c:85) */
+  int outfields;     /* -O 0 distance / 1 + p,q values / 2 + CI (:86, default 2) */
+  int correction;    /* --correction                            (:87) */
+  double dthreshold; /* -D, default 1                           (:84) */
+  int num_neigb;     /* -N, 0 = all                             (:83) */
+  int keep_shared;   /* --keepskf: keep sharedk_ct.dat          (:92) */
+} ko_dist_opts;
+int ko_dist_print(FILE *fp, const ko_dist_opts *o, int kmerlen, int dim_rd_len, int ref_num, int qry_num,
+                  const uint32_t *ref_ctx_ct, const uint32_t *qry_ctx_ct, const char *refnames, const char *qrynames,
+                  const uint32_t *ct);
+int ko_dist_search(const char *refdir, int ref_is_co, const char *qrydir, const char *outdir, const ko_dist_opts *o);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,7 +46,47 @@ static int composite_main(int argc, char **argv) {
   return rc ? 1 : 0;
 }
 
+/* kssd_oracle_cli stage2 [--no-index] -o mcodir codir          (mirrors `metakssd dist -o mcodir codir`)
+ * kssd_oracle_cli search [-M m] [-O f] [-N n] [-D d] [--correction c] [--keepskf] [--refco] -r refdir -o outdir qrydir */
+static int stage2_main(int argc, char **argv) {
+  const char *out = NULL, *in = NULL;
+  int dense = 1;
+  for (int i = 0; i < argc; i++) {
+    if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
+    else if (!strcmp(argv[i], "--no-index")) dense = 0;
+    else in = argv[i];
+  }
+  if (!out || !in) { fprintf(stderr, "usage: kssd_oracle_cli stage2 [--no-index] -o mcodir codir\n"); return 2; }
+  int rc = ko_stage2(in, out, dense);
+  if (rc) fprintf(stderr, "kssd_oracle_cli stage2: error %d\n", rc);
+  return rc ? 1 : 0;
+}
+
+static int search_main(int argc, char **argv) {
+  const char *ref = NULL, *out = NULL, *qry = NULL;
+  ko_dist_opts o = {0, 2, 0, 1.0, 0, 0};
+  int refco = 0;
+  for (int i = 0; i < argc; i++) {
+    if (!strcmp(argv[i], "-r") && i + 1 < argc) ref = argv[++i];
+    else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
+    else if (!strcmp(argv[i], "-M") && i + 1 < argc) o.metric = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-O") && i + 1 < argc) o.outfields = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-N") && i + 1 < argc) o.num_neigb = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-D") && i + 1 < argc) o.dthreshold = atof(argv[++i]);
+    else if (!strcmp(argv[i], "--correction") && i + 1 < argc) o.correction = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--keepskf")) o.keep_shared = 1;
+    else if (!strcmp(argv[i], "--refco")) refco = 1;
+    else qry = argv[i];
+  }
+  if (!ref || !out || !qry) { fprintf(stderr, "usage: kssd_oracle_cli search [options] -r refdir -o outdir qrydir\n"); return 2; }
+  int rc = ko_dist_search(ref, refco, qry, out, &o);
+  if (rc) fprintf(stderr, "kssd_oracle_cli search: error %d\n", rc);
+  return rc ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && !strcmp(argv[1], "stage2")) return stage2_main(argc - 2, argv + 2);
+  if (argc > 1 && !strcmp(argv[1], "search")) return search_main(argc - 2, argv + 2);
   if (argc > 1 && !strcmp(argv[1], "set")) return set_main(argc - 2, argv + 2);
   if (argc > 1 && !strcmp(argv[1], "composite")) return composite_main(argc - 2, argv + 2);
   const char *shuf = NULL, *out = NULL;

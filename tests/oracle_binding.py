@@ -148,3 +148,76 @@ class Oracle:
         rc = self.lib.ko_layout_from_partials(C.byref(self.P), len(parts), pk, pc, po, n, self.co.ctypes.data)
         assert rc == 0
         return self._dump(True)
+
+
+def mco_build(ids, index):
+    """ko_mco_build (stage II, co2mco.c:12-87) -> (gids, row_ids, row_ends)"""
+    lib = load()
+    vp = C.c_void_p
+    lib.ko_mco_build.argtypes = [vp, vp, C.c_int, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.ko_mco_build.restype = C.c_int
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    index = np.ascontiguousarray(index, dtype=np.uint64)
+    gids = np.zeros(max(ids.size, 1), np.uint32)
+    ri, re_, nr = vp(), vp(), C.c_size_t(0)
+    rc = lib.ko_mco_build(ids.ctypes.data, index.ctypes.data, index.size - 1, gids.ctypes.data, C.byref(ri), C.byref(re_), C.byref(nr))
+    assert rc == 0
+    n = nr.value
+    row_ids = np.ctypeslib.as_array(C.cast(ri, C.POINTER(C.c_uint32)), shape=(max(n, 1),))[:n].copy()
+    row_ends = np.ctypeslib.as_array(C.cast(re_, C.POINTER(C.c_uint64)), shape=(max(n, 1),))[:n].copy()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [vp]
+    libc.free(ri)
+    libc.free(re_)
+    return gids[:ids.size], row_ids, row_ends
+
+
+def mco_count(gids, row_ids, row_ends, qry_ids, qry_index, qry_ctx_ct, ref_num):
+    """ko_mco_count (command_dist.c:1033-1049) with the sparse row table -> qry_num x ref_num uint32"""
+    lib = load()
+    vp = C.c_void_p
+    lib.ko_mco_count.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, C.c_int, vp, C.c_int, vp]
+    lib.ko_mco_count.restype = None
+    gids = np.ascontiguousarray(gids, dtype=np.uint32)
+    row_ids = np.ascontiguousarray(row_ids, dtype=np.uint32)
+    row_ends = np.ascontiguousarray(row_ends, dtype=np.uint64)
+    qry_ids = np.ascontiguousarray(qry_ids, dtype=np.uint32)
+    qry_index = np.ascontiguousarray(qry_index, dtype=np.uint64)
+    ctx = np.ascontiguousarray(qry_ctx_ct, dtype=np.uint32)
+    ct = np.zeros((ctx.size, ref_num), np.uint32)
+    lib.ko_mco_count(gids.ctypes.data, None, row_ids.ctypes.data, row_ends.ctypes.data, row_ids.size, qry_ids.ctypes.data,
+                     qry_index.ctypes.data, ctx.size, ctx.ctypes.data, ref_num, ct.ctypes.data)
+    return ct
+
+
+class KoDistOpts(C.Structure):
+    _fields_ = [("metric", C.c_int), ("outfields", C.c_int), ("correction", C.c_int), ("dthreshold", C.c_double),
+                ("num_neigb", C.c_int), ("keep_shared", C.c_int)]
+
+
+def dist_print(path, ref_ctx_ct, qry_ctx_ct, refnames, qrynames, ct, kmerlen, dim_rd_len, metric=0, outfields=2, correction=0,
+               num_neigb=0, dthreshold=1.0):
+    """ko_dist_print (command_dist.c:1531-1690) into `path`; returns the oracle's status"""
+    lib = load()
+    vp = C.c_void_p
+    lib.ko_dist_print.argtypes = [vp, C.POINTER(KoDistOpts), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_char_p, C.c_char_p, vp]
+    lib.ko_dist_print.restype = C.c_int
+    libc = C.CDLL(None)
+    libc.fopen.restype = vp
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [vp]
+
+    def pack(names):
+        b = bytearray(256 * len(names))
+        for i, nm in enumerate(names):
+            e = nm.encode()[:255]
+            b[256 * i:256 * i + len(e)] = e
+        return bytes(b)
+    rc_, qc_ = np.ascontiguousarray(ref_ctx_ct, dtype=np.uint32), np.ascontiguousarray(qry_ctx_ct, dtype=np.uint32)
+    ct = np.ascontiguousarray(ct, dtype=np.uint32)
+    o = KoDistOpts(metric, outfields, correction, dthreshold, num_neigb, 0)
+    fp = libc.fopen(path.encode(), b"w")
+    rc = lib.ko_dist_print(fp, C.byref(o), kmerlen, dim_rd_len, rc_.size, qc_.size, rc_.ctypes.data, qc_.ctypes.data, pack(refnames),
+                           pack(qrynames), ct.ctypes.data)
+    libc.fclose(fp)
+    return rc

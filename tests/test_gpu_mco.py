@@ -1,0 +1,156 @@
+"""stage II (inverted index) and the `dist -r` shared-k-mer counting on the device vs the oracle:
+bit-exact gid lists, row table, dense-index slabs and count matrices."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mco():
+    from metakssd_amd import capi
+    m = capi.Mco(0)
+    yield m
+    m.close()
+
+
+def sketches(rs, nsk, universe, lo, hi, empty=(), extremes=False):
+    """nsk id sets drawn from a common universe (so that rows are shared), some empty; -> (ids, index)"""
+    pool = np.unique(rs.randint(0, 2 ** 32, size=universe, dtype=np.uint64).astype(np.uint32))
+    if extremes:
+        pool = np.unique(np.concatenate([pool, np.array([0, 1, 2 ** 32 - 1, 2 ** 32 - 2, 2 ** 27, 2 ** 27 - 1], np.uint32)]))
+    parts, index = [], [0]
+    for j in range(nsk):
+        n = 0 if j in empty else int(rs.randint(lo, hi + 1))
+        p = rs.permutation(pool)[:min(n, pool.size)]     # hash-table order in the real files: unsorted
+        parts.append(p)
+        index.append(index[-1] + p.size)
+    ids = np.concatenate(parts) if parts else np.zeros(0, np.uint32)
+    return ids.astype(np.uint32), np.array(index, np.uint64)
+
+
+@pytest.mark.parametrize("nsk,universe,lo,hi,empty,extremes", [
+    (4, 300, 50, 200, (), True),
+    (1, 50, 50, 50, (), False),
+    (7, 2000, 0, 1500, (0, 3, 6), True),
+    (300, 20000, 100, 3000, (5,), False),
+    (3, 10, 0, 0, (0, 1, 2), False),
+    (40, 400000, 50000, 150000, (), True),
+])
+def test_build_matches_oracle(mco, nsk, universe, lo, hi, empty, extremes):
+    rs = np.random.RandomState(nsk * 7 + universe)
+    ids, index = sketches(rs, nsk, universe, lo, hi, empty, extremes)
+    g, ri, re_ = mco.build(ids, index)
+    og, ori, ore = ob.mco_build(ids, index)
+    assert np.array_equal(g, og)
+    assert np.array_equal(ri, ori) and np.array_equal(re_, ore)
+    # dense index: the first slab, the last rows, and rows around table entries
+    def want(row0, nrows):
+        rows = np.arange(row0, row0 + nrows, dtype=np.uint64)
+        u = np.searchsorted(ori.astype(np.uint64), rows, side="right")
+        ends = np.concatenate([[0], ore]).astype(np.uint64)
+        return ends[u]
+    spots = [(0, 5000), (2 ** 32 - 4096, 4096), (2 ** 27 - 1000, 2000)]
+    if ori.size:
+        mid = int(ori[ori.size // 2])
+        spots.append((max(0, mid - 300), 600 if mid + 300 < 2 ** 32 else 300))
+    for row0, nrows in spots:
+        assert np.array_equal(mco.index_rows(row0, nrows), want(row0, nrows)), (row0, nrows)
+
+
+def test_index_full_slab_properties(mco):
+    """one whole 2^27-row slab: monotone, starts/ends at the table's values, changes exactly at the rows of the table"""
+    rs = np.random.RandomState(5)
+    ids, index = sketches(rs, 6, 5000, 500, 3000, (), True)
+    _, ri, re_ = mco.build(ids, index)
+    slab = mco.index_rows(0, 2 ** 27)
+    d = np.flatnonzero(np.diff(slab))
+    inslab = ri[ri < 2 ** 27]
+    first_is_row = int(inslab.size and inslab[0] == 0)
+    assert np.array_equal(d + 1, inslab[first_is_row:].astype(np.int64))
+    assert slab[-1] == (re_[inslab.size - 1] if inslab.size else 0)
+
+
+@pytest.mark.parametrize("nref,nqry,universe,lo,hi,zero_ct", [
+    (4, 3, 400, 50, 300, (2,)),            # LDS counters
+    (900, 20, 30000, 500, 8000, ()),       # LDS, long rows (cooperative walk)
+    (40000, 6, 200000, 1, 6, (1,)),        # more references than LDS counters: global atomics
+    (3000, 400, 20000, 5, 40, ()),         # many tiny query sketches: global atomics by the slice heuristic
+    (2, 1, 100000, 60000, 90000, ()),      # one big query sketch cut into slices
+])
+def test_count_matches_oracle(mco, nref, nqry, universe, lo, hi, zero_ct):
+    rs = np.random.RandomState(nref + nqry)
+    pool = np.unique(rs.randint(0, 2 ** 32, size=universe, dtype=np.uint64).astype(np.uint32))
+    def draw(nsk):
+        parts, index = [], [0]
+        for _ in range(nsk):
+            p = rs.permutation(pool)[:int(rs.randint(lo, hi + 1))]
+            parts.append(p)
+            index.append(index[-1] + p.size)
+        return np.concatenate(parts).astype(np.uint32), np.array(index, np.uint64)
+    rids, rindex = draw(nref)
+    qids, qindex = draw(nqry)
+    qids[::17] ^= 1                      # some ids that are in no row
+    ctx = np.diff(qindex).astype(np.uint32)
+    for k in zero_ct:
+        ctx[k] = 0                       # stat says empty: skipped whatever the lists hold (command_dist.c:1035)
+    og, ori, ore = ob.mco_build(rids, rindex)
+    want = ob.mco_count(og, ori, ore, qids, qindex, ctx, nref)
+    g, ri, re_ = mco.build(rids, rindex)
+    got = mco.count(nref, qindex, ctx, [{"qry_ids": qids}])               # device row table
+    assert np.array_equal(got, want)
+    # extents as the CLI takes them from the mmap'ed dense index
+    u = np.searchsorted(ori, qids, side="left")
+    hit = (u < ori.size) & (ori[np.minimum(u, ori.size - 1)] == qids)
+    ends = np.concatenate([[0], ore]).astype(np.uint64)
+    es = np.where(hit, ends[np.minimum(u, ori.size - 1)], 0).astype(np.uint64)
+    ee = np.where(hit, ends[np.minimum(u, ori.size - 1) + 1], 0).astype(np.uint64)
+    got2 = mco.count(nref, qindex, ctx, [{"gids": og, "ext_start": es, "ext_end": ee}])
+    assert np.array_equal(got2, want)
+    # two components accumulate
+    got3 = mco.count(nref, qindex, ctx, [{"gids": og, "ext_start": es, "ext_end": ee}, {"gids": og, "ext_start": es, "ext_end": ee}])
+    assert np.array_equal(got3, want * 2)
+    assert want.sum() > 0
+
+
+def test_count_properties_large(mco):
+    """size-independent checks at a size the oracle does not see: row sums = total row lengths of the query's ids;
+    a reference searched against itself has its sketch size on the diagonal"""
+    rs = np.random.RandomState(77)
+    nref = 2000
+    pool = np.unique(rs.randint(0, 2 ** 32, size=3_000_000, dtype=np.uint64).astype(np.uint32))
+    sizes = rs.randint(20000, 60000, size=nref)
+    starts = rs.randint(0, pool.size - 60000, size=nref)
+    parts = [pool[s:s + n] for s, n in zip(starts, sizes)]           # overlapping windows: heavy sharing
+    ids = np.concatenate(parts)
+    index = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    g, ri, re_ = mco.build(ids, index)
+    assert g.size == ids.size and np.all(np.diff(ri.astype(np.int64)) > 0) and re_[-1] == ids.size
+    sel = [3, 500, 1999]
+    qids = np.concatenate([parts[i] for i in sel])
+    qindex = np.concatenate([[0], np.cumsum([parts[i].size for i in sel])]).astype(np.uint64)
+    ct = mco.count(nref, qindex, np.diff(qindex).astype(np.uint32), [{"qry_ids": qids}])
+    lens = np.diff(np.concatenate([[0], re_]).astype(np.int64))
+    for row, i in enumerate(sel):
+        assert ct[row, i] == parts[i].size
+        u = np.searchsorted(ri, parts[i])
+        assert int(ct[row].sum()) == int(lens[u].sum())
+        assert np.all(ct[row] <= np.minimum(parts[i].size, sizes))
+
+
+def test_state_and_argument_errors(mco):
+    from metakssd_amd import capi
+    m = capi.Mco(0)
+    with pytest.raises(capi.MkError):
+        m.index_rows(0, 16)                                   # before any build
+    with pytest.raises(capi.MkError):
+        m.build(np.arange(4, dtype=np.uint32), np.array([0, 3, 2, 4], np.uint64))   # index not ascending
+    m.build(np.arange(4, dtype=np.uint32), np.array([0, 2, 4], np.uint64))
+    with pytest.raises(capi.MkError):
+        m.index_rows(2 ** 32 - 8, 16)                         # past the last row
+    with pytest.raises(capi.MkError):                          # extents beyond the gid lists
+        m.count(2, np.array([0, 1], np.uint64), [1], [{"gids": np.zeros(3, np.uint32), "ext_start": np.array([2], np.uint64),
+                                                       "ext_end": np.array([9], np.uint64)}])
+    m.close()
