@@ -113,6 +113,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--keep", default=None)
     ap.add_argument("--big", action="store_true", help="also run the 1.5 M-read K9 collision case")
+    ap.add_argument("--search", action="store_true", help="also stage II + `dist -r` (the reference writes 32 GiB per database: minutes each)")
+    ap.add_argument("--dense", action="store_true", help="with --search: the oracle writes its own 32 GiB index too and the two are compared")
     args = ap.parse_args()
     if not os.path.exists(REF):
         raise SystemExit("oracle/_ref/metakssd missing: run `make -C oracle ref` where /root/reference exists")
@@ -439,6 +441,57 @@ def main():
     run([REF, "dist", "-L", shufs["L1K7"], "-p", "1", "-o", os.path.join(work, "L1K7_pooldb.sk")] + pfa, work)
     group_case("L1K7_pooldb", "L1K7_pooldb", ["1\tfirst", "2\tsecond"])
     composite_case("L1K7_composite", "L1K7_pooldb", "L1K7_set_u_reads_A")
+
+
+    # ---- stage II (co2mco.c:12-87) and `dist -r` (command_dist.c:902-1079, :1531-1690): opt-in, 32 GiB per database ----
+    if args.search:
+        def search_db(label, shuf, ref_files, qry_sets):
+            nonlocal failures
+            names = [os.path.basename(f) for f in ref_files]
+            sk, rmco, omco = label + ".sk", label + ".refmco", label + ".oramco"
+            for d in (sk, rmco, omco):
+                shutil.rmtree(os.path.join(work, d), ignore_errors=True)
+            run([ORA, "-L", shufs[shuf], "-o", sk] + names, work)
+            r1 = subprocess.run([REF, "dist", "-o", rmco, sk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            r2 = subprocess.run([ORA, "stage2", "-o", omco, sk] + ([] if args.dense else ["--no-index"]), cwd=work, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE)
+            files = ["mco.0", "mcofiles.stat"] + (["mco.index.0"] if args.dense else [])
+            ok = r1.returncode == 0 and r2.returncode == 0 and all(
+                filecmp.cmp(os.path.join(work, rmco, f), os.path.join(work, omco, f), shallow=False) for f in files)
+            print("%s %-28s gids=%d %s" % ("ok  " if ok else "FAIL", label + "_stage2", os.path.getsize(os.path.join(work, rmco, "mco.0")) // 4,
+                                           "dense index compared" if args.dense else ""))
+            failures += 0 if ok else 1
+            if args.dense:
+                os.remove(os.path.join(work, omco, "mco.index.0"))
+            for qlabel, qflags, qfiles in qry_sets:
+                qsk = "%s_%s.qsk" % (label, qlabel)
+                shutil.rmtree(os.path.join(work, qsk), ignore_errors=True)
+                run([ORA, "-L", shufs[shuf]] + qflags + ["-o", qsk] + [os.path.basename(f) for f in qfiles], work)
+                for flags in ([], ["-M", "1"], ["-O", "0"], ["-O", "1", "-M", "1"], ["-N", "1"], ["-N", "3", "-M", "1"], ["-D", "0.05"],
+                              ["--correction", "1"], ["--correction", "1", "-M", "1", "-N", "2", "-D", "0.2"], ["-N", "%d" % (len(names) + 1)]):
+                    o1, o2, o3 = (os.path.join(work, "%s_%s.%s" % (label, qlabel, x)) for x in ("refout", "oraout", "oraout2"))
+                    for d in (o1, o2, o3):
+                        shutil.rmtree(d, ignore_errors=True)
+                    a = subprocess.run([REF, "dist", "-r", rmco, "-o", o1, "--keepskf"] + flags + [qsk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                    b = subprocess.run([ORA, "search", "-r", rmco, "-o", o2, "--keepskf"] + flags + [qsk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                    c = subprocess.run([ORA, "search", "--refco", "-r", sk, "-o", o3, "--keepskf"] + flags + [qsk], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                    if flags[:1] == ["-N"] and int(flags[1]) > len(names):   # the reference gives up after the header (:1574); the oracle reports an error
+                        ok = b.returncode != 0 and c.returncode != 0 and len(open(os.path.join(o1, "distance.out")).read().splitlines()) == 1
+                        lines = -1
+                    else:
+                        ok = a.returncode == 0 and b.returncode == 0 and c.returncode == 0
+                        for f in ("distance.out", "sharedk_ct.dat"):
+                            ok = ok and filecmp.cmp(os.path.join(o1, f), os.path.join(o2, f), shallow=False) and \
+                                filecmp.cmp(os.path.join(o1, f), os.path.join(o3, f), shallow=False)
+                        lines = len(open(os.path.join(o1, "distance.out")).read().splitlines()) if ok else -1
+                    print("%s %-28s %-40s lines=%d" % ("ok  " if ok else "FAIL", "%s_%s" % (label, qlabel), " ".join(flags), lines))
+                    failures += 0 if ok else 1
+            os.remove(os.path.join(work, rmco, "mco.index.0"))
+
+        tiny = os.path.join(work, "tiny.fa")     # shorter than one k-mer: an empty sketch among the queries
+        write_fa(tiny, [g[:10]])
+        search_db("L1K7_search", "L1K7", small, [("fa", [], [small[1], fas[0], tiny]), ("koc", ["-A"], [fq10, fq16])])
+        search_db("L3K10_search", "L3K10", fas, [("fa", [], [fas[2], tiny, small[0], fa1])])
 
     if args.big:
         fqb = os.path.join(work, "syn1p5m.fq")

@@ -27,8 +27,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 import util_inputs as ui  # noqa: E402
-from golden_cases import (CASES, COMPOSITE_CASES, SET_CASES, SHUF_SPECS, build_composite_inputs, build_input,  # noqa: E402
-                          build_set_inputs, make_shuf)
+from golden_cases import (CASES, COMPOSITE_CASES, SEARCH_CASES, SEARCH_DBS, SET_CASES, SHUF_SPECS, build_composite_inputs,  # noqa: E402
+                          build_input, build_search_inputs, build_set_inputs, make_shuf)
 
 REF = os.path.join(ROOT, "oracle", "_ref", "metakssd")
 ORA = os.path.join(ROOT, "oracle", "kssd_oracle_cli")  # only to lay out sketch directories in a given order (set -g cases)
@@ -43,10 +43,70 @@ def parse_stat(path):
                 infile_num=infile_num, all_ctx_ct=all_ctx, ctx_ct=cts)
 
 
+def search_section(manifest, work, shuf_paths, exp_root):
+    """stage II + `dist -r`: every database costs one 32 GiB mco.index.0 (deleted again); its xxh64 is what is kept"""
+    import xxhash
+    manifest["search_dbs"], manifest["search_cases"] = {}, {}
+    for db, c in SEARCH_DBS.items():
+        refs = build_search_inputs(db, c["refs"], work, write_committed=True)
+        sk, mco = db + ".sk", db + ".mco"
+        for cmd in ([ORA, "-L", shuf_paths[c["shuf"]], "-o", sk] + refs, [REF, "dist", "-o", mco, sk]):
+            r = subprocess.run(cmd, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            if r.returncode != 0:
+                raise SystemExit("%s: step failed: %s\n%s" % (db, " ".join(cmd), r.stderr.decode(errors="replace")[-300:]))
+        d = os.path.join(exp_root, db)
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d)
+        for f in ("mcofiles.stat", "mco.0"):
+            shutil.copy(os.path.join(work, mco, f), os.path.join(d, f))
+        h = xxhash.xxh64()
+        with open(os.path.join(work, mco, "mco.index.0"), "rb") as f:
+            while True:
+                b = f.read(1 << 26)
+                if not b:
+                    break
+                h.update(b)
+        manifest["search_dbs"][db] = {"shuf": c["shuf"], "refs": c["refs"], "index_xxh64": h.hexdigest(),
+                                      "index_bytes": os.path.getsize(os.path.join(work, mco, "mco.index.0")),
+                                      "gids": os.path.getsize(os.path.join(d, "mco.0")) // 4}
+        print("%-28s gids=%d index xxh64=%s" % (db, manifest["search_dbs"][db]["gids"], h.hexdigest()))
+        for case, sc in SEARCH_CASES.items():
+            if sc["db"] != db:
+                continue
+            qry = build_search_inputs(case, sc["query"], work, write_committed=True)
+            qsk, out = case + ".qsk", case + ".out"
+            for cmd in ([ORA, "-L", shuf_paths[c["shuf"]]] + sc["qflags"] + ["-o", qsk] + qry,
+                        [REF, "dist", "-r", mco, "-o", out] + sc["flags"] + ["--keepskf", qsk]):
+                r = subprocess.run(cmd, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                if r.returncode != 0:
+                    raise SystemExit("%s: step failed: %s\n%s" % (case, " ".join(cmd), r.stderr.decode(errors="replace")[-300:]))
+            dc = os.path.join(exp_root, case)
+            shutil.rmtree(dc, ignore_errors=True)
+            os.makedirs(dc)
+            for f in ("distance.out", "sharedk_ct.dat"):
+                shutil.copy(os.path.join(work, out, f), os.path.join(dc, f))
+            nlines = len(open(os.path.join(dc, "distance.out")).read().splitlines())
+            manifest["search_cases"][case] = dict(sc, lines=nlines)
+            print("%-28s lines=%d" % (case, nlines))
+        os.remove(os.path.join(work, mco, "mco.index.0"))
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("oracle/_ref/metakssd missing: run `make -C oracle ref`")
     exp_root = os.path.join(HERE, "expected")
+    if "--only-search" in sys.argv:   # add / refresh the stage II + search vectors, leave the rest as it is
+        manifest = json.load(open(os.path.join(HERE, "manifest.json")))
+        work = tempfile.mkdtemp(prefix="golden_")
+        shuf_paths = {}
+        for name in sorted({c["shuf"] for c in SEARCH_DBS.values()}):
+            shuf_paths[name] = os.path.join(work, name + ".shuf")
+            make_shuf(name, shuf_paths[name])
+            assert manifest["shufs"][name]["sha256"] == hashlib.sha256(open(shuf_paths[name], "rb").read()).hexdigest()
+        search_section(manifest, work, shuf_paths, exp_root)
+        json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+        shutil.rmtree(work, ignore_errors=True)
+        return
     shutil.rmtree(exp_root, ignore_errors=True)
     os.makedirs(exp_root)
     os.makedirs(os.path.join(HERE, "inputs"), exist_ok=True)
@@ -54,7 +114,7 @@ def main():
     manifest = {"shufs": {}, "cases": {}}
     shuf_paths = {}
     for name in sorted({c["shuf"] for c in CASES.values()} | {c["shuf"] for c in SET_CASES.values()} |
-                       {c["shuf"] for c in COMPOSITE_CASES.values()}):
+                       {c["shuf"] for c in COMPOSITE_CASES.values()} | {c["shuf"] for c in SEARCH_DBS.values()}):
         p = os.path.join(work, name + ".shuf")
         make_shuf(name, p)
         shuf_paths[name] = p
@@ -180,6 +240,7 @@ def main():
         print("%-28s lines=%d files=%s" % (case, len(lines), sorted(os.listdir(d))))
         for x in lines[:3]:
             print("    " + x)
+    search_section(manifest, work, shuf_paths, exp_root)
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
     shutil.rmtree(work, ignore_errors=True)
     tot = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(HERE) for f in fs)

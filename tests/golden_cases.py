@@ -127,6 +127,31 @@ COMPOSITE_CASES = {
 }
 
 
+# stage II + `dist -r` search.  Only single-component tables: the reference writes a 32 GiB mco.index.N per
+# component.  A database = `dist -o <mco> <sketch dir>` of the reference on a sketch directory laid out in the given order;
+# a case = the reference's `dist -r <mco> -o out <flags> --keepskf <query sketch dir>`.  Names inside the stat files are the
+# paths given on the command line: everything runs inside the work directory with relative names.
+SEARCH_DBS = {
+    "db_strains_L1K7": {"shuf": "L1K7", "refs": ["fa:sA", "fa:sB", "fa:sC", "fa:genome"]},
+    "db_small_L0K6": {"shuf": "L0K6", "refs": ["fa:sA", "fa:sC"]},
+    "db_strains_L3K10": {"shuf": "L3K10", "refs": ["fa:sA", "fa:sB", "fa:sC", "fa:genome"]},
+}
+SEARCH_CASES = {
+    "search_default_L1K7": {"db": "db_strains_L1K7", "qflags": [], "query": ["fa:sB", "fq:mix", "fa:genome"], "flags": []},
+    "search_ctm_n2_L1K7": {"db": "db_strains_L1K7", "qflags": [], "query": ["fa:sB", "fq:mix", "fa:genome"], "flags": ["-M", "1", "-O", "1", "-N", "2"]},
+    "search_corr_d_L1K7": {"db": "db_strains_L1K7", "qflags": [], "query": ["fa:sB", "fq:mix", "fa:genome"],
+                           "flags": ["--correction", "1", "-D", "0.08", "-O", "0"]},
+    "search_koc_qry_L1K7": {"db": "db_strains_L1K7", "qflags": ["-A"], "query": ["fq:mix", "fq:lowcov"], "flags": ["-N", "1"]},
+    "search_small_L0K6": {"db": "db_small_L0K6", "qflags": [], "query": ["fq:mixs", "fa:sC"], "flags": []},
+    "search_ctm_L3K10": {"db": "db_strains_L3K10", "qflags": [], "query": ["fa:sB", "fa:genome", "fq:pool"], "flags": ["-M", "1"]},
+}
+
+
+def build_search_inputs(name, specs, workdir, write_committed=False):
+    """input files for a search database / query, returned as names relative to workdir"""
+    return [os.path.basename(build_input("%s_%d" % (name, i), workdir, write_committed=write_committed, spec=sp)) for i, sp in enumerate(specs)]
+
+
 CASES = {
     # BASELINE.json config 1/2: 100 k synthetic 150 bp reads, L3K11 -A (input regenerated from the formula)
     "syn100k_L3K11": {"shuf": "L3K11", "flags": ["-A"], "input": "synth:seed=1,first=0,n=100000,len=150"},

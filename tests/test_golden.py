@@ -292,3 +292,158 @@ def test_oracle_composite_reproduces_reference_golden(case, shuf_files, tmp_path
 def test_product_cli_composite_reproduces_reference_golden(case, shuf_files, tmp_path):
     """the README's MarkerDB recipe and the profiling step, every stage on the device build"""
     run_composite_case(case, shuf_files, tmp_path, [PRODUCT_CLI, "dist", "-p", "4"], [PRODUCT_CLI, "set"], [PRODUCT_CLI, "composite"])
+
+
+# ---- stage II + `dist -r` search (SURVEY.md 8f N4) --------------------------------------------------------------
+SEARCH_DBS = MANIFEST.get("search_dbs", {})
+SEARCH_CASES = MANIFEST.get("search_cases", {})
+
+
+def _run(cmd, cwd):
+    r = subprocess.run(cmd, cwd=cwd, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, (cmd, r.stderr.decode(errors="replace")[-400:])
+    return r
+
+
+def make_search_db_sketch(db, shuf_files, tmp_path, dist_cmd):
+    """the database's sketch directory `<db>.sk` inside tmp_path, names relative like in make_golden.py"""
+    entry = SEARCH_DBS[db]
+    refs = gc.build_search_inputs(db, entry["refs"], str(tmp_path))
+    _run(dist_cmd + ["-L", shuf_files(entry["shuf"]), "-o", db + ".sk"] + refs, str(tmp_path))
+    return db + ".sk"
+
+
+def make_search_query_sketch(case, shuf_files, tmp_path, dist_cmd):
+    entry = SEARCH_CASES[case]
+    qry = gc.build_search_inputs(case, entry["query"], str(tmp_path))
+    _run(dist_cmd + ["-L", shuf_files(SEARCH_DBS[entry["db"]]["shuf"])] + entry["qflags"] + ["-o", case + ".qsk"] + qry, str(tmp_path))
+    return case + ".qsk"
+
+
+def dense_index_xxh64(row_ids, row_ends):
+    """hash of the 2^32-entry mco.index.N that the row table stands for, built in 2^26-row pieces"""
+    import numpy as np
+    import xxhash
+    h = xxhash.xxh64()
+    ends = np.concatenate([[0], np.asarray(row_ends, np.uint64)]).astype(np.uint64)
+    rid = np.asarray(row_ids, np.uint64)
+    step = 1 << 26
+    for r0 in range(0, 1 << 32, step):
+        lo, hi = np.searchsorted(rid, [r0, r0 + step], side="left")
+        if lo == hi:
+            piece = np.full(step, ends[lo], np.uint64)
+        else:
+            rows = np.arange(r0, r0 + step, dtype=np.uint64)
+            piece = ends[np.searchsorted(rid, rows, side="right")]
+        h.update(piece.tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("db", sorted(SEARCH_DBS))
+def test_oracle_stage2_reproduces_reference_golden(db, shuf_files, tmp_path):
+    sk = make_search_db_sketch(db, shuf_files, tmp_path, [ORACLE_CLI])
+    _run([ORACLE_CLI, "stage2", "--no-index", "-o", db + ".mco", sk], str(tmp_path))
+    exp = os.path.join(gc.GOLDEN, "expected", db)
+    for f in ("mco.0", "mcofiles.stat"):
+        assert filecmp.cmp(os.path.join(exp, f), str(tmp_path / (db + ".mco") / f), shallow=False), f
+    if db == "db_strains_L3K10":   # the 32 GiB index once on the CPU: from the oracle's row table
+        import numpy as np
+        import oracle_binding as ob
+        ids = np.fromfile(str(tmp_path / sk / "combco.0"), np.uint32)
+        index = np.fromfile(str(tmp_path / sk / "combco.index.0"), np.uint64)
+        _, ri, re_ = ob.mco_build(ids, index)
+        assert dense_index_xxh64(ri, re_) == SEARCH_DBS[db]["index_xxh64"]
+
+
+@pytest.mark.parametrize("case", sorted(SEARCH_CASES))
+def test_oracle_search_reproduces_reference_golden(case, shuf_files, tmp_path):
+    entry = SEARCH_CASES[case]
+    sk = make_search_db_sketch(entry["db"], shuf_files, tmp_path, [ORACLE_CLI])
+    qsk = make_search_query_sketch(case, shuf_files, tmp_path, [ORACLE_CLI])
+    _run([ORACLE_CLI, "search", "--refco", "-r", sk, "-o", "out", "--keepskf"] + entry["flags"] + [qsk], str(tmp_path))
+    exp = os.path.join(gc.GOLDEN, "expected", case)
+    for f in ("distance.out", "sharedk_ct.dat"):
+        assert filecmp.cmp(os.path.join(exp, f), str(tmp_path / "out" / f), shallow=False), f
+    assert len(open(os.path.join(exp, "distance.out")).read().splitlines()) == entry["lines"] > 1
+
+
+def _flags_to_kwargs(flags):
+    kw, it = {}, iter(flags)
+    for f in it:
+        v = next(it)
+        kw[{"-M": "metric", "-O": "outfields", "-N": "num_neigb", "-D": "dthreshold", "--correction": "correction"}[f]] = \
+            float(v) if f == "-D" else int(v)
+    return kw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("db", sorted(SEARCH_DBS))
+def test_product_abi_stage2_search_reproduces_reference_golden(db, shuf_files, tmp_path):
+    """sketch directories by the product CLI, inverted index / dense index / counts through the C ABI, text by mk_dist_print"""
+    import numpy as np
+    import xxhash
+    from metakssd_amd import capi
+    sk = make_search_db_sketch(db, shuf_files, tmp_path, [PRODUCT_CLI, "dist", "--quiet", "-p", "4"])
+    exp = os.path.join(gc.GOLDEN, "expected", db)
+    ids = np.fromfile(str(tmp_path / sk / "combco.0"), np.uint32)
+    index = np.fromfile(str(tmp_path / sk / "combco.index.0"), np.uint64)
+    rstat, rnames = parse_stat(str(tmp_path / sk / "cofiles.stat"))
+    m = capi.Mco(0)
+    gids, ri, re_ = m.build(ids, index)
+    assert np.array_equal(gids, np.fromfile(os.path.join(exp, "mco.0"), np.uint32))
+    h = xxhash.xxh64()
+    for r0 in range(0, 1 << 32, 1 << 27):
+        h.update(m.index_rows(r0, 1 << 27).tobytes())
+    assert h.hexdigest() == SEARCH_DBS[db]["index_xxh64"]
+    for case in sorted(c for c, e in SEARCH_CASES.items() if e["db"] == db):
+        entry = SEARCH_CASES[case]
+        qsk = make_search_query_sketch(case, shuf_files, tmp_path, [PRODUCT_CLI, "dist", "--quiet", "-p", "4"])
+        qids = np.fromfile(str(tmp_path / qsk / "combco.0"), np.uint32)
+        qindex = np.fromfile(str(tmp_path / qsk / "combco.index.0"), np.uint64)
+        qstat, qnames = parse_stat(str(tmp_path / qsk / "cofiles.stat"))
+        ct = m.count(rstat["infile_num"], qindex, qstat["ctx_ct"], [{"qry_ids": qids}])
+        cexp = os.path.join(gc.GOLDEN, "expected", case)
+        assert np.array_equal(ct.ravel(), np.fromfile(os.path.join(cexp, "sharedk_ct.dat"), np.uint32)), case
+        out = str(tmp_path / (case + ".distance.out"))
+        assert capi.dist_print(out, rstat["ctx_ct"], qstat["ctx_ct"], rnames, qnames, ct, qstat["kmerlen"], qstat["dim_rd_len"],
+                               **_flags_to_kwargs(entry["flags"])) == 0
+        assert filecmp.cmp(os.path.join(cexp, "distance.out"), out, shallow=False), case
+    m.close()
+
+
+@pytest.mark.gpu
+def test_product_cli_stage2_search_end_to_end(shuf_files, tmp_path):
+    """`metakssd dist -o <mco> <sketches>` (the 32 GiB mco.index.0 on disk) and `metakssd dist -r <mco> ... <query>` against the
+    reference's files; skipped where the scratch disk cannot hold the index"""
+    import shutil
+    import xxhash
+    db = "db_strains_L1K7"
+    if shutil.disk_usage(str(tmp_path)).free < 48 << 30:
+        pytest.skip("needs 32 GiB of scratch space for mco.index.0")
+    dist = [PRODUCT_CLI, "dist", "--quiet", "-p", "4"]
+    sk = make_search_db_sketch(db, shuf_files, tmp_path, dist)
+    try:
+        _run([PRODUCT_CLI, "dist", "--quiet", "-o", db + ".mco", sk], str(tmp_path))
+        exp = os.path.join(gc.GOLDEN, "expected", db)
+        for f in ("mco.0", "mcofiles.stat"):
+            assert filecmp.cmp(os.path.join(exp, f), str(tmp_path / (db + ".mco") / f), shallow=False), f
+        h = xxhash.xxh64()
+        with open(str(tmp_path / (db + ".mco") / "mco.index.0"), "rb") as f:
+            for b in iter(lambda: f.read(1 << 26), b""):
+                h.update(b)
+        assert h.hexdigest() == SEARCH_DBS[db]["index_xxh64"]
+        for case in sorted(c for c, e in SEARCH_CASES.items() if e["db"] == db):
+            entry = SEARCH_CASES[case]
+            qsk = make_search_query_sketch(case, shuf_files, tmp_path, dist)
+            _run([PRODUCT_CLI, "dist", "--quiet", "-r", db + ".mco", "-o", case + ".out", "--keepskf"] + entry["flags"] + [qsk], str(tmp_path))
+            for f in ("distance.out", "sharedk_ct.dat"):
+                assert filecmp.cmp(os.path.join(gc.GOLDEN, "expected", case, f), str(tmp_path / (case + ".out") / f), shallow=False), (case, f)
+        # without --keepskf the counts file is removed (command_dist.c:1633); a second run into the same directory works
+        case = "search_default_L1K7"
+        _run([PRODUCT_CLI, "dist", "--quiet", "-r", db + ".mco", "-o", "again", case + ".qsk"], str(tmp_path))
+        assert sorted(os.listdir(str(tmp_path / "again"))) == ["distance.out"]
+    finally:
+        try:
+            os.remove(str(tmp_path / (db + ".mco") / "mco.index.0"))
+        except OSError:
+            pass
