@@ -14,7 +14,8 @@
  *   mk_mco_index_kernel     a slab of the dense 2^32-entry mco.index.N filled from the row table
  *   mk_mco_extent_kernel    query id -> its row's extent (device row table; the CLI takes extents from the mmap'ed index)
  *   mk_mco_count_kernel     the counting loop: one workgroup per slice of a query sketch, counters in LDS (one per
- *                           reference genome, up to 32 768) flushed once per slice; global atomics above that
+ *                           reference genome, up to 32 768) flushed once per slice; global atomics above that; the
+ *                           genome lists are repacked to 16 bits (mk_mco_pack16_kernel) below 65 535 genomes
  */
 #include <hip/hip_runtime.h>
 
@@ -23,6 +24,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -67,6 +69,9 @@ struct mk_mco {
   bool counting = false;
   uint32_t *d_gids = nullptr;
   uint64_t gids_cap = 0;
+  uint16_t *d_gids16 = nullptr;
+  uint64_t gids16_cap = 0;
+  bool lds_configured16 = false;
   uint32_t *d_qids = nullptr;
   unsigned long long *d_es = nullptr, *d_ee = nullptr;
   uint64_t q_cap = 0;
@@ -214,8 +219,16 @@ __global__ void __launch_bounds__(256) mk_mco_extent_kernel(const uint32_t *qids
 }
 
 /* command_dist.c:1038-1045: for every id of the slice, every genome of its row: ct[query][genome]++ */
-template <bool LDS>
-__global__ void __launch_bounds__(1024) mk_mco_count_kernel(const mk_mco_item *items, uint32_t nitems, const uint32_t *gids,
+/* genome numbers as 16-bit values when the database has fewer than 65 536 genomes: the lists are the bytes this kernel moves */
+__global__ void __launch_bounds__(256) mk_mco_pack16_kernel(const uint32_t *in, uint64_t n, uint16_t *out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t v = in[i];
+    out[i] = v < 0xFFFFu ? (uint16_t)v : (uint16_t)0xFFFFu; /* >= ref_num: ignored by the counting kernel */
+  }
+}
+
+template <bool LDS, class G>
+__global__ void __launch_bounds__(1024) mk_mco_count_kernel(const mk_mco_item *items, uint32_t nitems, const G *gids,
                                                             const unsigned long long *es, const unsigned long long *ee, uint32_t R,
                                                             uint32_t *ct) {
   extern __shared__ uint32_t mk_mco_acc[];
@@ -233,21 +246,58 @@ __global__ void __launch_bounds__(1024) mk_mco_count_kernel(const mk_mco_item *i
       const unsigned long long i = base + lane;
       unsigned long long s = 0, e = 0;
       if (i < end) { s = es[i]; e = ee[i]; }
-      const bool wide = e - s > 32ull;
-      if (!wide)
-        for (unsigned long long g = s; g < e; g++) { /* short row: the lane walks it */
-          const uint32_t r = gids[g];
-          if (r < R) atomicAdd(&tgt[r], 1u);
-        }
+      /* Both walks issue every load of a step before the first increment: the kernel is bound by memory latency, not
+       * by bytes or by the atomics.  short row (<= 8 genomes): the lane walks its own row */
+      const bool wide = e - s > 8ull;
+      if (!wide && e > s) {
+        uint32_t r[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) r[u] = s + u < e ? (uint32_t)gids[s + u] : 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++)
+          if (r[u] < R) atomicAdd(&tgt[r[u]], 1u);
+      }
+      /* longer rows: the wave walks them together, 512 genomes per step, and has the first step of the next row in
+       * flight while it increments for the current one */
       unsigned long long m = __ballot(wide);
-      while (m) { /* long row: the wave walks it together */
+      uint32_t cur[8];
+      unsigned long long cs = 0, ce = 0;
+      bool have = m != 0ull;
+      if (have) {
         const int l = __ffsll((long long)m) - 1;
         m &= m - 1;
-        const unsigned long long ws = __shfl(s, l, 64), we = __shfl(e, l, 64);
-        for (unsigned long long g = ws + lane; g < we; g += 64u) {
-          const uint32_t r = gids[g];
-          if (r < R) atomicAdd(&tgt[r], 1u);
+        cs = __shfl(s, l, 64); ce = __shfl(e, l, 64);
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) cur[u] = cs + lane + 64u * u < ce ? (uint32_t)gids[cs + lane + 64u * u] : 0xFFFFFFFFu;
+      }
+      while (have) {
+        uint32_t nxt[8];
+        unsigned long long ns = 0, ne = 0;
+        const bool more = m != 0ull;
+        if (more) {
+          const int l = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          ns = __shfl(s, l, 64); ne = __shfl(e, l, 64);
+#pragma unroll
+          for (uint32_t u = 0; u < 8; u++) nxt[u] = ns + lane + 64u * u < ne ? (uint32_t)gids[ns + lane + 64u * u] : 0xFFFFFFFFu;
         }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++)
+          if (cur[u] < R) atomicAdd(&tgt[cur[u]], 1u);
+        for (unsigned long long g = cs + 512u + lane; g - lane < ce; g += 512u) { /* rows beyond 512 genomes */
+          uint32_t r[8];
+#pragma unroll
+          for (uint32_t u = 0; u < 8; u++) r[u] = g + 64u * u < ce ? (uint32_t)gids[g + 64u * u] : 0xFFFFFFFFu;
+#pragma unroll
+          for (uint32_t u = 0; u < 8; u++)
+            if (r[u] < R) atomicAdd(&tgt[r[u]], 1u);
+        }
+        if (more) {
+#pragma unroll
+          for (uint32_t u = 0; u < 8; u++) cur[u] = nxt[u];
+        }
+        cs = ns; ce = ne;
+        have = more;
       }
     }
     if (LDS) {
@@ -298,7 +348,7 @@ extern "C" int mk_mco_destroy(mk_mco *m) {
   for (int b = 0; b < 2; b++) { (void)hipFree(m->d_key[b]); (void)hipFree(m->d_val[b]); }
   (void)hipFree(m->d_tmp); (void)hipFree(m->d_index); (void)hipFree(m->d_chunk); (void)hipFree(m->d_chunk_off);
   (void)hipFree(m->d_total); (void)hipFree(m->d_row_ids); (void)hipFree(m->d_row_ends); (void)hipFree(m->d_slab);
-  (void)hipFree(m->d_ct); (void)hipFree(m->d_gids); (void)hipFree(m->d_qids); (void)hipFree(m->d_es); (void)hipFree(m->d_ee);
+  (void)hipFree(m->d_ct); (void)hipFree(m->d_gids); (void)hipFree(m->d_gids16); (void)hipFree(m->d_qids); (void)hipFree(m->d_es); (void)hipFree(m->d_ee);
   (void)hipFree(m->d_items);
   if (m->h_total) (void)hipHostFree(m->h_total);
   if (m->h_gids) (void)hipHostFree(m->h_gids);
@@ -484,20 +534,34 @@ extern "C" int mk_mco_count_add(mk_mco *m, const uint32_t *gids, uint64_t ngids,
   MK_MCO_HIP(m, hipStreamSynchronize(m->stream)); /* `items` leaves scope */
   const uint32_t nitems = (uint32_t)items.size(), R = m->ref_num;
   /* LDS counters pay when a slice brings more increments than the R-counter zero + flush costs */
-  const bool lds = R <= MK_MCO_LDS_REFS && nq / nitems >= R / 16u;
+  const bool lds = R <= MK_MCO_LDS_REFS && nq / nitems >= R / 16u && !getenv("MK_MCO_NO_LDS");
+  const bool narrow = R <= 0xFFFFu && nlists > 0 && !getenv("MK_MCO_WIDE");
+  if (narrow) {
+    if ((rc = mk_mco_grow(m, &m->d_gids16, &m->gids16_cap, nlists))) return rc;
+    hipLaunchKernelGGL(mk_mco_pack16_kernel, dim3(mk_mco_blocks(m, nlists, 256)), dim3(256), 0, m->stream, d_lists, nlists, m->d_gids16);
+  }
   if (lds) {
-    if (!m->lds_configured) {
-      MK_MCO_HIP(m, hipFuncSetAttribute((const void *)mk_mco_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(MK_MCO_LDS_REFS * 4u)));
-      m->lds_configured = true;
+    bool &configured = narrow ? m->lds_configured16 : m->lds_configured;
+    if (!configured) {
+      const void *fn = narrow ? (const void *)mk_mco_count_kernel<true, uint16_t> : (const void *)mk_mco_count_kernel<true, uint32_t>;
+      MK_MCO_HIP(m, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MK_MCO_LDS_REFS * 4u)));
+      configured = true;
     }
     const unsigned grid = nitems < (unsigned)m->num_cu * 2u ? nitems : (unsigned)m->num_cu * 2u;
-    hipLaunchKernelGGL(mk_mco_count_kernel<true>, dim3(grid), dim3(1024), (size_t)R * 4u, m->stream, m->d_items, nitems, d_lists, m->d_es,
-                       m->d_ee, R, m->d_ct);
+    if (narrow)
+      hipLaunchKernelGGL((mk_mco_count_kernel<true, uint16_t>), dim3(grid), dim3(1024), (size_t)R * 4u, m->stream, m->d_items, nitems,
+                         (const uint16_t *)m->d_gids16, m->d_es, m->d_ee, R, m->d_ct);
+    else
+      hipLaunchKernelGGL((mk_mco_count_kernel<true, uint32_t>), dim3(grid), dim3(1024), (size_t)R * 4u, m->stream, m->d_items, nitems, d_lists,
+                         m->d_es, m->d_ee, R, m->d_ct);
   } else {
     const unsigned grid = nitems < (unsigned)m->num_cu * 8u ? nitems : (unsigned)m->num_cu * 8u;
-    hipLaunchKernelGGL(mk_mco_count_kernel<false>, dim3(grid), dim3(1024), 0, m->stream, m->d_items, nitems, d_lists, m->d_es, m->d_ee, R,
-                       m->d_ct);
+    if (narrow)
+      hipLaunchKernelGGL((mk_mco_count_kernel<false, uint16_t>), dim3(grid), dim3(1024), 0, m->stream, m->d_items, nitems,
+                         (const uint16_t *)m->d_gids16, m->d_es, m->d_ee, R, m->d_ct);
+    else
+      hipLaunchKernelGGL((mk_mco_count_kernel<false, uint32_t>), dim3(grid), dim3(1024), 0, m->stream, m->d_items, nitems, d_lists, m->d_es,
+                         m->d_ee, R, m->d_ct);
   }
   MK_MCO_HIP(m, hipGetLastError());
   MK_MCO_HIP(m, hipStreamSynchronize(m->stream)); /* the caller's buffers are free again */

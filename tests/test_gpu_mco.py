@@ -77,6 +77,7 @@ def test_index_full_slab_properties(mco):
     (4, 3, 400, 50, 300, (2,)),            # LDS counters
     (900, 20, 30000, 500, 8000, ()),       # LDS, long rows (cooperative walk)
     (40000, 6, 200000, 1, 6, (1,)),        # more references than LDS counters: global atomics
+    (70000, 4, 300000, 1, 5, ()),          # more than 65 535 references: 32-bit genome lists
     (3000, 400, 20000, 5, 40, ()),         # many tiny query sketches: global atomics by the slice heuristic
     (2, 1, 100000, 60000, 90000, ()),      # one big query sketch cut into slices
 ])
@@ -86,7 +87,12 @@ def test_count_matches_oracle(mco, nref, nqry, universe, lo, hi, zero_ct):
     def draw(nsk):
         parts, index = [], [0]
         for _ in range(nsk):
-            p = rs.permutation(pool)[:int(rs.randint(lo, hi + 1))]
+            n = int(rs.randint(lo, hi + 1))
+            if n * 8 < pool.size:     # small sketch: distinct random picks without shuffling the whole pool
+                p = pool[np.unique(rs.randint(0, pool.size, size=n))]
+                p = p[rs.permutation(p.size)]
+            else:
+                p = rs.permutation(pool)[:n]
             parts.append(p)
             index.append(index[-1] + p.size)
         return np.concatenate(parts).astype(np.uint32), np.array(index, np.uint64)
