@@ -35,6 +35,7 @@
 #define MK_MCO_SLAB_ROWS (1ull << 27) /* dense-index rows per mk_mco_index_rows call (1 GiB) */
 #define MK_MCO_LDS_REFS 32768u      /* reference genomes whose counters fit in LDS (128 KiB) */
 #define MK_MCO_SLICE 16384u         /* query ids per work item */
+#define MK_MCO_STAGE_CELLS (16ull << 20) /* cells of the count matrix per pinned staging piece (64 MiB) */
 
 struct mk_mco_item {
   unsigned long long a; /* first position in the component's query id list */
@@ -78,6 +79,7 @@ struct mk_mco {
   mk_mco_item *d_items = nullptr;
   uint64_t item_cap = 0;
   bool lds_configured = false;
+  uint32_t *h_stage[2] = {nullptr, nullptr};
   char err[256] = {0};
 };
 
@@ -354,6 +356,8 @@ extern "C" int mk_mco_destroy(mk_mco *m) {
   if (m->h_gids) (void)hipHostFree(m->h_gids);
   if (m->h_row_ids) (void)hipHostFree(m->h_row_ids);
   if (m->h_row_ends) (void)hipHostFree(m->h_row_ends);
+  for (int b = 0; b < 2; b++)
+    if (m->h_stage[b]) (void)hipHostFree(m->h_stage[b]);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return MK_OK;
@@ -575,10 +579,24 @@ extern "C" int mk_mco_count_finish(mk_mco *m, uint32_t *ct) {
   const uint64_t cells = (uint64_t)m->ref_num * m->qry_num;
   m->counting = false;
   if (cells == 0) return MK_OK;
-  std::vector<uint32_t> tmp;
-  try { tmp.resize(cells); } catch (...) { return mk_mco_fail(m, MK_ERR_NOMEM, "no host memory for %llu counters", (unsigned long long)cells); }
-  MK_MCO_HIP(m, hipMemcpyAsync(tmp.data(), m->d_ct, cells * 4, hipMemcpyDeviceToHost, m->stream));
-  MK_MCO_HIP(m, hipStreamSynchronize(m->stream));
-  for (uint64_t i = 0; i < cells; i++) ct[i] += tmp[i];
+  /* the matrix comes back through two pinned pieces: the copy of piece i+1 runs while piece i is added into ct */
+  const uint64_t piece = MK_MCO_STAGE_CELLS;
+  if (!m->h_stage[0]) {
+    MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_stage[0], piece * 4, hipHostMallocDefault));
+    MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_stage[1], piece * 4, hipHostMallocDefault));
+  }
+  const uint64_t npieces = (cells + piece - 1) / piece;
+  MK_MCO_HIP(m, hipMemcpyAsync(m->h_stage[0], m->d_ct, (cells < piece ? cells : piece) * 4, hipMemcpyDeviceToHost, m->stream));
+  for (uint64_t p = 0; p < npieces; p++) {
+    MK_MCO_HIP(m, hipStreamSynchronize(m->stream)); /* piece p has arrived */
+    if (p + 1 < npieces) {
+      const uint64_t off = (p + 1) * piece, len = cells - off < piece ? cells - off : piece;
+      MK_MCO_HIP(m, hipMemcpyAsync(m->h_stage[(p + 1) & 1], m->d_ct + off, len * 4, hipMemcpyDeviceToHost, m->stream));
+    }
+    const uint64_t off = p * piece, len = cells - off < piece ? cells - off : piece;
+    const uint32_t *src = m->h_stage[p & 1];
+    uint32_t *dst = ct + off;
+    for (uint64_t i = 0; i < len; i++) dst[i] += src[i];
+  }
   return MK_OK;
 }
