@@ -393,3 +393,47 @@ def test_cli_set_c_combines_pan_directories(tmp_path):
     (tmp_path / "q" / "cofiles.stat").write_bytes(struct.pack("<IB3xiiiiQ", 78, 0, 14, 2, 1, 3, 999))
     r = subprocess.run([cli, "set", "-c", "-o", out] + dirs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"not match 0th shuf_id" in r.stderr
+
+
+# ---- distance.out (host code of the `dist -r` search) ---------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_dist_print_equals_oracle_on_random_matrices(seed, tmp_path):
+    """mk_dist_print (product, host C) against ko_dist_print (oracle restatement pinned on the reference): the same bytes for
+    random sketch sizes / shared counts, every option combination, including empty sketches, identical sketches, shared = 0"""
+    import numpy as np
+    import oracle_binding as ob
+    from metakssd_amd import capi
+    rs = np.random.RandomState(seed)
+    R, Q = int(rs.randint(1, 40)), int(rs.randint(1, 12))
+    ref_ct = rs.randint(0, 5000, size=R).astype(np.uint32)
+    qry_ct = rs.randint(0, 5000, size=Q).astype(np.uint32)
+    ref_ct[rs.randint(0, R)] = 0 if seed % 2 else ref_ct[0]
+    qry_ct[rs.randint(0, Q)] = 0
+    qry_ct[0] = ref_ct[0]
+    ct = np.zeros((Q, R), np.uint32)
+    for q in range(Q):
+        for r in range(R):
+            m = int(min(qry_ct[q], ref_ct[r]))
+            ct[q, r] = 0 if m == 0 or rs.rand() < 0.2 else (m if rs.rand() < 0.15 else rs.randint(0, m + 1))
+    rn = ["ref/genome_%d.fa" % i for i in range(R)]
+    qn = ["q%d.fq.gz" % i for i in range(Q)]
+    for metric in (0, 1):
+        for outfields in (0, 1, 2):
+            for corr in (0, 1):
+                for nb in sorted({0, 1, min(3, R), R}):
+                    for dth in (1.0, 0.3, 0.02):
+                        kw = dict(metric=metric, outfields=outfields, correction=corr, num_neigb=nb, dthreshold=dth)
+                        a, b = str(tmp_path / "a.out"), str(tmp_path / "b.out")
+                        assert capi.dist_print(a, ref_ct, qry_ct, rn, qn, ct, 2 * (6 + seed % 5), 2 * (seed % 3), **kw) == 0
+                        assert ob.dist_print(b, ref_ct, qry_ct, rn, qn, ct, 2 * (6 + seed % 5), 2 * (seed % 3), **kw) == 0
+                        assert open(a, "rb").read() == open(b, "rb").read(), kw
+
+
+def test_dist_print_rejects_what_the_reference_gives_up_on(tmp_path):
+    import numpy as np
+    from metakssd_amd import capi
+    args = ([5, 6], [4], ["a", "b"], ["q"], np.array([[1, 2]], np.uint32), 20, 6)
+    assert capi.dist_print(str(tmp_path / "x"), *args, num_neigb=3) == capi.MK_ERR_ARG       # -N above the number of references
+    assert capi.dist_print(str(tmp_path / "x"), *args, metric=2) == capi.MK_ERR_ARG
+    assert capi.dist_print(str(tmp_path / "x"), *args, outfields=3) == capi.MK_ERR_ARG
+    assert capi.dist_print(str(tmp_path / "x"), *args, num_neigb=2) == 0
