@@ -1026,8 +1026,8 @@ static int run_stage2(const char *codir, const char *mcodir, int device, int qui
   mk_mco *m;
   if (mk_mco_create(device, &m) != MK_OK) die("mk_mco_create failed: %s", mk_mco_last_error(NULL));
   const uint64_t slab = 1ull << 27;
-  uint64_t *rows = malloc(slab * 8);
-  if (!rows) die("out of memory");
+  uint64_t *rows = NULL; /* pinned: the slabs come back at PCIe speed instead of through a pageable bounce buffer */
+  if (mk_host_alloc((void **)&rows, slab * 8) != MK_OK) die("out of memory");
   for (int c = 0; c < comp_num; c++) {
     size_t nb = 0, ib = 0;
     snprintf(path, sizeof path, "%s/combco.index.%d", codir, c);
@@ -1058,7 +1058,7 @@ static int run_stage2(const char *codir, const char *mcodir, int device, int qui
     if (fclose(f)) die("%s: write failed", path);
     if (!quiet) printf("component %d: %llu ids in %llu rows\n", c, (unsigned long long)n, (unsigned long long)nrows);
   }
-  free(rows); free(st);
+  mk_host_free(rows); free(st);
   mk_mco_destroy(m);
   return 0;
 }

@@ -99,3 +99,43 @@ def gather_file_sketches(mine, ncomp, dst=0, group=None, device=None):
                 at += int(ll[f, c])
             out.append(comps)
     return out
+
+
+# ---- `dist -r` search (SURVEY.md 8f N4): query sketches are the unit -- every rank counts a contiguous block of query
+# sketches against the whole database; the rows of the count matrix are gathered in rank order, nothing is reduced -----
+def shard_queries(qry_num, rank, world):
+    """[lo, hi) of the query sketches `rank` counts (contiguous, rank order == sketch order)"""
+    return shard_range(qry_num, rank, world)
+
+
+def gather_count_rows(local_ct, qry_num, ref_num, dst=0, group=None, device=None):
+    """local_ct: uint32 numpy array (my query sketches x ref_num).  Returns on `dst` the whole qry_num x ref_num matrix
+    (rows in sketch order), None elsewhere.  One exchange: every other rank sends its block to `dst`."""
+    import numpy as np
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device or torch.device("cpu")
+    local_ct = np.ascontiguousarray(local_ct, dtype=np.uint32).reshape(-1, ref_num) if ref_num else np.zeros((0, 0), np.uint32)
+    lo, hi = shard_queries(qry_num, rank, world)
+    assert local_ct.shape[0] == hi - lo or ref_num == 0
+    ops, bufs = [], {}
+    if rank == dst:
+        for r in range(world):
+            rlo, rhi = shard_queries(qry_num, r, world)
+            n = (rhi - rlo) * ref_num
+            if r != dst and n:
+                bufs[r] = torch.empty(n, dtype=torch.int32, device=dev)
+                ops.append(dist.P2POp(dist.irecv, bufs[r], r, group))
+    elif local_ct.size:
+        ops.append(dist.P2POp(dist.isend, torch.from_numpy(local_ct.reshape(-1).view(np.int32).copy()).to(dev), dst, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank != dst:
+        return None
+    out = np.zeros((qry_num, ref_num), np.uint32)
+    for r in range(world):
+        rlo, rhi = shard_queries(qry_num, r, world)
+        if rhi > rlo and ref_num:
+            out[rlo:rhi] = local_ct if r == dst else bufs[r].cpu().numpy().view(np.uint32).reshape(rhi - rlo, ref_num)
+    return out

@@ -34,6 +34,20 @@ def test_file_sharded_sketches_gather_in_file_order_over_gloo(world, tmp_path):
     assert open(result).read() == "OK"
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_query_sharded_search_rows_gather_over_gloo(world, tmp_path):
+    """`dist -r` search: query sketches are the unit, every rank counts its block against the whole database,
+    rank 0 receives the rows in sketch order -- equal to the unsharded matrix"""
+    result = str(tmp_path / "result.txt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MK_DIST_RESULT=result)
+    port = 33500 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_search_worker.py")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    assert open(result).read() == "OK"
+
+
 def test_shard_ranges_cover_and_order():
     sys.path.insert(0, ROOT)
     from metakssd_amd.shard import shard_range

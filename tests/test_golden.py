@@ -438,6 +438,20 @@ def test_product_cli_stage2_search_end_to_end(shuf_files, tmp_path):
             _run([PRODUCT_CLI, "dist", "--quiet", "-r", db + ".mco", "-o", case + ".out", "--keepskf"] + entry["flags"] + [qsk], str(tmp_path))
             for f in ("distance.out", "sharedk_ct.dat"):
                 assert filecmp.cmp(os.path.join(gc.GOLDEN, "expected", case, f), str(tmp_path / (case + ".out") / f), shallow=False), (case, f)
+        # the same search with the query sketches sharded over two ranks (one device, gloo): rows gathered on rank 0
+        import sys
+        case = "search_ctm_n2_L1K7"
+        tool = os.path.join(ROOT, "tools", "search_multi.py")
+        for world in (1, 2):
+            launch = [sys.executable] if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                                          "--master-addr", "127.0.0.1", "--master-port", str(34500 + os.getpid() % 2000)]
+            extra = [] if world == 1 else ["--backend", "gloo", "--same-device"]
+            r = subprocess.run(launch + [tool, "-r", db + ".mco", "-o", "multi%d" % world] + SEARCH_CASES[case]["flags"] + [case + ".qsk"] + extra,
+                               cwd=str(tmp_path), env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdin=subprocess.DEVNULL,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+            for f in ("distance.out", "sharedk_ct.dat"):
+                assert filecmp.cmp(os.path.join(gc.GOLDEN, "expected", case, f), str(tmp_path / ("multi%d" % world) / f), shallow=False), (world, f)
         # without --keepskf the counts file is removed (command_dist.c:1633); a second run into the same directory works
         case = "search_default_L1K7"
         _run([PRODUCT_CLI, "dist", "--quiet", "-r", db + ".mco", "-o", "again", case + ".qsk"], str(tmp_path))
