@@ -419,7 +419,7 @@ def test_product_cli_stage2_search_end_to_end(shuf_files, tmp_path):
     import xxhash
     db = "db_strains_L1K7"
     if shutil.disk_usage(str(tmp_path)).free < 48 << 30:
-        pytest.skip("needs 32 GiB of scratch space for mco.index.0")
+        pytest.skip("needs 32 GiB of scratch space for mco.index.0 (three times in a row)")
     dist = [PRODUCT_CLI, "dist", "--quiet", "-p", "4"]
     sk = make_search_db_sketch(db, shuf_files, tmp_path, dist)
     try:
@@ -456,8 +456,33 @@ def test_product_cli_stage2_search_end_to_end(shuf_files, tmp_path):
         case = "search_default_L1K7"
         _run([PRODUCT_CLI, "dist", "--quiet", "-r", db + ".mco", "-o", "again", case + ".qsk"], str(tmp_path))
         assert sorted(os.listdir(str(tmp_path / "again"))) == ["distance.out"]
+        # -f: print again from a kept counts file, other options; the file given with -f is removed like any other (:1633)
+        case = "search_default_L1K7"
+        shutil.copy(str(tmp_path / (case + ".out") / "sharedk_ct.dat"), str(tmp_path / "kept.dat"))
+        _run([PRODUCT_CLI, "dist", "--quiet", "-r", db + ".mco", "-o", "fromskf", "-f", "kept.dat", "-M", "1", "-O", "1", "-N", "2",
+              "search_ctm_n2_L1K7.qsk"], str(tmp_path))
+        assert filecmp.cmp(os.path.join(gc.GOLDEN, "expected", "search_ctm_n2_L1K7", "distance.out"), str(tmp_path / "fromskf" / "distance.out"),
+                           shallow=False)
+        assert not os.path.exists(str(tmp_path / "kept.dat"))
+        os.remove(str(tmp_path / (db + ".mco") / "mco.index.0"))
+        # `-r <sketch directory>`: stage II goes next to the sketches (command_dist.c:119-122), then the search runs against it
+        shutil.copytree(str(tmp_path / sk), str(tmp_path / "inplace.sk"))
+        _run([PRODUCT_CLI, "dist", "--quiet", "-r", "inplace.sk", "-o", "inplace.out", "--keepskf", case + ".qsk"], str(tmp_path))
+        assert filecmp.cmp(os.path.join(exp, "mco.0"), str(tmp_path / "inplace.sk" / "mco.0"), shallow=False)
+        for f in ("distance.out", "sharedk_ct.dat"):
+            assert filecmp.cmp(os.path.join(gc.GOLDEN, "expected", case, f), str(tmp_path / "inplace.out" / f), shallow=False), f
+        os.remove(str(tmp_path / "inplace.sk" / "mco.index.0"))
+        # `-L .. -r <genome files>`: stage I (without abundances) and stage II into the output directory (:68-114)
+        os.makedirs(str(tmp_path / "genomes"))
+        for i, f in enumerate(gc.build_search_inputs(db, SEARCH_DBS[db]["refs"], str(tmp_path))):
+            shutil.copy(str(tmp_path / f), str(tmp_path / "genomes" / ("g%d.fa" % i)))
+        _run([PRODUCT_CLI, "dist", "--quiet", "-L", shuf_files(SEARCH_DBS[db]["shuf"]), "-A", "-r", "genomes", "-o", "fromraw"], str(tmp_path))
+        assert sorted(os.listdir(str(tmp_path / "fromraw"))) == ["cofiles.stat", "combco.0", "combco.index.0", "mco.0", "mco.index.0", "mcofiles.stat"]
+        assert filecmp.cmp(os.path.join(exp, "mco.0"), str(tmp_path / "fromraw" / "mco.0"), shallow=False)
+        os.remove(str(tmp_path / "fromraw" / "mco.index.0"))
     finally:
-        try:
-            os.remove(str(tmp_path / (db + ".mco") / "mco.index.0"))
-        except OSError:
-            pass
+        for d in (db + ".mco", "inplace.sk", "fromraw"):
+            try:
+                os.remove(str(tmp_path / d / "mco.index.0"))
+            except OSError:
+                pass
