@@ -1231,6 +1231,8 @@ int main(int argc, char **argv) {
   /* dist_dispatch(), command_dist.c:49-250: what the arguments are decides the mode */
   if (refpath) {
     if (dopt.metric < 0 || dopt.metric > 1 || dopt.outfields < 0 || dopt.outfields > 2) die("-M takes 0/1 and -O 0/1/2");
+    struct stat rst;
+    if (stat(refpath, &rst) != 0) die("test_get_fullpath()::%s: %s", refpath, strerror(errno)); /* command_dist.c:321-322 */
     const int ref_co = dir_has(refpath, "cofiles.stat"), ref_mco = dir_has(refpath, "mcofiles.stat");
     if (ref_co && !ref_mco) run_stage2(refpath, refpath, device, quiet); /* :119-122: the index goes next to the sketches */
     if (ref_co || ref_mco) {

@@ -30,4 +30,25 @@ run $B composite -r o4 -q o5
 run $B composite -r o5 -q o4
 run $B reverse o4
 ls o1 o2 o4 2>/dev/null | tr '\n' ' '; echo
-rm -rf $W
+# stage II / search (none of these may start writing a 32 GiB index)
+mkdir fakemco badmco
+python3 - <<'PY'
+import struct
+st = open("o4/cofiles.stat", "rb").read()
+shuf_id, = struct.unpack_from("<I", st, 0)
+k, dr, comp, n = struct.unpack_from("<iiii", st, 8)
+open("fakemco/mcofiles.stat", "wb").write(struct.pack("<Iiiii", shuf_id, k, dr, comp, n) + st[32:])
+open("badmco/mcofiles.stat", "wb").write(struct.pack("<Iiiii", shuf_id + 1, k, dr, comp, n) + st[32:])
+open("fakemco/mco.0", "wb").write(b"")
+open("fakemco/mco.index.0", "wb").write(b"\0" * 4096)
+PY
+run $B dist -r nothere -o s1 o4
+run $B dist -r badmco -o s2 o4
+run $B dist -r fakemco -o s3 o4
+run $B dist -r fakemco -o s4 nothere
+run $B dist -r fakemco -o s5 fakemco
+run $B dist -r fakemco -o s6 -M 7 o4
+run $B dist -r fakemco -o s7 -f nothere.dat o4
+run $B dist -r fakemco -o s8 -f one.fq -N 50 o4
+run $B dist -o s9 o4 o5
+cd / && rm -rf $W
