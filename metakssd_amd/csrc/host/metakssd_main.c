@@ -1160,7 +1160,8 @@ static int run_search(const char *refdir, const char *qrydir, const char *outdir
         else started++;
       }
       for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
-      rc = mk_mco_count_add(m, gids, gb / 4, NULL, es, ee, (const uint64_t *)qidx, qry_ct);
+      static const uint32_t no_gids = 0; /* a database of empty sketches has an empty mco.N: still a valid (all-zero) search */
+      rc = mk_mco_count_add(m, gids ? gids : &no_gids, gb / 4, NULL, es, ee, (const uint64_t *)qidx, qry_ct);
       if (rc != MK_OK) die("mk_mco_count_add failed (%d): %s", rc, mk_mco_last_error(m));
       free(es); free(ee); free(qids); free(qidx);
       munmap((void *)index, xb);
