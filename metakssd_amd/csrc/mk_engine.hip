@@ -439,7 +439,7 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   size_t lds = 0;
   for (;; threads -= 256) {
     lds = ((size_t)a.bm_words + (size_t)(threads / 64) * a.wave_lds_dwords) * 4u;
-    if (onepass) lds += 2u * 5u * 64u * 4u; /* staging offset table of the one-pass kernels (NPIECES = 5) */
+    if (vec) lds += 2u * (a.ppr <= 5u ? 5u : (uint32_t)MK_MAX_PIECES) * 64u * 4u; /* staging offset table of the 16-byte kernels: [2*NPIECES][64] */
     if (lds <= 160u * 1024u || threads <= 512) break;
   }
   if (lds > 160u * 1024u) return mk_fail(e, MK_ERR_ARG, "scan: LDS budget exceeded (%zu bytes)", lds);

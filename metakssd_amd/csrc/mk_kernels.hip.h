@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   uint32_t *bitmap = lds;
   uint32_t *tile = lds + a.bm_words + wave * a.wave_lds_dwords;
 
-  if constexpr (ONEPASS) { /* staging offset table (see goff_of below): [2*NPIECES][64] dwords behind the wave tiles */
+  if constexpr (VEC16) { /* staging offset table (see goff_of below): [2*NPIECES][64] dwords behind the wave tiles */
     if (wave == 0) {
       uint32_t *t = lds + a.bm_words + WAVES * a.wave_lds_dwords + lane;
 #pragma unroll
@@ -379,13 +379,13 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
    * needed (a handful of ops per piece per step) rather than held in 2*NP registers */
   auto goff_calc = [&](int i) { const uint32_t q = lane + 64u * i; const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr; return r * a.stride + c * PW; };
   auto loff_calc = [&](int i) { const uint32_t q = lane + 64u * i; const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr; return r * a.rowdw + c * (PW / 4u); };
-  /* ONEPASS: the 2*NP offsets live in a table in LDS (they depend on the lane only, one table serves every wave).  Left to
-   * itself the compiler hoists them out of the tile loop, runs out of registers and reloads them from SCRATCH at every tile:
-   * 31 MB of scratch across the grid, i.e. 2.4 GB of extra HBM reads per launch (rocprofv3 FETCH_SIZE).  LDS reads cannot be
-   * hoisted across the tile stores and cost no VALU issue. */
+  /* 16-byte path: the 2*NP offsets live in a table in LDS (they depend on the lane only, one table serves every wave).
+   * Left to itself the compiler hoists them out of the tile loop, runs out of registers in the 1024-thread builds and
+   * reloads them from SCRATCH at every tile: 31 MB of scratch across the grid, i.e. 2.4 GB of extra HBM reads per launch of
+   * the benchmark (rocprofv3 FETCH_SIZE).  LDS reads cannot be hoisted across the tile stores and cost no VALU issue. */
   const uint32_t *offtab = lds + a.bm_words + WAVES * a.wave_lds_dwords + lane;
-  auto goff_of = [&](int i) { if constexpr (ONEPASS) return offtab[128 * i]; else return goff_calc(i); };
-  auto loff_of = [&](int i) { if constexpr (ONEPASS) return offtab[128 * i + 64]; else return loff_calc(i); };
+  auto goff_of = [&](int i) { if constexpr (VEC16) return offtab[128 * i]; else return goff_calc(i); };
+  auto loff_of = [&](int i) { if constexpr (VEC16) return offtab[128 * i + 64]; else return loff_calc(i); };
   auto issue_loads = [&](uint32_t tile_id, uint32_t cb) {
     const uint32_t row0 = tile_id << 6;
     const uint8_t *base = a.rows + (uint64_t)row0 * a.stride + (uint64_t)cb * a.CB;
