@@ -328,14 +328,14 @@ def dense_index_xxh64(row_ids, row_ends):
     ends = np.concatenate([[0], np.asarray(row_ends, np.uint64)]).astype(np.uint64)
     rid = np.asarray(row_ids, np.uint64)
     step = 1 << 26
+    buf = np.empty(step, np.uint64)                     # one reused 512 MiB piece: no per-piece allocation, no tobytes() copy
     for r0 in range(0, 1 << 32, step):
         lo, hi = np.searchsorted(rid, [r0, r0 + step], side="left")
         if lo == hi:
-            piece = np.full(step, ends[lo], np.uint64)
+            buf.fill(ends[lo])
         else:
-            rows = np.arange(r0, r0 + step, dtype=np.uint64)
-            piece = ends[np.searchsorted(rid, rows, side="right")]
-        h.update(piece.tobytes())
+            buf[:] = ends[np.searchsorted(rid, np.arange(r0, r0 + step, dtype=np.uint64), side="right")]
+        h.update(buf)
     return h.hexdigest()
 
 
