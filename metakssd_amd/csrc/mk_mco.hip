@@ -192,19 +192,29 @@ __global__ void __launch_bounds__(256) mk_mco_rowwrite_kernel(const uint32_t *ke
     if ((flags >> k) & 1u) { row_ids[o] = key[i0 + k]; row_ends[o] = i0 + k + 1; o++; }
 }
 
-/* co2mco.c:59-66: out[r - row0] = cumulative end of the last non-empty row <= r (0 before the first one) */
+/* co2mco.c:59-66: out[r - row0] = cumulative end of the last non-empty row <= r (0 before the first one).  A block owns
+ * MK_MCO_INDEX_ROWS consecutive rows; two block-uniform searches bound the table entries that fall into them.  Most blocks of
+ * the 2^32-row index hold none: they stream one constant with 16-byte stores (the write roofline); the others search per row
+ * inside the block's few entries. */
+#define MK_MCO_INDEX_ROWS 2048u
 __global__ void __launch_bounds__(256) mk_mco_index_kernel(const uint32_t *row_ids, const unsigned long long *row_ends, uint64_t nrows_tab,
                                                            uint64_t row0, uint64_t nrows, unsigned long long *out) {
-  const uint64_t b0 = (uint64_t)blockIdx.x * blockDim.x;
+  const uint64_t b0 = (uint64_t)blockIdx.x * MK_MCO_INDEX_ROWS;
   if (b0 >= nrows) return;
-  const uint64_t last = b0 + blockDim.x - 1 < nrows ? b0 + blockDim.x - 1 : nrows - 1;
-  /* the block's rows see table positions [lo, hi]: both searches run on block-uniform values */
-  const uint64_t lo = mk_mco_upper(row_ids, 0, nrows_tab, (uint64_t)(row0 + b0));
-  const uint64_t hi = mk_mco_upper(row_ids, lo, nrows_tab, (uint64_t)(row0 + last));
-  const uint64_t r = b0 + threadIdx.x;
-  if (r >= nrows) return;
-  const uint64_t u = mk_mco_upper(row_ids, lo ? lo - 1 : 0, hi, (uint64_t)(row0 + r));
-  out[r] = u ? row_ends[u - 1] : 0ull;
+  const uint64_t last = b0 + MK_MCO_INDEX_ROWS - 1 < nrows ? b0 + MK_MCO_INDEX_ROWS - 1 : nrows - 1;
+  const uint64_t lo = mk_mco_upper(row_ids, 0, nrows_tab, (uint64_t)(row0 + b0));     /* table entries <= first row */
+  const uint64_t hi = mk_mco_upper(row_ids, lo, nrows_tab, (uint64_t)(row0 + last));  /* table entries <= last row */
+  if (lo == hi && last - b0 + 1 == MK_MCO_INDEX_ROWS) { /* no row of the table starts inside a full block: one value */
+    const unsigned long long v = lo ? row_ends[lo - 1] : 0ull;
+    ulonglong2 *o = (ulonglong2 *)(out + b0); /* out and b0 are 16-byte aligned */
+#pragma unroll
+    for (uint32_t k = 0; k < MK_MCO_INDEX_ROWS / 512u; k++) o[threadIdx.x + 256u * k] = make_ulonglong2(v, v);
+    return;
+  }
+  for (uint64_t r = b0 + threadIdx.x; r <= last; r += 256u) {
+    const uint64_t u = mk_mco_upper(row_ids, lo, hi, (uint64_t)(row0 + r));
+    out[r] = u ? row_ends[u - 1] : 0ull;
+  }
 }
 
 /* command_dist.c:1040-1041 from the row table instead of the dense index */
@@ -465,7 +475,7 @@ extern "C" int mk_mco_index_rows(mk_mco *m, uint64_t row0, uint64_t nrows, uint6
   if (nrows == 0) return MK_OK;
   MK_MCO_HIP(m, hipSetDevice(m->device));
   if (!m->d_slab) MK_MCO_HIP(m, hipMalloc((void **)&m->d_slab, MK_MCO_SLAB_ROWS * 8));
-  hipLaunchKernelGGL(mk_mco_index_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, m->stream, m->d_row_ids, m->d_row_ends,
+  hipLaunchKernelGGL(mk_mco_index_kernel, dim3((unsigned)((nrows + MK_MCO_INDEX_ROWS - 1) / MK_MCO_INDEX_ROWS)), dim3(256), 0, m->stream, m->d_row_ids, m->d_row_ends,
                      m->nrows, row0, nrows, m->d_slab);
   MK_MCO_HIP(m, hipGetLastError());
   MK_MCO_HIP(m, hipMemcpyAsync(out, m->d_slab, nrows * 8, hipMemcpyDeviceToHost, m->stream));
