@@ -1,12 +1,13 @@
 /*
  * kssd_oracle.h -- TEST INFRASTRUCTURE ONLY.
  *
- * CPU restatement (plain C) of the MetaKSSD `dist -L <.shuf> [-A]` sketching path.  It is the
- * parity checker for the HIP engine; nothing in the product (metakssd_amd/, include/) may link,
- * import or execute it.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ * CPU restatement (plain C) of the MetaKSSD `dist -L <.shuf> [-A]` sketching path and of the rows widened into after it
+ * (`set`, `composite -q`, stage II and the `dist -r` search).  It is the parity checker for the HIP engine; nothing in
+ * the product (metakssd_amd/, include/) may link, import or execute it.  Only tests/, __graft_entry__.smoke(), bench.py's
+ * cpu_baseline leg and the measurement / fuzz scripts under tools/ (as the checker and the timed CPU baseline) use it.
  *
  * Every function cites the reference file:line it restates (paths relative to /root/reference).
- * Parity is PINNED: oracle/check_vs_ref.sh runs this restatement and the compiled reference
+ * Parity is PINNED: oracle/check_vs_ref.py runs this restatement and the compiled reference
  * (oracle/_ref/metakssd, built from the reference's own sources by oracle/Makefile) on the same
  * inputs and compares the payload files byte for byte; tests/golden/ holds vectors produced by
  * the compiled reference (tests/golden/make_golden.py).
