@@ -5,11 +5,13 @@ cd $GRAFT_REPO_ROOT/metakssd_amd/csrc
 cp ../lib/libmetakssd_hip.so /tmp/lib_orig.so
 gcc -std=gnu11 -O2 -fPIC -I../../include -Ihost -c host/mk_shuf_params.c -o /tmp/a1.o; gcc -std=gnu11 -O2 -fPIC -I../../include -Ihost -c host/mk_frontend.c -o /tmp/a2.o; gcc -std=gnu11 -O2 -fPIC -I../../include -Ihost -c host/mk_sketchdir.c -o /tmp/a3.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -Ihost -c mk_setop.hip -o /tmp/a4.o 2>/dev/null
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -Ihost -c mk_mco.hip -o /tmp/a5.o 2>/dev/null
+gcc -std=gnu11 -O2 -fPIC -I../../include -Ihost -c host/mk_distprint.c -o /tmp/a6.o
 IFS='|' read -ra VS <<< "${VARIANTS:-none|-DMK_ABLATE=3}"
 for v in "${VS[@]}"; do
   if [ "$v" != "none" ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -Ihost -Wno-unused-value $v -c mk_engine.hip -o /tmp/mk_engine_ab.o 2>/dev/null
-    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/libmetakssd_hip.so /tmp/mk_engine_ab.o /tmp/a1.o /tmp/a2.o /tmp/a3.o /tmp/a4.o
+    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/libmetakssd_hip.so /tmp/mk_engine_ab.o /tmp/a1.o /tmp/a2.o /tmp/a3.o /tmp/a4.o /tmp/a5.o /tmp/a6.o -lm
   else
     cp /tmp/lib_orig.so ../lib/libmetakssd_hip.so
   fi
