@@ -160,3 +160,28 @@ def test_state_and_argument_errors(mco):
         m.count(2, np.array([0, 1], np.uint64), [1], [{"gids": np.zeros(3, np.uint32), "ext_start": np.array([2], np.uint64),
                                                        "ext_end": np.array([9], np.uint64)}])
     m.close()
+
+
+@pytest.mark.parametrize("env", [{"MK_MCO_WIDE": "1"}, {"MK_MCO_NO_LDS": "1"}, {"MK_MCO_WIDE": "1", "MK_MCO_NO_LDS": "1"}])
+def test_count_kernel_variants_agree(mco, monkeypatch, env):
+    """the measurement switches select the other instantiations of the counting kernel (32-bit lists with LDS counters,
+    global atomics on a small database): same matrix"""
+    rs = np.random.RandomState(17)
+    pool = np.unique(rs.randint(0, 2 ** 32, size=40000, dtype=np.uint64).astype(np.uint32))
+    def draw(nsk, lo, hi):
+        parts, index = [], [0]
+        for _ in range(nsk):
+            p = rs.permutation(pool)[:int(rs.randint(lo, hi + 1))]
+            parts.append(p)
+            index.append(index[-1] + p.size)
+        return np.concatenate(parts).astype(np.uint32), np.array(index, np.uint64)
+    rids, rindex = draw(700, 200, 9000)
+    qids, qindex = draw(9, 0, 20000)
+    ctx = np.diff(qindex).astype(np.uint32)
+    og, ori, ore = ob.mco_build(rids, rindex)
+    want = ob.mco_count(og, ori, ore, qids, qindex, ctx, 700)
+    mco.build(rids, rindex)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = mco.count(700, qindex, ctx, [{"qry_ids": qids}])
+    assert np.array_equal(got, want)
