@@ -7,10 +7,14 @@
  * command_dist.c:201-248, run_stageI() :341-500) and writes the same sketch directory
  * (cofiles.stat, combco.N, combco.index.N, combco.N.a).
  *
+ * Also built, each on the device behind the same C ABI: FASTQ without -A (-n / -Q, fastq2co), `set -u|-q|-i|-s|-g|-c|-P`,
+ * `composite -r -q [-b]` / `-d`, stage II (`dist -o <mco> <sketch dir>`, `dist -L .. -r <genomes> -o <db>`) and the
+ * database search `dist -r <mco> -o <out> [-M -O -N -D --correction --keepskf -f] <sketch dir>`.
+ *
  * Differences, all documented in DESIGN.md: inputs are processed in discovery order (the reference
- * applies a time-seeded shuffle, command_dist.c:215); FASTQ without -A (the 4-bit -n/-Q path,
- * fastq2co) and every non-sketching mode of `dist` are not part of this build; -p N sets the number of host
- * threads that read and frame/window input files ahead of the GPU (default 8); --device selects the GPU.
+ * applies a time-seeded shuffle, command_dist.c:215); --byread, combine_queries, composite -i/-s and reverse are not
+ * part of this build; -p N sets the number of host threads that read and frame/window input files ahead of the GPU
+ * (default 8); --device selects the GPU.
  */
 #define _GNU_SOURCE
 #include "metakssd_hip.h"
