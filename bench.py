@@ -3,21 +3,29 @@
 
 One step = one whole sketch of the rank's resident read shard: table clear (mk_sketch_begin), scan of
 every read (mk_sketch_push_reads_device, reads already in HBM), and finish (distinct-key compaction,
-reference-order layout, slot-order dump, result copied to the host).  With N > 1 ranks (one process per
-GPU, launched by torch.distributed.run) each rank scans its own contiguous read range with global
-ordinals, ranks != 0 send their distinct-key lists to rank 0 over RCCL, rank 0 folds them in and
-finishes -- "weak" scaling: per-GPU reads fixed.
+reference-order layout, slot-order dump straight into the host's result arrays).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the scan kernel
-(HIP-event timed inside the engine on its launch stream) and, at N=1, `cpu_baseline`: the compiled
-reference (oracle/_ref/metakssd, kind "reference") or the oracle port timed on this host's cores over a
-bounded sample of the same workload.
+Workloads (BASELINE.json configs):
+  N = 1 (default)       config 3: 50 M reads on one GPU.
+  N > 1 (default)       config 4: 500 M reads split into N contiguous ranges ("strong" scaling): every rank scans its
+                        range with global ordinals, ranks != 0 send their distinct-key lists to rank 0 over RCCL,
+                        rank 0 folds them in with one import launch and finishes.
+  --reads-per-gpu R     the weak-scaling variant (R reads on every rank), any N.
+  --total-reads T       config 4's table regime at any N (N = 1: 80 GB of rows on one GPU).
+
+Rank 0 prints ONE JSON line (contract in the task statement): `value` is the HBM-resident whole-job rate; `roofline`
+is the scan kernel (HIP-event timed inside the engine on its launch stream); at N = 1 also
+  `cpu_baseline`  the compiled reference (oracle/_ref/metakssd, kind "reference") or the oracle port on this host's cores
+                  over a bounded sample of the same workload,
+  `t_stream`      the same reads from PINNED HOST rows through mk_sketch_push_reads (H2D double-buffered) to the result,
+  `t_e2e`         the product command line on the workload written as a FASTQ file in /dev/shm: process start to the
+                  sketch directory on disk (SURVEY.md 8d's three timings).  Neither host-inclusive rate is `value`.
 """
 import argparse
+import hashlib
 import json
 import os
 import shutil
-import struct
 import subprocess
 import sys
 import tempfile
@@ -30,6 +38,8 @@ READ_LEN = 150
 STRIDE = 160
 SEED = 20261002
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+CONFIG3_READS = 50_000_000
+CONFIG4_READS = 500_000_000
 
 
 def cpu_baseline(shuf, sample_reads, gpu_sketch):
@@ -44,7 +54,7 @@ def cpu_baseline(shuf, sample_reads, gpu_sketch):
             fq = os.path.join(tmp, "sample.fq")
             sp = os.path.join(tmp, "L3K11.shuf")
             shuf.write(sp)
-            rc = capi.lib.mk_synth_fastq_write(fq.encode(), SEED, 0, sample_reads, READ_LEN)
+            rc = capi.lib.mk_synth_fastq_write_mt(fq.encode(), SEED, 0, sample_reads, READ_LEN, min(cores, 64))
             assert rc == 0
             out = os.path.join(tmp, "out")
             t0 = time.perf_counter()
@@ -76,14 +86,99 @@ def cpu_baseline(shuf, sample_reads, gpu_sketch):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def leg_stream(torch, capi, eng, reads_dev, n, reps=3):
+    """t_stream: the workload's rows in pinned host memory -> mk_sketch_push_reads -> finish (result on the host)"""
+    pinned = torch.empty(n * STRIDE, dtype=torch.uint8, pin_memory=True)
+    pinned.copy_(reads_dev)
+    torch.cuda.synchronize()
+    best, total = None, 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        eng.begin(capi.MK_MODE_KOC)
+        capi._check(capi.lib.mk_sketch_push_reads(eng.h, pinned.data_ptr(), STRIDE, n, 0), eng.h)
+        r = eng.finish_raw()
+        dt = time.perf_counter() - t0
+        total = int(r.total)
+        capi.lib.mk_result_release(eng.h, r)
+        best = dt if best is None or dt < best else best
+    del pinned
+    return {"gbases_s": n * READ_LEN / best / 1e9, "h2d_gb_s": n * STRIDE / best / 1e9, "seconds": best, "reps": reps,
+            "distinct_keys": total,
+            "what": "%d reads as %d-byte rows in pinned host memory -> mk_sketch_push_reads (64 MiB H2D pieces, copy and scan "
+                    "streams overlapped) -> mk_sketch_finish; best of %d" % (n, STRIDE, reps)}
+
+
+def leg_e2e(capi, shuf, n, resident_sketch, reps=3):
+    """t_e2e: `metakssd dist -L L3K11.shuf -A` on the workload as a FASTQ file in /dev/shm, process start to sketch on disk"""
+    import numpy as np
+    cores = os.cpu_count() or 1
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    need = n * (2 * READ_LEN + 18)
+    if shm:
+        st = os.statvfs(shm)
+        if st.f_bavail * st.f_frsize < need * 1.2:
+            return {"gbases_s": None, "what": "skipped: /dev/shm has %.1f GB free, the FASTQ needs %.1f GB" %
+                    (st.f_bavail * st.f_frsize / 1e9, need / 1e9)}
+    tmp = tempfile.mkdtemp(prefix="mke2e_", dir=shm)
+    try:
+        fq, sp = os.path.join(tmp, "reads.fq"), os.path.join(tmp, "L3K11.shuf")
+        shuf.write(sp)
+        t0 = time.perf_counter()
+        rc = capi.lib.mk_synth_fastq_write_mt(fq.encode(), SEED, 0, n, READ_LEN, min(cores, 64))
+        if rc != 0:
+            return {"gbases_s": None, "what": "skipped: writing the FASTQ failed (%d)" % rc}
+        t_write = time.perf_counter() - t0
+        cli = os.path.join(ROOT, "metakssd_amd", "bin", "metakssd")
+        runs = []
+        for rep in range(reps):
+            out = os.path.join(tmp, "out%d" % rep)
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, "dist", "-L", sp, "-A", "-o", out, "--quiet", "--timing", fq], stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"gbases_s": None, "what": "CLI failed: " + r.stderr.decode(errors="replace")[-300:]}
+            tm = {}
+            for ln in r.stdout.decode(errors="replace").splitlines():
+                if ln.startswith('{"timing"'):
+                    tm = json.loads(ln)["timing"]
+            runs.append((wall, tm, out))
+        wall, tm, out = min(runs, key=lambda x: x[0])
+        ids = np.fromfile(os.path.join(out, "combco.0"), dtype=np.uint32)
+        cnt = np.fromfile(os.path.join(out, "combco.0.a"), dtype=np.uint16)
+        same = bool(np.array_equal(ids, resident_sketch[0][0]) and np.array_equal(cnt, resident_sketch[0][1]))
+        init_s = tm.get("hip_ready", 0.0)
+        return {"gbases_s": n * READ_LEN / max(wall - init_s, 1e-9) / 1e9, "gbases_s_wall": n * READ_LEN / wall / 1e9,
+                "wall_s": wall, "init_s": init_s, "file_gb": os.path.getsize(fq) / 1e9, "threads": tm.get("threads"),
+                "timeline_s": tm, "walls_s": [round(x[0], 4) for x in runs],
+                "sketch_equals_resident_run": same, "fastq_write_s": t_write,
+                "what": "`metakssd dist -L L3K11.shuf -A -o out --quiet --timing reads.fq`, %d reads = %.2f GB of FASTQ in /dev/shm; "
+                        "wall_s = process start to exit (best of %d), init_s = HIP runtime start-up inside it (first HIP call "
+                        "returning; nothing of the input is touched before that: the row buffers are pinned memory), "
+                        "gbases_s = bases / (wall_s - init_s), gbases_s_wall = bases / wall_s; the engine's tables and the .shuf "
+                        "upload are inside both" % (n, os.path.getsize(fq) / 1e9, reps)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def kernel_source_id():
+    h = hashlib.sha256()
+    for f in ("mk_kernels.hip.h", "mk_engine.hip"):
+        h.update(open(os.path.join(ROOT, "metakssd_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads-per-gpu", type=int, default=50_000_000, help="BASELINE config 3: 50 M reads on one GPU")
+    ap.add_argument("--steps", type=int, default=300, help="default: about a second of timed work at 3.5 ms per step")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reads-per-gpu", type=int, default=None, help="weak scaling: this many reads on every rank")
+    ap.add_argument("--total-reads", type=int, default=None,
+                    help="strong scaling: this many reads split over the ranks (default with N > 1: 500 M = BASELINE config 4)")
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip t_stream / t_e2e (N = 1 only anyway)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo moves the lists through the host (debug)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (needs --backend gloo)")
@@ -94,7 +189,7 @@ def main():
     import torch
     import torch.distributed as dist
     from metakssd_amd import capi
-    from metakssd_amd.shard import gather_partials
+    from metakssd_amd.shard import gather_partials_concat, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -114,13 +209,25 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    # ---- workload: contiguous global read ranges, rank-ordered ----
+    if args.reads_per_gpu is not None:
+        scaling, n, first, total_reads = "weak", args.reads_per_gpu, rank * args.reads_per_gpu, world * args.reads_per_gpu
+        workload = "%d synthetic 150 bp reads per GPU" % n
+    elif args.total_reads is not None or world > 1:
+        total_reads = args.total_reads if args.total_reads is not None else CONFIG4_READS
+        lo, hi = shard_range(total_reads, rank, world)
+        scaling, n, first = "strong", hi - lo, lo
+        workload = "%d synthetic 150 bp reads split into %d contiguous ranges (BASELINE config 4%s)" % (
+            total_reads, world, "" if total_reads == CONFIG4_READS else " at another size")
+    else:
+        scaling, n, first, total_reads = "weak", CONFIG3_READS, 0, CONFIG3_READS
+        workload = "%d synthetic 150 bp reads on one GPU (BASELINE config 3)" % n
+
     shuf = capi.Shuf.generate(11, 6, 3, 11)  # L3K11 = {k=11, subk=6, drlevel=3}, same bytes as the tests' table
     eng = capi.Engine(shuf, local_rank)
     stream = torch.cuda.current_stream().cuda_stream
     eng.set_stream(stream)
 
-    n = args.reads_per_gpu
-    first = rank * n  # contiguous global read ranges, rank-ordered
     reads = torch.empty(n * STRIDE, dtype=torch.uint8, device=dev)
     capi.synth_rows_device(local_rank, stream, SEED, first, n, READ_LEN, STRIDE, reads.data_ptr())
     torch.cuda.synchronize()
@@ -130,26 +237,33 @@ def main():
         pk = torch.empty(cap, dtype=torch.int64, device=dev)
         pc = torch.empty(cap, dtype=torch.int32, device=dev)
         po = torch.empty(cap, dtype=torch.int64, device=dev)
+        if rank == 0:  # everybody's lists land back to back in these (xdev) and go into the table with one import launch
+            rk = torch.empty(cap, dtype=torch.int64, device=xdev)
+            rc_ = torch.empty(cap, dtype=torch.int32, device=xdev)
+            ro = torch.empty(cap, dtype=torch.int64, device=xdev)
 
     result = {}
     flags = {"keep": False}
+    tail = {"t": 0.0, "steps": 0, "on": False}
 
     def step():
         eng.begin(capi.MK_MODE_KOC)
         eng.push_reads_device(reads.data_ptr(), STRIDE, n, first)
         if world > 1:
+            if tail["on"]:  # instrumented steps only: where the scan ends and rank 0's serial tail begins
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
             if rank != 0:
                 m = eng.partial_export(pk.data_ptr(), pc.data_ptr(), po.data_ptr(), cap)
-                gather_partials(pk[:m].to(xdev), pc[:m].to(xdev), po[:m].to(xdev), m, dst=0)
+                gather_partials_concat(pk[:m].to(xdev), pc[:m].to(xdev), po[:m].to(xdev), m, dst=0)
             else:
-                empty = (pk[:0].to(xdev), pc[:0].to(xdev), po[:0].to(xdev))
-                for (k, c, o) in gather_partials(*empty, 0, dst=0):
-                    k, c, o = k.to(dev), c.to(dev), o.to(dev)
-                    # the engine runs on torch's current stream: the import is ordered after the receives/copies;
-                    # the tensors must outlive the import kernel, hence the engine-side sync before they are dropped
-                    torch.cuda.current_stream().synchronize()
-                    eng.partial_import(k.data_ptr(), c.data_ptr(), o.data_ptr(), k.numel())
-                    eng.sync()
+                total_in = gather_partials_concat(pk[:0].to(xdev), pc[:0].to(xdev), po[:0].to(xdev), 0, dst=0, out=(rk, rc_, ro))
+                if total_in:
+                    k, c, o = (rk[:total_in].to(dev), rc_[:total_in].to(dev), ro[:total_in].to(dev)) if xdev != dev else (rk, rc_, ro)
+                    # the engine runs on torch's current stream: the import is ordered after the receives / copies
+                    eng.partial_import(k.data_ptr(), c.data_ptr(), o.data_ptr(), total_in)
+                    result["_alive"] = (k, c, o)  # until the next step's fence
         if rank == 0:
             if flags["keep"]:
                 result["sketch"] = eng.finish()
@@ -158,6 +272,11 @@ def main():
                 r = eng.finish_raw()
                 result["distinct"] = int(r.total)
                 capi.lib.mk_result_release(eng.h, r)
+        if world > 1 and tail["on"]:
+            torch.cuda.synchronize()
+            if rank == 0:
+                tail["t"] += time.perf_counter() - t0
+                tail["steps"] += 1
 
     def fence():
         torch.cuda.synchronize()
@@ -182,18 +301,35 @@ def main():
     prof = eng.profile()
     eng.profile_enable(False)
 
+    if world > 1:  # rank 0's serial tail (gather + import + finish), from three separately fenced steps
+        tail["on"] = True
+        for _ in range(3):
+            step()
+        tail["on"] = False
+        fence()
+
     verified = None
-    if args.verify:
+    need_sketch = args.verify or (world == 1 and not args.no_host_legs)
+    if need_sketch:
         flags["keep"] = True
         step()
         fence()
-        if rank == 0:
-            import numpy as np
-            allreads = torch.empty(world * n * STRIDE, dtype=torch.uint8, device=dev)
-            capi.synth_rows_device(local_rank, stream, SEED, 0, world * n, READ_LEN, STRIDE, allreads.data_ptr())
+        flags["keep"] = False
+    if args.verify and rank == 0:
+        import numpy as np
+        tot = total_reads
+        allreads = reads if world == 1 else torch.empty(tot * STRIDE, dtype=torch.uint8, device=dev)
+        if world > 1:
+            capi.synth_rows_device(local_rank, stream, SEED, 0, tot, READ_LEN, STRIDE, allreads.data_ptr())
             torch.cuda.synchronize()
+        # N = 1: the shards-merged-through-export/import sketch of the same reads (8 shards on this one engine) is the check
+        if world == 1:
+            merged = sharded_sketch_one_gpu(torch, capi, eng, reads, n, 8, cap, dev)
+            single = result["sketch"]
+            verified = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(single, merged))
+        else:
             eng.begin(capi.MK_MODE_KOC)
-            eng.push_reads_device(allreads.data_ptr(), STRIDE, world * n, 0)
+            eng.push_reads_device(allreads.data_ptr(), STRIDE, tot, 0)
             single = eng.finish()
             verified = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(single, result["sketch"]))
             if not verified:
@@ -201,56 +337,67 @@ def main():
                 ka = np.sort(a[0].astype(np.uint64) << np.uint64(16) | a[1].astype(np.uint64))
                 kb = np.sort(b[0].astype(np.uint64) << np.uint64(16) | b[1].astype(np.uint64))
                 result["verify_detail"] = {"n_single": int(len(a[0])), "n_merged": int(len(b[0])),
-                                           "same_multiset": bool(len(ka) == len(kb) and np.array_equal(ka, kb)),
-                                           "first_diff": int(np.argmax(a[0][:min(len(a[0]), len(b[0]))] != b[0][:min(len(a[0]), len(b[0]))]))
-                                           if len(a[0]) and len(b[0]) else -1,
-                                           "only_single": int(len(np.setdiff1d(ka, kb))), "only_merged": int(len(np.setdiff1d(kb, ka)))}
+                                           "same_multiset": bool(len(ka) == len(kb) and np.array_equal(ka, kb))}
             del allreads
-        flags["keep"] = False
 
     if rank == 0:
-        bases_per_step = float(world) * n * READ_LEN
+        bases_per_step = float(total_reads) * READ_LEN
         value = bases_per_step * args.steps / dt / 1e9
         # ---- roofline of the dominant kernel (mk_scan_kernel), per launch ----
         # algorithmic bytes (SURVEY.md 8d / DESIGN.md): 1 B per base scanned + 16 B per accepted k-mer occurrence
         # (slot read + slot write); the table clear/dump terms (16 S + 6 D) belong to the finish kernels.
-        kmers = n * (READ_LEN - 21)
-        accepted = kmers / 4096.0
-        scan_bytes = n * READ_LEN + 16.0 * accepted
-        scan_ms = prof["scan_ms"] / max(1, prof["scan_launches"])
+        launches = max(1, prof["scan_launches"])
+        reads_per_launch = prof["rows_scanned"] / launches
+        scan_bytes = reads_per_launch * READ_LEN + 16.0 * reads_per_launch * (READ_LEN - 21) / 4096.0
+        scan_ms = prof["scan_ms"] / launches
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("reads_per_launch") == n:
+                if tj.get("reads_per_launch") == int(reads_per_launch) and tj.get("kernel_source_id") == kernel_source_id():
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/scan_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel source " \
+                                     "in separate runs (tools/pmc_traffic.sh), not measured inside this run"
+                else:
+                    traffic_source = "none for this kernel source / launch size (profiles/scan_traffic.json is for another build)"
             except Exception:
                 traffic = None
         line = {
             "metric": "Gbases/s sketched (150 bp synthetic reads, L3K11 -A)",
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u64 k-mers over u8 bases (integer)", "data": "synthetic",
-            "config": {"workload": "%d synthetic 150 bp reads per GPU resident in HBM (160 B rows), L3K11 .shuf "
-                                   "{k=11,subk=6,drlevel=3}, -A counted sketch, begin+scan+finish per step" % n,
-                       "reads_per_gpu": n, "read_len": READ_LEN, "row_stride": STRIDE,
-                       "distinct_keys": result.get("distinct"), "parallelism": "reads sharded x%d, gather to rank 0" % world},
+            "config": {"workload": workload + ", resident in HBM (160 B rows), L3K11 .shuf {k=11,subk=6,drlevel=3}, -A counted "
+                                              "sketch, begin+scan+finish per step",
+                       "total_reads": total_reads, "reads_on_rank0": n, "read_len": READ_LEN, "row_stride": STRIDE,
+                       "distinct_keys": result.get("distinct"),
+                       "table_load": (result.get("distinct") or 0) / float(eng.params.hashsize),
+                       "parallelism": "reads sharded x%d, gather to rank 0" % world},
             "roofline": {"bound": "hbm", "kernel": "mk_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms,
-                         "launches": prof["scan_launches"]},
+                         "launches": prof["scan_launches"], "kernel_source_id": kernel_source_id()},
             "phases_ms_per_step": {"clear": prof["clear_ms"] / args.steps, "scan": prof["scan_ms"] / args.steps,
                                    "resolve": prof["resolve_ms"] / args.steps,
                                    "finish": prof["finish_ms"] / args.steps},
         }
+        if world > 1 and tail["steps"]:
+            line["rank0_tail_ms"] = tail["t"] / tail["steps"] * 1e3
+            line["rank0_tail_what"] = "gather of the other ranks' key lists + one import launch + finish on rank 0, " \
+                                      "from 3 separately fenced steps after the timed region"
         if verified is not None:
             line["merged_equals_single_engine"] = bool(verified)
             if "verify_detail" in result:
                 line["verify_detail"] = result["verify_detail"]
         if args.backend != "nccl":
             line["config"]["parallelism"] += " (debug transport: %s%s)" % (args.backend, ", same device" if args.same_device else "")
+        if world == 1 and not args.no_host_legs:
+            try:
+                line["t_stream"] = leg_stream(torch, capi, eng, reads, n)
+            except Exception as ex:
+                line["t_stream"] = {"gbases_s": None, "what": "failed: %s" % ex}
         if world == 1 and not args.no_cpu_baseline:
             m = min(args.cpu_sample_reads, n)
             eng.begin(capi.MK_MODE_KOC)
@@ -261,11 +408,44 @@ def main():
             except Exception as ex:  # a missing zcat etc. must not lose the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": os.cpu_count(), "kind": "reference",
                                         "sample": "failed: %s" % ex}
+        if world == 1 and not args.no_host_legs:
+            sketch = result["sketch"]
+            del reads
+            eng.close()  # the command line brings its own engine: give the memory back first
+            torch.cuda.empty_cache()
+            try:
+                line["t_e2e"] = leg_e2e(capi, shuf, n, sketch)
+            except Exception as ex:
+                line["t_e2e"] = {"gbases_s": None, "what": "failed: %s" % ex}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def sharded_sketch_one_gpu(torch, capi, eng, reads, n, shards, cap, dev):
+    """the N-GPU flow on one engine: every shard scanned on its own with global ordinals and exported, then all lists
+    imported into a fresh table with one launch and finished (what rank 0 does at N = shards)"""
+    from metakssd_amd.shard import shard_range
+    ks, cs, os_ = [], [], []
+    for s in range(shards):
+        lo, hi = shard_range(n, s, shards)
+        eng.begin(capi.MK_MODE_KOC)
+        eng.push_reads_device(reads.data_ptr() + lo * STRIDE, STRIDE, hi - lo, lo)
+        k = torch.empty(cap, dtype=torch.int64, device=dev)
+        c = torch.empty(cap, dtype=torch.int32, device=dev)
+        o = torch.empty(cap, dtype=torch.int64, device=dev)
+        m = eng.partial_export(k.data_ptr(), c.data_ptr(), o.data_ptr(), cap)
+        ks.append(k[:m].clone()); cs.append(c[:m].clone()); os_.append(o[:m].clone())
+        del k, c, o
+    K, Cc, O = torch.cat(ks), torch.cat(cs), torch.cat(os_)
+    torch.cuda.synchronize()
+    eng.begin(capi.MK_MODE_KOC)
+    eng.partial_import(K.data_ptr(), Cc.data_ptr(), O.data_ptr(), K.numel())
+    out = eng.finish()
+    torch.cuda.synchronize()
+    return out
 
 
 if __name__ == "__main__":

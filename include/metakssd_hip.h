@@ -132,6 +132,14 @@ int mk_engine_destroy(mk_engine *e);
 /* Run all engine work on a caller-owned hipStream_t (e.g. torch's current stream) so that it is ordered with the
  * caller's own work on that stream.  NULL selects HIP's default stream (that is what torch.cuda.current_stream()
  * normally is), NOT the engine's own stream: mk_engine_use_own_stream() goes back to that (the initial state). */
+/* Engine options, settable between sketches (not between begin and finish):
+ *   MK_OPT_SPARSE   -1 / 0 / 1: dirty-block bookkeeping of the table passes by table size (default: on from 2^26 slots) / off / on
+ *   MK_OPT_CAND_CAP records per scan wave in the candidate append buffers (default 8192; 0 = resolve every filter hit inline)
+ *   MK_OPT_RESULT_CAP entries the pinned result arrays hold now (default: 2 M at the first finish; a larger sketch grows them
+ *                   and writes its result a second time)
+ * Results are bit-identical for every setting; the tests run both. */
+enum { MK_OPT_SPARSE = 1, MK_OPT_CAND_CAP = 2, MK_OPT_RESULT_CAP = 3 };
+int mk_engine_set_option(mk_engine *e, int option, int64_t value);
 int mk_engine_set_stream(mk_engine *e, void *hip_stream);
 int mk_engine_use_own_stream(mk_engine *e);
 const char *mk_last_error(const mk_engine *e); /* e may be NULL: last error of a failed create */
@@ -150,6 +158,12 @@ int mk_sketch_begin_occ(mk_engine *e, int min_occurrence);
 int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t stride, uint64_t nreads, uint64_t first_read_ordinal);
 int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev, uint32_t stride, uint64_t nreads,
                                 uint64_t first_read_ordinal);
+/* Asynchronous host variant: returns once the copies are queued; `rows` must stay untouched until
+ * mk_sketch_push_wait(e, *ticket) has returned (mk_sketch_finish does not wait for tickets).  Up to 16 pushes may be in
+ * flight; the oldest is waited for inside the call beyond that.  mk_sketch_push_reads = async + wait. */
+int mk_sketch_push_reads_async(mk_engine *e, const uint8_t *rows, uint32_t stride, uint64_t nreads, uint64_t first_read_ordinal,
+                               uint64_t *ticket);
+int mk_sketch_push_wait(mk_engine *e, uint64_t ticket);
 int mk_sketch_finish(mk_engine *e, mk_result *out);
 int mk_result_release(mk_engine *e, mk_result *r);
 int mk_engine_sync(mk_engine *e);
@@ -181,6 +195,8 @@ int mk_synth_rows_device(int device, void *hip_stream, uint64_t seed, uint64_t f
                          uint32_t stride, uint8_t *rows_dev);
 /* FASTQ text of the same reads: "@r<i>\n<bases>\n+\n<'I'*len>\n" */
 int mk_synth_fastq_write(const char *path, uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len);
+/* the same file written by `nthreads` threads (record offsets are computable: pwrite into place) */
+int mk_synth_fastq_write_mt(const char *path, uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len, int nthreads);
 
 /* ---- host-side stage I helpers (run_stageI bookkeeping, command_dist.c:341-500) ----------------- */
 /* FASTQ framing of mt_shortreads2koc's reader (iseq2comem.c:672-673) over a memory buffer: copies
@@ -206,6 +222,36 @@ int mk_fastq_frame_q(const uint8_t *buf, size_t n, int final, int32_t qmin, int3
 int mk_fastq_frame_mt(const uint8_t *buf, size_t n, int final, int occ, int32_t qmin, int32_t TL, uint64_t records_before,
                       uint8_t *rows, uint32_t stride, uint64_t max_rows, int nthreads, uint64_t *nrows, uint64_t *nrecords,
                       size_t *consumed);
+/* ---- whole-file FASTQ stream (mk_fastq_stream.c): replaces the serial 4 x fgets reader between the parallel loops of
+ * mt_shortreads2koc() (iseq2comem.c:672-673) / fastq2co() (:343-363) for a file that is in memory (mmap).  `nthreads` host
+ * threads frame chunks of the text into row buffers, the calling thread hands the buffers to `sink` in file order with
+ * consecutive row ordinals.  Rows, their order and the error behaviour are those of mk_fastq_frame / mk_fastq_frame_q over
+ * the whole text with final != 0, whatever the file contains; row strides are chosen per buffer (multiples of 16). */
+typedef struct mk_fastq_opts {
+  int32_t occ;          /* 0: mt_shortreads2koc's reader; 1: fastq2co's (quality mask, its record rule, long-read windows) */
+  int32_t qmin, TL;     /* occ only: -Q, k-mer length in bases */
+  int32_t nthreads;     /* framer threads (1..256) */
+  int32_t inflight;     /* pushes kept in flight before the oldest is waited for (1..8); ignored without sink.wait */
+  uint64_t chunk_bytes; /* text bytes per framing job, 0 = 8 MiB */
+} mk_fastq_opts;
+typedef struct mk_fastq_stats {
+  uint64_t rows, records, chunks, chunks_discarded, serial_rows; /* discarded / serial: work redone on the calling thread */
+  uint32_t threads;
+  double t_setup_s, t_wait_frame_s, t_push_s, t_total_s; /* calling thread: buffer pool, waiting for framers, in push/wait */
+} mk_fastq_stats;
+typedef struct mk_rows_sink {
+  void *ctx;
+  int (*push)(void *ctx, const uint8_t *rows, uint32_t stride, uint64_t nrows, uint64_t first_row_ordinal, uint64_t *token);
+  int (*wait)(void *ctx, uint64_t token);       /* NULL: push is synchronous, the buffer is free when it returns */
+  uint8_t *(*alloc)(void *ctx, size_t bytes);   /* row buffers (pinned for an engine) */
+  void (*release)(void *ctx, uint8_t *p);
+} mk_rows_sink;
+int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const mk_rows_sink *sink, uint64_t first_ordinal,
+                    mk_fastq_stats *st);
+/* the stream bound to an engine: pinned row buffers, mk_sketch_push_reads_async / mk_sketch_push_wait */
+int mk_sketch_push_fastq(mk_engine *e, const uint8_t *text, size_t n, const mk_fastq_opts *o, uint64_t first_ordinal,
+                         mk_fastq_stats *st);
+
 /* FASTA front end of fasta2co (iseq2comem.c:240-279): strips line breaks, maps headers/invalid bytes to
  * window resets and cuts the base stream into rows of `stride` bytes overlapping by TL-1 bases so that
  * every k-mer lies in exactly one row.  Call mk_fasta_window_init once per file, then feed the file in

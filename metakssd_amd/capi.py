@@ -16,6 +16,7 @@ MK_OK = 0
 MK_ERR_ARG, MK_ERR_NO_DEVICE, MK_ERR_HIP, MK_ERR_CROWDED = -1, -2, -3, -4
 MK_ERR_STATE, MK_ERR_IO, MK_ERR_FORMAT, MK_ERR_NOMEM = -5, -6, -7, -8
 MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET, MK_MODE_OCC_SET = 0, 1, 2, 3
+MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP = 1, 2, 3
 
 
 class MkError(RuntimeError):
@@ -61,6 +62,27 @@ class FastaStateC(C.Structure):
                 ("pending", C.c_uint8 * 4096)]
 
 
+class FastqOptsC(C.Structure):
+    _fields_ = [("occ", C.c_int32), ("qmin", C.c_int32), ("TL", C.c_int32), ("nthreads", C.c_int32), ("inflight", C.c_int32),
+                ("chunk_bytes", C.c_uint64)]
+
+
+class FastqStatsC(C.Structure):
+    _fields_ = [("rows", C.c_uint64), ("records", C.c_uint64), ("chunks", C.c_uint64), ("chunks_discarded", C.c_uint64),
+                ("serial_rows", C.c_uint64), ("threads", C.c_uint32), ("t_setup_s", C.c_double), ("t_wait_frame_s", C.c_double),
+                ("t_push_s", C.c_double), ("t_total_s", C.c_double)]
+
+
+_PUSH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64))
+_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)
+_ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+_RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
+class RowsSinkC(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("push", _PUSH_FN), ("wait", _WAIT_FN), ("alloc", _ALLOC_FN), ("release", _RELEASE_FN)]
+
+
 class DistOptsC(C.Structure):
     _fields_ = [("metric", C.c_int32), ("outfields", C.c_int32), ("correction", C.c_int32), ("num_neigb", C.c_int32),
                 ("dthreshold", C.c_double)]
@@ -80,12 +102,15 @@ def _load():
         "mk_device_count": [C.POINTER(C.c_int)],
         "mk_engine_create": [C.POINTER(ParamsC), C.c_int, C.POINTER(vp)],
         "mk_engine_destroy": [vp],
+        "mk_engine_set_option": [vp, C.c_int, C.c_int64],
         "mk_engine_set_stream": [vp, vp],
         "mk_engine_use_own_stream": [vp],
         "mk_sketch_begin": [vp, C.c_int],
         "mk_sketch_begin_occ": [vp, C.c_int],
         "mk_sketch_push_reads": [vp, vp, u32, u64, u64],
         "mk_sketch_push_reads_device": [vp, vp, u32, u64, u64],
+        "mk_sketch_push_reads_async": [vp, vp, u32, u64, u64, C.POINTER(u64)],
+        "mk_sketch_push_wait": [vp, u64],
         "mk_sketch_finish": [vp, C.POINTER(ResultC)],
         "mk_result_release": [vp, C.POINTER(ResultC)],
         "mk_engine_sync": [vp],
@@ -100,6 +125,9 @@ def _load():
         "mk_synth_rows_host": [u64, u64, u64, u32, u32, vp],
         "mk_synth_rows_device": [C.c_int, vp, u64, u64, u64, u32, u32, vp],
         "mk_synth_fastq_write": [C.c_char_p, u64, u64, u64, u32],
+        "mk_synth_fastq_write_mt": [C.c_char_p, u64, u64, u64, u32, C.c_int],
+        "mk_fastq_stream": [vp, C.c_size_t, C.POINTER(FastqOptsC), C.POINTER(RowsSinkC), u64, C.POINTER(FastqStatsC)],
+        "mk_sketch_push_fastq": [vp, vp, C.c_size_t, C.POINTER(FastqOptsC), u64, C.POINTER(FastqStatsC)],
         "mk_fastq_frame": [vp, C.c_size_t, C.c_int, vp, u32, u64, C.POINTER(u64), C.POINTER(C.c_size_t)],
         "mk_fastq_frame_q": [vp, C.c_size_t, C.c_int, i32, i32, u64, vp, u32, u64, C.POINTER(u64), C.POINTER(u64),
                              C.POINTER(C.c_size_t)],
@@ -237,6 +265,34 @@ def fastq_frame_mt(buf, stride, nthreads, occ=False, TL=22, qmin=0, final=True, 
     return rows[: n.value * stride], n.value, nrec.value, used.value, rc
 
 
+def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2):
+    """the whole-file FASTQ stream (mk_fastq_stream) into host memory: returns (list of (rows u8 array, stride, nrows,
+    first ordinal) in push order, stats, rc).  Buffers come from malloc here; the engine-bound form is Engine.push_fastq."""
+    b = np.frombuffer(buf, dtype=np.uint8)
+    pushes, keep = [], {}
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+
+    def push(ctx, rows, stride, nrows, ord0, token):
+        a = np.ctypeslib.as_array(C.cast(rows, C.POINTER(C.c_uint8)), shape=(nrows * stride,)).copy()
+        pushes.append((a, stride, nrows, ord0))
+        token[0] = len(pushes)
+        return 0
+
+    def wait(ctx, token):
+        return 0
+
+    sink = RowsSinkC(None, _PUSH_FN(push), _WAIT_FN(wait), _ALLOC_FN(lambda ctx, n: libc.malloc(n)),
+                     _RELEASE_FN(lambda ctx, p: libc.free(p)))
+    keep["sink"] = sink
+    o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes)
+    st = FastqStatsC()
+    rc = lib.mk_fastq_stream(b.ctypes.data if len(b) else None, len(b), C.byref(o), C.byref(sink), first_ordinal, C.byref(st))
+    return pushes, st, rc
+
+
 def fasta_windows(buf, TL, stride, chunk=None):
     """FASTA bytes -> overlapped fixed-stride rows; `chunk` feeds the input in pieces of that many bytes"""
     b = np.frombuffer(buf, dtype=np.uint8)
@@ -269,7 +325,7 @@ def fasta_windows(buf, TL, stride, chunk=None):
 class Engine:
     """one GPU's sketch engine (mk_engine): begin -> push_reads* -> finish"""
 
-    def __init__(self, shuf, device=0):
+    def __init__(self, shuf, device=0, sparse=None, cand_cap=None):
         self.shuf = shuf  # keeps the host table alive
         self.params = shuf.params()
         self.h = C.c_void_p()
@@ -277,6 +333,14 @@ class Engine:
         if rc != MK_OK:
             raise MkError(rc, lib.mk_last_error(None).decode(errors="replace"))
         self.device = device
+        if sparse is not None:
+            self.set_option(MK_OPT_SPARSE, int(sparse))
+        if cand_cap is not None:
+            self.set_option(MK_OPT_CAND_CAP, int(cand_cap))
+
+    def set_option(self, option, value):
+        """mk_engine_set_option: MK_OPT_SPARSE (-1/0/1), MK_OPT_CAND_CAP (records per scan wave); between sketches only"""
+        _check(lib.mk_engine_set_option(self.h, option, value), self.h)
 
     def close(self):
         if self.h:
@@ -311,6 +375,24 @@ class Engine:
         if n:
             _check(lib.mk_sketch_push_reads(self.h, rows.ctypes.data, stride, n, first_read_ordinal), self.h)
         return n
+
+    def push_fastq(self, buf, nthreads=8, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2):
+        """whole FASTQ text (bytes / numpy u8 / mmap) -> framed by host threads and pushed (mk_sketch_push_fastq); returns stats"""
+        b = np.frombuffer(buf, dtype=np.uint8)
+        o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes)
+        st = FastqStatsC()
+        _check(lib.mk_sketch_push_fastq(self.h, b.ctypes.data if len(b) else None, len(b), C.byref(o), first_ordinal, C.byref(st)), self.h)
+        return st
+
+    def push_reads_async(self, rows, stride, first_read_ordinal=0):
+        """queue the copies and the scan; `rows` (host numpy u8) must stay untouched until push_wait(ticket)"""
+        assert rows.dtype == np.uint8 and rows.flags["C_CONTIGUOUS"] and rows.size % stride == 0
+        t = C.c_uint64(0)
+        _check(lib.mk_sketch_push_reads_async(self.h, rows.ctypes.data, stride, rows.size // stride, first_read_ordinal, C.byref(t)), self.h)
+        return t.value
+
+    def push_wait(self, ticket):
+        _check(lib.mk_sketch_push_wait(self.h, ticket), self.h)
 
     def push_reads_device(self, dev_ptr, stride, nreads, first_read_ordinal=0):
         _check(lib.mk_sketch_push_reads_device(self.h, C.c_void_p(dev_ptr), stride, nreads, first_read_ordinal), self.h)

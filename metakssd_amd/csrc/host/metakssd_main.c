@@ -22,6 +22,7 @@
 #include <dirent.h>
 #include <errno.h>
 #include <pthread.h>
+#include <signal.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,6 +30,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -111,8 +113,24 @@ static double now_s(void) {
 #define IOBUF ((size_t)64 << 20)
 #define ROWBUF ((size_t)64 << 20)
 
+/* The engine is created on a helper thread (HIP start-up, 2 GB of tables, the .shuf upload) while the main thread maps the
+ * input and starts framing; whoever needs the engine first waits for it here. */
 typedef struct {
+  pthread_t th;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  int done, rc, device;
+  const mk_params *P;
   mk_engine *eng;
+  char err[512];
+  double t_start, t_hip_ready, t_ready; /* seconds since process start */
+} engine_future;
+
+static double g_t0; /* process start (monotonic) */
+
+typedef struct {
+  engine_future *fut;
+  mk_engine *eng; /* NULL until engine_get() */
   uint8_t *io;   /* raw text */
   uint8_t *rows; /* pinned rows */
   uint64_t next_ordinal;
@@ -120,6 +138,11 @@ typedef struct {
   int occ;      /* FASTQ without -A: fastq2co()'s reader (quality mask, its record rule) */
   int qmin, TL; /* -Q, k-mer length */
   int nthreads; /* host threads for framing one big FASTQ (mk_fastq_frame_mt) */
+  /* the sketch the current file goes into: begun lazily, by whoever pushes first */
+  int begun, mode, min_occ;
+  uint64_t chunk_bytes;
+  mk_fastq_stats fq_stats;
+  double t_first_push, t_last_push;
 } ctx_t;
 
 #define CHECK(e, call)                                                  \
@@ -128,21 +151,118 @@ typedef struct {
     if (_rc != MK_OK) die("%s failed (%d): %s", #call, _rc, mk_last_error(e)); \
   } while (0)
 
-/* input opened like the reference does: through `zcat -fc` when compressed (iseq2comem.c:216,666-669),
- * directly otherwise (same bytes, no child process) */
-static FILE *open_input(const char *path, int *is_pipe) {
-  if (is_compressed(path)) {
-    char cmd[PATHLEN * 2 + 16];
-    snprintf(cmd, sizeof cmd, "zcat -fc '%s'", path);
-    *is_pipe = 1;
-    return popen(cmd, "r");
-  }
-  *is_pipe = 0;
-  return fopen(path, "rb");
+static void *engine_thread(void *arg) {
+  engine_future *f = arg;
+  int n = 0;
+  f->t_start = now_s() - g_t0;
+  int rc = mk_device_count(&n); /* first HIP call of the process: runtime start-up */
+  f->t_hip_ready = now_s() - g_t0;
+  if (rc == MK_OK) rc = mk_engine_create(f->P, f->device, &f->eng);
+  if (rc != MK_OK) snprintf(f->err, sizeof f->err, "%s", mk_last_error(NULL));
+  f->t_ready = now_s() - g_t0;
+  pthread_mutex_lock(&f->mu);
+  f->rc = rc;
+  f->done = 1;
+  pthread_cond_broadcast(&f->cv);
+  pthread_mutex_unlock(&f->mu);
+  return NULL;
 }
 
-/* an uncompressed regular file is framed straight out of its page-cache mapping: no copy into the I/O buffer (that copy,
- * not the framing, is what bounds a single-threaded read loop), the framing threads fault the pages in concurrently */
+static void engine_start(engine_future *f, const mk_params *P, int device) {
+  memset(f, 0, sizeof *f);
+  f->P = P; f->device = device;
+  pthread_mutex_init(&f->mu, NULL);
+  pthread_cond_init(&f->cv, NULL);
+  if (pthread_create(&f->th, NULL, engine_thread, f) != 0) { engine_thread(f); return; }
+}
+
+static mk_engine *engine_get(ctx_t *c) {
+  if (c->eng) return c->eng;
+  engine_future *f = c->fut;
+  pthread_mutex_lock(&f->mu);
+  while (!f->done) pthread_cond_wait(&f->cv, &f->mu);
+  pthread_mutex_unlock(&f->mu);
+  if (f->rc != MK_OK) die("mk_engine_create failed (%d): %s", f->rc, f->err);
+  c->eng = f->eng;
+  return c->eng;
+}
+
+/* mk_sketch_begin for the current file, once, at the first push (or at finish for an input without rows) */
+static mk_engine *sketch_engine(ctx_t *c) {
+  mk_engine *e = engine_get(c);
+  if (!c->begun) {
+    if (c->mode == MK_MODE_OCC_SET) CHECK(e, mk_sketch_begin_occ(e, c->min_occ)); /* command_dist.c:385-386 */
+    else CHECK(e, mk_sketch_begin(e, c->mode));
+    c->begun = 1;
+  }
+  return e;
+}
+
+/* input opened like the reference does: through `zcat -fc` when compressed (iseq2comem.c:216,666-669), directly otherwise
+ * (same bytes, no child process).  zcat is started with an argument vector, not through a shell: a file name is never
+ * interpreted; its exit status is checked when the input is closed (a corrupt .gz must not yield a silently short sketch). */
+typedef struct { FILE *f; pid_t pid; const char *path; } input_t;
+
+static int open_input(const char *path, input_t *in) {
+  in->pid = 0; in->path = path; in->f = NULL;
+  if (!is_compressed(path)) { in->f = fopen(path, "rb"); return in->f != NULL; }
+  int fd[2];
+  if (pipe(fd) != 0) return 0;
+  const pid_t pid = fork();
+  if (pid < 0) { close(fd[0]); close(fd[1]); return 0; }
+  if (pid == 0) {
+    dup2(fd[1], 1);
+    close(fd[0]); close(fd[1]);
+    execlp("zcat", "zcat", "-fc", "--", path, (char *)NULL);
+    _exit(127);
+  }
+  close(fd[1]);
+  in->pid = pid;
+  in->f = fdopen(fd[0], "rb");
+  return in->f != NULL;
+}
+
+static void close_input(input_t *in) {
+  if (in->f) fclose(in->f);
+  if (in->pid > 0) {
+    int st = 0;
+    if (waitpid(in->pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
+      die("%s: `zcat -fc` failed (status %d): the input was not read completely", in->path, WIFEXITED(st) ? WEXITSTATUS(st) : -1);
+  }
+}
+
+/* buffers of the windowed paths (pipes, FASTA); a mapped FASTQ file does not need them */
+static void ensure_buffers(ctx_t *c) {
+  if (c->io) return;
+  c->io = malloc(IOBUF);
+  if (!c->io || mk_host_alloc((void **)&c->rows, ROWBUF) != MK_OK) die("out of memory");
+}
+
+static void push_rows(ctx_t *c, const uint8_t *rows, uint32_t stride, uint64_t nrows) {
+  mk_engine *e = sketch_engine(c);
+  CHECK(e, mk_sketch_push_reads(e, rows, stride, nrows, c->next_ordinal));
+  c->next_ordinal += nrows;
+  c->nrows_total += nrows;
+}
+
+/* ---- sink of the whole-file FASTQ stream: pinned buffers, asynchronous pushes, the engine awaited at the first push ---- */
+static int cli_sink_push(void *ctx, const uint8_t *rows, uint32_t stride, uint64_t nrows, uint64_t ord, uint64_t *token) {
+  ctx_t *c = ctx;
+  mk_engine *e = sketch_engine(c);
+  if (c->t_first_push == 0) c->t_first_push = now_s() - g_t0;
+  return mk_sketch_push_reads_async(e, rows, stride, nrows, ord, token);
+}
+static int cli_sink_wait(void *ctx, uint64_t token) { return mk_sketch_push_wait(((ctx_t *)ctx)->eng, token); }
+static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) {
+  (void)ctx;
+  void *p = NULL;
+  return mk_host_alloc(&p, bytes) == MK_OK ? p : NULL;
+}
+static void cli_sink_release(void *ctx, uint8_t *p) { (void)ctx; mk_host_free(p); }
+
+/* an uncompressed regular file is framed straight out of its page-cache mapping by the whole-file stream
+ * (mk_fastq_stream.c): no copy into an I/O buffer, `-p` threads fault the pages in and frame concurrently, the buffers
+ * go to the engine in file order while later chunks are still being framed */
 static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   if (is_compressed(path)) return 0;
   int fd = open(path, O_RDONLY);
@@ -153,43 +273,34 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   const uint8_t *map = mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
   close(fd);
   if (map == MAP_FAILED) return 0;
-  madvise((void *)map, size, MADV_SEQUENTIAL);
-  uint32_t stride = 160;
-  uint64_t records = 0;
-  size_t off = 0;
-  while (off < size) {
-    const size_t win = size - off < IOBUF ? size - off : IOBUF;
-    const int final = off + win == size;
-    uint64_t nrows = 0, nrec = 0;
-    size_t used = 0;
-    int rc = mk_fastq_frame_mt(map + off, win, final, c->occ, c->qmin, c->TL, records, c->rows, stride, ROWBUF / stride, c->nthreads,
-                               &nrows, &nrec, &used);
-    records += nrec;
-    if (nrows) {
-      CHECK(c->eng, mk_sketch_push_reads(c->eng, c->rows, stride, nrows, c->next_ordinal));
-      c->next_ordinal += nrows;
-      c->nrows_total += nrows;
-    }
-    off += used;
-    if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : stride * 2; continue; }
-    if (rc == MK_ERR_ARG || rc == MK_ERR_FORMAT)
-      die("%s: FASTQ line longer than the reference's fgets() width (%s): outside the framing contract", path,
-          c->occ ? "19998 characters, iseq2comem.c:319,343" : "4094 characters, iseq2comem.c:656,673");
-    if (rc != MK_OK) die("mk_fastq_frame failed (%d)", rc);
-    if (used == 0) {
-      if (final) break; /* trailing partial record: dropped like the reference does */
-      if (win == IOBUF) die("%s: a single FASTQ record exceeds the %zu-byte window", path, IOBUF);
-    }
+  mk_fastq_opts o;
+  memset(&o, 0, sizeof o);
+  o.occ = c->occ; o.qmin = c->qmin; o.TL = c->TL;
+  o.nthreads = c->nthreads; o.inflight = 3; o.chunk_bytes = c->chunk_bytes;
+  mk_rows_sink sink = {c, cli_sink_push, cli_sink_wait, cli_sink_alloc, cli_sink_release};
+  mk_fastq_stats fs;
+  const int rc = mk_fastq_stream(map, size, &o, &sink, c->next_ordinal, &fs);
+  if (rc == MK_ERR_ARG || rc == MK_ERR_FORMAT)
+    die("%s: FASTQ line longer than the reference's fgets() width (%s): outside the framing contract", path,
+        c->occ ? "19998 characters, iseq2comem.c:319,343" : "4094 characters, iseq2comem.c:656,673");
+  if (rc != MK_OK) {
+    engine_get(c); /* no usable device: say that (pinned buffers cannot be had either), not "out of memory" */
+    die("mk_fastq_stream failed (%d): %s", rc, mk_last_error(c->eng));
   }
+  c->next_ordinal += fs.rows;
+  c->nrows_total += fs.rows;
+  c->fq_stats = fs;
+  c->t_last_push = now_s() - g_t0;
   munmap((void *)map, size);
   return 1;
 }
 
 static void sketch_fastq(ctx_t *c, const char *path) {
   if (sketch_fastq_mapped(c, path)) return;
-  int is_pipe;
-  FILE *f = open_input(path, &is_pipe);
-  if (!f) die("mtfastq2koc():%s: %s", path, strerror(errno));
+  ensure_buffers(c);
+  input_t in;
+  if (!open_input(path, &in)) die("mtfastq2koc():%s: %s", path, strerror(errno));
+  FILE *f = in.f;
   uint32_t stride = 160;
   size_t have = 0;
   int eof = 0;
@@ -210,11 +321,7 @@ static void sketch_fastq(ctx_t *c, const char *path) {
       int rc = mk_fastq_frame_mt(c->io + off, have - off, eof, c->occ, c->qmin, c->TL, records, c->rows, stride, ROWBUF / stride,
                                  c->nthreads, &nrows, &nrec, &used);
       records += nrec;
-      if (nrows) {
-        CHECK(c->eng, mk_sketch_push_reads(c->eng, c->rows, stride, nrows, c->next_ordinal));
-        c->next_ordinal += nrows;
-        c->nrows_total += nrows;
-      }
+      if (nrows) push_rows(c, c->rows, stride, nrows);
       off += used;
       if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : stride * 2; continue; } /* longer read: widen rows */
       if (rc == MK_ERR_ARG || rc == MK_ERR_FORMAT)
@@ -228,16 +335,17 @@ static void sketch_fastq(ctx_t *c, const char *path) {
     if (have == IOBUF) die("%s: a single FASTQ record exceeds the %zu-byte I/O buffer", path, IOBUF);
     if (eof && have && off == 0) break; /* trailing partial record: dropped like the reference does */
   }
-  if (is_pipe) pclose(f); else fclose(f);
+  close_input(&in);
 }
 
 static void sketch_fasta(ctx_t *c, const char *path, int TL) {
-  int is_pipe;
-  FILE *f = open_input(path, &is_pipe);
-  if (!f) die("fasta2co():%s: %s", path, strerror(errno));
+  ensure_buffers(c);
+  input_t in;
+  if (!open_input(path, &in)) die("fasta2co():%s: %s", path, strerror(errno));
+  FILE *f = in.f;
   const uint32_t stride = 512;
   mk_fasta_state st;
-  CHECK(c->eng, mk_fasta_window_init(&st, TL));
+  if (mk_fasta_window_init(&st, TL) != MK_OK) die("mk_fasta_window_init failed");
   int eof = 0, any = 0;
   while (!eof) {
     size_t have = fread(c->io, 1, IOBUF, f);
@@ -249,16 +357,12 @@ static void sketch_fasta(ctx_t *c, const char *path, int TL) {
       const int wrc = mk_fasta_window(&st, c->io + off, have - off, eof, c->rows, stride, ROWBUF / stride, &nrows, &used);
       if (wrc == MK_ERR_FORMAT) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", path); /* iseq2comem.c:269 */
       if (wrc != MK_OK) die("mk_fasta_window failed (%d)", wrc);
-      if (nrows) {
-        CHECK(c->eng, mk_sketch_push_reads(c->eng, c->rows, stride, nrows, c->next_ordinal));
-        c->next_ordinal += nrows;
-        c->nrows_total += nrows;
-      }
+      if (nrows) push_rows(c, c->rows, stride, nrows);
       off += used;
     } while (off < have);
   }
   if (!any) die("fastco():eof or fread error file=%s", path); /* iseq2comem.c:235 */
-  if (is_pipe) pclose(f); else fclose(f);
+  close_input(&in);
 }
 
 /* ---- parallel front end for many small inputs (genome directories, many small FASTQ files) ---------------
@@ -276,7 +380,8 @@ typedef struct {
 typedef struct {
   strlist *files;
   int TL;
-  int occ, qmin; /* FASTQ without -A */
+  int qmin;      /* -Q (FASTQ without -A) */
+  int koc_until; /* FASTQ files with an index below this are read the -A way (mt_shortreads2koc's reader), the others fastq2co's */
   int nbufs;
   uint8_t *bufs[PF_MAX_BUFS];
   int free_bufs[PF_MAX_BUFS], nfree;
@@ -287,22 +392,28 @@ typedef struct {
 } pf_t;
 
 static uint8_t *slurp(const char *path, size_t *n_out, size_t limit, int *too_big) {
-  int is_pipe;
-  FILE *f = open_input(path, &is_pipe);
-  if (!f) return NULL;
+  input_t in;
+  if (!open_input(path, &in)) return NULL;
   size_t cap = (size_t)8 << 20, n = 0;
   uint8_t *b = malloc(cap);
+  if (!b) die("out of memory");
   for (;;) {
     if (n == cap) {
       if (cap >= limit) { *too_big = 1; break; }
       cap *= 2;
-      b = realloc(b, cap);
+      uint8_t *nb = realloc(b, cap);
+      if (!nb) die("out of memory");
+      b = nb;
     }
-    size_t r = fread(b + n, 1, cap - n, f);
+    size_t r = fread(b + n, 1, cap - n, in.f);
     if (r == 0) break;
     n += r;
   }
-  if (is_pipe) pclose(f); else fclose(f);
+  if (*too_big && in.pid > 0) { /* the rest is read again by the streaming path: do not wait for zcat to push it all out */
+    fclose(in.f); in.f = NULL;
+    kill(in.pid, SIGTERM);
+    waitpid(in.pid, NULL, 0);
+  } else close_input(&in);
   *n_out = n;
   return b;
 }
@@ -331,8 +442,8 @@ static void *pf_worker(void *arg) {
         uint64_t nrows = 0;
         size_t used = 0;
         uint64_t nrec = 0;
-        int rc = pf->occ ? mk_fastq_frame_q(text, n, 1, pf->qmin, pf->TL, 0, pf->bufs[b], stride, ROWBUF / stride, &nrows, &nrec, &used)
-                         : mk_fastq_frame(text, n, 1, pf->bufs[b], stride, ROWBUF / stride, &nrows, &used);
+        int rc = i >= pf->koc_until ? mk_fastq_frame_q(text, n, 1, pf->qmin, pf->TL, 0, pf->bufs[b], stride, ROWBUF / stride, &nrows, &nrec, &used)
+                                    : mk_fastq_frame(text, n, 1, pf->bufs[b], stride, ROWBUF / stride, &nrows, &used);
         if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : stride * 2; continue; }
         if (rc != MK_OK) s.err = rc;
         else if (used < n) s.too_big = 1; /* more rows than one buffer holds */
@@ -1192,6 +1303,7 @@ static int run_search(const char *refdir, const char *qrydir, const char *outdir
 }
 
 int main(int argc, char **argv) {
+  g_t0 = now_s();
   setvbuf(stdout, NULL, _IOLBF, 0);
   if (argc < 2) usage();
   if (!strcmp(argv[1], "shuffle")) return cmd_shuffle(argc - 2, argv + 2);
@@ -1200,7 +1312,12 @@ int main(int argc, char **argv) {
   if (strcmp(argv[1], "dist") != 0) die("only the `dist` sketching path, `set`, `composite -q` and `shuffle` are part of this build (got `%s`)", argv[1]);
 
   const char *shuf_path = NULL, *outdir = ".";
-  int abundance = 0, uniq = 0, device = 0, quiet = 0, nthreads = 8;
+  int abundance = 0, uniq = 0, device = 0, quiet = 0, timing = 0;
+  /* -p: host threads of the front end (reference default: every processor, command_dist_wrapper.c:284-293) */
+  int nthreads = (int)sysconf(_SC_NPROCESSORS_ONLN);
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 64) nthreads = 64;
+  uint64_t chunk_bytes = 0;
   int kmerocrs = 1, kmerqlty = 0; /* command_dist_wrapper.c:79-80 */
   const char *refpath = NULL, *skf = NULL;
   mk_dist_opts dopt = {0, 2, 0, 0, 1.0}; /* command_dist_wrapper.c:83-87 */
@@ -1221,6 +1338,8 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "-Q") && i + 1 < argc) kmerqlty = atoi(argv[++i]); /* :182-185 */
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--quiet")) quiet = 1;
+    else if (!strcmp(argv[i], "--timing")) timing = 1;
+    else if (!strcmp(argv[i], "--chunk-mib") && i + 1 < argc) chunk_bytes = (uint64_t)atoi(argv[++i]) << 20;
     else if (!strcmp(argv[i], "-r") && i + 1 < argc) refpath = argv[++i];
     else if (!strcmp(argv[i], "-M") && i + 1 < argc) dopt.metric = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-O") && i + 1 < argc) dopt.outfields = atoi(argv[++i]);
@@ -1262,8 +1381,7 @@ int main(int argc, char **argv) {
   discover(&files, args.n, args.v);
   if (files.n == 0) die("not valid raw seq format");
 
-  double t0 = now_s();
-  const int dbg = getenv("MK_DEBUG") != NULL;
+  const double t0 = g_t0;
   mk_shuf sh;
   int rc = mk_shuf_read(shuf_path, &sh);
   if (rc != MK_OK) die("read_dim_shuffle_file(): cannot read %s (%d)", shuf_path, rc);
@@ -1271,24 +1389,26 @@ int main(int argc, char **argv) {
   rc = mk_params_init(&sh, &P);
   if (rc != MK_OK) die("get_hashsz(): primer_ind out of range(0 ~ 24) for k=%d drlevel=%d (command_dist.c:291-303)", sh.k, sh.drlevel);
   if (!quiet) printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%u\thashlimit=%u\n", P.shuf_id, P.k, P.hashsize, P.hashlimit);
+  const double t_shuf = now_s() - t0;
 
-  if (dbg) fprintf(stderr, "[t] shuf read + params: %.3f s\n", now_s() - t0);
-  ctx_t c = {0};
-  rc = mk_engine_create(&P, device, &c.eng);
-  if (rc != MK_OK) die("mk_engine_create failed (%d): %s", rc, mk_last_error(NULL));
-  if (dbg) fprintf(stderr, "[t] + engine create: %.3f s\n", now_s() - t0);
-  c.io = malloc(IOBUF);
-  if (!c.io || mk_host_alloc((void **)&c.rows, ROWBUF) != MK_OK) die("out of memory");
-  if (dbg) fprintf(stderr, "[t] + host buffers: %.3f s\n", now_s() - t0);
+  /* HIP start-up and the engine's tables on a helper thread; the main thread goes on to map and frame the input */
+  engine_future fut;
+  engine_start(&fut, &P, device);
+  ctx_t c;
+  memset(&c, 0, sizeof c);
+  c.fut = &fut;
+  c.chunk_bytes = chunk_bytes;
 
-  /* -A is switched off for good by the first non-FASTQ input (command_dist.c:389-392) */
-  for (int i = 0; i < files.n; i++)
-    if (!is_fastq(files.v[i]) && abundance) {
-      abundance = 0;
-      printf("Warning: close abundance mode (-A) since non-fastq file input.\n");
-    }
+  /* -A stays on only if every input is FASTQ: the reference switches it off when its file loop reaches the first
+   * non-FASTQ input (command_dist.c:389-392) and then writes no combco.N.a at all (:427-431).  FASTQ files in front of
+   * that point have by then been sketched by mt_shortreads2koc() + write_fqkoc2files() (every key, -n / -Q ignored), the
+   * ones behind it go through fastq2co(): the same here, in our file order. */
+  int first_nonfq = files.n;
+  for (int i = files.n - 1; i >= 0; i--)
+    if (!is_fastq(files.v[i])) first_nonfq = i;
+  const int koc_dir = abundance && first_nonfq == files.n;
   mk_sketchdir *sd;
-  rc = mk_sketchdir_open(outdir, &P, abundance, files.n, &sd);
+  rc = mk_sketchdir_open(outdir, &P, koc_dir, files.n, &sd);
   if (rc != MK_OK) die("cannot create sketch directory %s (%d)", outdir, rc);
 
   /* worker threads prepare files ahead when there are several inputs */
@@ -1298,7 +1418,8 @@ int main(int argc, char **argv) {
   int nworkers = 0;
   if (files.n > 1 && nthreads > 1) {
     pf.files = &files; pf.TL = P.TL;
-    pf.occ = !abundance; pf.qmin = kmerqlty;
+    pf.qmin = kmerqlty;
+    pf.koc_until = abundance ? first_nonfq : 0; /* files in front of this index are read the mt_shortreads2koc way */
     pf.nbufs = nthreads < PF_MAX_BUFS ? nthreads : PF_MAX_BUFS;
     if (pf.nbufs > files.n) pf.nbufs = files.n;
     pf.slots = calloc(files.n, sizeof(pf_slot));
@@ -1314,13 +1435,19 @@ int main(int argc, char **argv) {
     if (nworkers == 0) { free(pf.slots); pf.slots = NULL; }
   }
 
+  double t_finish = 0;
   for (int i = 0; i < files.n; i++) {
     const char *path = files.v[i];
     c.next_ordinal = 0;
     const int fq = is_fastq(path);
+    if (!fq && abundance) {
+      abundance = 0;
+      printf("Warning: close abundance mode (-A) since non-fastq file input.\n");
+    }
     if (fq && abundance && !quiet) printf("running mt_shortreads2koc()\n");
-    if (fq && !abundance) CHECK(c.eng, mk_sketch_begin_occ(c.eng, kmerocrs)); /* command_dist.c:385-386 */
-    else CHECK(c.eng, mk_sketch_begin(c.eng, fq ? MK_MODE_KOC : (uniq ? MK_MODE_UNIQ_SET : MK_MODE_SET)));
+    c.begun = 0;
+    c.mode = fq ? (abundance ? MK_MODE_KOC : MK_MODE_OCC_SET) : (uniq ? MK_MODE_UNIQ_SET : MK_MODE_SET);
+    c.min_occ = kmerocrs;
     c.occ = fq && !abundance; c.qmin = kmerqlty; c.TL = P.TL; c.nthreads = nthreads;
     int handled = 0;
     if (nworkers) {
@@ -1333,8 +1460,7 @@ int main(int argc, char **argv) {
       if (sl.err == MK_ERR_FORMAT && !fq) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", path);
       if (sl.err) die("%s: sequence or header line of 4095+ characters: outside the FASTQ framing contract (iseq2comem.c:656,673)", path);
       if (!sl.too_big) {
-        if (sl.nrows) CHECK(c.eng, mk_sketch_push_reads(c.eng, pf.bufs[sl.buf], sl.stride, sl.nrows, 0));
-        c.nrows_total += sl.nrows;
+        if (sl.nrows) push_rows(&c, pf.bufs[sl.buf], sl.stride, sl.nrows);
         pthread_mutex_lock(&pf.mu); /* push returned: the buffer has been copied to the device */
         pf.free_bufs[pf.nfree++] = sl.buf;
         pthread_cond_broadcast(&pf.cv_buf);
@@ -1346,26 +1472,41 @@ int main(int argc, char **argv) {
       if (fq) sketch_fastq(&c, path);
       else sketch_fasta(&c, path, P.TL);
     }
-    if (dbg) fprintf(stderr, "[t] + framing/push of %s: %.3f s\n", path, now_s() - t0);
+    mk_engine *eng = sketch_engine(&c); /* an input without a single row still gives an (empty) sketch */
     mk_result res;
-    rc = mk_sketch_finish(c.eng, &res);
+    const double tf = now_s();
+    rc = mk_sketch_finish(eng, &res);
+    t_finish += now_s() - tf;
     if (rc == MK_ERR_CROWDED) die("the context space is too crowd, try rerun the program using -k%d", P.k + 1);
-    if (rc != MK_OK) die("mk_sketch_finish failed (%d): %s", rc, mk_last_error(c.eng));
+    if (rc != MK_OK) die("mk_sketch_finish failed (%d): %s", rc, mk_last_error(eng));
     rc = mk_sketchdir_add(sd, path, &res);
     if (rc != MK_OK) die("writing sketch for %s failed (%d)", path, rc);
-    mk_result_release(c.eng, &res);
+    mk_result_release(eng, &res);
     if (!quiet) printf("%d/%d decomposing %s\r", i + 1, files.n, path);
   }
   if (!quiet) printf("\n");
-  if (dbg) fprintf(stderr, "[t] + finish/write: %.3f s\n", now_s() - t0);
   rc = mk_sketchdir_close(sd);
   if (rc != MK_OK) die("closing sketch directory failed (%d)", rc);
-  if (!quiet) printf("sketched %llu rows from %d file(s) in %.3f s\n", (unsigned long long)c.nrows_total, files.n, now_s() - t0);
-  mk_host_free(c.rows);
-  free(c.io);
-  mk_engine_destroy(c.eng);
-  if (dbg) fprintf(stderr, "[t] + teardown: %.3f s\n", now_s() - t0);
-  mk_shuf_free(&sh);
-  if (stage2_after) return run_stage2(outdir, outdir, device, quiet);
-  return 0;
+  const double t_written = now_s() - t0;
+  if (!quiet) printf("sketched %llu rows from %d file(s) in %.3f s\n", (unsigned long long)c.nrows_total, files.n, t_written);
+  if (timing) /* one JSON line for bench.py / tools: seconds since process start unless named *_s */
+    printf("{\"timing\": {\"shuf_read\": %.4f, \"hip_ready\": %.4f, \"engine_ready\": %.4f, \"first_push\": %.4f, \"last_push\": %.4f, "
+           "\"written\": %.4f, \"finish_s\": %.4f, \"rows\": %llu, \"threads\": %u, \"chunks\": %llu, \"chunks_discarded\": %llu, "
+           "\"serial_rows\": %llu, \"stream_setup_s\": %.4f, \"stream_wait_frame_s\": %.4f, \"stream_push_s\": %.4f, \"stream_total_s\": %.4f}}\n",
+           t_shuf, fut.t_hip_ready, fut.t_ready, c.t_first_push, c.t_last_push, t_written, t_finish, (unsigned long long)c.nrows_total,
+           c.fq_stats.threads, (unsigned long long)c.fq_stats.chunks, (unsigned long long)c.fq_stats.chunks_discarded,
+           (unsigned long long)c.fq_stats.serial_rows, c.fq_stats.t_setup_s, c.fq_stats.t_wait_frame_s, c.fq_stats.t_push_s,
+           c.fq_stats.t_total_s);
+  if (stage2_after) {
+    if (c.rows) mk_host_free(c.rows);
+    free(c.io);
+    mk_engine_destroy(engine_get(&c));
+    mk_shuf_free(&sh);
+    return run_stage2(outdir, outdir, device, quiet);
+  }
+  /* everything is on disk: leave without tearing down 2 GB of device tables and the pinned pools page by page */
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);
 }
+

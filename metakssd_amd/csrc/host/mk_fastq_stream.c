@@ -1,0 +1,335 @@
+/*
+ * mk_fastq_stream.c -- whole-file FASTQ front end: a pool of host threads frames a memory-mapped FASTQ file into
+ * fixed-stride row buffers while the calling thread hands the finished buffers to the engine in file order (host C).
+ *
+ * Replaces the serial reader of mt_shortreads2koc() (iseq2comem.c:657-673: 65536 x {fgets header; fgets sequence into
+ * fq_buff[l]; fgets '+'; fgets quality} between the parallel loops -- the reference's Amdahl ceiling)
+ * and of fastq2co() (iseq2comem.c:343-363).  Same record rule as there: records are groups of four lines counted from
+ * the start of the file, whatever the lines contain.
+ *
+ * How the threads find record boundaries without a counting pass: the file is cut into chunks of `chunk_bytes`; the
+ * framer of chunk c GUESSES the first record start at or behind the chunk's first byte (a line that starts with '@' whose
+ * second successor starts with '+': in well-formed FASTQ only a header line qualifies, because the line two behind a
+ * quality line is a sequence line) and frames every record that starts in front of the next chunk.  The caller's
+ * thread walks the chunks in order and accepts a chunk only if its guessed start is exactly where the previous accepted
+ * chunk ended -- by induction from offset 0 that is the position the serial reader would be at.  Anything else (a guess
+ * fooled by a malformed file, a chunk that ran out of row space, a chunk without a record start) is framed serially from
+ * the true position, so the rows and their order are those of the serial framer on every input; only the speed depends
+ * on the guesses.  Row ordinals are assigned when a buffer is pushed, so framing needs no global row index.
+ */
+#include "metakssd_hip.h"
+#include "mk_host_internal.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define FS_NONE ((size_t)-1)
+
+typedef struct {
+  int ready;
+  int buf; /* index into bufs[], -1 = returned already */
+  size_t start, end;
+  uint64_t nrows, nrec;
+  uint32_t stride;
+  int rc;
+} fs_slot;
+
+typedef struct {
+  const uint8_t *text;
+  size_t n, chunk;
+  uint64_t nchunks;
+  int occ, qmin, TL;
+  size_t buf_bytes;
+  int nbufs;
+  uint8_t **bufs;
+  int *freelist, nfree;
+  fs_slot *slots;
+  uint64_t next;
+  int stop;
+  pthread_mutex_t mu;
+  pthread_cond_t cv_buf, cv_ready;
+} fs_t;
+
+static double fs_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static uint32_t fs_round_stride(size_t need) { /* need = bytes of the longest row including its '\n' */
+  size_t s = (need + 15u) & ~(size_t)15u;
+  if (s < 32) s = 32;
+  if (s > 4096) s = 4096;
+  return (uint32_t)s;
+}
+
+/* first line start at or behind `from` */
+static size_t fs_line_start(const uint8_t *t, size_t n, size_t from) {
+  if (from == 0 || from >= n || t[from - 1] == '\n') return from < n ? from : FS_NONE;
+  const uint8_t *nl = memchr(t + from, '\n', n - from);
+  if (!nl || (size_t)(nl - t) + 1 >= n) return FS_NONE;
+  return (size_t)(nl - t) + 1;
+}
+
+/* guessed record start in [lo, hi): a line starting with '@' whose second successor starts with '+' */
+static size_t fs_guess_start(const uint8_t *t, size_t n, size_t lo, size_t hi) {
+  size_t p = fs_line_start(t, n, lo);
+  while (p != FS_NONE && p < hi) {
+    const uint8_t *nl1 = memchr(t + p, '\n', n - p);
+    if (!nl1) return FS_NONE;
+    const size_t l2 = (size_t)(nl1 - t) + 1;
+    if (l2 >= n) return FS_NONE;
+    if (t[p] == '@') {
+      const uint8_t *nl2 = memchr(t + l2, '\n', n - l2);
+      if (!nl2) return FS_NONE;
+      const size_t l3 = (size_t)(nl2 - t) + 1;
+      if (l3 < n && t[l3] == '+') return p;
+    }
+    p = l2;
+  }
+  return FS_NONE;
+}
+
+/* longest sequence line (with its '\n') among the first records from `start`: the chunk's first row stride */
+static uint32_t fs_sample_stride(const uint8_t *t, size_t n, size_t start, int occ) {
+  size_t p = start, longest = 0;
+  for (int rec = 0; rec < 16 && p < n; rec++) {
+    for (int line = 0; line < 4 && p < n; line++) {
+      const uint8_t *nl = memchr(t + p, '\n', n - p);
+      const size_t len = nl ? (size_t)(nl - t) + 1 - p : n - p;
+      if (line == 1 && len > longest) longest = len;
+      p += len;
+    }
+  }
+  (void)occ;
+  return fs_round_stride(longest ? longest : 32);
+}
+
+/* frames the records starting in [start, stop) into `buf`; grows the stride and starts over when a read does not fit */
+static void fs_frame_range(const fs_t *f, size_t start, size_t stop, int first_of_file, uint8_t *buf, fs_slot *s) {
+  uint32_t stride = fs_sample_stride(f->text, f->n, start, f->occ);
+  if (f->occ && stride < 2u * (uint32_t)f->TL + 4u) stride = fs_round_stride(2u * (size_t)f->TL + 4u);
+  for (;;) {
+    uint64_t nrows = 0, nrec = 0;
+    size_t used = 0;
+    uint32_t need = 0;
+    int rc;
+    if (f->occ)
+      rc = mk_fastq_frame_q_range(f->text + start, f->n - start, stop - start, 1, f->qmin, f->TL, first_of_file ? 0 : 1, buf, stride,
+                                  f->buf_bytes / stride, &nrows, &nrec, &used, &need);
+    else {
+      rc = mk_fastq_frame_range(f->text + start, f->n - start, stop - start, 1, buf, stride, f->buf_bytes / stride, &nrows, &used, &need);
+      nrec = nrows;
+    }
+    if (rc == MK_ERR_ARG && need > stride && stride < 4096) { /* a longer read than sampled: wider rows, frame the range again */
+      stride = fs_round_stride((size_t)need + need / 8u);
+      continue;
+    }
+    s->start = start; s->end = start + used; s->nrows = nrows; s->nrec = nrec; s->stride = stride; s->rc = rc;
+    return;
+  }
+}
+
+static void *fs_worker(void *arg) {
+  fs_t *f = arg;
+  for (;;) {
+    pthread_mutex_lock(&f->mu);
+    while (!f->stop && f->next < f->nchunks && f->nfree == 0) pthread_cond_wait(&f->cv_buf, &f->mu);
+    if (f->stop || f->next >= f->nchunks) { pthread_mutex_unlock(&f->mu); return NULL; }
+    const uint64_t c = f->next++;
+    const int b = f->freelist[--f->nfree]; /* taken together with the chunk number: the lowest open chunk always has a buffer */
+    pthread_mutex_unlock(&f->mu);
+
+    fs_slot s;
+    memset(&s, 0, sizeof s);
+    s.buf = b;
+    const size_t lo = (size_t)c * f->chunk, hi = lo + f->chunk < f->n ? lo + f->chunk : f->n;
+    const size_t start = c == 0 ? 0 : fs_guess_start(f->text, f->n, lo, hi);
+    if (start == FS_NONE) { s.start = s.end = FS_NONE; }
+    else fs_frame_range(f, start, hi, c == 0, f->bufs[b], &s);
+
+    pthread_mutex_lock(&f->mu);
+    if (s.nrows == 0) { f->freelist[f->nfree++] = b; s.buf = -1; pthread_cond_broadcast(&f->cv_buf); }
+    s.ready = 1;
+    f->slots[c] = s;
+    pthread_cond_broadcast(&f->cv_ready);
+    pthread_mutex_unlock(&f->mu);
+  }
+}
+
+static void fs_release(fs_t *f, int b) {
+  if (b < 0) return;
+  pthread_mutex_lock(&f->mu);
+  f->freelist[f->nfree++] = b;
+  pthread_cond_broadcast(&f->cv_buf);
+  pthread_mutex_unlock(&f->mu);
+}
+
+typedef struct { uint64_t token; int buf; } fs_inflight;
+
+int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const mk_rows_sink *sink, uint64_t first_ordinal,
+                    mk_fastq_stats *st) {
+  if ((!text && n) || !o || !sink || !sink->push || !sink->alloc || !sink->release) return MK_ERR_ARG;
+  if (o->occ && (o->TL < 2 || o->TL > 32)) return MK_ERR_ARG;
+  mk_fastq_stats stats;
+  memset(&stats, 0, sizeof stats);
+  const double t0 = fs_now();
+  fs_t f;
+  memset(&f, 0, sizeof f);
+  f.text = text; f.n = n;
+  f.occ = o->occ != 0; f.qmin = o->qmin; f.TL = o->TL;
+  f.chunk = o->chunk_bytes ? (size_t)o->chunk_bytes : (size_t)8 << 20;
+  if (f.chunk < 4096) f.chunk = 4096;
+  f.nchunks = n ? (n + f.chunk - 1) / f.chunk : 0;
+  int T = o->nthreads < 1 ? 1 : o->nthreads > 256 ? 256 : o->nthreads;
+  if ((uint64_t)T > f.nchunks) T = (int)(f.nchunks ? f.nchunks : 1);
+  const int depth = o->inflight < 1 ? 1 : o->inflight > 8 ? 8 : o->inflight;
+  /* rows of a chunk take at most about as many bytes as its text (a record is two lines of the read's length plus a
+   * header; the row is one); a chunk that needs more ends early and the pusher frames the rest serially */
+  f.buf_bytes = f.chunk + f.chunk / 8 + 8192;
+  f.nbufs = T + depth + 1;
+  int rc = MK_OK;
+  uint8_t *serial_buf = NULL;
+  pthread_t *th = NULL;
+  int nth = 0;
+  fs_inflight fifo[8];
+  int nfifo = 0;
+  f.bufs = calloc((size_t)f.nbufs, sizeof *f.bufs);
+  f.freelist = calloc((size_t)f.nbufs, sizeof *f.freelist);
+  f.slots = calloc((size_t)(f.nchunks ? f.nchunks : 1), sizeof *f.slots);
+  th = calloc((size_t)T, sizeof *th);
+  if (!f.bufs || !f.freelist || !f.slots || !th) { rc = MK_ERR_NOMEM; goto out_nothreads; }
+  pthread_mutex_init(&f.mu, NULL);
+  pthread_cond_init(&f.cv_buf, NULL);
+  pthread_cond_init(&f.cv_ready, NULL);
+  for (int t = 0; t < T && f.nchunks; t++)
+    if (pthread_create(&th[nth], NULL, fs_worker, &f) == 0) nth++;
+  if (f.nchunks && nth == 0) { rc = MK_ERR_NOMEM; goto out; }
+  /* the framers start on the first buffer while the rest of the pool is still being allocated (pinning pages takes time) */
+  for (int b = 0; b < f.nbufs; b++) {
+    uint8_t *p = sink->alloc(sink->ctx, f.buf_bytes);
+    if (!p) { pthread_mutex_lock(&f.mu); f.nbufs = b; pthread_mutex_unlock(&f.mu); break; }
+    pthread_mutex_lock(&f.mu);
+    f.bufs[b] = p;
+    f.freelist[f.nfree++] = b;
+    pthread_cond_signal(&f.cv_buf);
+    pthread_mutex_unlock(&f.mu);
+  }
+  if (f.nbufs < 2) { rc = MK_ERR_NOMEM; goto out; }
+  stats.t_setup_s = fs_now() - t0;
+
+  {
+    size_t pos = 0;
+    uint64_t ord = first_ordinal;
+    /* rows of [from, to) framed on this thread and pushed synchronously: the fallback for everything the guesses miss */
+#define FS_SERIAL(from_, to_)                                                                                      \
+    do {                                                                                                           \
+      size_t sp_ = (from_);                                                                                        \
+      const size_t sto_ = (to_);                                                                                   \
+      if (!serial_buf && !(serial_buf = sink->alloc(sink->ctx, f.buf_bytes))) { rc = MK_ERR_NOMEM; break; }        \
+      while (rc == MK_OK && sp_ < sto_) {                                                                          \
+        fs_slot ss_;                                                                                               \
+        memset(&ss_, 0, sizeof ss_);                                                                               \
+        fs_frame_range(&f, sp_, sto_, sp_ == 0, serial_buf, &ss_);                                                 \
+        if (ss_.nrows) {                                                                                           \
+          uint64_t tok_ = 0;                                                                                       \
+          rc = sink->push(sink->ctx, serial_buf, ss_.stride, ss_.nrows, ord, &tok_);                               \
+          if (rc == MK_OK && sink->wait) rc = sink->wait(sink->ctx, tok_);                                         \
+          ord += ss_.nrows; stats.rows += ss_.nrows; stats.records += ss_.nrec; stats.serial_rows += ss_.nrows;    \
+        }                                                                                                          \
+        if (rc == MK_OK && ss_.rc != MK_OK) rc = ss_.rc;                                                           \
+        if (ss_.end == sp_) break; /* nothing consumed: only possible at the end of the file */                    \
+        sp_ = ss_.end;                                                                                             \
+      }                                                                                                            \
+      pos = sp_;                                                                                                   \
+    } while (0)
+
+    for (uint64_t c = 0; c < f.nchunks && rc == MK_OK; c++) {
+      const double tw = fs_now();
+      pthread_mutex_lock(&f.mu);
+      while (!f.slots[c].ready) pthread_cond_wait(&f.cv_ready, &f.mu);
+      const fs_slot s = f.slots[c];
+      pthread_mutex_unlock(&f.mu);
+      stats.t_wait_frame_s += fs_now() - tw;
+      stats.chunks++;
+      if (s.start == FS_NONE) continue; /* no record starts in this chunk as far as the guess can tell */
+      if (s.start > pos) { /* the previous accepted chunk ended early, or the chunks in between had no usable guess */
+        FS_SERIAL(pos, s.start);
+        if (rc != MK_OK) { fs_release(&f, s.buf); break; }
+      }
+      if (s.start != pos) { /* the guess was not a record boundary of the serial reader: drop the chunk's rows */
+        stats.chunks_discarded++;
+        fs_release(&f, s.buf);
+        continue;
+      }
+      if (s.nrows) {
+        uint64_t tok = 0;
+        const double tp = fs_now();
+        rc = sink->push(sink->ctx, f.bufs[s.buf], s.stride, s.nrows, ord, &tok);
+        if (rc != MK_OK) { fs_release(&f, s.buf); break; }
+        ord += s.nrows; stats.rows += s.nrows; stats.records += s.nrec;
+        if (!sink->wait) fs_release(&f, s.buf);
+        else {
+          if (nfifo == depth) { /* oldest push must be done before its buffer goes back to the framers */
+            rc = sink->wait(sink->ctx, fifo[0].token);
+            fs_release(&f, fifo[0].buf);
+            memmove(fifo, fifo + 1, sizeof fifo[0] * (size_t)(--nfifo));
+          }
+          fifo[nfifo].token = tok; fifo[nfifo].buf = s.buf; nfifo++;
+        }
+        stats.t_push_s += fs_now() - tp;
+      }
+      pos = s.end;
+      if (s.rc != MK_OK) rc = s.rc; /* a line beyond the reference's fgets() width: the file is outside the contract */
+    }
+    if (rc == MK_OK && pos < n) FS_SERIAL(pos, n);
+#undef FS_SERIAL
+  }
+
+out:
+  pthread_mutex_lock(&f.mu);
+  f.stop = 1;
+  pthread_cond_broadcast(&f.cv_buf);
+  pthread_mutex_unlock(&f.mu);
+  for (int t = 0; t < nth; t++) pthread_join(th[t], NULL);
+  for (int i = 0; i < nfifo; i++) { /* the caller's buffers may go only when the copies out of them are done */
+    const int wrc = sink->wait ? sink->wait(sink->ctx, fifo[i].token) : MK_OK;
+    if (rc == MK_OK) rc = wrc;
+  }
+  for (int b = 0; b < f.nbufs; b++) if (f.bufs[b]) sink->release(sink->ctx, f.bufs[b]);
+  if (serial_buf) sink->release(sink->ctx, serial_buf);
+  pthread_mutex_destroy(&f.mu);
+  pthread_cond_destroy(&f.cv_buf);
+  pthread_cond_destroy(&f.cv_ready);
+out_nothreads:
+  free(f.bufs); free(f.freelist); free(f.slots); free(th);
+  stats.threads = (uint32_t)nth;
+  stats.t_total_s = fs_now() - t0;
+  if (st) *st = stats;
+  return rc;
+}
+
+/* ---- the stream bound to an engine: pinned buffers, asynchronous pushes --------------------------------------------- */
+typedef struct { mk_engine *e; } fs_engine_ctx;
+
+static int fs_eng_push(void *ctx, const uint8_t *rows, uint32_t stride, uint64_t nrows, uint64_t ord, uint64_t *token) {
+  return mk_sketch_push_reads_async(((fs_engine_ctx *)ctx)->e, rows, stride, nrows, ord, token);
+}
+static int fs_eng_wait(void *ctx, uint64_t token) { return mk_sketch_push_wait(((fs_engine_ctx *)ctx)->e, token); }
+static uint8_t *fs_eng_alloc(void *ctx, size_t bytes) {
+  (void)ctx;
+  void *p = NULL;
+  return mk_host_alloc(&p, bytes) == MK_OK ? (uint8_t *)p : NULL;
+}
+static void fs_eng_release(void *ctx, uint8_t *p) { (void)ctx; mk_host_free(p); }
+
+int mk_sketch_push_fastq(mk_engine *e, const uint8_t *text, size_t n, const mk_fastq_opts *o, uint64_t first_ordinal,
+                         mk_fastq_stats *st) {
+  if (!e) return MK_ERR_ARG;
+  fs_engine_ctx ctx = {e};
+  mk_rows_sink sink = {&ctx, fs_eng_push, fs_eng_wait, fs_eng_alloc, fs_eng_release};
+  return mk_fastq_stream(text, n, o, &sink, first_ordinal, st);
+}

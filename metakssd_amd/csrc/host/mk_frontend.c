@@ -8,13 +8,16 @@
  *            without resetting the k-mer window, '>' header lines skipped with a reset, any other
  *            non-ACGT byte resets)
  */
+#define _GNU_SOURCE
 #include "metakssd_hip.h"
 #include "mk_host_internal.h"
 
+#include <fcntl.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #define MK_FQ_LEN 4096 /* iseq2comem.c:656: fgets() never returns more than FQ_LEN-1 characters */
 
@@ -55,6 +58,91 @@ int mk_synth_fastq_write(const char *path, uint64_t seed, uint64_t first_read, u
   return ok ? MK_OK : MK_ERR_IO;
 }
 
+/* ---- the same file from several threads: record i is "@r<i>\n" + len + 1 + 2 + len + 1 bytes, so the offset of every
+ * record follows from the number of decimal digits of the read numbers in front of it */
+static uint64_t mk_digits_sum(uint64_t a, uint64_t b) { /* sum of the decimal digit counts of a .. b-1 */
+  uint64_t sum = 0, lo = 1, d = 1;
+  if (a == 0 && b > 0) { sum += 1; a = 1; } /* "0" has one digit */
+  while (a < b) {
+    const uint64_t hi = lo > UINT64_MAX / 10 ? UINT64_MAX : lo * 10; /* numbers with d digits: [lo, hi) */
+    if (a < hi) {
+      const uint64_t e = b < hi ? b : hi;
+      sum += (e - a) * d;
+      a = e;
+    }
+    lo = hi; d++;
+  }
+  return sum;
+}
+
+typedef struct {
+  int fd;
+  uint64_t seed, first, lo, hi, off; /* reads [lo, hi) of the file, file offset of read lo */
+  uint32_t len;
+  int rc;
+} mk_fqw_job;
+
+static void *mk_fqw_run(void *arg) {
+  mk_fqw_job *j = arg;
+  const size_t cap = (size_t)4 << 20, rec_max = 2 * (size_t)j->len + 32;
+  uint8_t *b = (uint8_t *)malloc(cap + rec_max);
+  if (!b) { j->rc = MK_ERR_NOMEM; return NULL; }
+  size_t fill = 0;
+  uint64_t off = j->off;
+  for (uint64_t r = j->lo; r <= j->hi; r++) {
+    if (r == j->hi || fill >= cap) {
+      size_t done = 0;
+      while (done < fill) {
+        ssize_t w = pwrite(j->fd, b + done, fill - done, (off_t)(off + done));
+        if (w <= 0) { j->rc = MK_ERR_IO; free(b); return NULL; }
+        done += (size_t)w;
+      }
+      off += fill;
+      fill = 0;
+      if (r == j->hi) break;
+    }
+    fill += (size_t)sprintf((char *)b + fill, "@r%llu\n", (unsigned long long)(j->first + r));
+    mk_synth_rows_host(j->seed, j->first + r, 1, j->len, j->len + 1, b + fill);
+    fill += j->len + 1;
+    b[fill++] = '+'; b[fill++] = '\n';
+    memset(b + fill, 'I', j->len);
+    fill += j->len;
+    b[fill++] = '\n';
+  }
+  free(b);
+  return NULL;
+}
+
+int mk_synth_fastq_write_mt(const char *path, uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len, int nthreads) {
+  if (!path || len == 0 || len > 4094) return MK_ERR_ARG;
+  enum { MAXT = 256 };
+  int T = nthreads < 1 ? 1 : nthreads > MAXT ? MAXT : nthreads;
+  if ((uint64_t)T > nreads) T = nreads ? (int)nreads : 1;
+  const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (fd < 0) return MK_ERR_IO;
+  const uint64_t fixed = 2ull * len + 7; /* "@r" "\n" seq "\n" "+\n" qual "\n" without the digits */
+  const uint64_t total = nreads * fixed + mk_digits_sum(first_read, first_read + nreads);
+  if (ftruncate(fd, (off_t)total) != 0) { close(fd); return MK_ERR_IO; }
+  mk_fqw_job job[MAXT];
+  pthread_t th[MAXT];
+  for (int t = 0; t < T; t++) {
+    mk_fqw_job *j = &job[t];
+    j->fd = fd; j->seed = seed; j->first = first_read; j->len = len; j->rc = MK_OK;
+    j->lo = nreads / (uint64_t)T * (uint64_t)t;
+    j->hi = t + 1 == T ? nreads : nreads / (uint64_t)T * (uint64_t)(t + 1);
+    j->off = j->lo * fixed + mk_digits_sum(first_read, first_read + j->lo);
+  }
+  int started = 0;
+  for (int t = 1; t < T; t++) { if (pthread_create(&th[t], NULL, mk_fqw_run, &job[t]) != 0) break; started = t; }
+  int rc = MK_OK;
+  for (int t = started + 1; t < T; t++) mk_fqw_run(&job[t]); /* threads that could not be started: their share here */
+  mk_fqw_run(&job[0]);
+  for (int t = 1; t <= started; t++) pthread_join(th[t], NULL);
+  for (int t = 0; t < T; t++) if (job[t].rc != MK_OK) rc = job[t].rc;
+  if (close(fd) != 0) rc = MK_ERR_IO;
+  return rc;
+}
+
 /* one text line starting at p: returns its length including the '\n' (or up to `end` when the file ends
  * without one, only if final); 0 = incomplete line, need more data */
 static size_t mk_line(const uint8_t *p, const uint8_t *end, int final) {
@@ -63,13 +151,16 @@ static size_t mk_line(const uint8_t *p, const uint8_t *end, int final) {
   return final ? (size_t)(end - p) : 0;
 }
 
-int mk_fastq_frame(const uint8_t *buf, size_t n, int final, uint8_t *rows, uint32_t stride, uint64_t max_rows,
-                   uint64_t *nrows, size_t *consumed) {
-  if ((!buf && n) || !rows || !nrows || !consumed || stride < 4 || stride > 4096 || (stride & 3)) return MK_ERR_ARG;
-  const uint8_t *p = buf, *end = buf + n;
+/* the framer proper: records that START in front of buf + stop (stop <= n; a record may end behind it).  *need = bytes a
+ * row must hold when MK_ERR_ARG reports a sequence line longer than the stride. */
+int mk_fastq_frame_range(const uint8_t *buf, size_t n, size_t stop, int final, uint8_t *rows, uint32_t stride, uint64_t max_rows,
+                         uint64_t *nrows, size_t *consumed, uint32_t *need) {
+  if ((!buf && n) || !rows || !nrows || !consumed || stride < 4 || stride > 4096 || (stride & 3) || stop > n) return MK_ERR_ARG;
+  const uint8_t *p = buf, *end = buf + n, *stop_at = buf + stop;
   uint64_t r = 0;
   int rc = MK_OK;
-  while (r < max_rows && p < end) {
+  if (need) *need = 0;
+  while (r < max_rows && p < stop_at) {
     /* four lines per record; a record missing any of them is dropped (the && chain at iseq2comem.c:673) */
     size_t l1 = mk_line(p, end, final);
     if (!l1) break;
@@ -90,16 +181,22 @@ int mk_fastq_frame(const uint8_t *buf, size_t n, int final, uint8_t *rows, uint3
       p = end;
       break;
     }
-    if (l2 > stride) { rc = MK_ERR_ARG; break; } /* caller must re-frame from here with a larger stride */
+    if (l2 > stride) { rc = MK_ERR_ARG; if (need) *need = (uint32_t)l2; break; } /* caller must re-frame from here with a larger stride */
     uint8_t *row = rows + r * (uint64_t)stride;
+    if (stride - l2 <= 16 && stride >= 16) memset(row + stride - 16, 0, 16); /* the tail first, then the line over it */
+    else if (l2 < stride) memset(row + l2, 0, stride - l2);
     memcpy(row, s, l2);
-    if (l2 < stride) memset(row + l2, 0, stride - l2);
     r++;
     p = t + l4;
   }
   *nrows = r;
   *consumed = (size_t)(p - buf);
   return rc;
+}
+
+int mk_fastq_frame(const uint8_t *buf, size_t n, int final, uint8_t *rows, uint32_t stride, uint64_t max_rows,
+                   uint64_t *nrows, size_t *consumed) {
+  return mk_fastq_frame_range(buf, n, n, final, rows, stride, max_rows, nrows, consumed, NULL);
 }
 
 #define MK_FQCO_LEN 20000 /* iseq2comem.c:319: fastq2co()'s fgets() width */
@@ -114,14 +211,22 @@ static uint64_t mk_rows_for(size_t L, uint32_t cap, uint32_t TL) {
 int mk_fastq_frame_q(const uint8_t *buf, size_t n, int final, int32_t qmin, int32_t TL, uint64_t records_before,
                      uint8_t *rows, uint32_t stride, uint64_t max_rows, uint64_t *nrows, uint64_t *nrecords,
                      size_t *consumed) {
+  return mk_fastq_frame_q_range(buf, n, n, final, qmin, TL, records_before, rows, stride, max_rows, nrows, nrecords, consumed, NULL);
+}
+
+/* records that START in front of buf + stop; *need as in mk_fastq_frame_range */
+int mk_fastq_frame_q_range(const uint8_t *buf, size_t n, size_t stop, int final, int32_t qmin, int32_t TL, uint64_t records_before,
+                           uint8_t *rows, uint32_t stride, uint64_t max_rows, uint64_t *nrows, uint64_t *nrecords,
+                           size_t *consumed, uint32_t *need_stride) {
   if ((!buf && n) || !rows || !nrows || !nrecords || !consumed || stride > 4096 || (stride & 3) || TL < 2 || TL > 32 ||
-      stride < 2u * (uint32_t)TL + 4)
+      stride < 2u * (uint32_t)TL + 4 || stop > n)
     return MK_ERR_ARG;
-  const uint8_t *p = buf, *end = buf + n;
+  const uint8_t *p = buf, *end = buf + n, *stop_at = buf + stop;
   const uint32_t cap = stride - 1;
   uint64_t r = 0, rec = 0;
   int rc = MK_OK;
-  while (p < end) {
+  if (need_stride) *need_stride = 0;
+  while (p < stop_at) {
     const uint8_t *ln[4];
     size_t len[4] = {0, 0, 0, 0};
     const uint8_t *q = p;
@@ -143,7 +248,7 @@ int mk_fastq_frame_q(const uint8_t *buf, size_t n, int final, int32_t qmin, int3
     if (rc) break;
     size_t L = len[1];
     if (L && ln[1][L - 1] == '\n') L--;
-    if (L > cap && stride < 4096) { rc = MK_ERR_ARG; break; } /* caller re-frames from here with wider rows */
+    if (L > cap && stride < 4096) { rc = MK_ERR_ARG; if (need_stride) *need_stride = (uint32_t)(L + 1 > 4096 ? 4096 : L + 1); break; } /* caller re-frames from here with wider rows */
     const uint64_t need = mk_rows_for(L, cap, (uint32_t)TL);
     if (r + need > max_rows) {
       if (r == 0) rc = MK_ERR_ARG;

@@ -21,4 +21,13 @@ static inline MK_HD uint64_t mk_mix64(uint64_t z) {
 static inline MK_HD uint64_t mk_synth_word(uint64_t seed, uint64_t read, uint64_t j) {
   return mk_mix64(mk_mix64(seed ^ read) + j);
 }
+#if !defined(__HIPCC__)
+#include <stddef.h>
+/* range forms of the two FASTQ framers (mk_frontend.c), shared with the whole-file stream (mk_fastq_stream.c) */
+int mk_fastq_frame_range(const uint8_t *buf, size_t n, size_t stop, int final, uint8_t *rows, uint32_t stride, uint64_t max_rows,
+                         uint64_t *nrows, size_t *consumed, uint32_t *need);
+int mk_fastq_frame_q_range(const uint8_t *buf, size_t n, size_t stop, int final, int32_t qmin, int32_t TL, uint64_t records_before,
+                           uint8_t *rows, uint32_t stride, uint64_t max_rows, uint64_t *nrows, uint64_t *nrecords,
+                           size_t *consumed, uint32_t *need);
+#endif
 #endif

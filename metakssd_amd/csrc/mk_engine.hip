@@ -18,6 +18,7 @@
 static thread_local char g_create_error[512] = "";
 
 struct mk_evpair { hipEvent_t a, b; };
+#define MK_TICKETS 16
 
 struct mk_engine {
   int device = 0;
@@ -52,9 +53,8 @@ struct mk_engine {
   unsigned long long *d_comp_totals = nullptr, *h_comp_totals = nullptr; /* [component] */
   unsigned long long *d_counters = nullptr; /* [0]=distinct, [1]=dump total, [2..3]=err flags (as u32) */
   unsigned long long *h_counters = nullptr; /* pinned mirror */
-  uint32_t *d_out_ids = nullptr;
-  uint16_t *d_out_cnt = nullptr;
-  uint64_t out_cap = 0;
+  /* result arrays: pinned host memory that the dump kernels write directly (it is mapped into the device's address
+   * space), so that a finish needs one host synchronisation and no separate result copy */
   uint32_t *h_ids = nullptr;
   uint16_t *h_cnt = nullptr;
   uint64_t h_cap = 0;
@@ -65,13 +65,18 @@ struct mk_engine {
   size_t stage_bytes = 0;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_scanned[2] = {nullptr, nullptr};
   int stage_next = 0;
+  /* asynchronous pushes: ticket t is done when ev_ticket[t % MK_TICKETS] (recorded behind its last copy) has fired */
+  hipEvent_t ev_ticket[MK_TICKETS] = {};
+  uint64_t tickets_issued = 0;
+  /* dynamic-LDS limit already granted to each scan-kernel instantiation on this engine's device */
+  std::vector<std::pair<const void *, size_t>> lds_granted;
 
   int mode = -1;
   uint32_t min_occ = 1; /* MK_MODE_OCC_SET: dump keys seen at least this often */
   bool begun = false, compacted = false;
   uint64_t D = 0;
 
-  /* launch tuning (overridable through MK_SCAN_THREADS / MK_SCAN_CB for experiments) */
+  /* launch tuning (fixed in the shipped library; a -DMK_TUNING build reads MK_SCAN_THREADS / MK_SCAN_CB / ..) */
   int tune_threads = 1024;
   bool tune_onepass = true;
   uint32_t tune_cb = MK_MAX_CB;
@@ -134,7 +139,8 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipFree(e->d_dirty_acc); hipFree(e->d_dirty_slot); hipFree(e->d_list_acc); hipFree(e->d_list_slot); hipFree(e->d_nlist);
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters);
-  if (e->h_comp_totals) hipHostFree(e->h_comp_totals); hipFree(e->d_out_ids); hipFree(e->d_out_cnt);
+  if (e->h_comp_totals) hipHostFree(e->h_comp_totals);
+  for (int i = 0; i < MK_TICKETS; i++) if (e->ev_ticket[i]) hipEventDestroy(e->ev_ticket[i]);
   if (e->h_counters) hipHostFree(e->h_counters);
   if (e->h_ids) hipHostFree(e->h_ids);
   if (e->h_cnt) hipHostFree(e->h_cnt);
@@ -148,6 +154,40 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   if (e->own_stream) hipStreamDestroy(e->own_stream);
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
   delete e;
+  return MK_OK;
+}
+
+/* allocates / frees the dirty-block bookkeeping of the sparse table passes */
+static int mk_config_sparse(mk_engine *e, bool on) {
+  hipFree(e->d_dirty_acc); hipFree(e->d_dirty_slot); hipFree(e->d_list_acc); hipFree(e->d_list_slot); hipFree(e->d_nlist);
+  e->d_dirty_acc = e->d_dirty_slot = e->d_list_acc = e->d_list_slot = e->d_nlist = nullptr;
+  e->tab.dirty = nullptr;
+  e->tab.dirty_shift = 0;
+  e->sparse = on;
+  e->tables_tracked = false;
+  if (!on) return MK_OK;
+  const uint64_t S = e->P.hashsize;
+  e->acc_blocks = (uint32_t)((S + MK_SPARSE_BLOCK - 1) / MK_SPARSE_BLOCK);
+  e->acc_words = (e->acc_blocks + 31u) / 32u;
+  const uint32_t nch = (uint32_t)((S + MK_DUMP_CHUNK - 1) / MK_DUMP_CHUNK);
+  e->slot_words = (nch + 31u) / 32u;
+  MK_HIP(e, hipMalloc(&e->d_dirty_acc, (size_t)e->acc_words * 4));
+  MK_HIP(e, hipMalloc(&e->d_dirty_slot, (size_t)e->slot_words * 4));
+  MK_HIP(e, hipMalloc(&e->d_list_acc, (size_t)e->acc_words * 32 * 4));
+  MK_HIP(e, hipMalloc(&e->d_list_slot, (size_t)e->slot_words * 32 * 4));
+  MK_HIP(e, hipMalloc(&e->d_nlist, 4 * sizeof(uint32_t)));
+  e->tab.dirty = e->d_dirty_acc;
+  e->tab.dirty_shift = MK_SPARSE_SHIFT;
+  return MK_OK;
+}
+
+static int mk_config_cand(mk_engine *e, uint32_t cap) {
+  hipFree(e->d_cand); hipFree(e->d_cand_count);
+  e->d_cand = nullptr; e->d_cand_count = nullptr;
+  e->cand_cap = cap;
+  MK_HIP(e, hipMalloc(&e->d_cand, (size_t)e->cand_slots * (e->cand_cap + 1) * sizeof(uint4)));
+  MK_HIP(e, hipMalloc(&e->d_cand_count, (size_t)e->cand_slots * sizeof(uint32_t)));
+  MK_HIP(e, hipMemset(e->d_cand_count, 0, (size_t)e->cand_slots * sizeof(uint32_t)));
   return MK_OK;
 }
 
@@ -211,23 +251,9 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   e->tab.kc = (unsigned long long *)e->d_tab;
   e->tab.ordinv = e->tab.kc + S;
   MK_HIP(e, hipMalloc(&e->d_slot, S * sizeof(uint32_t)));
-  /* sparse bookkeeping from 2^26 slots up (L2K11: 537 M slots for a genome's few thousand keys); MK_SPARSE=0/1 forces it
-   * off/on (the tests run the small tables both ways) */
-  e->sparse = S >= (1ull << 26);
-  if (const char *t = getenv("MK_SPARSE")) e->sparse = atoi(t) != 0;
-  if (e->sparse) {
-    e->acc_blocks = (uint32_t)((S + MK_SPARSE_BLOCK - 1) / MK_SPARSE_BLOCK);
-    e->acc_words = (e->acc_blocks + 31u) / 32u;
-    const uint32_t nch = (uint32_t)((S + MK_DUMP_CHUNK - 1) / MK_DUMP_CHUNK);
-    e->slot_words = (nch + 31u) / 32u;
-    MK_HIP(e, hipMalloc(&e->d_dirty_acc, (size_t)e->acc_words * 4));
-    MK_HIP(e, hipMalloc(&e->d_dirty_slot, (size_t)e->slot_words * 4));
-    MK_HIP(e, hipMalloc(&e->d_list_acc, (size_t)e->acc_words * 32 * 4));
-    MK_HIP(e, hipMalloc(&e->d_list_slot, (size_t)e->slot_words * 32 * 4));
-    MK_HIP(e, hipMalloc(&e->d_nlist, 4 * sizeof(uint32_t)));
-    e->tab.dirty = e->d_dirty_acc;
-    e->tab.dirty_shift = MK_SPARSE_SHIFT;
-  }
+  /* sparse bookkeeping from 2^26 slots up (L2K11: 537 M slots for a genome's few thousand keys);
+   * mk_engine_set_option(MK_OPT_SPARSE) forces it off/on (the tests run the small tables both ways) */
+  { int rc = mk_config_sparse(e, S >= (1ull << 26)); if (rc) return rc; }
   e->dist.cap = S; /* hashlimit+1 entries suffice for KOC/SET; MK_MODE_OCC_SET may fill the table (fastq2co never aborts) */
   MK_HIP(e, hipMalloc(&e->dist.key, e->dist.cap * 8));
   MK_HIP(e, hipMalloc(&e->dist.ord, e->dist.cap * 8));
@@ -243,14 +269,13 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   e->tab.err = (uint32_t *)(e->d_counters + 2);
   e->comps.resize((size_t)p->component_num);
   e->cand_slots = (uint32_t)e->num_cu * 16u; /* at most 16 waves per workgroup, one workgroup per CU */
-  e->cand_cap = 8192u;
-  if (const char *t = getenv("MK_CAND_CAP")) { int v = atoi(t); if (v >= 0) e->cand_cap = (uint32_t)v; }
-  MK_HIP(e, hipMalloc(&e->d_cand, (size_t)e->cand_slots * (e->cand_cap + 1) * sizeof(uint4)));
-  MK_HIP(e, hipMalloc(&e->d_cand_count, (size_t)e->cand_slots * sizeof(uint32_t)));
-  MK_HIP(e, hipMemset(e->d_cand_count, 0, (size_t)e->cand_slots * sizeof(uint32_t)));
+  { int rc = mk_config_cand(e, 8192u); if (rc) return rc; }
+  for (int i = 0; i < MK_TICKETS; i++) MK_HIP(e, hipEventCreateWithFlags(&e->ev_ticket[i], hipEventDisableTiming));
+#ifdef MK_TUNING /* experiment knobs: compiled only into tools/ builds (make tuning), never into the shipped library */
   if (const char *t = getenv("MK_SCAN_THREADS")) { int v = atoi(t); if (v == 512 || v == 768 || v == 1024) e->tune_threads = v; }
   if (const char *t = getenv("MK_SCAN_ONEPASS")) e->tune_onepass = atoi(t) != 0;
   if (const char *t = getenv("MK_SCAN_CB")) { int v = atoi(t); if (v >= 16 && v <= MK_MAX_CB && v % 16 == 0) e->tune_cb = (uint32_t)v; }
+#endif
   return MK_OK;
 }
 
@@ -274,6 +299,32 @@ extern "C" int mk_engine_create(const mk_params *p, int device, mk_engine **out)
   }
   *out = e;
   return MK_OK;
+}
+
+extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
+  if (!e) return MK_ERR_ARG;
+  if (e->begun) return mk_fail(e, MK_ERR_STATE, "mk_engine_set_option inside a sketch (between begin and finish)");
+  MK_HIP(e, hipSetDevice(e->device));
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  switch (option) {
+    case MK_OPT_SPARSE:
+      if (value < -1 || value > 1) return mk_fail(e, MK_ERR_ARG, "MK_OPT_SPARSE takes -1 (by table size), 0 or 1");
+      return mk_config_sparse(e, value < 0 ? e->P.hashsize >= (1u << 26) : value != 0);
+    case MK_OPT_CAND_CAP:
+      if (value < 0 || value > (1 << 20)) return mk_fail(e, MK_ERR_ARG, "MK_OPT_CAND_CAP takes 0 .. 2^20 records per scan wave");
+      return mk_config_cand(e, (uint32_t)value);
+    case MK_OPT_RESULT_CAP: {
+      if (value < 1 || value > (int64_t)e->P.hashsize) return mk_fail(e, MK_ERR_ARG, "MK_OPT_RESULT_CAP takes 1 .. hashsize entries");
+      if (e->h_ids) hipHostFree(e->h_ids);
+      if (e->h_cnt) hipHostFree(e->h_cnt);
+      e->h_ids = nullptr; e->h_cnt = nullptr; e->h_cap = 0;
+      MK_HIP(e, hipHostMalloc((void **)&e->h_ids, (size_t)value * 4, hipHostMallocDefault));
+      MK_HIP(e, hipHostMalloc((void **)&e->h_cnt, (size_t)value * 2, hipHostMallocDefault));
+      e->h_cap = (uint64_t)value;
+      return MK_OK;
+    }
+    default: return mk_fail(e, MK_ERR_ARG, "unknown engine option %d", option);
+  }
 }
 
 extern "C" int mk_engine_set_stream(mk_engine *e, void *hip_stream) {
@@ -375,35 +426,38 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
 
 /* ---- scan launch -------------------------------------------------------------------------------------- */
 template <int K, bool V, int T, int NP, bool OP>
-static hipError_t mk_launch_scan_t(const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
-  /* the dynamic-LDS limit is a per-device attribute of the kernel: remember what each device was given */
-  static size_t configured[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (lds > configured[dev]) {
-    hipError_t r = hipFuncSetAttribute((const void *)mk_scan_kernel<K, V, T, NP, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+static hipError_t mk_launch_scan_t(mk_engine *e, const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
+  /* the dynamic-LDS limit is a per-device attribute of the kernel.  What this engine has asked for is remembered in the
+   * engine (one engine = one device; calls on one engine are serialised by the caller), so engines driven from
+   * different host threads share no state here; asking again for another engine on the same device is harmless. */
+  const void *fn = (const void *)mk_scan_kernel<K, V, T, NP, OP>;
+  size_t *granted = nullptr;
+  for (auto &g : e->lds_granted) if (g.first == fn) granted = &g.second;
+  if (!granted) { e->lds_granted.emplace_back(fn, 0); granted = &e->lds_granted.back().second; }
+  if (lds > *granted) {
+    hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (r != hipSuccess) return r;
-    configured[dev] = lds;
+    *granted = lds;
   }
   hipLaunchKernelGGL((mk_scan_kernel<K, V, T, NP, OP>), grid, dim3(T), lds, s, a);
   return hipGetLastError();
 }
 template <int K, bool V>
-static hipError_t mk_launch_scan_k(int threads, bool onepass, const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
+static hipError_t mk_launch_scan_k(mk_engine *e, int threads, bool onepass, const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
   /* piece registers: 16-byte path CB <= 80 -> 5 pieces, CB <= 128 -> 8; 4-byte path up to 32 */
   constexpr int NPBIG = V ? MK_MAX_PIECES : MK_MAX_CB / 4;
   constexpr int NPSMALL = V ? 5 : 20;
   const bool small = a.ppr <= (uint32_t)NPSMALL;
   if constexpr (V) {
     if (onepass && small) /* one-pass staging: 2 x 5 pieces live */
-      return threads >= 1024 ? mk_launch_scan_t<K, V, 1024, NPSMALL, true>(a, grid, lds, s)
-             : threads >= 768 ? mk_launch_scan_t<K, V, 768, NPSMALL, true>(a, grid, lds, s)
-                              : mk_launch_scan_t<K, V, 512, NPSMALL, true>(a, grid, lds, s);
+      return threads >= 1024 ? mk_launch_scan_t<K, V, 1024, NPSMALL, true>(e, a, grid, lds, s)
+             : threads >= 768 ? mk_launch_scan_t<K, V, 768, NPSMALL, true>(e, a, grid, lds, s)
+                              : mk_launch_scan_t<K, V, 512, NPSMALL, true>(e, a, grid, lds, s);
   }
   switch (threads) {
-    case 1024: return small ? mk_launch_scan_t<K, V, 1024, NPSMALL, false>(a, grid, lds, s) : mk_launch_scan_t<K, V, 1024, NPBIG, false>(a, grid, lds, s);
-    case 768: return small ? mk_launch_scan_t<K, V, 768, NPSMALL, false>(a, grid, lds, s) : mk_launch_scan_t<K, V, 768, NPBIG, false>(a, grid, lds, s);
-    default: return small ? mk_launch_scan_t<K, V, 512, NPSMALL, false>(a, grid, lds, s) : mk_launch_scan_t<K, V, 512, NPBIG, false>(a, grid, lds, s);
+    case 1024: return small ? mk_launch_scan_t<K, V, 1024, NPSMALL, false>(e, a, grid, lds, s) : mk_launch_scan_t<K, V, 1024, NPBIG, false>(e, a, grid, lds, s);
+    case 768: return small ? mk_launch_scan_t<K, V, 768, NPSMALL, false>(e, a, grid, lds, s) : mk_launch_scan_t<K, V, 768, NPBIG, false>(e, a, grid, lds, s);
+    default: return small ? mk_launch_scan_t<K, V, 512, NPSMALL, false>(e, a, grid, lds, s) : mk_launch_scan_t<K, V, 512, NPBIG, false>(e, a, grid, lds, s);
   }
 }
 
@@ -448,20 +502,22 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   uint64_t blocks = (ntiles + waves - 1) / waves;
   if (blocks > (uint64_t)e->num_cu) blocks = (uint64_t)e->num_cu;
   dim3 grid((unsigned)blocks);
+#ifdef MK_TUNING
   if (getenv("MK_DEBUG")) {
     static int once = 0;
     if (!once++) fprintf(stderr, "scan cfg: threads %d blocks %llu CB %u ncb %u rowdw %u lds %zu B onepass %d\n", threads,
                          (unsigned long long)blocks, a.CB, a.ncb, a.rowdw, lds, (int)onepass);
   }
+#endif
 
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   hipError_t r;
   /* tuned kernels: 24-bit inner substring (subk 6), k in {10,11}, every column block a whole number of 8-base pairs */
   switch ((e->P.subk == 6 && stride % 8u == 0 && a.CB % 8u == 0) ? e->P.k : 0) {
-    case 11: r = vec ? mk_launch_scan_k<11, true>(threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<11, false>(threads, false, a, grid, lds, e->stream); break;
-    case 10: r = vec ? mk_launch_scan_k<10, true>(threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<10, false>(threads, false, a, grid, lds, e->stream); break;
-    default: r = vec ? mk_launch_scan_k<0, true>(threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<0, false>(threads, false, a, grid, lds, e->stream); break;
+    case 11: r = vec ? mk_launch_scan_k<11, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<11, false>(e, threads, false, a, grid, lds, e->stream); break;
+    case 10: r = vec ? mk_launch_scan_k<10, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<10, false>(e, threads, false, a, grid, lds, e->stream); break;
+    default: r = vec ? mk_launch_scan_k<0, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<0, false>(e, threads, false, a, grid, lds, e->stream); break;
   }
   if (r != hipSuccess) return mk_fail(e, MK_ERR_HIP, "scan launch: %s", hipGetErrorString(r));
   if (e->profiling) {
@@ -477,7 +533,9 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
     if (e->profiling) { ev2 = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev2.a, e->stream)); }
     /* the resolve workgroups build the LDS filter too (pair records name a pair, not a base): fewer, looping workgroups */
     uint32_t rgrid = used_slots < (uint32_t)e->num_cu * 4u ? used_slots : (uint32_t)e->num_cu * 4u; /* measured: 512: 0.31, 1024: 0.30, 4096: 0.34 ms */
+#ifdef MK_TUNING
     if (const char *t = getenv("MK_RESOLVE_GRID")) { const uint32_t g = (uint32_t)atoi(t); if (g && g <= used_slots) rgrid = g; }
+#endif
     hipLaunchKernelGGL(mk_resolve_kernel, dim3(rgrid), dim3(MK_RESOLVE_THREADS), (size_t)a.bm_words * 4u, e->stream, a, used_slots);
     MK_HIP(e, hipGetLastError());
     if (e->profiling) { MK_HIP(e, hipEventRecord(ev2.b, e->stream)); e->ev_resolve.push_back(ev2); }
@@ -514,10 +572,11 @@ extern "C" int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev
   return MK_OK;
 }
 
-extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t stride, uint64_t nreads,
-                                    uint64_t first_read_ordinal) {
+extern "C" int mk_sketch_push_reads_async(mk_engine *e, const uint8_t *rows, uint32_t stride, uint64_t nreads,
+                                          uint64_t first_read_ordinal, uint64_t *ticket) {
   int rc = mk_check_push(e, rows, stride);
   if (rc) return rc;
+  if (!ticket) return MK_ERR_ARG;
   MK_HIP(e, hipSetDevice(e->device));
   if ((first_read_ordinal + nreads) >> 51) return mk_fail(e, MK_ERR_ARG, "read ordinal too large");
   const size_t chunk_max = (size_t)64 << 20;
@@ -541,23 +600,42 @@ extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t 
     MK_HIP(e, hipEventRecord(e->ev_scanned[b], e->stream));
     done += n;
   }
-  MK_HIP(e, hipStreamSynchronize(e->copy_stream)); /* caller's buffer is free again; the last scan may still run */
+  /* the ticket fires when the last copy out of `rows` is done.  A ring slot is reused only after its previous ticket
+   * has been waited for here, so a caller may keep up to MK_TICKETS pushes in flight without ever waiting itself. */
+  const uint64_t t = e->tickets_issued;
+  hipEvent_t ev = e->ev_ticket[t % MK_TICKETS];
+  if (t >= MK_TICKETS) MK_HIP(e, hipEventSynchronize(ev));
+  MK_HIP(e, hipEventRecord(ev, e->copy_stream));
+  e->tickets_issued = t + 1;
+  *ticket = t;
   return MK_OK;
 }
 
+extern "C" int mk_sketch_push_wait(mk_engine *e, uint64_t ticket) {
+  if (!e) return MK_ERR_ARG;
+  if (ticket >= e->tickets_issued) return mk_fail(e, MK_ERR_ARG, "mk_sketch_push_wait: ticket %llu was never issued", (unsigned long long)ticket);
+  if (ticket + MK_TICKETS < e->tickets_issued) return MK_OK; /* its ring slot has been reused: waited for at that point */
+  MK_HIP(e, hipSetDevice(e->device));
+  MK_HIP(e, hipEventSynchronize(e->ev_ticket[ticket % MK_TICKETS]));
+  return MK_OK;
+}
+
+extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t stride, uint64_t nreads,
+                                    uint64_t first_read_ordinal) {
+  uint64_t t = 0;
+  int rc = mk_sketch_push_reads_async(e, rows, stride, nreads, first_read_ordinal, &t);
+  if (rc) return rc;
+  return mk_sketch_push_wait(e, t); /* caller's buffer is free again; the last scan may still run */
+}
+
 /* ---- compaction / partials --------------------------------------------------------------------------- */
-static int mk_compact(mk_engine *e) {
-  if (e->compacted) return MK_OK;
+/* table -> distinct-key list on the device; the number of keys lands in d_counters[0].  No host synchronisation. */
+static int mk_compact_launch(mk_engine *e) {
   MK_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(unsigned long long), e->stream));
   /* co[n]=0 stays "empty" in the FASTA set flavours (iseq2comem.c:300-302); the FASTQ slot words carry a count
    * field, so key 0 is an ordinary key there (:398-399, :704-705) */
   const int drop0 = e->mode == MK_MODE_SET || e->mode == MK_MODE_UNIQ_SET;
-  /* fastq2co() tests `keycount > hashlimit` but never advances keycount (:404): only a full table stops it */
-  const uint64_t limit = e->mode == MK_MODE_OCC_SET ? (uint64_t)e->kp.S - 1 : (uint64_t)e->P.hashlimit;
-#ifndef MK_COMPACT_BLOCKS_PER_CU
-#define MK_COMPACT_BLOCKS_PER_CU 2
-#endif
-  const unsigned blocks = (unsigned)(e->num_cu * MK_COMPACT_BLOCKS_PER_CU);
+  const unsigned blocks = (unsigned)(e->num_cu * 2);
   if (e->sparse) { /* only the blocks somebody installed a key in */
     hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_acc, e->acc_words, e->d_list_acc, e->d_nlist + 2, 0);
     hipLaunchKernelGGL(mk_compact_kernel<MK_SPARSE_BLOCK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
@@ -567,13 +645,36 @@ static int mk_compact(mk_engine *e) {
                        e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
   }
   MK_HIP(e, hipGetLastError());
-  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
-  MK_HIP(e, hipStreamSynchronize(e->stream));
+  return MK_OK;
+}
+
+/* most distinct keys a sketch may hold before the reference gives up */
+static uint64_t mk_key_limit(const mk_engine *e) {
+  /* fastq2co() tests `keycount > hashlimit` but never advances keycount (:404): only a full table stops it */
+  return e->mode == MK_MODE_OCC_SET ? (uint64_t)e->kp.S - 1 : (uint64_t)e->P.hashlimit;
+}
+
+/* device error flags + key count -> return code (after the counters have been copied to h_counters) */
+static int mk_check_counters(mk_engine *e) {
   const uint32_t errflags = (uint32_t)(e->h_counters[2] & 0xffffffffu);
   e->D = e->h_counters[0];
-  if ((errflags & 1u) || e->D > limit)
+  if (errflags & 4u) return mk_fail(e, MK_ERR_HIP, "scan kernel: LDS filter not at offset 0");
+  if ((errflags & 1u) || e->D > mk_key_limit(e))
     return mk_fail(e, MK_ERR_CROWDED, "the context space is too crowd (%llu distinct keys > limit %llu), try k=%d",
-                   (unsigned long long)e->D, (unsigned long long)limit, e->P.k + 1);
+                   (unsigned long long)e->D, (unsigned long long)mk_key_limit(e), e->P.k + 1);
+  if (errflags & 2u) return mk_fail(e, MK_ERR_HIP, "layout kernel did not converge");
+  return MK_OK;
+}
+
+/* compaction with the key count brought to the host (the multi-GPU export needs it there) */
+static int mk_compact(mk_engine *e) {
+  if (e->compacted) return MK_OK;
+  int rc = mk_compact_launch(e);
+  if (rc) return rc;
+  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  rc = mk_check_counters(e);
+  if (rc) return rc;
   e->compacted = true;
   return MK_OK;
 }
@@ -623,100 +724,107 @@ extern "C" int mk_partial_import(mk_engine *e, const uint64_t *keys_dev, const u
 }
 
 /* ---- finish: layout + dump ------------------------------------------------------------------------------ */
+static int mk_result_capacity(mk_engine *e, uint64_t want) {
+  if (want <= e->h_cap && e->h_ids) return MK_OK;
+  if (e->h_ids) hipHostFree(e->h_ids);
+  if (e->h_cnt) hipHostFree(e->h_cnt);
+  e->h_ids = nullptr; e->h_cnt = nullptr; e->h_cap = 0;
+  const uint64_t cap = want + want / 8 + 1024;
+  MK_HIP(e, hipHostMalloc((void **)&e->h_ids, cap * 4, hipHostMallocDefault));
+  MK_HIP(e, hipHostMalloc((void **)&e->h_cnt, cap * 2, hipHostMallocDefault));
+  e->h_cap = cap;
+  return MK_OK;
+}
+
+/* the ordered dump of the layout table into the (host-mapped) result arrays; with count_pass == false only the write
+ * kernel runs again (after the result arrays have grown; the chunk offsets of the first pass are still valid) */
+static int mk_launch_dump(mk_engine *e, bool count_pass) {
+  const int C = e->P.component_num;
+  const bool koc = e->mode == MK_MODE_KOC;
+  mk_dump_args da{};
+  da.slot = e->d_slot; da.S = e->kp.S; da.d = e->dist;
+  da.dirty_slot = e->sparse ? e->d_dirty_slot : nullptr;
+  da.comp_num = (uint32_t)C; da.comp_code_bits = (uint32_t)e->P.comp_code_bits;
+  da.cnt_lo = e->mode == MK_MODE_OCC_SET ? e->min_occ : 1u; /* write_fqco2file(): marked keys only (iseq2comem.c:611) */
+  da.cnt_hi = e->mode == MK_MODE_UNIQ_SET ? 1u : 0xffffffffu;  /* uniq_fasta2co(): repeated keys dropped */
+  da.nchunks = e->nchunks;
+  da.out_cap = e->h_cap;
+  const unsigned dblocks = (e->nchunks + 3) / 4; /* 4 waves (chunks) per 256-thread block */
+  if (C == 1) {
+    da.comp = 0;
+    if (count_pass) {
+      hipLaunchKernelGGL(mk_dump_count_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, e->d_chunk);
+      hipLaunchKernelGGL(mk_dump_scan_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_chunk, e->nchunks, e->d_comp_totals);
+    }
+    hipLaunchKernelGGL(mk_dump_write_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, (const uint32_t *)e->d_chunk,
+                       (const unsigned long long *)e->d_comp_totals, e->h_ids, koc ? e->h_cnt : nullptr);
+  } else {
+    /* all components in one count pass and one write pass; components back to back in the output */
+    if (count_pass) {
+      hipLaunchKernelGGL(mk_dumpc_count_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, e->d_chunk);
+      hipLaunchKernelGGL(mk_dumpc_scan_kernel, dim3((unsigned)C), dim3(1024), 0, e->stream, e->d_chunk, e->nchunks, e->d_comp_totals);
+    }
+    hipLaunchKernelGGL(mk_dumpc_write_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, (const uint32_t *)e->d_chunk,
+                       (const unsigned long long *)e->d_comp_totals, e->h_ids, koc ? e->h_cnt : nullptr);
+  }
+  MK_HIP(e, hipGetLastError());
+  return MK_OK;
+}
+
+/* One host synchronisation per finish: compaction, layout and dump take the key count from device memory, the dump writes
+ * ids and counts straight into the pinned result arrays, and the counters (key count, component sizes, error flags) come
+ * back in one small copy in front of the only hipStreamSynchronize.  Only a result larger than the arrays (first big
+ * sketch on this engine) costs a second round: grow, write again. */
 extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
   if (!e || !out) return MK_ERR_ARG;
   if (!e->begun) return mk_fail(e, MK_ERR_STATE, "finish before mk_sketch_begin");
   MK_HIP(e, hipSetDevice(e->device));
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
-  int rc = mk_compact(e);
+  int rc = MK_OK;
+  if (!e->compacted) rc = mk_compact_launch(e);
   if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
-  const uint64_t D = e->D;
   const uint32_t S = e->kp.S;
   const int C = e->P.component_num;
   const bool koc = e->mode == MK_MODE_KOC;
-
-  /* output capacity */
-  if (D > e->out_cap) {
-    hipFree(e->d_out_ids); hipFree(e->d_out_cnt);
-    e->d_out_ids = nullptr; e->d_out_cnt = nullptr;
-    uint64_t cap = D + D / 8 + 1024;
-    MK_HIP(e, hipMalloc(&e->d_out_ids, cap * 4));
-    MK_HIP(e, hipMalloc(&e->d_out_cnt, cap * 2));
-    e->out_cap = cap;
-  }
-  if (D > e->h_cap || !e->h_ids) { /* also for an empty first result: mk_component pointers are never NULL where promised */
-    if (e->h_ids) hipHostFree(e->h_ids);
-    if (e->h_cnt) hipHostFree(e->h_cnt);
-    e->h_ids = nullptr; e->h_cnt = nullptr;
-    uint64_t cap = D + D / 8 + 1024;
-    MK_HIP(e, hipHostMalloc((void **)&e->h_ids, cap * 4, hipHostMallocDefault));
-    MK_HIP(e, hipHostMalloc((void **)&e->h_cnt, cap * 2, hipHostMallocDefault));
-    e->h_cap = cap;
+  if (!e->h_ids) { /* first finish: room for 2 M keys (50 M reads at L3K11 leave 1.6 M), never more than the table admits */
+    const uint64_t lim = mk_key_limit(e) + 1;
+    rc = mk_result_capacity(e, lim < (2u << 20) ? lim : (2u << 20));
+    if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
   }
 
-  uint64_t total = 0;
-  if (D > 0) {
-    if (!e->sparse) MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), e->stream)); /* sparse: kept empty by begin */
-    uint64_t lb = (D + 255) / 256;
-    if (lb > (uint64_t)e->num_cu * 16) lb = (uint64_t)e->num_cu * 16;
-    hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)lb), dim3(256), 0, e->stream, e->dist, D, e->d_slot, S, e->tab.err,
-                       e->sparse ? e->d_dirty_slot : nullptr, (uint32_t)MK_DUMP_SHIFT);
-    MK_HIP(e, hipGetLastError());
-
-    mk_dump_args da{};
-    da.slot = e->d_slot; da.S = S; da.d = e->dist;
-    da.dirty_slot = e->sparse ? e->d_dirty_slot : nullptr;
-    da.comp_num = (uint32_t)C; da.comp_code_bits = (uint32_t)e->P.comp_code_bits;
-    da.cnt_lo = e->mode == MK_MODE_OCC_SET ? e->min_occ : 1u; /* write_fqco2file(): marked keys only (iseq2comem.c:611) */
-    da.cnt_hi = e->mode == MK_MODE_UNIQ_SET ? 1u : 0xffffffffu;  /* uniq_fasta2co(): repeated keys dropped */
-    da.nchunks = e->nchunks;
-    const unsigned dblocks = (e->nchunks + 3) / 4; /* 4 waves (chunks) per 256-thread block */
-    if (C == 1) {
-      da.comp = 0;
-      hipLaunchKernelGGL(mk_dump_count_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, e->d_chunk);
-      hipLaunchKernelGGL(mk_dump_scan_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_chunk, e->nchunks, e->d_counters + 1);
-      hipLaunchKernelGGL(mk_dump_write_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, (const uint32_t *)e->d_chunk,
-                         e->d_out_ids, koc ? e->d_out_cnt : nullptr);
-      MK_HIP(e, hipGetLastError());
-      MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
-      MK_HIP(e, hipStreamSynchronize(e->stream));
-      const uint64_t nc = e->h_counters[1];
-      if (nc > D) return mk_fail(e, MK_ERR_HIP, "dump produced more entries than distinct keys");
-      e->comps[0].n = nc;
-      e->comps[0].ids = e->h_ids;
-      e->comps[0].counts = koc ? e->h_cnt : nullptr;
-      total = nc;
-    } else {
-      /* all components in one count pass and one write pass; components back to back in the output */
-      hipLaunchKernelGGL(mk_dumpc_count_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, e->d_chunk);
-      hipLaunchKernelGGL(mk_dumpc_scan_kernel, dim3((unsigned)C), dim3(1024), 0, e->stream, e->d_chunk, e->nchunks, e->d_comp_totals);
-      hipLaunchKernelGGL(mk_dumpc_write_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, (const uint32_t *)e->d_chunk,
-                         (const unsigned long long *)e->d_comp_totals, e->d_out_ids, koc ? e->d_out_cnt : nullptr);
-      MK_HIP(e, hipGetLastError());
-      MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
-      MK_HIP(e, hipMemcpyAsync(e->h_comp_totals, e->d_comp_totals, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
-      MK_HIP(e, hipStreamSynchronize(e->stream));
-      for (int c = 0; c < C; c++) {
-        const uint64_t nc = e->h_comp_totals[c];
-        if (total + nc > D) return mk_fail(e, MK_ERR_HIP, "dump produced more entries than distinct keys");
-        e->comps[c].n = nc;
-        e->comps[c].ids = e->h_ids + total;
-        e->comps[c].counts = koc ? e->h_cnt + total : nullptr;
-        total += nc;
-      }
-    }
-    if ((uint32_t)(e->h_counters[2] & 0xffffffffu) & 2u) return mk_fail(e, MK_ERR_HIP, "layout kernel did not converge");
-    if ((uint32_t)(e->h_counters[2] & 0xffffffffu) & 4u) return mk_fail(e, MK_ERR_HIP, "scan kernel: LDS filter not at offset 0");
-    if (total) {
-      MK_HIP(e, hipMemcpyAsync(e->h_ids, e->d_out_ids, total * 4, hipMemcpyDeviceToHost, e->stream));
-      if (koc) MK_HIP(e, hipMemcpyAsync(e->h_cnt, e->d_out_cnt, total * 2, hipMemcpyDeviceToHost, e->stream));
-    }
-  } else {
-    for (int c = 0; c < C; c++) { e->comps[c].n = 0; e->comps[c].ids = e->h_ids; e->comps[c].counts = koc ? e->h_cnt : nullptr; }
-  }
-  if (e->profiling) { MK_HIP(e, hipEventRecord(ev.b, e->stream)); e->ev_finish.push_back(ev); }
+  if (!e->sparse) MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), e->stream)); /* sparse: kept empty by begin */
+  hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)e->num_cu * 16u), dim3(256), 0, e->stream, e->dist,
+                     (const unsigned long long *)e->d_counters, (unsigned long long)mk_key_limit(e), e->d_slot, S, e->tab.err,
+                     e->sparse ? e->d_dirty_slot : nullptr, (uint32_t)MK_DUMP_SHIFT);
+  MK_HIP(e, hipGetLastError());
+  rc = mk_launch_dump(e, true);
+  if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
+  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  MK_HIP(e, hipMemcpyAsync(e->h_comp_totals, e->d_comp_totals, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  if (e->profiling) MK_HIP(e, hipEventRecord(ev.b, e->stream));
   MK_HIP(e, hipStreamSynchronize(e->stream));
+  rc = mk_check_counters(e);
+  if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
+  e->compacted = true;
+  uint64_t total = 0;
+  for (int c = 0; c < C; c++) total += e->h_comp_totals[c];
+  if (total > e->D) { if (e->profiling) e->ev_pool.push_back(ev); return mk_fail(e, MK_ERR_HIP, "dump produced more entries than distinct keys"); }
+  if (total > e->h_cap) { /* the write kernel held back: grow the result arrays and run it again */
+    rc = mk_result_capacity(e, total);
+    if (rc == MK_OK) rc = mk_launch_dump(e, false);
+    if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
+    if (e->profiling) MK_HIP(e, hipEventRecord(ev.b, e->stream));
+    MK_HIP(e, hipStreamSynchronize(e->stream));
+  }
+  if (e->profiling) e->ev_finish.push_back(ev);
+  uint64_t at = 0;
+  for (int c = 0; c < C; c++) {
+    e->comps[c].n = e->h_comp_totals[c];
+    e->comps[c].ids = e->h_ids + at;
+    e->comps[c].counts = koc ? e->h_cnt + at : nullptr;
+    at += e->h_comp_totals[c];
+  }
   out->component_num = C;
   out->total = total;
   out->components = e->comps.data();

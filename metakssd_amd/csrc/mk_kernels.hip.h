@@ -150,11 +150,7 @@ __device__ __forceinline__ uint64_t mk_revcomp(uint64_t f, uint32_t TL) {
  * cheaper than the reference's A=0 C=1 G=2 T=3 (Basemap, global_basic.c:62-69).  The two codings differ by the
  * Gray map c ^ (c >> 1), which is its own inverse on 2 bits; the LDS filter is built over re-coded substrings
  * and every candidate k-mer is re-coded once here, before anything reference-defined is computed from it. */
-#ifdef MK_STD_CODES
-__device__ __forceinline__ uint64_t mk_scan_to_ref_codes(uint64_t k) { return k; }
-#else
 __device__ __forceinline__ uint64_t mk_scan_to_ref_codes(uint64_t k) { return k ^ ((k >> 1) & 0x5555555555555555ull); }
-#endif
 
 /* One candidate = the FORWARD k-mer whose inner substring passed the strand-symmetric LDS filter.  Form the
  * canonical k-mer (iseq2comem.c:691), look it up in the .shuf table (:692-695), reduce to the key (:696-699)
@@ -350,6 +346,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   const uint32_t filter_base = (uint32_t)(uintptr_t)(mk_lds_cu32)bitmap;
   if (K != 0 && (filter_base != 0u || a.bm_words != 16384u)) {
     if (threadIdx.x == 0) atomicOr(&a.tab.err[0], 4u);
+    if (lane == 0) a.cand_count[blockIdx.x * WAVES + wave] = 0u; /* nothing for the resolve kernel to pick up */
     return;
   }
   const mk_scan_args *ka = (const mk_scan_args *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -515,14 +512,9 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     if (__any(mn == 0u)) hits4(q, pos0);
   };
   auto decode = [&](uint32_t w, uint32_t &codes, uint32_t &x) {
-#ifdef MK_STD_CODES
-    codes = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
-    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u, codes);
-#else
     codes = (w >> 1) & 0x03030303u; /* scan coding A0 C1 T2 G3, see mk_scan_to_ref_codes */
     /* expected upper-case letter of each code, compared with the byte folded to upper case */
     const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, codes);
-#endif
     x = (w & 0xDFDFDFDFu) ^ expect; /* byte j zero <=> byte j in ACGTacgt */
   };
   /* One dword outside the fast path.
@@ -670,20 +662,14 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                 probe(f3, m4, d4); probe(f4, m5, d5); probe(f5, m6, d6); probe(f6, m7, d7);
                 flo = f7;
                 __builtin_amdgcn_sched_barrier(0); /* all eight probes in flight before the first result is read */
-#ifndef MK_NO_SINGLE_WAIT
                 __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) once, instead of a staggered wait per probe */
-#endif
                 /* t == 0 <=> all filter bits set.  Binary descent over the min tree: a pair without hits costs one
                  * test, a single hit about six. */
                 const uint32_t t0 = m0 & ~d0, t1 = m1 & ~d1, t2 = m2 & ~d2, t3 = m3 & ~d3;
                 const uint32_t t4 = m4 & ~d4, t5 = m5 & ~d5, t6 = m6 & ~d6, t7 = m7 & ~d7;
                 /* groups of 3, 3, 2: v_min3_u32 */
                 const uint32_t ta = min(min(t0, t1), t2), tb = min(min(t3, t4), t5), tc = min(t6, t7);
-#if defined(MK_ABLATE) && MK_ABLATE == 3
-                if (__any(min(min(ta, tb), tc) == 0xffffffffu)) {
-#else
                 if (__any(min(min(ta, tb), tc) == 0u)) {
-#endif
                   /* some lane's filter test fired somewhere in this pair: those lanes append one pair record and the
                    * resolve kernel, which holds the same filter, finds the base.  jmin = first base with a complete
                    * k-mer (< 8 here), e = bases in front of the common newline (1..8). */
@@ -883,8 +869,13 @@ __global__ void __launch_bounds__(MK_COMPACT_THREADS) mk_compact_kernel(mk_table
  * Sequential FCFS insertion puts key K in the first slot of its probe sequence that no EARLIER key holds.
  * That fixed point is unique, so it can be reached in any order: a walking key takes a slot from a later
  * occupant and the evicted key resumes from the start of its own sequence. */
-__global__ void __launch_bounds__(256) mk_layout_kernel(mk_dist d, uint64_t D, uint32_t *slot, uint32_t S, uint32_t *err,
-                                                        uint32_t *dirty_slot, uint32_t dirty_slot_shift) {
+__global__ void __launch_bounds__(256) mk_layout_kernel(mk_dist d, const unsigned long long *Dp, unsigned long long limit,
+                                                        uint32_t *slot, uint32_t S, uint32_t *err, uint32_t *dirty_slot,
+                                                        uint32_t dirty_slot_shift) {
+  /* the number of distinct keys is read from device memory (the compaction kernel in front of this one wrote it): the
+   * host does not wait for it.  More keys than the reference admits: the host reports MK_ERR_CROWDED, nothing to lay out. */
+  const uint64_t D = *Dp;
+  if (D > limit) return;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += (uint64_t)gridDim.x * blockDim.x) {
     uint32_t cur = (uint32_t)i;
     unsigned long long ord = d.ord[cur];
@@ -935,6 +926,7 @@ struct mk_dump_args {
   uint32_t cnt_lo, cnt_hi; /* keep keys whose (clamped) count lies in [cnt_lo, cnt_hi] */
   const uint32_t *dirty_slot; /* sparse bookkeeping: one bit per MK_DUMP_CHUNK slots of the layout table, NULL = all chunks */
   uint32_t nchunks;
+  uint64_t out_cap; /* entries the output arrays hold: the write kernels do nothing when the dump is larger (host grows, reruns) */
 };
 
 __device__ __forceinline__ bool mk_dump_pred(const mk_dump_args &a, uint64_t n, uint32_t &idx) {
@@ -993,11 +985,15 @@ __global__ void __launch_bounds__(1024) mk_dump_scan_kernel(uint32_t *chunk_coun
   if (threadIdx.x == 0) *total_out = carry_s;
 }
 
-__global__ void __launch_bounds__(256) mk_dump_write_kernel(mk_dump_args a, const uint32_t *chunk_off, uint32_t *out_ids,
+/* out_ids / out_cnt may be pinned host memory mapped into the device (the engine's result arrays): a wave writes
+ * consecutive entries, i.e. whole 256-byte / 128-byte segments */
+__global__ void __launch_bounds__(256) mk_dump_write_kernel(mk_dump_args a, const uint32_t *chunk_off,
+                                                            const unsigned long long *totals, uint32_t *out_ids,
                                                             uint16_t *out_cnt) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (chunk >= a.nchunks) return;
+  if (totals[0] > a.out_cap) return;
   if (a.dirty_slot && !((a.dirty_slot[chunk >> 5] >> (chunk & 31u)) & 1u)) return;
   uint32_t off = chunk_off[chunk];
   for (uint32_t it = 0; it < MK_DUMP_CHUNK / 64u; it++) {
@@ -1089,6 +1085,11 @@ __global__ void __launch_bounds__(256) mk_dumpc_write_kernel(mk_dump_args a, con
   const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (chunk >= a.nchunks) return;
   if (a.dirty_slot && !((a.dirty_slot[chunk >> 5] >> (chunk & 31u)) & 1u)) return; /* wave-uniform */
+  {
+    unsigned long long all = 0;
+    for (uint32_t c = 0; c < a.comp_num; c++) all += totals[c];
+    if (all > a.out_cap) return;
+  }
   if (lane < a.comp_num) {
     unsigned long long start = 0;
     for (uint32_t c = 0; c < lane; c++) start += totals[c];

@@ -48,6 +48,39 @@ def gather_partials(keys, counts, ords, n, dst=0, group=None):
     return out
 
 
+def gather_partials_concat(keys, counts, ords, n, dst=0, group=None, out=None):
+    """the same exchange with the received lists landing back to back in out = (keys, counts, ords) on `dst` (tensors of
+    the exchange device with room for every rank's list), so that one mk_partial_import launch folds them all in.
+    Returns the number of entries received on `dst`, 0 elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = keys.device
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
+    sizes = [int(s.item()) for s in sizes]
+    ops, total = [], 0
+    if rank == dst:
+        rk, rc, ro = out
+        incoming = sum(sizes[r] for r in range(world) if r != dst)
+        if incoming > rk.numel():
+            raise ValueError("gather_partials_concat: %d incoming entries, room for %d" % (incoming, rk.numel()))
+        for r in range(world):
+            if r == dst or sizes[r] == 0:
+                continue
+            a, b = total, total + sizes[r]
+            ops += [dist.P2POp(dist.irecv, rk[a:b], r, group), dist.P2POp(dist.irecv, rc[a:b], r, group),
+                    dist.P2POp(dist.irecv, ro[a:b], r, group)]
+            total = b
+    elif n > 0:
+        ops += [dist.P2POp(dist.isend, keys[:n].contiguous(), dst, group),
+                dist.P2POp(dist.isend, counts[:n].contiguous(), dst, group),
+                dist.P2POp(dist.isend, ords[:n].contiguous(), dst, group)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return total
+
+
 # ---- config 5 (SURVEY.md 8e): whole input files are the unit -- no reduction, only a gather in file order -----------
 def shard_files(nfiles, rank, world):
     """indices of the files `rank` sketches: contiguous blocks, so that rank order == file order"""

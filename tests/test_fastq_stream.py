@@ -1,0 +1,155 @@
+"""the whole-file FASTQ stream (mk_fastq_stream, metakssd_amd/csrc/host/mk_fastq_stream.c) on the CPU: whatever the file
+contains and however it is cut into chunks, the rows it hands on -- and their order and ordinals -- are those of the serial
+framers, which tests/test_host.py and tools/fuzz_framing.py pin on the reference's readers (iseq2comem.c:672-673, :343-363)"""
+import numpy as np
+import pytest
+
+import util_inputs as ui
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from metakssd_amd import capi as c
+    return c
+
+
+def seqs_of_rows(rows, stride, n):
+    """row payloads up to and including the terminating newline (the zero padding behind it carries nothing)"""
+    out = []
+    r = rows.reshape(n, stride) if n else np.zeros((0, stride), np.uint8)
+    for i in range(n):
+        row = r[i].tobytes()
+        j = row.find(b"\n")
+        out.append(row if j < 0 else row[: j + 1])
+        assert j < 0 or not any(row[j + 1:]), "padding behind the newline must be zero"
+    return out
+
+
+def serial_rows(capi, data, occ, TL=14, qmin=54):
+    """the serial framer at the widest stride: the definition of what the stream has to deliver"""
+    if occ:
+        rows, n, nrec, used, rc = capi.fastq_frame_q(data, 4096, TL, qmin=qmin)
+    else:
+        rows, n, used, rc = capi.fastq_frame(data, 4096)
+        nrec = n
+    return seqs_of_rows(rows, 4096, n), nrec, rc
+
+
+def stream_rows(capi, data, occ, T, chunk, TL=14, qmin=54, first=1000):
+    pushes, st, rc = capi.fastq_stream(data, nthreads=T, chunk_bytes=chunk, occ=occ, TL=TL, qmin=qmin, first_ordinal=first)
+    out, ord_expect = [], first
+    for rows, stride, n, ord0 in pushes:
+        assert stride % 16 == 0 and 32 <= stride <= 4096
+        assert ord0 == ord_expect, "row ordinals must be consecutive in push order"
+        ord_expect += n
+        out += seqs_of_rows(rows, stride, n)
+    assert st.rows == len(out)
+    return out, st, rc
+
+
+def check(capi, data, occ, threads=(1, 3, 8), chunks=(4096, 5000, 65536, 1 << 20), **kw):
+    want, nrec, rc = serial_rows(capi, data, occ, **kw)
+    assert rc == 0
+    for T in threads:
+        for chunk in chunks:
+            got, st, rc = stream_rows(capi, data, occ, T, chunk, **kw)
+            assert rc == 0, (T, chunk)
+            assert got == want, (T, chunk, len(got), len(want))
+            assert st.records == nrec, (T, chunk)
+    return want
+
+
+@pytest.mark.parametrize("occ", [False, True])
+@pytest.mark.parametrize("variant", ["plain", "ragged", "crlf", "trunc", "nonl", "long_headers", "short"])
+def test_stream_equals_serial_framer(capi, variant, occ):
+    rs = np.random.RandomState(5)
+    if variant == "plain":
+        seqs = [ui.rand_seq(rs, 150) for _ in range(3000)]
+    elif variant == "long_headers":
+        seqs = [ui.rand_seq(rs, 40) for _ in range(4000)]
+    elif variant == "short":
+        seqs = [ui.rand_seq(rs, int(rs.randint(0, 30))) for _ in range(6000)]
+    else:
+        seqs = ui.ragged_reads(rs, 4000)
+    quals = ui.random_quals(rs, seqs) if occ else None
+    data = ui.fastq_bytes(seqs, crlf=variant == "crlf", final_newline=variant != "nonl", drop_last_qual=variant == "trunc", quals=quals)
+    if variant == "long_headers":
+        data = data.replace(b"@r", b"@" + b"x" * 700 + b"r")
+    want = check(capi, data, occ)
+    assert len(want) >= len(seqs) - 1
+
+
+@pytest.mark.parametrize("occ", [False, True])
+def test_stream_survives_text_built_to_fool_the_boundary_guess(capi, occ):
+    """quality lines that start with '@', sequence lines that start with '+' or '@', stray blank lines and missing lines:
+    the guessed record starts are then wrong in places, the stream has to notice (chunks discarded / framed serially) and
+    still deliver exactly the serial reader's rows"""
+    rs = np.random.RandomState(17)
+    lines = []
+    for r in range(5000):
+        L = int(rs.choice([20, 60, 150]))
+        s = ui.rand_seq(rs, L)
+        q = bytes(rs.choice(np.frombuffer(b"@+#5I", np.uint8), size=L).astype(np.uint8))
+        if rs.rand() < 0.3:
+            q = b"@" + q[1:]
+        hdr = b"@r%d" % r
+        if rs.rand() < 0.05:
+            s = b"+" + s[1:]
+        if rs.rand() < 0.05:
+            s = b"@" + s[1:]
+        rec = [hdr, s, b"+" if rs.rand() < 0.7 else b"+r%d" % r, q]
+        if rs.rand() < 0.01:
+            rec.insert(int(rs.randint(0, 5)), b"")  # shifts every later record by one line
+        if rs.rand() < 0.01:
+            del rec[int(rs.randint(0, len(rec)))]
+        lines += rec
+    data = b"\n".join(lines) + b"\n"
+    want, nrec, rc = serial_rows(capi, data, occ)
+    assert rc == 0 and len(want) > 1000
+    saw_fallback = False
+    for T in (1, 4, 8):
+        for chunk in (4096, 20000, 1 << 18):
+            got, st, rc = stream_rows(capi, data, occ, T, chunk)
+            assert rc == 0 and got == want, (T, chunk)
+            saw_fallback |= st.chunks_discarded > 0 or st.serial_rows > 0
+    assert saw_fallback, "this input is meant to defeat the guess at least once"
+
+
+def test_stream_edge_inputs(capi):
+    for occ in (False, True):
+        for data in (b"", b"\n", b"@r0\n", b"@r0\nACGT\n", b"@r0\nACGT\n+\n", b"@r0\nACGT\n+\nIIII", b"@r0\nACGT\n+\nIIII\n",
+                     b"\n\n\n\n\n\n\n\n", b"@r0\nACGT\n+\nIIII\n@r1\nAC", b"ACGT" * 3000, b"@" * 9000 + b"\n" + b"+\n" * 40):
+            want, nrec, want_rc = serial_rows(capi, data, occ)
+            assert want_rc in (0, capi.MK_ERR_FORMAT)  # the 9000- and 12000-character lines are beyond mt_shortreads2koc's reader
+            for T in (1, 4):
+                for chunk in (4096, 1 << 20):
+                    got, st, rc = stream_rows(capi, data, occ, T, chunk)
+                    assert rc == want_rc and (rc != 0 or got == want), (occ, data[:30], T, chunk)
+
+
+def test_stream_widens_rows_for_longer_reads_and_refuses_overlong_lines(capi):
+    rs = np.random.RandomState(3)
+    # read lengths grow along the file: the stride sampled at a chunk's head is too small further down
+    seqs = [ui.rand_seq(rs, 30 + (i // 40)) for i in range(8000)]
+    data = ui.fastq_bytes(seqs)
+    check(capi, data, False, threads=(4,), chunks=(1 << 16, 1 << 20))
+    # a 4095-character line is beyond mt_shortreads2koc's fgets() width: MK_ERR_FORMAT, like the serial framer
+    bad = ui.fastq_bytes([b"ACGT" * 10] * 50 + [b"A" * 4095] + [b"ACGT" * 10] * 50)
+    assert capi.fastq_frame(bad, 4096)[3] == capi.MK_ERR_FORMAT
+    for chunk in (4096, 1 << 20):
+        got, st, rc = stream_rows(capi, bad, False, 4, chunk)
+        assert rc == capi.MK_ERR_FORMAT
+    # fastq2co's reader cuts reads above 4095 bases into overlapping 4096-byte rows; 19999+ characters are refused
+    long_seqs = [ui.rand_seq(rs, int(L)) for L in (100, 5000, 150, 12000, 4095, 4096, 30)] * 6
+    datal = ui.fastq_bytes(long_seqs, quals=ui.random_quals(rs, long_seqs))
+    check(capi, datal, True, threads=(3,), chunks=(4096, 1 << 16, 1 << 20))
+    assert stream_rows(capi, ui.fastq_bytes([b"A" * 19999]), True, 2, 4096)[2] == capi.MK_ERR_FORMAT
+
+
+def test_threaded_synthetic_fastq_writer_equals_serial(capi, tmp_path):
+    for first, n in ((0, 1), (0, 12345), (95, 1200), (999990, 25), (10 ** 9 - 3, 10)):
+        a, b = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")
+        assert capi.lib.mk_synth_fastq_write(a.encode(), 7, first, n, 150) == 0
+        for T in (1, 3, 16):
+            assert capi.lib.mk_synth_fastq_write_mt(b.encode(), 7, first, n, 150, T) == 0
+            assert open(a, "rb").read() == open(b, "rb").read(), (first, n, T)

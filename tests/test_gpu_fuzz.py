@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("seed,sparse", [(11, "0"), (12, "1")])
 def test_randomized_engine_vs_oracle(seed, sparse):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--cases", "250", "--seed", str(seed)],
-                       env=dict(os.environ, MK_SPARSE=sparse), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--cases", "250", "--seed", str(seed),
+                        "--sparse", sparse], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and "250 cases, 0 mismatches" in out, out[-1500:]
 

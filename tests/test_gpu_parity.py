@@ -245,11 +245,9 @@ def test_device_resident_push_and_device_synth(capi, engine_for, shufs, oracle_f
     assert_same(got, want)
 
 
-def test_candidate_buffer_overflow_path(capi, shufs, oracle_for, monkeypatch):
+def test_candidate_buffer_overflow_path(capi, shufs, oracle_for):
     """a wave whose candidate append buffer is full resolves hits inline: force it with a zero-capacity buffer"""
-    monkeypatch.setenv("MK_CAND_CAP", "0")
-    eng = capi.Engine(shufs("L0K6"), 0)
-    monkeypatch.delenv("MK_CAND_CAP")
+    eng = capi.Engine(shufs("L0K6"), 0, cand_cap=0)
     try:
         rs = np.random.RandomState(12)
         rows = ui.rows_from_seqs(ui.pool_reads(rs, 20000, 3000), 160)
@@ -261,11 +259,9 @@ def test_candidate_buffer_overflow_path(capi, shufs, oracle_for, monkeypatch):
     assert_same(got, want)
 
 
-def test_candidate_buffer_partial_overflow(capi, shufs, oracle_for, monkeypatch):
+def test_candidate_buffer_partial_overflow(capi, shufs, oracle_for):
     """small buffer: some candidates go through the append buffer, the rest through the inline path"""
-    monkeypatch.setenv("MK_CAND_CAP", "100")
-    eng = capi.Engine(shufs("L0K6"), 0)
-    monkeypatch.delenv("MK_CAND_CAP")
+    eng = capi.Engine(shufs("L0K6"), 0, cand_cap=100)
     try:
         rows = capi.synth_rows_host(8, 0, 500, 150, 160)
         got = run_koc(capi, eng, rows, 160)
@@ -478,13 +474,11 @@ def test_genome_directory_sharded_by_file_equals_cli(capi, shufs, tmp_path, worl
 
 
 @pytest.mark.parametrize("name", ["L0K6", "L1K7", "L0K6z"])
-def test_sparse_bookkeeping_over_a_sequence_of_sketches(capi, shufs, oracle_for, monkeypatch, name):
+def test_sparse_bookkeeping_over_a_sequence_of_sketches(capi, shufs, oracle_for, name):
     """tables of 2^26+ slots track which blocks were touched and clear / compact / dump only those (mk_table::dirty);
-    MK_SPARSE=1 forces that on a small dense table, where one engine then runs sketches of very different sizes and
+    MK_OPT_SPARSE=1 forces that on a small dense table, where one engine then runs sketches of very different sizes and
     flavours back to back -- every one must equal the oracle, i.e. nothing of an earlier sketch may survive a clear"""
-    monkeypatch.setenv("MK_SPARSE", "1")
-    eng = capi.Engine(shufs(name), 0)
-    monkeypatch.delenv("MK_SPARSE")
+    eng = capi.Engine(shufs(name), 0, sparse=1)
     ora = oracle_for(shufs(name))
     rs = np.random.RandomState(91)
     try:
@@ -511,3 +505,115 @@ def test_sparse_bookkeeping_over_a_sequence_of_sketches(capi, shufs, oracle_for,
                 assert_same(got, want, "%s fasta" % name)
     finally:
         eng.close()
+
+
+# ---- round 2: asynchronous pushes, the whole-file FASTQ stream bound to an engine, result-array growth, options ----------
+def test_async_pushes_with_tickets(capi, shufs, oracle_for):
+    """mk_sketch_push_reads_async keeps several host buffers in flight; the sketch equals the oracle's and every ticket
+    can be waited for in any order (also long after its ring slot has been reused)"""
+    eng = capi.Engine(shufs("L1K7"), 0)
+    try:
+        rs = np.random.RandomState(44)
+        seqs = ui.pool_reads(rs, 40000, 4000)
+        rows = ui.rows_from_seqs(seqs, 160)
+        n = len(seqs)
+        eng.begin(capi.MK_MODE_KOC)
+        tickets, parts, per = [], [], 97
+        for lo in range(0, n, per):
+            part = np.ascontiguousarray(rows[lo * 160:min(n, lo + per) * 160])
+            parts.append(part)  # stays alive until its ticket has been waited for
+            tickets.append(eng.push_reads_async(part, 160, lo))
+        assert len(tickets) > 32  # more than the engine's ticket ring
+        for t in reversed(tickets):
+            eng.push_wait(t)
+        with pytest.raises(capi.MkError):
+            eng.push_wait(tickets[-1] + 1)
+        got = eng.finish()
+    finally:
+        eng.close()
+    rc, want = oracle_for(shufs("L1K7")).koc_from_rows(rows, 160)
+    assert rc == 0
+    assert_same(got, want)
+
+
+@pytest.mark.parametrize("occ", [False, True])
+def test_engine_fastq_stream_equals_oracle(capi, shufs, oracle_for, occ):
+    """mk_sketch_push_fastq: host threads frame the FASTQ text into pinned buffers, pushes go out asynchronously in file
+    order; small chunks so that many buffers, strides and the serial fallback all occur"""
+    rs = np.random.RandomState(8)
+    seqs = ui.ragged_reads(rs, 6000) + ui.pool_reads(rs, 30000, 3000)
+    quals = ui.random_quals(rs, seqs)
+    data = ui.fastq_bytes(seqs, quals=quals)
+    name = "L1K7"
+    eng = capi.Engine(shufs(name), 0)
+    ora = oracle_for(shufs(name))
+    try:
+        for T, chunk in ((1, 1 << 20), (6, 4096), (8, 1 << 16)):
+            if occ:
+                eng.begin_occ(2)
+                st = eng.push_fastq(data, nthreads=T, chunk_bytes=chunk, occ=True, TL=14, qmin=54)
+                got = eng.finish()
+                rc, want = ora.co_from_fastq(data, Q=54, M=2)
+            else:
+                eng.begin(capi.MK_MODE_KOC)
+                st = eng.push_fastq(data, nthreads=T, chunk_bytes=chunk)
+                got = eng.finish()
+                rc, want = ora.koc_from_fastq(data)
+            assert rc == 0 and st.records == len(seqs)
+            assert_same(got, want, "T=%d chunk=%d" % (T, chunk))
+    finally:
+        eng.close()
+
+
+def test_result_arrays_grow_and_options_are_refused_inside_a_sketch(capi, shufs, oracle_for):
+    """the dump writes into pinned host arrays; a sketch larger than they are is written a second time after they have
+    grown (MK_OPT_RESULT_CAP makes them tiny here); options cannot change between begin and finish"""
+    eng = capi.Engine(shufs("L0K6"), 0)
+    try:
+        eng.set_option(capi.MK_OPT_RESULT_CAP, 7)
+        rows = capi.synth_rows_host(21, 0, 300, 150, 160)
+        got = run_koc(capi, eng, rows, 160)
+        rc, want = oracle_for(shufs("L0K6")).koc_from_rows(rows, 160)
+        assert rc == 0 and len(want[0][0]) > 1000
+        assert_same(got, want)
+        got2 = run_koc(capi, eng, rows[: 160 * 5], 160)  # smaller result in the grown arrays
+        rc, want2 = oracle_for(shufs("L0K6")).koc_from_rows(rows[: 160 * 5], 160)
+        assert_same(got2, want2)
+        eng.begin(capi.MK_MODE_KOC)
+        with pytest.raises(capi.MkError):
+            eng.set_option(capi.MK_OPT_SPARSE, 1)
+        eng.finish()
+        with pytest.raises(capi.MkError):
+            eng.set_option(99, 1)
+        for sparse in (1, 0, -1):  # switching the bookkeeping between sketches keeps results exact
+            eng.set_option(capi.MK_OPT_SPARSE, sparse)
+            assert_same(run_koc(capi, eng, rows, 160), want, "sparse=%d" % sparse)
+    finally:
+        eng.close()
+
+
+def test_two_engines_on_two_host_threads(capi, shufs, oracle_for):
+    """one engine per host thread on the same device (the multi-GPU command line drives one engine per GPU this way): the
+    scan kernels' dynamic-LDS limits are kept per engine, nothing is shared between the threads"""
+    import threading
+    names = ["L3K11", "L3K10"]
+    rows = capi.synth_rows_host(31, 0, 60000, 150, 160)
+    out = {}
+
+    def work(name):
+        eng = capi.Engine(shufs(name), 0)
+        try:
+            for _ in range(3):
+                out[name] = run_koc(capi, eng, rows, 160, pushes=3)
+        finally:
+            eng.close()
+
+    th = [threading.Thread(target=work, args=(nm,)) for nm in names]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for nm in names:
+        rc, want = oracle_for(shufs(nm)).koc_from_rows(rows, 160)
+        assert rc == 0
+        assert_same(out[nm], want, nm)
