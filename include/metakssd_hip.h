@@ -171,6 +171,10 @@ int mk_engine_sync(mk_engine *e);
 /* pinned host memory for the caller's read batches (hipHostMalloc) */
 int mk_host_alloc(void **p, size_t bytes);
 int mk_host_free(void *p);
+/* pin memory the caller already owns (hipHostRegister / hipHostUnregister): row buffers, or the .shuf table before
+ * mk_engine_create (its upload then takes 1 ms instead of 20) */
+int mk_host_register(void *p, size_t bytes);
+int mk_host_unregister(void *p);
 
 /* ---- multi-GPU merge: distinct keys of this engine's shard ---------------------- */
 /* number of distinct keys currently held (runs the compaction kernel) */
@@ -233,11 +237,17 @@ typedef struct mk_fastq_opts {
   int32_t nthreads;     /* framer threads (1..256) */
   int32_t inflight;     /* pushes kept in flight before the oldest is waited for (1..8); ignored without sink.wait */
   uint64_t chunk_bytes; /* text bytes per framing job, 0 = 8 MiB */
+  int32_t drop_pages;   /* != 0 ONLY for a read-only FILE mapping the caller is done with afterwards: a framer gives the
+                           pages of its chunk back (madvise MADV_DONTNEED) when it has framed them, so that the page-table
+                           work of unmapping a multi-GB file is spread over the threads instead of landing in one munmap.
+                           Never set it for anonymous memory (the text would read back as zeros). */
+  int32_t reserved;
 } mk_fastq_opts;
 typedef struct mk_fastq_stats {
   uint64_t rows, records, chunks, chunks_discarded, serial_rows; /* discarded / serial: work redone on the calling thread */
   uint32_t threads;
   double t_setup_s, t_wait_frame_s, t_push_s, t_total_s; /* calling thread: buffer pool, waiting for framers, in push/wait */
+  double t_push_call_s, t_wait_call_s, t_push_call_max_s, t_first_push_call_s; /* t_push_s split: sink.push / sink.wait calls */
 } mk_fastq_stats;
 typedef struct mk_rows_sink {
   void *ctx;

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmetakssd_hip.so")
+LIB_PATH = os.environ.get("MK_LIBRARY") or os.path.join(_HERE, "lib", "libmetakssd_hip.so")  # MK_LIBRARY: an experiment build (make tuning)
 
 MK_OK = 0
 MK_ERR_ARG, MK_ERR_NO_DEVICE, MK_ERR_HIP, MK_ERR_CROWDED = -1, -2, -3, -4
@@ -64,13 +64,14 @@ class FastaStateC(C.Structure):
 
 class FastqOptsC(C.Structure):
     _fields_ = [("occ", C.c_int32), ("qmin", C.c_int32), ("TL", C.c_int32), ("nthreads", C.c_int32), ("inflight", C.c_int32),
-                ("chunk_bytes", C.c_uint64)]
+                ("chunk_bytes", C.c_uint64), ("drop_pages", C.c_int32), ("reserved", C.c_int32)]
 
 
 class FastqStatsC(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("records", C.c_uint64), ("chunks", C.c_uint64), ("chunks_discarded", C.c_uint64),
                 ("serial_rows", C.c_uint64), ("threads", C.c_uint32), ("t_setup_s", C.c_double), ("t_wait_frame_s", C.c_double),
-                ("t_push_s", C.c_double), ("t_total_s", C.c_double)]
+                ("t_push_s", C.c_double), ("t_total_s", C.c_double), ("t_push_call_s", C.c_double), ("t_wait_call_s", C.c_double),
+                ("t_push_call_max_s", C.c_double), ("t_first_push_call_s", C.c_double)]
 
 
 _PUSH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64))
@@ -116,6 +117,8 @@ def _load():
         "mk_engine_sync": [vp],
         "mk_host_alloc": [C.POINTER(vp), C.c_size_t],
         "mk_host_free": [vp],
+        "mk_host_register": [vp, C.c_size_t],
+        "mk_host_unregister": [vp],
         "mk_partial_count": [vp, C.POINTER(u64)],
         "mk_partial_export": [vp, vp, vp, vp, u64, C.POINTER(u64)],
         "mk_partial_import": [vp, vp, vp, vp, u64],
@@ -265,7 +268,7 @@ def fastq_frame_mt(buf, stride, nthreads, occ=False, TL=22, qmin=0, final=True, 
     return rows[: n.value * stride], n.value, nrec.value, used.value, rc
 
 
-def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2):
+def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2, drop_pages=False):
     """the whole-file FASTQ stream (mk_fastq_stream) into host memory: returns (list of (rows u8 array, stride, nrows,
     first ordinal) in push order, stats, rc).  Buffers come from malloc here; the engine-bound form is Engine.push_fastq."""
     b = np.frombuffer(buf, dtype=np.uint8)
@@ -287,7 +290,7 @@ def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first
     sink = RowsSinkC(None, _PUSH_FN(push), _WAIT_FN(wait), _ALLOC_FN(lambda ctx, n: libc.malloc(n)),
                      _RELEASE_FN(lambda ctx, p: libc.free(p)))
     keep["sink"] = sink
-    o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes)
+    o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 1 if drop_pages else 0, 0)
     st = FastqStatsC()
     rc = lib.mk_fastq_stream(b.ctypes.data if len(b) else None, len(b), C.byref(o), C.byref(sink), first_ordinal, C.byref(st))
     return pushes, st, rc
@@ -379,7 +382,7 @@ class Engine:
     def push_fastq(self, buf, nthreads=8, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2):
         """whole FASTQ text (bytes / numpy u8 / mmap) -> framed by host threads and pushed (mk_sketch_push_fastq); returns stats"""
         b = np.frombuffer(buf, dtype=np.uint8)
-        o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes)
+        o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 0, 0)
         st = FastqStatsC()
         _check(lib.mk_sketch_push_fastq(self.h, b.ctypes.data if len(b) else None, len(b), C.byref(o), first_ordinal, C.byref(st)), self.h)
         return st

@@ -120,6 +120,7 @@ typedef struct {
   pthread_mutex_t mu;
   pthread_cond_t cv;
   int done, rc, device;
+  int have_params;      /* the main thread has read the .shuf file: P may be used */
   const mk_params *P;
   mk_engine *eng;
   char err[512];
@@ -142,7 +143,8 @@ typedef struct {
   int begun, mode, min_occ;
   uint64_t chunk_bytes;
   mk_fastq_stats fq_stats;
-  double t_first_push, t_last_push;
+  double t_first_push, t_last_push, t_unmapped, t_begin_s;
+  int drop_pages, inflight;
 } ctx_t;
 
 #define CHECK(e, call)                                                  \
@@ -155,8 +157,12 @@ static void *engine_thread(void *arg) {
   engine_future *f = arg;
   int n = 0;
   f->t_start = now_s() - g_t0;
-  int rc = mk_device_count(&n); /* first HIP call of the process: runtime start-up */
+  int rc = mk_device_count(&n); /* first HIP call of the process: runtime start-up, while the main thread reads the .shuf file */
   f->t_hip_ready = now_s() - g_t0;
+  pthread_mutex_lock(&f->mu);
+  while (!f->have_params) pthread_cond_wait(&f->cv, &f->mu);
+  pthread_mutex_unlock(&f->mu);
+  if (rc == MK_OK && !f->P) rc = MK_ERR_ARG; /* the main thread gave up */
   if (rc == MK_OK) rc = mk_engine_create(f->P, f->device, &f->eng);
   if (rc != MK_OK) snprintf(f->err, sizeof f->err, "%s", mk_last_error(NULL));
   f->t_ready = now_s() - g_t0;
@@ -168,12 +174,20 @@ static void *engine_thread(void *arg) {
   return NULL;
 }
 
-static void engine_start(engine_future *f, const mk_params *P, int device) {
+static void engine_start(engine_future *f, int device) {
   memset(f, 0, sizeof *f);
-  f->P = P; f->device = device;
+  f->device = device;
   pthread_mutex_init(&f->mu, NULL);
   pthread_cond_init(&f->cv, NULL);
-  if (pthread_create(&f->th, NULL, engine_thread, f) != 0) { engine_thread(f); return; }
+  if (pthread_create(&f->th, NULL, engine_thread, f) != 0) die("cannot start a thread: %s", strerror(errno));
+}
+
+static void engine_params(engine_future *f, const mk_params *P) {
+  pthread_mutex_lock(&f->mu);
+  f->P = P;
+  f->have_params = 1;
+  pthread_cond_broadcast(&f->cv);
+  pthread_mutex_unlock(&f->mu);
 }
 
 static mk_engine *engine_get(ctx_t *c) {
@@ -191,8 +205,10 @@ static mk_engine *engine_get(ctx_t *c) {
 static mk_engine *sketch_engine(ctx_t *c) {
   mk_engine *e = engine_get(c);
   if (!c->begun) {
+    const double tb = now_s();
     if (c->mode == MK_MODE_OCC_SET) CHECK(e, mk_sketch_begin_occ(e, c->min_occ)); /* command_dist.c:385-386 */
     else CHECK(e, mk_sketch_begin(e, c->mode));
+    c->t_begin_s += now_s() - tb;
     c->begun = 1;
   }
   return e;
@@ -276,7 +292,8 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   mk_fastq_opts o;
   memset(&o, 0, sizeof o);
   o.occ = c->occ; o.qmin = c->qmin; o.TL = c->TL;
-  o.nthreads = c->nthreads; o.inflight = 3; o.chunk_bytes = c->chunk_bytes;
+  o.nthreads = c->nthreads; o.inflight = c->inflight; o.chunk_bytes = c->chunk_bytes;
+  o.drop_pages = c->drop_pages; /* a private read-only file mapping that is unmapped below */
   mk_rows_sink sink = {c, cli_sink_push, cli_sink_wait, cli_sink_alloc, cli_sink_release};
   mk_fastq_stats fs;
   const int rc = mk_fastq_stream(map, size, &o, &sink, c->next_ordinal, &fs);
@@ -292,6 +309,7 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   c->fq_stats = fs;
   c->t_last_push = now_s() - g_t0;
   munmap((void *)map, size);
+  c->t_unmapped = now_s() - g_t0;
   return 1;
 }
 
@@ -1318,6 +1336,7 @@ int main(int argc, char **argv) {
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 64) nthreads = 64;
   uint64_t chunk_bytes = 0;
+  int drop_pages = 1, inflight = 3, slow_exit = 0;
   int kmerocrs = 1, kmerqlty = 0; /* command_dist_wrapper.c:79-80 */
   const char *refpath = NULL, *skf = NULL;
   mk_dist_opts dopt = {0, 2, 0, 0, 1.0}; /* command_dist_wrapper.c:83-87 */
@@ -1340,6 +1359,9 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--quiet")) quiet = 1;
     else if (!strcmp(argv[i], "--timing")) timing = 1;
     else if (!strcmp(argv[i], "--chunk-mib") && i + 1 < argc) chunk_bytes = (uint64_t)atoi(argv[++i]) << 20;
+    else if (!strcmp(argv[i], "--inflight") && i + 1 < argc) inflight = atoi(argv[++i]); /* row buffers queued for copying */
+    else if (!strcmp(argv[i], "--slow-exit")) slow_exit = 1; /* destroy the engine and return from main() instead of _exit() */
+    else if (!strcmp(argv[i], "--keep-pages")) drop_pages = 0; /* measurement: leave all unmapping to the final munmap */
     else if (!strcmp(argv[i], "-r") && i + 1 < argc) refpath = argv[++i];
     else if (!strcmp(argv[i], "-M") && i + 1 < argc) dopt.metric = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-O") && i + 1 < argc) dopt.outfields = atoi(argv[++i]);
@@ -1382,6 +1404,10 @@ int main(int argc, char **argv) {
   if (files.n == 0) die("not valid raw seq format");
 
   const double t0 = g_t0;
+  /* HIP start-up and then the engine's tables on a helper thread; the main thread reads the .shuf file meanwhile and goes
+   * on to map and frame the input */
+  engine_future fut;
+  engine_start(&fut, device);
   mk_shuf sh;
   int rc = mk_shuf_read(shuf_path, &sh);
   if (rc != MK_OK) die("read_dim_shuffle_file(): cannot read %s (%d)", shuf_path, rc);
@@ -1391,13 +1417,16 @@ int main(int argc, char **argv) {
   if (!quiet) printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%u\thashlimit=%u\n", P.shuf_id, P.k, P.hashsize, P.hashlimit);
   const double t_shuf = now_s() - t0;
 
-  /* HIP start-up and the engine's tables on a helper thread; the main thread goes on to map and frame the input */
-  engine_future fut;
-  engine_start(&fut, &P, device);
+  /* the table pinned (it blocks until the helper thread's HIP start-up is through): the engine's upload of it is then
+   * 1 ms of DMA instead of 20 ms through staging buffers.  A failure only means the slower upload. */
+  (void)mk_host_register(sh.table, (size_t)sh.len * sizeof(int32_t));
+  engine_params(&fut, &P);
   ctx_t c;
   memset(&c, 0, sizeof c);
   c.fut = &fut;
   c.chunk_bytes = chunk_bytes;
+  c.drop_pages = drop_pages;
+  c.inflight = inflight;
 
   /* -A stays on only if every input is FASTQ: the reference switches it off when its file loop reaches the first
    * non-FASTQ input (command_dist.c:389-392) and then writes no combco.N.a at all (:427-431).  FASTQ files in front of
@@ -1490,19 +1519,25 @@ int main(int argc, char **argv) {
   const double t_written = now_s() - t0;
   if (!quiet) printf("sketched %llu rows from %d file(s) in %.3f s\n", (unsigned long long)c.nrows_total, files.n, t_written);
   if (timing) /* one JSON line for bench.py / tools: seconds since process start unless named *_s */
-    printf("{\"timing\": {\"shuf_read\": %.4f, \"hip_ready\": %.4f, \"engine_ready\": %.4f, \"first_push\": %.4f, \"last_push\": %.4f, "
-           "\"written\": %.4f, \"finish_s\": %.4f, \"rows\": %llu, \"threads\": %u, \"chunks\": %llu, \"chunks_discarded\": %llu, "
-           "\"serial_rows\": %llu, \"stream_setup_s\": %.4f, \"stream_wait_frame_s\": %.4f, \"stream_push_s\": %.4f, \"stream_total_s\": %.4f}}\n",
-           t_shuf, fut.t_hip_ready, fut.t_ready, c.t_first_push, c.t_last_push, t_written, t_finish, (unsigned long long)c.nrows_total,
+    printf("{\"timing\": {\"t0_abs\": %.6f, \"exit_abs\": %.6f, \"shuf_read\": %.4f, \"hip_ready\": %.4f, \"engine_ready\": %.4f, \"first_push\": %.4f, \"last_push\": %.4f, \"unmapped\": %.4f, "
+           "\"written\": %.4f, \"finish_s\": %.4f, \"begin_s\": %.4f, \"rows\": %llu, \"threads\": %u, \"chunks\": %llu, \"chunks_discarded\": %llu, "
+           "\"serial_rows\": %llu, \"stream_setup_s\": %.4f, \"stream_wait_frame_s\": %.4f, \"stream_push_s\": %.4f, \"stream_total_s\": %.4f, "
+           "\"push_call_s\": %.4f, \"wait_call_s\": %.4f, \"push_call_max_s\": %.4f, \"first_push_call_s\": %.4f}}\n",
+           g_t0, now_s(), t_shuf, fut.t_hip_ready, fut.t_ready, c.t_first_push, c.t_last_push, c.t_unmapped, t_written, t_finish, c.t_begin_s, (unsigned long long)c.nrows_total,
            c.fq_stats.threads, (unsigned long long)c.fq_stats.chunks, (unsigned long long)c.fq_stats.chunks_discarded,
            (unsigned long long)c.fq_stats.serial_rows, c.fq_stats.t_setup_s, c.fq_stats.t_wait_frame_s, c.fq_stats.t_push_s,
-           c.fq_stats.t_total_s);
+           c.fq_stats.t_total_s, c.fq_stats.t_push_call_s, c.fq_stats.t_wait_call_s, c.fq_stats.t_push_call_max_s,
+           c.fq_stats.t_first_push_call_s);
   if (stage2_after) {
     if (c.rows) mk_host_free(c.rows);
     free(c.io);
     mk_engine_destroy(engine_get(&c));
     mk_shuf_free(&sh);
     return run_stage2(outdir, outdir, device, quiet);
+  }
+  if (slow_exit) { /* profilers collect their data in exit handlers */
+    mk_engine_destroy(engine_get(&c));
+    return 0;
   }
   /* everything is on disk: leave without tearing down 2 GB of device tables and the pinned pools page by page */
   fflush(stdout);

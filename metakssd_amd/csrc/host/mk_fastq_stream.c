@@ -17,6 +17,7 @@
  * the true position, so the rows and their order are those of the serial framer on every input; only the speed depends
  * on the guesses.  Row ordinals are assigned when a buffer is pushed, so framing needs no global row index.
  */
+#define _GNU_SOURCE
 #include "metakssd_hip.h"
 #include "mk_host_internal.h"
 
@@ -24,6 +25,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <time.h>
 
 #define FS_NONE ((size_t)-1)
@@ -41,7 +43,7 @@ typedef struct {
   const uint8_t *text;
   size_t n, chunk;
   uint64_t nchunks;
-  int occ, qmin, TL;
+  int occ, qmin, TL, drop_pages;
   size_t buf_bytes;
   int nbufs;
   uint8_t **bufs;
@@ -147,9 +149,20 @@ static void *fs_worker(void *arg) {
     memset(&s, 0, sizeof s);
     s.buf = b;
     const size_t lo = (size_t)c * f->chunk, hi = lo + f->chunk < f->n ? lo + f->chunk : f->n;
+#ifdef MADV_POPULATE_READ
+    if (f->drop_pages) /* a file mapping: map the chunk's pages with one call instead of a fault per 64 KiB (Linux 5.14+; ignored elsewhere) */
+      (void)madvise((void *)(f->text + (lo & ~(size_t)4095)), hi - (lo & ~(size_t)4095), MADV_POPULATE_READ);
+#endif
     const size_t start = c == 0 ? 0 : fs_guess_start(f->text, f->n, lo, hi);
     if (start == FS_NONE) { s.start = s.end = FS_NONE; }
     else fs_frame_range(f, start, hi, c == 0, f->bufs[b], &s);
+    if (f->drop_pages && hi - lo > ((size_t)256 << 10)) {
+      /* this chunk's text is done with, except its first 128 KiB, which the previous chunk's last record may still reach
+       * into (a record is at most 4 lines of 20000 characters).  Dropping a page somebody still reads is harmless -- it
+       * faults back in from the page cache -- but costs time. */
+      const size_t a = (lo + ((size_t)128 << 10) + 4095) & ~(size_t)4095, b2 = hi & ~(size_t)4095;
+      if (b2 > a) madvise((void *)(f->text + a), b2 - a, MADV_DONTNEED);
+    }
 
     pthread_mutex_lock(&f->mu);
     if (s.nrows == 0) { f->freelist[f->nfree++] = b; s.buf = -1; pthread_cond_broadcast(&f->cv_buf); }
@@ -181,6 +194,7 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
   memset(&f, 0, sizeof f);
   f.text = text; f.n = n;
   f.occ = o->occ != 0; f.qmin = o->qmin; f.TL = o->TL;
+  f.drop_pages = o->drop_pages != 0 && ((uintptr_t)text & 4095u) == 0;
   f.chunk = o->chunk_bytes ? (size_t)o->chunk_bytes : (size_t)8 << 20;
   if (f.chunk < 4096) f.chunk = 4096;
   f.nchunks = n ? (n + f.chunk - 1) / f.chunk : 0;
@@ -269,12 +283,20 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
         uint64_t tok = 0;
         const double tp = fs_now();
         rc = sink->push(sink->ctx, f.bufs[s.buf], s.stride, s.nrows, ord, &tok);
+        {
+          const double d = fs_now() - tp;
+          if (stats.t_push_call_s == 0) stats.t_first_push_call_s = d;
+          stats.t_push_call_s += d;
+          if (d > stats.t_push_call_max_s) stats.t_push_call_max_s = d;
+        }
         if (rc != MK_OK) { fs_release(&f, s.buf); break; }
         ord += s.nrows; stats.rows += s.nrows; stats.records += s.nrec;
         if (!sink->wait) fs_release(&f, s.buf);
         else {
           if (nfifo == depth) { /* oldest push must be done before its buffer goes back to the framers */
+            const double tw2 = fs_now();
             rc = sink->wait(sink->ctx, fifo[0].token);
+            stats.t_wait_call_s += fs_now() - tw2;
             fs_release(&f, fifo[0].buf);
             memmove(fifo, fifo + 1, sizeof fifo[0] * (size_t)(--nfifo));
           }

@@ -19,6 +19,8 @@ static thread_local char g_create_error[512] = "";
 
 struct mk_evpair { hipEvent_t a, b; };
 #define MK_TICKETS 16
+#define MK_REGIONS 3
+#define MK_REGION_BYTES ((size_t)256 << 20)
 
 struct mk_engine {
   int device = 0;
@@ -53,6 +55,8 @@ struct mk_engine {
   unsigned long long *d_comp_totals = nullptr, *h_comp_totals = nullptr; /* [component] */
   unsigned long long *d_counters = nullptr; /* [0]=distinct, [1]=dump total, [2..3]=err flags (as u32) */
   unsigned long long *h_counters = nullptr; /* pinned mirror */
+  unsigned long long *h_setup = nullptr, *d_setup = nullptr; /* start-up: number of accepted substrings found on the device */
+  uint32_t setup_expect = 0;
   /* result arrays: pinned host memory that the dump kernels write directly (it is mapped into the device's address
    * space), so that a finish needs one host synchronisation and no separate result copy */
   uint32_t *h_ids = nullptr;
@@ -60,11 +64,18 @@ struct mk_engine {
   uint64_t h_cap = 0;
   std::vector<mk_component> comps;
 
-  /* host-push staging: two device buffers, copy stream ahead of the compute stream */
-  uint8_t *d_stage[2] = {nullptr, nullptr};
+  /* host-push staging: MK_REGIONS device regions filled by the copy stream; consecutive pushes (same stride, consecutive
+   * ordinals) land back to back in the open region and are scanned with ONE launch when it is full or at the next
+   * flush point -- a scan launch per 4 MiB push would cost more than copying it (launch + filter build + event hops) */
+  uint8_t *d_stage[MK_REGIONS] = {};
   size_t stage_bytes = 0;
-  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_scanned[2] = {nullptr, nullptr};
-  int stage_next = 0;
+  hipEvent_t ev_copied[MK_REGIONS] = {}, ev_scanned[MK_REGIONS] = {};
+  bool stage_two_streams[MK_REGIONS] = {}; /* the last scan of the region ran on another stream than the copies: ev_scanned is live */
+  int stage_cur = 0;
+  bool region_open = false;
+  size_t region_fill = 0;
+  uint32_t region_stride = 0;
+  uint64_t region_first_ord = 0, region_rows = 0;
   /* asynchronous pushes: ticket t is done when ev_ticket[t % MK_TICKETS] (recorded behind its last copy) has fired */
   hipEvent_t ev_ticket[MK_TICKETS] = {};
   uint64_t tickets_issued = 0;
@@ -121,6 +132,17 @@ extern "C" int mk_host_alloc(void **p, size_t bytes) {
   return r == hipSuccess ? MK_OK : mk_fail(nullptr, MK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(r));
 }
 extern "C" int mk_host_free(void *p) { return hipHostFree(p) == hipSuccess ? MK_OK : MK_ERR_HIP; }
+extern "C" int mk_host_register(void *p, size_t bytes) {
+  if (!p || !bytes) return MK_ERR_ARG;
+  hipError_t r = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  if (r != hipSuccess) { (void)hipGetLastError(); return mk_fail(nullptr, MK_ERR_HIP, "hipHostRegister(%zu): %s", bytes, hipGetErrorString(r)); }
+  return MK_OK;
+}
+extern "C" int mk_host_unregister(void *p) {
+  if (hipHostUnregister(p) == hipSuccess) return MK_OK;
+  (void)hipGetLastError();
+  return MK_ERR_HIP;
+}
 
 static mk_evpair mk_ev_get(mk_engine *e) {
   mk_evpair p{nullptr, nullptr};
@@ -130,10 +152,39 @@ static mk_evpair mk_ev_get(mk_engine *e) {
   return p;
 }
 
+/* the accept list and bitmap were made on the device from the uploaded table; a table that is not a permutation (the
+ * reference uses such a table as it is) takes the general host pass */
+static int mk_setup_finish(mk_engine *e) {
+  const mk_params *p = &e->P;
+  const uint32_t found = (uint32_t)(e->h_setup[0] & 0xffffffffu);
+  if (found == e->setup_expect) { e->n_accept = found; return MK_OK; }
+  const uint64_t L = p->shuf_len;
+  const uint32_t dbits = 4u * (uint32_t)p->subk;
+  std::vector<uint32_t> acc;
+  std::vector<uint32_t> bits((size_t)((L + 31) / 32), 0u);
+  for (uint64_t d = 0; d < L; d++) {
+    int32_t v = p->shuf_table[d];
+    if (v >= p->dim_start && v < p->dim_end) {
+      bits[d >> 5] |= 1u << (d & 31u);
+      acc.push_back((uint32_t)d);
+      uint32_t n = ~(uint32_t)d, rr = 0; /* reverse the 2-bit groups of the complement within dbits */
+      for (uint32_t i = 0; i < dbits; i += 2) rr |= ((n >> i) & 3u) << (dbits - 2u - i);
+      acc.push_back(rr);
+    }
+  }
+  e->n_accept = (uint32_t)acc.size();
+  hipFree(e->d_accept); e->d_accept = nullptr;
+  MK_HIP(e, hipMalloc(&e->d_accept, (acc.size() + 1) * sizeof(uint32_t)));
+  if (!acc.empty()) MK_HIP(e, hipMemcpy(e->d_accept, acc.data(), acc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  MK_HIP(e, hipMemcpy(e->d_accept_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return MK_OK;
+}
+
 extern "C" int mk_engine_destroy(mk_engine *e) {
   if (!e) return MK_ERR_ARG;
   hipSetDevice(e->device);
   hipDeviceSynchronize();
+  hipFree(e->d_setup);
   hipFree(e->d_cand); hipFree(e->d_cand_count);
   hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_accept_bits); hipFree(e->d_tab); hipFree(e->d_slot);
   hipFree(e->d_dirty_acc); hipFree(e->d_dirty_slot); hipFree(e->d_list_acc); hipFree(e->d_list_slot); hipFree(e->d_nlist);
@@ -144,7 +195,7 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   if (e->h_counters) hipHostFree(e->h_counters);
   if (e->h_ids) hipHostFree(e->h_ids);
   if (e->h_cnt) hipHostFree(e->h_cnt);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < MK_REGIONS; i++) {
     hipFree(e->d_stage[i]);
     if (e->ev_copied[i]) hipEventDestroy(e->ev_copied[i]);
     if (e->ev_scanned[i]) hipEventDestroy(e->ev_scanned[i]);
@@ -152,7 +203,6 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   for (auto *v : {&e->ev_scan, &e->ev_resolve, &e->ev_clear, &e->ev_finish, &e->ev_pool})
     for (auto &p : *v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   if (e->own_stream) hipStreamDestroy(e->own_stream);
-  if (e->copy_stream) hipStreamDestroy(e->copy_stream);
   delete e;
   return MK_OK;
 }
@@ -191,15 +241,30 @@ static int mk_config_cand(mk_engine *e, uint32_t cap) {
   return MK_OK;
 }
 
+#ifdef MK_TUNING
+#include <time.h>
+static double mk_tick_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+#define MK_TICK(label) do { if (getenv("MK_DEBUG")) { double n_ = mk_tick_now(); fprintf(stderr, "[engine create] %-22s %.4f s\n", label, n_ - tick_); tick_ = n_; } } while (0)
+#else
+#define MK_TICK(label) do { } while (0)
+#endif
+
 static int mk_engine_init(mk_engine *e, const mk_params *p) {
+#ifdef MK_TUNING
+  double tick_ = mk_tick_now();
+#endif
   MK_HIP(e, hipSetDevice(e->device));
-  hipDeviceProp_t prop;
-  MK_HIP(e, hipGetDeviceProperties(&prop, e->device));
-  e->num_cu = prop.multiProcessorCount;
+  MK_HIP(e, hipDeviceGetAttribute(&e->num_cu, hipDeviceAttributeMultiprocessorCount, e->device)); /* hipGetDeviceProperties takes 30 ms */
+  MK_TICK("device");
   MK_HIP(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
-  MK_HIP(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  MK_TICK("stream 1");
+  /* host-to-device copies ride on the engine's own stream: a second stream means a second hardware queue (30-60 ms of
+   * start-up on this runtime), and the scan of a 128 MiB staging region (45 us) is nothing next to copying it (2.3 ms),
+   * so there is no overlap worth a queue.  With a caller stream (mk_engine_set_stream) the scans run there and the copies
+   * stay here, ordered by events. */
+  e->copy_stream = e->own_stream;
   e->stream = e->own_stream;
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < MK_REGIONS; i++) {
     MK_HIP(e, hipEventCreateWithFlags(&e->ev_copied[i], hipEventDisableTiming));
     MK_HIP(e, hipEventCreateWithFlags(&e->ev_scanned[i], hipEventDisableTiming));
   }
@@ -217,28 +282,36 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
 
   /* .shuf table + the filter list B = A u revcomp(A), A = accepted inner substrings (iseq2comem.c:693-694).
    * The inner substring (2*subk bases) sits in the middle of the k-mer, so the reverse-complement k-mer's
-   * inner substring is the reverse complement of the forward one: see mk_kernels.hip.h, "LDS filter". */
+   * inner substring is the reverse complement of the forward one: see mk_kernels.hip.h, "LDS filter".
+   * The table goes up asynchronously out of the caller's memory (registered for the duration of the copy) and the list
+   * and the accept bitmap are made from it on the device: 64 MiB through a pageable copy plus a host pass over 16 M
+   * entries cost 50 ms of every start-up. */
   const uint64_t L = p->shuf_len;
-  std::vector<uint32_t> acc;
-  std::vector<uint32_t> bits((size_t)((L + 31) / 32), 0u);
   const uint32_t dbits = 4u * (uint32_t)p->subk;
-  for (uint64_t d = 0; d < L; d++) {
-    int32_t v = p->shuf_table[d];
-    if (v >= p->dim_start && v < p->dim_end) {
-      bits[d >> 5] |= 1u << (d & 31u);
-      acc.push_back((uint32_t)d);
-      uint32_t n = ~(uint32_t)d, r = 0; /* reverse the 2-bit groups of the complement within dbits */
-      for (uint32_t i = 0; i < dbits; i += 2) r |= ((n >> i) & 3u) << (dbits - 2u - i);
-      acc.push_back(r);
-    }
-  }
-  e->n_accept = (uint32_t)acc.size();
+  const size_t bit_words = (size_t)((L + 31) / 32);
+  const uint32_t expect = 2u * (uint32_t)(p->dim_end - p->dim_start); /* a permutation has exactly this many */
   MK_HIP(e, hipMalloc(&e->d_shuf, L * sizeof(int32_t)));
-  MK_HIP(e, hipMemcpy(e->d_shuf, p->shuf_table, L * sizeof(int32_t), hipMemcpyHostToDevice));
-  MK_HIP(e, hipMalloc(&e->d_accept, (acc.size() + 1) * sizeof(uint32_t)));
-  if (!acc.empty()) MK_HIP(e, hipMemcpy(e->d_accept, acc.data(), acc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  MK_HIP(e, hipMalloc(&e->d_accept_bits, bits.size() * sizeof(uint32_t)));
-  MK_HIP(e, hipMemcpy(e->d_accept_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  MK_HIP(e, hipMalloc(&e->d_accept_bits, bit_words * sizeof(uint32_t)));
+  MK_HIP(e, hipMalloc(&e->d_accept, ((size_t)expect + 2) * sizeof(uint32_t)));
+  MK_HIP(e, hipMalloc(&e->d_counters, 8 * sizeof(unsigned long long)));
+  MK_HIP(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->own_stream));
+  MK_HIP(e, hipMalloc(&e->d_setup, sizeof(unsigned long long)));
+  MK_HIP(e, hipHostMalloc((void **)&e->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault));
+  e->h_setup = e->h_counters + 8;
+  MK_TICK("events + first allocs");
+  /* 1.2 ms when the caller has pinned the table (mk_host_register), about 20 ms through the runtime's staging buffers
+   * when it is ordinary memory; either way the table is free again when mk_engine_create returns */
+  MK_HIP(e, hipMemcpyAsync(e->d_shuf, p->shuf_table, L * sizeof(int32_t), hipMemcpyHostToDevice, e->own_stream));
+  MK_HIP(e, hipMemsetAsync(e->d_accept_bits, 0, bit_words * sizeof(uint32_t), e->own_stream));
+  MK_HIP(e, hipMemsetAsync(e->d_setup, 0, sizeof(unsigned long long), e->own_stream));
+  hipLaunchKernelGGL(mk_accept_build_kernel, dim3((unsigned)e->num_cu * 8u), dim3(256), 0, e->own_stream, (const int32_t *)e->d_shuf, L,
+                     p->dim_start, p->dim_end, dbits, e->d_accept, expect, (uint32_t *)e->d_setup, e->d_accept_bits);
+  MK_HIP(e, hipGetLastError());
+  MK_HIP(e, hipMemcpyAsync(e->h_setup, e->d_setup, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->own_stream));
+  MK_HIP(e, hipStreamSynchronize(e->own_stream));
+  e->setup_expect = expect;
+  { int rc = mk_setup_finish(e); if (rc) return rc; }
+  MK_TICK("shuf upload + accept");
   /* LDS filter: 2^bm_bits words of 32 bits indexed by the inner substring's bits 10.. (at most 64 KiB) */
   {
     int wb = 4 * p->subk - 10;
@@ -263,13 +336,12 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   MK_HIP(e, hipMalloc(&e->d_chunk, (size_t)e->nchunks * (size_t)p->component_num * sizeof(uint32_t)));
   MK_HIP(e, hipMalloc(&e->d_comp_totals, MK_MAX_COMP * sizeof(unsigned long long)));
   MK_HIP(e, hipHostMalloc((void **)&e->h_comp_totals, MK_MAX_COMP * sizeof(unsigned long long), hipHostMallocDefault));
-  MK_HIP(e, hipMalloc(&e->d_counters, 8 * sizeof(unsigned long long)));
-  MK_HIP(e, hipMemset(e->d_counters, 0, 8 * sizeof(unsigned long long)));
-  MK_HIP(e, hipHostMalloc((void **)&e->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   e->tab.err = (uint32_t *)(e->d_counters + 2);
   e->comps.resize((size_t)p->component_num);
   e->cand_slots = (uint32_t)e->num_cu * 16u; /* at most 16 waves per workgroup, one workgroup per CU */
+  MK_TICK("tables");
   { int rc = mk_config_cand(e, 8192u); if (rc) return rc; }
+  MK_TICK("candidate buffers");
   for (int i = 0; i < MK_TICKETS; i++) MK_HIP(e, hipEventCreateWithFlags(&e->ev_ticket[i], hipEventDisableTiming));
 #ifdef MK_TUNING /* experiment knobs: compiled only into tools/ builds (make tuning), never into the shipped library */
   if (const char *t = getenv("MK_SCAN_THREADS")) { int v = atoi(t); if (v == 512 || v == 768 || v == 1024) e->tune_threads = v; }
@@ -301,6 +373,8 @@ extern "C" int mk_engine_create(const mk_params *p, int device, mk_engine **out)
   return MK_OK;
 }
 
+static int mk_flush_region(mk_engine *e);
+
 extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
   if (!e) return MK_ERR_ARG;
   if (e->begun) return mk_fail(e, MK_ERR_STATE, "mk_engine_set_option inside a sketch (between begin and finish)");
@@ -329,6 +403,11 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
 
 extern "C" int mk_engine_set_stream(mk_engine *e, void *hip_stream) {
   if (!e) return MK_ERR_ARG;
+  if (e->region_open) { /* staged rows are scanned on the stream they were pushed for */
+    MK_HIP(e, hipSetDevice(e->device));
+    int rc = mk_flush_region(e);
+    if (rc) return rc;
+  }
   /* NULL is a real stream (HIP's default stream, which is what torch.cuda.current_stream() usually is): it must
    * not mean "keep the engine's own stream", or caller-side ordering silently disappears */
   e->stream = (hipStream_t)hip_stream;
@@ -336,6 +415,11 @@ extern "C" int mk_engine_set_stream(mk_engine *e, void *hip_stream) {
 }
 extern "C" int mk_engine_use_own_stream(mk_engine *e) {
   if (!e) return MK_ERR_ARG;
+  if (e->region_open) {
+    MK_HIP(e, hipSetDevice(e->device));
+    int rc = mk_flush_region(e);
+    if (rc) return rc;
+  }
   e->stream = e->own_stream;
   return MK_OK;
 }
@@ -343,7 +427,8 @@ extern "C" int mk_engine_use_own_stream(mk_engine *e) {
 extern "C" int mk_engine_sync(mk_engine *e) {
   if (!e) return MK_ERR_ARG;
   MK_HIP(e, hipSetDevice(e->device));
-  MK_HIP(e, hipStreamSynchronize(e->copy_stream));
+  { int rc = mk_flush_region(e); if (rc) return rc; }
+  if (e->copy_stream != e->stream) MK_HIP(e, hipStreamSynchronize(e->copy_stream));
   MK_HIP(e, hipStreamSynchronize(e->stream));
   return MK_OK;
 }
@@ -416,6 +501,7 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   }
   MK_HIP(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->stream));
   if (e->profiling) { MK_HIP(e, hipEventRecord(ev.b, e->stream)); e->ev_clear.push_back(ev); }
+  e->region_open = false; /* rows staged for a sketch that was never finished are dropped with it */
   e->mode = mode;
   e->min_occ = 1;
   e->begun = true;
@@ -572,6 +658,25 @@ extern "C" int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev
   return MK_OK;
 }
 
+/* scan what has been copied into the open staging region (one launch), and close it */
+static int mk_flush_region(mk_engine *e) {
+  if (!e->region_open) return MK_OK;
+  const int b = e->stage_cur;
+  e->region_open = false;
+  e->stage_cur = (b + 1) % MK_REGIONS;
+  if (e->region_rows == 0) return MK_OK;
+  const bool two_streams = e->stream != e->copy_stream; /* same stream: program order is the dependency */
+  if (two_streams) {
+    MK_HIP(e, hipEventRecord(e->ev_copied[b], e->copy_stream));
+    MK_HIP(e, hipStreamWaitEvent(e->stream, e->ev_copied[b], 0));
+  }
+  int rc = mk_launch_scan(e, e->d_stage[b], e->region_stride, e->region_rows, e->region_first_ord);
+  if (rc) return rc;
+  if (two_streams) MK_HIP(e, hipEventRecord(e->ev_scanned[b], e->stream));
+  e->stage_two_streams[b] = two_streams;
+  return MK_OK;
+}
+
 extern "C" int mk_sketch_push_reads_async(mk_engine *e, const uint8_t *rows, uint32_t stride, uint64_t nreads,
                                           uint64_t first_read_ordinal, uint64_t *ticket) {
   int rc = mk_check_push(e, rows, stride);
@@ -579,26 +684,46 @@ extern "C" int mk_sketch_push_reads_async(mk_engine *e, const uint8_t *rows, uin
   if (!ticket) return MK_ERR_ARG;
   MK_HIP(e, hipSetDevice(e->device));
   if ((first_read_ordinal + nreads) >> 51) return mk_fail(e, MK_ERR_ARG, "read ordinal too large");
-  const size_t chunk_max = (size_t)64 << 20;
+#ifdef MK_TUNING
+  double tick_ = mk_tick_now();
+  const bool first_push_ = !e->d_stage[0];
+#endif
   if (!e->d_stage[0]) {
-    e->stage_bytes = chunk_max;
-    for (int i = 0; i < 2; i++) MK_HIP(e, hipMalloc(&e->d_stage[i], e->stage_bytes));
+    e->stage_bytes = MK_REGION_BYTES;
+    for (int i = 0; i < MK_REGIONS; i++) MK_HIP(e, hipMalloc(&e->d_stage[i], e->stage_bytes));
   }
-  uint64_t rows_per_chunk = e->stage_bytes / stride;
-  rows_per_chunk &= ~(uint64_t)63;
+#ifdef MK_TUNING
+  if (first_push_) MK_TICK("push1: staging alloc");
+#endif
   for (uint64_t done = 0; done < nreads;) {
-    const uint64_t n = nreads - done < rows_per_chunk ? nreads - done : rows_per_chunk;
-    const int b = e->stage_next;
-    e->stage_next ^= 1;
-    /* copy stream: wait until the scan that last read this buffer is finished, then H2D */
-    MK_HIP(e, hipStreamWaitEvent(e->copy_stream, e->ev_scanned[b], 0));
-    MK_HIP(e, hipMemcpyAsync(e->d_stage[b], rows + done * stride, n * stride, hipMemcpyHostToDevice, e->copy_stream));
-    MK_HIP(e, hipEventRecord(e->ev_copied[b], e->copy_stream));
-    MK_HIP(e, hipStreamWaitEvent(e->stream, e->ev_copied[b], 0));
-    rc = mk_launch_scan(e, e->d_stage[b], stride, n, first_read_ordinal + done);
-    if (rc) return rc;
-    MK_HIP(e, hipEventRecord(e->ev_scanned[b], e->stream));
+    const uint64_t ord = first_read_ordinal + done;
+    /* rows that do not continue the open region (another stride, a gap in the ordinals) start a new one */
+    if (e->region_open && (stride != e->region_stride || ord != e->region_first_ord + e->region_rows ||
+                           e->region_fill + stride > e->stage_bytes)) {
+      rc = mk_flush_region(e);
+      if (rc) return rc;
+    }
+    if (!e->region_open) {
+      /* copy stream: the scan that last read this region must be finished before it is overwritten */
+      if (e->stage_two_streams[e->stage_cur]) MK_HIP(e, hipStreamWaitEvent(e->copy_stream, e->ev_scanned[e->stage_cur], 0));
+      e->region_open = true;
+      e->region_fill = 0; e->region_rows = 0;
+      e->region_stride = stride; e->region_first_ord = ord;
+    }
+    const uint64_t room = (e->stage_bytes - e->region_fill) / stride;
+    const uint64_t n = nreads - done < room ? nreads - done : room;
+    MK_HIP(e, hipMemcpyAsync(e->d_stage[e->stage_cur] + e->region_fill, rows + done * stride, n * stride, hipMemcpyHostToDevice,
+                             e->copy_stream));
+#ifdef MK_TUNING
+    if (first_push_ && done == 0) MK_TICK("push1: first memcpyAsync");
+#endif
+    e->region_fill += n * stride;
+    e->region_rows += n;
     done += n;
+    if (e->region_fill + stride > e->stage_bytes) { /* full: scan it while the next one fills */
+      rc = mk_flush_region(e);
+      if (rc) return rc;
+    }
   }
   /* the ticket fires when the last copy out of `rows` is done.  A ring slot is reused only after its previous ticket
    * has been waited for here, so a caller may keep up to MK_TICKETS pushes in flight without ever waiting itself. */
@@ -606,6 +731,9 @@ extern "C" int mk_sketch_push_reads_async(mk_engine *e, const uint8_t *rows, uin
   hipEvent_t ev = e->ev_ticket[t % MK_TICKETS];
   if (t >= MK_TICKETS) MK_HIP(e, hipEventSynchronize(ev));
   MK_HIP(e, hipEventRecord(ev, e->copy_stream));
+#ifdef MK_TUNING
+  if (first_push_) MK_TICK("push1: ticket record");
+#endif
   e->tickets_issued = t + 1;
   *ticket = t;
   return MK_OK;
@@ -631,6 +759,7 @@ extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t 
 /* ---- compaction / partials --------------------------------------------------------------------------- */
 /* table -> distinct-key list on the device; the number of keys lands in d_counters[0].  No host synchronisation. */
 static int mk_compact_launch(mk_engine *e) {
+  { int rc = mk_flush_region(e); if (rc) return rc; } /* rows copied but not scanned yet */
   MK_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(unsigned long long), e->stream));
   /* co[n]=0 stays "empty" in the FASTA set flavours (iseq2comem.c:300-302); the FASTQ slot words carry a count
    * field, so key 0 is an ordinary key there (:398-399, :704-705) */
@@ -668,7 +797,7 @@ static int mk_check_counters(mk_engine *e) {
 
 /* compaction with the key count brought to the host (the multi-GPU export needs it there) */
 static int mk_compact(mk_engine *e) {
-  if (e->compacted) return MK_OK;
+  if (e->compacted && !e->region_open) return MK_OK;
   int rc = mk_compact_launch(e);
   if (rc) return rc;
   MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
@@ -782,7 +911,7 @@ extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   int rc = MK_OK;
-  if (!e->compacted) rc = mk_compact_launch(e);
+  if (!e->compacted || e->region_open) rc = mk_compact_launch(e);
   if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
   const uint32_t S = e->kp.S;
   const int C = e->P.component_num;

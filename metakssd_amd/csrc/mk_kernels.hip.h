@@ -1118,6 +1118,26 @@ __global__ void __launch_bounds__(256) mk_dumpc_write_kernel(mk_dump_args a, con
   }
 }
 
+/* ---- engine start-up: the accepted inner substrings of a .shuf table (iseq2comem.c:693-694) as the scan filter's source
+ * list {d, revcomp(d)} and as a bitmap, straight from the uploaded table */
+__global__ void __launch_bounds__(256) mk_accept_build_kernel(const int32_t *shuf, uint64_t L, int32_t dim_start, int32_t dim_end,
+                                                              uint32_t dbits, uint32_t *accept, uint32_t cap, uint32_t *count,
+                                                              uint32_t *bits) {
+  for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < L; d += (uint64_t)gridDim.x * blockDim.x) {
+    const int32_t v = shuf[d];
+    if (v >= dim_start && v < dim_end) {
+      atomicOr(&bits[d >> 5], 1u << (d & 31u));
+      const uint32_t at = atomicAdd(count, 2u);
+      if (at + 2u <= cap) {
+        uint32_t n = ~(uint32_t)d, r = 0; /* reverse the 2-bit groups of the complement within dbits */
+        for (uint32_t i = 0; i < dbits; i += 2) r |= ((n >> i) & 3u) << (dbits - 2u - i);
+        accept[at] = (uint32_t)d;
+        accept[at + 1] = r;
+      }
+    }
+  }
+}
+
 /* ---- synthetic reads: 16 bytes of one row per thread ------------------------------------------------- */
 __global__ void __launch_bounds__(256) mk_synth_kernel(uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len,
                                                        uint32_t stride, uint8_t *rows) {

@@ -153,3 +153,25 @@ def test_threaded_synthetic_fastq_writer_equals_serial(capi, tmp_path):
         for T in (1, 3, 16):
             assert capi.lib.mk_synth_fastq_write_mt(b.encode(), 7, first, n, 150, T) == 0
             assert open(a, "rb").read() == open(b, "rb").read(), (first, n, T)
+
+
+def test_stream_over_a_file_mapping_with_pages_dropped_behind_the_framers(capi, tmp_path):
+    """the command line's configuration: the text is a private read-only mapping of the file and every framer hands its
+    chunk's pages back (MADV_DONTNEED) as it goes; re-reads fault back in from the page cache, the rows stay the same"""
+    import mmap
+    rs = np.random.RandomState(23)
+    seqs = ui.ragged_reads(rs, 20000)
+    data = ui.fastq_bytes(seqs)
+    path = tmp_path / "in.fq"
+    path.write_bytes(data)
+    want, nrec, rc = serial_rows(capi, data, False)
+    with open(path, "rb") as f:
+        mm = mmap.mmap(f.fileno(), 0, flags=mmap.MAP_PRIVATE, prot=mmap.PROT_READ)
+        for T, chunk in ((4, 1 << 18), (8, 1 << 20), (2, 300000)):
+            pushes, st, rc = capi.fastq_stream(mm, nthreads=T, chunk_bytes=chunk, drop_pages=True)
+            got = []
+            for rows, stride, n, ord0 in pushes:
+                got += seqs_of_rows(rows, stride, n)
+            assert rc == 0 and got == want, (T, chunk)
+        assert bytes(mm[:100]) == data[:100]  # a file mapping reads back the file, not zeros
+        mm.close()

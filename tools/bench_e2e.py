@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--chunks", default="8")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--variants", default="", help="';'-separated extra CLI flag sets to run each configuration with, e.g. ';--keep-pages'")
     a = ap.parse_args()
     from metakssd_amd import capi
     cores = os.cpu_count() or 1
@@ -35,24 +36,29 @@ def main():
         print("wrote %.2f GB in %.1f s (%d cores)" % (os.path.getsize(fq) / 1e9, time.perf_counter() - t0, cores), flush=True)
         cli = os.path.join(ROOT, "metakssd_amd", "bin", "metakssd")
         ref_hash = None
-        for chunk in [int(x) for x in a.chunks.split(",")]:
-            for T in [int(x) for x in a.threads.split(",")]:
+        combos = [(chunk, T, v) for v in a.variants.split(";") for chunk in [int(x) for x in a.chunks.split(",")]
+                  for T in [int(x) for x in a.threads.split(",")]]
+        for chunk, T, variant in combos:
+            if True:
                 for rep in range(a.reps):
                     out = os.path.join(tmp, "out")
                     shutil.rmtree(out, ignore_errors=True)
+                    m0 = time.monotonic()
                     t0 = time.perf_counter()
                     r = subprocess.run([cli, "dist", "-L", sp, "-A", "-o", out, "--quiet", "--timing", "-p", str(T), "--chunk-mib",
-                                        str(chunk), fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                                        str(chunk)] + variant.split() + [fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                     wall = time.perf_counter() - t0
+                    m1 = time.monotonic()
                     tm = {}
                     for ln in r.stdout.decode(errors="replace").splitlines():
                         if ln.startswith('{"timing"'):
                             tm = json.loads(ln)["timing"]
                     h = subprocess.run("cat %s/combco.0 %s/combco.0.a | sha256sum" % (out, out), shell=True, stdout=subprocess.PIPE).stdout.decode().split()[0]
                     ref_hash = ref_hash or h
-                    rec = {"p": T, "chunk_mib": chunk, "rep": rep, "rc": r.returncode, "wall_s": round(wall, 4),
+                    rec = {"p": T, "chunk_mib": chunk, "flags": variant, "rep": rep, "rc": r.returncode, "wall_s": round(wall, 4),
                            "gbases_s_wall": round(a.reads * 150 / wall / 1e9, 2),
                            "gbases_s_minus_init": round(a.reads * 150 / max(wall - tm.get("hip_ready", 0), 1e-9) / 1e9, 2),
+                           "spawn_s": round(tm.get("t0_abs", m0) - m0, 4), "exit_s": round(m1 - tm.get("exit_abs", m1), 4),
                            "same_sketch": h == ref_hash, "timing": tm}
                     if r.returncode:
                         rec["stderr"] = r.stderr.decode(errors="replace")[-300:]

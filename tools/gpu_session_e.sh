@@ -1,0 +1,31 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+python - <<'PY' > gpurun_out/e_push_timing.log 2>&1
+import os, subprocess, sys, json
+sys.path.insert(0, '.')
+from metakssd_amd import capi
+capi.Shuf.generate(11, 6, 3, 11).write('/dev/shm/L3K11.shuf')
+capi.lib.mk_synth_fastq_write_mt(b'/dev/shm/big.fq', 20261002, 0, 50000000, 150, 64)
+def run(tag, env_extra, args, pre=[], reps=2):
+    env = dict(os.environ, **env_extra)
+    for i in range(reps):
+        r = subprocess.run(pre + ['metakssd_amd/bin/metakssd', 'dist', '-L', '/dev/shm/L3K11.shuf', '-A', '-o', '/dev/shm/o', '--quiet', '--timing'] + args + ['/dev/shm/big.fq'], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        for ln in r.stdout.decode().splitlines():
+            if ln.startswith('{"timing"'):
+                t = json.loads(ln)['timing']
+                print(tag, "hip %.3f eng %.3f first %.3f last %.3f written %.3f | waitf %.3f push_call %.3f wait_call %.3f first_push %.4f | H2D %.1f GB/s | written-hip %.3f -> %.1f Gbases/s" % (t['hip_ready'], t['engine_ready'], t['first_push'], t['last_push'], t['written'], t['stream_wait_frame_s'], t['push_call_s'], t['wait_call_s'], t['first_push_call_s'], 8.0 / (t['last_push'] - t['first_push']), t['written'] - t['hip_ready'], 7.5 / (t['written'] - t['hip_ready'])), flush=True)
+            elif 'engine create' in ln: print('   ', ln)
+run('warm          ', {}, ['-p', '16'], reps=1)
+run('p16 c8        ', {}, ['-p', '16'])
+run('p16 c8 ticks  ', {'LD_LIBRARY_PATH': os.path.abspath('metakssd_amd/lib_tuning'), 'MK_DEBUG': '1'}, ['-p', '16'], reps=1)
+run('p24 c8        ', {}, ['-p', '24'])
+run('p32 c8        ', {}, ['-p', '32'])
+run('p16 c4        ', {}, ['-p', '16', '--chunk-mib', '4'])
+run('p16 c8 nosdma ', {'HSA_ENABLE_SDMA': '0'}, ['-p', '16'])
+run('p16 node0     ', {}, ['-p', '16'], pre=['taskset', '-c', '0-63,128-191'])
+run('p16 node1     ', {}, ['-p', '16'], pre=['taskset', '-c', '64-127,192-255'])
+run('p32 node0     ', {}, ['-p', '32'], pre=['taskset', '-c', '0-63,128-191'])
+PY
+cat gpurun_out/e_push_timing.log
+rm -rf /dev/shm/L3K11.shuf /dev/shm/big.fq /dev/shm/o
