@@ -137,8 +137,10 @@ int mk_engine_destroy(mk_engine *e);
  *   MK_OPT_CAND_CAP records per scan wave in the candidate append buffers (default 8192; 0 = resolve every filter hit inline)
  *   MK_OPT_RESULT_CAP entries the pinned result arrays hold now (default: 2 M at the first finish; a larger sketch grows them
  *                   and writes its result a second time)
+ *   MK_OPT_DIRECT_HOST 0 / 1: host pushes of rows in pinned memory are scanned in place over PCIe (one scan launch per push,
+ *                   no staging copy) instead of being copied into staging regions first (default 0)
  * Results are bit-identical for every setting; the tests run both. */
-enum { MK_OPT_SPARSE = 1, MK_OPT_CAND_CAP = 2, MK_OPT_RESULT_CAP = 3 };
+enum { MK_OPT_SPARSE = 1, MK_OPT_CAND_CAP = 2, MK_OPT_RESULT_CAP = 3, MK_OPT_DIRECT_HOST = 4 };
 int mk_engine_set_option(mk_engine *e, int option, int64_t value);
 int mk_engine_set_stream(mk_engine *e, void *hip_stream);
 int mk_engine_use_own_stream(mk_engine *e);
@@ -175,6 +177,10 @@ int mk_host_free(void *p);
  * mk_engine_create (its upload then takes 1 ms instead of 20) */
 int mk_host_register(void *p, size_t bytes);
 int mk_host_unregister(void *p);
+/* a large pinned block the quick way (anonymous mapping touched by several threads, then one hipHostRegister): a quarter of
+ * mk_host_alloc's time for hundreds of MiB; free with the same `bytes` */
+int mk_host_arena_alloc(void **p, size_t bytes);
+int mk_host_arena_free(void *p, size_t bytes);
 
 /* ---- multi-GPU merge: distinct keys of this engine's shard ---------------------- */
 /* number of distinct keys currently held (runs the compaction kernel) */
@@ -236,7 +242,7 @@ typedef struct mk_fastq_opts {
   int32_t qmin, TL;     /* occ only: -Q, k-mer length in bases */
   int32_t nthreads;     /* framer threads (1..256) */
   int32_t inflight;     /* pushes kept in flight before the oldest is waited for (1..8); ignored without sink.wait */
-  uint64_t chunk_bytes; /* text bytes per framing job, 0 = 8 MiB */
+  uint64_t chunk_bytes; /* text bytes per framing job = one row buffer = one host-to-device copy, 0 = 32 MiB */
   int32_t drop_pages;   /* != 0 ONLY for a read-only FILE mapping the caller is done with afterwards: a framer gives the
                            pages of its chunk back (madvise MADV_DONTNEED) when it has framed them, so that the page-table
                            work of unmapping a multi-GB file is spread over the threads instead of landing in one munmap.
@@ -253,8 +259,8 @@ typedef struct mk_rows_sink {
   void *ctx;
   int (*push)(void *ctx, const uint8_t *rows, uint32_t stride, uint64_t nrows, uint64_t first_row_ordinal, uint64_t *token);
   int (*wait)(void *ctx, uint64_t token);       /* NULL: push is synchronous, the buffer is free when it returns */
-  uint8_t *(*alloc)(void *ctx, size_t bytes);   /* row buffers (pinned for an engine) */
-  void (*release)(void *ctx, uint8_t *p);
+  uint8_t *(*alloc)(void *ctx, size_t bytes);   /* called once: one block for all row buffers (pinned for an engine) */
+  void (*release)(void *ctx, uint8_t *p, size_t bytes);
 } mk_rows_sink;
 int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const mk_rows_sink *sink, uint64_t first_ordinal,
                     mk_fastq_stats *st);

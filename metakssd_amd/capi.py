@@ -16,7 +16,7 @@ MK_OK = 0
 MK_ERR_ARG, MK_ERR_NO_DEVICE, MK_ERR_HIP, MK_ERR_CROWDED = -1, -2, -3, -4
 MK_ERR_STATE, MK_ERR_IO, MK_ERR_FORMAT, MK_ERR_NOMEM = -5, -6, -7, -8
 MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET, MK_MODE_OCC_SET = 0, 1, 2, 3
-MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP = 1, 2, 3
+MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP, MK_OPT_DIRECT_HOST = 1, 2, 3, 4
 
 
 class MkError(RuntimeError):
@@ -77,7 +77,7 @@ class FastqStatsC(C.Structure):
 _PUSH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64))
 _WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
-_RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class RowsSinkC(C.Structure):
@@ -117,6 +117,8 @@ def _load():
         "mk_engine_sync": [vp],
         "mk_host_alloc": [C.POINTER(vp), C.c_size_t],
         "mk_host_free": [vp],
+        "mk_host_arena_alloc": [C.POINTER(vp), C.c_size_t],
+        "mk_host_arena_free": [vp, C.c_size_t],
         "mk_host_register": [vp, C.c_size_t],
         "mk_host_unregister": [vp],
         "mk_partial_count": [vp, C.POINTER(u64)],
@@ -288,7 +290,7 @@ def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first
         return 0
 
     sink = RowsSinkC(None, _PUSH_FN(push), _WAIT_FN(wait), _ALLOC_FN(lambda ctx, n: libc.malloc(n)),
-                     _RELEASE_FN(lambda ctx, p: libc.free(p)))
+                     _RELEASE_FN(lambda ctx, p, n: libc.free(p)))
     keep["sink"] = sink
     o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 1 if drop_pages else 0, 0)
     st = FastqStatsC()

@@ -144,7 +144,9 @@ typedef struct {
   uint64_t chunk_bytes;
   mk_fastq_stats fq_stats;
   double t_first_push, t_last_push, t_unmapped, t_begin_s;
-  int drop_pages, inflight;
+  int drop_pages, inflight, direct_host;
+  uint8_t *arena; /* pinned row-buffer pool of the FASTQ stream */
+  size_t arena_bytes;
 } ctx_t;
 
 #define CHECK(e, call)                                                  \
@@ -198,6 +200,7 @@ static mk_engine *engine_get(ctx_t *c) {
   pthread_mutex_unlock(&f->mu);
   if (f->rc != MK_OK) die("mk_engine_create failed (%d): %s", f->rc, f->err);
   c->eng = f->eng;
+  if (c->direct_host) mk_engine_set_option(c->eng, MK_OPT_DIRECT_HOST, 1);
   return c->eng;
 }
 
@@ -269,12 +272,17 @@ static int cli_sink_push(void *ctx, const uint8_t *rows, uint32_t stride, uint64
   return mk_sketch_push_reads_async(e, rows, stride, nrows, ord, token);
 }
 static int cli_sink_wait(void *ctx, uint64_t token) { return mk_sketch_push_wait(((ctx_t *)ctx)->eng, token); }
-static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) {
-  (void)ctx;
+static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) { /* the pinned arena is kept for the next file and goes with the process */
+  ctx_t *c = ctx;
+  if (c->arena && c->arena_bytes >= bytes) return c->arena;
+  if (c->arena) mk_host_arena_free(c->arena, c->arena_bytes);
+  c->arena = NULL; c->arena_bytes = 0;
   void *p = NULL;
-  return mk_host_alloc(&p, bytes) == MK_OK ? p : NULL;
+  if (mk_host_arena_alloc(&p, bytes) != MK_OK) return NULL;
+  c->arena = p; c->arena_bytes = bytes;
+  return p;
 }
-static void cli_sink_release(void *ctx, uint8_t *p) { (void)ctx; mk_host_free(p); }
+static void cli_sink_release(void *ctx, uint8_t *p, size_t bytes) { (void)ctx; (void)p; (void)bytes; }
 
 /* an uncompressed regular file is framed straight out of its page-cache mapping by the whole-file stream
  * (mk_fastq_stream.c): no copy into an I/O buffer, `-p` threads fault the pages in and frame concurrently, the buffers
@@ -296,6 +304,9 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   o.drop_pages = c->drop_pages; /* a private read-only file mapping that is unmapped below */
   mk_rows_sink sink = {c, cli_sink_push, cli_sink_wait, cli_sink_alloc, cli_sink_release};
   mk_fastq_stats fs;
+  /* the engine first: its queue creation takes three times as long (45 ms instead of 14) when it runs into the driver
+   * together with the pinning of the row buffers, and no row can be pushed before it is there anyway */
+  (void)engine_get(c);
   const int rc = mk_fastq_stream(map, size, &o, &sink, c->next_ordinal, &fs);
   if (rc == MK_ERR_ARG || rc == MK_ERR_FORMAT)
     die("%s: FASTQ line longer than the reference's fgets() width (%s): outside the framing contract", path,
@@ -1266,7 +1277,7 @@ static int run_search(const char *refdir, const char *qrydir, const char *outdir
     int rc = mk_mco_count_begin(m, (uint32_t)ref_num, (uint32_t)qry_num);
     if (rc != MK_OK) die("mk_mco_count_begin failed (%d): %s", rc, mk_mco_last_error(m));
     if (nthreads < 1) nthreads = 1;
-    if (nthreads > 64) nthreads = 64;
+    if (nthreads > 24) nthreads = 24; /* 20-24 framer threads keep PCIe busy; more only take memory bandwidth from the copies */
     for (int c = 0; c < r_comp; c++) {
       size_t gb = 0, xb = 0, ib = 0, cb = 0;
       snprintf(path, sizeof path, "%s/mco.index.%d", refdir, c);
@@ -1334,9 +1345,9 @@ int main(int argc, char **argv) {
   /* -p: host threads of the front end (reference default: every processor, command_dist_wrapper.c:284-293) */
   int nthreads = (int)sysconf(_SC_NPROCESSORS_ONLN);
   if (nthreads < 1) nthreads = 1;
-  if (nthreads > 64) nthreads = 64;
-  uint64_t chunk_bytes = 0;
-  int drop_pages = 1, inflight = 3, slow_exit = 0;
+  if (nthreads > 24) nthreads = 24; /* 20-24 framer threads keep PCIe busy; more only take memory bandwidth from the copies */
+  uint64_t chunk_bytes = (uint64_t)32 << 20; /* text per framing job = about 17 MiB of rows per host-to-device copy */
+  int drop_pages = 1, inflight = 3, slow_exit = 0, direct_host = 0;
   int kmerocrs = 1, kmerqlty = 0; /* command_dist_wrapper.c:79-80 */
   const char *refpath = NULL, *skf = NULL;
   mk_dist_opts dopt = {0, 2, 0, 0, 1.0}; /* command_dist_wrapper.c:83-87 */
@@ -1360,6 +1371,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--timing")) timing = 1;
     else if (!strcmp(argv[i], "--chunk-mib") && i + 1 < argc) chunk_bytes = (uint64_t)atoi(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--inflight") && i + 1 < argc) inflight = atoi(argv[++i]); /* row buffers queued for copying */
+    else if (!strcmp(argv[i], "--direct")) direct_host = 1; /* MK_OPT_DIRECT_HOST: scan pinned row buffers in place */
     else if (!strcmp(argv[i], "--slow-exit")) slow_exit = 1; /* destroy the engine and return from main() instead of _exit() */
     else if (!strcmp(argv[i], "--keep-pages")) drop_pages = 0; /* measurement: leave all unmapping to the final munmap */
     else if (!strcmp(argv[i], "-r") && i + 1 < argc) refpath = argv[++i];
@@ -1417,9 +1429,6 @@ int main(int argc, char **argv) {
   if (!quiet) printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%u\thashlimit=%u\n", P.shuf_id, P.k, P.hashsize, P.hashlimit);
   const double t_shuf = now_s() - t0;
 
-  /* the table pinned (it blocks until the helper thread's HIP start-up is through): the engine's upload of it is then
-   * 1 ms of DMA instead of 20 ms through staging buffers.  A failure only means the slower upload. */
-  (void)mk_host_register(sh.table, (size_t)sh.len * sizeof(int32_t));
   engine_params(&fut, &P);
   ctx_t c;
   memset(&c, 0, sizeof c);
@@ -1427,6 +1436,7 @@ int main(int argc, char **argv) {
   c.chunk_bytes = chunk_bytes;
   c.drop_pages = drop_pages;
   c.inflight = inflight;
+  c.direct_host = direct_host;
 
   /* -A stays on only if every input is FASTQ: the reference switches it off when its file loop reaches the first
    * non-FASTQ input (command_dist.c:389-392) and then writes no combco.N.a at all (:427-431).  FASTQ files in front of

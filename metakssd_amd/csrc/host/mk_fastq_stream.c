@@ -195,7 +195,7 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
   f.text = text; f.n = n;
   f.occ = o->occ != 0; f.qmin = o->qmin; f.TL = o->TL;
   f.drop_pages = o->drop_pages != 0 && ((uintptr_t)text & 4095u) == 0;
-  f.chunk = o->chunk_bytes ? (size_t)o->chunk_bytes : (size_t)8 << 20;
+  f.chunk = o->chunk_bytes ? (size_t)o->chunk_bytes : (size_t)32 << 20;
   if (f.chunk < 4096) f.chunk = 4096;
   f.nchunks = n ? (n + f.chunk - 1) / f.chunk : 0;
   int T = o->nthreads < 1 ? 1 : o->nthreads > 256 ? 256 : o->nthreads;
@@ -211,6 +211,8 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
   int nth = 0;
   fs_inflight fifo[8];
   int nfifo = 0;
+  uint8_t *pool = NULL;
+  size_t pool_bytes = 0;
   f.bufs = calloc((size_t)f.nbufs, sizeof *f.bufs);
   f.freelist = calloc((size_t)f.nbufs, sizeof *f.freelist);
   f.slots = calloc((size_t)(f.nchunks ? f.nchunks : 1), sizeof *f.slots);
@@ -222,17 +224,19 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
   for (int t = 0; t < T && f.nchunks; t++)
     if (pthread_create(&th[nth], NULL, fs_worker, &f) == 0) nth++;
   if (f.nchunks && nth == 0) { rc = MK_ERR_NOMEM; goto out; }
-  /* the framers start on the first buffer while the rest of the pool is still being allocated (pinning pages takes time) */
+  /* one block for all row buffers (+ one for the serial fallback): the sink decides how to get pinned memory quickly */
+  f.buf_bytes = (f.buf_bytes + 4095) & ~(size_t)4095;
+  pool_bytes = f.buf_bytes * (size_t)(f.nbufs + 1);
+  pool = sink->alloc(sink->ctx, pool_bytes);
+  if (!pool) { rc = MK_ERR_NOMEM; goto out; }
+  pthread_mutex_lock(&f.mu);
   for (int b = 0; b < f.nbufs; b++) {
-    uint8_t *p = sink->alloc(sink->ctx, f.buf_bytes);
-    if (!p) { pthread_mutex_lock(&f.mu); f.nbufs = b; pthread_mutex_unlock(&f.mu); break; }
-    pthread_mutex_lock(&f.mu);
-    f.bufs[b] = p;
+    f.bufs[b] = pool + (size_t)b * f.buf_bytes;
     f.freelist[f.nfree++] = b;
-    pthread_cond_signal(&f.cv_buf);
-    pthread_mutex_unlock(&f.mu);
   }
-  if (f.nbufs < 2) { rc = MK_ERR_NOMEM; goto out; }
+  pthread_cond_broadcast(&f.cv_buf);
+  pthread_mutex_unlock(&f.mu);
+  serial_buf = pool + (size_t)f.nbufs * f.buf_bytes;
   stats.t_setup_s = fs_now() - t0;
 
   {
@@ -243,7 +247,6 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
     do {                                                                                                           \
       size_t sp_ = (from_);                                                                                        \
       const size_t sto_ = (to_);                                                                                   \
-      if (!serial_buf && !(serial_buf = sink->alloc(sink->ctx, f.buf_bytes))) { rc = MK_ERR_NOMEM; break; }        \
       while (rc == MK_OK && sp_ < sto_) {                                                                          \
         fs_slot ss_;                                                                                               \
         memset(&ss_, 0, sizeof ss_);                                                                               \
@@ -321,8 +324,7 @@ out:
     const int wrc = sink->wait ? sink->wait(sink->ctx, fifo[i].token) : MK_OK;
     if (rc == MK_OK) rc = wrc;
   }
-  for (int b = 0; b < f.nbufs; b++) if (f.bufs[b]) sink->release(sink->ctx, f.bufs[b]);
-  if (serial_buf) sink->release(sink->ctx, serial_buf);
+  if (pool) sink->release(sink->ctx, pool, pool_bytes);
   pthread_mutex_destroy(&f.mu);
   pthread_cond_destroy(&f.cv_buf);
   pthread_cond_destroy(&f.cv_ready);
@@ -344,9 +346,9 @@ static int fs_eng_wait(void *ctx, uint64_t token) { return mk_sketch_push_wait((
 static uint8_t *fs_eng_alloc(void *ctx, size_t bytes) {
   (void)ctx;
   void *p = NULL;
-  return mk_host_alloc(&p, bytes) == MK_OK ? (uint8_t *)p : NULL;
+  return mk_host_arena_alloc(&p, bytes) == MK_OK ? (uint8_t *)p : NULL;
 }
-static void fs_eng_release(void *ctx, uint8_t *p) { (void)ctx; mk_host_free(p); }
+static void fs_eng_release(void *ctx, uint8_t *p, size_t bytes) { (void)ctx; mk_host_arena_free(p, bytes); }
 
 int mk_sketch_push_fastq(mk_engine *e, const uint8_t *text, size_t n, const mk_fastq_opts *o, uint64_t first_ordinal,
                          mk_fastq_stats *st) {

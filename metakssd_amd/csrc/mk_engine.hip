@@ -72,6 +72,7 @@ struct mk_engine {
   hipEvent_t ev_copied[MK_REGIONS] = {}, ev_scanned[MK_REGIONS] = {};
   bool stage_two_streams[MK_REGIONS] = {}; /* the last scan of the region ran on another stream than the copies: ev_scanned is live */
   int stage_cur = 0;
+  bool direct_host = false; /* MK_OPT_DIRECT_HOST */
   bool region_open = false;
   size_t region_fill = 0;
   uint32_t region_stride = 0;
@@ -132,6 +133,55 @@ extern "C" int mk_host_alloc(void **p, size_t bytes) {
   return r == hipSuccess ? MK_OK : mk_fail(nullptr, MK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(r));
 }
 extern "C" int mk_host_free(void *p) { return hipHostFree(p) == hipSuccess ? MK_OK : MK_ERR_HIP; }
+/* A large pinned block made the cheap way: anonymous mapping (huge pages where the kernel gives them), its pages touched by
+ * several threads at once, then ONE hipHostRegister.  hipHostMalloc pins at 0.2 ms per MiB on one thread (45 ms for the
+ * FASTQ stream's 230 MiB of row buffers, as long as creating the engine); this takes a quarter of that. */
+#include <pthread.h>
+#include <sys/mman.h>
+struct mk_touch_job { uint8_t *p; size_t n; pthread_t th; };
+static void *mk_touch_run(void *arg) {
+  mk_touch_job *j = (mk_touch_job *)arg;
+  for (size_t off = 0; off < j->n; off += 4096) j->p[off] = 0;
+  return nullptr;
+}
+extern "C" int mk_host_arena_alloc(void **out, size_t bytes) {
+  if (!out || !bytes) return MK_ERR_ARG;
+  const size_t huge = (size_t)2 << 20;
+  const size_t len = (bytes + huge - 1) & ~(huge - 1);
+  void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (m == MAP_FAILED) return mk_fail(nullptr, MK_ERR_NOMEM, "mmap(%zu) failed", len);
+#ifdef MADV_HUGEPAGE
+  (void)madvise(m, len, MADV_HUGEPAGE);
+#endif
+  enum { T = 8 };
+  mk_touch_job job[T];
+  int started = 0;
+  for (int t = 0; t < T; t++) {
+    const size_t lo = len / T * (size_t)t, hi = t + 1 == T ? len : len / T * (size_t)(t + 1);
+    job[t].p = (uint8_t *)m + lo; job[t].n = hi - lo;
+    if (t + 1 < T && pthread_create(&job[t].th, nullptr, mk_touch_run, &job[t]) == 0) started |= 1 << t;
+    else mk_touch_run(&job[t]);
+  }
+  for (int t = 0; t < T; t++) if (started & (1 << t)) pthread_join(job[t].th, nullptr);
+  hipError_t r = hipHostRegister(m, len, hipHostRegisterDefault);
+  if (r != hipSuccess) {
+    (void)hipGetLastError();
+    munmap(m, len);
+    return mk_fail(nullptr, r == hipErrorOutOfMemory ? MK_ERR_NOMEM : MK_ERR_HIP, "hipHostRegister(%zu): %s", len, hipGetErrorString(r));
+  }
+  *out = m;
+  return MK_OK;
+}
+extern "C" int mk_host_arena_free(void *p, size_t bytes) {
+  if (!p) return MK_ERR_ARG;
+  const size_t huge = (size_t)2 << 20;
+  const size_t len = (bytes + huge - 1) & ~(huge - 1);
+  const bool ok = hipHostUnregister(p) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  munmap(p, len);
+  return ok ? MK_OK : MK_ERR_HIP;
+}
+
 extern "C" int mk_host_register(void *p, size_t bytes) {
   if (!p || !bytes) return MK_ERR_ARG;
   hipError_t r = hipHostRegister(p, bytes, hipHostRegisterDefault);
@@ -387,6 +437,9 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
     case MK_OPT_CAND_CAP:
       if (value < 0 || value > (1 << 20)) return mk_fail(e, MK_ERR_ARG, "MK_OPT_CAND_CAP takes 0 .. 2^20 records per scan wave");
       return mk_config_cand(e, (uint32_t)value);
+    case MK_OPT_DIRECT_HOST:
+      e->direct_host = value != 0;
+      return MK_OK;
     case MK_OPT_RESULT_CAP: {
       if (value < 1 || value > (int64_t)e->P.hashsize) return mk_fail(e, MK_ERR_ARG, "MK_OPT_RESULT_CAP takes 1 .. hashsize entries");
       if (e->h_ids) hipHostFree(e->h_ids);
@@ -688,6 +741,25 @@ extern "C" int mk_sketch_push_reads_async(mk_engine *e, const uint8_t *rows, uin
   double tick_ = mk_tick_now();
   const bool first_push_ = !e->d_stage[0];
 #endif
+  if (e->direct_host) {
+    /* rows in pinned (hipHostMalloc / registered) memory are mapped into the device: the scan kernel can read them over
+     * PCIe itself, no staging copy.  The ticket then fires when that scan is done with the rows. */
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, rows) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
+      rc = mk_flush_region(e);
+      if (rc) return rc;
+      rc = mk_launch_scan(e, (const uint8_t *)attr.devicePointer, stride, nreads, first_read_ordinal);
+      if (rc) return rc;
+      const uint64_t t = e->tickets_issued;
+      hipEvent_t ev = e->ev_ticket[t % MK_TICKETS];
+      if (t >= MK_TICKETS) MK_HIP(e, hipEventSynchronize(ev));
+      MK_HIP(e, hipEventRecord(ev, e->stream));
+      e->tickets_issued = t + 1;
+      *ticket = t;
+      return MK_OK;
+    }
+    (void)hipGetLastError(); /* ordinary memory: the staged path */
+  }
   if (!e->d_stage[0]) {
     e->stage_bytes = MK_REGION_BYTES;
     for (int i = 0; i < MK_REGIONS; i++) MK_HIP(e, hipMalloc(&e->d_stage[i], e->stage_bytes));

@@ -97,6 +97,30 @@ def test_product_cli_reproduces_reference_golden(case, shuf_files, tmp_path):
     check_against_golden(case, out, inp)
 
 
+REF_HIP = os.path.join(ROOT, "oracle", "_ref_hip", "metakssd")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(MANIFEST["cases"]))
+def test_reference_program_with_dropin_tu_reproduces_golden(case, shuf_files, tmp_path):
+    """oracle/_ref_hip/metakssd = the reference's own translation units (its main, option parser, dist_dispatch, run_stageI
+    with the per-component concatenation and cofiles.stat, command_dist.c:341-500) linked with integration/iseq2comem_hip.c
+    in place of iseq2comem.c (oracle/Makefile, target ref_hip): the library is a drop-in under the reference's call sites
+    (command_dist.c:380-398), and the sketch directories are the ones the unmodified reference wrote"""
+    if not os.path.exists(REF_HIP):
+        pytest.skip("oracle/_ref_hip/metakssd not built (needs the reference sources: make -C oracle ref_hip)")
+    entry = MANIFEST["cases"][case]
+    inp = gc.build_input(case, str(tmp_path))
+    out = str(tmp_path / "out")
+    r = subprocess.run([REF_HIP, "dist", "-L", shuf_files(entry["shuf"])] + entry["flags"] + ["-p", "4", "-o", out, inp],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if entry["aborted"]:
+        assert b"too crowd" in r.stderr  # err(errno, ..): the exit status is whatever errno was, as in the reference
+        return
+    assert r.returncode == 0, r.stderr.decode()
+    check_against_golden(case, out, inp)
+
+
 def _write_multi_inputs(d):
     """three FASTA genomes + (separately) three FASTQ files, deterministic"""
     import numpy as np

@@ -617,3 +617,36 @@ def test_two_engines_on_two_host_threads(capi, shufs, oracle_for):
         rc, want = oracle_for(shufs(nm)).koc_from_rows(rows, 160)
         assert rc == 0
         assert_same(out[nm], want, nm)
+
+
+def test_direct_scan_of_pinned_host_rows(capi, shufs, oracle_for):
+    """MK_OPT_DIRECT_HOST: rows in pinned host memory are scanned in place over PCIe (no staging copy); rows in ordinary
+    memory still take the staged path on the same engine; tickets then stand for finished scans"""
+    import ctypes as C
+    eng = capi.Engine(shufs("L1K7"), 0)
+    try:
+        eng.set_option(capi.MK_OPT_DIRECT_HOST, 1)
+        rs = np.random.RandomState(77)
+        seqs = ui.pool_reads(rs, 30000, 3000) + ui.ragged_reads(rs, 500)
+        stride = 304
+        rows = ui.rows_from_seqs(seqs, stride)
+        n = len(seqs)
+        p = C.c_void_p()
+        assert capi.lib.mk_host_alloc(C.byref(p), rows.size) == 0
+        C.memmove(p, rows.ctypes.data, rows.size)
+        eng.begin(capi.MK_MODE_KOC)
+        cut1, cut2 = 1000, 2200
+        t = C.c_uint64(0)
+        capi._check(capi.lib.mk_sketch_push_reads_async(eng.h, p, stride, cut1, 0, C.byref(t)), eng.h)          # pinned: in place
+        eng.push_reads(rows[cut1 * stride:cut2 * stride], stride, cut1)                                       # pageable: staged
+        t2 = C.c_uint64(0)
+        capi._check(capi.lib.mk_sketch_push_reads_async(eng.h, C.c_void_p(p.value + cut2 * stride), stride, n - cut2, cut2, C.byref(t2)), eng.h)
+        eng.push_wait(t.value)
+        eng.push_wait(t2.value)
+        got = eng.finish()
+        capi.lib.mk_host_free(p)
+    finally:
+        eng.close()
+    rc, want = oracle_for(shufs("L1K7")).koc_from_rows(rows, stride)
+    assert rc == 0
+    assert_same(got, want)

@@ -1,21 +1,35 @@
 #!/bin/bash
 # HBM traffic of the scan kernel from TCC counters: FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots).
+# Writes profiles-ready JSON (with the kernel source id bench.py checks) to gpurun_out/scan_traffic.json.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/traffic_$C -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline > gpurun_out/traffic_$C.log 2>&1
+  rm -rf gpurun_out/traffic_$C
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/traffic_$C -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-host-legs > gpurun_out/traffic_$C.log 2>&1
 done
 python3 - <<'PY'
-import collections, csv, glob, json
+import collections, csv, glob, json, sys
+sys.path.insert(0, '.')
+import bench
 out = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob("gpurun_out/traffic_%s/runc/*counter_collection.csv" % C)[0]
+    f = glob.glob("gpurun_out/traffic_%s/**/*counter_collection.csv" % C, recursive=True)[0]
     per = collections.defaultdict(float)
     names = {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == C:
             per[r["Dispatch_Id"]] += float(r["Counter_Value"]); names[r["Dispatch_Id"]] = r["Kernel_Name"]
-    for kern in ("mk_scan_kernel", "mk_resolve_kernel", "mk_compact_kernel"):
+    for kern in ("mk_scan_kernel", "mk_resolve_kernel", "mk_compact_kernel", "mk_layout_kernel", "mk_dump_write_kernel"):
         v = [per[d] for d in per if kern in names[d]]
         out.setdefault(kern, {})[C] = sum(v) / max(1, len(v))
-print(json.dumps(out))
+    kname = [names[d] for d in per if "mk_scan_kernel" in names[d]]
+sc = out["mk_scan_kernel"]
+res = {"kernel": kname[0] if kname else "mk_scan_kernel", "kernel_source_id": bench.kernel_source_id(), "reads_per_launch": 50000000,
+       "FETCH_SIZE_KB": sc["FETCH_SIZE"], "WRITE_SIZE_KB": sc["WRITE_SIZE"],
+       "hbm_bytes_per_launch": 2 * sc["FETCH_SIZE"] * 1024 + sc["WRITE_SIZE"] * 1024,
+       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (tools/pmc_traffic.sh); bytes = 2*FETCH_SIZE*1024 + "
+                 "WRITE_SIZE*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads, MI355X_MICROARCH.md HBM "
+                 "section; verified on a known byte count with this kernel's staging pattern: tools/ubench_fetch.hip)",
+       "other_kernels_KB": {k: v for k, v in out.items() if k != "mk_scan_kernel"}}
+json.dump(res, open("gpurun_out/scan_traffic.json", "w"), indent=1)
+print(json.dumps(res))
 PY
