@@ -1,0 +1,44 @@
+/*
+ * metakssd_multi.h -- C ABI of libmetakssd_multi.so: one sketch over several GPUs of one node (BASELINE config 4).
+ *
+ * The reference's parallel axis is one process with OpenMP threads over one shared table (iseq2comem.c:675-720) or over
+ * files (command_dist.c:363-372).  Here: one engine per GPU (libmetakssd_hip.so), the caller deals fixed-stride row buffers
+ * with GLOBAL read ordinals to the engines in any pattern (the command line deals the FASTQ stream's buffers round-robin so
+ * that every GPU's PCIe link is busy), every GPU scans into its own table with no traffic between GPUs, and
+ * mk_multi_finish is the one exchange: the distinct-key lists {key, count, first ordinal} of engines 1.. go to engine 0's
+ * GPU with grouped ncclSend / ncclRecv (RCCL over xGMI: every sender has its own link to GPU 0), engine 0 folds them in with
+ * ONE import launch and lays out and dumps the result.  Counts add and first ordinals take the minimum, both commutative, so
+ * the result is bit-identical to one engine scanning everything -- and to the reference's sequential run.
+ *
+ * A separate library because it links librccl.so (570 MB): the single-GPU command line never loads it.
+ * When the device list names one GPU several times (tests on a one-GPU box) or RCCL cannot be initialised, the lists move
+ * with plain device copies (hipMemcpyPeerAsync) instead; mk_multi_transport() says which.
+ */
+#ifndef METAKSSD_MULTI_H
+#define METAKSSD_MULTI_H
+#include "metakssd_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mk_multi mk_multi;
+
+/* engines on devices[0..n) (created concurrently, one host thread each), engine 0 is where results are finished */
+int mk_multi_create(const mk_params *p, const int *devices, int n, mk_multi **out);
+int mk_multi_destroy(mk_multi *m);
+const char *mk_multi_last_error(const mk_multi *m); /* m may be NULL: last error of a failed create */
+int mk_multi_count(const mk_multi *m);
+mk_engine *mk_multi_engine(mk_multi *m, int i); /* push rows with mk_sketch_push_reads[_async|_device] on these */
+const char *mk_multi_transport(const mk_multi *m); /* "rccl" or "device copies" */
+
+int mk_multi_begin(mk_multi *m, int mode);           /* mk_sketch_begin on every engine */
+int mk_multi_begin_occ(mk_multi *m, int min_occurrence);
+/* gather + import + finish; the result is engine 0's (valid until its next begin).  gather_ms / tail_ms (may be NULL):
+ * wall time of the exchange alone and of everything in this call */
+int mk_multi_finish(mk_multi *m, mk_result *out, double *gather_ms, double *tail_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

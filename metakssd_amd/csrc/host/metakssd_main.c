@@ -18,8 +18,10 @@
  */
 #define _GNU_SOURCE
 #include "metakssd_hip.h"
+#include "metakssd_multi.h"
 
 #include <dirent.h>
+#include <dlfcn.h>
 #include <errno.h>
 #include <pthread.h>
 #include <signal.h>
@@ -120,6 +122,8 @@ typedef struct {
   pthread_mutex_t mu;
   pthread_cond_t cv;
   int done, rc, device;
+  int ndev, devs[64];   /* --devices: more than one GPU -> libmetakssd_multi.so */
+  mk_multi *multi;
   int have_params;      /* the main thread has read the .shuf file: P may be used */
   const mk_params *P;
   mk_engine *eng;
@@ -129,9 +133,39 @@ typedef struct {
 
 static double g_t0; /* process start (monotonic) */
 
+/* libmetakssd_multi.so (it links librccl.so, 570 MB) is loaded only when --devices names several GPUs */
+static struct {
+  int (*create)(const mk_params *, const int *, int, mk_multi **);
+  const char *(*last_error)(const mk_multi *);
+  mk_engine *(*engine)(mk_multi *, int);
+  const char *(*transport)(const mk_multi *);
+  int (*begin)(mk_multi *, int);
+  int (*begin_occ)(mk_multi *, int);
+  int (*finish)(mk_multi *, mk_result *, double *, double *);
+} g_multi;
+
+static void load_multi(void) {
+  void *h = dlopen("libmetakssd_multi.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) die("--devices with several GPUs needs libmetakssd_multi.so: %s", dlerror());
+  *(void **)&g_multi.create = dlsym(h, "mk_multi_create");
+  *(void **)&g_multi.last_error = dlsym(h, "mk_multi_last_error");
+  *(void **)&g_multi.engine = dlsym(h, "mk_multi_engine");
+  *(void **)&g_multi.transport = dlsym(h, "mk_multi_transport");
+  *(void **)&g_multi.begin = dlsym(h, "mk_multi_begin");
+  *(void **)&g_multi.begin_occ = dlsym(h, "mk_multi_begin_occ");
+  *(void **)&g_multi.finish = dlsym(h, "mk_multi_finish");
+  if (!g_multi.create || !g_multi.last_error || !g_multi.engine || !g_multi.transport || !g_multi.begin || !g_multi.begin_occ || !g_multi.finish)
+    die("libmetakssd_multi.so: missing symbols");
+}
+
 typedef struct {
   engine_future *fut;
-  mk_engine *eng; /* NULL until engine_get() */
+  mk_engine *eng; /* NULL until engine_get(); with several GPUs: engine 0, where the sketch is finished */
+  mk_multi *multi;
+  int ndev;
+  mk_engine *engs[64];
+  uint64_t rr;    /* row buffers dealt so far (round-robin over the engines) */
+  double gather_ms, tail_ms;
   uint8_t *io;   /* raw text */
   uint8_t *rows; /* pinned rows */
   uint64_t next_ordinal;
@@ -165,8 +199,14 @@ static void *engine_thread(void *arg) {
   while (!f->have_params) pthread_cond_wait(&f->cv, &f->mu);
   pthread_mutex_unlock(&f->mu);
   if (rc == MK_OK && !f->P) rc = MK_ERR_ARG; /* the main thread gave up */
-  if (rc == MK_OK) rc = mk_engine_create(f->P, f->device, &f->eng);
-  if (rc != MK_OK) snprintf(f->err, sizeof f->err, "%s", mk_last_error(NULL));
+  if (rc == MK_OK && f->ndev > 1) {
+    rc = g_multi.create(f->P, f->devs, f->ndev, &f->multi);
+    if (rc != MK_OK) snprintf(f->err, sizeof f->err, "%s", g_multi.last_error(NULL));
+    else f->eng = g_multi.engine(f->multi, 0);
+  } else if (rc == MK_OK) {
+    rc = mk_engine_create(f->P, f->device, &f->eng);
+    if (rc != MK_OK) snprintf(f->err, sizeof f->err, "%s", mk_last_error(NULL));
+  } else snprintf(f->err, sizeof f->err, "%s", mk_last_error(NULL));
   f->t_ready = now_s() - g_t0;
   pthread_mutex_lock(&f->mu);
   f->rc = rc;
@@ -176,9 +216,12 @@ static void *engine_thread(void *arg) {
   return NULL;
 }
 
-static void engine_start(engine_future *f, int device) {
+static void engine_start(engine_future *f, int device, const int *devs, int ndev) {
   memset(f, 0, sizeof *f);
   f->device = device;
+  f->ndev = ndev;
+  for (int i = 0; i < ndev && i < 64; i++) f->devs[i] = devs[i];
+  if (ndev > 1) load_multi();
   pthread_mutex_init(&f->mu, NULL);
   pthread_cond_init(&f->cv, NULL);
   if (pthread_create(&f->th, NULL, engine_thread, f) != 0) die("cannot start a thread: %s", strerror(errno));
@@ -200,7 +243,11 @@ static mk_engine *engine_get(ctx_t *c) {
   pthread_mutex_unlock(&f->mu);
   if (f->rc != MK_OK) die("mk_engine_create failed (%d): %s", f->rc, f->err);
   c->eng = f->eng;
-  if (c->direct_host) mk_engine_set_option(c->eng, MK_OPT_DIRECT_HOST, 1);
+  c->multi = f->multi;
+  c->ndev = f->multi ? f->ndev : 1;
+  for (int i = 0; i < c->ndev; i++) c->engs[i] = f->multi ? g_multi.engine(f->multi, i) : f->eng;
+  for (int i = 0; i < c->ndev; i++)
+    if (c->direct_host) mk_engine_set_option(c->engs[i], MK_OPT_DIRECT_HOST, 1);
   return c->eng;
 }
 
@@ -209,7 +256,10 @@ static mk_engine *sketch_engine(ctx_t *c) {
   mk_engine *e = engine_get(c);
   if (!c->begun) {
     const double tb = now_s();
-    if (c->mode == MK_MODE_OCC_SET) CHECK(e, mk_sketch_begin_occ(e, c->min_occ)); /* command_dist.c:385-386 */
+    if (c->multi) {
+      const int rc = c->mode == MK_MODE_OCC_SET ? g_multi.begin_occ(c->multi, c->min_occ) : g_multi.begin(c->multi, c->mode);
+      if (rc != MK_OK) die("mk_multi_begin failed (%d): %s", rc, g_multi.last_error(c->multi));
+    } else if (c->mode == MK_MODE_OCC_SET) CHECK(e, mk_sketch_begin_occ(e, c->min_occ)); /* command_dist.c:385-386 */
     else CHECK(e, mk_sketch_begin(e, c->mode));
     c->t_begin_s += now_s() - tb;
     c->begun = 1;
@@ -267,11 +317,18 @@ static void push_rows(ctx_t *c, const uint8_t *rows, uint32_t stride, uint64_t n
 /* ---- sink of the whole-file FASTQ stream: pinned buffers, asynchronous pushes, the engine awaited at the first push ---- */
 static int cli_sink_push(void *ctx, const uint8_t *rows, uint32_t stride, uint64_t nrows, uint64_t ord, uint64_t *token) {
   ctx_t *c = ctx;
-  mk_engine *e = sketch_engine(c);
+  (void)sketch_engine(c);
   if (c->t_first_push == 0) c->t_first_push = now_s() - g_t0;
-  return mk_sketch_push_reads_async(e, rows, stride, nrows, ord, token);
+  /* several GPUs: the row buffers are dealt round-robin, so that every GPU's PCIe link carries a share at any time;
+   * ordinals are global, so it does not matter which engine sees which rows */
+  const int k = (int)(c->rr++ % (uint64_t)c->ndev);
+  uint64_t t = 0;
+  const int rc = mk_sketch_push_reads_async(c->engs[k], rows, stride, nrows, ord, &t);
+  if (rc != MK_OK && c->ndev > 1) fprintf(stderr, "metakssd: GPU %d: %s\n", k, mk_last_error(c->engs[k]));
+  *token = t * 64u + (uint64_t)k;
+  return rc;
 }
-static int cli_sink_wait(void *ctx, uint64_t token) { return mk_sketch_push_wait(((ctx_t *)ctx)->eng, token); }
+static int cli_sink_wait(void *ctx, uint64_t token) { return mk_sketch_push_wait(((ctx_t *)ctx)->engs[token % 64u], token / 64u); }
 static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) { /* the pinned arena is kept for the next file and goes with the process */
   ctx_t *c = ctx;
   if (c->arena && c->arena_bytes >= bytes) return c->arena;
@@ -503,9 +560,26 @@ static void *pf_worker(void *arg) {
   }
 }
 
+/* "0-7", "0,2,5", "0,0": GPU numbers of --devices */
+static int parse_devices(const char *s, int *out, int cap) {
+  int n = 0;
+  while (*s && n < cap) {
+    char *end;
+    long a = strtol(s, &end, 10);
+    if (end == s || a < 0) die("--devices: cannot parse '%s'", s);
+    long b = a;
+    if (*end == '-') { s = end + 1; b = strtol(s, &end, 10); if (end == s || b < a) die("--devices: bad range"); }
+    for (long d = a; d <= b && n < cap; d++) out[n++] = (int)d;
+    s = *end == ',' ? end + 1 : end;
+    if (*end && *end != ',') die("--devices: cannot parse '%s'", end);
+  }
+  if (n == 0) die("--devices: empty list");
+  return n;
+}
+
 static void usage(void) {
   fprintf(stderr,
-          "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D] <fastq|fasta|dir>...\n"
+          "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D | --devices 0-7] <fastq|fasta|dir>...\n"
           "       metakssd dist -o <mco dir> <sketch dir>                      (stage II: inverted index)\n"
           "       metakssd dist -L <file.shuf> -r <genomes> -o <db dir>         (stage I + II)\n"
           "       metakssd dist -r <mco dir> -o <outdir> [-M 0|1] [-O 0|1|2] [-N n] [-D d] [--correction 0|1] [--keepskf] [-f skf] <sketch dir>\n"
@@ -1348,6 +1422,7 @@ int main(int argc, char **argv) {
   if (nthreads > 24) nthreads = 24; /* 20-24 framer threads keep PCIe busy; more only take memory bandwidth from the copies */
   uint64_t chunk_bytes = (uint64_t)32 << 20; /* text per framing job = about 17 MiB of rows per host-to-device copy */
   int drop_pages = 1, inflight = 3, slow_exit = 0, direct_host = 0;
+  int devs[64], ndev = 0; /* --devices 0-7 / 0,2,5 / 0,0 (the same GPU twice: two engines, for tests) */
   int kmerocrs = 1, kmerqlty = 0; /* command_dist_wrapper.c:79-80 */
   const char *refpath = NULL, *skf = NULL;
   mk_dist_opts dopt = {0, 2, 0, 0, 1.0}; /* command_dist_wrapper.c:83-87 */
@@ -1367,6 +1442,7 @@ int main(int argc, char **argv) {
     }
     else if (!strcmp(argv[i], "-Q") && i + 1 < argc) kmerqlty = atoi(argv[++i]); /* :182-185 */
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--devices") && i + 1 < argc) ndev = parse_devices(argv[++i], devs, 64);
     else if (!strcmp(argv[i], "--quiet")) quiet = 1;
     else if (!strcmp(argv[i], "--timing")) timing = 1;
     else if (!strcmp(argv[i], "--chunk-mib") && i + 1 < argc) chunk_bytes = (uint64_t)atoi(argv[++i]) << 20;
@@ -1419,7 +1495,7 @@ int main(int argc, char **argv) {
   /* HIP start-up and then the engine's tables on a helper thread; the main thread reads the .shuf file meanwhile and goes
    * on to map and frame the input */
   engine_future fut;
-  engine_start(&fut, device);
+  engine_start(&fut, ndev ? devs[0] : device, devs, ndev);
   mk_shuf sh;
   int rc = mk_shuf_read(shuf_path, &sh);
   if (rc != MK_OK) die("read_dim_shuffle_file(): cannot read %s (%d)", shuf_path, rc);
@@ -1514,7 +1590,10 @@ int main(int argc, char **argv) {
     mk_engine *eng = sketch_engine(&c); /* an input without a single row still gives an (empty) sketch */
     mk_result res;
     const double tf = now_s();
-    rc = mk_sketch_finish(eng, &res);
+    if (c.multi) {
+      rc = g_multi.finish(c.multi, &res, &c.gather_ms, &c.tail_ms);
+      if (rc != MK_OK && rc != MK_ERR_CROWDED) die("mk_multi_finish failed (%d): %s", rc, g_multi.last_error(c.multi));
+    } else rc = mk_sketch_finish(eng, &res);
     t_finish += now_s() - tf;
     if (rc == MK_ERR_CROWDED) die("the context space is too crowd, try rerun the program using -k%d", P.k + 1);
     if (rc != MK_OK) die("mk_sketch_finish failed (%d): %s", rc, mk_last_error(eng));
@@ -1532,21 +1611,21 @@ int main(int argc, char **argv) {
     printf("{\"timing\": {\"t0_abs\": %.6f, \"exit_abs\": %.6f, \"shuf_read\": %.4f, \"hip_ready\": %.4f, \"engine_ready\": %.4f, \"first_push\": %.4f, \"last_push\": %.4f, \"unmapped\": %.4f, "
            "\"written\": %.4f, \"finish_s\": %.4f, \"begin_s\": %.4f, \"rows\": %llu, \"threads\": %u, \"chunks\": %llu, \"chunks_discarded\": %llu, "
            "\"serial_rows\": %llu, \"stream_setup_s\": %.4f, \"stream_wait_frame_s\": %.4f, \"stream_push_s\": %.4f, \"stream_total_s\": %.4f, "
-           "\"push_call_s\": %.4f, \"wait_call_s\": %.4f, \"push_call_max_s\": %.4f, \"first_push_call_s\": %.4f}}\n",
+           "\"push_call_s\": %.4f, \"wait_call_s\": %.4f, \"push_call_max_s\": %.4f, \"first_push_call_s\": %.4f, \"gpus\": %d, \"gather_ms\": %.3f, \"tail_ms\": %.3f, \"transport\": \"%s\"}}\n",
            g_t0, now_s(), t_shuf, fut.t_hip_ready, fut.t_ready, c.t_first_push, c.t_last_push, c.t_unmapped, t_written, t_finish, c.t_begin_s, (unsigned long long)c.nrows_total,
            c.fq_stats.threads, (unsigned long long)c.fq_stats.chunks, (unsigned long long)c.fq_stats.chunks_discarded,
            (unsigned long long)c.fq_stats.serial_rows, c.fq_stats.t_setup_s, c.fq_stats.t_wait_frame_s, c.fq_stats.t_push_s,
            c.fq_stats.t_total_s, c.fq_stats.t_push_call_s, c.fq_stats.t_wait_call_s, c.fq_stats.t_push_call_max_s,
-           c.fq_stats.t_first_push_call_s);
+           c.fq_stats.t_first_push_call_s, c.ndev ? c.ndev : 1, c.gather_ms, c.tail_ms, c.multi ? g_multi.transport(c.multi) : "-");
   if (stage2_after) {
     if (c.rows) mk_host_free(c.rows);
     free(c.io);
-    mk_engine_destroy(engine_get(&c));
+    if (!c.multi) mk_engine_destroy(engine_get(&c));
     mk_shuf_free(&sh);
     return run_stage2(outdir, outdir, device, quiet);
   }
   if (slow_exit) { /* profilers collect their data in exit handlers */
-    mk_engine_destroy(engine_get(&c));
+    if (!c.multi) mk_engine_destroy(engine_get(&c));
     return 0;
   }
   /* everything is on disk: leave without tearing down 2 GB of device tables and the pinned pools page by page */

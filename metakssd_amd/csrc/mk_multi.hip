@@ -1,0 +1,236 @@
+/*
+ * mk_multi.hip -- libmetakssd_multi.so: several engines of libmetakssd_hip.so on the GPUs of one node and the one exchange
+ * that merges their partial sketches on GPU 0 (include/metakssd_multi.h).  RCCL point-to-point inside one group call; plain
+ * device copies when the same GPU is named twice or RCCL is not usable.
+ */
+#include "metakssd_multi.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <time.h>
+
+#include <vector>
+
+static thread_local char g_multi_error[512] = "";
+
+struct mk_multi {
+  int n = 0;
+  std::vector<int> dev;
+  std::vector<mk_engine *> eng;
+  std::vector<hipStream_t> xs;     /* exchange stream per engine, on its device */
+  std::vector<ncclComm_t> comm;    /* empty: device copies */
+  bool rccl = false;
+  mk_params P{};
+  char err[512] = "";
+  /* exchange buffers: [i] = export of engine i on its own device; recv = everything back to back on device 0 */
+  std::vector<unsigned long long *> xk, xo;
+  std::vector<uint32_t *> xc;
+  std::vector<uint64_t> xcap;
+  unsigned long long *rk = nullptr, *ro = nullptr;
+  uint32_t *rc = nullptr;
+  uint64_t rcap = 0;
+};
+
+static int mm_fail(mk_multi *m, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  snprintf(m ? m->err : g_multi_error, 512, "%s", buf);
+  return code;
+}
+#define MM_HIP(m, call)                                                                                        \
+  do {                                                                                                         \
+    hipError_t _r = (call);                                                                                    \
+    if (_r != hipSuccess) return mm_fail((m), _r == hipErrorOutOfMemory ? MK_ERR_NOMEM : MK_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_r)); \
+  } while (0)
+
+static double mm_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+
+extern "C" const char *mk_multi_last_error(const mk_multi *m) { return m ? m->err : g_multi_error; }
+extern "C" int mk_multi_count(const mk_multi *m) { return m ? m->n : 0; }
+extern "C" mk_engine *mk_multi_engine(mk_multi *m, int i) { return m && i >= 0 && i < m->n ? m->eng[(size_t)i] : nullptr; }
+extern "C" const char *mk_multi_transport(const mk_multi *m) { return m && m->rccl ? "rccl" : "device copies"; }
+
+struct mm_create_job { const mk_params *p; int device; mk_engine *e; int rc; char err[512]; pthread_t th; };
+static void *mm_create_run(void *arg) {
+  mm_create_job *j = (mm_create_job *)arg;
+  j->rc = mk_engine_create(j->p, j->device, &j->e);
+  if (j->rc != MK_OK) snprintf(j->err, sizeof j->err, "%s", mk_last_error(nullptr));
+  return nullptr;
+}
+
+extern "C" int mk_multi_destroy(mk_multi *m) {
+  if (!m) return MK_ERR_ARG;
+  for (int i = 0; i < m->n; i++) {
+    if ((size_t)i < m->dev.size()) hipSetDevice(m->dev[(size_t)i]);
+    if ((size_t)i < m->xk.size()) { hipFree(m->xk[(size_t)i]); hipFree(m->xc[(size_t)i]); hipFree(m->xo[(size_t)i]); }
+    if ((size_t)i < m->xs.size() && m->xs[(size_t)i]) hipStreamDestroy(m->xs[(size_t)i]);
+  }
+  if (!m->dev.empty()) { hipSetDevice(m->dev[0]); hipFree(m->rk); hipFree(m->rc); hipFree(m->ro); }
+  for (auto c : m->comm) if (c) ncclCommDestroy(c);
+  for (auto e : m->eng) if (e) mk_engine_destroy(e);
+  delete m;
+  return MK_OK;
+}
+
+extern "C" int mk_multi_create(const mk_params *p, const int *devices, int n, mk_multi **out) {
+  if (!p || !devices || !out || n < 1 || n > 64) return mm_fail(nullptr, MK_ERR_ARG, "mk_multi_create: bad argument");
+  mk_multi *m = new mk_multi();
+  m->n = n;
+  m->P = *p;
+  m->dev.assign(devices, devices + n);
+  m->eng.assign((size_t)n, nullptr);
+  /* the engines concurrently: 40 ms each of queue creation, table upload and allocations */
+  std::vector<mm_create_job> job((size_t)n);
+  for (int i = 0; i < n; i++) {
+    job[(size_t)i].p = p; job[(size_t)i].device = devices[i]; job[(size_t)i].e = nullptr; job[(size_t)i].rc = MK_OK; job[(size_t)i].err[0] = 0;
+    if (i == 0 || pthread_create(&job[(size_t)i].th, nullptr, mm_create_run, &job[(size_t)i]) != 0) { job[(size_t)i].th = 0; }
+  }
+  mm_create_run(&job[0]);
+  for (int i = 1; i < n; i++) {
+    if (job[(size_t)i].th) pthread_join(job[(size_t)i].th, nullptr);
+    else mm_create_run(&job[(size_t)i]);
+  }
+  int rc = MK_OK;
+  for (int i = 0; i < n; i++) {
+    m->eng[(size_t)i] = job[(size_t)i].e;
+    if (job[(size_t)i].rc != MK_OK && rc == MK_OK) { rc = job[(size_t)i].rc; mm_fail(nullptr, rc, "engine on device %d: %s", devices[i], job[(size_t)i].err); }
+  }
+  if (rc != MK_OK) { mk_multi_destroy(m); return rc; }
+  m->xs.assign((size_t)n, nullptr);
+  m->xk.assign((size_t)n, nullptr); m->xc.assign((size_t)n, nullptr); m->xo.assign((size_t)n, nullptr);
+  m->xcap.assign((size_t)n, 0);
+  for (int i = 0; i < n; i++) {
+    if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&m->xs[(size_t)i], hipStreamNonBlocking) != hipSuccess) {
+      mm_fail(nullptr, MK_ERR_HIP, "exchange stream on device %d", devices[i]);
+      mk_multi_destroy(m);
+      return MK_ERR_HIP;
+    }
+  }
+  /* RCCL needs every rank on its own device */
+  bool distinct = n > 1;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++)
+      if (devices[i] == devices[j]) distinct = false;
+  if (distinct) {
+    m->comm.assign((size_t)n, nullptr);
+    if (ncclCommInitAll(m->comm.data(), n, devices) == ncclSuccess) m->rccl = true;
+    else { for (auto &c : m->comm) c = nullptr; m->comm.clear(); }
+  }
+  *out = m;
+  return MK_OK;
+}
+
+extern "C" int mk_multi_begin(mk_multi *m, int mode) {
+  if (!m) return MK_ERR_ARG;
+  for (int i = 0; i < m->n; i++) {
+    int rc = mk_sketch_begin(m->eng[(size_t)i], mode);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(m->eng[(size_t)i]));
+  }
+  return MK_OK;
+}
+extern "C" int mk_multi_begin_occ(mk_multi *m, int min_occurrence) {
+  if (!m) return MK_ERR_ARG;
+  for (int i = 0; i < m->n; i++) {
+    /* the occurrence threshold applies to the MERGED counts: the partial sketches keep every key (threshold 1 on 1..) */
+    int rc = mk_sketch_begin_occ(m->eng[(size_t)i], i == 0 ? min_occurrence : 1);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(m->eng[(size_t)i]));
+  }
+  return MK_OK;
+}
+
+extern "C" int mk_multi_finish(mk_multi *m, mk_result *out, double *gather_ms, double *tail_ms) {
+  if (!m || !out) return MK_ERR_ARG;
+  const double t0 = mm_now();
+  const int n = m->n;
+  std::vector<uint64_t> cnt((size_t)n, 0), off((size_t)n, 0);
+  uint64_t total = 0;
+  /* 1. every other engine: compaction, export into a buffer on its own device */
+  for (int i = 1; i < n; i++) {
+    mk_engine *e = m->eng[(size_t)i];
+    uint64_t d = 0;
+    int rc = mk_partial_count(e, &d);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(e));
+    if (d > m->xcap[(size_t)i]) {
+      MM_HIP(m, hipSetDevice(m->dev[(size_t)i]));
+      hipFree(m->xk[(size_t)i]); hipFree(m->xc[(size_t)i]); hipFree(m->xo[(size_t)i]);
+      m->xk[(size_t)i] = nullptr; m->xc[(size_t)i] = nullptr; m->xo[(size_t)i] = nullptr; m->xcap[(size_t)i] = 0;
+      const uint64_t cap = d + d / 8 + 1024;
+      MM_HIP(m, hipMalloc(&m->xk[(size_t)i], cap * 8));
+      MM_HIP(m, hipMalloc(&m->xc[(size_t)i], cap * 4));
+      MM_HIP(m, hipMalloc(&m->xo[(size_t)i], cap * 8));
+      m->xcap[(size_t)i] = cap;
+    }
+    uint64_t got = 0;
+    rc = mk_partial_export(e, (uint64_t *)m->xk[(size_t)i], m->xc[(size_t)i], (uint64_t *)m->xo[(size_t)i], m->xcap[(size_t)i], &got);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(e));
+    cnt[(size_t)i] = got;
+    off[(size_t)i] = total;
+    total += got;
+  }
+  const double t1 = mm_now();
+  /* 2. the exchange: all lists back to back on device 0 */
+  if (total > m->rcap) {
+    MM_HIP(m, hipSetDevice(m->dev[0]));
+    hipFree(m->rk); hipFree(m->rc); hipFree(m->ro);
+    m->rk = nullptr; m->rc = nullptr; m->ro = nullptr; m->rcap = 0;
+    const uint64_t cap = total + total / 8 + 1024;
+    MM_HIP(m, hipMalloc(&m->rk, cap * 8));
+    MM_HIP(m, hipMalloc(&m->rc, cap * 4));
+    MM_HIP(m, hipMalloc(&m->ro, cap * 8));
+    m->rcap = cap;
+  }
+  if (total) {
+    if (m->rccl) {
+      ncclResult_t r = ncclGroupStart();
+      for (int i = 1; i < n && r == ncclSuccess; i++) {
+        const uint64_t c = cnt[(size_t)i];
+        if (!c) continue;
+        /* rank i -> rank 0, three arrays; the receives on rank 0 land at the list's offset */
+        r = ncclSend(m->xk[(size_t)i], c * 8, ncclUint8, 0, m->comm[(size_t)i], m->xs[(size_t)i]);
+        if (r == ncclSuccess) r = ncclRecv(m->rk + off[(size_t)i], c * 8, ncclUint8, i, m->comm[0], m->xs[0]);
+        if (r == ncclSuccess) r = ncclSend(m->xc[(size_t)i], c * 4, ncclUint8, 0, m->comm[(size_t)i], m->xs[(size_t)i]);
+        if (r == ncclSuccess) r = ncclRecv(m->rc + off[(size_t)i], c * 4, ncclUint8, i, m->comm[0], m->xs[0]);
+        if (r == ncclSuccess) r = ncclSend(m->xo[(size_t)i], c * 8, ncclUint8, 0, m->comm[(size_t)i], m->xs[(size_t)i]);
+        if (r == ncclSuccess) r = ncclRecv(m->ro + off[(size_t)i], c * 8, ncclUint8, i, m->comm[0], m->xs[0]);
+      }
+      const ncclResult_t r2 = ncclGroupEnd();
+      if (r != ncclSuccess || r2 != ncclSuccess)
+        return mm_fail(m, MK_ERR_HIP, "RCCL exchange: %s", ncclGetErrorString(r != ncclSuccess ? r : r2));
+      for (int i = 0; i < n; i++) {
+        MM_HIP(m, hipSetDevice(m->dev[(size_t)i]));
+        MM_HIP(m, hipStreamSynchronize(m->xs[(size_t)i]));
+      }
+    } else {
+      MM_HIP(m, hipSetDevice(m->dev[0]));
+      for (int i = 1; i < n; i++) {
+        const uint64_t c = cnt[(size_t)i];
+        if (!c) continue;
+        MM_HIP(m, hipMemcpyPeerAsync(m->rk + off[(size_t)i], m->dev[0], m->xk[(size_t)i], m->dev[(size_t)i], c * 8, m->xs[0]));
+        MM_HIP(m, hipMemcpyPeerAsync(m->rc + off[(size_t)i], m->dev[0], m->xc[(size_t)i], m->dev[(size_t)i], c * 4, m->xs[0]));
+        MM_HIP(m, hipMemcpyPeerAsync(m->ro + off[(size_t)i], m->dev[0], m->xo[(size_t)i], m->dev[(size_t)i], c * 8, m->xs[0]));
+      }
+      MM_HIP(m, hipStreamSynchronize(m->xs[0]));
+    }
+  }
+  const double t2 = mm_now();
+  /* 3. one import launch over everything, then the reference-order layout and dump on engine 0 */
+  mk_engine *e0 = m->eng[0];
+  if (total) {
+    int rc = mk_partial_import(e0, (const uint64_t *)m->rk, m->rc, (const uint64_t *)m->ro, total);
+    if (rc) return mm_fail(m, rc, "import: %s", mk_last_error(e0));
+  }
+  int rc = mk_sketch_finish(e0, out);
+  if (rc) return mm_fail(m, rc, "%s", mk_last_error(e0));
+  /* the other engines' sketches are spent: leave them ready for the next begin */
+  if (gather_ms) *gather_ms = t2 - t1;
+  if (tail_ms) *tail_ms = mm_now() - t0;
+  return MK_OK;
+}

@@ -11,8 +11,12 @@ HEADER = os.path.join(ROOT, "include", "metakssd_hip.h")
 LIB = os.path.join(ROOT, "metakssd_amd", "lib", "libmetakssd_hip.so")
 
 
-def declared_functions():
-    src = open(HEADER).read()
+MULTI_HEADER = os.path.join(ROOT, "include", "metakssd_multi.h")
+MULTI_LIB = os.path.join(ROOT, "metakssd_amd", "lib", "libmetakssd_multi.so")
+
+
+def declared_functions(header=HEADER):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(mk_[a-z0-9_]+)\s*\(", src)))
 
@@ -29,6 +33,18 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(LIB)
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, "declared in include/metakssd_hip.h but not exported: %s" % missing
+
+
+def test_multi_gpu_library_exports_every_declared_symbol():
+    """include/metakssd_multi.h -> libmetakssd_multi.so (engines on several GPUs + the RCCL exchange); loading it pulls in
+    librccl.so, which is why it is a library of its own"""
+    lib = ctypes.CDLL(MULTI_LIB)
+    names = declared_functions(MULTI_HEADER)
+    assert "mk_multi_create" in names and "mk_multi_finish" in names
+    missing = [n for n in names if n.startswith("mk_multi_") and not hasattr(lib, n)]
+    assert not missing, missing
+    deps = os.popen("ldd %s" % os.path.join(ROOT, "metakssd_amd", "bin", "metakssd")).read()
+    assert "rccl" not in deps and "metakssd_multi" not in deps, "the single-GPU command line must not load RCCL at start-up"
 
 
 def test_no_cpu_fallback_without_device():

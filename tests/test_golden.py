@@ -510,3 +510,38 @@ def test_product_cli_stage2_search_end_to_end(shuf_files, tmp_path):
                 os.remove(str(tmp_path / d / "mco.index.0"))
             except OSError:
                 pass
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shuf,flags", [("L1K7", ["-A"]), ("L0K6", ["-A"]), ("L1K7", ["-n", "2"])])
+def test_cli_several_engines_equal_one(shuf, flags, shuf_files, tmp_path):
+    """`metakssd dist --devices a,b,..` (libmetakssd_multi.so): the FASTQ stream's row buffers are dealt round-robin to one
+    engine per listed GPU, mk_multi_finish gathers the partial sketches on the first one (RCCL between distinct GPUs; on
+    this one-GPU box the list names GPU 0 several times and the lists move with device copies), one import launch, finish.
+    The sketch directory is byte-identical to the single-engine run -- SURVEY.md 8e's merge algebra through the C product."""
+    import numpy as np
+    import util_inputs as ui
+    rs = np.random.RandomState(5)
+    seqs = ui.pool_reads(rs, 3000 if shuf == "L0K6" else 30000, 9000) + ui.ragged_reads(rs, 300)
+    fq = str(tmp_path / "in.fq")
+    open(fq, "wb").write(ui.fastq_bytes(seqs, quals=ui.random_quals(rs, seqs)))
+    assert os.path.getsize(fq) > 2 << 20  # several 1 MiB chunks
+    outs = []
+    for devs in (None, "0,0", "0,0,0"):
+        out = str(tmp_path / ("out_" + (devs or "single").replace(",", "_")))
+        cmd = [PRODUCT_CLI, "dist", "-L", shuf_files(shuf)] + flags + ["-p", "4", "--chunk-mib", "1", "--timing", "-o", out]
+        if devs:
+            cmd += ["--devices", devs]
+        r = subprocess.run(cmd + [fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        if devs:
+            tm = [json.loads(ln)["timing"] for ln in r.stdout.decode().splitlines() if ln.startswith('{"timing"')][0]
+            assert tm["gpus"] == len(devs.split(",")) and tm["transport"] == "device copies"
+        outs.append(out)
+    names = sorted(f for f in os.listdir(outs[0]) if f.startswith("combco"))
+    assert names and os.path.getsize(os.path.join(outs[0], "combco.0")) > 4000
+    for other in outs[1:]:
+        assert sorted(f for f in os.listdir(other) if f.startswith("combco")) == names
+        for f in names:
+            assert filecmp.cmp(os.path.join(outs[0], f), os.path.join(other, f), shallow=False), (other, f)
+        assert parse_stat(os.path.join(outs[0], "cofiles.stat")) == parse_stat(os.path.join(other, "cofiles.stat"))
