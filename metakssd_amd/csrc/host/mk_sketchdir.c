@@ -32,16 +32,19 @@ struct mk_sketchdir {
   uint64_t all_ctx_ct;
 };
 
-static void mk_sd_free(mk_sketchdir *d) {
-  if (!d) return;
+/* returns MK_ERR_IO when closing a sketch file fails (a full disk shows up at fclose, not at fwrite) */
+static int mk_sd_free(mk_sketchdir *d) {
+  if (!d) return MK_OK;
+  int rc = MK_OK;
   int C = d->P.component_num;
   for (int c = 0; c < C; c++) {
-    if (d->fid && d->fid[c]) fclose(d->fid[c]);
-    if (d->fab && d->fab[c]) fclose(d->fab[c]);
+    if (d->fid && d->fid[c] && fclose(d->fid[c]) != 0) rc = MK_ERR_IO;
+    if (d->fab && d->fab[c] && fclose(d->fab[c]) != 0) rc = MK_ERR_IO;
     if (d->index) free(d->index[c]);
   }
   free(d->fid); free(d->fab); free(d->index); free(d->ctx_ct); free(d->names);
   free(d);
+  return rc;
 }
 
 int mk_sketchdir_open(const char *outdir, const mk_params *p, int koc, int nfiles, mk_sketchdir **out) {
@@ -128,6 +131,6 @@ int mk_sketchdir_close(mk_sketchdir *d) {
       if (fclose(f) != 0) rc = MK_ERR_IO;
     }
   }
-  mk_sd_free(d);
-  return rc;
+  const int crc = mk_sd_free(d);
+  return rc != MK_OK ? rc : crc;
 }

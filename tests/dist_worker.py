@@ -19,7 +19,7 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from metakssd_amd import capi
-    from metakssd_amd.shard import gather_partials, shard_range
+    from metakssd_amd.shard import gather_partials, gather_partials_concat, shard_range
     from oracle_binding import Oracle
     import util_inputs as ui
 
@@ -39,6 +39,18 @@ def main():
     to = torch.from_numpy(ords.view(np.int64).copy())
     got = gather_partials(tk, tc, to, len(keys), dst=0)
     ok = True
+    # the same exchange with everything landing back to back in preallocated buffers (what bench.py's rank 0 imports with
+    # one launch): same entries in rank order
+    cap = 200000
+    outbuf = (torch.empty(cap, dtype=torch.int64), torch.empty(cap, dtype=torch.int32), torch.empty(cap, dtype=torch.int64))
+    if rank == 0:
+        tot = gather_partials_concat(tk[:0], tc[:0], to[:0], 0, dst=0, out=outbuf)
+        cat_k = torch.cat([k for (k, c, o) in got]) if got else tk[:0]
+        cat_c = torch.cat([c for (k, c, o) in got]) if got else tc[:0]
+        cat_o = torch.cat([o for (k, c, o) in got]) if got else to[:0]
+        ok &= tot == cat_k.numel() and torch.equal(outbuf[0][:tot], cat_k) and torch.equal(outbuf[1][:tot], cat_c) and torch.equal(outbuf[2][:tot], cat_o)
+    else:
+        assert gather_partials_concat(tk, tc, to, len(keys), dst=0) == 0
     if rank == 0:
         parts = [(keys, cnts, ords)]
         for (k, c, o) in got:

@@ -2,7 +2,7 @@
 """BASELINE config 5: reference-genome directory sketch (no -A), L3K10 and L2K11, multi-FASTA input.
 G synthetic genomes of MB megabases each (2 contigs, 70-column lines) in /dev/shm; times the product CLI and,
 on a few genomes, the compiled reference (oracle/_ref/metakssd) when present."""
-import os, subprocess, sys, tempfile, time
+import json, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -34,6 +34,9 @@ for name, (k, s, l, seed) in {"L3K10": (10, 6, 3, 10), "L2K11": (11, 5, 2, 211)}
         subprocess.check_call([cli, "dist", "-L", sp, "-p", os.environ.get("THREADS", "8"), "-o", os.path.join(d, "out_%s_%d" % (name, rep)), "--quiet", gd])
         dt = time.perf_counter() - t0
         print("%s product CLI rep %d: %.2f s for %d genomes = %.1f genomes/s, %.2f Gbases/s" % (name, rep, dt, G, G / dt, G * MB / 1e3 / dt))
+        print(json.dumps({"tool": "tools/bench_config5.py", "shuf": name, "who": "product CLI", "rep": rep, "genomes": G, "mbases_each": MB,
+                          "threads": int(os.environ.get("THREADS", "8")), "seconds": round(dt, 3), "genomes_per_s": round(G / dt, 1),
+                          "gbases_per_s": round(G * MB / 1e3 / dt, 3)}))
     if os.path.exists(ref):
         few = sorted(os.listdir(gd))[:int(os.environ.get("REF_GENOMES", "64"))]
         sub = os.path.join(d, "few_" + name); os.makedirs(sub)
@@ -42,4 +45,6 @@ for name, (k, s, l, seed) in {"L3K10": (10, 6, 3, 10), "L2K11": (11, 5, 2, 211)}
         subprocess.run([ref, "dist", "-L", sp, "-p", str(os.cpu_count()), "-o", os.path.join(d, "ref_" + name), sub], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         dt = time.perf_counter() - t0
         print("%s compiled reference (-p %d): %.2f s for %d genomes = %.2f genomes/s" % (name, os.cpu_count(), dt, len(few), len(few) / dt))
+        print(json.dumps({"tool": "tools/bench_config5.py", "shuf": name, "who": "compiled reference -p %d" % os.cpu_count(), "genomes": len(few),
+                          "mbases_each": MB, "seconds": round(dt, 3), "genomes_per_s": round(len(few) / dt, 2)}))
 subprocess.call(["rm", "-rf", d])

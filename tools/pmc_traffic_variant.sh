@@ -1,10 +1,6 @@
 #!/bin/bash
-# TCC traffic of the scan kernel for a build variant: VARIANT="-DMK_ABLATE=3" bash tools/pmc_traffic_variant.sh
-cd $GRAFT_REPO_ROOT/metakssd_amd/csrc
-cp ../lib/libmetakssd_hip.so /tmp/lib_orig.so
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -Ihost -Wno-unused-value $VARIANT -c mk_engine.hip -o /tmp/mk_engine_v.o 2>/dev/null
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/libmetakssd_hip.so /tmp/mk_engine_v.o build/mk_setop.o build/mk_shuf_params.o build/mk_frontend.o build/mk_sketchdir.o
+# TCC traffic of the scan kernel for a build variant: VARIANT="-DMK_SOMETHING=1" bash tools/pmc_traffic_variant.sh
+# (scratch library via `make tuning`, selected with MK_LIBRARY; the shipped library is not touched)
 cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/traffic_*
-bash tools/pmc_traffic.sh | tail -1
-cp /tmp/lib_orig.so metakssd_amd/lib/libmetakssd_hip.so
+make -s -C metakssd_amd/csrc tuning TUNING_OUT=/tmp/mk_variant_pmc VARIANT="$VARIANT" || exit 1
+MK_LIBRARY=/tmp/mk_variant_pmc/libmetakssd_hip.so bash tools/pmc_traffic.sh | tail -1
