@@ -96,9 +96,14 @@ typedef struct mk_params {
   uint64_t tupmask, domask, undomask; /* iseq2comem.c:69,74-76 */
   const int32_t *shuf_table; /* host pointer, 16^subk entries; must outlive mk_engine_create */
   uint64_t shuf_len;
+  int32_t component_sz;      /* COMPONENT_SZ, global_basic.h:35-37: 8 unless the reference was built with -DCOMPONENT_SZ=n */
+  int32_t reserved;
 } mk_params;
 
 int mk_params_init(const mk_shuf *shuf, mk_params *out);
+/* for sketch directories of a reference build with another -DCOMPONENT_SZ (1..8): component_num = 16^(k-drlevel-component_sz),
+ * ids below 16^component_sz, stage II index files of 16^component_sz rows.  MK_ERR_ARG above 16 components. */
+int mk_params_init_csz(const mk_shuf *shuf, int32_t component_sz, mk_params *out);
 
 /* ---- engine ---------------------------------------------------------------------------------- */
 typedef struct mk_engine mk_engine;
@@ -363,6 +368,11 @@ int mk_mco_index_rows(mk_mco *m, uint64_t row0, uint64_t nrows, uint64_t *out);
  * mk_mco_build, still on the device); the row of query id i is gids[ext_start[i] .. ext_end[i]) -- what the reference
  * reads from the mmap'ed index (:1040-1041) -- or, with ext_start == NULL, is looked up on the device in the row table
  * of the last build from qry_ids[i].  Sketches with qry_ctx_ct[k] == 0 are skipped (:1035). */
+/* which instantiation of the counting kernel runs (same matrix either way; the tests run all):
+ *   MK_MCO_OPT_GLOBAL_COUNTERS 1: global atomics straight into the matrix even where per-workgroup LDS counters would be chosen
+ *   MK_MCO_OPT_WIDE_LISTS      1: genome lists stay 32-bit even below 65 535 genomes */
+enum { MK_MCO_OPT_GLOBAL_COUNTERS = 1, MK_MCO_OPT_WIDE_LISTS = 2 };
+int mk_mco_set_option(mk_mco *m, int option, int64_t value);
 int mk_mco_count_begin(mk_mco *m, uint32_t ref_num, uint32_t qry_num);
 int mk_mco_count_add(mk_mco *m, const uint32_t *gids, uint64_t ngids, const uint32_t *qry_ids, const uint64_t *ext_start,
                      const uint64_t *ext_end, const uint64_t *qry_index, const uint32_t *qry_ctx_ct);

@@ -41,7 +41,7 @@ class ParamsC(C.Structure):
                 ("dim_start", C.c_int32), ("dim_end", C.c_int32),
                 ("hashsize", C.c_uint32), ("hashlimit", C.c_uint32),
                 ("tupmask", C.c_uint64), ("domask", C.c_uint64), ("undomask", C.c_uint64),
-                ("shuf_table", C.POINTER(C.c_int32)), ("shuf_len", C.c_uint64)]
+                ("shuf_table", C.POINTER(C.c_int32)), ("shuf_len", C.c_uint64), ("component_sz", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ComponentC(C.Structure):
@@ -100,6 +100,7 @@ def _load():
         "mk_shuf_generate": [i32, i32, i32, u64, C.POINTER(ShufC)],
         "mk_shuf_write": [C.POINTER(ShufC), C.c_char_p],
         "mk_params_init": [C.POINTER(ShufC), C.POINTER(ParamsC)],
+        "mk_params_init_csz": [C.POINTER(ShufC), i32, C.POINTER(ParamsC)],
         "mk_device_count": [C.POINTER(C.c_int)],
         "mk_engine_create": [C.POINTER(ParamsC), C.c_int, C.POINTER(vp)],
         "mk_engine_destroy": [vp],
@@ -152,6 +153,7 @@ def _load():
         "mk_mco_destroy": [vp],
         "mk_mco_build": [vp, vp, vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
         "mk_mco_index_rows": [vp, u64, u64, vp],
+        "mk_mco_set_option": [vp, C.c_int, C.c_int64],
         "mk_mco_count_begin": [vp, u32, u32],
         "mk_mco_count_add": [vp, vp, u64, vp, vp, vp, vp, vp],
         "mk_mco_count_finish": [vp, vp],
@@ -212,9 +214,9 @@ class Shuf:
     def table(self):
         return np.ctypeslib.as_array(self.c.table, shape=(self.c.len,))
 
-    def params(self):
+    def params(self, component_sz=8):
         p = ParamsC()
-        _check(lib.mk_params_init(C.byref(self.c), C.byref(p)))
+        _check(lib.mk_params_init_csz(C.byref(self.c), component_sz, C.byref(p)))
         return p
 
     def __del__(self):
@@ -330,9 +332,9 @@ def fasta_windows(buf, TL, stride, chunk=None):
 class Engine:
     """one GPU's sketch engine (mk_engine): begin -> push_reads* -> finish"""
 
-    def __init__(self, shuf, device=0, sparse=None, cand_cap=None):
+    def __init__(self, shuf, device=0, sparse=None, cand_cap=None, component_sz=8):
         self.shuf = shuf  # keeps the host table alive
-        self.params = shuf.params()
+        self.params = shuf.params(component_sz)
         self.h = C.c_void_p()
         rc = lib.mk_engine_create(C.byref(self.params), device, C.byref(self.h))
         if rc != MK_OK:

@@ -12,7 +12,7 @@
  * database search `dist -r <mco> -o <out> [-M -O -N -D --correction --keepskf -f] <sketch dir>`.
  *
  * Differences, all documented in DESIGN.md: inputs are processed in discovery order (the reference
- * applies a time-seeded shuffle, command_dist.c:215); --byread, combine_queries, composite -i/-s and reverse are not
+ * applies a time-seeded shuffle, command_dist.c:215); --byread, composite -i/-s and reverse are not
  * part of this build; -p N sets the number of host threads that read and frame/window input files ahead of the GPU
  * (default 8); --device selects the GPU.
  */
@@ -132,6 +132,7 @@ typedef struct {
 } engine_future;
 
 static double g_t0; /* process start (monotonic) */
+static int g_component_sz = 8; /* --component-sz: the reference's compile-time COMPONENT_SZ (global_basic.h:35-37) */
 
 /* libmetakssd_multi.so (it links librccl.so, 570 MB) is loaded only when --devices names several GPUs */
 static struct {
@@ -1263,10 +1264,12 @@ static int run_stage2(const char *codir, const char *mcodir, int device, int qui
     snprintf(path, sizeof path, "%s/mco.index.%d", mcodir, c);
     f = fopen(path, "wb");
     if (!f) die("%s", path);
-    for (uint64_t r0 = 0; r0 < (1ull << 32); r0 += slab) { /* 1LLU << 4*COMPONENT_SZ rows, co2mco.c:19, 63-66 */
-      rc = mk_mco_index_rows(m, r0, slab, rows);
+    const uint64_t comp_rows = 1ull << (4 * g_component_sz); /* 1LLU << 4*COMPONENT_SZ rows, co2mco.c:19, 63-66 */
+    for (uint64_t r0 = 0; r0 < comp_rows; r0 += slab) {
+      const uint64_t nr = comp_rows - r0 < slab ? comp_rows - r0 : slab;
+      rc = mk_mco_index_rows(m, r0, nr, rows);
       if (rc != MK_OK) die("mk_mco_index_rows failed (%d): %s", rc, mk_mco_last_error(m));
-      if (fwrite(rows, 8, slab, f) != slab) die("%s: write failed", path);
+      if (fwrite(rows, 8, nr, f) != nr) die("%s: write failed", path);
     }
     if (fclose(f)) die("%s: write failed", path);
     snprintf(path, sizeof path, "%s/mco.%d", mcodir, c);
@@ -1278,6 +1281,97 @@ static int run_stage2(const char *codir, const char *mcodir, int device, int qui
   }
   mk_host_free(rows); free(st);
   mk_mco_destroy(m);
+  return 0;
+}
+
+/* combine_queries() (command_dist.c:1718-1924): `dist -o <out> <sketch dir> <sketch dir>...` strings several sketch directories
+ * (batches of queries) together: combco.N appended, combco.index.N continued with the running offset, the cofiles.stat
+ * header of the first directory with the summed sketch and k-mer counts, then everybody's count lists and names.  Host only.
+ * As there: -A sketches are refused, a directory without cofiles.stat, with another shuf_id or with abundances is skipped
+ * with a message. */
+static int run_combine(int ndirs, char **dirs, const char *outdir) {
+  char path[PATHLEN * 2 + 32];
+  size_t n0 = 0;
+  mkdir(outdir, 0700);
+  snprintf(path, sizeof path, "%s/cofiles.stat", dirs[0]);
+  uint8_t *h0 = read_whole(path, &n0);
+  if (!h0 || n0 < 32) die("combine_queries():%s", path);
+  if (h0[4]) die("combine_queries(): abundance model not supported yet");
+  uint32_t id0;
+  int32_t comp_num, infile_num;
+  uint64_t all_ctx_ct;
+  memcpy(&id0, h0, 4); memcpy(&comp_num, h0 + 16, 4); memcpy(&infile_num, h0 + 20, 4); memcpy(&all_ctx_ct, h0 + 24, 8);
+  if (n0 < 32 + (size_t)infile_num * (4 + PATHLEN)) die("combine_queries():%s", path);
+  /* count lists and name records of every accepted directory, in order */
+  size_t ct_bytes = 0, nm_bytes = 0;
+  uint8_t *cts = NULL, *nms = NULL;
+#define APPEND(buf, len, src, n) do { buf = realloc(buf, len + (n)); if (!buf) die("out of memory"); memcpy(buf + len, src, n); len += (n); } while (0)
+  APPEND(cts, ct_bytes, h0 + 32, 4 * (size_t)infile_num);
+  APPEND(nms, nm_bytes, h0 + 32 + 4 * (size_t)infile_num, (size_t)PATHLEN * infile_num);
+  FILE **co = malloc(sizeof(FILE *) * (size_t)comp_num), **ix = malloc(sizeof(FILE *) * (size_t)comp_num);
+  uint64_t *offset = calloc((size_t)comp_num, 8);
+  for (int c = 0; c < comp_num; c++) {
+    size_t nb = 0, ib = 0;
+    snprintf(path, sizeof path, "%s/combco.%d", outdir, c);
+    if (!(co[c] = fopen(path, "wb"))) die("%s", path);
+    snprintf(path, sizeof path, "%s/combco.index.%d", outdir, c);
+    if (!(ix[c] = fopen(path, "wb"))) die("%s", path);
+    snprintf(path, sizeof path, "%s/combco.%d", dirs[0], c);
+    uint8_t *ids = read_whole(path, &nb);
+    if (!ids) die("%s", path);
+    if (nb && fwrite(ids, 1, nb, co[c]) != nb) die("%s: write failed", path);
+    free(ids);
+    snprintf(path, sizeof path, "%s/combco.index.%d", dirs[0], c);
+    uint8_t *idx = read_whole(path, &ib);
+    if (!idx || ib < 8) die("%s", path);
+    if (fwrite(idx, 1, ib, ix[c]) != ib) die("%s: write failed", path);
+    memcpy(&offset[c], idx + ib - 8, 8);
+    free(idx);
+  }
+  for (int i = 1; i < ndirs; i++) {
+    size_t ni = 0;
+    snprintf(path, sizeof path, "%s/cofiles.stat", dirs[i]);
+    uint8_t *h = read_whole(path, &ni);
+    if (!h || ni < 32) { printf("%dth query %s is not a valid query: no %s file\n", i, dirs[i], "cofiles.stat"); free(h); continue; }
+    uint32_t idi;
+    int32_t fi;
+    uint64_t cti;
+    memcpy(&idi, h, 4); memcpy(&fi, h + 20, 4); memcpy(&cti, h + 24, 8);
+    if (idi != id0) { printf("combine_queries(): %dth shuf_id: %u not match 0th shuf_id: %u\n", i, idi, id0); free(h); continue; }
+    if (h[4]) { printf("combine_queries(): %dth query abundance model not supported yet \n", i); free(h); continue; }
+    if (ni < 32 + (size_t)fi * (4 + PATHLEN)) die("combine_queries():%s", path);
+    all_ctx_ct += cti;
+    infile_num += fi;
+    APPEND(cts, ct_bytes, h + 32, 4 * (size_t)fi);
+    APPEND(nms, nm_bytes, h + 32 + 4 * (size_t)fi, (size_t)PATHLEN * fi);
+    free(h);
+    for (int c = 0; c < comp_num; c++) {
+      size_t nb = 0, ib = 0;
+      snprintf(path, sizeof path, "%s/combco.%d", dirs[i], c);
+      uint8_t *ids = read_whole(path, &nb);
+      if (!ids) die("%s", path);
+      if (nb && fwrite(ids, 1, nb, co[c]) != nb) die("%s: write failed", path);
+      free(ids);
+      snprintf(path, sizeof path, "%s/combco.index.%d", dirs[i], c);
+      uint64_t *idx = (uint64_t *)read_whole(path, &ib);
+      if (!idx || ib < 8) die("%s", path);
+      const size_t ne = ib / 8;
+      for (size_t k = 1; k < ne; k++) idx[k] += offset[c];
+      if (ne > 1 && fwrite(idx + 1, 8, ne - 1, ix[c]) != ne - 1) die("%s: write failed", path);
+      offset[c] = idx[ne - 1];
+      free(idx);
+    }
+  }
+#undef APPEND
+  for (int c = 0; c < comp_num; c++)
+    if (fclose(co[c]) || fclose(ix[c])) die("combine_queries(): write failed");
+  memcpy(h0 + 20, &infile_num, 4);
+  memcpy(h0 + 24, &all_ctx_ct, 8);
+  snprintf(path, sizeof path, "%s/cofiles.stat", outdir);
+  FILE *f = fopen(path, "wb");
+  if (!f || fwrite(h0, 1, 32, f) != 32 || fwrite(cts, 1, ct_bytes, f) != ct_bytes || fwrite(nms, 1, nm_bytes, f) != nm_bytes || fclose(f))
+    die("%s: write failed", path);
+  free(h0); free(cts); free(nms); free(co); free(ix); free(offset);
   return 0;
 }
 
@@ -1356,7 +1450,7 @@ static int run_search(const char *refdir, const char *qrydir, const char *outdir
       size_t gb = 0, xb = 0, ib = 0, cb = 0;
       snprintf(path, sizeof path, "%s/mco.index.%d", refdir, c);
       const uint64_t *index = map_whole(path, &xb);
-      if (!index || xb != (8ull << 32)) die("%s: not a 2^32-row index", path);
+      if (!index || xb != (8ull << (4 * g_component_sz))) die("%s: not a 16^%d-row index (--component-sz)", path, g_component_sz);
       snprintf(path, sizeof path, "%s/mco.%d", refdir, c);
       const uint32_t *gids = map_whole(path, &gb);
       if (!gids && gb) die("%s", path);
@@ -1444,6 +1538,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--devices") && i + 1 < argc) ndev = parse_devices(argv[++i], devs, 64);
     else if (!strcmp(argv[i], "--quiet")) quiet = 1;
+    else if (!strcmp(argv[i], "--component-sz") && i + 1 < argc) g_component_sz = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--timing")) timing = 1;
     else if (!strcmp(argv[i], "--chunk-mib") && i + 1 < argc) chunk_bytes = (uint64_t)atoi(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--inflight") && i + 1 < argc) inflight = atoi(argv[++i]); /* row buffers queued for copying */
@@ -1482,7 +1577,7 @@ int main(int argc, char **argv) {
     abundance = 0;
     stage2_after = 1;
   } else if (args.n >= 1 && dir_has(args.v[0], "cofiles.stat")) {
-    if (args.n > 1) die("combining several sketch directories (combine_queries) is not part of this build");
+    if (args.n > 1) return run_combine(args.n, args.v, outdir); /* :191-194 */
     return run_stage2(args.v[0], outdir, device, quiet); /* :187-190 */
   }
   if (!shuf_path) die("-L <file.shuf> is required (numeric levels generate a time-seeded table in the reference; use `metakssd shuffle`)");
@@ -1500,7 +1595,8 @@ int main(int argc, char **argv) {
   int rc = mk_shuf_read(shuf_path, &sh);
   if (rc != MK_OK) die("read_dim_shuffle_file(): cannot read %s (%d)", shuf_path, rc);
   mk_params P;
-  rc = mk_params_init(&sh, &P);
+  rc = mk_params_init_csz(&sh, g_component_sz, &P);
+  if (rc == MK_ERR_ARG) die("--component-sz %d with k=%d drlevel=%d: more than 16 components (or out of 1..8)", g_component_sz, sh.k, sh.drlevel);
   if (rc != MK_OK) die("get_hashsz(): primer_ind out of range(0 ~ 24) for k=%d drlevel=%d (command_dist.c:291-303)", sh.k, sh.drlevel);
   if (!quiet) printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%u\thashlimit=%u\n", P.shuf_id, P.k, P.hashsize, P.hashlimit);
   const double t_shuf = now_s() - t0;

@@ -77,8 +77,13 @@ void mk_shuf_free(mk_shuf *s) {
   if (s && s->table) { free(s->table); s->table = NULL; s->len = 0; }
 }
 
-int mk_params_init(const mk_shuf *s, mk_params *P) {
+int mk_params_init(const mk_shuf *s, mk_params *P) { return mk_params_init_csz(s, MK_COMPONENT_SZ, P); }
+
+/* the same with the reference's compile-time COMPONENT_SZ (global_basic.h:35-37, `make alert` builds with -DCOMPONENT_SZ=8)
+ * as a parameter: ids of one component live in [0, 16^component_sz) */
+int mk_params_init_csz(const mk_shuf *s, int32_t component_sz, mk_params *P) {
   if (!s || !P || !s->table) return MK_ERR_ARG;
+  if (component_sz < 1 || component_sz > 8) return MK_ERR_ARG; /* ids are 32-bit */
   int k = s->k, subk = s->subk, drl = s->drlevel;
   if (k < 1 || k > 16 || subk < 0 || subk >= 8 || subk > k || drl < 0 || drl > subk) return MK_ERR_FORMAT;
   if (s->len != (1ULL << (4 * subk))) return MK_ERR_FORMAT;
@@ -91,8 +96,10 @@ int mk_params_init(const mk_shuf *s, mk_params *P) {
   P->half_outctx_len = k - subk;
   P->TL = 2 * k;
   P->crvsaddmove = 4 * k - 2;
-  P->component_num = (k - drl > MK_COMPONENT_SZ) ? (int32_t)(1UL << (4 * (k - drl - MK_COMPONENT_SZ))) : 1;
-  P->comp_code_bits = (k - drl > MK_COMPONENT_SZ) ? 4 * (k - drl - MK_COMPONENT_SZ) : 0;
+  P->component_sz = component_sz;
+  if (k - drl - component_sz > 1) return MK_ERR_ARG; /* more than 16 components: the engine dumps at most 16 in one pass */
+  P->component_num = (k - drl > component_sz) ? (int32_t)(1UL << (4 * (k - drl - component_sz))) : 1;
+  P->comp_code_bits = (k - drl > component_sz) ? 4 * (k - drl - component_sz) : 0;
   P->tupmask = 0xffffffffffffffffULL >> (64 - 4 * k);
   P->domask = ((1ULL << (4 * subk)) - 1) << (2 * P->half_outctx_len);
   P->undomask = ((1ULL << (2 * P->half_outctx_len)) - 1) << (2 * (k + subk));

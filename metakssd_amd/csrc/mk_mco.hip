@@ -44,6 +44,7 @@ struct mk_mco_item {
 
 struct mk_mco {
   int device = 0, num_cu = 256;
+  bool opt_global_counters = false, opt_wide_lists = false; /* mk_mco_set_option */
   hipStream_t stream = nullptr;
   /* build */
   uint32_t *d_key[2] = {nullptr, nullptr}, *d_val[2] = {nullptr, nullptr};
@@ -483,6 +484,15 @@ extern "C" int mk_mco_index_rows(mk_mco *m, uint64_t row0, uint64_t nrows, uint6
   return MK_OK;
 }
 
+extern "C" int mk_mco_set_option(mk_mco *m, int option, int64_t value) {
+  if (!m) return MK_ERR_ARG;
+  switch (option) {
+    case MK_MCO_OPT_GLOBAL_COUNTERS: m->opt_global_counters = value != 0; return MK_OK;
+    case MK_MCO_OPT_WIDE_LISTS: m->opt_wide_lists = value != 0; return MK_OK;
+    default: return mk_mco_fail(m, MK_ERR_ARG, "unknown mk_mco option %d", option);
+  }
+}
+
 extern "C" int mk_mco_count_begin(mk_mco *m, uint32_t ref_num, uint32_t qry_num) {
   if (!m) return MK_ERR_ARG;
   MK_MCO_HIP(m, hipSetDevice(m->device));
@@ -548,8 +558,8 @@ extern "C" int mk_mco_count_add(mk_mco *m, const uint32_t *gids, uint64_t ngids,
   MK_MCO_HIP(m, hipStreamSynchronize(m->stream)); /* `items` leaves scope */
   const uint32_t nitems = (uint32_t)items.size(), R = m->ref_num;
   /* LDS counters pay when a slice brings more increments than the R-counter zero + flush costs */
-  const bool lds = R <= MK_MCO_LDS_REFS && nq / nitems >= R / 16u && !getenv("MK_MCO_NO_LDS");
-  const bool narrow = R <= 0xFFFFu && nlists > 0 && !getenv("MK_MCO_WIDE");
+  const bool lds = R <= MK_MCO_LDS_REFS && nq / nitems >= R / 16u && !m->opt_global_counters;
+  const bool narrow = R <= 0xFFFFu && nlists > 0 && !m->opt_wide_lists;
   if (narrow) {
     if ((rc = mk_mco_grow(m, &m->d_gids16, &m->gids16_cap, nlists))) return rc;
     hipLaunchKernelGGL(mk_mco_pack16_kernel, dim3(mk_mco_blocks(m, nlists, 256)), dim3(256), 0, m->stream, d_lists, nlists, m->d_gids16);

@@ -14,7 +14,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 SHUF_SPECS = {
     "L3K11": (11, 6, 3, 11), "L3K10": (10, 6, 3, 10), "L2K11": (11, 5, 2, 211),
     "L3K9": (9, 6, 3, 9), "L0K6": (6, 3, 0, 6), "L1K7": (7, 4, 1, 7),
+    "L1K8": (8, 4, 1, 81),   # k - drlevel = 7: sixteen components under a -DCOMPONENT_SZ=6 build (the csz6 database)
 }
+
+# ---- a database with SIXTEEN components that fits a test: the reference built with -DCOMPONENT_SZ=6 (global_basic.h:35-37),
+# whose stage II index has 16^6 rows (128 MiB) per component instead of 16^8 (32 GiB).  Stage I per genome, combine_queries,
+# stage II and the search all by that build (oracle/_ref/metakssd_csz6); the product runs with --component-sz 6.
+CSZ6 = {"shuf": "L1K8", "component_sz": 6, "refs": ["fa:sA", "fa:sB", "fa:sC", "fa:genome"], "query": ["fa:sB", "fq:mix", "fa:genome"],
+        "search_flags": [["-N", "2"], ["-M", "1", "-O", "1"]]}
 
 
 def make_shuf(name, path):

@@ -545,3 +545,71 @@ def test_cli_several_engines_equal_one(shuf, flags, shuf_files, tmp_path):
         for f in names:
             assert filecmp.cmp(os.path.join(outs[0], f), os.path.join(other, f), shallow=False), (other, f)
         assert parse_stat(os.path.join(outs[0], "cofiles.stat")) == parse_stat(os.path.join(other, "cofiles.stat"))
+
+
+# ---- sixteen components end to end (stage I, combine, stage II, search) with COMPONENT_SZ = 6 --------------------------------
+CSZ6 = MANIFEST.get("csz6")
+
+
+@pytest.mark.gpu
+def test_product_cli_sixteen_component_database_end_to_end(shuf_files, tmp_path):
+    """k - drlevel above COMPONENT_SZ splits every sketch into 16 component files (iseq2comem.c:64-65, 543-549) and stage II
+    and the search loop over them (co2mco.c:25, command_dist.c:990-1056).  With the real COMPONENT_SZ = 8 a 16-component
+    database needs 16 x 32 GiB of index; the reference built with -DCOMPONENT_SZ=6 (oracle/_ref/metakssd_csz6) needs 16 x
+    128 MiB, the product takes the same constant as --component-sz 6.
+      stage I + combine_queries: byte-identical to that reference build's directories (tests/golden/expected/csz6_db);
+      stage II + search: that reference build aborts in combco2mco() on the second component (double free, recorded in the
+      manifest), so the product's files are checked component by component against the oracle's restatement of the loops."""
+    import numpy as np
+    import oracle_binding as ob
+    assert CSZ6 and CSZ6["reference_stage2_aborts"]
+    shuf = shuf_files(CSZ6["shuf"])
+    dist = [PRODUCT_CLI, "dist", "--quiet", "-p", "4", "--component-sz", "6"]
+    exp = os.path.join(gc.GOLDEN, "expected", "csz6_db")
+
+    def sketch(tag, specs, want_files):
+        files = gc.build_search_inputs("csz6_" + tag, specs, str(tmp_path))
+        assert files == want_files
+        dirs = []
+        for i, f in enumerate(files):  # one directory per input and then combine_queries: the way the golden directory was made
+            _run(dist + ["-L", shuf, "-o", "%s_%d.sk" % (tag, i), f], str(tmp_path))
+            dirs.append("%s_%d.sk" % (tag, i))
+        _run([PRODUCT_CLI, "dist", "-o", tag + ".sk"] + dirs, str(tmp_path))
+        got = sorted(f for f in os.listdir(str(tmp_path / (tag + ".sk"))) if f.startswith("combco"))
+        want = sorted(os.listdir(os.path.join(exp, tag + "_sk")))
+        assert got == want and len(got) == 32
+        for f in want:
+            assert filecmp.cmp(os.path.join(exp, tag + "_sk", f), str(tmp_path / (tag + ".sk") / f), shallow=False), (tag, f)
+        stat, names = parse_stat(str(tmp_path / (tag + ".sk") / "cofiles.stat"))
+        assert stat == CSZ6[tag + "_sk_stat"] and names == files
+        # all inputs in one stage-I run: the same directory again (our file order is the argument order)
+        _run(dist + ["-L", shuf, "-o", tag + "_oneshot.sk"] + files, str(tmp_path))
+        for f in want:
+            assert filecmp.cmp(os.path.join(exp, tag + "_sk", f), str(tmp_path / (tag + "_oneshot.sk") / f), shallow=False), (tag, f)
+        return stat, names
+
+    rstat, rnames = sketch("ref", gc.CSZ6["refs"], CSZ6["ref_files"])
+    qstat, qnames = sketch("qry", gc.CSZ6["query"], CSZ6["qry_files"])
+    _run([PRODUCT_CLI, "dist", "--quiet", "--component-sz", "6", "-o", "db.mco", "ref.sk"], str(tmp_path))
+    rows = 1 << 24
+    want_ct = np.zeros((qstat["infile_num"], rstat["infile_num"]), np.uint32)
+    for c in range(16):
+        ids = np.fromfile(str(tmp_path / "ref.sk" / ("combco.%d" % c)), np.uint32)
+        index = np.fromfile(str(tmp_path / "ref.sk" / ("combco.index.%d" % c)), np.uint64)
+        og, ori, ore = ob.mco_build(ids, index)
+        assert np.array_equal(np.fromfile(str(tmp_path / "db.mco" / ("mco.%d" % c)), np.uint32), og), c
+        dense = np.concatenate([[0], ore]).astype(np.uint64)[np.searchsorted(ori.astype(np.uint64), np.arange(rows, dtype=np.uint64), side="right")]
+        got_index = np.fromfile(str(tmp_path / "db.mco" / ("mco.index.%d" % c)), np.uint64)
+        assert got_index.size == rows and np.array_equal(got_index, dense), c
+        qids = np.fromfile(str(tmp_path / "qry.sk" / ("combco.%d" % c)), np.uint32)
+        qindex = np.fromfile(str(tmp_path / "qry.sk" / ("combco.index.%d" % c)), np.uint64)
+        want_ct += ob.mco_count(og, ori, ore, qids, qindex, qstat["ctx_ct"], rstat["infile_num"])
+    assert want_ct.sum() > 1000
+    for i, flags in enumerate(gc.CSZ6["search_flags"]):
+        out = "search%d.out" % i
+        _run([PRODUCT_CLI, "dist", "--quiet", "--component-sz", "6", "-r", "db.mco", "-o", out, "--keepskf"] + flags + ["qry.sk"], str(tmp_path))
+        assert np.array_equal(np.fromfile(str(tmp_path / out / "sharedk_ct.dat"), np.uint32), want_ct.ravel()), flags
+        want_txt = str(tmp_path / ("want%d.txt" % i))
+        assert ob.dist_print(want_txt, rstat["ctx_ct"], qstat["ctx_ct"], rnames, qnames, want_ct, qstat["kmerlen"], qstat["dim_rd_len"],
+                             **_flags_to_kwargs(flags)) == 0
+        assert filecmp.cmp(want_txt, str(tmp_path / out / "distance.out"), shallow=False), flags

@@ -162,10 +162,10 @@ def test_state_and_argument_errors(mco):
     m.close()
 
 
-@pytest.mark.parametrize("env", [{"MK_MCO_WIDE": "1"}, {"MK_MCO_NO_LDS": "1"}, {"MK_MCO_WIDE": "1", "MK_MCO_NO_LDS": "1"}])
-def test_count_kernel_variants_agree(mco, monkeypatch, env):
-    """the measurement switches select the other instantiations of the counting kernel (32-bit lists with LDS counters,
-    global atomics on a small database): same matrix"""
+@pytest.mark.parametrize("opts", [{2: 1}, {1: 1}, {1: 1, 2: 1}])
+def test_count_kernel_variants_agree(mco, opts):
+    """mk_mco_set_option selects the other instantiations of the counting kernel (MK_MCO_OPT_WIDE_LISTS = 2: 32-bit lists with
+    LDS counters, MK_MCO_OPT_GLOBAL_COUNTERS = 1: global atomics on a small database): same matrix"""
     rs = np.random.RandomState(17)
     pool = np.unique(rs.randint(0, 2 ** 32, size=40000, dtype=np.uint64).astype(np.uint32))
     def draw(nsk, lo, hi):
@@ -181,7 +181,12 @@ def test_count_kernel_variants_agree(mco, monkeypatch, env):
     og, ori, ore = ob.mco_build(rids, rindex)
     want = ob.mco_count(og, ori, ore, qids, qindex, ctx, 700)
     mco.build(rids, rindex)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    got = mco.count(700, qindex, ctx, [{"qry_ids": qids}])
+    from metakssd_amd import capi
+    try:
+        for k, v in opts.items():
+            assert capi.lib.mk_mco_set_option(mco.h, k, v) == 0
+        got = mco.count(700, qindex, ctx, [{"qry_ids": qids}])
+    finally:
+        for k in (1, 2):
+            capi.lib.mk_mco_set_option(mco.h, k, 0)
     assert np.array_equal(got, want)

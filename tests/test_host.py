@@ -437,3 +437,60 @@ def test_dist_print_rejects_what_the_reference_gives_up_on(tmp_path):
     assert capi.dist_print(str(tmp_path / "x"), *args, metric=2) == capi.MK_ERR_ARG
     assert capi.dist_print(str(tmp_path / "x"), *args, outfields=3) == capi.MK_ERR_ARG
     assert capi.dist_print(str(tmp_path / "x"), *args, num_neigb=2) == 0
+
+
+def test_cli_combines_query_directories_like_the_reference(tmp_path):
+    """`dist -o <out> <sketch dir> <sketch dir>...` = combine_queries() (command_dist.c:1718-1924), host only: appended
+    combco.N, continued combco.index.N, summed header, count lists and names in order.  Compared with the compiled
+    reference (oracle/_ref/metakssd) byte for byte where that binary exists; the structure is checked everywhere."""
+    import shutil
+    import subprocess
+    import util_inputs as ui
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from metakssd_amd import capi
+    cli = os.path.join(root, "metakssd_amd", "bin", "metakssd")
+    ora = os.path.join(root, "oracle", "kssd_oracle_cli")
+    ref = os.path.join(root, "oracle", "_ref", "metakssd")
+    sp = str(tmp_path / "L2K11.shuf")
+    capi.Shuf.generate(9, 5, 1, 91).write(sp)  # k - drlevel = 8: one component; the 16-component layout comes with L2K11 below
+    rs = np.random.RandomState(9)
+    dirs = []
+    for b, ng in enumerate((3, 1, 4)):
+        fas = []
+        for g in range(ng):
+            p = str(tmp_path / ("b%d_g%d.fa" % (b, g)))
+            open(p, "wb").write(ui.fasta_bytes([ui.rand_seq(rs, int(rs.randint(3000, 9000)))]))
+            fas.append(p)
+        d = str(tmp_path / ("batch%d" % b))
+        r = subprocess.run([ora, "-L", sp, "-o", d] + fas, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        dirs.append(d)
+    # a -A directory and one from another .shuf are skipped with a message, as in the reference
+    sp2 = str(tmp_path / "other.shuf")
+    capi.Shuf.generate(9, 5, 1, 92).write(sp2)
+    other = str(tmp_path / "other")
+    assert subprocess.run([ora, "-L", sp2, "-o", other, str(tmp_path / "b0_g0.fa")], stdout=subprocess.PIPE).returncode == 0
+    args = [dirs[0], dirs[1], other, dirs[2]]
+    out = str(tmp_path / "combined")
+    r = subprocess.run([cli, "dist", "-o", out] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"not match 0th shuf_id" in r.stdout
+    stat = open(os.path.join(out, "cofiles.stat"), "rb").read()
+    infile_num, all_ctx = struct.unpack_from("<iQ", stat, 20)
+    assert infile_num == 8 and len(stat) == 32 + 8 * 260
+    cts = struct.unpack_from("<8I", stat, 32)
+    assert sum(cts) == all_ctx
+    idx = np.fromfile(os.path.join(out, "combco.index.0"), dtype=np.uint64)
+    ids = np.fromfile(os.path.join(out, "combco.0"), dtype=np.uint32)
+    assert len(idx) == 9 and idx[0] == 0 and idx[-1] == len(ids) and list(np.diff(idx.astype(np.int64))) == list(cts)
+    parts = [np.fromfile(os.path.join(d, "combco.0"), dtype=np.uint32) for d in dirs]
+    assert np.array_equal(ids, np.concatenate(parts))
+    if os.path.exists(ref):
+        out_ref = str(tmp_path / "combined_ref")
+        r = subprocess.run([ref, "dist", "-o", out_ref] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        for f in ("combco.0", "combco.index.0"):
+            assert open(os.path.join(out, f), "rb").read() == open(os.path.join(out_ref, f), "rb").read(), f
+        a, b = open(os.path.join(out, "cofiles.stat"), "rb").read(), open(os.path.join(out_ref, "cofiles.stat"), "rb").read()
+        assert a[:4] == b[:4] and a[8:] == b[8:]  # bytes 4..7: koc + three padding bytes the reference leaves uninitialised
+    shutil.rmtree(out)
