@@ -618,6 +618,10 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   a.rowdw = (a.CB / 4u) | 1u;
   a.wave_lds_dwords = ((64u * a.rowdw + 1u) & ~1u) + 2u; /* +2: the unconditional word prefetch reads up to 2 dwords past a row */
   a.bm_words = 1u << e->bm_bits;
+  /* tuned kernels: 24-bit inner substring (subk 6), k in {10,11}, every column block a whole number of 8-base pairs; they
+   * keep the pair filter's 256-entry mask table in front of the filter */
+  const int tuned_k = (e->P.subk == 6 && stride % 8u == 0 && a.CB % 8u == 0 && (e->P.k == 10 || e->P.k == 11)) ? e->P.k : 0;
+  a.mt_words = tuned_k ? MK_ZMASK_WORDS : 0u;
   a.dimmask = (uint32_t)((1ull << (4 * e->P.subk)) - 1ull);
   a.accept = e->d_accept; a.n_accept = e->n_accept;
   a.shuf = e->d_shuf;
@@ -631,7 +635,7 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   int threads = e->tune_threads;
   size_t lds = 0;
   for (;; threads -= 256) {
-    lds = ((size_t)a.bm_words + (size_t)(threads / 64) * a.wave_lds_dwords) * 4u;
+    lds = ((size_t)a.mt_words + (size_t)a.bm_words + (size_t)(threads / 64) * a.wave_lds_dwords) * 4u;
     if (vec) lds += 2u * (a.ppr <= 5u ? 5u : (uint32_t)MK_MAX_PIECES) * 64u * 4u; /* staging offset table of the 16-byte kernels: [2*NPIECES][64] */
     if (lds <= 160u * 1024u || threads <= 512) break;
   }
@@ -652,8 +656,7 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   hipError_t r;
-  /* tuned kernels: 24-bit inner substring (subk 6), k in {10,11}, every column block a whole number of 8-base pairs */
-  switch ((e->P.subk == 6 && stride % 8u == 0 && a.CB % 8u == 0) ? e->P.k : 0) {
+  switch (tuned_k) {
     case 11: r = vec ? mk_launch_scan_k<11, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<11, false>(e, threads, false, a, grid, lds, e->stream); break;
     case 10: r = vec ? mk_launch_scan_k<10, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<10, false>(e, threads, false, a, grid, lds, e->stream); break;
     default: r = vec ? mk_launch_scan_k<0, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<0, false>(e, threads, false, a, grid, lds, e->stream); break;

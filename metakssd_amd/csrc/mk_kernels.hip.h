@@ -26,6 +26,7 @@
 #define MK_MAX_CB 128                  /* widest column block staged per step, bytes */
 #define MK_MAX_PIECES 8                /* 16-byte pieces per lane per step = MK_MAX_CB/16 */
 #define MK_EMPTY32 0xFFFFFFFFu
+#define MK_ZMASK_WORDS 256u            /* tuned scan kernels: filter masks by the low 8 bits of the pair key, 1 KiB of LDS */
 #define MK_CNT_BITS 24                 /* slot word = key << 24 | count (the reference's slot is key << 16 | count16) */
 #define MK_CNT_MASK 0xFFFFFFull
 #define MK_CNT_SAT 0xF00000ull         /* stop adding long before the count field could carry into the key */
@@ -58,6 +59,7 @@ struct mk_scan_args {
   uint32_t rowdw;     /* LDS dwords per staged row (odd => conflict-free row reads) */
   uint32_t wave_lds_dwords;
   uint32_t bm_words;  /* LDS filter words (power of two) */
+  uint32_t mt_words;  /* tuned kernels: the 256-entry mask table in front of the filter (LDS offset 0), else 0 */
   uint32_t dimmask;   /* 2^(4*subk)-1: the inner substring after uni >> out2 */
   const uint32_t *accept; /* inner substrings d with dim_start <= shuf[d] < dim_end */
   uint32_t n_accept;
@@ -68,8 +70,8 @@ struct mk_scan_args {
   /* filter hits ("candidates") leave the scan kernel through per-wave append buffers in HBM */
   /* [nslots][cand_cap] 16-byte candidate records:
    *   single k-mer (slow paths, generic kernel): {fwd lo, fwd hi, ord lo, ord hi | 0x80000000}
-   *   pair (tuned loop: some base of this lane's 8-base pair passed the LDS filter):
-   *       {flo at the pair start, packed codes << 16 | e << 12 | jmin << 9 | pos0 >> 3, h2 & 0xFFFF | h3 << 16, row index}
+   *   pair (tuned loop: some base pair of this lane's 8-base window passed the LDS pair filter):
+   *       {flo at the window start, packed codes << 16 | e << 12 | jmin << 9 | pos0 >> 3, h2 & 0xFFFF | h3 << 16, row index}
    * The resolve kernel holds the same LDS filter, finds the base(s) that passed and rebuilds their k-mers, so the scan
    * kernel's hit path is one ballot and one 16-byte store. */
   uint4 *cand;
@@ -190,7 +192,7 @@ __device__ __forceinline__ void mk_resolve_record(const mk_scan_args &a, const u
 #pragma unroll
   for (uint32_t j = 0; j < 8; j++) {
     const uint32_t x = (before >> SH) & 0xFFFFFFu;
-    if (j >= jmin && j < e && (mk_filter_mask(x) & ~filter[(x >> 10) & (a.bm_words - 1u)]) == 0u) hits |= 1u << j;
+    if (j >= jmin && j < e && (!filter || (mk_filter_mask(x) & ~filter[(x >> 10) & (a.bm_words - 1u)]) == 0u)) hits |= 1u << j;
     before = __builtin_amdgcn_alignbit(r.x, lo, 30u - 2u * j);
   }
   while (hits) {
@@ -205,7 +207,8 @@ __device__ __forceinline__ void mk_resolve_record(const mk_scan_args &a, const u
 
 /* overflow path of the scan kernel (a wave's append buffer is full: dense accept-everything tables): resolve
  * this lane's record on the spot.  Out of line; reads the argument block through the kernarg pointer so that
- * the call does not push the hot loop's parameters into scratch. */
+ * the call does not push the hot loop's parameters into scratch.  filter == NULL (tuned kernels, whose LDS holds the pair
+ * filter): every base of the window goes to the exact test. */
 __device__ __noinline__ void mk_resolve_inline(const mk_scan_args *ka, bool hit, uint4 r, const uint32_t *filter) {
   if (hit) mk_resolve_record(*ka, r, filter);
 }
@@ -307,6 +310,32 @@ __device__ __forceinline__ uint32_t mk_nonzero_bytes(uint32_t v) { /* bit 7 of b
   return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
 }
 
+/* ---- pair filter of the tuned scan kernels ---------------------------------------------------------------------------
+ * Two consecutive k-mers' inner substrings overlap in 22 of their 24 bits: x_{j+1} = (x_j << 2 | code) mod 2^24, so
+ * z = x_j[0..21] = x_{j+1}[2..23].  The tuned loop probes ONE key z per PAIR of bases against a filter over
+ *     Z = { d mod 2^22 : d in B } u { d >> 2 : d in B },       B = A u revcomp(A) as above:
+ * x_j in B puts z in the first set, x_{j+1} in B in the second, so a pair without a filter hit holds no accepted k-mer.
+ * Word = z[8..21] (the same 16384 words), bits = a table lookup by z[0..7] (256 masks of up to four bits each, 1 KiB at LDS
+ * offset 0): the 22 bits of z are all used, none twice.  Half the LDS probes and a third of the instructions of the
+ * per-base test; it flags about 1.6 times as many 8-base windows (z drops two bits of either substring), which the resolve
+ * kernel, working per base with the filter above, throws out again. */
+__device__ __forceinline__ uint32_t mk_zmask(uint32_t b) {
+  const uint32_t h = b * 0x9E3779B1u;
+  return (1u << (h >> 27)) | (1u << ((h >> 22) & 31u)) | (1u << ((h >> 17) & 31u)) | (1u << ((h >> 12) & 31u));
+}
+__device__ __forceinline__ void mk_build_zfilter(uint32_t *masktab, uint32_t *bitmap, const mk_scan_args &a) {
+  for (uint32_t i = threadIdx.x; i < MK_ZMASK_WORDS; i += blockDim.x) masktab[i] = mk_zmask(i);
+  for (uint32_t i = threadIdx.x; i < a.bm_words; i += blockDim.x) bitmap[i] = 0u;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < a.n_accept; i += blockDim.x) {
+    const uint32_t d = (uint32_t)mk_scan_to_ref_codes(a.accept[i]); /* reference coding -> scan coding (same map) */
+    const uint32_t z1 = d & 0x3FFFFFu, z2 = d >> 2;
+    atomicOr(&bitmap[(z1 >> 8) & (a.bm_words - 1u)], masktab[z1 & 255u]);
+    atomicOr(&bitmap[(z2 >> 8) & (a.bm_words - 1u)], masktab[z2 & 255u]);
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ void mk_build_filter(uint32_t *bitmap, const mk_scan_args &a) {
   for (uint32_t i = threadIdx.x; i < a.bm_words; i += blockDim.x) bitmap[i] = 0u;
   __syncthreads();
@@ -325,12 +354,13 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   extern __shared__ __align__(16) uint32_t lds[];
   constexpr uint32_t WAVES = THREADS / 64;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t *bitmap = lds;
-  uint32_t *tile = lds + a.bm_words + wave * a.wave_lds_dwords;
+  /* LDS: [mask table (tuned kernels)] [filter] [wave tiles] [staging offset table] */
+  uint32_t *bitmap = lds + a.mt_words;
+  uint32_t *tile = lds + a.mt_words + a.bm_words + wave * a.wave_lds_dwords;
 
   if constexpr (VEC16) { /* staging offset table (see goff_of below): [2*NPIECES][64] dwords behind the wave tiles */
     if (wave == 0) {
-      uint32_t *t = lds + a.bm_words + WAVES * a.wave_lds_dwords + lane;
+      uint32_t *t = lds + a.mt_words + a.bm_words + WAVES * a.wave_lds_dwords + lane;
 #pragma unroll
       for (int i = 0; i < NPIECES; i++) {
         const uint32_t q = lane + 64u * i;
@@ -340,11 +370,13 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
       }
     }
   }
-  mk_build_filter(bitmap, a); /* ends with a barrier: the table is visible to every wave */
+  /* both end with a barrier: the tables are visible to every wave */
+  if constexpr (K != 0) mk_build_zfilter(lds, bitmap, a);
+  else mk_build_filter(bitmap, a);
 
-  /* the filter sits at the start of the dynamic LDS (offset 0: the tuned loop addresses it absolutely) */
+  /* the tuned loop addresses the mask table (LDS offset 0) and the filter (right behind it) absolutely */
   const uint32_t filter_base = (uint32_t)(uintptr_t)(mk_lds_cu32)bitmap;
-  if (K != 0 && (filter_base != 0u || a.bm_words != 16384u)) {
+  if (K != 0 && (filter_base != MK_ZMASK_WORDS * 4u || a.mt_words != MK_ZMASK_WORDS || a.bm_words != 16384u || a.dimmask != 0xFFFFFFu)) {
     if (threadIdx.x == 0) atomicOr(&a.tab.err[0], 4u);
     if (lane == 0) a.cand_count[blockIdx.x * WAVES + wave] = 0u; /* nothing for the resolve kernel to pick up */
     return;
@@ -380,7 +412,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
    * Left to itself the compiler hoists them out of the tile loop, runs out of registers in the 1024-thread builds and
    * reloads them from SCRATCH at every tile: 31 MB of scratch across the grid, i.e. 2.4 GB of extra HBM reads per launch of
    * the benchmark (rocprofv3 FETCH_SIZE).  LDS reads cannot be hoisted across the tile stores and cost no VALU issue. */
-  const uint32_t *offtab = lds + a.bm_words + WAVES * a.wave_lds_dwords + lane;
+  const uint32_t *offtab = lds + a.mt_words + a.bm_words + WAVES * a.wave_lds_dwords + lane;
   auto goff_of = [&](int i) { if constexpr (VEC16) return offtab[128 * i]; else return goff_calc(i); };
   auto loff_of = [&](int i) { if constexpr (VEC16) return offtab[128 * i + 64]; else return loff_calc(i); };
   auto issue_loads = [&](uint32_t tile_id, uint32_t cb) {
@@ -455,8 +487,14 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
 
   auto lookup = [&](uint32_t &mask, uint32_t &word) { /* probe the current forward k-mer's inner substring */
     const uint32_t xx = km.dimx(a.kp, dimmask);
-    word = *(mk_lds_cu32)(uintptr_t)(((xx >> 8) & wmask4) + filter_base);
-    mask = mk_filter_mask(xx);
+    if constexpr (K != 0) { /* the LDS holds the pair filter: x in B puts its low 22 bits into Z (mk_build_zfilter) */
+      const uint32_t z = xx & 0x3FFFFFu;
+      word = *(mk_lds_cu32)(uintptr_t)(((z >> 6) & wmask4) + filter_base);
+      mask = lds[z & 255u];
+    } else {
+      word = *(mk_lds_cu32)(uintptr_t)(((xx >> 8) & wmask4) + filter_base);
+      mask = mk_filter_mask(xx);
+    }
   };
   /* append the lanes flagged in `hit` (forward k-mer `fwd` ending at row position `pos`) to this wave's
    * candidate buffer: plain stores, nothing to wait for */
@@ -465,7 +503,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     if (m == 0) return;
     const uint32_t cnt = (uint32_t)__popcll(m);
     if (qn + cnt > a.cand_cap) { /* buffer full (dense tables only): resolve right here */
-      mk_resolve_inline(ka, hit, r, bitmap);
+      mk_resolve_inline(ka, hit, r, K != 0 ? nullptr : bitmap);
       return;
     }
     if (hit) my_cand[qn + mk_mbcnt(m)] = r;
@@ -600,10 +638,17 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
           bool have_pair = false;
           if (uniform) {
             uint32_t flo = km.flo;
-            /* one-hot filter words of the three previous bases' substrings (see probe below) */
-            uint32_t oh1, oh2, oh3;
-            auto oh_init = [&]() {
-              oh1 = 1u << ((flo >> (SH + 2u)) & 31u); oh2 = 1u << ((flo >> (SH + 4u)) & 31u); oh3 = 1u << ((flo >> (SH + 6u)) & 31u);
+            /* Pair probing (see mk_build_zfilter): bases (2t, 2t+1) of the 8-base window share the key z = x_{2t}[0..21],
+             * which sits in bits SH+2.. of before_{2t+1} (the low word in front of base 2t+1).  Filter word z[8..21]:
+             * bits SH+10.. of before_{2t+1}; mask-table entry z[0..7]: the low word D = (SH-2)/2 bases earlier holds
+             * those bits at 2..9 -- a dword address after one AND.  pm[] carries before_{-D}..before_{-1} (the previous
+             * window's last low words) for the pairs whose earlier word lies in front of this window. */
+            constexpr uint32_t D = (SH - 2u) / 2u;
+            static_assert(SH >= 4u && SH <= 8u, "pair probing: z[0..7] at bits 2..9 of a low word D bases earlier");
+            uint32_t pm[3] = {0u, 0u, 0u};
+            auto oh_init = [&]() { /* before_{k-D} = flo >> 2(D-k): only bits 2..9 matter, and those are exact */
+#pragma unroll
+              for (uint32_t k = 0; k < D; k++) pm[k] = flo >> (2u * (D - k));
             };
             oh_init();
             for (;;) { /* inner fast loop: leaves at a pair boundary */
@@ -643,32 +688,28 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                 flo = __builtin_amdgcn_alignbit(fstart, lo, 16);
                 oh_init();
               } else {
-                uint32_t m0, m1, m2, m3, m4, m5, m6, m7, d0, d1, d2, d3, d4, d5, d6, d7;
                 const uint32_t f0 = __builtin_amdgcn_alignbit(fstart, lo, 30), f1 = __builtin_amdgcn_alignbit(fstart, lo, 28);
                 const uint32_t f2 = __builtin_amdgcn_alignbit(fstart, lo, 26), f3 = __builtin_amdgcn_alignbit(fstart, lo, 24);
                 const uint32_t f4 = __builtin_amdgcn_alignbit(fstart, lo, 22), f5 = __builtin_amdgcn_alignbit(fstart, lo, 20);
                 const uint32_t f6 = __builtin_amdgcn_alignbit(fstart, lo, 18), f7 = __builtin_amdgcn_alignbit(fstart, lo, 16);
-                /* Filter fields at offsets 0, 2, 6 of the substring x_j: because x_{j-1} = x_j >> 2, the three bits of
-                 * base j are the one-hot words of the low 5 bits of x_j, x_{j-1} and x_{j-3} -- one new one-hot per
-                 * base, the other two are carried (across pairs too: oh1..oh3).  The substring of base j sits in the
-                 * low word BEFORE base j is rolled in. */
-                auto probe = [&](uint32_t before, uint32_t &m, uint32_t &wd) {
-                  wd = *(mk_lds_cu32)(uintptr_t)((before >> (SH + 8u)) & 0xFFFCu);
-                  const uint32_t oh = mk_onehot_at<SH>(before);
-                  m = oh | oh1 | oh3;
-                  oh3 = oh2; oh2 = oh1; oh1 = oh;
-                };
-                probe(fstart, m0, d0); probe(f0, m1, d1); probe(f1, m2, d2); probe(f2, m3, d3);
-                probe(f3, m4, d4); probe(f4, m5, d5); probe(f5, m6, d6); probe(f6, m7, d7);
+                /* before_0 .. before_7; only the ones a probe names are ever computed (k = 11: f0, f2, f4, f6) */
+                const uint32_t bj[8] = {fstart, f0, f1, f2, f3, f4, f5, f6};
+                uint32_t mm[4], dd[4];
+#pragma unroll
+                for (uint32_t t = 0; t < 4; t++) {
+                  const uint32_t wsrc = bj[2u * t + 1u];
+                  const uint32_t msrc = 2u * t >= D ? bj[2u * t - D] : pm[2u * t];
+                  dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u);
+                  mm[t] = *(mk_lds_cu32)(uintptr_t)(msrc & 0x3FCu);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < D; k++) pm[k] = bj[8u - D + k];
                 flo = f7;
-                __builtin_amdgcn_sched_barrier(0); /* all eight probes in flight before the first result is read */
+                __builtin_amdgcn_sched_barrier(0); /* all probes in flight before the first result is read */
                 __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) once, instead of a staggered wait per probe */
-                /* t == 0 <=> all filter bits set.  Binary descent over the min tree: a pair without hits costs one
-                 * test, a single hit about six. */
-                const uint32_t t0 = m0 & ~d0, t1 = m1 & ~d1, t2 = m2 & ~d2, t3 = m3 & ~d3;
-                const uint32_t t4 = m4 & ~d4, t5 = m5 & ~d5, t6 = m6 & ~d6, t7 = m7 & ~d7;
-                /* groups of 3, 3, 2: v_min3_u32 */
-                const uint32_t ta = min(min(t0, t1), t2), tb = min(min(t3, t4), t5), tc = min(t6, t7);
+                /* t == 0 <=> every bit of the pair's mask is set in its filter word */
+                const uint32_t tt0 = mm[0] & ~dd[0], tt1 = mm[1] & ~dd[1], tt2 = mm[2] & ~dd[2], tt3 = mm[3] & ~dd[3];
+                const uint32_t ta = min(min(tt0, tt1), tt2), tb = tt3, tc = 0xFFFFFFFFu;
                 if (__any(min(min(ta, tb), tc) == 0u)) {
                   /* some lane's filter test fired somewhere in this pair: those lanes append one pair record and the
                    * resolve kernel, which holds the same filter, finds the base.  jmin = first base with a complete
