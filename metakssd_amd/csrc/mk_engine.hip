@@ -673,12 +673,23 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
     const uint32_t used_slots = (uint32_t)blocks * waves;
     mk_evpair ev2{};
     if (e->profiling) { ev2 = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev2.a, e->stream)); }
-    /* the resolve workgroups build the LDS filter too (pair records name a pair, not a base): fewer, looping workgroups */
-    uint32_t rgrid = used_slots < (uint32_t)e->num_cu * 4u ? used_slots : (uint32_t)e->num_cu * 4u; /* measured: 512: 0.31, 1024: 0.30, 4096: 0.34 ms */
+    /* one resolve workgroup per CU (LDS: the exact filter + two rings per wave), each walking slots b, b + grid, ... */
+    uint32_t rgrid = used_slots < (uint32_t)e->num_cu ? used_slots : (uint32_t)e->num_cu;
 #ifdef MK_TUNING
     if (const char *t = getenv("MK_RESOLVE_GRID")) { const uint32_t g = (uint32_t)atoi(t); if (g && g <= used_slots) rgrid = g; }
 #endif
-    hipLaunchKernelGGL(mk_resolve_kernel, dim3(rgrid), dim3(MK_RESOLVE_THREADS), (size_t)a.bm_words * 4u, e->stream, a, used_slots);
+    const size_t rlds = (size_t)a.bm_words * 4u + (size_t)(MK_RESOLVE_THREADS / 64) * 2u * MK_RQ_CAP * sizeof(uint4);
+    {
+      const void *fn = (const void *)mk_resolve_kernel;
+      size_t *granted = nullptr;
+      for (auto &g : e->lds_granted) if (g.first == fn) granted = &g.second;
+      if (!granted) { e->lds_granted.emplace_back(fn, 0); granted = &e->lds_granted.back().second; }
+      if (rlds > *granted) {
+        MK_HIP(e, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        *granted = rlds;
+      }
+    }
+    hipLaunchKernelGGL(mk_resolve_kernel, dim3(rgrid), dim3(MK_RESOLVE_THREADS), rlds, e->stream, a, used_slots);
     MK_HIP(e, hipGetLastError());
     if (e->profiling) { MK_HIP(e, hipEventRecord(ev2.b, e->stream)); e->ev_resolve.push_back(ev2); }
   }

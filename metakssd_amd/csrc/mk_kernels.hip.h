@@ -215,16 +215,158 @@ __device__ __noinline__ void mk_resolve_inline(const mk_scan_args *ka, bool hit,
 
 __device__ __forceinline__ void mk_build_filter(uint32_t *bitmap, const mk_scan_args &a);
 
-/* resolves the candidates the scan kernel appended: a workgroup builds the LDS filter once and then walks producer slots */
-#define MK_RESOLVE_THREADS 1024 /* measured 256: 0.233 ms, 512: 0.230, 1024: 0.212 (50 M reads, 7 M candidates) */
+/* ---- resolve kernel ----------------------------------------------------------------------------------------------------
+ * Resolves the candidates the scan kernel appended.  A workgroup builds the exact per-base LDS filter once and walks
+ * producer slots; per record the work is LDS-only (which of the window's 8 bases pass the filter).  What follows a passing
+ * base is a chain of dependent global accesses (accept bitmap in L2 -> .shuf entry -> table slot load -> CAS -> atomicMax),
+ * and only about one record in seven has such a base: run lane by lane behind the filter test, every round of that chain
+ * would serve a handful of lanes and the kernel is bound by the chain's latency (0.39 ms for 22.8 M records).  So the
+ * stages are decoupled through two small per-wave rings in LDS:
+ *     records --filter test--> ring 1 {forward k-mer, ordinal} --canonical k-mer + accept bit--> ring 2 {canonical k-mer,
+ *     ordinal} --.shuf entry, key, upsert--> table
+ * A ring is drained 64 entries at a time, one per lane, so every round of either chain runs with all lanes busy.  Same-wave
+ * producer and consumer: no workgroup barrier (DS operations of a wave execute in order).  The table update commutes
+ * (mk_upsert), so the order in which candidates arrive is free. */
+#define MK_RESOLVE_THREADS 1024
+#define MK_RQ_CAP 128u /* ring entries per wave: a push adds at most 64 to fewer than 64 */
+
+struct mk_wring {
+  uint4 *q;
+  uint32_t head, tail; /* wave-uniform */
+};
+__device__ __forceinline__ void mk_wring_push(mk_wring &w, bool has, const uint4 v) {
+  const uint64_t b = __ballot(has);
+  if (has) w.q[(w.tail + mk_mbcnt(b)) & (MK_RQ_CAP - 1u)] = v;
+  w.tail += (uint32_t)__popcll(b);
+}
+/* takes up to 64 entries: lane l gets entry head + l; returns whether this lane got one */
+__device__ __forceinline__ bool mk_wring_pop(mk_wring &w, uint32_t lane, uint4 &v) {
+  const uint32_t have = w.tail - w.head, n = have < 64u ? have : 64u;
+  v = w.q[(w.head + lane) & (MK_RQ_CAP - 1u)];
+  w.head += n;
+  return lane < n;
+}
+
+/* ring 2 -> table: .shuf entry (iseq2comem.c:692-695), key (:696-699), upsert */
+__device__ __forceinline__ void mk_resolve_accepted(const mk_scan_args &a, bool on, const uint4 v) {
+  if (!on) return;
+  const uint64_t uni = ((uint64_t)v.y << 32) | v.x;
+  const uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
+  const int32_t pf = a.shuf[dim];
+  if (pf >= a.kp.dim_start && pf < a.kp.dim_end)
+    mk_upsert(a.tab, a.kp.S, mk_reduce_key(a.kp, uni, (uint64_t)(pf - a.kp.dim_start)), ((uint64_t)v.w << 32) | v.z, 1u);
+}
+/* ring 1 -> ring 2: canonical k-mer (iseq2comem.c:691) and the accept bit of its inner substring */
+__device__ __forceinline__ void mk_resolve_candidate(const mk_scan_args &a, bool on, const uint4 v, mk_wring &r2) {
+  bool pass = false;
+  uint4 o = v;
+  if (on) {
+    const uint64_t fwd = mk_scan_to_ref_codes(((uint64_t)v.y << 32) | v.x);
+    const uint64_t rc = mk_revcomp(fwd, a.kp.TL);
+    const uint64_t uni = fwd < rc ? fwd : rc;
+    const uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
+    pass = (a.accept_bits[dim >> 5] >> (dim & 31u)) & 1u;
+    o.x = (uint32_t)uni; o.y = (uint32_t)(uni >> 32);
+  }
+  mk_wring_push(r2, pass, o);
+}
+
 __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk_scan_args a, uint32_t nslots) {
   extern __shared__ __align__(16) uint32_t rlds[];
   mk_build_filter(rlds, a);
-  for (uint32_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
-    const uint32_t n = a.cand_count[slot];
-    const uint4 *c = a.cand + (size_t)slot * a.cand_cap;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) mk_resolve_record(a, c[i], rlds);
+  const uint32_t lane = mk_lane(), wave = threadIdx.x >> 6, wave0 = wave << 6;
+  uint4 *rings = (uint4 *)(rlds + a.bm_words) + (size_t)wave * 2u * MK_RQ_CAP;
+  mk_wring r1{rings, 0u, 0u}, r2{rings + MK_RQ_CAP, 0u, 0u};
+
+  auto drain2 = [&](uint32_t least) {
+    while (r2.tail - r2.head >= least) {
+      uint4 v;
+      const bool on = mk_wring_pop(r2, lane, v);
+      mk_wave_lds_fence();
+      mk_resolve_accepted(a, on, v);
+    }
+  };
+  auto drain1 = [&](uint32_t least) {
+    while (r1.tail - r1.head >= least) {
+      uint4 v;
+      const bool on = mk_wring_pop(r1, lane, v);
+      mk_wave_lds_fence();
+      mk_resolve_candidate(a, on, v, r2);
+      mk_wave_lds_fence();
+      drain2(64u);
+    }
+  };
+
+  /* pair records only come from the tuned kernels (k = 10, 11); for any other geometry every record is a single k-mer */
+  const uint32_t K = a.kp.TL >> 1, SH = K > 7u ? 2u * (K - 6u) - 2u : 0u;
+  const uint32_t hm = a.kp.TL > 16u ? (uint32_t)((1ull << (2u * a.kp.TL - 32u)) - 1ull) : 0u; /* mk_kmer_hi<K>::HMASK */
+  const uint32_t wmask = a.bm_words - 1u;
+
+  /* this wave's records: blocks wave, wave + WAVES, ... of every slot the workgroup owns; the next block's load is issued
+   * before the current one is worked on */
+  uint32_t slot = blockIdx.x, base = wave0, n = slot < nslots ? a.cand_count[slot] : 0u;
+  auto fetch = [&](uint4 &r) -> bool { /* false: nothing left */
+    while (slot < nslots && base >= n) {
+      slot += gridDim.x;
+      base = wave0;
+      n = slot < nslots ? a.cand_count[slot] : 0u;
+    }
+    if (slot >= nslots) return false;
+    const uint32_t i = base + lane;
+    r = i < n ? a.cand[(size_t)slot * a.cand_cap + i] : make_uint4(0u, 0u, 0u, 0u); /* all-zero pair record: e == 0, no base tested */
+    base += blockDim.x;
+    return true;
+  };
+
+  uint4 r, rn;
+  bool more = fetch(r);
+  while (more) {
+    more = fetch(rn);
+    const bool single = (r.w & 0x80000000u) != 0u;
+    if (__any(single)) { /* slow tiers and the generic kernel hand over whole k-mers */
+      mk_wring_push(r1, single, make_uint4(r.x, r.y, r.z, r.w & 0x7FFFFFFFu));
+      mk_wave_lds_fence();
+      drain1(64u);
+    }
+    /* pair record: which of the window's bases pass the exact filter?  The mask of base j is the OR of three one-hot words,
+     * of the low 5 bits of the substrings 0, 1 and 3 bases earlier (mk_filter_mask: fields at offsets 0, 2, 6). */
+    const uint32_t jmin = (r.y >> 9) & 7u, e = single ? 0u : (r.y >> 12) & 15u;
+    const uint32_t lo = r.y & 0xFFFF0000u;
+    uint32_t hits = 0;
+    {
+      uint32_t oh3 = 1u << ((r.x >> (SH + 6u)) & 31u), oh2 = 1u << ((r.x >> (SH + 4u)) & 31u), oh1 = 1u << ((r.x >> (SH + 2u)) & 31u);
+      uint32_t before = r.x;
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t oh0 = 1u << ((before >> SH) & 31u);
+        const uint32_t word = rlds[(before >> (SH + 10u)) & wmask];
+        if (((oh0 | oh1 | oh3) & ~word) == 0u) hits |= 1u << j;
+        oh3 = oh2; oh2 = oh1; oh1 = oh0;
+        before = __builtin_amdgcn_alignbit(r.x, lo, 30u - 2u * j);
+      }
+      hits &= (0xFFu << jmin) & ~(0xFFFFFFFFu << e);
+    }
+    if (__any(hits != 0u)) {
+      const uint32_t pos0 = (r.y & 0x1FFu) << 3, h2 = r.z & 0xFFFFu, h3 = r.z >> 16;
+      const uint64_t ord0 = ((a.first_ord + (uint64_t)r.w) << 12) | pos0;
+      do {
+        const bool has = hits != 0u;
+        const uint32_t j = has ? (uint32_t)__builtin_ctz(hits) : 0u;
+        hits &= hits - 1u;
+        const uint32_t dd = 2u * (j + 1u);
+        const uint32_t fl = __builtin_amdgcn_alignbit(r.x, lo, 30u - 2u * j);
+        const uint32_t fhi = ((h3 << dd) | (h2 >> (16u - dd))) & hm;
+        const uint64_t ord = ord0 + j;
+        mk_wring_push(r1, has, make_uint4(fl, fhi, (uint32_t)ord, (uint32_t)(ord >> 32)));
+        mk_wave_lds_fence();
+        drain1(64u);
+      } while (__any(hits != 0u));
+    }
+    r = rn;
   }
+  mk_wave_lds_fence();
+  drain1(1u);
+  drain2(1u);
 }
 
 /* LDS filter: a blocked Bloom filter over B = A u revcomp(A), A = the accepted inner substrings
