@@ -673,8 +673,9 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
     const uint32_t used_slots = (uint32_t)blocks * waves;
     mk_evpair ev2{};
     if (e->profiling) { ev2 = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev2.a, e->stream)); }
-    /* one resolve workgroup per CU (LDS: the exact filter + two rings per wave), each walking slots b, b + grid, ... */
-    uint32_t rgrid = used_slots < (uint32_t)e->num_cu ? used_slots : (uint32_t)e->num_cu;
+    /* one resolve workgroup per CU (LDS: the exact filter + two rings per wave); a resolve wave owns whole slots */
+    const uint32_t rwgs = (used_slots + MK_RESOLVE_THREADS / 64 - 1) / (MK_RESOLVE_THREADS / 64);
+    uint32_t rgrid = rwgs < (uint32_t)e->num_cu ? rwgs : (uint32_t)e->num_cu;
 #ifdef MK_TUNING
     if (const char *t = getenv("MK_RESOLVE_GRID")) { const uint32_t g = (uint32_t)atoi(t); if (g && g <= used_slots) rgrid = g; }
 #endif

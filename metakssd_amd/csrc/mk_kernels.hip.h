@@ -229,6 +229,9 @@ __device__ __forceinline__ void mk_build_filter(uint32_t *bitmap, const mk_scan_
  * (mk_upsert), so the order in which candidates arrive is free. */
 #define MK_RESOLVE_THREADS 1024
 #define MK_RQ_CAP 128u /* ring entries per wave: a push adds at most 64 to fewer than 64 */
+#ifndef MK_RESOLVE_UNROLL
+#define MK_RESOLVE_UNROLL 4u /* blocks of 64 records a wave has in flight */
+#endif
 
 struct mk_wring {
   uint4 *q;
@@ -274,7 +277,7 @@ __device__ __forceinline__ void mk_resolve_candidate(const mk_scan_args &a, bool
 __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk_scan_args a, uint32_t nslots) {
   extern __shared__ __align__(16) uint32_t rlds[];
   mk_build_filter(rlds, a);
-  const uint32_t lane = mk_lane(), wave = threadIdx.x >> 6, wave0 = wave << 6;
+  const uint32_t lane = mk_lane(), wave = threadIdx.x >> 6;
   uint4 *rings = (uint4 *)(rlds + a.bm_words) + (size_t)wave * 2u * MK_RQ_CAP;
   mk_wring r1{rings, 0u, 0u}, r2{rings + MK_RQ_CAP, 0u, 0u};
 
@@ -302,26 +305,30 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
   const uint32_t hm = a.kp.TL > 16u ? (uint32_t)((1ull << (2u * a.kp.TL - 32u)) - 1ull) : 0u; /* mk_kmer_hi<K>::HMASK */
   const uint32_t wmask = a.bm_words - 1u;
 
-  /* this wave's records: blocks wave, wave + WAVES, ... of every slot the workgroup owns; the next block's load is issued
-   * before the current one is worked on */
-  uint32_t slot = blockIdx.x, base = wave0, n = slot < nslots ? a.cand_count[slot] : 0u;
-  auto fetch = [&](uint4 &r) -> bool { /* false: nothing left */
+  /* a wave owns whole slots (slot = global wave index + multiples of the number of waves: one slot each when the grid
+   * matches the scan's) and takes MK_RESOLVE_UNROLL blocks of 64 records per round; the loads of the next round are issued
+   * before the current one is worked on -- one 16-byte load per lane in flight would cap the kernel at
+   * 16 KiB per CU per memory latency, about 2 TB/s */
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wave, base = 0u, n = slot < nslots ? a.cand_count[slot] : 0u;
+  auto fetch = [&](uint4 (&r)[MK_RESOLVE_UNROLL]) -> bool { /* false: nothing left */
     while (slot < nslots && base >= n) {
-      slot += gridDim.x;
-      base = wave0;
+      slot += nwaves;
+      base = 0u;
       n = slot < nslots ? a.cand_count[slot] : 0u;
     }
     if (slot >= nslots) return false;
-    const uint32_t i = base + lane;
-    r = i < n ? a.cand[(size_t)slot * a.cand_cap + i] : make_uint4(0u, 0u, 0u, 0u); /* all-zero pair record: e == 0, no base tested */
-    base += blockDim.x;
+    const uint4 *c = a.cand + (size_t)slot * a.cand_cap;
+#pragma unroll
+    for (uint32_t u = 0; u < MK_RESOLVE_UNROLL; u++) {
+      const uint32_t i = base + u * 64u + lane;
+      r[u] = i < n ? c[i] : make_uint4(0u, 0u, 0u, 0u); /* all-zero pair record: e == 0, no base tested */
+    }
+    base += 64u * MK_RESOLVE_UNROLL;
     return true;
   };
 
-  uint4 r, rn;
-  bool more = fetch(r);
-  while (more) {
-    more = fetch(rn);
+  auto process = [&](const uint4 r) {
     const bool single = (r.w & 0x80000000u) != 0u;
     if (__any(single)) { /* slow tiers and the generic kernel hand over whole k-mers */
       mk_wring_push(r1, single, make_uint4(r.x, r.y, r.z, r.w & 0x7FFFFFFFu));
@@ -362,7 +369,16 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
         drain1(64u);
       } while (__any(hits != 0u));
     }
-    r = rn;
+  };
+
+  uint4 r[MK_RESOLVE_UNROLL], rn[MK_RESOLVE_UNROLL];
+  bool more = fetch(r);
+  while (more) {
+    more = fetch(rn);
+#pragma unroll
+    for (uint32_t u = 0; u < MK_RESOLVE_UNROLL; u++) process(r[u]);
+#pragma unroll
+    for (uint32_t u = 0; u < MK_RESOLVE_UNROLL; u++) r[u] = rn[u];
   }
   mk_wave_lds_fence();
   drain1(1u);
@@ -457,13 +473,19 @@ __device__ __forceinline__ uint32_t mk_nonzero_bytes(uint32_t v) { /* bit 7 of b
  * z = x_j[0..21] = x_{j+1}[2..23].  The tuned loop probes ONE key z per PAIR of bases against a filter over
  *     Z = { d mod 2^22 : d in B } u { d >> 2 : d in B },       B = A u revcomp(A) as above:
  * x_j in B puts z in the first set, x_{j+1} in B in the second, so a pair without a filter hit holds no accepted k-mer.
- * Word = z[8..21] (the same 16384 words), bits = a table lookup by z[0..7] (256 masks of up to four bits each, 1 KiB at LDS
+ * Word = z[8..21] (the same 16384 words), bits = a table lookup by z[0..7] (256 masks of six bits each, 1 KiB at LDS
  * offset 0): the 22 bits of z are all used, none twice.  Half the LDS probes and a third of the instructions of the
  * per-base test; it flags about 1.6 times as many 8-base windows (z drops two bits of either substring), which the resolve
  * kernel, working per base with the filter above, throws out again. */
 __device__ __forceinline__ uint32_t mk_zmask(uint32_t b) {
-  const uint32_t h = b * 0x9E3779B1u;
-  return (1u << (h >> 27)) | (1u << ((h >> 22) & 31u)) | (1u << ((h >> 17) & 31u)) | (1u << ((h >> 12) & 31u));
+  /* six DISTINCT bit positions per entry (simulated over random accept sets: 1.96 % of the 8-base windows flagged, against
+   * 2.46 % with four positions that may coincide; five to seven positions are within 0.03 % of each other, eight is worse) */
+  uint32_t m = 0, h = b * 0x9E3779B1u + 0x7F4A7C15u;
+  while (__builtin_popcount(m) < 6) {
+    m |= 1u << (h >> 27);
+    h = h * 0x85EBCA6Bu + 0xC2B2AE35u;
+  }
+  return m;
 }
 __device__ __forceinline__ void mk_build_zfilter(uint32_t *masktab, uint32_t *bitmap, const mk_scan_args &a) {
   for (uint32_t i = threadIdx.x; i < MK_ZMASK_WORDS; i += blockDim.x) masktab[i] = mk_zmask(i);
@@ -800,7 +822,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
               decode(w0, c0, x0);
               decode(w1, c1, x1);
               uint32_t e = 8u; /* bases of this pair in front of the (common) newline */
-              const uint32_t bad = x0 | x1; /* non-zero: a byte of this lane's pair is not ACGTacgt */
+              const uint64_t bad = ((uint64_t)x1 << 32) | x0; /* non-zero: a byte of this lane's pair is not ACGTacgt (one 64-bit compare) */
               /* Not eight valid bases everywhere: still fine if every lane has the same bytes-before-newline pattern
                * with only valid bases in front of it (the tail of fixed-length reads).  Returns false when the pair
                * has to go to the slow path; sets e otherwise. */
@@ -819,7 +841,9 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
               };
               /* tested BEFORE the probes go out: folding this test into the hit test (one branch per pair, probes
                * issued speculatively) measured 4 % slower */
-              if (!__all(bad == 0u) && !common_newline()) { have_pair = true; break; }
+              uint64_t lanes_ok; /* asm: the compiler splits the compare into an OR over a re-derived x0 and a 32-bit compare (two more VALU) */
+              asm("v_cmp_eq_u64_e64 %0, 0, %1" : "=s"(lanes_ok) : "v"(bad));
+              if (lanes_ok != __builtin_amdgcn_read_exec() && !common_newline()) { have_pair = true; break; }
               const uint32_t fstart = flo;
               /* the eight codes of the pair packed big-endian into the top 16 bits of `lo` (one v_dot4_u32_u8 per dword:
                * weights 64,16,4,1; one v_perm_b32 to place the two bytes): the low word after base j is then ONE funnel
