@@ -16,7 +16,7 @@ MK_OK = 0
 MK_ERR_ARG, MK_ERR_NO_DEVICE, MK_ERR_HIP, MK_ERR_CROWDED = -1, -2, -3, -4
 MK_ERR_STATE, MK_ERR_IO, MK_ERR_FORMAT, MK_ERR_NOMEM = -5, -6, -7, -8
 MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET, MK_MODE_OCC_SET = 0, 1, 2, 3
-MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP, MK_OPT_DIRECT_HOST = 1, 2, 3, 4
+MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP, MK_OPT_DIRECT_HOST, MK_OPT_FRONT_BITS = 1, 2, 3, 4, 5
 
 
 class MkError(RuntimeError):
@@ -332,7 +332,7 @@ def fasta_windows(buf, TL, stride, chunk=None):
 class Engine:
     """one GPU's sketch engine (mk_engine): begin -> push_reads* -> finish"""
 
-    def __init__(self, shuf, device=0, sparse=None, cand_cap=None, component_sz=8):
+    def __init__(self, shuf, device=0, sparse=None, cand_cap=None, component_sz=8, front_bits=None):
         self.shuf = shuf  # keeps the host table alive
         self.params = shuf.params(component_sz)
         self.h = C.c_void_p()
@@ -344,6 +344,8 @@ class Engine:
             self.set_option(MK_OPT_SPARSE, int(sparse))
         if cand_cap is not None:
             self.set_option(MK_OPT_CAND_CAP, int(cand_cap))
+        if front_bits is not None:
+            self.set_option(MK_OPT_FRONT_BITS, int(front_bits))
 
     def set_option(self, option, value):
         """mk_engine_set_option: MK_OPT_SPARSE (-1/0/1), MK_OPT_CAND_CAP (records per scan wave); between sketches only"""

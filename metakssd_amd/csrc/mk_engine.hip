@@ -53,7 +53,13 @@ struct mk_engine {
   uint32_t *d_chunk = nullptr; /* [component][chunk] */
   uint32_t nchunks = 0;
   unsigned long long *d_comp_totals = nullptr, *h_comp_totals = nullptr; /* [component] */
-  unsigned long long *d_counters = nullptr; /* [0]=distinct, [1]=dump total, [2..3]=err flags (as u32) */
+  unsigned long long *d_counters = nullptr; /* [0]=distinct, [1]=dump total, [2..3]=err flags (as u32), [4..5]=mk_table::front (as u32[4]) */
+  void *d_front = nullptr;          /* front table: kc1[front_slots], ordinv1[front_slots] (mk_table, "Front table") */
+  mk_front *d_front_desc = nullptr; /* its descriptor in device memory (mk_table::fr) */
+  mk_front front{};                 /* host copy */
+  uint64_t front_slots = 0;
+  int front_bits_opt = -1;          /* MK_OPT_FRONT_BITS */
+  bool big_maybe_dirty = true;      /* the S-slot table may hold keys: begin clears it (false: known to be all zero) */
   unsigned long long *h_counters = nullptr; /* pinned mirror */
   unsigned long long *h_setup = nullptr, *d_setup = nullptr; /* start-up: number of accepted substrings found on the device */
   uint32_t setup_expect = 0;
@@ -236,7 +242,7 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipDeviceSynchronize();
   hipFree(e->d_setup);
   hipFree(e->d_cand); hipFree(e->d_cand_count);
-  hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_accept_bits); hipFree(e->d_tab); hipFree(e->d_slot);
+  hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_accept_bits); hipFree(e->d_tab); hipFree(e->d_front); hipFree(e->d_front_desc); hipFree(e->d_slot);
   hipFree(e->d_dirty_acc); hipFree(e->d_dirty_slot); hipFree(e->d_list_acc); hipFree(e->d_list_slot); hipFree(e->d_nlist);
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters);
@@ -298,6 +304,34 @@ static double mk_tick_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); re
 #else
 #define MK_TICK(label) do { } while (0)
 #endif
+
+/* front table of 2^bits slots (0: none; -1: by table size -- the power of two at or below a sixth of the slots, from 2^20
+ * slots up, with dense bookkeeping) */
+static int mk_config_front(mk_engine *e, int bits) {
+  hipFree(e->d_front);
+  e->d_front = nullptr; e->front_slots = 0;
+  e->tab.fr = nullptr;
+  e->front = mk_front{};
+  e->big_maybe_dirty = true;
+  const uint64_t S = e->P.hashsize;
+  if (bits < 0) {
+    bits = 0;
+    if (!e->sparse && S >= (1ull << 20)) while ((2ull << bits) <= S / 6) bits++; /* hashsize is a prime just below a power of two: S/8 would halve it */
+  }
+  if (bits == 0 || e->sparse) return MK_OK;
+  e->front_slots = 1ull << bits;
+  MK_HIP(e, hipMalloc(&e->d_front, e->front_slots * 16));
+  if (!e->d_front_desc) MK_HIP(e, hipMalloc((void **)&e->d_front_desc, sizeof(mk_front)));
+  e->front.kc1 = (unsigned long long *)e->d_front;
+  e->front.ordinv1 = e->front.kc1 + e->front_slots;
+  e->front.state = (uint32_t *)(e->d_counters + 4);
+  { uint32_t sb = 0; while ((1ull << sb) < S) sb++; e->front.shift = sb > (uint32_t)bits ? sb - (uint32_t)bits : 0u; } /* (S-1) >> shift < 2^bits */
+  e->front.mask = (uint32_t)(e->front_slots - 1);
+  e->front.limit = (uint32_t)(e->front_slots / 4); /* closed to new keys from a quarter full at the start of a launch */
+  MK_HIP(e, hipMemcpy(e->d_front_desc, &e->front, sizeof(mk_front), hipMemcpyHostToDevice));
+  e->tab.fr = e->d_front_desc;
+  return MK_OK;
+}
 
 static int mk_engine_init(mk_engine *e, const mk_params *p) {
 #ifdef MK_TUNING
@@ -377,6 +411,7 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   /* sparse bookkeeping from 2^26 slots up (L2K11: 537 M slots for a genome's few thousand keys);
    * mk_engine_set_option(MK_OPT_SPARSE) forces it off/on (the tests run the small tables both ways) */
   { int rc = mk_config_sparse(e, S >= (1ull << 26)); if (rc) return rc; }
+  { int rc = mk_config_front(e, -1); if (rc) return rc; }
   e->dist.cap = S; /* hashlimit+1 entries suffice for KOC/SET; MK_MODE_OCC_SET may fill the table (fastq2co never aborts) */
   MK_HIP(e, hipMalloc(&e->dist.key, e->dist.cap * 8));
   MK_HIP(e, hipMalloc(&e->dist.ord, e->dist.cap * 8));
@@ -431,9 +466,15 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
   MK_HIP(e, hipSetDevice(e->device));
   MK_HIP(e, hipStreamSynchronize(e->stream));
   switch (option) {
-    case MK_OPT_SPARSE:
+    case MK_OPT_SPARSE: {
       if (value < -1 || value > 1) return mk_fail(e, MK_ERR_ARG, "MK_OPT_SPARSE takes -1 (by table size), 0 or 1");
-      return mk_config_sparse(e, value < 0 ? e->P.hashsize >= (1u << 26) : value != 0);
+      int rc = mk_config_sparse(e, value < 0 ? e->P.hashsize >= (1u << 26) : value != 0);
+      return rc ? rc : mk_config_front(e, e->front_bits_opt); /* no front table with sparse bookkeeping */
+    }
+    case MK_OPT_FRONT_BITS:
+      if (value < -1 || (value > 0 && value < 3) || value > 28) return mk_fail(e, MK_ERR_ARG, "MK_OPT_FRONT_BITS takes -1 (by table size), 0 (none) or 3..28");
+      e->front_bits_opt = (int)value;
+      return mk_config_front(e, e->front_bits_opt);
     case MK_OPT_CAND_CAP:
       if (value < 0 || value > (1 << 20)) return mk_fail(e, MK_ERR_ARG, "MK_OPT_CAND_CAP takes 0 .. 2^20 records per scan wave");
       return mk_config_cand(e, (uint32_t)value);
@@ -544,7 +585,12 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
                        (const uint32_t *)e->d_list_slot, (const uint32_t *)(e->d_nlist + 1), (uint32_t)MK_DUMP_SHIFT);
     MK_HIP(e, hipGetLastError());
   } else {
-    MK_HIP(e, hipMemsetAsync(e->d_tab, 0, e->tab_bytes, e->stream));
+    /* behind a front table the S-slot table is cleared only when the last sketch may have used it */
+    if (!e->tab.fr || e->big_maybe_dirty) MK_HIP(e, hipMemsetAsync(e->d_tab, 0, e->tab_bytes, e->stream));
+    if (e->tab.fr) {
+      MK_HIP(e, hipMemsetAsync(e->d_front, 0, e->front_slots * 16, e->stream));
+      e->big_maybe_dirty = false;
+    }
     if (e->sparse) {
       MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)e->kp.S * sizeof(uint32_t), e->stream));
       MK_HIP(e, hipMemsetAsync(e->d_dirty_acc, 0, (size_t)e->acc_words * 4, e->stream));
@@ -653,6 +699,7 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   }
 #endif
 
+  e->big_maybe_dirty = true; /* until a counter copy says otherwise (mk_check_counters) */
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   hipError_t r;
@@ -855,10 +902,23 @@ static int mk_compact_launch(mk_engine *e) {
   if (e->sparse) { /* only the blocks somebody installed a key in */
     hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_acc, e->acc_words, e->d_list_acc, e->d_nlist + 2, 0);
     hipLaunchKernelGGL(mk_compact_kernel<MK_SPARSE_BLOCK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
-                       e->d_counters, drop0, (const uint32_t *)e->d_list_acc, (const uint32_t *)(e->d_nlist + 2));
+                       e->d_counters, drop0, (const uint32_t *)e->d_list_acc, (const uint32_t *)(e->d_nlist + 2), (const uint32_t *)nullptr, 0u);
   } else {
-    hipLaunchKernelGGL(mk_compact_kernel<MK_COMPACT_CHUNK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
-                       e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+    if (e->tab.fr) {
+      /* big table empty (state[1] == 0, the common case): list the front table, the other two kernels return at once.
+       * Otherwise fold the front table into the big one and list that. */
+      const uint32_t *big_used = e->front.state + 1;
+      mk_table ft = e->tab;
+      ft.kc = e->front.kc1; ft.ordinv = e->front.ordinv1;
+      hipLaunchKernelGGL(mk_compact_kernel<MK_COMPACT_CHUNK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, ft, (uint32_t)e->front_slots,
+                         e->dist, e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr, big_used, 0u);
+      hipLaunchKernelGGL(mk_front_fold_kernel, dim3(blocks), dim3(1024), 0, e->stream, e->tab, e->kp.S);
+      hipLaunchKernelGGL(mk_compact_kernel<MK_COMPACT_CHUNK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
+                         e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr, big_used, 1u);
+    } else {
+      hipLaunchKernelGGL(mk_compact_kernel<MK_COMPACT_CHUNK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
+                         e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
+    }
   }
   MK_HIP(e, hipGetLastError());
   return MK_OK;
@@ -874,6 +934,7 @@ static uint64_t mk_key_limit(const mk_engine *e) {
 static int mk_check_counters(mk_engine *e) {
   const uint32_t errflags = (uint32_t)(e->h_counters[2] & 0xffffffffu);
   e->D = e->h_counters[0];
+  if (e->tab.fr && (uint32_t)(e->h_counters[4] >> 32) == 0u && !e->region_open) e->big_maybe_dirty = false; /* state[1]: nobody used the big table */
   if (errflags & 4u) return mk_fail(e, MK_ERR_HIP, "scan kernel: LDS filter not at offset 0");
   if ((errflags & 1u) || e->D > mk_key_limit(e))
     return mk_fail(e, MK_ERR_CROWDED, "the context space is too crowd (%llu distinct keys > limit %llu), try k=%d",
@@ -887,7 +948,7 @@ static int mk_compact(mk_engine *e) {
   if (e->compacted && !e->region_open) return MK_OK;
   int rc = mk_compact_launch(e);
   if (rc) return rc;
-  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
   MK_HIP(e, hipStreamSynchronize(e->stream));
   rc = mk_check_counters(e);
   if (rc) return rc;
@@ -930,9 +991,10 @@ extern "C" int mk_partial_import(mk_engine *e, const uint64_t *keys_dev, const u
   if (n == 0) return MK_OK;
   if (!keys_dev || !counts_dev || !ords_dev) return MK_ERR_ARG;
   MK_HIP(e, hipSetDevice(e->device));
-  uint64_t blocks = (n + 255) / 256;
-  if (blocks > (uint64_t)e->num_cu * 16) blocks = (uint64_t)e->num_cu * 16;
-  hipLaunchKernelGGL(mk_import_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, e->tab, e->kp.S,
+  uint64_t blocks = (n + 1023) / 1024;
+  if (blocks > (uint64_t)e->num_cu * 2) blocks = (uint64_t)e->num_cu * 2;
+  e->big_maybe_dirty = true;
+  hipLaunchKernelGGL(mk_import_kernel, dim3((unsigned)blocks), dim3(1024), 0, e->stream, e->tab, e->kp.S,
                      (const unsigned long long *)keys_dev, counts_dev, (const unsigned long long *)ords_dev, n);
   MK_HIP(e, hipGetLastError());
   e->compacted = false;
@@ -1016,7 +1078,7 @@ extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
   MK_HIP(e, hipGetLastError());
   rc = mk_launch_dump(e, true);
   if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
-  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
   MK_HIP(e, hipMemcpyAsync(e->h_comp_totals, e->d_comp_totals, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
   if (e->profiling) MK_HIP(e, hipEventRecord(ev.b, e->stream));
   MK_HIP(e, hipStreamSynchronize(e->stream));

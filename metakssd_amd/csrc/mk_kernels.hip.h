@@ -47,7 +47,27 @@ struct mk_table {
    * blocks that were used.  NULL = dense bookkeeping (every pass walks all S slots). */
   uint32_t *dirty;
   uint32_t dirty_shift;
+  /* Front table (dense bookkeeping, tables of 2^20 slots and more): a small accumulation table of the same slot format in
+   * front of the S-slot one.  The S slots exist because the reference's hashlimit admits 0.6 S distinct keys; a sketch of
+   * 50 M reads leaves 1.6 M in 33.5 M slots, and every pass over the table (clear, compaction) pays for S.  The resolve and
+   * import kernels put keys into the front table while it is open (fewer than `limit` keys at the end of the last launch) and
+   * a key finds a place within MK_FRONT_PROBES probes; everything else -- a closed or crowded front table, the scan kernel's
+   * own overflow path -- goes to the big table and sets state[1].  The two tables are independent partial accumulators
+   * (a key may sit in both): when state[1] is set, the compaction first folds the front table into the big one
+   * (mk_front_fold_kernel: counts add, first ordinals combine by min, exactly the multi-GPU merge) and lists the big table;
+   * otherwise it lists the front table and the big one is neither read nor, at the next begin, cleared. */
+  const struct mk_front *fr; /* NULL = no front table.  Behind a pointer: the table descriptor travels in every kernel's
+                              * argument block, and 40 more bytes of it cost the scan kernel 56 more spilled SGPRs */
 };
+struct mk_front {
+  unsigned long long *kc1, *ordinv1;
+  uint32_t *state;      /* [0] keys installed in the front table, [1] != 0: the big table holds keys, [2] != 0: closed, [3] launch ticket */
+  uint32_t shift;       /* home slot in the big table >> shift = first front slot: ceil(log2 S) - log2(front slots) */
+  uint32_t mask;        /* front slots - 1 */
+  uint32_t limit;
+  uint32_t reserved;
+};
+#define MK_FRONT_PROBES 16u
 
 struct mk_scan_args {
   const uint8_t *rows;
@@ -110,7 +130,11 @@ __device__ __forceinline__ uint64_t mk_reduce_key(const mk_keyparams &kp, uint64
 /* counted upsert into the accumulation table (arrival order is irrelevant: counts add, first ordinals
  * combine by min; the reference-order layout is rebuilt afterwards by mk_layout_kernel).
  * New key: one CAS (installs key with count `add`) + one atomicMax; known key: one atomicAdd + one atomicMax. */
-__device__ __forceinline__ void mk_upsert(const mk_table &tab, uint32_t S, uint64_t key, uint64_t ord, uint32_t add) {
+__device__ __forceinline__ void mk_upsert_big(const mk_table &tab, uint32_t S, uint64_t key, uint64_t ord, uint32_t add) {
+  if (tab.fr) { /* the compaction has to look at the big table */
+    uint32_t *st = tab.fr->state;
+    if (__hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(&st[1], 1u);
+  }
   uint32_t n, h2;
   mk_probe_init(key, S, n, h2);
   const unsigned long long fresh = ((unsigned long long)key << MK_CNT_BITS) | add;
@@ -136,6 +160,52 @@ __device__ __forceinline__ void mk_upsert(const mk_table &tab, uint32_t S, uint6
     n = mk_probe_next(n, h2, S);
   }
   atomicOr(&tab.err[0], 1u); /* every slot taken by other keys */
+}
+/* the same through the front table when it is open (front_open: state[2] == 0 at the start of the launch).  The front slot
+ * of a key is its home slot in the big table scaled down ((key % S) >> shift), so that a pass over the front table meets
+ * the keys in the order of their home slots, which is the order the layout kernel and the dump walk the layout table in.
+ * Returns true when the key was installed in the front table (the caller counts those into state[0]). */
+__device__ __forceinline__ bool mk_upsert(const mk_table &tab, uint32_t S, uint64_t key, uint64_t ord, uint32_t add, bool front_open) {
+  if (front_open) {
+    const mk_front f = *tab.fr;
+    uint32_t n = (uint32_t)(key % S) >> f.shift;
+    const uint32_t step = (uint32_t)(key * 0x9E3779B1u) | 1u; /* odd: the sequence visits every slot of the power-of-two table */
+    const unsigned long long fresh = ((unsigned long long)key << MK_CNT_BITS) | add;
+    for (uint32_t i = 0; i < MK_FRONT_PROBES; i++) {
+      unsigned long long cur = __hip_atomic_load(&f.kc1[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool mine = false;
+      if (cur == 0ull) {
+        const unsigned long long prev = atomicCAS(&f.kc1[n], 0ull, fresh);
+        if (prev == 0ull) mine = true;
+        else cur = prev;
+      }
+      if (mine || (cur >> MK_CNT_BITS) == key) {
+        if (!mine && (cur & MK_CNT_MASK) < MK_CNT_SAT) atomicAdd(&f.kc1[n], (unsigned long long)add);
+        atomicMax(&f.ordinv1[n], ~(unsigned long long)ord);
+        return mine;
+      }
+      n = (n + step) & f.mask;
+    }
+  }
+  mk_upsert_big(tab, S, key, ord, add);
+  return false;
+}
+/* end of a launch that inserts: the workgroup's count of front-table installs goes to front[0]; the last workgroup to get
+ * here decides whether the front table is still open for the NEXT launch.  Called by one thread per workgroup. */
+__device__ __forceinline__ void mk_front_launch_end(const mk_table &tab, uint32_t installed, uint32_t nworkgroups) {
+  if (!tab.fr) return;
+  uint32_t *st = tab.fr->state;
+  if (installed) atomicAdd(&st[0], installed);
+  __threadfence();
+  if (atomicAdd(&st[3], 1u) == nworkgroups - 1u) {
+    __threadfence();
+    const uint32_t total = __hip_atomic_load(&st[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&st[2], total > tab.fr->limit ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&st[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ bool mk_front_open(const mk_table &tab) {
+  return tab.fr && __hip_atomic_load(&tab.fr->state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
 }
 
 /* reverse complement of a k-mer of `TL` bases held in the low 2*TL bits: reverse the 2-bit groups of the
@@ -168,7 +238,7 @@ __device__ __forceinline__ void mk_resolve_one(const mk_scan_args &a, uint64_t s
   const int32_t pf = a.shuf[dim];
   if (pf >= a.kp.dim_start && pf < a.kp.dim_end) {
     const uint64_t key = mk_reduce_key(a.kp, uni, (uint64_t)(pf - a.kp.dim_start));
-    mk_upsert(a.tab, a.kp.S, key, ord, 1u);
+    mk_upsert_big(a.tab, a.kp.S, key, ord, 1u); /* (overflow path of the scan kernel only: straight to the big table) */
   }
 }
 
@@ -230,8 +300,9 @@ __device__ __forceinline__ void mk_build_filter(uint32_t *bitmap, const mk_scan_
 #define MK_RESOLVE_THREADS 1024
 #define MK_RQ_CAP 128u /* ring entries per wave: a push adds at most 64 to fewer than 64 */
 #ifndef MK_RESOLVE_UNROLL
-#define MK_RESOLVE_UNROLL 4u /* blocks of 64 records a wave has in flight */
+#define MK_RESOLVE_UNROLL 4u /* blocks of 64 records a wave takes per round */
 #endif
+
 
 struct mk_wring {
   uint4 *q;
@@ -251,13 +322,18 @@ __device__ __forceinline__ bool mk_wring_pop(mk_wring &w, uint32_t lane, uint4 &
 }
 
 /* ring 2 -> table: .shuf entry (iseq2comem.c:692-695), key (:696-699), upsert */
-__device__ __forceinline__ void mk_resolve_accepted(const mk_scan_args &a, bool on, const uint4 v) {
-  if (!on) return;
+/* Out of line, its operands (key geometry, table and front-table descriptors, .shuf pointer) read through the kernarg
+ * pointer: it runs once per 64 accepted candidates, and inlined at every drain site it kept some twenty SGPRs live across
+ * the per-record loop, which then spilled over two hundred of them. */
+__device__ __noinline__ bool mk_resolve_accepted(const mk_scan_args *ka, bool on, const uint4 v, bool front_open) {
+  if (!on) return false;
+  const mk_scan_args &a = *ka;
   const uint64_t uni = ((uint64_t)v.y << 32) | v.x;
   const uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
   const int32_t pf = a.shuf[dim];
   if (pf >= a.kp.dim_start && pf < a.kp.dim_end)
-    mk_upsert(a.tab, a.kp.S, mk_reduce_key(a.kp, uni, (uint64_t)(pf - a.kp.dim_start)), ((uint64_t)v.w << 32) | v.z, 1u);
+    return mk_upsert(a.tab, a.kp.S, mk_reduce_key(a.kp, uni, (uint64_t)(pf - a.kp.dim_start)), ((uint64_t)v.w << 32) | v.z, 1u, front_open);
+  return false;
 }
 /* ring 1 -> ring 2: canonical k-mer (iseq2comem.c:691) and the accept bit of its inner substring */
 __device__ __forceinline__ void mk_resolve_candidate(const mk_scan_args &a, bool on, const uint4 v, mk_wring &r2) {
@@ -276,6 +352,11 @@ __device__ __forceinline__ void mk_resolve_candidate(const mk_scan_args &a, bool
 
 __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk_scan_args a, uint32_t nslots) {
   extern __shared__ __align__(16) uint32_t rlds[];
+  __shared__ uint32_t wg_installed;
+  const mk_scan_args *ka = (const mk_scan_args *)__builtin_amdgcn_kernarg_segment_ptr();
+  if (threadIdx.x == 0) wg_installed = 0u;
+  const bool front_open = mk_front_open(a.tab);
+  uint32_t installed = 0; /* wave-uniform: keys this wave put into the front table */
   mk_build_filter(rlds, a);
   const uint32_t lane = mk_lane(), wave = threadIdx.x >> 6;
   uint4 *rings = (uint4 *)(rlds + a.bm_words) + (size_t)wave * 2u * MK_RQ_CAP;
@@ -286,7 +367,7 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
       uint4 v;
       const bool on = mk_wring_pop(r2, lane, v);
       mk_wave_lds_fence();
-      mk_resolve_accepted(a, on, v);
+      installed += (uint32_t)__popcll(__ballot(mk_resolve_accepted(ka, on, v, front_open)));
     }
   };
   auto drain1 = [&](uint32_t least) {
@@ -307,8 +388,8 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
 
   /* a wave owns whole slots (slot = global wave index + multiples of the number of waves: one slot each when the grid
    * matches the scan's) and takes MK_RESOLVE_UNROLL blocks of 64 records per round; the loads of the next round are issued
-   * before the current one is worked on -- one 16-byte load per lane in flight would cap the kernel at
-   * 16 KiB per CU per memory latency, about 2 TB/s */
+   * before the current one is worked on.  (One block per round with the loop body once: 0.224 instead of 0.195 ms -- the
+   * slot bookkeeping of `fetch` is then paid per 64 records.) */
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
   uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wave, base = 0u, n = slot < nslots ? a.cand_count[slot] : 0u;
   auto fetch = [&](uint4 (&r)[MK_RESOLVE_UNROLL]) -> bool { /* false: nothing left */
@@ -383,6 +464,11 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
   mk_wave_lds_fence();
   drain1(1u);
   drain2(1u);
+  if (a.tab.fr) {
+    if (lane == 0 && installed) atomicAdd(&wg_installed, installed);
+    __syncthreads();
+    if (threadIdx.x == 0) mk_front_launch_end(a.tab, wg_installed, gridDim.x);
+  }
 }
 
 /* LDS filter: a blocked Bloom filter over B = A u revcomp(A), A = the accepted inner substrings
@@ -950,10 +1036,36 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
 }
 
 /* ---- multi-GPU: fold an exported shard into this table -------------------------------------------- */
-__global__ void __launch_bounds__(256) mk_import_kernel(mk_table tab, uint32_t S, const unsigned long long *keys,
-                                                        const uint32_t *counts, const unsigned long long *ords, uint64_t n) {
+__global__ void __launch_bounds__(1024) mk_import_kernel(mk_table tab, uint32_t S, const unsigned long long *keys,
+                                                         const uint32_t *counts, const unsigned long long *ords, uint64_t n) {
+  __shared__ uint32_t wg_installed;
+  if (threadIdx.x == 0) wg_installed = 0u;
+  __syncthreads();
+  const bool front_open = mk_front_open(tab);
+  uint32_t installed = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    mk_upsert(tab, S, keys[i], ords[i], counts[i]);
+    installed += mk_upsert(tab, S, keys[i], ords[i], counts[i], front_open) ? 1u : 0u;
+  if (tab.fr) {
+    if (installed) atomicAdd(&wg_installed, installed);
+    __syncthreads();
+    if (threadIdx.x == 0) mk_front_launch_end(tab, wg_installed, gridDim.x);
+  }
+}
+
+/* front table -> big table (only when the big table holds keys): the merge of two partial accumulators, as in the import.
+ * Counts are clamped to 65535 first: min(sum of clamped, 65535) == min(sum, 65535), and the slot's count field cannot carry. */
+__global__ void __launch_bounds__(1024) mk_front_fold_kernel(mk_table tab, uint32_t S) {
+  const mk_front f = *tab.fr;
+  if (__hip_atomic_load(&f.state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+  const uint64_t slots = (uint64_t)f.mask + 1u;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long kc = f.kc1[i];
+    if (kc == 0ull) continue;
+    const uint32_t c = (uint32_t)(kc & MK_CNT_MASK);
+    mk_upsert_big(tab, S, kc >> MK_CNT_BITS, ~f.ordinv1[i], c > 65535u ? 65535u : c);
+    f.kc1[i] = 0ull; /* folded once: a later compaction of the same sketch (export, more pushes, finish) must not add it again */
+    f.ordinv1[i] = 0ull;
+  }
 }
 
 /* ---- table -> dense list of distinct keys ------------------------------------------------------------ */
@@ -1018,7 +1130,11 @@ __global__ void __launch_bounds__(256) mk_dirty_clear_kernel(unsigned long long 
 template <uint32_t CHUNK>
 __global__ void __launch_bounds__(MK_COMPACT_THREADS) mk_compact_kernel(mk_table tab, uint32_t S, mk_dist out,
                                                                         unsigned long long *counter, int drop_key0,
-                                                                        const uint32_t *list, const uint32_t *nlist) {
+                                                                        const uint32_t *list, const uint32_t *nlist,
+                                                                        const uint32_t *big_used, uint32_t run_if) {
+  /* with a front table: the pass over it runs when the big table is empty (run_if 0), the pass over the big table when it is
+   * not (run_if 1; the front table has been folded into it by then) */
+  if (big_used && (__hip_atomic_load(big_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) != (run_if != 0u)) return;
   __shared__ uint32_t wtotal[MK_COMPACT_THREADS / 64];
   __shared__ unsigned long long block_base;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;

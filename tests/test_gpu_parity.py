@@ -507,6 +507,79 @@ def test_sparse_bookkeeping_over_a_sequence_of_sketches(capi, shufs, oracle_for,
         eng.close()
 
 
+@pytest.mark.parametrize("bits", [3, 7, 12])
+@pytest.mark.parametrize("name", ["L0K6", "L1K7", "L3K9"])
+def test_front_table_over_a_sequence_of_sketches(capi, shufs, oracle_for, name, bits):
+    """MK_OPT_FRONT_BITS: new keys go to a small table in front of the hashsize-slot one while it is open; a key lives in the
+    front table iff it is found within 16 probes there; the big table is cleared and compacted only when somebody used it.
+    8 slots: nearly everything spills; 128: closes after the first launch of the larger sketches; 4096: most sketches never
+    touch the big table, so its clear is skipped -- and must not be skipped after one that did.  Every sketch equals the
+    oracle, across flavours, crowded and abandoned sketches."""
+    eng = capi.Engine(shufs(name), 0, sparse=0, front_bits=bits)
+    ora = oracle_for(shufs(name))
+    rs = np.random.RandomState(93 + bits)
+    try:
+        for step, nreads in enumerate([300, 3, 0, 2500, 1, 200, 40, 900, 5]):
+            seqs = ui.pool_reads(rs, 30000, nreads) if nreads else []
+            rows = ui.rows_from_seqs(seqs, 160) if nreads else np.zeros(0, np.uint8)
+            got = run_koc(capi, eng, rows, 160, pushes=1 + step % 4)
+            rc, want = ora.koc_from_rows(rows, 160) if nreads else (0, [(np.zeros(0, np.uint32), np.zeros(0, np.uint16))])
+            assert rc == 0
+            assert_same(got, want, "%s step %d" % (name, step))
+            if step == 1 and name != "L3K9":  # a crowded sketch in between
+                big = capi.synth_rows_host(5, 0, 30000 if name == "L1K7" else 5000, 150, 160)
+                eng.begin(capi.MK_MODE_KOC)
+                eng.push_reads(big, 160, 0)
+                with pytest.raises(capi.CrowdedError):
+                    eng.finish()
+            if step == 3:  # begun, fed (big table used), abandoned: the next begin cannot know and must clear
+                eng.begin(capi.MK_MODE_KOC)
+                eng.push_reads(ui.rows_from_seqs(ui.pool_reads(rs, 30000, 1500), 160), 160, 0)
+            if step == 5:  # a FASTA set sketch on the same engine
+                fa = ui.fasta_bytes([ui.rand_seq(rs, 9000), ui.rand_seq(rs, 4000)])
+                eng.begin(capi.MK_MODE_SET)
+                eng.push_reads(capi.fasta_windows(fa, 2 * shufs(name).c.k, 256), 256, 0)
+                got = eng.finish()
+                rc, want = ora.co_from_fasta(fa)
+                assert rc == 0
+                assert_same(got, want, "%s fasta" % name)
+    finally:
+        eng.close()
+
+
+def test_front_table_shard_merge(capi, shufs, oracle_for):
+    """export / import with front tables of different sizes on the two sides: the importing engine's table is part front,
+    part big, the import closes the front table between its launches"""
+    name = "L1K7"
+    rs = np.random.RandomState(97)
+    seqs = ui.pool_reads(rs, 30000, 3000)
+    rows = ui.rows_from_seqs(seqs, 160)
+    rc, want = oracle_for(shufs(name)).koc_from_rows(rows, 160)
+    assert rc == 0
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    a = capi.Engine(shufs(name), 0, sparse=0, front_bits=6)
+    b = capi.Engine(shufs(name), 0, sparse=0, front_bits=9)
+    try:
+        half = 1500
+        a.begin(capi.MK_MODE_KOC); a.push_reads(rows[:half * 160], 160, 0)
+        b.begin(capi.MK_MODE_KOC); b.push_reads(rows[half * 160:], 160, half)
+        n = b.partial_count()
+        bufs = [C.c_void_p() for _ in range(3)]
+        for p_, sz in zip(bufs, (8, 4, 8)):
+            assert hip.hipMalloc(C.byref(p_), C.c_size_t(max(1, n) * sz)) == 0
+        assert b.partial_export(bufs[0].value, bufs[1].value, bufs[2].value, n) == n
+        a.partial_import(bufs[0].value, bufs[1].value, bufs[2].value, n)
+        a.partial_import(bufs[0].value, bufs[1].value, bufs[2].value, 0)
+        got = a.finish()
+        for p_ in bufs:
+            hip.hipFree(p_)
+        # counts of the second half were imported once
+        assert_same(got, want, "front-table merge")
+    finally:
+        a.close(); b.close()
+
+
 # ---- round 2: asynchronous pushes, the whole-file FASTQ stream bound to an engine, result-array growth, options ----------
 def test_async_pushes_with_tickets(capi, shufs, oracle_for):
     """mk_sketch_push_reads_async keeps several host buffers in flight; the sketch equals the oracle's and every ticket

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="also draw the 16-component L2K11 geometry (slow oracle)")
     ap.add_argument("--sparse", type=int, default=-1, help="MK_OPT_SPARSE: -1 by table size, 0 off, 1 on")
+    ap.add_argument("--front-bits", type=int, default=None, help="MK_OPT_FRONT_BITS: front table of 2^n slots (with --sparse 0)")
     a = ap.parse_args()
     from metakssd_amd import capi
     from oracle_binding import Oracle
@@ -63,7 +64,7 @@ def main():
         key = (k, subk, drl)
         if key not in shufs:
             shufs[key] = capi.Shuf.generate(k, subk, drl, 1000 + k * 100 + subk * 10 + drl)
-            engines[key] = capi.Engine(shufs[key], 0, sparse=a.sparse)
+            engines[key] = capi.Engine(shufs[key], 0, sparse=a.sparse, front_bits=a.front_bits)
             oracles[key] = Oracle(shufs[key].c.id, k, subk, drl, shufs[key].table)
         eng, ora, P = engines[key], oracles[key], shufs[key].params()
         dense = P.dim_end - P.dim_start >= 16 ** subk  # accept-everything tables crowd quickly
