@@ -377,6 +377,22 @@ def main():
                     traffic_source = "none for this kernel source / launch size (profiles/scan_traffic.json is for another build)"
             except Exception:
                 traffic = None
+        # a measured ceiling beside the nominal 8 TB/s: device-to-device copy of 2 GiB of the rows, read + write bytes
+        copy_gbs = None
+        if world == 1:
+            try:
+                nb = min(int(reads.numel()), 2 << 30)
+                dst = torch.empty(nb, dtype=torch.uint8, device=dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                dst.copy_(reads[:nb]); torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    dst.copy_(reads[:nb])
+                e1.record(); torch.cuda.synchronize()
+                copy_gbs = 10 * 2.0 * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9
+                del dst
+            except Exception:
+                copy_gbs = None
         line = {
             "metric": "Gbases/s sketched (150 bp synthetic reads, L3K11 -A)",
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -391,7 +407,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "mk_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms,
-                         "launches": prof["scan_launches"], "kernel_source_id": kernel_source_id()},
+                         "launches": prof["scan_launches"], "kernel_source_id": kernel_source_id(),
+                         "measured_copy_gb_s": copy_gbs},
             "phases_ms_per_step": {"clear": prof["clear_ms"] / args.steps, "scan": prof["scan_ms"] / args.steps,
                                    "resolve": prof["resolve_ms"] / args.steps,
                                    "finish": prof["finish_ms"] / args.steps},
