@@ -652,14 +652,17 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   mk_scan_args a{};
   a.rows = rows_dev; a.nreads = nreads; a.first_ord = first_ord; a.stride = stride;
   const bool vec = (stride % 16u == 0) && (((uintptr_t)rows_dev & 15u) == 0);
-  /* column blocks: fewest blocks of at most max_cb bytes, equal width, 16-byte (vec) / 4-byte granular */
-  const uint32_t g = vec ? 16u : 4u;
+  /* column blocks: fewest blocks of at most max_cb bytes, equal width, 16-byte (vec) / 4-byte granular -- 8-byte where the
+   * tuned kernels can run (they take whole 8-base windows: a 152-byte row is 80 + 72, not 76 + 76, which fell to the generic
+   * kernel at five times the time) */
+  const bool tuned_geom = e->P.subk == 6 && (e->P.k == 10 || e->P.k == 11) && stride % 8u == 0;
+  const uint32_t g = vec ? 16u : (tuned_geom ? 8u : 4u);
   const uint32_t max_cb = e->tune_cb;
   a.ncb = (stride + max_cb - 1) / max_cb;
   a.CB = ((stride + a.ncb - 1) / a.ncb + g - 1) / g * g;
   if (a.CB > max_cb) { a.ncb++; a.CB = ((stride + a.ncb - 1) / a.ncb + g - 1) / g * g; }
   a.ncb = (stride + a.CB - 1) / a.CB;
-  a.ppr = a.CB / g;
+  a.ppr = a.CB / (vec ? 16u : 4u); /* staging pieces: 16 or 4 bytes */
   a.ppr_inv = (1u << 20) / a.ppr + 1u;
   a.rowdw = (a.CB / 4u) | 1u;
   a.wave_lds_dwords = ((64u * a.rowdw + 1u) & ~1u) + 2u; /* +2: the unconditional word prefetch reads up to 2 dwords past a row */
