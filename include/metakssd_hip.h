@@ -160,6 +160,11 @@ int mk_sketch_begin(mk_engine *e, int mode); /* MK_MODE_OCC_SET here means min_o
  * (mk_fastq_frame_q).  fastq2co() never advances its key counter (:404), so it does not abort at hashlimit: this
  * flavour reports MK_ERR_CROWDED only when the table itself is full (distinct keys >= hashsize). */
 int mk_sketch_begin_occ(mk_engine *e, int min_occurrence);
+/* Row pitch.  Any multiple of 4 in 4..4096 is accepted; multiples of 16 take the 16-byte staging path.  AVOID MULTIPLES OF 128:
+ * the 64 rows of a tile then start in the same few L2 channels and the scan runs at half its rate (7.5 Gbases of 250-base
+ * reads: 4.48 ms at a pitch of 256, 2.69 ms at 272; the same at 128, 384, 512, 640 -- profiles/r02_c_probe_read_length.json).
+ * MK_ROW_PITCH(bytes incl. the newline) is what this library's own front ends use. */
+#define MK_ROW_PITCH(need) ((((need) + 15u) & ~15u) + (((((need) + 15u) & ~15u) & 127u) == 0u && (((need) + 15u) & ~15u) < 4096u ? 16u : 0u))
 /* Fixed-stride rows, each an ASCII sequence line terminated by '\n' (the layout of the reference's
  * fq_buff[l][FQ_LEN], iseq2comem.c:659,673); a row without '\n' ends at `stride`.  stride % 4 == 0,
  * 4 <= stride <= 4096.  Read i of this call has global ordinal first_read_ordinal + i: ordinals define

@@ -186,7 +186,7 @@ static void sketch_fastq(const char *who, mk_engine *e, const char *path, const 
       if (nrows && mk_sketch_push_reads(e, rows, stride, nrows, ord) != MK_OK) err(errno, "%s: %s", who, mk_last_error(e));
       ord += nrows;
       off += used;
-      if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : stride * 2; continue; }
+      if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : MK_ROW_PITCH(stride * 2); continue; }
       if (rc != MK_OK) err(errno, "%s: %s: a line is longer than the reader's fgets() width", who, path);
       if (nrows == 0 || off >= have) break;
     }
@@ -204,7 +204,7 @@ static void sketch_fasta(const char *who, mk_engine *e, const char *path, const 
   FILE *f = piped(who, path, pipecmd);
   uint8_t *io = malloc(WINBUF), *rows = NULL;
   if (!io || mk_host_alloc((void **)&rows, WINBUF) != MK_OK) err(errno, "%s: out of memory", who);
-  const uint32_t stride = 512;
+  const uint32_t stride = MK_ROW_PITCH(512u); /* 528: not a multiple of 128 */
   mk_fasta_state st;
   mk_fasta_window_init(&st, g_params.TL);
   uint64_t ord = 0;

@@ -410,7 +410,7 @@ static void sketch_fastq(ctx_t *c, const char *path) {
       records += nrec;
       if (nrows) push_rows(c, c->rows, stride, nrows);
       off += used;
-      if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : stride * 2; continue; } /* longer read: widen rows */
+      if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : MK_ROW_PITCH(stride * 2); continue; } /* longer read: widen rows */
       if (rc == MK_ERR_ARG || rc == MK_ERR_FORMAT)
         die("%s: FASTQ line longer than the reference's fgets() width (%s): outside the framing contract", path,
             c->occ ? "19998 characters, iseq2comem.c:319,343" : "4094 characters, iseq2comem.c:656,673");
@@ -430,7 +430,7 @@ static void sketch_fasta(ctx_t *c, const char *path, int TL) {
   input_t in;
   if (!open_input(path, &in)) die("fasta2co():%s: %s", path, strerror(errno));
   FILE *f = in.f;
-  const uint32_t stride = 512;
+  const uint32_t stride = MK_ROW_PITCH(512u); /* 528: not a multiple of 128 */
   mk_fasta_state st;
   if (mk_fasta_window_init(&st, TL) != MK_OK) die("mk_fasta_window_init failed");
   int eof = 0, any = 0;
@@ -531,7 +531,7 @@ static void *pf_worker(void *arg) {
         uint64_t nrec = 0;
         int rc = i >= pf->koc_until ? mk_fastq_frame_q(text, n, 1, pf->qmin, pf->TL, 0, pf->bufs[b], stride, ROWBUF / stride, &nrows, &nrec, &used)
                                     : mk_fastq_frame(text, n, 1, pf->bufs[b], stride, ROWBUF / stride, &nrows, &used);
-        if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : stride * 2; continue; }
+        if (rc == MK_ERR_ARG && stride < 4096) { stride = stride * 2 > 4096 ? 4096 : MK_ROW_PITCH(stride * 2); continue; }
         if (rc != MK_OK) s.err = rc;
         else if (used < n) s.too_big = 1; /* more rows than one buffer holds */
         s.nrows = nrows; s.stride = stride;
@@ -539,7 +539,7 @@ static void *pf_worker(void *arg) {
       }
     } else {
       mk_fasta_state st;
-      const uint32_t stride = 512;
+      const uint32_t stride = MK_ROW_PITCH(512u); /* 528: not a multiple of 128 */
       uint64_t nrows = 0;
       size_t used = 0;
       if (n == 0) s.err = MK_ERR_STATE; /* empty input: the reference's "eof or fread error" (iseq2comem.c:235) */

@@ -65,6 +65,7 @@ static uint32_t fs_round_stride(size_t need) { /* need = bytes of the longest ro
   size_t s = (need + 15u) & ~(size_t)15u;
   if (s < 32) s = 32;
   if (s > 4096) s = 4096;
+  if ((s & 127u) == 0 && s < 4096) s += 16; /* a pitch of k * 128 bytes halves the scan rate (L2 channel aliasing): include/metakssd_hip.h */
   return (uint32_t)s;
 }
 

@@ -40,6 +40,7 @@ def stream_rows(capi, data, occ, T, chunk, TL=14, qmin=54, first=1000):
     out, ord_expect = [], first
     for rows, stride, n, ord0 in pushes:
         assert stride % 16 == 0 and 32 <= stride <= 4096
+        assert stride % 128 != 0 or stride == 4096, "a row pitch of k * 128 bytes halves the scan rate (metakssd_hip.h, MK_ROW_PITCH)"
         assert ord0 == ord_expect, "row ordinals must be consecutive in push order"
         ord_expect += n
         out += seqs_of_rows(rows, stride, n)
@@ -175,3 +176,15 @@ def test_stream_over_a_file_mapping_with_pages_dropped_behind_the_framers(capi, 
             assert rc == 0 and got == want, (T, chunk)
         assert bytes(mm[:100]) == data[:100]  # a file mapping reads back the file, not zeros
         mm.close()
+
+
+@pytest.mark.parametrize("length,pitch", [(110, 112), (111, 112), (112, 144), (125, 144), (127, 144), (250, 272), (255, 272), (256, 272), (500, 528)])
+def test_stream_row_pitch_avoids_multiples_of_128(capi, length, pitch):
+    """reads whose natural pitch (length + newline, rounded up to 16) is 128, 256, 512 get 16 bytes more: every row of a tile
+    would otherwise start in the same few L2 channels (profiles/r02_c_probe_read_length.json)"""
+    rs = np.random.RandomState(length)
+    seqs = [ui.rand_seq(rs, length) for _ in range(300)]
+    data = ui.fastq_bytes(seqs)
+    pushes, st, rc = capi.fastq_stream(data, nthreads=2, chunk_bytes=1 << 20, occ=0, TL=14, qmin=54, first_ordinal=0)
+    assert rc == 0 and st.rows == 300
+    assert {stride for _, stride, _, _ in pushes} == {pitch}
