@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--front-bits", type=int, default=None,
                     help="experiments: MK_OPT_FRONT_BITS of the engine (default: the engine's own choice; 0 = no front table)")
+    ap.add_argument("--cand-cap", type=int, default=None, help="experiments: MK_OPT_CAND_CAP of the engine (records per scan wave)")
     ap.add_argument("--verify", action="store_true",
                     help="after timing, rank 0 re-sketches ALL ranks' reads on one engine and compares with the merged result")
     args = ap.parse_args()
@@ -237,7 +238,7 @@ def main():
         workload = "%d synthetic 150 bp reads on one GPU (BASELINE config 3)" % n
 
     shuf = capi.Shuf.generate(11, 6, 3, 11)  # L3K11 = {k=11, subk=6, drlevel=3}, same bytes as the tests' table
-    eng = capi.Engine(shuf, local_rank, front_bits=args.front_bits)
+    eng = capi.Engine(shuf, local_rank, front_bits=args.front_bits, cand_cap=args.cand_cap)
     stream = torch.cuda.current_stream().cuda_stream
     eng.set_stream(stream)
 

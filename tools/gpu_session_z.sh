@@ -1,8 +1,8 @@
 #!/bin/bash
-# 150-base reads: one-pass staging on / off, column block widths
+# candidate buffers: 8192 records per scan wave (a pitch of 128 KiB between the waves' buffers) against pitches that are not powers of two
 cd $GRAFT_REPO_ROOT
-make -s -C metakssd_amd/csrc tuning TUNING_OUT=/tmp/mk_tuning VARIANT="-DMK_TUNING_BUILD=1" || exit 1
-for v in "MK_SCAN_ONEPASS=1" "MK_SCAN_ONEPASS=0" "MK_SCAN_CB=64" "MK_SCAN_CB=48" "MK_SCAN_CB=32"; do
-env $v MK_DEBUG=1 MK_LIBRARY=/tmp/mk_tuning/libmetakssd_hip.so python bench.py --steps 50 --warmup 3 --no-cpu-baseline --no-host-legs 2>/tmp/err.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', {k: round(v,3) for k,v in d['phases_ms_per_step'].items()}, d['config']['distinct_keys'])"
-grep "scan cfg" /tmp/err.log | head -1
+for i in 1 2; do
+for c in 8192 8208 8256 8448 9000; do
+python bench.py --cand-cap $c --steps 60 --warmup 3 --no-cpu-baseline --no-host-legs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('cand_cap $c', {k: round(v,3) for k,v in d['phases_ms_per_step'].items()}, round(d['ms_per_step'],3))"
+done
 done
