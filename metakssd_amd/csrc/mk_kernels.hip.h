@@ -872,153 +872,138 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
          * of the forward k-mer one base earlier, so the loop rolls ONLY the low word; the high word is rebuilt on
          * demand from h2/h3 = flo at the two previous pair ends (fhi(j) = flo(j-16) & HMASK): for the rare filter
          * hits and when the slow path takes over.
-         * The loop runs while the LIVE lanes of the wave (rows not past their newline) are UNIFORM: the same run length
-         * `urun`, where every run of TL bases and more counts as TL (a full window is a full window: a lane that met an
-         * N is back in step with the others 22 bases later).  A pair of dwords (8 bases) then needs one validity test and
-         * one filter-hit test; k-mers that are not complete yet (read heads, j < jmin) or lie behind the lane's newline
-         * (read tails, j >= e, e per lane: trimmed reads end in different pairs) are probed like the others and
-         * discarded in the hit path; finished lanes run along on whatever their row holds, their hits dropped there
-         * too.  Measured on 50 M reads (tools/probe_ragged_reads.py): an N in 1 % of the reads 4.5 -> 3.2 ms, reads
-         * trimmed to 100..150 bases 4.6 -> 2.45 ms, where the first version left the loop for the rest of the row. */
+         * Two instantiations of one pair body (8 bases = 2 dwords of the row):
+         *  A  while the LIVE lanes of the wave (rows not past their newline) are IN STEP -- the same run length `urun`, every
+         *     run of TL bases and more counting as TL -- and all eight bytes of every live lane are bases: one validity test
+         *     and one filter-hit test per pair, run length and the first complete k-mer (jmin) in scalar registers.  Fixed-
+         *     length reads without N never leave it before their last pair.
+         *  B  any other pair: per lane, e = the bases in front of the first byte that is not one (an N, the newline: k-mers
+         *     ending behind it cannot be complete inside this pair), jmin from the lane's own run length, which then restarts
+         *     behind the last such byte; a newline finishes the lane.  Costs a dozen VALU more than A.  A lane that met an N
+         *     is back in step 22 bases later; finished lanes run along on whatever their row holds, hits dropped.
+         * k-mers that are not complete yet (j < jmin) or lie behind e are probed like the others and discarded by the
+         * resolve kernel (jmin and e travel in the record).  This is iseq2comem.c:682-690 per lane: a base counts when the
+         * TL bytes up to it are bases of one row.  The first version of B was the byte-wise predicated path of the generic
+         * kernel, entered for the rest of the row: 50 M reads trimmed to 100..150 bases 4.6 -> 2.4 ms, an N in 1 % of the
+         * reads 4.5 -> 2.24 ms, in 5 % 7.6 -> 2.5 ms, and the untouched rows 2.28 -> 2.14 ms on the same box (the kernel
+         * lost the byte-wise path, its registers and its spills) (tools/probe_ragged_reads.py). */
         constexpr uint32_t SH = 2u * (K - 6) - 2u; /* out2 - 2 */
         constexpr uint32_t HM = mk_kmer<K>::HMASK;
         static_assert(SH + 24u <= 32u, "inner substring must lie inside flo(j-1)");
+        /* Pair probing (see mk_build_zfilter): bases (2t, 2t+1) of the 8-base window share the key z = x_{2t}[0..21],
+         * which sits in bits SH+2.. of before_{2t+1} (the low word in front of base 2t+1).  Filter word z[8..21]:
+         * bits SH+10.. of before_{2t+1}; mask-table entry z[0..7]: the low word D = (SH-2)/2 bases earlier holds
+         * those bits at 2..9 -- a dword address after one AND.  pm[] carries before_{-D}..before_{-1} (the previous
+         * window's last low words) for the pairs whose earlier word lies in front of this window. */
+        constexpr uint32_t D = (SH - 2u) / 2u;
+        static_assert(SH >= 4u && SH <= 8u, "pair probing: z[0..7] at bits 2..9 of a low word D bases earlier");
         uint32_t urun = 0;
         auto in_step = [&]() -> bool { /* sets urun; needs a live lane */
           const uint32_t rc = min(run, TL);
           urun = __builtin_amdgcn_readlane(rc, (int)__builtin_ctzll(~__ballot(done) & __builtin_amdgcn_read_exec()));
           return __all(done || rc == urun);
         };
-        bool uniform = in_step();
+        bool step = in_step();
         uint32_t nw0 = myrow[0], nw1 = myrow[1];
         uint32_t p = 0;
-        while (p < npairs) {
-          uint32_t w0, w1, c0, x0, c1, x1;
-          bool have_pair = false;
-          if (uniform) {
-            uint32_t flo = km.flo;
-            /* Pair probing (see mk_build_zfilter): bases (2t, 2t+1) of the 8-base window share the key z = x_{2t}[0..21],
-             * which sits in bits SH+2.. of before_{2t+1} (the low word in front of base 2t+1).  Filter word z[8..21]:
-             * bits SH+10.. of before_{2t+1}; mask-table entry z[0..7]: the low word D = (SH-2)/2 bases earlier holds
-             * those bits at 2..9 -- a dword address after one AND.  pm[] carries before_{-D}..before_{-1} (the previous
-             * window's last low words) for the pairs whose earlier word lies in front of this window. */
-            constexpr uint32_t D = (SH - 2u) / 2u;
-            static_assert(SH >= 4u && SH <= 8u, "pair probing: z[0..7] at bits 2..9 of a low word D bases earlier");
-            uint32_t pm[3] = {0u, 0u, 0u};
-            auto oh_init = [&]() { /* before_{k-D} = flo >> 2(D-k): only bits 2..9 matter, and those are exact */
+        uint32_t flo = km.flo;
+        uint32_t pm[3] = {0u, 0u, 0u};
+        auto oh_init = [&]() { /* before_{k-D} = flo >> 2(D-k): only bits 2..9 matter, and those are exact */
 #pragma unroll
-              for (uint32_t k = 0; k < D; k++) pm[k] = flo >> (2u * (D - k));
-            };
+          for (uint32_t k = 0; k < D; k++) pm[k] = flo >> (2u * (D - k));
+        };
+        oh_init();
+        uint32_t w0, w1, c0, x0, c1, x1;
+        auto next_pair = [&]() {
+          w0 = nw0; w1 = nw1;
+          nw0 = myrow[2 * p + 2]; /* unconditional prefetch: at most 2 dwords past the row, inside the wave's LDS */
+          nw1 = myrow[2 * p + 3];
+          decode(w0, c0, x0);
+          decode(w1, c1, x1);
+        };
+        /* roll, probe, hand hits over.  rollonly: nobody completes a k-mer in this pair (wave-uniform); jmin, e: first base
+         * with a complete k-mer and bases that count, scalar in A, per lane in B; live: this lane may have a hit */
+        auto pair_body = [&](const bool rollonly, const uint32_t jmin, const uint32_t e, const bool live) {
+          const uint32_t fstart = flo;
+          /* the eight codes of the pair packed big-endian into the top 16 bits of `lo` (one v_dot4_u32_u8 per dword:
+           * weights 64,16,4,1; one v_perm_b32 to place the two bytes): the low word after base j is then ONE funnel
+           * shift of {fstart, lo} -- no eight-long dependent roll chain */
+          const uint32_t lo = __builtin_amdgcn_perm(__builtin_amdgcn_udot4(c0, 0x01041040u, 0u, false),
+                                                    __builtin_amdgcn_udot4(c1, 0x01041040u, 0u, false), 0x04000C0Cu);
+          if (rollonly) {
+            flo = __builtin_amdgcn_alignbit(fstart, lo, 16);
             oh_init();
-            uint64_t donem = __ballot(done); /* finished lanes: their bytes do not count in the validity test, their hits are dropped */
-            for (;;) { /* inner fast loop: leaves at a pair boundary */
-              w0 = nw0; w1 = nw1;
-              nw0 = myrow[2 * p + 2]; /* unconditional prefetch: at most 2 dwords past the row, inside the wave's LDS */
-              nw1 = myrow[2 * p + 3];
-              decode(w0, c0, x0);
-              decode(w1, c1, x1);
-              const uint64_t bad = ((uint64_t)x1 << 32) | x0; /* non-zero: a byte of this lane's pair is not ACGTacgt (one 64-bit compare) */
-              /* Not eight valid bases in every live lane: still fine if what is not a base lies behind the lane's newline
-               * (the tails of the reads, wherever they are).  Returns false when the pair has to go to the slow path
-               * (an N, a stray byte); e = bases of this lane's pair in front of its newline otherwise. */
-              auto row_tails = [&](uint32_t &e) -> bool {
-                const uint32_t nl0 = mk_nonzero_bytes(w0 ^ 0x0A0A0A0Au) ^ 0x80808080u; /* 0x80 where byte == '\n' */
-                const uint32_t nl1 = mk_nonzero_bytes(w1 ^ 0x0A0A0A0Au) ^ 0x80808080u;
-                const uint64_t nl = ((uint64_t)nl1 << 32) | nl0;
-                const uint32_t ee = nl ? (uint32_t)__builtin_ctzll(nl) >> 3 : 8u;
-                const uint64_t inval = ((uint64_t)mk_nonzero_bytes(x1) << 32) | mk_nonzero_bytes(x0);
-                const uint64_t front = ee >= 8u ? ~0ull : ((1ull << (8u * ee)) - 1ull);
-                if (!__all(done || (inval & front) == 0ull)) return false;
-                e = ee;
-                return true;
-              };
-              /* the pair itself: roll, probe, hand hits over.  Written once, instantiated twice: with e = 8 as a constant
-               * (no lane ends here: the only kind of pair fixed-length reads have in front of their last one) and with a
-               * per-lane e. */
-              auto pair_body = [&](const uint32_t e) {
-                const uint32_t fstart = flo;
-                /* the eight codes of the pair packed big-endian into the top 16 bits of `lo` (one v_dot4_u32_u8 per dword:
-                 * weights 64,16,4,1; one v_perm_b32 to place the two bytes): the low word after base j is then ONE funnel
-                 * shift of {fstart, lo} -- no eight-long dependent roll chain */
-                const uint32_t lo = __builtin_amdgcn_perm(__builtin_amdgcn_udot4(c0, 0x01041040u, 0u, false),
-                                                          __builtin_amdgcn_udot4(c1, 0x01041040u, 0u, false), 0x04000C0Cu);
-                if (urun + 8u < TL) { /* nobody completes a k-mer in this pair: roll only */
-                  flo = __builtin_amdgcn_alignbit(fstart, lo, 16);
-                  oh_init();
-                } else {
-                  const uint32_t f0 = __builtin_amdgcn_alignbit(fstart, lo, 30), f1 = __builtin_amdgcn_alignbit(fstart, lo, 28);
-                  const uint32_t f2 = __builtin_amdgcn_alignbit(fstart, lo, 26), f3 = __builtin_amdgcn_alignbit(fstart, lo, 24);
-                  const uint32_t f4 = __builtin_amdgcn_alignbit(fstart, lo, 22), f5 = __builtin_amdgcn_alignbit(fstart, lo, 20);
-                  const uint32_t f6 = __builtin_amdgcn_alignbit(fstart, lo, 18), f7 = __builtin_amdgcn_alignbit(fstart, lo, 16);
-                  /* before_0 .. before_7; only the ones a probe names are ever computed (k = 11: f0, f2, f4, f6) */
-                  const uint32_t bj[8] = {fstart, f0, f1, f2, f3, f4, f5, f6};
-                  uint32_t mm[4], dd[4];
+          } else {
+            const uint32_t f0 = __builtin_amdgcn_alignbit(fstart, lo, 30), f1 = __builtin_amdgcn_alignbit(fstart, lo, 28);
+            const uint32_t f2 = __builtin_amdgcn_alignbit(fstart, lo, 26), f3 = __builtin_amdgcn_alignbit(fstart, lo, 24);
+            const uint32_t f4 = __builtin_amdgcn_alignbit(fstart, lo, 22), f5 = __builtin_amdgcn_alignbit(fstart, lo, 20);
+            const uint32_t f6 = __builtin_amdgcn_alignbit(fstart, lo, 18), f7 = __builtin_amdgcn_alignbit(fstart, lo, 16);
+            /* before_0 .. before_7; only the ones a probe names are ever computed (k = 11: f0, f2, f4, f6) */
+            const uint32_t bj[8] = {fstart, f0, f1, f2, f3, f4, f5, f6};
+            uint32_t mm[4], dd[4];
 #pragma unroll
-                  for (uint32_t t = 0; t < 4; t++) {
-                    const uint32_t wsrc = bj[2u * t + 1u];
-                    const uint32_t msrc = 2u * t >= D ? bj[2u * t - D] : pm[2u * t];
-                    dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u);
-                    mm[t] = *(mk_lds_cu32)(uintptr_t)(msrc & 0x3FCu);
-                  }
+            for (uint32_t t = 0; t < 4; t++) {
+              const uint32_t wsrc = bj[2u * t + 1u];
+              const uint32_t msrc = 2u * t >= D ? bj[2u * t - D] : pm[2u * t];
+              dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u);
+              mm[t] = *(mk_lds_cu32)(uintptr_t)(msrc & 0x3FCu);
+            }
 #pragma unroll
-                  for (uint32_t k = 0; k < D; k++) pm[k] = bj[8u - D + k];
-                  flo = f7;
-                  __builtin_amdgcn_sched_barrier(0); /* all probes in flight before the first result is read */
-                  __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) once, instead of a staggered wait per probe */
-                  /* t == 0 <=> every bit of the pair's mask is set in its filter word */
-                  const uint32_t tt0 = mm[0] & ~dd[0], tt1 = mm[1] & ~dd[1], tt2 = mm[2] & ~dd[2], tt3 = mm[3] & ~dd[3];
-                  const uint32_t ta = min(min(tt0, tt1), tt2), tb = tt3, tc = 0xFFFFFFFFu;
-                  if (__any(min(min(ta, tb), tc) == 0u)) {
-                    /* some lane's filter test fired somewhere in this pair: those lanes append one pair record and the
-                     * resolve kernel, which holds the same filter, finds the base.  jmin = first base with a complete
-                     * k-mer (< 8 here), e = bases in front of the lane's newline (0..8). */
-                    const uint32_t jmin = urun + 1u >= TL ? 0u : TL - 1u - urun;
-                    const uint32_t meta = ((col0 + 8u * p) >> 3) | (jmin << 9) | (e << 12);
-                    push_record(min(min(ta, tb), tc) == 0u && !done, /* (a finished lane may have sent the wave here) */
-                                make_uint4(fstart, (lo & 0xFFFF0000u) | meta, (h2 & 0xFFFFu) | (h3 << 16), (uint32_t)(row0 + lane)));
-                  }
-                }
-                h3 = h2; h2 = fstart;
-                urun += 8u;
-                ++p;
-              };
+            for (uint32_t k = 0; k < D; k++) pm[k] = bj[8u - D + k];
+            flo = f7;
+            __builtin_amdgcn_sched_barrier(0); /* all probes in flight before the first result is read */
+            __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) once, instead of a staggered wait per probe */
+            /* t == 0 <=> every bit of the pair's mask is set in its filter word */
+            const uint32_t tt0 = mm[0] & ~dd[0], tt1 = mm[1] & ~dd[1], tt2 = mm[2] & ~dd[2], tt3 = mm[3] & ~dd[3];
+            const uint32_t ta = min(min(tt0, tt1), tt2), tb = tt3, tc = 0xFFFFFFFFu;
+            if (__any(min(min(ta, tb), tc) == 0u)) {
+              /* some lane's filter test fired somewhere in this pair: those lanes append one pair record and the
+               * resolve kernel, which holds the exact filter, finds the base */
+              const uint32_t meta = ((col0 + 8u * p) >> 3) | (jmin << 9) | (e << 12);
+              push_record(min(min(ta, tb), tc) == 0u && live, /* (a lane without a say may have sent the wave here) */
+                          make_uint4(fstart, (lo & 0xFFFF0000u) | meta, (h2 & 0xFFFFu) | (h3 << 16), (uint32_t)(row0 + lane)));
+            }
+          }
+          h3 = h2; h2 = fstart;
+          ++p;
+        };
+        uint64_t donem = __ballot(done); /* finished lanes: their bytes do not count in A's validity test */
+        for (;;) {
+          if (step) { /* ---- A */
+            bool left = false;
+            for (;;) {
+              next_pair();
+              const uint64_t bad = ((uint64_t)x1 << 32) | x0; /* non-zero: a byte of this lane's pair is not ACGTacgt */
               /* tested BEFORE the probes go out: folding this test into the hit test (one branch per pair, probes
                * issued speculatively) measured 4 % slower */
               uint64_t lanes_ok; /* asm: the compiler splits the compare into an OR over a re-derived x0 and a 32-bit compare (two more VALU) */
               asm("v_cmp_eq_u64_e64 %0, 0, %1" : "=s"(lanes_ok) : "v"(bad));
-              if ((lanes_ok | donem) == __builtin_amdgcn_read_exec()) {
-                pair_body(8u);
-              } else {
-                uint32_t e;
-                if (!row_tails(e)) { have_pair = true; break; }
-                pair_body(e);
-                done = done || e < 8u; /* rows that ended in this pair */
-                donem = __ballot(done);
-                if (donem == __builtin_amdgcn_read_exec()) break; /* every lane is finished */
-              }
+              if ((lanes_ok | donem) != __builtin_amdgcn_read_exec()) { left = true; break; }
+              pair_body(urun + 8u < TL, urun + 1u >= TL ? 0u : TL - 1u - urun, 8u, !done);
+              urun += 8u;
               if (p == npairs) break;
             }
-            km.flo = flo;
-            km.fhi = h3 & HM; /* = flo(-17) & HMASK at this pair boundary */
-            run = urun;
-            if (!have_pair) break; /* step exhausted or tile finished */
+            run = urun; /* the lanes' own counters take over */
+            if (!left) break; /* block exhausted */
           } else {
-            w0 = nw0; w1 = nw1;
-            nw0 = myrow[2 * p + 2];
-            nw1 = myrow[2 * p + 3];
-            decode(w0, c0, x0);
-            decode(w1, c1, x1);
+            next_pair();
           }
-          /* slow handling of one pair (full two-word roll) */
-          const uint32_t fstart = km.flo;
-          const uint32_t pos0 = col0 + 8u * p;
-          slow_dword(w0, c0, x0, pos0);
-          slow_dword(w1, c1, x1, pos0 + 4u);
-          h3 = h2; h2 = fstart;
-          p++;
-          if (__all(done)) break;
-          uniform = in_step();
+          { /* ---- B, on the pair that is loaded */
+            const uint64_t inval = ((uint64_t)mk_nonzero_bytes(x1) << 32) | mk_nonzero_bytes(x0); /* 0x80 per byte that is no base */
+            const uint64_t nl = ((uint64_t)(mk_nonzero_bytes(w1 ^ 0x0A0A0A0Au) ^ 0x80808080u) << 32) |
+                                (mk_nonzero_bytes(w0 ^ 0x0A0A0A0Au) ^ 0x80808080u);             /* 0x80 per '\n' */
+            const uint32_t e = inval ? (uint32_t)__builtin_ctzll(inval) >> 3 : 8u;
+            const uint32_t jm = run + 1u >= TL ? 0u : TL - 1u - run; /* >= e: nothing of this lane counts here */
+            pair_body(false, jm & 7u, e, !done && jm < e);
+            run = inval ? (uint32_t)__builtin_clzll(inval) >> 3 : min(run + 8u, 0xFFFFu); /* bases behind the last byte that is none */
+            done = done || nl != 0ull;
+            donem = __ballot(done);
+            if (donem == __builtin_amdgcn_read_exec() || p == npairs) break;
+            step = in_step();
+          }
         }
+        km.flo = flo;
+        km.fhi = h3 & HM; /* = flo(-17) & HMASK at this pair boundary */
       } else {
         uint32_t nw0 = myrow[0], nw1 = ndw > 1 ? myrow[1] : 0x0a0a0a0au;
         for (uint32_t p = 0; p < npairs; p++) {
