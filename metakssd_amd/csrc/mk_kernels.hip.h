@@ -91,7 +91,8 @@ struct mk_scan_args {
   /* [nslots][cand_cap] 16-byte candidate records:
    *   single k-mer (slow paths, generic kernel): {fwd lo, fwd hi, ord lo, ord hi | 0x80000000}
    *   pair (tuned loop: some base pair of this lane's 8-base window passed the LDS pair filter):
-   *       {flo at the window start, packed codes << 16 | e << 12 | jmin << 9 | pos0 >> 3, h2 & 0xFFFF | h3 << 16, row index}
+   *       {flo at the window start, packed codes << 16 | e << 12 | jmin << 9 | pos0 >> 3, h2 & 0xFFFF | h3 << 16 (h2, h3 = flo at the two
+   *        previous window starts), row index}
    * The resolve kernel holds the same LDS filter, finds the base(s) that passed and rebuilds their k-mers, so the scan
    * kernel's hit path is one ballot and one 16-byte store. */
   uint4 *cand;
@@ -725,7 +726,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
 
   mk_kmer<K> km;
   km.reset();
-  uint32_t h2 = 0, h3 = 0; /* tuned loop: low word of the forward k-mer at the two previous pair (8-base) boundaries */
+  uint32_t hh = 0; /* tuned loop: low halves of the forward k-mer's low word at the two previous pair (8-base) boundaries: older << 16 | newer */
   uint32_t run = 0;  /* valid bases since the last reset (the reference's base-1) */
   bool done = true;  /* this lane's row hit its '\n' (or does not exist) */
   uint32_t qn = 0;   /* candidates appended to this wave's buffer so far (wave-uniform) */
@@ -847,7 +848,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   issue_loads(nt_tile, nt_cb);
   for (uint32_t tile_id = wave_global; tile_id < ntiles; tile_id += nwaves) {
     const uint32_t row0 = tile_id << 6;
-    km.reset(); run = 0; h2 = 0; h3 = 0;
+    km.reset(); run = 0; hh = 0;
     done = row0 + lane >= a.nreads;
     ord_row = (a.first_ord + row0 + lane) << 12;
     for (uint32_t cb = 0; cb < a.ncb; cb++) {
@@ -870,7 +871,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
         /* ---- tuned loop (K in 9..11, subk 6: geometry folded at compile time) --------------------------------
          * The k-mer ending at base j has its 24-bit inner substring in bits SH..SH+23 of flo(j-1), the low word
          * of the forward k-mer one base earlier, so the loop rolls ONLY the low word; the high word is rebuilt on
-         * demand from h2/h3 = flo at the two previous pair ends (fhi(j) = flo(j-16) & HMASK): for the rare filter
+         * demand from hh = the low halves of flo at the two previous pair ends (fhi(j) = flo(j-16) & HMASK): for the rare filter
          * hits and when the slow path takes over.
          * Two instantiations of one pair body (8 bases = 2 dwords of the row):
          *  A  while the LIVE lanes of the wave (rows not past their newline) are IN STEP -- the same run length `urun`, every
@@ -893,8 +894,8 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
         /* Pair probing (see mk_build_zfilter): bases (2t, 2t+1) of the 8-base window share the key z = x_{2t}[0..21],
          * which sits in bits SH+2.. of before_{2t+1} (the low word in front of base 2t+1).  Filter word z[8..21]:
          * bits SH+10.. of before_{2t+1}; mask-table entry z[0..7]: the low word D = (SH-2)/2 bases earlier holds
-         * those bits at 2..9 -- a dword address after one AND.  pm[] carries before_{-D}..before_{-1} (the previous
-         * window's last low words) for the pairs whose earlier word lies in front of this window. */
+         * those bits at 2..9 -- a dword address after one AND.  pa[] carries those addresses out of before_{-D}..before_{-1}
+         * (the previous window's last low words) for the pairs whose earlier word lies in front of this window. */
         constexpr uint32_t D = (SH - 2u) / 2u;
         static_assert(SH >= 4u && SH <= 8u, "pair probing: z[0..7] at bits 2..9 of a low word D bases earlier");
         uint32_t urun = 0;
@@ -907,10 +908,10 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
         uint32_t nw0 = myrow[0], nw1 = myrow[1];
         uint32_t p = 0;
         uint32_t flo = km.flo;
-        uint32_t pm[3] = {0u, 0u, 0u};
+        uint32_t pa[3] = {0u, 0u, 0u}; /* mask-table addresses out of before_{-D}..before_{-1}: carried ready for use (no move, no AND at the use) */
         auto oh_init = [&]() { /* before_{k-D} = flo >> 2(D-k): only bits 2..9 matter, and those are exact */
 #pragma unroll
-          for (uint32_t k = 0; k < D; k++) pm[k] = flo >> (2u * (D - k));
+          for (uint32_t k = 0; k < D; k++) pa[k] = (flo >> (2u * (D - k))) & 0x3FCu;
         };
         oh_init();
         uint32_t w0, w1, c0, x0, c1, x1;
@@ -944,12 +945,11 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
 #pragma unroll
             for (uint32_t t = 0; t < 4; t++) {
               const uint32_t wsrc = bj[2u * t + 1u];
-              const uint32_t msrc = 2u * t >= D ? bj[2u * t - D] : pm[2u * t];
               dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u);
-              mm[t] = *(mk_lds_cu32)(uintptr_t)(msrc & 0x3FCu);
+              mm[t] = *(mk_lds_cu32)(uintptr_t)(2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t]);
             }
 #pragma unroll
-            for (uint32_t k = 0; k < D; k++) pm[k] = bj[8u - D + k];
+            for (uint32_t k = 0; k < D; k++) pa[k] = bj[8u - D + k] & 0x3FCu;
             flo = f7;
             __builtin_amdgcn_sched_barrier(0); /* all probes in flight before the first result is read */
             __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) once, instead of a staggered wait per probe */
@@ -961,10 +961,10 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                * resolve kernel, which holds the exact filter, finds the base */
               const uint32_t meta = ((col0 + 8u * p) >> 3) | (jmin << 9) | (e << 12);
               push_record(min(min(ta, tb), tc) == 0u && live, /* (a lane without a say may have sent the wave here) */
-                          make_uint4(fstart, (lo & 0xFFFF0000u) | meta, (h2 & 0xFFFFu) | (h3 << 16), (uint32_t)(row0 + lane)));
+                          make_uint4(fstart, (lo & 0xFFFF0000u) | meta, hh, (uint32_t)(row0 + lane)));
             }
           }
-          h3 = h2; h2 = fstart;
+          hh = __builtin_amdgcn_perm(hh, fstart, 0x05040100u); /* hh << 16 | fstart & 0xFFFF */
           ++p;
         };
         uint64_t donem = __ballot(done); /* finished lanes: their bytes do not count in A's validity test */
@@ -1003,7 +1003,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
           }
         }
         km.flo = flo;
-        km.fhi = h3 & HM; /* = flo(-17) & HMASK at this pair boundary */
+        km.fhi = (hh >> 16) & HM; /* = flo(-17) & HMASK at this pair boundary (kept for symmetry with the generic kernel's state) */
       } else {
         uint32_t nw0 = myrow[0], nw1 = ndw > 1 ? myrow[1] : 0x0a0a0a0au;
         for (uint32_t p = 0; p < npairs; p++) {
