@@ -260,9 +260,12 @@ def main():
     flags = {"keep": False}
     tail = {"t": 0.0, "steps": 0, "on": False}
 
-    def step():
+    def step(push=None):
         eng.begin(capi.MK_MODE_KOC)
-        eng.push_reads_device(reads.data_ptr(), STRIDE, n, first)
+        if push is None:
+            eng.push_reads_device(reads.data_ptr(), STRIDE, n, first)
+        else:
+            push()
         if world > 1:
             if tail["on"]:  # instrumented steps only: where the scan ends and rank 0's serial tail begins
                 torch.cuda.synchronize()
@@ -321,6 +324,27 @@ def main():
             step()
         tail["on"] = False
         fence()
+
+    # t_stream with N > 1 (BASELINE config 4 is quoted "including the gather"): every rank streams rows out of ITS pinned host
+    # buffer over ITS PCIe link (mk_sketch_push_reads), then the same export / gather / import / finish.  At most 50 M reads per
+    # rank are pinned (8 GB): with fewer ranks than that allows the leg runs on the first 50 M reads of each rank's range.
+    stream_n = None
+    if world > 1 and not args.no_host_legs:
+        ns = min(n, 50_000_000)
+        pinned = torch.empty(ns * STRIDE, dtype=torch.uint8, pin_memory=True)
+        pinned.copy_(reads[:ns * STRIDE])
+        torch.cuda.synchronize()
+        push_host = lambda: capi._check(capi.lib.mk_sketch_push_reads(eng.h, pinned.data_ptr(), STRIDE, ns, first), eng.h)  # noqa: E731
+        step(push_host)
+        fence()
+        ts0 = time.perf_counter()
+        for _ in range(3):
+            step(push_host)
+        fence()
+        tsd = torch.tensor([time.perf_counter() - ts0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tsd, op=dist.ReduceOp.MAX)
+        stream_n = (ns, float(tsd.item()) / 3.0)
+        del pinned
 
     verified = None
     need_sketch = args.verify or (world == 1 and not args.no_host_legs)
@@ -418,6 +442,13 @@ def main():
             line["rank0_tail_ms"] = tail["t"] / tail["steps"] * 1e3
             line["rank0_tail_what"] = "gather of the other ranks' key lists + one import launch + finish on rank 0, " \
                                       "from 3 separately fenced steps after the timed region"
+        if stream_n is not None:
+            ns, sec = stream_n
+            line["t_stream"] = {"gbases_s": world * ns * READ_LEN / sec / 1e9, "h2d_gb_s": world * ns * STRIDE / sec / 1e9,
+                                "seconds": sec, "reads_per_rank": ns, "reps": 3,
+                                "what": "every rank: %d of its reads as %d-byte rows in pinned host memory -> mk_sketch_push_reads over "
+                                        "its own PCIe link -> export, gather to rank 0, one import, finish on rank 0; mean of 3 fenced "
+                                        "steps, max over ranks; aggregate over %d ranks" % (ns, STRIDE, world)}
         if verified is not None:
             line["merged_equals_single_engine"] = bool(verified)
             if "verify_detail" in result:

@@ -283,13 +283,14 @@ def test_bench_two_rank_flow_merged_equals_single(capi):
     port = 29700 + os.getpid() % 1000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
-           "--reads-per-gpu", "1000000", "--steps", "1", "--warmup", "1", "--verify"]
+           "--reads-per-gpu", "1000000", "--steps", "1", "--warmup", "1", "--verify"]  # (the N > 1 t_stream leg runs too)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
     line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["merged_equals_single_engine"] is True
     assert d["config"]["distinct_keys"] > 50000
+    assert d["t_stream"]["reads_per_rank"] == 1000000 and d["t_stream"]["gbases_s"] > 0 and "rank0_tail_ms" in d
 
 
 # ---- FASTQ without -A: fastq2co + write_fqco2file through MK_MODE_OCC_SET -----------------------
