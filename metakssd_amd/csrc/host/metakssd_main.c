@@ -1637,9 +1637,19 @@ int main(int argc, char **argv) {
     pthread_mutex_init(&pf.mu, NULL);
     pthread_cond_init(&pf.cv_buf, NULL);
     pthread_cond_init(&pf.cv_ready, NULL);
-    for (int b = 0; b < pf.nbufs; b++) {
-      if (mk_host_alloc((void **)&pf.bufs[b], ROWBUF) != MK_OK) { pf.nbufs = b; break; }
-      pf.free_bufs[pf.nfree++] = b;
+    /* one pinned block for all row buffers (an anonymous mapping touched in parallel and registered once): sixteen
+     * hipHostMalloc calls of 64 MiB took 0.2 s of a 0.9 s run over 1024 genomes */
+    void *arena = NULL;
+    if (mk_host_arena_alloc(&arena, (size_t)pf.nbufs * ROWBUF) == MK_OK) {
+      for (int b = 0; b < pf.nbufs; b++) {
+        pf.bufs[b] = (uint8_t *)arena + (size_t)b * ROWBUF;
+        pf.free_bufs[pf.nfree++] = b;
+      }
+    } else {
+      for (int b = 0; b < pf.nbufs; b++) {
+        if (mk_host_alloc((void **)&pf.bufs[b], ROWBUF) != MK_OK) { pf.nbufs = b; break; }
+        pf.free_bufs[pf.nfree++] = b;
+      }
     }
     for (int t = 0; t < pf.nbufs; t++)
       if (pthread_create(&workers[nworkers], NULL, pf_worker, &pf) == 0) nworkers++;

@@ -31,8 +31,11 @@ for name, (k, s, l, seed) in {"L3K10": (10, 6, 3, 10), "L2K11": (11, 5, 2, 211)}
     sp = os.path.join(d, name + ".shuf"); capi.Shuf.generate(k, s, l, seed).write(sp)
     for rep in range(2):
         t0 = time.perf_counter()
-        subprocess.check_call([cli, "dist", "-L", sp, "-p", os.environ.get("THREADS", "8"), "-o", os.path.join(d, "out_%s_%d" % (name, rep)), "--quiet", gd])
+        out = subprocess.check_output([cli, "dist", "-L", sp, "-p", os.environ.get("THREADS", "8"), "-o", os.path.join(d, "out_%s_%d" % (name, rep)), "--quiet", "--timing", gd])
         dt = time.perf_counter() - t0
+        tl = [json.loads(ln)["timing"] for ln in out.decode(errors="replace").splitlines() if ln.startswith('{"timing"')]
+        if tl:  # where the main thread's time goes: finish_s = sum of the mk_sketch_finish calls (each ends in a synchronisation)
+            print("  timeline: engine ready %.3f, written %.3f, in finish calls %.3f s" % (tl[0]["engine_ready"], tl[0]["written"], tl[0]["finish_s"]))
         print("%s product CLI rep %d: %.2f s for %d genomes = %.1f genomes/s, %.2f Gbases/s" % (name, rep, dt, G, G / dt, G * MB / 1e3 / dt))
         print(json.dumps({"tool": "tools/bench_config5.py", "shuf": name, "who": "product CLI", "rep": rep, "genomes": G, "mbases_each": MB,
                           "threads": int(os.environ.get("THREADS", "8")), "seconds": round(dt, 3), "genomes_per_s": round(G / dt, 1),
