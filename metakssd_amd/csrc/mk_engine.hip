@@ -655,7 +655,7 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   /* column blocks: fewest blocks of at most max_cb bytes, equal width, 16-byte (vec) / 4-byte granular -- 8-byte where the
    * tuned kernels can run (they take whole 8-base windows: a 152-byte row is 80 + 72, not 76 + 76, which fell to the generic
    * kernel at five times the time) */
-  const bool tuned_geom = e->P.subk == 6 && (e->P.k == 10 || e->P.k == 11) && stride % 8u == 0;
+  const bool tuned_geom = e->P.subk == 6 && e->P.k >= 9 && e->P.k <= 11 && stride % 8u == 0;
   const uint32_t g = vec ? 16u : (tuned_geom ? 8u : 4u);
   const uint32_t max_cb = e->tune_cb;
   a.ncb = (stride + max_cb - 1) / max_cb;
@@ -667,9 +667,9 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   a.rowdw = (a.CB / 4u) | 1u;
   a.wave_lds_dwords = ((64u * a.rowdw + 1u) & ~1u) + 2u; /* +2: the unconditional word prefetch reads up to 2 dwords past a row */
   a.bm_words = 1u << e->bm_bits;
-  /* tuned kernels: 24-bit inner substring (subk 6), k in {10,11}, every column block a whole number of 8-base pairs; they
+  /* tuned kernels: 24-bit inner substring (subk 6), k in {9,10,11}, every column block a whole number of 8-base pairs; they
    * keep the pair filter's 256-entry mask table in front of the filter */
-  const int tuned_k = (e->P.subk == 6 && stride % 8u == 0 && a.CB % 8u == 0 && (e->P.k == 10 || e->P.k == 11)) ? e->P.k : 0;
+  const int tuned_k = (e->P.subk == 6 && stride % 8u == 0 && a.CB % 8u == 0 && e->P.k >= 9 && e->P.k <= 11) ? e->P.k : 0;
   a.mt_words = tuned_k ? MK_ZMASK_WORDS : 0u;
   a.dimmask = (uint32_t)((1ull << (4 * e->P.subk)) - 1ull);
   a.accept = e->d_accept; a.n_accept = e->n_accept;
@@ -709,6 +709,7 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
   switch (tuned_k) {
     case 11: r = vec ? mk_launch_scan_k<11, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<11, false>(e, threads, false, a, grid, lds, e->stream); break;
     case 10: r = vec ? mk_launch_scan_k<10, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<10, false>(e, threads, false, a, grid, lds, e->stream); break;
+    case 9: r = vec ? mk_launch_scan_k<9, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<9, false>(e, threads, false, a, grid, lds, e->stream); break;
     default: r = vec ? mk_launch_scan_k<0, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<0, false>(e, threads, false, a, grid, lds, e->stream); break;
   }
   if (r != hipSuccess) return mk_fail(e, MK_ERR_HIP, "scan launch: %s", hipGetErrorString(r));

@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
     }
   };
 
-  /* pair records only come from the tuned kernels (k = 10, 11); for any other geometry every record is a single k-mer */
+  /* pair records only come from the tuned kernels (k = 9, 10, 11 with subk 6); for any other geometry every record is a single k-mer */
   const uint32_t K = a.kp.TL >> 1, SH = K > 7u ? 2u * (K - 6u) - 2u : 0u;
   const uint32_t hm = a.kp.TL > 16u ? (uint32_t)((1ull << (2u * a.kp.TL - 32u)) - 1ull) : 0u; /* mk_kmer_hi<K>::HMASK */
   const uint32_t wmask = a.bm_words - 1u;
