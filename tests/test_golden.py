@@ -547,6 +547,52 @@ def test_cli_several_engines_equal_one(shuf, flags, shuf_files, tmp_path):
         assert parse_stat(os.path.join(outs[0], "cofiles.stat")) == parse_stat(os.path.join(other, "cofiles.stat"))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shuf,flags", [("L1K7", []), ("L3K10", ["-u"]), ("L2K11", []), ("L1K7", ["-A"])])
+def test_cli_many_small_inputs_equal_one_by_one(shuf, flags, shuf_files, tmp_path):
+    """many inputs in one run (worker threads prepare the files ahead, one engine sketches them in input order, its tables
+    cleared -- sparsely at L2K11 -- in between): the directory (ids, index, counts, cofiles.stat) must be what sketching the
+    files one by one and concatenating gives -- file order and empty sketches included."""
+    import numpy as np
+    import util_inputs as ui
+    rs = np.random.RandomState(11)
+    fastq = "-A" in flags
+    paths = []
+    for i in range(21):
+        n = [60000, 500, 0, 12000][i % 4] if i != 7 else 150000
+        if fastq:
+            seqs = ui.pool_reads(rs, 20000, max(1, n // 150))
+            data = ui.fastq_bytes(seqs)
+            path = str(tmp_path / ("s%02d.fq" % i))
+        else:
+            data = ui.fasta_bytes([ui.rand_seq(rs, n // 2 + 30), ui.rand_seq(rs, n - n // 2 + 25)])
+            path = str(tmp_path / ("g%02d.fna" % i))
+        open(path, "wb").write(data)
+        paths.append(path)
+    base = [PRODUCT_CLI, "dist", "-L", shuf_files(shuf)] + flags
+    whole = str(tmp_path / "whole")
+    r = subprocess.run(base + ["-p", "6", "-o", whole] + paths, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    names = sorted(f for f in os.listdir(whole) if f.startswith("combco") and ".index." not in f)
+    assert names
+    cat = {f: b"" for f in names}
+    counts, per_comp = [], []
+    for i, path in enumerate(paths):
+        one = str(tmp_path / ("one%02d" % i))
+        r = subprocess.run(base + ["-p", "1", "-o", one, path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        for f in names:
+            cat[f] += open(os.path.join(one, f), "rb").read()
+        per_comp.append(os.path.getsize(os.path.join(one, "combco.0")) // 4)
+        counts.append(sum(os.path.getsize(os.path.join(one, f)) // 4 for f in names if not f.endswith(".a")))
+    for f in names:
+        assert open(os.path.join(whole, f), "rb").read() == cat[f], f
+    idx = np.fromfile(os.path.join(whole, "combco.index.0"), dtype=np.uint64)
+    assert list(np.diff(idx)) == per_comp and sum(counts) > 100
+    st, stnames = parse_stat(os.path.join(whole, "cofiles.stat"))
+    assert st["infile_num"] == len(paths) and stnames == paths and st["ctx_ct"] == counts and (fastq or counts[2] == 0)
+
+
 # ---- sixteen components end to end (stage I, combine, stage II, search) with COMPONENT_SZ = 6 --------------------------------
 CSZ6 = MANIFEST.get("csz6")
 
