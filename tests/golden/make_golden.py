@@ -43,6 +43,18 @@ def parse_stat(path):
                 infile_num=infile_num, all_ctx_ct=all_ctx, ctx_ct=cts)
 
 
+def tree_section():
+    """every committed fixture file (expected/ and inputs/) -> sha256: the tests take the expected file set from here, never
+    from os.listdir, so a fixture that goes missing (e.g. swallowed by a .gitignore pattern) turns the suite red"""
+    tree = {}
+    for sub in ("expected", "inputs"):
+        for dp, _, fs in os.walk(os.path.join(HERE, sub)):
+            for f in fs:
+                p = os.path.join(dp, f)
+                tree[os.path.relpath(p, HERE)] = hashlib.sha256(open(p, "rb").read()).hexdigest()
+    return tree
+
+
 def search_section(manifest, work, shuf_paths, exp_root):
     """stage II + `dist -r`: every database costs one 32 GiB mco.index.0 (deleted again); its xxh64 is what is kept"""
     import xxhash
@@ -140,10 +152,24 @@ def csz6_section(manifest, work, exp_root):
 
 
 def main():
+    if "--tree-only" in sys.argv:  # re-pin the committed fixture tree; refuses files whose per-case hash (made with the
+        manifest = json.load(open(os.path.join(HERE, "manifest.json")))  # reference at hand) no longer matches
+        tree = tree_section()
+        for sec in ("cases", "set_cases"):
+            for case, e in manifest.get(sec, {}).items():
+                if isinstance(e.get("files"), dict):
+                    for f, h in e["files"].items():
+                        if tree.get(os.path.join("expected", case, f)) != h:
+                            raise SystemExit("%s/%s: committed file is missing or differs from the reference-made hash" % (case, f))
+        manifest["tree"] = tree
+        json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+        print("tree: %d files pinned" % len(tree))
+        return
     if "--only-csz6" in sys.argv:
         manifest = json.load(open(os.path.join(HERE, "manifest.json")))
         work = tempfile.mkdtemp(prefix="golden_")
         csz6_section(manifest, work, os.path.join(HERE, "expected"))
+        manifest["tree"] = tree_section()
         json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
         shutil.rmtree(work, ignore_errors=True)
         return
@@ -159,6 +185,7 @@ def main():
             make_shuf(name, shuf_paths[name])
             assert manifest["shufs"][name]["sha256"] == hashlib.sha256(open(shuf_paths[name], "rb").read()).hexdigest()
         search_section(manifest, work, shuf_paths, exp_root)
+        manifest["tree"] = tree_section()
         json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
         shutil.rmtree(work, ignore_errors=True)
         return
@@ -296,6 +323,7 @@ def main():
         for x in lines[:3]:
             print("    " + x)
     search_section(manifest, work, shuf_paths, exp_root)
+    manifest["tree"] = tree_section()
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
     shutil.rmtree(work, ignore_errors=True)
     tot = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(HERE) for f in fs)
