@@ -21,6 +21,49 @@ PRODUCT_CLI = os.path.join(ROOT, "metakssd_amd", "bin", "metakssd")
 HEAVY = {"pool2000_L2K11", "fasta_L2K11", "fasta_uniq_L2K11", "lowcov_n3_L2K11"}  # 4.3 GB oracle table each
 
 
+def golden_listing(rel):
+    """file names the manifest pins directly under tests/golden/<rel> -- the expectation is the manifest, never os.listdir of
+    the working tree: a fixture that is not in the checkout must fail the case, not shrink it"""
+    pre = rel.rstrip("/") + "/"
+    names = sorted(k[len(pre):] for k in MANIFEST["tree"] if k.startswith(pre) and "/" not in k[len(pre):])
+    assert names, "manifest pins nothing under " + rel
+    return names
+
+
+def test_golden_tree_is_complete_and_unchanged():
+    """every fixture the manifest pins exists with the pinned bytes, and nothing unpinned sits beside them
+    (the count half of the -A vectors, combco.N.a, pins iseq2comem.c:516-562)"""
+    tree = MANIFEST["tree"]
+    for rel, want in sorted(tree.items()):
+        p = os.path.join(gc.GOLDEN, rel)
+        assert os.path.isfile(p), "golden fixture missing from the checkout: " + rel
+        assert hashlib.sha256(open(p, "rb").read()).hexdigest() == want, "golden fixture changed: " + rel
+    have = set()
+    for sub in ("expected", "inputs"):
+        for dp, _, fs in os.walk(os.path.join(gc.GOLDEN, sub)):
+            have.update(os.path.relpath(os.path.join(dp, f), gc.GOLDEN) for f in fs)
+    assert have == set(tree), "unpinned files: %s" % sorted(have - set(tree))
+    for sec in ("cases", "set_cases"):  # the per-case hashes written when the reference made the vectors agree with the tree
+        for case, e in MANIFEST[sec].items():
+            if isinstance(e.get("files"), dict):
+                for f, h in e["files"].items():
+                    assert tree["expected/%s/%s" % (case, f)] == h
+    acount = [k for k in tree if k.endswith(".a")]
+    assert len(acount) >= 29  # every -A case carries its 16-bit counts
+
+
+def test_golden_fixtures_are_tracked_by_git():
+    """.gitignore once hid the 29 combco.N.a files (pattern *.a): the tree must be what a clone gets"""
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("not a git checkout (gpurun snapshot)")
+    r = subprocess.run(["git", "-C", ROOT, "ls-files", "tests/golden"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if r.returncode != 0:
+        pytest.skip("git unavailable")
+    tracked = {ln[len("tests/golden/"):] for ln in r.stdout.decode().splitlines()}
+    missing = sorted(set(MANIFEST["tree"]) - tracked)
+    assert not missing, "pinned but untracked (check .gitignore): %s" % missing[:5]
+
+
 def parse_stat(path):
     b = open(path, "rb").read()
     shuf_id, koc = struct.unpack_from("<IB", b, 0)
@@ -50,7 +93,8 @@ def shuf_files(tmp_path_factory):
 def check_against_golden(case, outdir, input_path):
     entry = MANIFEST["cases"][case]
     exp = os.path.join(gc.GOLDEN, "expected", case)
-    want_files = sorted(os.listdir(exp))
+    want_files = golden_listing("expected/" + case)
+    assert want_files == sorted(entry["files"])
     got_files = sorted(f for f in os.listdir(outdir) if f.startswith("combco"))
     assert got_files == want_files
     for f in want_files:
@@ -186,7 +230,7 @@ def parse_header(path):
 def check_set_against_golden(case, outdir, inputs):
     entry = MANIFEST["set_cases"][case]
     exp = os.path.join(gc.GOLDEN, "expected", case)
-    want = sorted(os.listdir(exp))
+    want = golden_listing("expected/" + case)
     got = sorted(f for f in os.listdir(outdir) if f != "cofiles.stat")
     assert got == want  # in particular: no combco.N.a after -i / -s even when the header says koc (command_set.c:321-425)
     for f in want:
@@ -300,7 +344,7 @@ def run_composite_case(case, shuf_files, tmp_path, dist_cmd, set_cmd, comp_cmd):
     abv = str(tmp_path / "abv")
     r = subprocess.run(comp_cmd + ["-r", db, "-q", qsk, "-b", "-o", abv], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()
-    want_abv = sorted(f for f in os.listdir(exp) if f.endswith(".abv"))
+    want_abv = sorted(f for f in golden_listing("expected/" + case) if f.endswith(".abv"))
     assert sorted(os.listdir(abv)) == want_abv
     for f in want_abv:
         assert filecmp.cmp(os.path.join(exp, f), os.path.join(abv, f), shallow=False), f
@@ -622,7 +666,7 @@ def test_product_cli_sixteen_component_database_end_to_end(shuf_files, tmp_path)
             dirs.append("%s_%d.sk" % (tag, i))
         _run([PRODUCT_CLI, "dist", "-o", tag + ".sk"] + dirs, str(tmp_path))
         got = sorted(f for f in os.listdir(str(tmp_path / (tag + ".sk"))) if f.startswith("combco"))
-        want = sorted(os.listdir(os.path.join(exp, tag + "_sk")))
+        want = golden_listing("expected/csz6_db/" + tag + "_sk")
         assert got == want and len(got) == 32
         for f in want:
             assert filecmp.cmp(os.path.join(exp, tag + "_sk", f), str(tmp_path / (tag + ".sk") / f), shallow=False), (tag, f)
