@@ -18,8 +18,12 @@ is the scan kernel (HIP-event timed inside the engine on its launch stream); at 
   `cpu_baseline`  the compiled reference (oracle/_ref/metakssd, kind "reference") or the oracle port on this host's cores
                   over a bounded sample of the same workload,
   `t_stream`      the same reads from PINNED HOST rows through mk_sketch_push_reads (H2D double-buffered) to the result,
-  `t_e2e`         the product command line on the workload written as a FASTQ file in /dev/shm: process start to the
-                  sketch directory on disk (SURVEY.md 8d's three timings).  Neither host-inclusive rate is `value`.
+  `t_e2e`         the product command line on the workload written as a FASTQ file in /dev/shm: `gbases_s` from process
+                  start to the sketch directory on disk (SURVEY.md 8d's three timings), `gbases_s_wall` by the parent's clock
+                  around the whole process, `gbases_s_excl_init` without the HIP runtime's start-up; medians over the runs.
+                  Neither host-inclusive rate is `value`.
+  `config5`       BASELINE config 5 through the product command line: a directory of synthetic genomes as multi-FASTA files,
+                  no -A, L3K10 and L2K11 (genomes/s and Gbases/s by the parent's clock; --no-config5 skips it).
 """
 import argparse
 import hashlib
@@ -146,35 +150,127 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=4):
             if rep:
                 runs.append((m1 - m0, tm, out))
         bases = n * READ_LEN
-        work = lambda t: t.get("written", 0.0) - t.get("hip_ready", 0.0)  # noqa: E731
-        _, tm, out = min(runs, key=lambda x: work(x[1]))
-        wall = min(w for w, _, _ in runs)  # its own best: the teardown after `written` varies by 0.1 s between runs of one binary
+        import statistics
+        written = lambda t: t.get("written", 0.0)                                   # noqa: E731  process start -> directory complete
+        work = lambda t: t.get("written", 0.0) - t.get("hip_ready", 0.0)            # noqa: E731  the same without HIP start-up
+        runs.sort(key=lambda x: written(x[1]))
+        _, tm, out = runs[len(runs) // 2] if len(runs) % 2 else runs[len(runs) // 2 - 1]  # the median run (lower middle of an even count)
+        med = lambda xs: statistics.median(xs)                                      # noqa: E731
+        t_written, t_wall, t_work = med([written(t) for _, t, _ in runs]), med([w for w, _, _ in runs]), med([work(t) for _, t, _ in runs])
         ids = np.fromfile(os.path.join(out, "combco.0"), dtype=np.uint32)
         cnt = np.fromfile(os.path.join(out, "combco.0.a"), dtype=np.uint16)
         same = bool(np.array_equal(ids, resident_sketch[0][0]) and np.array_equal(cnt, resident_sketch[0][1]))
         keys = ("hip_ready", "engine_ready", "first_push", "last_push", "unmapped", "written", "finish_s", "threads", "chunks",
                 "chunks_discarded", "serial_rows", "stream_setup_s", "stream_wait_frame_s", "push_call_s", "wait_call_s")
-        return {"gbases_s": bases / max(work(tm), 1e-9) / 1e9, "seconds": work(tm), "init_s": tm.get("hip_ready"),
-                "gbases_s_wall": bases / wall / 1e9, "wall_s": wall,
+        return {"gbases_s": bases / max(t_written, 1e-9) / 1e9, "seconds": t_written,
+                "gbases_s_wall": bases / t_wall / 1e9, "wall_s": t_wall,
+                "gbases_s_excl_init": bases / max(t_work, 1e-9) / 1e9, "seconds_excl_init": t_work, "init_s": tm.get("hip_ready"),
                 "file_gb": os.path.getsize(fq) / 1e9,
                 "threads": tm.get("threads"), "timeline_s": {k: tm.get(k) for k in keys},
                 "all_runs": [{"wall_s": round(w, 4), "written_s": t.get("written"), "init_s": t.get("hip_ready"),
-                              "gbases_s": round(bases / max(work(t), 1e-9) / 1e9, 2)} for w, t, _ in runs],
+                              "gbases_s": round(bases / max(written(t), 1e-9) / 1e9, 2),
+                              "gbases_s_excl_init": round(bases / max(work(t), 1e-9) / 1e9, 2)} for w, t, _ in runs],
                 "sketch_equals_resident_run": same, "fastq_write_s": t_write,
                 "what": "`metakssd dist -L L3K11.shuf -A -o out --quiet --timing reads.fq`, %d reads = %.2f GB of FASTQ in /dev/shm, "
-                        "run %d times with a second in between, best by `seconds`.  seconds = HIP runtime ready (init_s after process "
-                        "start: the first HIP call returning; nothing of the input can be touched before, the row buffers are pinned "
-                        "memory) until the sketch directory is complete on disk: engine creation, mapping + framing the file on "
-                        "%s host threads, H2D, scan, finish, file output.  gbases_s = bases / seconds.  wall_s = the parent's "
-                        "clock around the whole process (spawn, init_s, seconds, runtime teardown at exit), best of the same runs on its "
-                        "own (all_runs has every pair); gbases_s_wall = bases / wall_s" % (n, os.path.getsize(fq) / 1e9, reps, tm.get("threads"))}
+                        "run %d times with a second in between; every figure is the MEDIAN over those runs.  seconds = process start "
+                        "until the sketch directory is complete on disk (HIP runtime start-up, engine creation, mapping + framing the "
+                        "file on %s host threads, H2D, scan, finish, file output); gbases_s = bases / seconds.  wall_s = the "
+                        "parent's clock around the whole process (spawn and the runtime's teardown at exit on top); gbases_s_wall = "
+                        "bases / wall_s.  seconds_excl_init = the same as seconds from the moment the first HIP call has returned "
+                        "(init_s after process start); gbases_s_excl_init = bases / seconds_excl_init" % (
+                            n, os.path.getsize(fq) / 1e9, reps, tm.get("threads"))}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def leg_config5(capi, genomes=512, mbases=4.0, threads=16, reps=3, ref_genomes=48):
+    """BASELINE config 5: `metakssd dist -L <shuf> -o out <genome directory>` (no -A) on synthetic multi-FASTA genomes in
+    /dev/shm, L3K10 and L2K11, whole command line by the parent's clock; the compiled reference on a few of the genomes"""
+    import numpy as np
+    import statistics
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    need = genomes * mbases * 1e6 * 1.03
+    if shm:
+        st = os.statvfs(shm)
+        if st.f_bavail * st.f_frsize < need * 1.2:
+            return {"what": "skipped: /dev/shm has %.1f GB free, the genomes need %.1f GB" % (st.f_bavail * st.f_frsize / 1e9, need / 1e9)}
+    tmp = tempfile.mkdtemp(prefix="mkc5_", dir=shm)
+    try:
+        gd = os.path.join(tmp, "genomes")
+        os.makedirs(gd)
+        # one pool of random bases laid out as 70-column lines; a genome = two contigs, each a run of whole lines from a
+        # position of its own (distinct genomes, no per-genome formatting work)
+        rs = np.random.RandomState(5)
+        nlines_pool = int(3 * mbases * 1e6 / 70)
+        pool = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, size=(nlines_pool, 70))]
+        pool = np.concatenate([pool, np.full((nlines_pool, 1), 10, np.uint8)], axis=1).reshape(-1)
+        half = int(mbases * 1e6 / 2 / 70)  # lines per contig
+        t0 = time.perf_counter()
+        for i in range(genomes):
+            a = (i * 7919) % (nlines_pool - 2 * half - 1)
+            b = (a + half + 1 + (i * 104729) % (nlines_pool - 2 * half - 1)) % (nlines_pool - half)
+            with open(os.path.join(gd, "g%04d.fna" % i), "wb") as f:
+                f.write(b">g%d_contig0\n" % i)
+                f.write(pool[71 * a: 71 * (a + half)].tobytes())
+                f.write(b">g%d_contig1\n" % i)
+                f.write(pool[71 * b: 71 * (b + half)].tobytes())
+        t_write = time.perf_counter() - t0
+        bases_each = 2 * half * 70
+        cli = os.path.join(ROOT, "metakssd_amd", "bin", "metakssd")
+        ref = os.path.join(ROOT, "oracle", "_ref", "metakssd")
+        out = {"genomes": genomes, "bases_per_genome": bases_each, "threads": threads, "write_s": round(t_write, 2),
+               "what": "`metakssd dist -L <shuf> -p %d -o out --quiet <dir of %d multi-FASTA genomes of %.1f Mbases, 2 contigs, 70-column "
+                       "lines, in /dev/shm>`: seconds = the parent's clock around the whole process, median of %d runs after one "
+                       "warm-up run; the FASTA text is parsed on the device (mk_sketch_push_stream)" % (threads, genomes, bases_each / 1e6, reps)}
+        for name, (k, sk, l, seed) in (("L3K10", (10, 6, 3, 10)), ("L2K11", (11, 5, 2, 211))):
+            sp = os.path.join(tmp, name + ".shuf")
+            capi.Shuf.generate(k, sk, l, seed).write(sp)
+            walls, fin = [], None
+            for rep in range(reps + 1):
+                od = os.path.join(tmp, "out_%s_%d" % (name, rep))
+                time.sleep(0.5)
+                m0 = time.monotonic()
+                r = subprocess.run([cli, "dist", "-L", sp, "-p", str(threads), "-o", od, "--quiet", "--timing", gd],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                m1 = time.monotonic()
+                if r.returncode != 0:
+                    out[name] = {"genomes_per_s": None, "what": "CLI failed: " + r.stderr.decode(errors="replace")[-300:]}
+                    break
+                for ln in r.stdout.decode(errors="replace").splitlines():
+                    if ln.startswith('{"timing"'):
+                        fin = json.loads(ln)["timing"]
+                if rep:
+                    walls.append(m1 - m0)
+                if rep < reps:
+                    shutil.rmtree(od, ignore_errors=True)
+            else:
+                w = statistics.median(walls)
+                out[name] = {"genomes_per_s": genomes / w, "gbases_s": genomes * bases_each / w / 1e9, "seconds": w,
+                             "all_runs_s": [round(x, 4) for x in walls],
+                             "finish_ms_per_genome": (fin or {}).get("finish_s", 0.0) / genomes * 1e3,
+                             "engine_ready_s": (fin or {}).get("engine_ready")}
+                if os.path.exists(ref) and ref_genomes:
+                    sub = os.path.join(tmp, "few_" + name)
+                    os.makedirs(sub)
+                    for fn in sorted(os.listdir(gd))[:ref_genomes]:
+                        os.symlink(os.path.join(gd, fn), os.path.join(sub, fn))
+                    cores = os.cpu_count() or 1
+                    t0 = time.perf_counter()
+                    rr = subprocess.run([ref, "dist", "-L", sp, "-p", str(cores), "-o", os.path.join(tmp, "ref_" + name), sub],
+                                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    dt = time.perf_counter() - t0
+                    if rr.returncode == 0:
+                        out[name]["cpu_baseline"] = {"genomes_per_s": ref_genomes / dt, "gbases_s": ref_genomes * bases_each / dt / 1e9,
+                                                     "cores": cores, "kind": "reference",
+                                                     "sample": "%d of the genomes, oracle/_ref/metakssd dist -p %d" % (ref_genomes, cores)}
+        return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
 def kernel_source_id():
     h = hashlib.sha256()
-    for f in ("mk_kernels.hip.h", "mk_engine.hip"):
+    for f in ("mk_kernels.hip.h", "mk_engine.hip", "mk_stream.hip.h"):
         h.update(open(os.path.join(ROOT, "metakssd_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -189,7 +285,8 @@ def main():
                     help="strong scaling: this many reads split over the ranks (default with N > 1: 500 M = BASELINE config 4)")
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-legs", action="store_true", help="skip t_stream / t_e2e (N = 1 only anyway)")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip t_stream / t_e2e / config5 (N = 1 only anyway)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the genome-directory leg (BASELINE config 5 through the command line)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo moves the lists through the host (debug)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (needs --backend gloo)")
@@ -421,7 +518,7 @@ def main():
         line = {
             "metric": "Gbases/s sketched (150 bp synthetic reads, L3K11 -A)",
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "timed_region_s": dt, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u64 k-mers over u8 bases (integer)", "data": "synthetic",
             "config": {"workload": workload + ", resident in HBM (160 B rows), L3K11 .shuf {k=11,subk=6,drlevel=3}, -A counted "
                                               "sketch, begin+scan+finish per step",
@@ -479,6 +576,11 @@ def main():
                 line["t_e2e"] = leg_e2e(capi, shuf, n, sketch)
             except Exception as ex:
                 line["t_e2e"] = {"gbases_s": None, "what": "failed: %s" % ex}
+        if world == 1 and not args.no_host_legs and not args.no_config5:
+            try:
+                line["config5"] = leg_config5(capi)
+            except Exception as ex:
+                line["config5"] = {"what": "failed: %s" % ex}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -141,7 +141,9 @@ int mk_engine_destroy(mk_engine *e);
  *   MK_OPT_SPARSE   -1 / 0 / 1: dirty-block bookkeeping of the table passes by table size (default: on from 2^26 slots) / off / on
  *   MK_OPT_CAND_CAP records per scan wave in the candidate append buffers (default 8192; 0 = resolve every filter hit inline)
  *   MK_OPT_RESULT_CAP entries the pinned result arrays hold now (default: 2 M at the first finish; a larger sketch grows them
- *                   and writes its result a second time)
+ *                   and writes its result a second time).  Setting it, like every later mk_sketch_finish on the engine,
+ *                   INVALIDATES the arrays an earlier mk_result pointed to (they are the engine's: copy what must outlive
+ *                   the next sketch)
  *   MK_OPT_DIRECT_HOST 0 / 1: host pushes of rows in pinned memory are scanned in place over PCIe (one scan launch per push,
  *                   no staging copy) instead of being copied into staging regions first (default 0)
  *   MK_OPT_FRONT_BITS -1 / 0 / 3..28: a small accumulation table of 2^n slots in front of the hashsize-slot one, so that the
@@ -179,6 +181,17 @@ int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev, uint32_t 
 int mk_sketch_push_reads_async(mk_engine *e, const uint8_t *rows, uint32_t stride, uint64_t nreads, uint64_t first_read_ordinal,
                                uint64_t *ticket);
 int mk_sketch_push_wait(mk_engine *e, uint64_t ticket);
+/* FASTA text as it is in the file (config 5; what SURVEY.md 8b calls mk_sketch_push_stream): the engine copies the bytes to
+ * the device and does there what fasta2co() / uniq_fasta2co() do while they walk their 64 KiB window (iseq2comem.c:240-279,
+ * :751-790): '\n' and '\r' are skipped without resetting the k-mer window, a '>' skips to the end of its line and resets, any
+ * other byte that is no base resets.  The k-mers (which may span line breaks) are then taken from overlapping rows of the
+ * resulting base stream in HBM -- no host byte loop (mk_fasta_window remains as the host-side equivalent; both give the same
+ * sketch).  Text may be pushed in pieces (each < 2^31 bytes): final == 0 for every piece but the last of the sketch, final != 0
+ * for the last (n == 0 is allowed).  `text` may be reused when the call returns for pageable memory; pinned memory must stay
+ * untouched until the next call on this engine that waits (a non-final push, mk_sketch_finish, mk_engine_sync).  A stream that
+ * ends inside a header line is the reference's "can not find seqences head start from '>'" abort: mk_sketch_finish returns
+ * MK_ERR_FORMAT.  May be mixed with mk_sketch_push_reads* in one sketch; ordinals follow the order of the calls. */
+int mk_sketch_push_stream(mk_engine *e, const uint8_t *text, uint64_t n, int final);
 int mk_sketch_finish(mk_engine *e, mk_result *out);
 int mk_result_release(mk_engine *e, mk_result *r);
 int mk_engine_sync(mk_engine *e);
@@ -201,6 +214,13 @@ int mk_partial_count(mk_engine *e, uint64_t *n);
 /* copy {key, min(count,65535), first ordinal} of every distinct key into caller DEVICE buffers */
 int mk_partial_export(mk_engine *e, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t *ords_dev, uint64_t capacity,
                       uint64_t *n_out);
+/* The same in two steps for a caller that drives several engines (one per GPU): mk_partial_count_begin queues the compaction
+ * and returns, the next mk_partial_count / mk_partial_export[_async] waits for it; mk_partial_export_async queues the three
+ * copies on the engine's stream and returns (mk_engine_sync waits).  Engines on different GPUs then compact and copy at the
+ * same time instead of one after the other (libmetakssd_multi.so does exactly that). */
+int mk_partial_count_begin(mk_engine *e);
+int mk_partial_export_async(mk_engine *e, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t *ords_dev, uint64_t capacity,
+                            uint64_t *n_out);
 /* fold another shard's export (DEVICE buffers) into this engine: counts add, first ordinals take min */
 int mk_partial_import(mk_engine *e, const uint64_t *keys_dev, const uint32_t *counts_dev, const uint64_t *ords_dev,
                       uint64_t n);

@@ -11,8 +11,9 @@
  * the result is bit-identical to one engine scanning everything -- and to the reference's sequential run.
  *
  * A separate library because it links librccl.so (570 MB): the single-GPU command line never loads it.
- * When the device list names one GPU several times (tests on a one-GPU box) or RCCL cannot be initialised, the lists move
- * with plain device copies (hipMemcpyPeerAsync) instead; mk_multi_transport() says which.
+ * When the device list names one GPU several times (tests on a one-GPU box) the lists move with plain device copies
+ * (hipMemcpyPeerAsync) instead; on distinct GPUs a failing RCCL is an error unless the caller opts in to copies
+ * (mk_multi_create_ex).  mk_multi_transport() says which transport is in use.
  */
 #ifndef METAKSSD_MULTI_H
 #define METAKSSD_MULTI_H
@@ -24,8 +25,16 @@ extern "C" {
 
 typedef struct mk_multi mk_multi;
 
-/* engines on devices[0..n) (created concurrently, one host thread each), engine 0 is where results are finished */
+/* engines on devices[0..n) (created concurrently, one host thread each), engine 0 is where results are finished.
+ * n <= 16: the table slot's count field has room for that many concurrent imports of 65535, not for 17 (mk_multi.hip).
+ * Transport: RCCL when the devices are distinct.  If RCCL cannot be initialised there, mk_multi_create FAILS (MK_ERR_HIP, the
+ * RCCL error in mk_multi_last_error(NULL)) unless the caller opted in to device copies -- MK_MULTI_ALLOW_DEVICE_COPIES here,
+ * MK_MULTI_ALLOW_COPIES=1 in the environment for mk_multi_create, --allow-device-copies on the command line.  A list that
+ * names one GPU several times can only use device copies and does.  The transport chosen is printed on stderr for n > 1. */
+enum { MK_MULTI_ALLOW_DEVICE_COPIES = 1u, /* RCCL failed to initialise: fall back to hipMemcpyPeerAsync instead of failing */
+       MK_MULTI_FORCE_DEVICE_COPIES = 2u  /* do not try RCCL at all */ };
 int mk_multi_create(const mk_params *p, const int *devices, int n, mk_multi **out);
+int mk_multi_create_ex(const mk_params *p, const int *devices, int n, unsigned flags, mk_multi **out);
 int mk_multi_destroy(mk_multi *m);
 const char *mk_multi_last_error(const mk_multi *m); /* m may be NULL: last error of a failed create */
 int mk_multi_count(const mk_multi *m);

@@ -200,34 +200,23 @@ static void sketch_fastq(const char *who, mk_engine *e, const char *path, const 
   mk_host_free(rows);
 }
 
+/* fasta2co()'s walk over the file (iseq2comem.c:224-279) happens on the device: the bytes the pipe delivers are pushed as
+ * they are, mk_sketch_push_stream drops line ends and header lines there */
 static void sketch_fasta(const char *who, mk_engine *e, const char *path, const char *pipecmd) {
   FILE *f = piped(who, path, pipecmd);
-  uint8_t *io = malloc(WINBUF), *rows = NULL;
-  if (!io || mk_host_alloc((void **)&rows, WINBUF) != MK_OK) err(errno, "%s: out of memory", who);
-  const uint32_t stride = MK_ROW_PITCH(512u); /* 528: not a multiple of 128 */
-  mk_fasta_state st;
-  mk_fasta_window_init(&st, g_params.TL);
-  uint64_t ord = 0;
-  int eof = 0, any = 0;
-  while (!eof) {
+  uint8_t *io = malloc(WINBUF);
+  if (!io) err(errno, "%s: out of memory", who);
+  int any = 0;
+  for (;;) {
     const size_t have = fread(io, 1, WINBUF, f);
-    if (have == 0) eof = 1; else any = 1;
-    size_t off = 0;
-    do {
-      uint64_t nrows = 0;
-      size_t used = 0;
-      const int rc = mk_fasta_window(&st, io + off, have - off, eof, rows, stride, WINBUF / stride, &nrows, &used);
-      if (rc == MK_ERR_FORMAT) err(errno, "fasta2co(): can not find seqences head start from '>' %d", 0); /* iseq2comem.c:269 */
-      if (rc != MK_OK) err(errno, "%s: mk_fasta_window failed (%d)", who, rc);
-      if (nrows && mk_sketch_push_reads(e, rows, stride, nrows, ord) != MK_OK) err(errno, "%s: %s", who, mk_last_error(e));
-      ord += nrows;
-      off += used;
-    } while (off < have);
+    if (have == 0) break;
+    any = 1;
+    if (mk_sketch_push_stream(e, io, have, 0) != MK_OK) err(errno, "%s: %s", who, mk_last_error(e));
   }
   if (!any) err(errno, "fastco():eof or fread error file=%s", path); /* iseq2comem.c:235 */
+  if (mk_sketch_push_stream(e, NULL, 0, 1) != MK_OK) err(errno, "%s: %s", who, mk_last_error(e));
   pclose(f);
   free(io);
-  mk_host_free(rows);
 }
 
 /* begin -> front end -> finish on the one engine, the result parked under `co` */
@@ -240,6 +229,7 @@ static llong *sketch(const char *who, int mode, int M, const char *path, llong *
   else sketch_fasta(who, e, path, pipecmd);
   mk_result r;
   const int rc = mk_sketch_finish(e, &r);
+  if (rc == MK_ERR_FORMAT) err(errno, "fasta2co(): can not find seqences head start from '>' %d", 0); /* iseq2comem.c:269 */
   if (rc == MK_ERR_CROWDED) /* iseq2comem.c:708-709 (and :303, :811 in the FASTA flavours) */
     err(errno, "the context space is too crowd, try rerun the program using -k%d", g_params.k + 1);
   if (rc != MK_OK) err(errno, "%s: %s", who, mk_last_error(e));

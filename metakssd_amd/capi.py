@@ -113,6 +113,9 @@ def _load():
         "mk_sketch_push_reads_device": [vp, vp, u32, u64, u64],
         "mk_sketch_push_reads_async": [vp, vp, u32, u64, u64, C.POINTER(u64)],
         "mk_sketch_push_wait": [vp, u64],
+        "mk_sketch_push_stream": [vp, vp, u64, C.c_int],
+        "mk_partial_count_begin": [vp],
+        "mk_partial_export_async": [vp, vp, vp, vp, u64, C.POINTER(u64)],
         "mk_sketch_finish": [vp, C.POINTER(ResultC)],
         "mk_result_release": [vp, C.POINTER(ResultC)],
         "mk_engine_sync": [vp],
@@ -392,6 +395,22 @@ class Engine:
         st = FastqStatsC()
         _check(lib.mk_sketch_push_fastq(self.h, b.ctypes.data if len(b) else None, len(b), C.byref(o), first_ordinal, C.byref(st)), self.h)
         return st
+
+    def push_stream(self, text, final=True, piece=None):
+        """FASTA text as it is in the file -> mk_sketch_push_stream; piece: push in pieces of that many bytes (the last one final)"""
+        b = np.frombuffer(bytes(text), dtype=np.uint8)
+        if not piece:
+            _check(lib.mk_sketch_push_stream(self.h, b.ctypes.data if len(b) else None, len(b), 1 if final else 0), self.h)
+            return
+        at = 0
+        while True:
+            n = min(piece, len(b) - at)
+            last = at + n >= len(b)
+            part = np.ascontiguousarray(b[at:at + n])
+            _check(lib.mk_sketch_push_stream(self.h, part.ctypes.data if n else None, n, 1 if (last and final) else 0), self.h)
+            at += n
+            if last:
+                break
 
     def push_reads_async(self, rows, stride, first_read_ordinal=0):
         """queue the copies and the scan; `rows` (host numpy u8) must stay untouched until push_wait(ticket)"""

@@ -45,7 +45,9 @@ static void die(const char *fmt, ...) {
   vfprintf(stderr, fmt, ap);
   fprintf(stderr, "\n");
   va_end(ap);
-  exit(1);
+  /* not exit(): with driver / worker threads still inside HIP calls the runtime's exit handlers can wait for them forever */
+  fflush(NULL);
+  _exit(1);
 }
 
 static int has_suffix(const char *s, const char *suf) {
@@ -123,6 +125,7 @@ typedef struct {
   pthread_cond_t cv;
   int done, rc, device;
   int ndev, devs[64];   /* --devices: more than one GPU -> libmetakssd_multi.so */
+  unsigned multi_flags; /* MK_MULTI_ALLOW_DEVICE_COPIES with --allow-device-copies */
   mk_multi *multi;
   int have_params;      /* the main thread has read the .shuf file: P may be used */
   const mk_params *P;
@@ -136,7 +139,7 @@ static int g_component_sz = 8; /* --component-sz: the reference's compile-time C
 
 /* libmetakssd_multi.so (it links librccl.so, 570 MB) is loaded only when --devices names several GPUs */
 static struct {
-  int (*create)(const mk_params *, const int *, int, mk_multi **);
+  int (*create)(const mk_params *, const int *, int, unsigned, mk_multi **);
   const char *(*last_error)(const mk_multi *);
   mk_engine *(*engine)(mk_multi *, int);
   const char *(*transport)(const mk_multi *);
@@ -148,7 +151,7 @@ static struct {
 static void load_multi(void) {
   void *h = dlopen("libmetakssd_multi.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) die("--devices with several GPUs needs libmetakssd_multi.so: %s", dlerror());
-  *(void **)&g_multi.create = dlsym(h, "mk_multi_create");
+  *(void **)&g_multi.create = dlsym(h, "mk_multi_create_ex");
   *(void **)&g_multi.last_error = dlsym(h, "mk_multi_last_error");
   *(void **)&g_multi.engine = dlsym(h, "mk_multi_engine");
   *(void **)&g_multi.transport = dlsym(h, "mk_multi_transport");
@@ -201,7 +204,7 @@ static void *engine_thread(void *arg) {
   pthread_mutex_unlock(&f->mu);
   if (rc == MK_OK && !f->P) rc = MK_ERR_ARG; /* the main thread gave up */
   if (rc == MK_OK && f->ndev > 1) {
-    rc = g_multi.create(f->P, f->devs, f->ndev, &f->multi);
+    rc = g_multi.create(f->P, f->devs, f->ndev, f->multi_flags, &f->multi);
     if (rc != MK_OK) snprintf(f->err, sizeof f->err, "%s", g_multi.last_error(NULL));
     else f->eng = g_multi.engine(f->multi, 0);
   } else if (rc == MK_OK) {
@@ -217,10 +220,11 @@ static void *engine_thread(void *arg) {
   return NULL;
 }
 
-static void engine_start(engine_future *f, int device, const int *devs, int ndev) {
+static void engine_start(engine_future *f, int device, const int *devs, int ndev, unsigned multi_flags) {
   memset(f, 0, sizeof *f);
   f->device = device;
   f->ndev = ndev;
+  f->multi_flags = multi_flags;
   for (int i = 0; i < ndev && i < 64; i++) f->devs[i] = devs[i];
   if (ndev > 1) load_multi();
   pthread_mutex_init(&f->mu, NULL);
@@ -425,11 +429,28 @@ static void sketch_fastq(ctx_t *c, const char *path) {
   close_input(&in);
 }
 
+static int g_host_fasta = 0; /* --host-fasta: window FASTA text on the host (mk_fasta_window) instead of on the device */
+
 static void sketch_fasta(ctx_t *c, const char *path, int TL) {
   ensure_buffers(c);
   input_t in;
   if (!open_input(path, &in)) die("fasta2co():%s: %s", path, strerror(errno));
   FILE *f = in.f;
+  if (!g_host_fasta) {
+    /* the file's bytes as they are, piece by piece: the device drops line ends and header lines (mk_sketch_push_stream) */
+    mk_engine *e = sketch_engine(c);
+    int any = 0;
+    for (;;) {
+      const size_t have = fread(c->io, 1, IOBUF, f);
+      if (have == 0) break;
+      any = 1;
+      CHECK(e, mk_sketch_push_stream(e, c->io, have, 0));
+    }
+    if (!any) die("fastco():eof or fread error file=%s", path); /* iseq2comem.c:235 */
+    CHECK(e, mk_sketch_push_stream(e, NULL, 0, 1));
+    close_input(&in);
+    return;
+  }
   const uint32_t stride = MK_ROW_PITCH(512u); /* 528: not a multiple of 128 */
   mk_fasta_state st;
   if (mk_fasta_window_init(&st, TL) != MK_OK) die("mk_fasta_window_init failed");
@@ -463,6 +484,8 @@ typedef struct {
   int buf;                   /* pinned buffer index, -1 = none */
   uint64_t nrows;
   uint32_t stride;
+  uint64_t text_bytes;       /* FASTA for the device stream: the buffer holds the file's bytes, not rows */
+  int is_text;
 } pf_slot;
 typedef struct {
   strlist *files;
@@ -505,6 +528,26 @@ static uint8_t *slurp(const char *path, size_t *n_out, size_t limit, int *too_bi
   return b;
 }
 
+/* the bytes of an uncompressed regular file straight into `dst` (a pinned row buffer): 1 = done, 0 = not that kind of file or
+ * larger than cap */
+static int slurp_into(const char *path, uint8_t *dst, size_t cap, size_t *n_out) {
+  if (is_compressed(path)) return 0;
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return 0;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size > cap) { close(fd); return 0; }
+  size_t n = 0;
+  while (n < (size_t)st.st_size) {
+    const ssize_t r = read(fd, dst + n, (size_t)st.st_size - n);
+    if (r <= 0) break;
+    n += (size_t)r;
+  }
+  close(fd);
+  if (n != (size_t)st.st_size) return 0;
+  *n_out = n;
+  return 1;
+}
+
 static void *pf_worker(void *arg) {
   pf_t *pf = arg;
   for (;;) {
@@ -520,6 +563,21 @@ static void *pf_worker(void *arg) {
     const char *path = pf->files->v[i];
     size_t n = 0;
     int too_big = 0;
+    if (!g_host_fasta && !is_fastq(path)) {
+      /* FASTA for the device stream: the file's bytes go into the pinned buffer as they are (no parsing on the host) */
+      if (slurp_into(path, pf->bufs[b], ROWBUF, &n)) {
+        if (n == 0) s.err = MK_ERR_STATE; /* empty input: the reference's "eof or fread error" (iseq2comem.c:235) */
+        s.is_text = 1; s.text_bytes = n;
+        pthread_mutex_lock(&pf->mu);
+        if (s.err) { pf->free_bufs[pf->nfree++] = b; s.buf = -1; pthread_cond_broadcast(&pf->cv_buf); }
+        s.ready = 1;
+        pf->slots[i] = s;
+        pthread_cond_broadcast(&pf->cv_ready);
+        pthread_mutex_unlock(&pf->mu);
+        continue;
+      }
+      /* compressed, a pipe, or larger than a buffer: through a heap copy below */
+    }
     uint8_t *text = slurp(path, &n, ROWBUF, &too_big);
     if (!text) s.err = MK_ERR_IO;
     else if (too_big) s.too_big = 1;
@@ -537,6 +595,9 @@ static void *pf_worker(void *arg) {
         s.nrows = nrows; s.stride = stride;
         break;
       }
+    } else if (!g_host_fasta) {
+      if (n == 0) s.err = MK_ERR_STATE;
+      else { memcpy(pf->bufs[b], text, n); s.is_text = 1; s.text_bytes = n; } /* (.gz genomes: the text came through zcat) */
     } else {
       mk_fasta_state st;
       const uint32_t stride = MK_ROW_PITCH(512u); /* 528: not a multiple of 128 */
@@ -1499,6 +1560,149 @@ static int run_search(const char *refdir, const char *qrydir, const char *outdir
   return 0;
 }
 
+/* ---- one input file -> one sketch on the engine(s) of `c` (run_stageI()'s loop body, command_dist.c:367-404) ------------- */
+typedef struct {
+  strlist *files;
+  const mk_params *P;
+  int abundance, uniq, first_nonfq, kmerocrs, kmerqlty, nthreads, quiet;
+  pf_t *pf;
+  int nworkers;
+} job_opts;
+
+static int sketch_one_file(ctx_t *c, const job_opts *o, int i, mk_result *res, double *t_finish) {
+  const char *path = o->files->v[i];
+  c->next_ordinal = 0;
+  const int fq = is_fastq(path);
+  /* -A holds until the file loop reaches the first input that is no FASTQ (command_dist.c:389-392) */
+  const int abundance = o->abundance && i < o->first_nonfq;
+  if (fq && abundance && !o->quiet) printf("running mt_shortreads2koc()\n");
+  c->begun = 0;
+  c->mode = fq ? (abundance ? MK_MODE_KOC : MK_MODE_OCC_SET) : (o->uniq ? MK_MODE_UNIQ_SET : MK_MODE_SET);
+  c->min_occ = o->kmerocrs;
+  c->occ = fq && !abundance; c->qmin = o->kmerqlty; c->TL = o->P->TL; c->nthreads = o->nthreads;
+  int handled = 0, held = -1;
+  pf_t *pf = o->pf;
+  if (o->nworkers) {
+    pthread_mutex_lock(&pf->mu);
+    while (!pf->slots[i].ready) pthread_cond_wait(&pf->cv_ready, &pf->mu);
+    pf_slot sl = pf->slots[i];
+    pthread_mutex_unlock(&pf->mu);
+    if (sl.err == MK_ERR_IO) die("%s: cannot open", path);
+    if (sl.err == MK_ERR_STATE && !fq) die("fastco():eof or fread error file=%s", path);
+    if (sl.err == MK_ERR_FORMAT && !fq) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", path);
+    if (sl.err) die("%s: sequence or header line of 4095+ characters: outside the FASTQ framing contract (iseq2comem.c:656,673)", path);
+    if (!sl.too_big) {
+      if (sl.is_text) {
+        mk_engine *e = sketch_engine(c);
+        CHECK(e, mk_sketch_push_stream(e, pf->bufs[sl.buf], sl.text_bytes, 1));
+        held = sl.buf; /* pinned text: the copy is queued, the buffer goes back once the finish below has waited */
+      } else {
+        if (sl.nrows) push_rows(c, pf->bufs[sl.buf], sl.stride, sl.nrows);
+        pthread_mutex_lock(&pf->mu); /* push returned: the buffer has been copied to the device */
+        pf->free_bufs[pf->nfree++] = sl.buf;
+        pthread_cond_broadcast(&pf->cv_buf);
+        pthread_mutex_unlock(&pf->mu);
+      }
+      handled = 1;
+    }
+  }
+  if (!handled) {
+    if (fq) sketch_fastq(c, path);
+    else sketch_fasta(c, path, o->P->TL);
+  }
+  mk_engine *eng = sketch_engine(c); /* an input without a single row still gives an (empty) sketch */
+  const double tf = now_s();
+  int rc;
+  if (c->multi) {
+    rc = g_multi.finish(c->multi, res, &c->gather_ms, &c->tail_ms);
+    if (rc != MK_OK && rc != MK_ERR_CROWDED) die("mk_multi_finish failed (%d): %s", rc, g_multi.last_error(c->multi));
+  } else rc = mk_sketch_finish(eng, res);
+  *t_finish += now_s() - tf;
+  if (held >= 0) {
+    pthread_mutex_lock(&pf->mu);
+    pf->free_bufs[pf->nfree++] = held;
+    pthread_cond_broadcast(&pf->cv_buf);
+    pthread_mutex_unlock(&pf->mu);
+  }
+  if (rc == MK_ERR_CROWDED) die("the context space is too crowd, try rerun the program using -k%d", o->P->k + 1);
+  if (rc == MK_ERR_FORMAT) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", path); /* iseq2comem.c:269 */
+  if (rc != MK_OK) die("mk_sketch_finish failed (%d): %s", rc, mk_last_error(eng));
+  return MK_OK;
+}
+
+/* ---- several GPUs, several files: whole files are the unit (SURVEY.md 8e "config 5"; the reference's team over files,
+ * command_dist.c:363-372).  One engine and one driver thread per listed GPU; the drivers take the next file from a shared
+ * cursor, sketch it whole on their engine and leave a copy of the result; the main thread writes the results in file order.
+ * No exchange between GPUs, no RCCL.  Naming one GPU several times gives that many engines on it: one file's finish then runs
+ * beside the next file's scan. */
+typedef struct {
+  int ready;
+  mk_result res;       /* a copy: components, ids and counts in malloc'ed memory */
+} file_result;
+typedef struct {
+  pthread_t th;
+  ctx_t c;
+  engine_future fut_dummy;
+  const job_opts *o;
+  int device;
+  int *cursor;
+  file_result *out;
+  pthread_mutex_t *mu;
+  pthread_cond_t *cv;
+  double t_finish;
+  int created;
+} shard_driver;
+
+static void copy_result(const mk_result *r, mk_result *dst) {
+  dst->component_num = r->component_num;
+  dst->total = r->total;
+  dst->components = malloc(sizeof(mk_component) * (size_t)(r->component_num > 0 ? r->component_num : 1));
+  if (!dst->components) die("out of memory");
+  for (int k = 0; k < r->component_num; k++) {
+    const mk_component *a = &r->components[k];
+    mk_component *b = &dst->components[k];
+    b->n = a->n;
+    b->ids = a->n ? malloc(4 * (size_t)a->n) : NULL;
+    b->counts = a->n && a->counts ? malloc(2 * (size_t)a->n) : NULL;
+    if (a->n && (!b->ids || (a->counts && !b->counts))) die("out of memory");
+    if (a->n) memcpy(b->ids, a->ids, 4 * (size_t)a->n);
+    if (a->n && a->counts) memcpy(b->counts, a->counts, 2 * (size_t)a->n);
+  }
+}
+static void free_result(mk_result *r) {
+  for (int k = 0; k < r->component_num; k++) { free(r->components[k].ids); free(r->components[k].counts); }
+  free(r->components);
+  r->components = NULL;
+}
+
+static void *shard_driver_run(void *arg) {
+  shard_driver *d = arg;
+  if (!d->c.eng) { /* engines 1..: created here, all at the same time; engine 0 came through the start-up future */
+    mk_engine *e = NULL;
+    const int rc = mk_engine_create(d->o->P, d->device, &e);
+    if (rc != MK_OK) die("mk_engine_create on GPU %d failed (%d): %s", d->device, rc, mk_last_error(NULL));
+    d->c.eng = e;
+    d->c.engs[0] = e;
+  }
+  for (;;) {
+    pthread_mutex_lock(d->mu);
+    const int i = (*d->cursor)++;
+    pthread_mutex_unlock(d->mu);
+    if (i >= d->o->files->n) return NULL;
+    mk_result res;
+    sketch_one_file(&d->c, d->o, i, &res, &d->t_finish);
+    file_result fr;
+    memset(&fr, 0, sizeof fr);
+    copy_result(&res, &fr.res);
+    mk_result_release(d->c.eng, &res);
+    fr.ready = 1;
+    pthread_mutex_lock(d->mu);
+    d->out[i] = fr;
+    pthread_cond_broadcast(d->cv);
+    pthread_mutex_unlock(d->mu);
+  }
+}
+
 int main(int argc, char **argv) {
   g_t0 = now_s();
   setvbuf(stdout, NULL, _IOLBF, 0);
@@ -1517,6 +1721,7 @@ int main(int argc, char **argv) {
   uint64_t chunk_bytes = (uint64_t)32 << 20; /* text per framing job = about 17 MiB of rows per host-to-device copy */
   int drop_pages = 1, inflight = 3, slow_exit = 0, direct_host = 0;
   int devs[64], ndev = 0; /* --devices 0-7 / 0,2,5 / 0,0 (the same GPU twice: two engines, for tests) */
+  int allow_copies = 0;   /* --allow-device-copies: distinct GPUs whose RCCL does not come up exchange with peer copies instead of failing */
   int kmerocrs = 1, kmerqlty = 0; /* command_dist_wrapper.c:79-80 */
   const char *refpath = NULL, *skf = NULL;
   mk_dist_opts dopt = {0, 2, 0, 0, 1.0}; /* command_dist_wrapper.c:83-87 */
@@ -1537,6 +1742,8 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "-Q") && i + 1 < argc) kmerqlty = atoi(argv[++i]); /* :182-185 */
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--devices") && i + 1 < argc) ndev = parse_devices(argv[++i], devs, 64);
+    else if (!strcmp(argv[i], "--allow-device-copies")) allow_copies = 1;
+    else if (!strcmp(argv[i], "--host-fasta")) g_host_fasta = 1; /* FASTA windows made on the host (mk_fasta_window), not on the device */
     else if (!strcmp(argv[i], "--quiet")) quiet = 1;
     else if (!strcmp(argv[i], "--component-sz") && i + 1 < argc) g_component_sz = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--timing")) timing = 1;
@@ -1589,8 +1796,11 @@ int main(int argc, char **argv) {
   const double t0 = g_t0;
   /* HIP start-up and then the engine's tables on a helper thread; the main thread reads the .shuf file meanwhile and goes
    * on to map and frame the input */
+  /* several GPUs and several files: the files are dealt to the GPUs whole (no exchange, no RCCL); several GPUs and ONE file: its
+   * rows are dealt round-robin and the partial sketches merged on GPU 0 (libmetakssd_multi.so) */
+  const int shard_files = ndev > 1 && files.n > 1;
   engine_future fut;
-  engine_start(&fut, ndev ? devs[0] : device, devs, ndev);
+  engine_start(&fut, ndev ? devs[0] : device, devs, shard_files ? 0 : ndev, allow_copies ? MK_MULTI_ALLOW_DEVICE_COPIES : 0u);
   mk_shuf sh;
   int rc = mk_shuf_read(shuf_path, &sh);
   if (rc != MK_OK) die("read_dim_shuffle_file(): cannot read %s (%d)", shuf_path, rc);
@@ -1632,6 +1842,7 @@ int main(int argc, char **argv) {
     pf.qmin = kmerqlty;
     pf.koc_until = abundance ? first_nonfq : 0; /* files in front of this index are read the mt_shortreads2koc way */
     pf.nbufs = nthreads < PF_MAX_BUFS ? nthreads : PF_MAX_BUFS;
+    if (shard_files && pf.nbufs < ndev + 1) pf.nbufs = ndev + 1 < PF_MAX_BUFS ? ndev + 1 : PF_MAX_BUFS; /* every driver may hold one */
     if (pf.nbufs > files.n) pf.nbufs = files.n;
     pf.slots = calloc(files.n, sizeof(pf_slot));
     pthread_mutex_init(&pf.mu, NULL);
@@ -1657,56 +1868,46 @@ int main(int argc, char **argv) {
   }
 
   double t_finish = 0;
-  for (int i = 0; i < files.n; i++) {
-    const char *path = files.v[i];
-    c.next_ordinal = 0;
-    const int fq = is_fastq(path);
-    if (!fq && abundance) {
-      abundance = 0;
-      printf("Warning: close abundance mode (-A) since non-fastq file input.\n");
+  job_opts jo = {&files, &P, abundance, uniq, first_nonfq, kmerocrs, kmerqlty, nthreads, quiet, &pf, nworkers};
+  if (first_nonfq < files.n && abundance) printf("Warning: close abundance mode (-A) since non-fastq file input.\n");
+  if (shard_files) {
+    /* several engines, whole files each */
+    shard_driver *drv = calloc((size_t)ndev, sizeof *drv);
+    file_result *results = calloc((size_t)files.n, sizeof *results);
+    pthread_mutex_t smu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_cond_t scv = PTHREAD_COND_INITIALIZER;
+    int cursor = 0;
+    if (!drv || !results) die("out of memory");
+    c.nthreads = nthreads;
+    (void)engine_get(&c); /* engine 0 (devs[0]) from the start-up thread */
+    for (int j = 0; j < ndev; j++) {
+      shard_driver *d = &drv[j];
+      d->o = &jo; d->device = devs[j]; d->cursor = &cursor; d->out = results; d->mu = &smu; d->cv = &scv;
+      d->c.chunk_bytes = chunk_bytes; d->c.drop_pages = drop_pages; d->c.inflight = inflight; d->c.direct_host = direct_host;
+      d->c.ndev = 1;
+      if (j == 0) { d->c.eng = c.eng; d->c.engs[0] = c.eng; }
+      if (pthread_create(&d->th, NULL, shard_driver_run, d) != 0) die("cannot start a thread: %s", strerror(errno));
     }
-    if (fq && abundance && !quiet) printf("running mt_shortreads2koc()\n");
-    c.begun = 0;
-    c.mode = fq ? (abundance ? MK_MODE_KOC : MK_MODE_OCC_SET) : (uniq ? MK_MODE_UNIQ_SET : MK_MODE_SET);
-    c.min_occ = kmerocrs;
-    c.occ = fq && !abundance; c.qmin = kmerqlty; c.TL = P.TL; c.nthreads = nthreads;
-    int handled = 0;
-    if (nworkers) {
-      pthread_mutex_lock(&pf.mu);
-      while (!pf.slots[i].ready) pthread_cond_wait(&pf.cv_ready, &pf.mu);
-      pf_slot sl = pf.slots[i];
-      pthread_mutex_unlock(&pf.mu);
-      if (sl.err == MK_ERR_IO) die("%s: cannot open", path);
-      if (sl.err == MK_ERR_STATE && !fq) die("fastco():eof or fread error file=%s", path);
-      if (sl.err == MK_ERR_FORMAT && !fq) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", path);
-      if (sl.err) die("%s: sequence or header line of 4095+ characters: outside the FASTQ framing contract (iseq2comem.c:656,673)", path);
-      if (!sl.too_big) {
-        if (sl.nrows) push_rows(&c, pf.bufs[sl.buf], sl.stride, sl.nrows);
-        pthread_mutex_lock(&pf.mu); /* push returned: the buffer has been copied to the device */
-        pf.free_bufs[pf.nfree++] = sl.buf;
-        pthread_cond_broadcast(&pf.cv_buf);
-        pthread_mutex_unlock(&pf.mu);
-        handled = 1;
-      }
+    for (int i = 0; i < files.n; i++) {
+      pthread_mutex_lock(&smu);
+      while (!results[i].ready) pthread_cond_wait(&scv, &smu);
+      file_result fr = results[i];
+      pthread_mutex_unlock(&smu);
+      rc = mk_sketchdir_add(sd, files.v[i], &fr.res);
+      if (rc != MK_OK) die("writing sketch for %s failed (%d)", files.v[i], rc);
+      free_result(&fr.res);
+      if (!quiet) printf("%d/%d decomposing %s\r", i + 1, files.n, files.v[i]);
     }
-    if (!handled) {
-      if (fq) sketch_fastq(&c, path);
-      else sketch_fasta(&c, path, P.TL);
+    for (int j = 0; j < ndev; j++) { pthread_join(drv[j].th, NULL); t_finish += drv[j].t_finish; c.nrows_total += drv[j].c.nrows_total; }
+  } else {
+    for (int i = 0; i < files.n; i++) {
+      mk_result res;
+      sketch_one_file(&c, &jo, i, &res, &t_finish);
+      rc = mk_sketchdir_add(sd, files.v[i], &res);
+      if (rc != MK_OK) die("writing sketch for %s failed (%d)", files.v[i], rc);
+      mk_result_release(c.eng, &res);
+      if (!quiet) printf("%d/%d decomposing %s\r", i + 1, files.n, files.v[i]);
     }
-    mk_engine *eng = sketch_engine(&c); /* an input without a single row still gives an (empty) sketch */
-    mk_result res;
-    const double tf = now_s();
-    if (c.multi) {
-      rc = g_multi.finish(c.multi, &res, &c.gather_ms, &c.tail_ms);
-      if (rc != MK_OK && rc != MK_ERR_CROWDED) die("mk_multi_finish failed (%d): %s", rc, g_multi.last_error(c.multi));
-    } else rc = mk_sketch_finish(eng, &res);
-    t_finish += now_s() - tf;
-    if (rc == MK_ERR_CROWDED) die("the context space is too crowd, try rerun the program using -k%d", P.k + 1);
-    if (rc != MK_OK) die("mk_sketch_finish failed (%d): %s", rc, mk_last_error(eng));
-    rc = mk_sketchdir_add(sd, path, &res);
-    if (rc != MK_OK) die("writing sketch for %s failed (%d)", path, rc);
-    mk_result_release(eng, &res);
-    if (!quiet) printf("%d/%d decomposing %s\r", i + 1, files.n, path);
   }
   if (!quiet) printf("\n");
   rc = mk_sketchdir_close(sd);

@@ -205,6 +205,10 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
   /* rows of a chunk take at most about as many bytes as its text (a record is two lines of the read's length plus a
    * header; the row is one); a chunk that needs more ends early and the pusher frames the rest serially */
   f.buf_bytes = f.chunk + f.chunk / 8 + 8192;
+  /* never less than ONE maximal record needs: a read of 19 998 characters (fastq2co()'s fgets width, iseq2comem.c:319,343) is cut
+   * into six 4096-byte rows; a buffer below that made the range framer give up on the record with MK_ERR_ARG and the stream
+   * reported a line beyond the reference's width */
+  if (f.buf_bytes < (size_t)8 * 4096 + 8192) f.buf_bytes = (size_t)8 * 4096 + 8192;
   f.nbufs = T + depth + 1;
   int rc = MK_OK;
   uint8_t *serial_buf = NULL;

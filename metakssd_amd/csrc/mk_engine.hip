@@ -7,6 +7,7 @@
  */
 #include "metakssd_hip.h"
 #include "mk_kernels.hip.h"
+#include "mk_stream.hip.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -89,9 +90,26 @@ struct mk_engine {
   /* dynamic-LDS limit already granted to each scan-kernel instantiation on this engine's device */
   std::vector<std::pair<const void *, size_t>> lds_granted;
 
+  /* key-list-driven dump (sparse bookkeeping): scratch sized to the number of keys, device-side result staging */
+  void *d_kl = nullptr;          /* skey[cap] | tkey[cap] | tidx[cap] | out_ids[cap] | out_cnt[cap] */
+  uint64_t kl_cap = 0;
+  uint32_t *d_kl_buckets = nullptr; /* bcount[nb + 1] | bcursor[nb] */
+  uint64_t kl_bucket_cap = 0;
+  bool slot_clean = false;       /* the layout table is all-empty (mk_kl_find_kernel hands every slot back) */
+  /* mk_sketch_push_stream: raw FASTA text -> base stream on the device (mk_stream.hip.h) */
+  uint8_t *d_text = nullptr, *d_stream = nullptr, *d_stream_tmp = nullptr;
+  size_t text_cap = 0, stream_cap = 0;
+  mk_fa_sum *d_fa_sum = nullptr;
+  size_t fa_sum_cap = 0;
+  mk_fa_state *d_fa_state = nullptr, *h_fa_state = nullptr; /* device state + pinned mirror */
+  uint64_t fa_tail = 0;      /* stream bytes carried from the last non-final push (exact: read back) */
+  uint64_t fa_rows_done = 0; /* virtual rows scanned so far in this sketch = ordinal of the next one */
+  bool fa_used = false, fa_final = false;
+
   int mode = -1;
   uint32_t min_occ = 1; /* MK_MODE_OCC_SET: dump keys seen at least this often */
   bool begun = false, compacted = false;
+  bool count_queued = false; /* mk_partial_count_begin: compaction + counter copy are on the stream, not waited for yet */
   uint64_t D = 0;
 
   /* launch tuning (fixed in the shipped library; a -DMK_TUNING build reads MK_SCAN_THREADS / MK_SCAN_CB / ..) */
@@ -246,6 +264,9 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipFree(e->d_dirty_acc); hipFree(e->d_dirty_slot); hipFree(e->d_list_acc); hipFree(e->d_list_slot); hipFree(e->d_nlist);
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters);
+  hipFree(e->d_kl); hipFree(e->d_kl_buckets);
+  hipFree(e->d_text); hipFree(e->d_stream); hipFree(e->d_stream_tmp); hipFree(e->d_fa_sum); hipFree(e->d_fa_state);
+  if (e->h_fa_state) hipHostFree(e->h_fa_state);
   if (e->h_comp_totals) hipHostFree(e->h_comp_totals);
   for (int i = 0; i < MK_TICKETS; i++) if (e->ev_ticket[i]) hipEventDestroy(e->ev_ticket[i]);
   if (e->h_counters) hipHostFree(e->h_counters);
@@ -317,8 +338,16 @@ static int mk_config_front(mk_engine *e, int bits) {
   if (bits < 0) {
     bits = 0;
     if (!e->sparse && S >= (1ull << 20)) while ((2ull << bits) <= S / 6) bits++; /* hashsize is a prime just below a power of two: S/8 would halve it */
+    if (e->sparse) {
+      /* sparse bookkeeping (tables of 2^26 slots and more: a genome's few thousand keys in half a billion slots): 2^18 front
+       * slots take a whole genome-sized sketch (limit 2^16 keys), cost 4 MiB to clear and to list, and the big table's dirty
+       * blocks are not touched at all; larger sketches spill into the big table as before */
+      uint32_t sb = 0;
+      while ((1ull << sb) < S) sb++;
+      bits = sb > 21u ? 18 : (sb > 6u ? (int)sb - 3 : 3);
+    }
   }
-  if (bits == 0 || e->sparse) return MK_OK;
+  if (bits == 0) return MK_OK;
   e->front_slots = 1ull << bits;
   MK_HIP(e, hipMalloc(&e->d_front, e->front_slots * 16));
   if (!e->d_front_desc) MK_HIP(e, hipMalloc((void **)&e->d_front_desc, sizeof(mk_front)));
@@ -469,7 +498,7 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
     case MK_OPT_SPARSE: {
       if (value < -1 || value > 1) return mk_fail(e, MK_ERR_ARG, "MK_OPT_SPARSE takes -1 (by table size), 0 or 1");
       int rc = mk_config_sparse(e, value < 0 ? e->P.hashsize >= (1u << 26) : value != 0);
-      return rc ? rc : mk_config_front(e, e->front_bits_opt); /* no front table with sparse bookkeeping */
+      return rc ? rc : mk_config_front(e, e->front_bits_opt);
     }
     case MK_OPT_FRONT_BITS:
       if (value < -1 || (value > 0 && value < 3) || value > 28) return mk_fail(e, MK_ERR_ARG, "MK_OPT_FRONT_BITS takes -1 (by table size), 0 (none) or 3..28");
@@ -577,13 +606,18 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   /* the table clear the reference does with memset(co,0,..) (iseq2comem.c:223,663) */
   if (e->sparse && e->tables_tracked) {
-    /* both tables are empty except in the blocks the last sketch marked: clear those, and the marks */
+    /* the accumulation table is empty except in the blocks the last sketch marked: clear those, and the marks.  The layout
+     * table is empty already (the key-list dump hands every slot back); after a finish that went wrong it is filled anew */
     hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_acc, e->acc_words, e->d_list_acc, e->d_nlist, 1);
-    hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_slot, e->slot_words, e->d_list_slot, e->d_nlist + 1, 1);
     hipLaunchKernelGGL(mk_dirty_clear_kernel, dim3((unsigned)e->num_cu * 8u), dim3(256), 0, e->stream, e->tab.kc, e->tab.ordinv, e->kp.S,
-                       (const uint32_t *)e->d_list_acc, (const uint32_t *)e->d_nlist, (uint32_t)MK_SPARSE_SHIFT, e->d_slot,
-                       (const uint32_t *)e->d_list_slot, (const uint32_t *)(e->d_nlist + 1), (uint32_t)MK_DUMP_SHIFT);
+                       (const uint32_t *)e->d_list_acc, (const uint32_t *)e->d_nlist, (uint32_t)MK_SPARSE_SHIFT, (uint32_t *)nullptr,
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t)MK_DUMP_SHIFT);
     MK_HIP(e, hipGetLastError());
+    if (e->tab.fr) MK_HIP(e, hipMemsetAsync(e->d_front, 0, e->front_slots * 16, e->stream));
+    if (!e->slot_clean) {
+      MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)e->kp.S * sizeof(uint32_t), e->stream));
+      e->slot_clean = true;
+    }
   } else {
     /* behind a front table the S-slot table is cleared only when the last sketch may have used it */
     if (!e->tab.fr || e->big_maybe_dirty) MK_HIP(e, hipMemsetAsync(e->d_tab, 0, e->tab_bytes, e->stream));
@@ -596,6 +630,7 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
       MK_HIP(e, hipMemsetAsync(e->d_dirty_acc, 0, (size_t)e->acc_words * 4, e->stream));
       MK_HIP(e, hipMemsetAsync(e->d_dirty_slot, 0, (size_t)e->slot_words * 4, e->stream));
       e->tables_tracked = true;
+      e->slot_clean = true;
     }
   }
   MK_HIP(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->stream));
@@ -605,7 +640,10 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   e->min_occ = 1;
   e->begun = true;
   e->compacted = false;
+  e->count_queued = false;
   e->D = 0;
+  if (e->fa_used) MK_HIP(e, hipMemsetAsync(e->d_fa_state, 0, sizeof(mk_fa_state), e->stream));
+  e->fa_used = false; e->fa_final = false; e->fa_tail = 0; e->fa_rows_done = 0;
   return MK_OK;
 }
 
@@ -646,12 +684,17 @@ static hipError_t mk_launch_scan_k(mk_engine *e, int threads, bool onepass, cons
   }
 }
 
-static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride, uint64_t nreads, uint64_t first_ord) {
+/* stride: bytes staged per row.  pitch: address step between rows (== stride for rows side by side; the overlapping virtual
+ * rows of a base stream step by less).  rowlen: 0, or the index at which a virtual row stops.  nreads_dev: NULL, or the row
+ * count in device memory (nreads is then an upper bound the launch is sized for). */
+static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t stride, uint32_t pitch, uint32_t rowlen, uint64_t nreads,
+                             const unsigned long long *nreads_dev, uint64_t first_ord) {
   if (nreads == 0) return MK_OK;
   if (nreads >= (1ull << 31)) return mk_fail(e, MK_ERR_ARG, "scan launch of %llu reads: the caller splits pushes below 2^31", (unsigned long long)nreads);
   mk_scan_args a{};
   a.rows = rows_dev; a.nreads = nreads; a.first_ord = first_ord; a.stride = stride;
-  const bool vec = (stride % 16u == 0) && (((uintptr_t)rows_dev & 15u) == 0);
+  a.pitch = pitch; a.rowlen = rowlen; a.nreads_dev = nreads_dev;
+  const bool vec = (stride % 16u == 0) && (pitch % 16u == 0) && (((uintptr_t)rows_dev & 15u) == 0);
   /* column blocks: fewest blocks of at most max_cb bytes, equal width, 16-byte (vec) / 4-byte granular -- 8-byte where the
    * tuned kernels can run (they take whole 8-base windows: a 152-byte row is 80 + 72, not 76 + 76, which fell to the generic
    * kernel at five times the time) */
@@ -745,8 +788,12 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
     MK_HIP(e, hipGetLastError());
     if (e->profiling) { MK_HIP(e, hipEventRecord(ev2.b, e->stream)); e->ev_resolve.push_back(ev2); }
   }
-  e->compacted = false;
+  e->compacted = false; e->count_queued = false;
   return MK_OK;
+}
+
+static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride, uint64_t nreads, uint64_t first_ord) {
+  return mk_launch_scan_ex(e, rows_dev, stride, stride, 0u, nreads, nullptr, first_ord);
 }
 
 static int mk_check_push(mk_engine *e, const void *rows, uint32_t stride) {
@@ -894,6 +941,101 @@ extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t 
   return mk_sketch_push_wait(e, t); /* caller's buffer is free again; the last scan may still run */
 }
 
+/* ---- FASTA text straight to the device (mk_sketch_push_stream) ------------------------------------------
+ * fasta2co() / uniq_fasta2co() read the file through a 64 KiB window and walk it byte by byte (iseq2comem.c:224-279).  Here
+ * the raw bytes are copied to HBM, three kernels (mk_stream.hip.h) drop line ends and header lines exactly like that walk,
+ * and the scan kernel reads overlapping virtual rows out of the resulting base stream.  Text may arrive in pieces; every
+ * piece but the last has final == 0 (rows whose last byte is not known yet wait in the stream buffer; one small
+ * synchronisation per non-final piece tells the host how many).  The sketch is identical to the one the host windows
+ * (mk_fasta_window + mk_sketch_push_reads) give: the k-mers and their order are the stream's, not the rows'. */
+#define MK_FA_PITCH 528u /* address step of the virtual rows: a multiple of 16, not of 128 (see MK_ROW_PITCH) */
+
+static int mk_fa_reserve(mk_engine *e, size_t n) {
+  if (!e->d_fa_state) {
+    MK_HIP(e, hipMalloc(&e->d_fa_state, sizeof(mk_fa_state)));
+    MK_HIP(e, hipMemset(e->d_fa_state, 0, sizeof(mk_fa_state)));
+    MK_HIP(e, hipHostMalloc((void **)&e->h_fa_state, sizeof(mk_fa_state), hipHostMallocDefault));
+  }
+  if (n > e->text_cap || !e->d_stream) { /* (also the first piece of all being empty: the buffers must exist) */
+    MK_HIP(e, hipStreamSynchronize(e->stream)); /* kernels of earlier pieces may still read the old buffers */
+    const size_t cap = n + n / 4 + ((size_t)1 << 20);
+    uint8_t *nt = nullptr, *ns = nullptr, *ntmp = nullptr;
+    /* stream: what is carried (less than one row and one step) + the new text + a row's width of slack behind it */
+    const size_t scap = cap + 8192;
+    MK_HIP(e, hipMalloc(&nt, cap));
+    MK_HIP(e, hipMalloc(&ns, scap));
+    MK_HIP(e, hipMalloc(&ntmp, 8192));
+    MK_HIP(e, hipMemset(ns, 0, scap));
+    if (e->d_stream && e->fa_tail) MK_HIP(e, hipMemcpy(ns, e->d_stream, e->fa_tail, hipMemcpyDeviceToDevice));
+    hipFree(e->d_kl); hipFree(e->d_kl_buckets);
+  hipFree(e->d_text); hipFree(e->d_stream); hipFree(e->d_stream_tmp);
+    e->d_text = nt; e->d_stream = ns; e->d_stream_tmp = ntmp;
+    e->text_cap = cap; e->stream_cap = scap;
+  }
+  const size_t nseg = (n + MK_FA_SEG - 1) / MK_FA_SEG;
+  if (nseg > e->fa_sum_cap) {
+    MK_HIP(e, hipStreamSynchronize(e->stream));
+    hipFree(e->d_fa_sum);
+    e->d_fa_sum = nullptr; e->fa_sum_cap = 0;
+    MK_HIP(e, hipMalloc(&e->d_fa_sum, (nseg + nseg / 4 + 256) * sizeof(mk_fa_sum)));
+    e->fa_sum_cap = nseg + nseg / 4 + 256;
+  }
+  return MK_OK;
+}
+
+extern "C" int mk_sketch_push_stream(mk_engine *e, const uint8_t *text, uint64_t n, int final) {
+  if (!e || (!text && n)) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "push before mk_sketch_begin");
+  if (e->fa_final) return mk_fail(e, MK_ERR_STATE, "mk_sketch_push_stream: the stream has been closed (final) for this sketch");
+  if (n >= (1ull << 31)) return mk_fail(e, MK_ERR_ARG, "mk_sketch_push_stream: at most 2^31 - 1 bytes per call");
+  if (e->P.TL + MK_FA_PITCH > 4000u) return mk_fail(e, MK_ERR_ARG, "mk_sketch_push_stream: k-mer too long for the stream rows");
+  MK_HIP(e, hipSetDevice(e->device));
+  { int rc = mk_flush_region(e); if (rc) return rc; } /* rows pushed the other way keep their place in the order of the pushes */
+  int rc = mk_fa_reserve(e, (size_t)n);
+  if (rc) return rc;
+  const uint32_t TL = (uint32_t)e->P.TL, pitch = MK_FA_PITCH, rowlen = pitch + TL - 1u;
+  const uint32_t width = (rowlen + 1u + 15u) & ~15u; /* staged bytes per row: through the cut, whole 16-byte pieces */
+  e->fa_used = true;
+  if (n) {
+    /* pinned text is copied asynchronously (the caller keeps it untouched until the next waiting call); pageable text may be
+     * reused as soon as this call returns, so the copy is waited for */
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, text) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();
+    MK_HIP(e, hipMemcpyAsync(e->d_text, text, (size_t)n, hipMemcpyHostToDevice, e->stream));
+    if (!pinned) MK_HIP(e, hipStreamSynchronize(e->stream));
+  }
+  const uint64_t nseg = (n + MK_FA_SEG - 1) / MK_FA_SEG;
+  if (nseg) hipLaunchKernelGGL(mk_fa_summary_kernel, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, e->stream, (const uint8_t *)e->d_text, n, e->d_fa_sum);
+  hipLaunchKernelGGL(mk_fa_scan_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_fa_sum, nseg, e->d_fa_state, e->d_stream, pitch, rowlen, TL,
+                     final ? 1 : 0, e->tab.err);
+  if (nseg) hipLaunchKernelGGL(mk_fa_emit_kernel, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, e->stream, (const uint8_t *)e->d_text, n,
+                               (const mk_fa_sum *)e->d_fa_sum, e->d_stream, (unsigned long long)e->fa_tail);
+  MK_HIP(e, hipGetLastError());
+  /* rows the launch is sized for: what the stream could hold at most */
+  const uint64_t ub_len = e->fa_tail + n;
+  uint64_t ub_rows = 0;
+  if (final) { if (ub_len >= TL) ub_rows = (ub_len - (TL - 1u) + pitch - 1u) / pitch; }
+  else if (ub_len >= rowlen) ub_rows = (ub_len - rowlen) / pitch + 1u;
+  if (ub_rows) {
+    rc = mk_launch_scan_ex(e, e->d_stream, width, pitch, rowlen, ub_rows, &e->d_fa_state->nrows, e->fa_rows_done);
+    if (rc) return rc;
+  }
+  if (final) { e->fa_final = true; return MK_OK; }
+  /* the tail that no complete row covers yet goes to the front of the buffer; how long it is comes back to the host */
+  hipLaunchKernelGGL(mk_fa_shift_kernel, dim3(8), dim3(1024), 0, e->stream, e->d_stream, e->d_stream_tmp, e->d_fa_state, pitch, 0);
+  hipLaunchKernelGGL(mk_fa_shift_kernel, dim3(8), dim3(1024), 0, e->stream, e->d_stream, e->d_stream_tmp, e->d_fa_state, pitch, 1);
+  MK_HIP(e, hipMemcpyAsync(e->h_fa_state, e->d_fa_state, sizeof(mk_fa_state), hipMemcpyDeviceToHost, e->stream));
+  hipLaunchKernelGGL(mk_fa_shift_done_kernel, dim3(1), dim3(1), 0, e->stream, e->d_fa_state, pitch);
+  MK_HIP(e, hipGetLastError());
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  const uint64_t taken = e->h_fa_state->nrows, len = e->h_fa_state->len;
+  e->fa_rows_done += taken;
+  e->fa_tail = len > taken * pitch ? len - taken * pitch : 0;
+  if (e->fa_tail > 8192) return mk_fail(e, MK_ERR_HIP, "mk_sketch_push_stream: stream tail of %llu bytes", (unsigned long long)e->fa_tail);
+  return MK_OK;
+}
+
 /* ---- compaction / partials --------------------------------------------------------------------------- */
 /* table -> distinct-key list on the device; the number of keys lands in d_counters[0].  No host synchronisation. */
 static int mk_compact_launch(mk_engine *e) {
@@ -904,9 +1046,21 @@ static int mk_compact_launch(mk_engine *e) {
   const int drop0 = e->mode == MK_MODE_SET || e->mode == MK_MODE_UNIQ_SET;
   const unsigned blocks = (unsigned)(e->num_cu * 2);
   if (e->sparse) { /* only the blocks somebody installed a key in */
+    const uint32_t *big_used = nullptr;
+    if (e->tab.fr) {
+      /* big table untouched (the usual case for a genome): list the front table, the kernels below return at once.  Otherwise
+       * the front table is folded into the big one (its dirty blocks are marked by the fold) and that is listed */
+      big_used = e->front.state + 1;
+      mk_table ft = e->tab;
+      ft.kc = e->front.kc1; ft.ordinv = e->front.ordinv1;
+      ft.dirty = nullptr;
+      hipLaunchKernelGGL(mk_compact_kernel<MK_COMPACT_CHUNK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, ft, (uint32_t)e->front_slots,
+                         e->dist, e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr, big_used, 0u);
+      hipLaunchKernelGGL(mk_front_fold_kernel, dim3(blocks), dim3(1024), 0, e->stream, e->tab, e->kp.S);
+    }
     hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_acc, e->acc_words, e->d_list_acc, e->d_nlist + 2, 0);
     hipLaunchKernelGGL(mk_compact_kernel<MK_SPARSE_BLOCK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
-                       e->d_counters, drop0, (const uint32_t *)e->d_list_acc, (const uint32_t *)(e->d_nlist + 2), (const uint32_t *)nullptr, 0u);
+                       e->d_counters, drop0, (const uint32_t *)e->d_list_acc, (const uint32_t *)(e->d_nlist + 2), big_used, 1u);
   } else {
     if (e->tab.fr) {
       /* big table empty (state[1] == 0, the common case): list the front table, the other two kernels return at once.
@@ -940,6 +1094,7 @@ static int mk_check_counters(mk_engine *e) {
   e->D = e->h_counters[0];
   if (e->tab.fr && (uint32_t)(e->h_counters[4] >> 32) == 0u && !e->region_open) e->big_maybe_dirty = false; /* state[1]: nobody used the big table */
   if (errflags & 4u) return mk_fail(e, MK_ERR_HIP, "scan kernel: LDS filter not at offset 0");
+  if (errflags & 8u) return mk_fail(e, MK_ERR_FORMAT, "fasta2co(): can not find seqences head start from '>' (the stream ends inside a header line)");
   if ((errflags & 1u) || e->D > mk_key_limit(e))
     return mk_fail(e, MK_ERR_CROWDED, "the context space is too crowd (%llu distinct keys > limit %llu), try k=%d",
                    (unsigned long long)e->D, (unsigned long long)mk_key_limit(e), e->P.k + 1);
@@ -960,13 +1115,54 @@ static int mk_compact(mk_engine *e) {
   return MK_OK;
 }
 
+/* the compaction and the copy of its counters queued, nothing waited for: several engines (one per GPU) compact at the same
+ * time when the caller starts them all and only then asks each for its count */
+extern "C" int mk_partial_count_begin(mk_engine *e) {
+  if (!e) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "partial_count_begin before mk_sketch_begin");
+  MK_HIP(e, hipSetDevice(e->device));
+  if (e->compacted && !e->region_open) return MK_OK;
+  int rc = mk_compact_launch(e);
+  if (rc) return rc;
+  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  e->count_queued = true;
+  return MK_OK;
+}
+
 extern "C" int mk_partial_count(mk_engine *e, uint64_t *n) {
   if (!e || !n) return MK_ERR_ARG;
   if (!e->begun) return mk_fail(e, MK_ERR_STATE, "partial_count before mk_sketch_begin");
   MK_HIP(e, hipSetDevice(e->device));
-  int rc = mk_compact(e);
+  int rc;
+  if (e->count_queued) { /* mk_partial_count_begin has launched it */
+    e->count_queued = false;
+    MK_HIP(e, hipStreamSynchronize(e->stream));
+    rc = mk_check_counters(e);
+    if (rc == MK_OK) e->compacted = true;
+  } else {
+    rc = mk_compact(e);
+  }
   if (rc) return rc;
   *n = e->D;
+  return MK_OK;
+}
+
+/* mk_partial_export without the final wait: the three copies are queued on the engine's stream (mk_engine_sync waits) */
+extern "C" int mk_partial_export_async(mk_engine *e, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t *ords_dev, uint64_t capacity,
+                                       uint64_t *n_out) {
+  if (!e || !n_out) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "partial_export before mk_sketch_begin");
+  MK_HIP(e, hipSetDevice(e->device));
+  uint64_t d = 0;
+  int rc = mk_partial_count(e, &d);
+  if (rc) return rc;
+  *n_out = d;
+  if (d > capacity) return mk_fail(e, MK_ERR_ARG, "partial_export: capacity %llu < %llu keys", (unsigned long long)capacity, (unsigned long long)d);
+  if (d == 0) return MK_OK;
+  if (!keys_dev || !counts_dev || !ords_dev) return MK_ERR_ARG;
+  MK_HIP(e, hipMemcpyAsync(keys_dev, e->dist.key, d * 8, hipMemcpyDeviceToDevice, e->stream));
+  MK_HIP(e, hipMemcpyAsync(counts_dev, e->dist.cnt, d * 4, hipMemcpyDeviceToDevice, e->stream));
+  MK_HIP(e, hipMemcpyAsync(ords_dev, e->dist.ord, d * 8, hipMemcpyDeviceToDevice, e->stream));
   return MK_OK;
 }
 
@@ -974,17 +1170,9 @@ extern "C" int mk_partial_export(mk_engine *e, uint64_t *keys_dev, uint32_t *cou
                                  uint64_t *n_out) {
   if (!e || !n_out) return MK_ERR_ARG;
   if (!e->begun) return mk_fail(e, MK_ERR_STATE, "partial_export before mk_sketch_begin");
-  MK_HIP(e, hipSetDevice(e->device));
-  int rc = mk_compact(e);
+  int rc = mk_partial_export_async(e, keys_dev, counts_dev, ords_dev, capacity, n_out);
   if (rc) return rc;
-  *n_out = e->D;
-  if (e->D > capacity) return mk_fail(e, MK_ERR_ARG, "partial_export: capacity %llu < %llu keys", (unsigned long long)capacity, (unsigned long long)e->D);
-  if (e->D == 0) return MK_OK;
-  if (!keys_dev || !counts_dev || !ords_dev) return MK_ERR_ARG;
-  MK_HIP(e, hipMemcpyAsync(keys_dev, e->dist.key, e->D * 8, hipMemcpyDeviceToDevice, e->stream));
-  MK_HIP(e, hipMemcpyAsync(counts_dev, e->dist.cnt, e->D * 4, hipMemcpyDeviceToDevice, e->stream));
-  MK_HIP(e, hipMemcpyAsync(ords_dev, e->dist.ord, e->D * 8, hipMemcpyDeviceToDevice, e->stream));
-  MK_HIP(e, hipStreamSynchronize(e->stream));
+  if (*n_out) MK_HIP(e, hipStreamSynchronize(e->stream));
   return MK_OK;
 }
 
@@ -1001,7 +1189,7 @@ extern "C" int mk_partial_import(mk_engine *e, const uint64_t *keys_dev, const u
   hipLaunchKernelGGL(mk_import_kernel, dim3((unsigned)blocks), dim3(1024), 0, e->stream, e->tab, e->kp.S,
                      (const unsigned long long *)keys_dev, counts_dev, (const unsigned long long *)ords_dev, n);
   MK_HIP(e, hipGetLastError());
-  e->compacted = false;
+  e->compacted = false; e->count_queued = false;
   return MK_OK;
 }
 
@@ -1053,6 +1241,103 @@ static int mk_launch_dump(mk_engine *e, bool count_pass) {
   return MK_OK;
 }
 
+/* finish for engines with sparse bookkeeping (tables of 2^26 slots and more; MK_OPT_SPARSE): compaction -> the key count
+ * comes to the host (one small synchronisation: the passes below are sized by it, not by the table) -> priority layout ->
+ * key-list dump into device staging -> one copy to the pinned result arrays.  The compaction has been launched. */
+static int mk_finish_keylist(mk_engine *e, mk_result *out, mk_evpair ev) {
+  const uint32_t S = e->kp.S;
+  const int C = e->P.component_num;
+  const bool koc = e->mode == MK_MODE_KOC;
+  auto bail = [&](int rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; };
+  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  int rc = mk_check_counters(e);
+  if (rc) { e->begun = false; return bail(rc); }
+  e->compacted = true;
+  const uint64_t D = e->D;
+  if (D > e->kl_cap) {
+    hipFree(e->d_kl);
+    e->d_kl = nullptr; e->kl_cap = 0;
+    const uint64_t cap = D + D / 4 + 65536;
+    MK_HIP(e, hipMalloc(&e->d_kl, cap * (8 + 8 + 4 + 4 + 2) + 64));
+    e->kl_cap = cap;
+  }
+  rc = mk_result_capacity(e, D ? D : 1);
+  if (rc) return bail(rc);
+  mk_kl_args a{};
+  a.d = e->dist; a.Dp = e->d_counters; a.limit = mk_key_limit(e);
+  a.slot = e->d_slot; a.S = S;
+  a.comp_num = (uint32_t)C; a.comp_code_bits = (uint32_t)e->P.comp_code_bits;
+  a.cnt_lo = e->mode == MK_MODE_OCC_SET ? e->min_occ : 1u; /* write_fqco2file(): marked keys only (iseq2comem.c:611) */
+  a.cnt_hi = e->mode == MK_MODE_UNIQ_SET ? 1u : 0xffffffffu;  /* uniq_fasta2co(): repeated keys dropped */
+  /* buckets of 2^shift consecutive slots per component, about eight keys each */
+  {
+    const uint64_t want = D / 8 + 256;
+    const uint64_t width = ((uint64_t)S * (uint64_t)C) / want;
+    uint32_t sh = 0;
+    while (sh < 31u && (2ull << sh) <= width) sh++;
+    a.shift = sh;
+    a.bpc = (S >> sh) + 1u;
+    a.nbuckets = (uint32_t)C * a.bpc;
+  }
+  if ((uint64_t)a.nbuckets * 2 + 2 > e->kl_bucket_cap) {
+    hipFree(e->d_kl_buckets);
+    e->d_kl_buckets = nullptr; e->kl_bucket_cap = 0;
+    const uint64_t cap = (uint64_t)a.nbuckets * 2 + 2 + 4096;
+    MK_HIP(e, hipMalloc(&e->d_kl_buckets, cap * 4));
+    e->kl_bucket_cap = cap;
+  }
+  a.bcount = e->d_kl_buckets; a.bcursor = e->d_kl_buckets + a.nbuckets + 1u;
+  {
+    uint8_t *p = (uint8_t *)e->d_kl;
+    a.skey = (unsigned long long *)p; p += e->kl_cap * 8;
+    a.tkey = (unsigned long long *)p; p += e->kl_cap * 8;
+    a.tidx = (uint32_t *)p; p += e->kl_cap * 4;
+    a.out_ids = (uint32_t *)p; p += e->kl_cap * 4;
+    a.out_cnt = koc ? (uint16_t *)p : nullptr;
+  }
+  a.totals = e->d_comp_totals;
+  a.out_cap = e->kl_cap;
+  uint16_t *stage_cnt = (uint16_t *)((uint8_t *)e->d_kl + e->kl_cap * 24);
+  MK_HIP(e, hipMemsetAsync(a.bcount, 0, ((size_t)a.nbuckets + 1) * 4, e->stream));
+  uint64_t blocks = (D + 255) / 256;
+  if (blocks > (uint64_t)e->num_cu * 16u) blocks = (uint64_t)e->num_cu * 16u;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, e->dist, (const unsigned long long *)e->d_counters,
+                     (unsigned long long)mk_key_limit(e), e->d_slot, S, e->tab.err, (uint32_t *)nullptr, (uint32_t)MK_DUMP_SHIFT);
+  hipLaunchKernelGGL(mk_kl_find_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, a);
+  hipLaunchKernelGGL(mk_kl_scan_kernel, dim3(1), dim3(1024), 0, e->stream, a);
+  hipLaunchKernelGGL(mk_kl_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, a);
+  hipLaunchKernelGGL(mk_kl_emit_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, a);
+  MK_HIP(e, hipGetLastError());
+  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  MK_HIP(e, hipMemcpyAsync(e->h_comp_totals, e->d_comp_totals, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  if (D) { /* at most D entries come out: the whole staging prefix in one copy each (the component totals say how much of it counts) */
+    MK_HIP(e, hipMemcpyAsync(e->h_ids, a.out_ids, D * 4, hipMemcpyDeviceToHost, e->stream));
+    if (koc) MK_HIP(e, hipMemcpyAsync(e->h_cnt, stage_cnt, D * 2, hipMemcpyDeviceToHost, e->stream));
+  }
+  if (e->profiling) MK_HIP(e, hipEventRecord(ev.b, e->stream));
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  rc = mk_check_counters(e);
+  if (rc) { e->begun = false; e->slot_clean = false; return bail(rc); } /* (layout did not converge: the table is filled anew) */
+  uint64_t total = 0;
+  for (int c = 0; c < C; c++) total += e->h_comp_totals[c];
+  if (total > D) { e->slot_clean = false; return bail(mk_fail(e, MK_ERR_HIP, "dump produced more entries than distinct keys")); }
+  if (e->profiling) e->ev_finish.push_back(ev);
+  uint64_t at = 0;
+  for (int c = 0; c < C; c++) {
+    e->comps[c].n = e->h_comp_totals[c];
+    e->comps[c].ids = e->h_ids + at;
+    e->comps[c].counts = koc ? e->h_cnt + at : nullptr;
+    at += e->h_comp_totals[c];
+  }
+  out->component_num = C;
+  out->total = total;
+  out->components = e->comps.data();
+  e->begun = false;
+  return MK_OK;
+}
+
 /* One host synchronisation per finish: compaction, layout and dump take the key count from device memory, the dump writes
  * ids and counts straight into the pinned result arrays, and the counters (key count, component sizes, error flags) come
  * back in one small copy in front of the only hipStreamSynchronize.  Only a result larger than the arrays (first big
@@ -1075,7 +1360,11 @@ extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
     if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
   }
 
-  if (!e->sparse) MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), e->stream)); /* sparse: kept empty by begin */
+  if (e->sparse) { /* large tables: the dump starts from the key list, not from the table (mk_kl_* kernels) */
+    rc = mk_finish_keylist(e, out, ev);
+    return rc;
+  }
+  MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), e->stream));
   hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)e->num_cu * 16u), dim3(256), 0, e->stream, e->dist,
                      (const unsigned long long *)e->d_counters, (unsigned long long)mk_key_limit(e), e->d_slot, S, e->tab.err,
                      e->sparse ? e->d_dirty_slot : nullptr, (uint32_t)MK_DUMP_SHIFT);
@@ -1087,7 +1376,11 @@ extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
   if (e->profiling) MK_HIP(e, hipEventRecord(ev.b, e->stream));
   MK_HIP(e, hipStreamSynchronize(e->stream));
   rc = mk_check_counters(e);
-  if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
+  if (rc) { /* the sketch is spent (crowded table, malformed stream): options may be set again, the next call is a begin */
+    e->begun = false;
+    if (e->profiling) e->ev_pool.push_back(ev);
+    return rc;
+  }
   e->compacted = true;
   uint64_t total = 0;
   for (int c = 0; c < C; c++) total += e->h_comp_totals[c];

@@ -72,7 +72,12 @@ struct mk_front {
 struct mk_scan_args {
   const uint8_t *rows;
   uint64_t nreads, first_ord;
-  uint32_t stride;
+  uint32_t stride;    /* bytes staged per row (the row's width) */
+  uint32_t pitch;     /* address step from one row to the next: == stride for rows that lie side by side, smaller for the
+                       * overlapping virtual rows of a base stream (mk_sketch_push_stream) */
+  uint32_t rowlen;    /* 0: a row ends at its '\n' or at `stride`; else: bytes from this index on are not part of the row
+                       * (virtual rows: the next row's k-mers) -- the staged tile gets a '\n' there */
+  const unsigned long long *nreads_dev; /* NULL, or the row count in device memory (nreads is then an upper bound) */
   uint32_t CB, ncb;   /* column block width (bytes, multiple of 4), blocks per row */
   uint32_t ppr;       /* pieces per row per block: CB/16 (vec path) or CB/4 (dword path) */
   uint32_t ppr_inv;   /* floor(2^20/ppr)+1 : q/ppr == (q*ppr_inv)>>20 for q < 2^20/ppr */
@@ -616,7 +621,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
       for (int i = 0; i < NPIECES; i++) {
         const uint32_t q = lane + 64u * i;
         const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr;
-        t[128 * i] = r * a.stride + c * 16u;
+        t[128 * i] = r * a.pitch + c * 16u;
         t[128 * i + 64] = r * a.rowdw + c * 4u;
       }
     }
@@ -637,7 +642,9 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   const uint32_t dimmask = a.dimmask;
   const uint32_t wmask4 = (a.bm_words - 1u) << 2;
   /* a launch covers fewer than 2^31 reads (the engine splits larger pushes), so tile and row indices are 32-bit */
-  const uint32_t ntiles = (uint32_t)((a.nreads + 63u) >> 6);
+  uint64_t nreads = a.nreads;
+  if (a.nreads_dev) { const uint64_t nd = *a.nreads_dev; if (nd < nreads) nreads = nd; }
+  const uint32_t ntiles = (uint32_t)((nreads + 63u) >> 6);
   const uint32_t wave_global = blockIdx.x * WAVES + wave;
   const uint32_t nwaves = gridDim.x * WAVES;
   uint4 *const my_cand = a.cand + (size_t)wave_global * a.cand_cap;
@@ -657,7 +664,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   piece_t regs2[ONEPASS ? NP : 1]; /* second column block of the same tile */
   /* row r_i and column c_i of piece i never change; the two offsets derived from them are recomputed where
    * needed (a handful of ops per piece per step) rather than held in 2*NP registers */
-  auto goff_calc = [&](int i) { const uint32_t q = lane + 64u * i; const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr; return r * a.stride + c * PW; };
+  auto goff_calc = [&](int i) { const uint32_t q = lane + 64u * i; const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr; return r * a.pitch + c * PW; };
   auto loff_calc = [&](int i) { const uint32_t q = lane + 64u * i; const uint32_t r = (q * a.ppr_inv) >> 20, c = q - r * a.ppr; return r * a.rowdw + c * (PW / 4u); };
   /* 16-byte path: the 2*NP offsets live in a table in LDS (they depend on the lane only, one table serves every wave).
    * Left to itself the compiler hoists them out of the tile loop, runs out of registers in the 1024-thread builds and
@@ -668,16 +675,16 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   auto loff_of = [&](int i) { if constexpr (VEC16) return offtab[128 * i + 64]; else return loff_calc(i); };
   auto issue_loads = [&](uint32_t tile_id, uint32_t cb) {
     const uint32_t row0 = tile_id << 6;
-    const uint8_t *base = a.rows + (uint64_t)row0 * a.stride + (uint64_t)cb * a.CB;
+    const uint8_t *base = a.rows + (uint64_t)row0 * a.pitch + (uint64_t)cb * a.CB;
     const uint32_t cols_here = min(a.CB, a.stride - cb * a.CB);
     if constexpr (ONEPASS) {
       /* host guarantees: ncb == 2, stride == 2*CB.  cb is 0 here. */
-      if (row0 + 64u <= a.nreads) {
+      if (row0 + 64u <= nreads) {
 #pragma unroll
         for (int i = 0; i < NP; i++)
           if ((uint32_t)i < a.ppr) { regs[i] = *(const piece_t *)(base + goff_of(i)); regs2[i] = *(const piece_t *)(base + a.CB + goff_of(i)); }
       } else {
-        const uint32_t rows_here = (uint32_t)(a.nreads - row0);
+        const uint32_t rows_here = (uint32_t)(nreads - row0);
 #pragma unroll
         for (int i = 0; i < NP; i++) {
           if ((uint32_t)i < a.ppr) {
@@ -687,12 +694,12 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
           }
         }
       }
-    } else if (row0 + 64u <= a.nreads && cols_here == a.CB) { /* full tile, full block: no predicates */
+    } else if (row0 + 64u <= nreads && cols_here == a.CB) { /* full tile, full block: no predicates */
 #pragma unroll
       for (int i = 0; i < NP; i++)
         if ((uint32_t)i < a.ppr) regs[i] = *(const piece_t *)(base + goff_of(i));
     } else {
-      const uint32_t rows_here = (uint32_t)(a.nreads - row0 < 64u ? a.nreads - row0 : 64u);
+      const uint32_t rows_here = (uint32_t)(nreads - row0 < 64u ? nreads - row0 : 64u);
 #pragma unroll
       for (int i = 0; i < NP; i++) {
         if ((uint32_t)i < a.ppr) {
@@ -849,12 +856,21 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   for (uint32_t tile_id = wave_global; tile_id < ntiles; tile_id += nwaves) {
     const uint32_t row0 = tile_id << 6;
     km.reset(); run = 0; hh = 0;
-    done = row0 + lane >= a.nreads;
+    done = row0 + lane >= nreads;
     ord_row = (a.first_ord + row0 + lane) << 12;
     for (uint32_t cb = 0; cb < a.ncb; cb++) {
       mk_wave_lds_fence();
       commit(cb);
       mk_wave_lds_fence();
+      if (a.rowlen) { /* virtual rows: the row stops at rowlen -- a '\n' there and behind it in that dword */
+        const uint32_t c0b = cb * a.CB;
+        if (a.rowlen >= c0b && a.rowlen < c0b + a.CB) {
+          uint32_t *q = tile + lane * a.rowdw + ((a.rowlen - c0b) >> 2);
+          const uint32_t sh = (a.rowlen & 3u) * 8u;
+          *q = (*q & ((1u << sh) - 1u)) | (0x0A0A0A0Au << sh);
+        }
+        mk_wave_lds_fence();
+      }
       if constexpr (ONEPASS) {
         /* both halves of this tile are in registers; the next tile's loads go out once the second half is in LDS */
         if (cb == 1u) { nt_tile += nwaves; if (nt_tile < ntiles) issue_loads(nt_tile, 0u); }
@@ -945,8 +961,21 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
 #pragma unroll
             for (uint32_t t = 0; t < 4; t++) {
               const uint32_t wsrc = bj[2u * t + 1u];
+#if defined(MK_TUNING) && defined(MK_ABL)
+              /* ablation builds (make tuning VARIANT=-DMK_ABL=n): timing probes with WRONG results, never shipped
+               * (profiles/r03_a_scan_ablation.txt).  2: no mask reads; 3: mask reads at conflict-free addresses (bank := lane);
+               * 4: filter-word reads at conflict-free addresses; 5: both conflict-free */
+              uint32_t wa = ((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u;
+              uint32_t ma = 2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t];
+              const uint32_t lane4 = (lane & 31u) << 2;
+              if (MK_ABL == 3 || MK_ABL == 5) ma = (ma & ~0x7Cu) | lane4;
+              if (MK_ABL == 4 || MK_ABL == 5) wa = (wa & ~0x7Cu) | lane4;
+              dd[t] = *(mk_lds_cu32)(uintptr_t)wa;
+              if (MK_ABL == 2) mm[t] = ma | 0x80000000u; else mm[t] = *(mk_lds_cu32)(uintptr_t)ma;
+#else
               dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u);
               mm[t] = *(mk_lds_cu32)(uintptr_t)(2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t]);
+#endif
             }
 #pragma unroll
             for (uint32_t k = 0; k < D; k++) pa[k] = bj[8u - D + k] & 0x3FCu;
@@ -1486,5 +1515,129 @@ __global__ void __launch_bounds__(256) mk_synth_kernel(uint64_t seed, uint64_t f
       }
     }
     *(uint4 *)(rows + r * stride + b0) = make_uint4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+/* ---- key-list-driven dump (large tables / small sketches) ----------------------------------------------------------------
+ * write_fqkoc2files() / wrt_co2cmpn_use_inn_subctx() walk all hashsize slots (iseq2comem.c:539-553, :638-646).  A genome leaves
+ * some 16 000 keys in L2K11's 537 M slots: sweeping the layout table, even only its touched 16 KiB chunks, reads megabytes per
+ * key-kilobyte of output.  Here the dump starts from the distinct-key list instead: once the priority insertion has converged
+ * every key finds its own slot again (a walk along its probe sequence), the order of the output is the order of
+ * (component, slot), and because slots are hash values that order is produced by a bucket pass -- keys are dealt to buckets of
+ * consecutive (component, slot) ranges holding about eight keys each, and a key's rank inside its bucket is counted directly.
+ *   mk_kl_find_kernel     key i -> its slot n; sort key (component << 32 | n); bucket counts; the slot is handed back EMPTY
+ *                         (the layout table is all-empty again without any sweep)
+ *   mk_kl_scan_kernel     exclusive scan of the bucket counts (one workgroup), component totals
+ *   mk_kl_scatter_kernel  (sort key, i) into its bucket's range, any order inside
+ *   mk_kl_emit_kernel     rank inside the bucket by counting smaller sort keys -> output position; id and count written there
+ * Cost is proportional to the number of keys, not to the table. */
+struct mk_kl_args {
+  mk_dist d;
+  const unsigned long long *Dp; /* number of distinct keys (device) */
+  unsigned long long limit;     /* more keys than this: the host reports MK_ERR_CROWDED, nothing to do */
+  uint32_t *slot;
+  uint32_t S;
+  uint32_t comp_num, comp_code_bits, cnt_lo, cnt_hi;
+  uint32_t shift, bpc;          /* bucket of (component, slot) = component * bpc + (slot >> shift): bpc = (S >> shift) + 1 per component */
+  uint32_t nbuckets;            /* comp_num * bpc */
+  uint32_t *bcount;             /* [nbuckets + 1]: counts, then exclusive starts */
+  uint32_t *bcursor;            /* [nbuckets] */
+  unsigned long long *skey;     /* [D] sort key per key index, ~0 = not part of the output */
+  unsigned long long *tkey;     /* [D] bucket-ordered sort keys */
+  uint32_t *tidx;               /* [D] ... and their key indices */
+  unsigned long long *totals;   /* [comp_num] */
+  uint32_t *out_ids;
+  uint16_t *out_cnt;            /* NULL: no counts */
+  uint64_t out_cap;
+};
+
+__global__ void __launch_bounds__(256) mk_kl_find_kernel(mk_kl_args a) {
+  const uint64_t D = *a.Dp;
+  if (D > a.limit) return;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long key = a.d.key[i];
+    uint32_t n, h2;
+    mk_probe_init(key, a.S, n, h2);
+    /* the layout has converged: the key sits in the first slot of its sequence that no earlier key holds.  Slots that other
+     * keys have already handed back read EMPTY: not a stop, only the key's own index is */
+    for (uint64_t guard = 0; guard <= a.S; guard++) {
+      if (__hip_atomic_load(&a.slot[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)i) break;
+      n = mk_probe_next(n, h2, a.S);
+    }
+    __hip_atomic_store(&a.slot[n], MK_EMPTY32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool keep = true;
+    if (a.cnt_lo > 1u || a.cnt_hi != 0xffffffffu) {
+      const uint32_t c = a.d.cnt[i];
+      keep = c >= a.cnt_lo && c <= a.cnt_hi;
+    }
+    unsigned long long sk = ~0ull;
+    if (keep) {
+      const uint32_t comp = a.comp_num > 1u ? (uint32_t)(key % a.comp_num) : 0u;
+      sk = ((unsigned long long)comp << 32) | n;
+      atomicAdd(&a.bcount[comp * a.bpc + (n >> a.shift)], 1u);
+    }
+    a.skey[i] = sk;
+  }
+}
+
+__global__ void __launch_bounds__(1024) mk_kl_scan_kernel(mk_kl_args a) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0u;
+  __syncthreads();
+  for (uint32_t base = 0; base < a.nbuckets; base += 1024u) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < a.nbuckets ? a.bcount[i] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o);
+      if ((int)lane >= o) incl += t;
+    }
+    if (lane == 63u) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
+    const uint32_t carry = carry_s;
+    if (i < a.nbuckets) { a.bcount[i] = carry + woff + incl - v; a.bcursor[i] = 0u; }
+    __syncthreads();
+    if (threadIdx.x == 1023u) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.bcount[a.nbuckets] = carry_s;
+  __syncthreads();
+  /* component c owns the buckets [c * bpc, (c + 1) * bpc) */
+  if (threadIdx.x < a.comp_num)
+    a.totals[threadIdx.x] = (unsigned long long)(a.bcount[(threadIdx.x + 1u) * a.bpc] - a.bcount[threadIdx.x * a.bpc]);
+}
+
+__global__ void __launch_bounds__(256) mk_kl_scatter_kernel(mk_kl_args a) {
+  const uint64_t D = *a.Dp;
+  if (D > a.limit) return;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long sk = a.skey[i];
+    if (sk == ~0ull) continue;
+    const uint32_t b = (uint32_t)(sk >> 32) * a.bpc + ((uint32_t)sk >> a.shift);
+    const uint32_t at = a.bcount[b] + atomicAdd(&a.bcursor[b], 1u);
+    a.tkey[at] = sk;
+    a.tidx[at] = (uint32_t)i;
+  }
+}
+
+__global__ void __launch_bounds__(256) mk_kl_emit_kernel(mk_kl_args a) {
+  const uint64_t D = *a.Dp;
+  if (D > a.limit) return;
+  const uint32_t n_out = a.bcount[a.nbuckets];
+  if ((uint64_t)n_out > a.out_cap) return; /* the host grows the result arrays and launches this kernel again */
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_out; j += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long sk = a.tkey[j];
+    const uint32_t b = (uint32_t)(sk >> 32) * a.bpc + ((uint32_t)sk >> a.shift);
+    const uint32_t lo = a.bcount[b], hi = a.bcount[b + 1u];
+    uint32_t rank = 0;
+    for (uint32_t t = lo; t < hi; t++) rank += a.tkey[t] < sk ? 1u : 0u; /* slots are distinct: no ties */
+    const uint32_t i = a.tidx[j];
+    a.out_ids[lo + rank] = (uint32_t)(a.d.key[i] >> a.comp_code_bits);
+    if (a.out_cnt) a.out_cnt[lo + rank] = (uint16_t)a.d.cnt[i];
   }
 }

@@ -11,6 +11,7 @@
 #include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -80,8 +81,14 @@ extern "C" int mk_multi_destroy(mk_multi *m) {
   return MK_OK;
 }
 
-extern "C" int mk_multi_create(const mk_params *p, const int *devices, int n, mk_multi **out) {
-  if (!p || !devices || !out || n < 1 || n > 64) return mm_fail(nullptr, MK_ERR_ARG, "mk_multi_create: bad argument");
+/* Most engines one sketch may be spread over.  The table slot's count field (24 bits, mk_kernels.hip.h MK_CNT_BITS) stops
+ * adding at 0xF00000 and every import adds at most 65535 per key: 16 concurrent imports stay below the key bits with room to
+ * spare (16 * 65535 < 2^20 <= 2^24 - 0xF00000), 17 and more could carry. */
+#define MK_MULTI_MAX_ENGINES 16
+
+extern "C" int mk_multi_create_ex(const mk_params *p, const int *devices, int n, unsigned flags, mk_multi **out) {
+  if (!p || !devices || !out || n < 1) return mm_fail(nullptr, MK_ERR_ARG, "mk_multi_create: bad argument");
+  if (n > MK_MULTI_MAX_ENGINES) return mm_fail(nullptr, MK_ERR_ARG, "mk_multi_create: %d engines, at most %d", n, MK_MULTI_MAX_ENGINES);
   mk_multi *m = new mk_multi();
   m->n = n;
   m->P = *p;
@@ -114,18 +121,37 @@ extern "C" int mk_multi_create(const mk_params *p, const int *devices, int n, mk
       return MK_ERR_HIP;
     }
   }
-  /* RCCL needs every rank on its own device */
+  /* RCCL needs every rank on its own device.  A list that names one GPU several times (how this path is tested on a one-GPU
+   * box) can only use device copies; on DISTINCT devices a failing RCCL is an error unless the caller asked for copies:
+   * a broken RCCL set-up must not pass silently for the xGMI exchange it was supposed to be */
   bool distinct = n > 1;
   for (int i = 0; i < n; i++)
     for (int j = 0; j < i; j++)
       if (devices[i] == devices[j]) distinct = false;
-  if (distinct) {
+  if (distinct && !(flags & MK_MULTI_FORCE_DEVICE_COPIES)) {
     m->comm.assign((size_t)n, nullptr);
-    if (ncclCommInitAll(m->comm.data(), n, devices) == ncclSuccess) m->rccl = true;
-    else { for (auto &c : m->comm) c = nullptr; m->comm.clear(); }
+    const ncclResult_t r = ncclCommInitAll(m->comm.data(), n, devices);
+    if (r == ncclSuccess) m->rccl = true;
+    else {
+      for (auto &c : m->comm) c = nullptr;
+      m->comm.clear();
+      if (!(flags & MK_MULTI_ALLOW_DEVICE_COPIES)) {
+        mm_fail(nullptr, MK_ERR_HIP, "ncclCommInitAll over %d devices failed: %s (pass MK_MULTI_ALLOW_DEVICE_COPIES / --allow-device-copies "
+                                     "to exchange with hipMemcpyPeerAsync instead)", n, ncclGetErrorString(r));
+        mk_multi_destroy(m);
+        return MK_ERR_HIP;
+      }
+    }
   }
+  if (n > 1) fprintf(stderr, "metakssd multi: %d engines, exchange transport: %s\n", n, m->rccl ? "rccl" : "device copies");
   *out = m;
   return MK_OK;
+}
+
+extern "C" int mk_multi_create(const mk_params *p, const int *devices, int n, mk_multi **out) {
+  /* MK_MULTI_ALLOW_COPIES=1 in the environment: the opt-in for callers that cannot pass flags */
+  const char *env = getenv("MK_MULTI_ALLOW_COPIES");
+  return mk_multi_create_ex(p, devices, n, env && env[0] == '1' ? MK_MULTI_ALLOW_DEVICE_COPIES : 0u, out);
 }
 
 extern "C" int mk_multi_begin(mk_multi *m, int mode) {
@@ -152,7 +178,13 @@ extern "C" int mk_multi_finish(mk_multi *m, mk_result *out, double *gather_ms, d
   const int n = m->n;
   std::vector<uint64_t> cnt((size_t)n, 0), off((size_t)n, 0);
   uint64_t total = 0;
-  /* 1. every other engine: compaction, export into a buffer on its own device */
+  /* 1. every other engine: compaction, export into a buffer on its own device.  All compactions are queued first, then
+   * every engine is asked for its count (the wait) and its three copies are queued, then one wait per device: the GPUs
+   * work at the same time, the host does the bookkeeping in between */
+  for (int i = 1; i < n; i++) {
+    const int rc = mk_partial_count_begin(m->eng[(size_t)i]);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(m->eng[(size_t)i]));
+  }
   for (int i = 1; i < n; i++) {
     mk_engine *e = m->eng[(size_t)i];
     uint64_t d = 0;
@@ -169,11 +201,15 @@ extern "C" int mk_multi_finish(mk_multi *m, mk_result *out, double *gather_ms, d
       m->xcap[(size_t)i] = cap;
     }
     uint64_t got = 0;
-    rc = mk_partial_export(e, (uint64_t *)m->xk[(size_t)i], m->xc[(size_t)i], (uint64_t *)m->xo[(size_t)i], m->xcap[(size_t)i], &got);
+    rc = mk_partial_export_async(e, (uint64_t *)m->xk[(size_t)i], m->xc[(size_t)i], (uint64_t *)m->xo[(size_t)i], m->xcap[(size_t)i], &got);
     if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(e));
     cnt[(size_t)i] = got;
     off[(size_t)i] = total;
     total += got;
+  }
+  for (int i = 1; i < n; i++) {
+    const int rc = mk_engine_sync(m->eng[(size_t)i]);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(m->eng[(size_t)i]));
   }
   const double t1 = mm_now();
   /* 2. the exchange: all lists back to back on device 0 */

@@ -592,6 +592,27 @@ def test_cli_several_engines_equal_one(shuf, flags, shuf_files, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_devices_fail_loudly(shuf_files, tmp_path):
+    """a device list the node cannot serve must end the run with a message, not fall back to something else: a GPU that does
+    not exist (one FASTQ: the merged-sketch path; several files: the file-sharded path), and more engines than the count
+    field of a table slot admits imports (mk_multi.hip: 16)"""
+    import util_inputs as ui
+    import numpy as np
+    rs = np.random.RandomState(6)
+    fq = str(tmp_path / "in.fq")
+    open(fq, "wb").write(ui.fastq_bytes(ui.pool_reads(rs, 3000, 500)))
+    fa = []
+    for i in range(3):
+        fa.append(str(tmp_path / ("g%d.fna" % i)))
+        open(fa[-1], "wb").write(ui.fasta_bytes([ui.rand_seq(rs, 3000)]))
+    base = [PRODUCT_CLI, "dist", "-L", shuf_files("L1K7")]
+    for extra, inputs in ((["-A", "--devices", "0,63"], [fq]), (["--devices", "0,63"], fa), (["-A", "--devices", ",".join(["0"] * 17)], [fq])):
+        r = subprocess.run(base + extra + ["-o", str(tmp_path / "out")] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode != 0, (extra, r.stdout.decode(), r.stderr.decode())
+        assert b"metakssd:" in r.stderr or b"failed" in r.stderr, r.stderr.decode()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shuf,flags", [("L1K7", []), ("L3K10", ["-u"]), ("L2K11", []), ("L1K7", ["-A"])])
 def test_cli_many_small_inputs_equal_one_by_one(shuf, flags, shuf_files, tmp_path):
     """many inputs in one run (worker threads prepare the files ahead, one engine sketches them in input order, its tables
@@ -635,6 +656,21 @@ def test_cli_many_small_inputs_equal_one_by_one(shuf, flags, shuf_files, tmp_pat
     assert list(np.diff(idx)) == per_comp and sum(counts) > 100
     st, stnames = parse_stat(os.path.join(whole, "cofiles.stat"))
     assert st["infile_num"] == len(paths) and stnames == paths and st["ctx_ct"] == counts and (fastq or counts[2] == 0)
+    # the same inputs dealt to three engines file by file (--devices with several files: whole files are the unit, results
+    # written in file order, command_dist.c:363-372), and with the FASTA text windowed on the host instead of on the device
+    variants = [("sharded", ["--devices", "0,0,0", "-p", "6"])]
+    if not fastq:
+        variants.append(("hostfasta", ["--host-fasta", "-p", "6"]))
+    for tag, extra in variants:
+        other = str(tmp_path / tag)
+        r = subprocess.run(base + extra + ["-o", other] + paths, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        assert sorted(os.listdir(other)) == sorted(os.listdir(whole)), tag
+        for f in sorted(os.listdir(whole)):
+            if f == "cofiles.stat":
+                assert parse_stat(os.path.join(other, f)) == parse_stat(os.path.join(whole, f)), tag
+            else:
+                assert filecmp.cmp(os.path.join(whole, f), os.path.join(other, f), shallow=False), (tag, f)
 
 
 # ---- sixteen components end to end (stage I, combine, stage II, search) with COMPONENT_SZ = 6 --------------------------------

@@ -90,3 +90,82 @@ def test_full_size_sketch_properties(capi, shufs, reads_dev):
     finally:
         e0.close()
         e1.close()
+
+
+# ---- BASELINE config 4's table regime on ONE GPU -----------------------------------------------------------------------------
+# 500 M synthetic 150 bp reads (80 GB of rows resident in HBM): 15 692 589 distinct keys in the 33 554 393-slot table (load 0.468,
+# 78 % of hashlimit, /root/reference/iseq2comem.c:61,701-718 -- the heavy-collision regime where the slot layout really depends
+# on first-occurrence order).  The sketch of the whole stream and the merge of 8 contiguous shards through
+# mk_partial_export / mk_partial_import (what 8 GPUs do) must agree byte for byte.
+N4, SHARDS4, DISTINCT4 = 500_000_000, 8, 15_692_589
+
+
+def test_config4_regime_whole_equals_eight_shards(capi, shufs):
+    import time
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    if free.value < N4 * STRIDE + (24 << 30):
+        pytest.skip("needs %d GB of free HBM" % ((N4 * STRIDE + (24 << 30)) >> 30))
+    shuf = shufs("L3K11")
+    rows = C.c_void_p()
+    assert hip.hipMalloc(C.byref(rows), C.c_size_t(N4 * STRIDE)) == 0
+    e0, e1 = capi.Engine(shuf, 0), capi.Engine(shuf, 0)
+    bufs = []
+    try:
+        capi.synth_rows_device(0, None, SEED, 0, N4, LEN, STRIDE, rows.value)
+        assert hip.hipDeviceSynchronize() == 0
+        per = 62_500_000  # rows per push: eight scan launches, as the bench does
+        e0.begin(capi.MK_MODE_KOC)
+        for first in range(0, N4, per):
+            e0.push_reads_device(rows.value + first * STRIDE, STRIDE, min(per, N4 - first), first)
+        e0.profile_enable(True)
+        e0.profile_reset()
+        t0 = time.time()
+        ids, cnt = e0.finish()[0]
+        t_finish = time.time() - t0
+        prof = e0.profile()
+        e0.profile_enable(False)
+        msg = "finish %.2f ms wall, %.2f ms on the device, %d keys" % (1e3 * t_finish, prof["finish_ms"], ids.size)
+        assert ids.size == DISTINCT4, msg
+        assert abs(ids.size / 33554393.0 - 0.468) < 0.001, msg
+        assert ids.size == np.unique(ids).size and cnt.min() >= 1, msg
+        total_occ = int(cnt.astype(np.int64).sum())
+        assert abs(total_occ - N4 * 129 / 4096) < 5 * (N4 * 129 / 4096) ** 0.5, msg
+
+        # eight contiguous shards: shard 0 stays in e0's table, 1..7 are sketched on e1 one after the other, exported and
+        # imported into e0 (what GPU 0 does with the lists of GPUs 1..7)
+        shard = N4 // SHARDS4
+        e0.begin(capi.MK_MODE_KOC)
+        e0.push_reads_device(rows.value, STRIDE, shard, 0)
+        cap = 4_000_000
+        for nbytes in (8 * cap, 4 * cap, 8 * cap):
+            p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+            bufs.append(p)
+        partial_total = 0
+        for s in range(1, SHARDS4):
+            first = s * shard
+            n = shard if s + 1 < SHARDS4 else N4 - first
+            e1.begin(capi.MK_MODE_KOC)
+            e1.push_reads_device(rows.value + first * STRIDE, STRIDE, n, first)
+            d = e1.partial_count()
+            assert d <= cap
+            assert e1.partial_export(bufs[0].value, bufs[1].value, bufs[2].value, cap) == d
+            partial_total += d
+            e0.partial_import(bufs[0].value, bufs[1].value, bufs[2].value, d)
+            e0.sync()  # the buffers are reused by the next shard
+        t0 = time.time()
+        mids, mcnt = e0.finish()[0]
+        t_merge_finish = time.time() - t0
+        msg += "; merged finish %.2f ms wall; partial lists of shards 1..7: %d keys" % (1e3 * t_merge_finish, partial_total)
+        assert np.array_equal(mids, ids), msg
+        assert np.array_equal(mcnt, cnt), msg
+        assert partial_total + 1 >= ids.size * 7 // 8, msg
+        print("\nconfig 4 regime on one GPU: " + msg)
+    finally:
+        for p in bufs:
+            hip.hipFree(p)
+        e0.close()
+        e1.close()
+        hip.hipFree(rows)

@@ -182,6 +182,66 @@ def test_fasta_windows_set_and_uniq(capi, engine_for, shufs, oracle_for, name, u
         assert_same(got, want, "%s uniq=%s stride=%d" % (name, uniq, stride))
 
 
+@pytest.mark.parametrize("uniq", [False, True])
+@pytest.mark.parametrize("name", ["L0K6", "L0K6z", "L1K7", "L3K10", "L3K11", "L2K11"])
+def test_fasta_device_stream_equals_oracle(capi, engine_for, shufs, oracle_for, name, uniq):
+    """mk_sketch_push_stream: the raw FASTA bytes go to the device, which drops line ends and header lines like fasta2co()'s
+    walk (iseq2comem.c:240-279) and scans overlapping rows of the base stream; whole, and in pieces that cut lines, headers
+    and k-mers anywhere"""
+    rs = np.random.RandomState(32)
+    big = name in ("L3K10", "L3K11", "L2K11")
+    g = ui.rand_seq(rs, 400000 if big else 30000)
+    if big:
+        contigs = [g[:150000], g[150000:150050] + b"N" * 37 + g[150050:300000], g[100000:180000],
+                   ui.revcomp(g[300000:400000]).lower()]
+    else:
+        contigs = [g[:20000], g[5000:12000], b"A" * 100 + g[500:900] + b"T" * 50, g[20000:20021], b"", g[20021:]]
+    fa = ui.fasta_bytes(contigs)
+    rc, want = oracle_for(shufs(name)).co_from_fasta(fa, uniq=uniq)
+    assert rc == 0
+    for piece in (None, 100000, 4099, 613):
+        if piece == 613 and big:
+            continue
+        eng = engine_for(name)
+        eng.begin(capi.MK_MODE_UNIQ_SET if uniq else capi.MK_MODE_SET)
+        eng.push_stream(fa, piece=piece)
+        assert_same(eng.finish(), want, "%s uniq=%s piece=%s" % (name, uniq, piece))
+
+
+@pytest.mark.parametrize("name", ["L0K6", "L1K7"])
+def test_fasta_device_stream_rough_text(capi, engine_for, shufs, oracle_for, name):
+    """CRLF, blank lines, '>' inside a sequence line, empty header, header directly behind sequence without newline at the end of
+    the file, lower case, other letters, digits -- against the oracle's restatement of the reference's byte walk"""
+    rs = np.random.RandomState(33)
+    a, b, c = ui.rand_seq(rs, 5000), ui.rand_seq(rs, 3000), ui.rand_seq(rs, 2000)
+    texts = [
+        b">h1\r\n" + a[:1000] + b"\r\n" + a[1000:2000] + b"\r\n\r\n" + a[2000:] + b"\n>\n" + b + b"\n",
+        b">x\n" + a[:700] + b">inline header to the end of this line\n" + a[700:1400] + b"\n" + c.lower() + b"\n",
+        a + b"\n" + b + b"\n",                                  # no header at all
+        b">only header\n",
+        b">h\n" + a[:30] + b"R" + a[30:90] + b"-" + a[90:400] + b"5" + a[400:] + b"\n>t\n" + c,   # no newline at the end
+        b"\n\n>h\n\n" + a + b"\n\n",
+        b">h\n" + b"\n".join(a[i:i + 7] for i in range(0, 3000, 7)) + b"\n",          # very short lines
+        b">h\n" + a[:21] + b"\n>g\n" + a[:22] + b"\n",                          # one base short of a k-mer / exactly one (k = 6,7: more)
+    ]
+    ora = oracle_for(shufs(name))
+    for i, fa in enumerate(texts):
+        rc, want = ora.co_from_fasta(fa)
+        assert rc == 0
+        for piece in (None, 17, 1000):
+            eng = engine_for(name)
+            eng.begin(capi.MK_MODE_SET)
+            eng.push_stream(fa, piece=piece)
+            assert_same(eng.finish(), want, "%s text %d piece=%s" % (name, i, piece))
+    # a stream that ends inside a header line: the reference gives up (iseq2comem.c:259-271)
+    eng = engine_for(name)
+    eng.begin(capi.MK_MODE_SET)
+    eng.push_stream(b">h\n" + a[:500] + b"\n>cut off")
+    with pytest.raises(capi.MkError) as ei:
+        eng.finish()
+    assert ei.value.code == capi.MK_ERR_FORMAT
+
+
 def test_shard_merge_equals_single_engine(capi, shufs, oracle_for):
     """two engines sketch disjoint contiguous read ranges with global ordinals; the second one's
     distinct-key list is imported into the first; the merged result equals the sequential sketch"""

@@ -2,6 +2,9 @@
 # HBM traffic of the scan kernel from TCC counters: FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots).
 # Writes profiles-ready JSON (with the kernel source id bench.py checks) to gpurun_out/scan_traffic.json.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# the JSON carries the id of the SHIPPED kernel source: a run against another library (MK_LIBRARY: make tuning VARIANT=..) would
+# file the variant's traffic under that id and bench.py would report it as the shipped kernel's -- refuse
+if [ -n "$MK_LIBRARY" ] && [ -z "$MK_TRAFFIC_VARIANT" ]; then echo "tools/pmc_traffic.sh: MK_LIBRARY is set ($MK_LIBRARY): use tools/pmc_traffic_variant.sh, which writes scan_traffic_variant.json under the variant's own id" >&2; exit 2; fi
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/traffic_$C
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/traffic_$C -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-host-legs > gpurun_out/traffic_$C.log 2>&1
@@ -23,13 +26,18 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
         out.setdefault(kern, {})[C] = sum(v) / max(1, len(v))
     kname = [names[d] for d in per if "mk_scan_kernel" in names[d]]
 sc = out["mk_scan_kernel"]
-res = {"kernel": kname[0] if kname else "mk_scan_kernel", "kernel_source_id": bench.kernel_source_id(), "reads_per_launch": 50000000,
+reads_per_launch = bench.CONFIG3_READS  # what `bench.py` without flags scans per launch (one push of the whole workload)
+import os
+variant = os.environ.get("MK_TRAFFIC_VARIANT")
+res = {"kernel": kname[0] if kname else "mk_scan_kernel",
+       "kernel_source_id": ("variant[%s] of %s" % (variant, bench.kernel_source_id())) if variant else bench.kernel_source_id(),
+       "reads_per_launch": reads_per_launch,
        "FETCH_SIZE_KB": sc["FETCH_SIZE"], "WRITE_SIZE_KB": sc["WRITE_SIZE"],
        "hbm_bytes_per_launch": 2 * sc["FETCH_SIZE"] * 1024 + sc["WRITE_SIZE"] * 1024,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (tools/pmc_traffic.sh); bytes = 2*FETCH_SIZE*1024 + "
                  "WRITE_SIZE*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads, MI355X_MICROARCH.md HBM "
                  "section; verified on a known byte count with this kernel's staging pattern: tools/ubench_fetch.hip)",
        "other_kernels_KB": {k: v for k, v in out.items() if k != "mk_scan_kernel"}}
-json.dump(res, open("gpurun_out/scan_traffic.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/scan_traffic_variant.json" if variant else "gpurun_out/scan_traffic.json", "w"), indent=1)
 print(json.dumps(res))
 PY

@@ -3,4 +3,4 @@
 # (scratch library via `make tuning`, selected with MK_LIBRARY; the shipped library is not touched)
 cd $GRAFT_REPO_ROOT
 make -s -C metakssd_amd/csrc tuning TUNING_OUT=/tmp/mk_variant_pmc VARIANT="$VARIANT" || exit 1
-MK_LIBRARY=/tmp/mk_variant_pmc/libmetakssd_hip.so bash tools/pmc_traffic.sh | tail -1
+MK_TRAFFIC_VARIANT="${VARIANT:-tuning build}" MK_LIBRARY=/tmp/mk_variant_pmc/libmetakssd_hip.so bash tools/pmc_traffic.sh | tail -1
