@@ -380,19 +380,31 @@ def main():
                     result["_alive"] = (k, c, o)  # until the next step's fence
         if rank == 0:
             if flags["keep"]:
+                drain()
                 result["sketch"] = eng.finish()
                 result["distinct"] = sum(len(x[0]) for x in result["sketch"])
             else:
-                r = eng.finish_raw()
-                result["distinct"] = int(r.total)
-                capi.lib.mk_result_release(eng.h, r)
+                # a pass is over when its result is in host memory; the copy of pass i (mk_sketch_finish_begin queues it on a
+                # stream of its own) runs beside the table clear and the scan of pass i + 1, and is waited for before pass
+                # i + 1 is finished -- every pass pays for all of its work inside the timed region, the last one before the fence
+                drain()
+                eng.finish_begin()
+                flags["pending"] = True
         if world > 1 and tail["on"]:
             torch.cuda.synchronize()
             if rank == 0:
                 tail["t"] += time.perf_counter() - t0
                 tail["steps"] += 1
 
+    def drain():
+        if flags.get("pending"):
+            r = eng.finish_end_raw()
+            result["distinct"] = int(r.total)
+            capi.lib.mk_result_release(eng.h, r)
+            flags["pending"] = False
+
     def fence():
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -193,6 +193,13 @@ int mk_sketch_push_wait(mk_engine *e, uint64_t ticket);
  * MK_ERR_FORMAT.  May be mixed with mk_sketch_push_reads* in one sketch; ordinals follow the order of the calls. */
 int mk_sketch_push_stream(mk_engine *e, const uint8_t *text, uint64_t n, int final);
 int mk_sketch_finish(mk_engine *e, mk_result *out);
+/* mk_sketch_finish in two halves, for callers that sketch one input after another: _begin runs compaction, layout and dump (into
+ * staging arrays in HBM), waits once for the counters and queues the copy of the result to the host on a stream of its own;
+ * when it returns the sketch is over and the NEXT one may be begun and pushed -- its kernels run beside that copy.  _end waits
+ * for the copy and hands out the result.  One result may be outstanding: _end comes before the next mk_sketch_finish /
+ * mk_sketch_finish_begin on the engine.  Errors of the sketch (MK_ERR_CROWDED, MK_ERR_FORMAT) are returned by _begin. */
+int mk_sketch_finish_begin(mk_engine *e);
+int mk_sketch_finish_end(mk_engine *e, mk_result *out);
 int mk_result_release(mk_engine *e, mk_result *r);
 int mk_engine_sync(mk_engine *e);
 

@@ -117,6 +117,8 @@ def _load():
         "mk_partial_count_begin": [vp],
         "mk_partial_export_async": [vp, vp, vp, vp, u64, C.POINTER(u64)],
         "mk_sketch_finish": [vp, C.POINTER(ResultC)],
+        "mk_sketch_finish_begin": [vp],
+        "mk_sketch_finish_end": [vp, C.POINTER(ResultC)],
         "mk_result_release": [vp, C.POINTER(ResultC)],
         "mk_engine_sync": [vp],
         "mk_host_alloc": [C.POINTER(vp), C.c_size_t],
@@ -446,6 +448,29 @@ class Engine:
         r = ResultC()
         _check(lib.mk_sketch_finish(self.h, C.byref(r)), self.h)
         return r
+
+    def finish_begin(self):
+        """first half of a finish: when it returns the next sketch may be begun and pushed; finish_end() hands out the result"""
+        _check(lib.mk_sketch_finish_begin(self.h), self.h)
+
+    def finish_end_raw(self):
+        r = ResultC()
+        _check(lib.mk_sketch_finish_end(self.h, C.byref(r)), self.h)
+        return r
+
+    def finish_end(self):
+        r = self.finish_end_raw()
+        out = []
+        for c in range(r.component_num):
+            comp = r.components[c]
+            n = comp.n
+            ids = np.ctypeslib.as_array(comp.ids, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+            cnt = None
+            if comp.counts:
+                cnt = np.ctypeslib.as_array(comp.counts, shape=(n,)).copy() if n else np.zeros(0, np.uint16)
+            out.append((ids, cnt))
+        self.last_total = r.total
+        return out
 
     def sync(self):
         _check(lib.mk_engine_sync(self.h), self.h)

@@ -90,6 +90,15 @@ struct mk_engine {
   /* dynamic-LDS limit already granted to each scan-kernel instantiation on this engine's device */
   std::vector<std::pair<const void *, size_t>> lds_granted;
 
+  /* mk_sketch_finish_begin / _end: the dump goes to staging arrays in HBM and from there to the pinned result arrays by DMA on a
+   * stream of its own, beside the next sketch's kernels */
+  uint32_t *d_res_ids = nullptr;
+  uint16_t *d_res_cnt = nullptr;
+  uint64_t res_cap = 0;
+  hipStream_t res_stream = nullptr;
+  hipEvent_t ev_res = nullptr;
+  bool res_pending = false;
+  uint64_t res_total = 0;
   /* key-list-driven dump (sparse bookkeeping): scratch sized to the number of keys, device-side result staging */
   void *d_kl = nullptr;          /* skey[cap] | tkey[cap] | tidx[cap] | out_ids[cap] | out_cnt[cap] */
   uint64_t kl_cap = 0;
@@ -265,6 +274,9 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters);
   hipFree(e->d_kl); hipFree(e->d_kl_buckets);
+  hipFree(e->d_res_ids); hipFree(e->d_res_cnt);
+  if (e->res_stream) hipStreamDestroy(e->res_stream);
+  if (e->ev_res) hipEventDestroy(e->ev_res);
   hipFree(e->d_text); hipFree(e->d_stream); hipFree(e->d_stream_tmp); hipFree(e->d_fa_sum); hipFree(e->d_fa_state);
   if (e->h_fa_state) hipHostFree(e->h_fa_state);
   if (e->h_comp_totals) hipHostFree(e->h_comp_totals);
@@ -968,6 +980,9 @@ static int mk_fa_reserve(mk_engine *e, size_t n) {
     MK_HIP(e, hipMemset(ns, 0, scap));
     if (e->d_stream && e->fa_tail) MK_HIP(e, hipMemcpy(ns, e->d_stream, e->fa_tail, hipMemcpyDeviceToDevice));
     hipFree(e->d_kl); hipFree(e->d_kl_buckets);
+  hipFree(e->d_res_ids); hipFree(e->d_res_cnt);
+  if (e->res_stream) hipStreamDestroy(e->res_stream);
+  if (e->ev_res) hipEventDestroy(e->ev_res);
   hipFree(e->d_text); hipFree(e->d_stream); hipFree(e->d_stream_tmp);
     e->d_text = nt; e->d_stream = ns; e->d_stream_tmp = ntmp;
     e->text_cap = cap; e->stream_cap = scap;
@@ -1208,7 +1223,8 @@ static int mk_result_capacity(mk_engine *e, uint64_t want) {
 
 /* the ordered dump of the layout table into the (host-mapped) result arrays; with count_pass == false only the write
  * kernel runs again (after the result arrays have grown; the chunk offsets of the first pass are still valid) */
-static int mk_launch_dump(mk_engine *e, bool count_pass) {
+static int mk_launch_dump(mk_engine *e, bool count_pass, uint32_t *out_ids = nullptr, uint16_t *out_cnt = nullptr, uint64_t out_cap = 0) {
+  if (!out_ids) { out_ids = e->h_ids; out_cnt = e->h_cnt; out_cap = e->h_cap; } /* straight into the pinned host arrays */
   const int C = e->P.component_num;
   const bool koc = e->mode == MK_MODE_KOC;
   mk_dump_args da{};
@@ -1218,7 +1234,7 @@ static int mk_launch_dump(mk_engine *e, bool count_pass) {
   da.cnt_lo = e->mode == MK_MODE_OCC_SET ? e->min_occ : 1u; /* write_fqco2file(): marked keys only (iseq2comem.c:611) */
   da.cnt_hi = e->mode == MK_MODE_UNIQ_SET ? 1u : 0xffffffffu;  /* uniq_fasta2co(): repeated keys dropped */
   da.nchunks = e->nchunks;
-  da.out_cap = e->h_cap;
+  da.out_cap = out_cap;
   const unsigned dblocks = (e->nchunks + 3) / 4; /* 4 waves (chunks) per 256-thread block */
   if (C == 1) {
     da.comp = 0;
@@ -1227,7 +1243,7 @@ static int mk_launch_dump(mk_engine *e, bool count_pass) {
       hipLaunchKernelGGL(mk_dump_scan_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_chunk, e->nchunks, e->d_comp_totals);
     }
     hipLaunchKernelGGL(mk_dump_write_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, (const uint32_t *)e->d_chunk,
-                       (const unsigned long long *)e->d_comp_totals, e->h_ids, koc ? e->h_cnt : nullptr);
+                       (const unsigned long long *)e->d_comp_totals, out_ids, koc ? out_cnt : nullptr);
   } else {
     /* all components in one count pass and one write pass; components back to back in the output */
     if (count_pass) {
@@ -1235,7 +1251,7 @@ static int mk_launch_dump(mk_engine *e, bool count_pass) {
       hipLaunchKernelGGL(mk_dumpc_scan_kernel, dim3((unsigned)C), dim3(1024), 0, e->stream, e->d_chunk, e->nchunks, e->d_comp_totals);
     }
     hipLaunchKernelGGL(mk_dumpc_write_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, (const uint32_t *)e->d_chunk,
-                       (const unsigned long long *)e->d_comp_totals, e->h_ids, koc ? e->h_cnt : nullptr);
+                       (const unsigned long long *)e->d_comp_totals, out_ids, koc ? out_cnt : nullptr);
   }
   MK_HIP(e, hipGetLastError());
   return MK_OK;
@@ -1342,8 +1358,53 @@ static int mk_finish_keylist(mk_engine *e, mk_result *out, mk_evpair ev) {
  * ids and counts straight into the pinned result arrays, and the counters (key count, component sizes, error flags) come
  * back in one small copy in front of the only hipStreamSynchronize.  Only a result larger than the arrays (first big
  * sketch on this engine) costs a second round: grow, write again. */
+static int mk_res_reserve(mk_engine *e, uint64_t want) {
+  if (!e->res_stream) {
+    MK_HIP(e, hipStreamCreateWithFlags(&e->res_stream, hipStreamNonBlocking));
+    MK_HIP(e, hipEventCreateWithFlags(&e->ev_res, hipEventDisableTiming));
+  }
+  if (want <= e->res_cap && e->d_res_ids) return MK_OK;
+  hipFree(e->d_res_ids); hipFree(e->d_res_cnt);
+  e->d_res_ids = nullptr; e->d_res_cnt = nullptr; e->res_cap = 0;
+  MK_HIP(e, hipMalloc(&e->d_res_ids, want * 4));
+  MK_HIP(e, hipMalloc(&e->d_res_cnt, want * 2));
+  e->res_cap = want;
+  return MK_OK;
+}
+
+static int mk_finish_impl(mk_engine *e, mk_result *out, bool staged);
+
 extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
   if (!e || !out) return MK_ERR_ARG;
+  if (e->res_pending) return mk_fail(e, MK_ERR_STATE, "mk_sketch_finish while the result of mk_sketch_finish_begin has not been taken (mk_sketch_finish_end)");
+  return mk_finish_impl(e, out, false);
+}
+
+/* The same finish in two halves.  _begin: compaction, layout and dump as in mk_sketch_finish, but the dump goes to staging
+ * arrays in HBM (a sweep at memory speed instead of 4-byte stores across PCIe), the one synchronisation brings the counters,
+ * and the copy to the pinned result arrays is queued on a stream of its own.  The sketch is over when _begin returns: the
+ * caller may begin and push the NEXT sketch, whose kernels then run beside that copy.  _end waits for the copy and hands out
+ * the result (valid until the next mk_sketch_finish / _finish_begin on the engine).  One result may be outstanding. */
+extern "C" int mk_sketch_finish_begin(mk_engine *e) {
+  if (!e) return MK_ERR_ARG;
+  if (e->res_pending) return mk_fail(e, MK_ERR_STATE, "mk_sketch_finish_begin: take the previous result first (mk_sketch_finish_end)");
+  mk_result r;
+  return mk_finish_impl(e, &r, true);
+}
+
+extern "C" int mk_sketch_finish_end(mk_engine *e, mk_result *out) {
+  if (!e || !out) return MK_ERR_ARG;
+  if (!e->res_pending) return mk_fail(e, MK_ERR_STATE, "mk_sketch_finish_end without mk_sketch_finish_begin");
+  MK_HIP(e, hipSetDevice(e->device));
+  MK_HIP(e, hipEventSynchronize(e->ev_res));
+  e->res_pending = false;
+  out->component_num = e->P.component_num;
+  out->total = e->res_total;
+  out->components = e->comps.data();
+  return MK_OK;
+}
+
+static int mk_finish_impl(mk_engine *e, mk_result *out, bool staged) {
   if (!e->begun) return mk_fail(e, MK_ERR_STATE, "finish before mk_sketch_begin");
   MK_HIP(e, hipSetDevice(e->device));
   mk_evpair ev{};
@@ -1362,14 +1423,24 @@ extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
 
   if (e->sparse) { /* large tables: the dump starts from the key list, not from the table (mk_kl_* kernels) */
     rc = mk_finish_keylist(e, out, ev);
+    if (rc == MK_OK && staged) { /* (the key-list dump is staged and copied already: the result is there) */
+      MK_HIP(e, mk_res_reserve(e, 1) == MK_OK ? hipSuccess : hipErrorOutOfMemory);
+      MK_HIP(e, hipEventRecord(e->ev_res, e->res_stream));
+      e->res_pending = true;
+      e->res_total = out->total;
+    }
     return rc;
+  }
+  if (staged) {
+    rc = mk_res_reserve(e, e->res_cap > e->h_cap ? e->res_cap : e->h_cap);
+    if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
   }
   MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), e->stream));
   hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)e->num_cu * 16u), dim3(256), 0, e->stream, e->dist,
                      (const unsigned long long *)e->d_counters, (unsigned long long)mk_key_limit(e), e->d_slot, S, e->tab.err,
                      e->sparse ? e->d_dirty_slot : nullptr, (uint32_t)MK_DUMP_SHIFT);
   MK_HIP(e, hipGetLastError());
-  rc = mk_launch_dump(e, true);
+  rc = staged ? mk_launch_dump(e, true, e->d_res_ids, e->d_res_cnt, e->res_cap) : mk_launch_dump(e, true);
   if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
   MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
   MK_HIP(e, hipMemcpyAsync(e->h_comp_totals, e->d_comp_totals, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
@@ -1385,14 +1456,24 @@ extern "C" int mk_sketch_finish(mk_engine *e, mk_result *out) {
   uint64_t total = 0;
   for (int c = 0; c < C; c++) total += e->h_comp_totals[c];
   if (total > e->D) { if (e->profiling) e->ev_pool.push_back(ev); return mk_fail(e, MK_ERR_HIP, "dump produced more entries than distinct keys"); }
-  if (total > e->h_cap) { /* the write kernel held back: grow the result arrays and run it again */
+  if (total > (staged ? (e->res_cap < e->h_cap ? e->res_cap : e->h_cap) : e->h_cap)) { /* the write kernel held back: grow the result arrays and run it again */
     rc = mk_result_capacity(e, total);
-    if (rc == MK_OK) rc = mk_launch_dump(e, false);
+    if (rc == MK_OK && staged) rc = mk_res_reserve(e, e->h_cap);
+    if (rc == MK_OK) rc = staged ? mk_launch_dump(e, false, e->d_res_ids, e->d_res_cnt, e->res_cap) : mk_launch_dump(e, false);
     if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
     if (e->profiling) MK_HIP(e, hipEventRecord(ev.b, e->stream));
     MK_HIP(e, hipStreamSynchronize(e->stream));
   }
   if (e->profiling) e->ev_finish.push_back(ev);
+  if (staged) { /* everything the copy reads is final (the stream has been waited for): queue it beside whatever comes next */
+    if (total) {
+      MK_HIP(e, hipMemcpyAsync(e->h_ids, e->d_res_ids, total * 4, hipMemcpyDeviceToHost, e->res_stream));
+      if (koc) MK_HIP(e, hipMemcpyAsync(e->h_cnt, e->d_res_cnt, total * 2, hipMemcpyDeviceToHost, e->res_stream));
+    }
+    MK_HIP(e, hipEventRecord(e->ev_res, e->res_stream));
+    e->res_pending = true;
+    e->res_total = total;
+  }
   uint64_t at = 0;
   for (int c = 0; c < C; c++) {
     e->comps[c].n = e->h_comp_totals[c];

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("seed,sparse,front", [(11, "0", None), (12, "1", None), (13, "0", "6"), (14, "0", "11")])
+@pytest.mark.parametrize("seed,sparse,front", [(11, "0", None), (12, "1", None), (13, "0", "6"), (14, "0", "11"), (15, "1", "5"), (16, "1", "0")])
 def test_randomized_engine_vs_oracle(seed, sparse, front):
     """front: MK_OPT_FRONT_BITS -- a front table of 64 slots overflows into the big table in almost every case and closes
     after the first launch, one of 2048 slots holds most small sketches whole"""

@@ -242,6 +242,47 @@ def test_fasta_device_stream_rough_text(capi, engine_for, shufs, oracle_for, nam
     assert ei.value.code == capi.MK_ERR_FORMAT
 
 
+@pytest.mark.parametrize("name,sparse", [("L1K7", 0), ("L1K7", 1), ("L3K11", 0), ("L2K11", -1)])
+def test_finish_in_two_halves_pipelined(capi, shufs, oracle_for, name, sparse):
+    """mk_sketch_finish_begin / _end: the result of sketch i is copied to the host while sketch i + 1 is already being scanned;
+    every result equals the oracle's (and so the plain mk_sketch_finish's), results larger than the staging arrays included"""
+    rs = np.random.RandomState(41)
+    eng = capi.Engine(shufs(name), 0, sparse=sparse)
+    ora = oracle_for(shufs(name))
+    try:
+        eng.set_option(capi.MK_OPT_RESULT_CAP, 64)  # the first results do not fit: grown inside finish_begin
+        batches = []
+        for i in range(4):
+            n = [3000, 0, 20000, 500][i]
+            seqs = ui.pool_reads(rs, 4000, n) if n else []
+            rows = ui.rows_from_seqs(seqs, 160) if n else np.zeros(0, np.uint8)
+            batches.append(rows)
+        wants = []
+        for rows in batches:
+            rc, want = ora.koc_from_rows(rows, 160)
+            assert rc == 0
+            wants.append(want)
+        pending = None
+        for i, rows in enumerate(batches):
+            eng.begin(capi.MK_MODE_KOC)
+            eng.push_reads(rows, 160, 0)
+            if pending is not None:
+                assert_same(eng.finish_end(), wants[pending], "%s sketch %d" % (name, pending))
+            eng.finish_begin()
+            with pytest.raises(capi.MkError):  # one result outstanding: neither finish may run before it has been taken
+                eng.finish_begin()
+            pending = i
+        assert_same(eng.finish_end(), wants[pending], "%s last sketch" % name)
+        with pytest.raises(capi.MkError):
+            eng.finish_end()
+        # and the plain finish still works on the same engine
+        eng.begin(capi.MK_MODE_KOC)
+        eng.push_reads(batches[0], 160, 0)
+        assert_same(eng.finish(), wants[0], "%s plain finish afterwards" % name)
+    finally:
+        eng.close()
+
+
 def test_shard_merge_equals_single_engine(capi, shufs, oracle_for):
     """two engines sketch disjoint contiguous read ranges with global ordinals; the second one's
     distinct-key list is imported into the first; the merged result equals the sequential sketch"""

@@ -123,15 +123,31 @@ def main():
             if stride < 2 * P.TL + 4:
                 stride = 256
             eng.begin(capi.MK_MODE_UNIQ_SET if flavour == "uniq" else capi.MK_MODE_SET)
-            try:
-                rows = capi.fasta_windows(fa, P.TL, stride, chunk=int(rs.choice([0, 100, 5000])) or None)
-                eng.push_reads(rows, stride, 0)
-            except capi.MkError as ex:  # input ends inside a '>' line: the reference aborts there, the oracle says KO_ERR_CONTRACT
-                if ex.code != capi.MK_ERR_FORMAT or rc != -5:
-                    raise
-                eng.finish()
-                crowded += 1
-                continue
+            if rs.rand() < 0.5:  # the text itself to the device (mk_sketch_push_stream), whole or in pieces cut anywhere
+                piece = int(rs.choice([0, 0, 37, 1000, 70001])) or None
+                desc += " device stream piece=%s" % piece
+                eng.push_stream(fa, piece=piece)
+                if rc == -5:  # input ends inside a '>' line: the reference aborts there; the engine reports it at finish
+                    try:
+                        eng.finish()
+                        ok_format = False
+                    except capi.MkError as ex:
+                        ok_format = ex.code == capi.MK_ERR_FORMAT
+                    if not ok_format:
+                        bad += 1
+                        print("MISMATCH", desc, "the oracle refuses the text (ends inside a header), the engine did not")
+                    crowded += 1
+                    continue
+            else:
+                try:
+                    rows = capi.fasta_windows(fa, P.TL, stride, chunk=int(rs.choice([0, 100, 5000])) or None)
+                    eng.push_reads(rows, stride, 0)
+                except capi.MkError as ex:  # input ends inside a '>' line: the reference aborts there, the oracle says KO_ERR_CONTRACT
+                    if ex.code != capi.MK_ERR_FORMAT or rc != -5:
+                        raise
+                    eng.finish()
+                    crowded += 1
+                    continue
         try:
             got = eng.finish()
             grc = 0
