@@ -114,6 +114,7 @@ struct mk_engine {
   uint64_t fa_tail = 0;      /* stream bytes carried from the last non-final push (exact: read back) */
   uint64_t fa_rows_done = 0; /* virtual rows scanned so far in this sketch = ordinal of the next one */
   bool fa_used = false, fa_final = false;
+  uint32_t fa_pitch = 0;     /* this sketch's row step (0: not chosen yet) */
 
   int mode = -1;
   uint32_t min_occ = 1; /* MK_MODE_OCC_SET: dump keys seen at least this often */
@@ -620,12 +621,15 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   if (e->sparse && e->tables_tracked) {
     /* the accumulation table is empty except in the blocks the last sketch marked: clear those, and the marks.  The layout
      * table is empty already (the key-list dump hands every slot back); after a finish that went wrong it is filled anew */
-    hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_acc, e->acc_words, e->d_list_acc, e->d_nlist, 1);
-    hipLaunchKernelGGL(mk_dirty_clear_kernel, dim3((unsigned)e->num_cu * 8u), dim3(256), 0, e->stream, e->tab.kc, e->tab.ordinv, e->kp.S,
-                       (const uint32_t *)e->d_list_acc, (const uint32_t *)e->d_nlist, (uint32_t)MK_SPARSE_SHIFT, (uint32_t *)nullptr,
-                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t)MK_DUMP_SHIFT);
-    MK_HIP(e, hipGetLastError());
-    if (e->tab.fr) MK_HIP(e, hipMemsetAsync(e->d_front, 0, e->front_slots * 16, e->stream));
+    if (!e->tab.fr || e->big_maybe_dirty) { /* (behind a front table: only when the last sketch may have reached the big table) */
+      hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_acc, e->acc_words, e->d_list_acc, e->d_nlist, 1,
+                         (const uint32_t *)nullptr);
+      hipLaunchKernelGGL(mk_dirty_clear_kernel, dim3((unsigned)e->num_cu * 8u), dim3(256), 0, e->stream, e->tab.kc, e->tab.ordinv, e->kp.S,
+                         (const uint32_t *)e->d_list_acc, (const uint32_t *)e->d_nlist, (uint32_t)MK_SPARSE_SHIFT, (uint32_t *)nullptr,
+                         (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t)MK_DUMP_SHIFT);
+      MK_HIP(e, hipGetLastError());
+    }
+    if (e->tab.fr) { MK_HIP(e, hipMemsetAsync(e->d_front, 0, e->front_slots * 16, e->stream)); e->big_maybe_dirty = false; }
     if (!e->slot_clean) {
       MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)e->kp.S * sizeof(uint32_t), e->stream));
       e->slot_clean = true;
@@ -655,7 +659,7 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   e->count_queued = false;
   e->D = 0;
   if (e->fa_used) MK_HIP(e, hipMemsetAsync(e->d_fa_state, 0, sizeof(mk_fa_state), e->stream));
-  e->fa_used = false; e->fa_final = false; e->fa_tail = 0; e->fa_rows_done = 0;
+  e->fa_used = false; e->fa_final = false; e->fa_tail = 0; e->fa_rows_done = 0; e->fa_pitch = 0;
   return MK_OK;
 }
 
@@ -960,7 +964,13 @@ extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t 
  * piece but the last has final == 0 (rows whose last byte is not known yet wait in the stream buffer; one small
  * synchronisation per non-final piece tells the host how many).  The sketch is identical to the one the host windows
  * (mk_fasta_window + mk_sketch_push_reads) give: the k-mers and their order are the stream's, not the rows'. */
-#define MK_FA_PITCH 528u /* address step of the virtual rows: a multiple of 16, not of 128 (see MK_ROW_PITCH) */
+/* address step of the virtual rows: a multiple of 16, not of 128 (see MK_ROW_PITCH).  Long rows cost the least overlap (TL - 1 of
+ * 528 bytes are scanned twice); a genome-sized text gets SHORT rows instead: a 4 MB genome is 118 tiles of 528-byte rows -- 118
+ * busy waves of the 4096 the chip holds, each walking 35 000 bases one after the other (38 us for the tuned kernel, 168 us for the
+ * generic one) -- and 560 tiles of 112-byte rows.  Chosen at the first piece of a sketch and kept for it. */
+#define MK_FA_PITCH 528u
+#define MK_FA_PITCH_SMALL 112u
+#define MK_FA_SMALL_BYTES ((uint64_t)32 << 20)
 
 static int mk_fa_reserve(mk_engine *e, size_t n) {
   if (!e->d_fa_state) {
@@ -979,11 +989,7 @@ static int mk_fa_reserve(mk_engine *e, size_t n) {
     MK_HIP(e, hipMalloc(&ntmp, 8192));
     MK_HIP(e, hipMemset(ns, 0, scap));
     if (e->d_stream && e->fa_tail) MK_HIP(e, hipMemcpy(ns, e->d_stream, e->fa_tail, hipMemcpyDeviceToDevice));
-    hipFree(e->d_kl); hipFree(e->d_kl_buckets);
-  hipFree(e->d_res_ids); hipFree(e->d_res_cnt);
-  if (e->res_stream) hipStreamDestroy(e->res_stream);
-  if (e->ev_res) hipEventDestroy(e->ev_res);
-  hipFree(e->d_text); hipFree(e->d_stream); hipFree(e->d_stream_tmp);
+    hipFree(e->d_text); hipFree(e->d_stream); hipFree(e->d_stream_tmp);
     e->d_text = nt; e->d_stream = ns; e->d_stream_tmp = ntmp;
     e->text_cap = cap; e->stream_cap = scap;
   }
@@ -1008,7 +1014,8 @@ extern "C" int mk_sketch_push_stream(mk_engine *e, const uint8_t *text, uint64_t
   { int rc = mk_flush_region(e); if (rc) return rc; } /* rows pushed the other way keep their place in the order of the pushes */
   int rc = mk_fa_reserve(e, (size_t)n);
   if (rc) return rc;
-  const uint32_t TL = (uint32_t)e->P.TL, pitch = MK_FA_PITCH, rowlen = pitch + TL - 1u;
+  if (!e->fa_pitch) e->fa_pitch = (final && n <= MK_FA_SMALL_BYTES) ? MK_FA_PITCH_SMALL : MK_FA_PITCH; /* a whole small text at once */
+  const uint32_t TL = (uint32_t)e->P.TL, pitch = e->fa_pitch, rowlen = pitch + TL - 1u;
   const uint32_t width = (rowlen + 1u + 15u) & ~15u; /* staged bytes per row: through the cut, whole 16-byte pieces */
   e->fa_used = true;
   if (n) {
@@ -1073,7 +1080,7 @@ static int mk_compact_launch(mk_engine *e) {
                          e->dist, e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr, big_used, 0u);
       hipLaunchKernelGGL(mk_front_fold_kernel, dim3(blocks), dim3(1024), 0, e->stream, e->tab, e->kp.S);
     }
-    hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_acc, e->acc_words, e->d_list_acc, e->d_nlist + 2, 0);
+    hipLaunchKernelGGL(mk_dirty_list_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_dirty_acc, e->acc_words, e->d_list_acc, e->d_nlist + 2, 0, big_used);
     hipLaunchKernelGGL(mk_compact_kernel<MK_SPARSE_BLOCK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
                        e->d_counters, drop0, (const uint32_t *)e->d_list_acc, (const uint32_t *)(e->d_nlist + 2), big_used, 1u);
   } else {

@@ -1114,7 +1114,12 @@ struct mk_dist {
  * mk_dirty_clear_kernel: re-establishes "all empty" on the listed blocks of the accumulation table (zero) and, with the
  * second list, of the layout table (0xFFFFFFFF). */
 __global__ void __launch_bounds__(1024) mk_dirty_list_kernel(uint32_t *bitmap, uint32_t nwords, uint32_t *list, uint32_t *count,
-                                                            int clear_bitmap) {
+                                                            int clear_bitmap, const uint32_t *big_used) {
+  /* behind a front table: nobody has installed a key in the big table (big_used[0] == 0) -- no block is marked */
+  if (big_used && __hip_atomic_load(big_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+    if (threadIdx.x == 0) *count = 0u;
+    return;
+  }
   __shared__ uint32_t base_s;
   if (threadIdx.x == 0) base_s = 0;
   __syncthreads();

@@ -16,7 +16,7 @@ nl = int(3 * 4e6 / 70)
 pool = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, size=(nl, 70))]
 pool = np.concatenate([pool, np.full((nl, 1), 10, np.uint8)], axis=1).reshape(-1)
 half = int(4e6 / 2 / 70)
-for i in range(128):
+for i in range(512):
     a = (i * 7919) % (nl - 2 * half - 1); b = (a + half + 1 + (i * 104729) % (nl - 2 * half - 1)) % (nl - half)
     with open("%s/g%04d.fna" % (gd, i), "wb") as f:
         f.write(b">g%d_0\n" % i); f.write(pool[71 * a: 71 * (a + half)].tobytes()); f.write(b">g%d_1\n" % i); f.write(pool[71 * b: 71 * (b + half)].tobytes())
@@ -25,12 +25,12 @@ capi.Shuf.generate(11, 5, 2, 211).write(d + "/L2K11.shuf")
 PY
 # engines per GPU: the same 128 genomes with 1, 2, 4 engines on GPU 0 (file-sharded --devices), wall seconds
 for S in L3K10 L2K11; do
-  for D in 0 0,0 0,0,0,0; do
+  for D in 0 0,0; do
     for rep in 1 2; do
       s=$(date +%s.%N)
       $GRAFT_REPO_ROOT/metakssd_amd/bin/metakssd dist -L /dev/shm/mkprof5/$S.shuf -p 16 --devices $D -o /dev/shm/mkprof5/o_${S}_${rep} --quiet /dev/shm/mkprof5/genomes > /dev/null 2>&1
       e=$(date +%s.%N)
-      echo "engines[$D] $S rep $rep: $(python3 -c "print(round($e-$s,3), 's ->', round(128/($e-$s)), 'genomes/s')")" | tee -a $GRAFT_REPO_ROOT/gpurun_out/r3e_engines.txt
+      echo "engines[$D] $S rep $rep: $(python3 -c "print(round($e-$s,3), 's ->', round(512/($e-$s)), 'genomes/s')")" | tee -a $GRAFT_REPO_ROOT/gpurun_out/r3e_engines.txt
       rm -rf /dev/shm/mkprof5/o_${S}_${rep}
     done
   done
