@@ -1569,7 +1569,9 @@ typedef struct {
   int nworkers;
 } job_opts;
 
-static int sketch_one_file(ctx_t *c, const job_opts *o, int i, mk_result *res, double *t_finish) {
+/* first half: begin + everything pushed (queued on the engine's stream: a pinned text buffer stays with the caller in *held
+ * until the finish has waited); second half: finish + the reference's error messages */
+static void sketch_file_push(ctx_t *c, const job_opts *o, int i, int *held_out) {
   const char *path = o->files->v[i];
   c->next_ordinal = 0;
   const int fq = is_fastq(path);
@@ -1610,7 +1612,14 @@ static int sketch_one_file(ctx_t *c, const job_opts *o, int i, mk_result *res, d
     if (fq) sketch_fastq(c, path);
     else sketch_fasta(c, path, o->P->TL);
   }
-  mk_engine *eng = sketch_engine(c); /* an input without a single row still gives an (empty) sketch */
+  (void)sketch_engine(c); /* an input without a single row still gives an (empty) sketch */
+  *held_out = held;
+}
+
+static void sketch_file_finish(ctx_t *c, const job_opts *o, int i, int held, mk_result *res, double *t_finish) {
+  const char *path = o->files->v[i];
+  pf_t *pf = o->pf;
+  mk_engine *eng = c->eng;
   const double tf = now_s();
   int rc;
   if (c->multi) {
@@ -1627,6 +1636,12 @@ static int sketch_one_file(ctx_t *c, const job_opts *o, int i, mk_result *res, d
   if (rc == MK_ERR_CROWDED) die("the context space is too crowd, try rerun the program using -k%d", o->P->k + 1);
   if (rc == MK_ERR_FORMAT) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", path); /* iseq2comem.c:269 */
   if (rc != MK_OK) die("mk_sketch_finish failed (%d): %s", rc, mk_last_error(eng));
+}
+
+static int sketch_one_file(ctx_t *c, const job_opts *o, int i, mk_result *res, double *t_finish) {
+  int held = -1;
+  sketch_file_push(c, o, i, &held);
+  sketch_file_finish(c, o, i, held, res, t_finish);
   return MK_OK;
 }
 
@@ -1703,6 +1718,13 @@ static void *shard_driver_run(void *arg) {
   }
 }
 
+typedef struct { pthread_t th; const mk_params *P; int device; mk_engine *eng; char err[512]; } second_engine_t;
+static void *second_engine_run(void *arg) {
+  second_engine_t *s = arg;
+  if (mk_engine_create(s->P, s->device, &s->eng) != MK_OK) { s->eng = NULL; snprintf(s->err, sizeof s->err, "%s", mk_last_error(NULL)); }
+  return NULL;
+}
+
 int main(int argc, char **argv) {
   g_t0 = now_s();
   setvbuf(stdout, NULL, _IOLBF, 0);
@@ -1721,6 +1743,7 @@ int main(int argc, char **argv) {
   uint64_t chunk_bytes = (uint64_t)32 << 20; /* text per framing job = about 17 MiB of rows per host-to-device copy */
   int drop_pages = 1, inflight = 3, slow_exit = 0, direct_host = 0;
   int devs[64], ndev = 0; /* --devices 0-7 / 0,2,5 / 0,0 (the same GPU twice: two engines, for tests) */
+  int engines_per_gpu = 0; /* --engines 1|2: engines taking the files of a directory in turn on one GPU (0: two for tables below 2^26 slots) */
   int allow_copies = 0;   /* --allow-device-copies: distinct GPUs whose RCCL does not come up exchange with peer copies instead of failing */
   int kmerocrs = 1, kmerqlty = 0; /* command_dist_wrapper.c:79-80 */
   const char *refpath = NULL, *skf = NULL;
@@ -1742,6 +1765,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "-Q") && i + 1 < argc) kmerqlty = atoi(argv[++i]); /* :182-185 */
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--devices") && i + 1 < argc) ndev = parse_devices(argv[++i], devs, 64);
+    else if (!strcmp(argv[i], "--engines") && i + 1 < argc) engines_per_gpu = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--allow-device-copies")) allow_copies = 1;
     else if (!strcmp(argv[i], "--host-fasta")) g_host_fasta = 1; /* FASTA windows made on the host (mk_fasta_window), not on the device */
     else if (!strcmp(argv[i], "--quiet")) quiet = 1;
@@ -1812,6 +1836,15 @@ int main(int argc, char **argv) {
   const double t_shuf = now_s() - t0;
 
   engine_params(&fut, &P);
+  /* a second engine on the same GPU for directories of many files (see the file loop); created beside the first.  Not for the
+   * 2^26-slot geometries unless asked: their tables take 21 GB and a tenth of a second to set up */
+  const int two_engines = !shard_files && ndev <= 1 && files.n >= 8 && (engines_per_gpu == 2 || (engines_per_gpu == 0 && P.hashsize < (1u << 26)));
+  second_engine_t second_engine;
+  memset(&second_engine, 0, sizeof second_engine);
+  if (two_engines) {
+    second_engine.P = &P; second_engine.device = ndev ? devs[0] : device;
+    if (pthread_create(&second_engine.th, NULL, second_engine_run, &second_engine) != 0) die("cannot start a thread: %s", strerror(errno));
+  }
   ctx_t c;
   memset(&c, 0, sizeof c);
   c.fut = &fut;
@@ -1899,6 +1932,35 @@ int main(int argc, char **argv) {
       if (!quiet) printf("%d/%d decomposing %s\r", i + 1, files.n, files.v[i]);
     }
     for (int j = 0; j < ndev; j++) { pthread_join(drv[j].th, NULL); t_finish += drv[j].t_finish; c.nrows_total += drv[j].c.nrows_total; }
+  } else if (two_engines) {
+    /* many files on one GPU: two engines take the files in turn and ONE thread drives both -- file i is begun and pushed on one
+     * engine (copy and kernels queued on its stream), then file i-1 is finished on the other: while the host waits there and
+     * writes the result, the GPU already works on file i.  (With a single engine the GPU idles through every host round trip:
+     * 160 us of kernels and 75 us of copy per 4 Mbase genome against 420 us per genome in steady state.) */
+    ctx_t cx[2];
+    cx[0] = c;
+    cx[1] = c;
+    (void)engine_get(&cx[0]);
+    pthread_join(second_engine.th, NULL);
+    if (!second_engine.eng) die("mk_engine_create (second engine) failed: %s", second_engine.err);
+    cx[1].eng = second_engine.eng; cx[1].engs[0] = second_engine.eng; cx[1].ndev = 1; cx[1].multi = NULL;
+    cx[1].io = NULL; cx[1].rows = NULL; cx[1].arena = NULL; cx[1].arena_bytes = 0; /* its own buffers for files that stream */
+    int held[2] = {-1, -1};
+    for (int i = 0; i <= files.n; i++) {
+      if (i < files.n) sketch_file_push(&cx[i & 1], &jo, i, &held[i & 1]);
+      if (i > 0) {
+        const int j = i - 1;
+        mk_result res;
+        sketch_file_finish(&cx[j & 1], &jo, j, held[j & 1], &res, &t_finish);
+        held[j & 1] = -1;
+        rc = mk_sketchdir_add(sd, files.v[j], &res);
+        if (rc != MK_OK) die("writing sketch for %s failed (%d)", files.v[j], rc);
+        mk_result_release(cx[j & 1].eng, &res);
+        if (!quiet) printf("%d/%d decomposing %s\r", j + 1, files.n, files.v[j]);
+      }
+    }
+    c.nrows_total = cx[0].nrows_total + cx[1].nrows_total - c.nrows_total;
+    c.eng = cx[0].eng;
   } else {
     for (int i = 0; i < files.n; i++) {
       mk_result res;

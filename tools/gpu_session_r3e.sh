@@ -23,14 +23,14 @@ for i in range(512):
 capi.Shuf.generate(10, 6, 3, 10).write(d + "/L3K10.shuf")
 capi.Shuf.generate(11, 5, 2, 211).write(d + "/L2K11.shuf")
 PY
-# engines per GPU: the same 128 genomes with 1, 2, 4 engines on GPU 0 (file-sharded --devices), wall seconds
+# engines taking the files in turn on GPU 0 (one driving thread), and the file-sharded drivers: 512 genomes, wall seconds
 for S in L3K10 L2K11; do
-  for D in 0 0,0; do
-    for rep in 1 2; do
+  for V in "--engines 1" "--engines 2" "--devices 0,0"; do
+    for rep in 1 2 3; do
       s=$(date +%s.%N)
-      $GRAFT_REPO_ROOT/metakssd_amd/bin/metakssd dist -L /dev/shm/mkprof5/$S.shuf -p 16 --devices $D -o /dev/shm/mkprof5/o_${S}_${rep} --quiet /dev/shm/mkprof5/genomes > /dev/null 2>&1
+      $GRAFT_REPO_ROOT/metakssd_amd/bin/metakssd dist -L /dev/shm/mkprof5/$S.shuf -p 16 $V -o /dev/shm/mkprof5/o_${S}_${rep} --quiet /dev/shm/mkprof5/genomes > /dev/null 2>&1
       e=$(date +%s.%N)
-      echo "engines[$D] $S rep $rep: $(python3 -c "print(round($e-$s,3), 's ->', round(512/($e-$s)), 'genomes/s')")" | tee -a $GRAFT_REPO_ROOT/gpurun_out/r3e_engines.txt
+      echo "[$V] $S rep $rep: $(python3 -c "print(round($e-$s,3), 's ->', round(512/($e-$s)), 'genomes/s')")" | tee -a $GRAFT_REPO_ROOT/gpurun_out/r3e_engines.txt
       rm -rf /dev/shm/mkprof5/o_${S}_${rep}
     done
   done
