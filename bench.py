@@ -183,7 +183,7 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=4):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def leg_config5(capi, genomes=1024, mbases=4.0, threads=16, reps=3, ref_genomes=48):
+def leg_config5(capi, genomes=1024, mbases=4.0, threads=16, reps=3, ref_genomes=48, extra_flags=(), only=None):
     """BASELINE config 5: `metakssd dist -L <shuf> -o out <genome directory>` (no -A) on synthetic multi-FASTA genomes in
     /dev/shm, L3K10 and L2K11, whole command line by the parent's clock; the compiled reference on a few of the genomes"""
     import numpy as np
@@ -223,6 +223,8 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=16, reps=3, ref_genomes=
                        "lines, in /dev/shm>`: seconds = the parent's clock around the whole process, median of %d runs after one "
                        "warm-up run; the FASTA text is parsed on the device (mk_sketch_push_stream)" % (threads, genomes, bases_each / 1e6, reps)}
         for name, (k, sk, l, seed) in (("L3K10", (10, 6, 3, 10)), ("L2K11", (11, 5, 2, 211))):
+            if only and name != only:
+                continue
             sp = os.path.join(tmp, name + ".shuf")
             capi.Shuf.generate(k, sk, l, seed).write(sp)
             walls, fin = [], None
@@ -230,7 +232,7 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=16, reps=3, ref_genomes=
                 od = os.path.join(tmp, "out_%s_%d" % (name, rep))
                 time.sleep(0.5)
                 m0 = time.monotonic()
-                r = subprocess.run([cli, "dist", "-L", sp, "-p", str(threads), "-o", od, "--quiet", "--timing", gd],
+                r = subprocess.run([cli, "dist", "-L", sp, "-p", str(threads)] + list(extra_flags) + ["-o", od, "--quiet", "--timing", gd],
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                 m1 = time.monotonic()
                 if r.returncode != 0:
