@@ -1743,7 +1743,7 @@ int main(int argc, char **argv) {
   uint64_t chunk_bytes = (uint64_t)32 << 20; /* text per framing job = about 17 MiB of rows per host-to-device copy */
   int drop_pages = 1, inflight = 3, slow_exit = 0, direct_host = 0;
   int devs[64], ndev = 0; /* --devices 0-7 / 0,2,5 / 0,0 (the same GPU twice: two engines, for tests) */
-  int engines_per_gpu = 0; /* --engines 1|2: engines taking the files of a directory in turn on one GPU (0: two for tables below 2^26 slots) */
+  int engines_per_gpu = 0; /* --engines 1|2: engines taking the files of a directory in turn on one GPU (default: two from eight files on) */
   int allow_copies = 0;   /* --allow-device-copies: distinct GPUs whose RCCL does not come up exchange with peer copies instead of failing */
   int kmerocrs = 1, kmerqlty = 0; /* command_dist_wrapper.c:79-80 */
   const char *refpath = NULL, *skf = NULL;
@@ -1836,9 +1836,10 @@ int main(int argc, char **argv) {
   const double t_shuf = now_s() - t0;
 
   engine_params(&fut, &P);
-  /* a second engine on the same GPU for directories of many files (see the file loop); created beside the first.  Not for the
-   * 2^26-slot geometries unless asked: their tables take 21 GB and a tenth of a second to set up */
-  const int two_engines = !shard_files && ndev <= 1 && files.n >= 8 && (engines_per_gpu == 2 || (engines_per_gpu == 0 && P.hashsize < (1u << 26)));
+  /* a second engine on the same GPU for directories of many files (see the file loop), created beside the first.  Pays for the
+   * 21 GB geometries as well (1024 genomes at L2K11: 1 771 genomes/s against 1 537, tools/bench_config5_variants.py);
+   * --engines 1 turns it off */
+  const int two_engines = !shard_files && ndev <= 1 && files.n >= 8 && engines_per_gpu != 1;
   second_engine_t second_engine;
   memset(&second_engine, 0, sizeof second_engine);
   if (two_engines) {
