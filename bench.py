@@ -551,7 +551,9 @@ def main():
                          "measured_copy_gb_s": copy_gbs},
             "phases_ms_per_step": {"clear": prof["clear_ms"] / args.steps, "scan": prof["scan_ms"] / args.steps,
                                    "resolve": prof["resolve_ms"] / args.steps,
-                                   "finish": prof["finish_ms"] / args.steps},
+                                   "finish": prof["finish_ms"] / args.steps,
+                                   # layout + dump + copy of pass i on the side stream, beside clear + scan of pass i + 1
+                                   "finish_side_stream": prof.get("finish_side_ms", 0.0) / args.steps},
         }
         if world > 1 and tail["steps"]:
             line["rank0_tail_ms"] = tail["t"] / tail["steps"] * 1e3

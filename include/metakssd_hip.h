@@ -126,9 +126,11 @@ typedef struct mk_profile {
   uint64_t scan_launches;
   double resolve_ms;     /* candidate resolution launches (canonical k-mer, exact .shuf check, upsert) */
   double clear_ms;       /* table clear in mk_sketch_begin */
-  double finish_ms;      /* compaction + priority layout + ordered dump (device part of finish) */
+  double finish_ms;      /* compaction + priority layout + ordered dump (device part of finish); for mk_sketch_finish_begin: the
+                          * part on the engine's stream (compaction) */
   uint64_t bases_scanned; /* sum of nreads*stride handed to scan launches (row bytes, not bases) */
   uint64_t rows_scanned;
+  double finish_side_ms; /* mk_sketch_finish_begin: layout + dump + copy to the host on the side stream, beside the next sketch */
 } mk_profile;
 
 int mk_device_count(int *n);
@@ -195,9 +197,12 @@ int mk_sketch_push_stream(mk_engine *e, const uint8_t *text, uint64_t n, int fin
 int mk_sketch_finish(mk_engine *e, mk_result *out);
 /* mk_sketch_finish in two halves, for callers that sketch one input after another: _begin runs compaction, layout and dump (into
  * staging arrays in HBM), waits once for the counters and queues the copy of the result to the host on a stream of its own;
- * when it returns the sketch is over and the NEXT one may be begun and pushed -- its kernels run beside that copy.  _end waits
- * for the copy and hands out the result.  One result may be outstanding: _end comes before the next mk_sketch_finish /
- * mk_sketch_finish_begin on the engine.  Errors of the sketch (MK_ERR_CROWDED, MK_ERR_FORMAT) are returned by _begin. */
+ * when it returns the sketch is over and the NEXT one may be begun and pushed -- its kernels run beside that copy.  With dense
+ * bookkeeping (tables below 2^26 slots) _begin keeps only the compaction on the engine's stream: priority layout, dump and copy are
+ * queued on the side stream, so a pass over resident reads costs clear + scan + resolve + compaction.  _end waits for the side
+ * stream and hands out the result.  One result may be outstanding: _end comes before the next mk_sketch_finish /
+ * mk_sketch_finish_begin / mk_partial_* on the engine.  Errors of the sketch (MK_ERR_CROWDED, MK_ERR_FORMAT) are returned by
+ * _begin. */
 int mk_sketch_finish_begin(mk_engine *e);
 int mk_sketch_finish_end(mk_engine *e, mk_result *out);
 int mk_result_release(mk_engine *e, mk_result *r);

@@ -54,7 +54,7 @@ class ResultC(C.Structure):
 
 class ProfileC(C.Structure):
     _fields_ = [("scan_ms", C.c_double), ("scan_launches", C.c_uint64), ("resolve_ms", C.c_double), ("clear_ms", C.c_double),
-                ("finish_ms", C.c_double), ("bases_scanned", C.c_uint64), ("rows_scanned", C.c_uint64)]
+                ("finish_ms", C.c_double), ("bases_scanned", C.c_uint64), ("rows_scanned", C.c_uint64), ("finish_side_ms", C.c_double)]
 
 
 class FastaStateC(C.Structure):

@@ -97,8 +97,12 @@ struct mk_engine {
   uint64_t res_cap = 0;
   hipStream_t res_stream = nullptr;
   hipEvent_t ev_res = nullptr;
-  bool res_pending = false;
+  bool res_koc = false;
+  uint64_t res_D = 0;
+  bool res_pending = false, res_side = false; /* res_side: layout and dump of the outstanding result run on res_stream */
   uint64_t res_total = 0;
+  unsigned long long *d_snap = nullptr, *h_snap = nullptr; /* key count and flags of the sketch being finished on the side stream */
+  std::vector<mk_evpair> ev_finish_side;
   /* key-list-driven dump (sparse bookkeeping): scratch sized to the number of keys, device-side result staging */
   void *d_kl = nullptr;          /* skey[cap] | tkey[cap] | tidx[cap] | out_ids[cap] | out_cnt[cap] */
   uint64_t kl_cap = 0;
@@ -275,7 +279,8 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters);
   hipFree(e->d_kl); hipFree(e->d_kl_buckets);
-  hipFree(e->d_res_ids); hipFree(e->d_res_cnt);
+  hipFree(e->d_res_ids); hipFree(e->d_res_cnt); hipFree(e->d_snap);
+  if (e->h_snap) hipHostFree(e->h_snap);
   if (e->res_stream) hipStreamDestroy(e->res_stream);
   if (e->ev_res) hipEventDestroy(e->ev_res);
   hipFree(e->d_text); hipFree(e->d_stream); hipFree(e->d_stream_tmp); hipFree(e->d_fa_sum); hipFree(e->d_fa_state);
@@ -290,7 +295,7 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
     if (e->ev_copied[i]) hipEventDestroy(e->ev_copied[i]);
     if (e->ev_scanned[i]) hipEventDestroy(e->ev_scanned[i]);
   }
-  for (auto *v : {&e->ev_scan, &e->ev_resolve, &e->ev_clear, &e->ev_finish, &e->ev_pool})
+  for (auto *v : {&e->ev_scan, &e->ev_resolve, &e->ev_clear, &e->ev_finish, &e->ev_finish_side, &e->ev_pool})
     for (auto &p : *v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   if (e->own_stream) hipStreamDestroy(e->own_stream);
   delete e;
@@ -575,7 +580,8 @@ extern "C" int mk_profile_reset(mk_engine *e) {
   if (!e) return MK_ERR_ARG;
   MK_HIP(e, hipSetDevice(e->device));
   MK_HIP(e, hipStreamSynchronize(e->stream));
-  for (auto *v : {&e->ev_scan, &e->ev_resolve, &e->ev_clear, &e->ev_finish}) {
+  if (e->res_stream) MK_HIP(e, hipStreamSynchronize(e->res_stream));
+  for (auto *v : {&e->ev_scan, &e->ev_resolve, &e->ev_clear, &e->ev_finish, &e->ev_finish_side}) {
     for (auto &p : *v) e->ev_pool.push_back(p);
     v->clear();
   }
@@ -587,6 +593,7 @@ extern "C" int mk_profile_get(mk_engine *e, mk_profile *out) {
   if (!e || !out) return MK_ERR_ARG;
   MK_HIP(e, hipSetDevice(e->device));
   MK_HIP(e, hipStreamSynchronize(e->stream));
+  if (e->res_stream) MK_HIP(e, hipStreamSynchronize(e->res_stream));
   memset(out, 0, sizeof *out);
   auto sum = [&](std::vector<mk_evpair> &v) {
     double s = 0;
@@ -598,6 +605,7 @@ extern "C" int mk_profile_get(mk_engine *e, mk_profile *out) {
   out->resolve_ms = sum(e->ev_resolve);
   out->clear_ms = sum(e->ev_clear);
   out->finish_ms = sum(e->ev_finish);
+  out->finish_side_ms = sum(e->ev_finish_side);
   out->rows_scanned = e->prof_rows;
   out->bases_scanned = e->prof_bytes;
   return MK_OK;
@@ -1061,6 +1069,8 @@ extern "C" int mk_sketch_push_stream(mk_engine *e, const uint8_t *text, uint64_t
 /* ---- compaction / partials --------------------------------------------------------------------------- */
 /* table -> distinct-key list on the device; the number of keys lands in d_counters[0].  No host synchronisation. */
 static int mk_compact_launch(mk_engine *e) {
+  if (e->res_pending) /* the key list of the previous sketch is still being laid out and dumped on the side stream */
+    return mk_fail(e, MK_ERR_STATE, "the result of mk_sketch_finish_begin has not been taken yet (mk_sketch_finish_end)");
   { int rc = mk_flush_region(e); if (rc) return rc; } /* rows copied but not scanned yet */
   MK_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(unsigned long long), e->stream));
   /* co[n]=0 stays "empty" in the FASTA set flavours (iseq2comem.c:300-302); the FASTQ slot words carry a count
@@ -1230,8 +1240,10 @@ static int mk_result_capacity(mk_engine *e, uint64_t want) {
 
 /* the ordered dump of the layout table into the (host-mapped) result arrays; with count_pass == false only the write
  * kernel runs again (after the result arrays have grown; the chunk offsets of the first pass are still valid) */
-static int mk_launch_dump(mk_engine *e, bool count_pass, uint32_t *out_ids = nullptr, uint16_t *out_cnt = nullptr, uint64_t out_cap = 0) {
+static int mk_launch_dump(mk_engine *e, bool count_pass, uint32_t *out_ids = nullptr, uint16_t *out_cnt = nullptr, uint64_t out_cap = 0,
+                          hipStream_t st = nullptr, bool unset = false) {
   if (!out_ids) { out_ids = e->h_ids; out_cnt = e->h_cnt; out_cap = e->h_cap; } /* straight into the pinned host arrays */
+  if (!st) st = e->stream;
   const int C = e->P.component_num;
   const bool koc = e->mode == MK_MODE_KOC;
   mk_dump_args da{};
@@ -1242,22 +1254,23 @@ static int mk_launch_dump(mk_engine *e, bool count_pass, uint32_t *out_ids = nul
   da.cnt_hi = e->mode == MK_MODE_UNIQ_SET ? 1u : 0xffffffffu;  /* uniq_fasta2co(): repeated keys dropped */
   da.nchunks = e->nchunks;
   da.out_cap = out_cap;
+  da.unset = unset ? e->d_slot : nullptr;
   const unsigned dblocks = (e->nchunks + 3) / 4; /* 4 waves (chunks) per 256-thread block */
   if (C == 1) {
     da.comp = 0;
     if (count_pass) {
-      hipLaunchKernelGGL(mk_dump_count_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, e->d_chunk);
-      hipLaunchKernelGGL(mk_dump_scan_kernel, dim3(1), dim3(1024), 0, e->stream, e->d_chunk, e->nchunks, e->d_comp_totals);
+      hipLaunchKernelGGL(mk_dump_count_kernel, dim3(dblocks), dim3(256), 0, st, da, e->d_chunk);
+      hipLaunchKernelGGL(mk_dump_scan_kernel, dim3(1), dim3(1024), 0, st, e->d_chunk, e->nchunks, e->d_comp_totals);
     }
-    hipLaunchKernelGGL(mk_dump_write_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, (const uint32_t *)e->d_chunk,
+    hipLaunchKernelGGL(mk_dump_write_kernel, dim3(dblocks), dim3(256), 0, st, da, (const uint32_t *)e->d_chunk,
                        (const unsigned long long *)e->d_comp_totals, out_ids, koc ? out_cnt : nullptr);
   } else {
     /* all components in one count pass and one write pass; components back to back in the output */
     if (count_pass) {
-      hipLaunchKernelGGL(mk_dumpc_count_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, e->d_chunk);
-      hipLaunchKernelGGL(mk_dumpc_scan_kernel, dim3((unsigned)C), dim3(1024), 0, e->stream, e->d_chunk, e->nchunks, e->d_comp_totals);
+      hipLaunchKernelGGL(mk_dumpc_count_kernel, dim3(dblocks), dim3(256), 0, st, da, e->d_chunk);
+      hipLaunchKernelGGL(mk_dumpc_scan_kernel, dim3((unsigned)C), dim3(1024), 0, st, e->d_chunk, e->nchunks, e->d_comp_totals);
     }
-    hipLaunchKernelGGL(mk_dumpc_write_kernel, dim3(dblocks), dim3(256), 0, e->stream, da, (const uint32_t *)e->d_chunk,
+    hipLaunchKernelGGL(mk_dumpc_write_kernel, dim3(dblocks), dim3(256), 0, st, da, (const uint32_t *)e->d_chunk,
                        (const unsigned long long *)e->d_comp_totals, out_ids, koc ? out_cnt : nullptr);
   }
   MK_HIP(e, hipGetLastError());
@@ -1369,6 +1382,8 @@ static int mk_res_reserve(mk_engine *e, uint64_t want) {
   if (!e->res_stream) {
     MK_HIP(e, hipStreamCreateWithFlags(&e->res_stream, hipStreamNonBlocking));
     MK_HIP(e, hipEventCreateWithFlags(&e->ev_res, hipEventDisableTiming));
+    MK_HIP(e, hipMalloc(&e->d_snap, 8 * sizeof(unsigned long long)));
+    MK_HIP(e, hipHostMalloc((void **)&e->h_snap, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   }
   if (want <= e->res_cap && e->d_res_ids) return MK_OK;
   hipFree(e->d_res_ids); hipFree(e->d_res_cnt);
@@ -1405,6 +1420,22 @@ extern "C" int mk_sketch_finish_end(mk_engine *e, mk_result *out) {
   MK_HIP(e, hipSetDevice(e->device));
   MK_HIP(e, hipEventSynchronize(e->ev_res));
   e->res_pending = false;
+  if (e->res_side) { /* layout and dump ran on the side stream: their flags and sizes have come back with the result */
+    e->res_side = false;
+    const int C = e->P.component_num;
+    const bool koc = e->res_koc;
+    if ((uint32_t)(e->h_snap[2] & 0xffffffffu) & 2u) { e->slot_clean = false; return mk_fail(e, MK_ERR_HIP, "layout kernel did not converge"); }
+    uint64_t total = 0, at = 0;
+    for (int c = 0; c < C; c++) total += e->h_comp_totals[c];
+    if (total > e->res_D) return mk_fail(e, MK_ERR_HIP, "dump produced more entries than distinct keys");
+    for (int c = 0; c < C; c++) {
+      e->comps[c].n = e->h_comp_totals[c];
+      e->comps[c].ids = e->h_ids + at;
+      e->comps[c].counts = koc ? e->h_cnt + at : nullptr;
+      at += e->h_comp_totals[c];
+    }
+    e->res_total = total;
+  }
   out->component_num = e->P.component_num;
   out->total = e->res_total;
   out->components = e->comps.data();
@@ -1439,15 +1470,74 @@ static int mk_finish_impl(mk_engine *e, mk_result *out, bool staged) {
     return rc;
   }
   if (staged) {
-    rc = mk_res_reserve(e, e->res_cap > e->h_cap ? e->res_cap : e->h_cap);
+    /* Two halves, the second on a stream of its own.  On the engine's stream only the compaction and one small copy: the
+     * wait brings the key count and the sketch's flags (a crowded table ends here).  Layout, dump and the copy to the host
+     * touch nothing but the key list, the layout table and the staging arrays, so they are queued on the side stream and the
+     * caller's next mk_sketch_begin / pushes run beside them; the count and flags they need are a snapshot (the next begin
+     * clears the counters). */
+    rc = mk_res_reserve(e, e->res_cap ? e->res_cap : e->h_cap);
     if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
+    hipStream_t rs = e->res_stream;
+    MK_HIP(e, hipMemcpyAsync(e->d_snap, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, e->stream));
+    MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    if (e->profiling) MK_HIP(e, hipEventRecord(ev.b, e->stream));
+    MK_HIP(e, hipEventRecord(e->ev_res, e->stream));
+    /* the side stream's kernels take the key count from the snapshot: queued now, behind the compaction, while the host still
+     * waits for the engine's stream */
+    MK_HIP(e, hipStreamWaitEvent(rs, e->ev_res, 0));
+    mk_evpair ev2{};
+    if (e->profiling) { ev2 = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev2.a, rs)); }
+    if (!e->slot_clean) MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), rs));
+    hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)e->num_cu * 16u), dim3(256), 0, rs, e->dist, (const unsigned long long *)e->d_snap,
+                       (unsigned long long)mk_key_limit(e), e->d_slot, S, (uint32_t *)(e->d_snap + 2), (uint32_t *)nullptr, (uint32_t)MK_DUMP_SHIFT);
+    MK_HIP(e, hipGetLastError());
+    rc = mk_launch_dump(e, true, e->d_res_ids, e->d_res_cnt, e->res_cap, rs, true);
+    if (rc) return rc;
+    e->slot_clean = true; /* the write pass hands every slot back (a dump that held back, below, fills the table anew) */
+    MK_HIP(e, hipStreamSynchronize(e->stream));
+    rc = mk_check_counters(e);
+    if (rc) { /* crowded: the layout kernel did nothing, the dump wrote nothing */
+      e->begun = false;
+      MK_HIP(e, hipStreamSynchronize(rs));
+      if (e->profiling) { e->ev_pool.push_back(ev); e->ev_pool.push_back(ev2); }
+      return rc;
+    }
+    if (e->profiling) e->ev_finish.push_back(ev);
+    const uint64_t D = e->D;
+    rc = mk_result_capacity(e, D ? D : 1);
+    if (rc) return rc;
+    if (D > e->res_cap) { /* the write pass held back (more keys than the staging arrays hold): larger arrays, layout and dump again */
+      MK_HIP(e, hipStreamSynchronize(rs));
+      rc = mk_res_reserve(e, D + D / 8 + 1024);
+      if (rc) return rc;
+      MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), rs));
+      hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)e->num_cu * 16u), dim3(256), 0, rs, e->dist, (const unsigned long long *)e->d_snap,
+                         (unsigned long long)mk_key_limit(e), e->d_slot, S, (uint32_t *)(e->d_snap + 2), (uint32_t *)nullptr, (uint32_t)MK_DUMP_SHIFT);
+      MK_HIP(e, hipGetLastError());
+      rc = mk_launch_dump(e, true, e->d_res_ids, e->d_res_cnt, e->res_cap, rs, true);
+      if (rc) return rc;
+    }
+    if (D) { /* at most D entries come out (all of them with -A): the staging prefix in one copy each */
+      MK_HIP(e, hipMemcpyAsync(e->h_ids, e->d_res_ids, D * 4, hipMemcpyDeviceToHost, rs));
+      if (koc) MK_HIP(e, hipMemcpyAsync(e->h_cnt, e->d_res_cnt, D * 2, hipMemcpyDeviceToHost, rs));
+    }
+    MK_HIP(e, hipMemcpyAsync(e->h_comp_totals, e->d_comp_totals, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, rs));
+    MK_HIP(e, hipMemcpyAsync(e->h_snap, e->d_snap, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, rs));
+    if (e->profiling) { MK_HIP(e, hipEventRecord(ev2.b, rs)); e->ev_finish_side.push_back(ev2); }
+    MK_HIP(e, hipEventRecord(e->ev_res, rs));
+    e->res_pending = true; e->res_side = true;
+    e->res_koc = koc; e->res_D = D; /* (the next begin resets mode and key count before this result is taken) */
+    e->compacted = false; /* the key list belongs to the side stream until mk_sketch_finish_end */
+    e->begun = false;
+    return MK_OK;
   }
   MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), e->stream));
+  e->slot_clean = false; /* (the plain finish leaves the layout in the table: its write pass may have to run again) */
   hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)e->num_cu * 16u), dim3(256), 0, e->stream, e->dist,
                      (const unsigned long long *)e->d_counters, (unsigned long long)mk_key_limit(e), e->d_slot, S, e->tab.err,
                      e->sparse ? e->d_dirty_slot : nullptr, (uint32_t)MK_DUMP_SHIFT);
   MK_HIP(e, hipGetLastError());
-  rc = staged ? mk_launch_dump(e, true, e->d_res_ids, e->d_res_cnt, e->res_cap) : mk_launch_dump(e, true);
+  rc = mk_launch_dump(e, true);
   if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
   MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
   MK_HIP(e, hipMemcpyAsync(e->h_comp_totals, e->d_comp_totals, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
@@ -1463,24 +1553,14 @@ static int mk_finish_impl(mk_engine *e, mk_result *out, bool staged) {
   uint64_t total = 0;
   for (int c = 0; c < C; c++) total += e->h_comp_totals[c];
   if (total > e->D) { if (e->profiling) e->ev_pool.push_back(ev); return mk_fail(e, MK_ERR_HIP, "dump produced more entries than distinct keys"); }
-  if (total > (staged ? (e->res_cap < e->h_cap ? e->res_cap : e->h_cap) : e->h_cap)) { /* the write kernel held back: grow the result arrays and run it again */
+  if (total > e->h_cap) { /* the write kernel held back: grow the result arrays and run it again */
     rc = mk_result_capacity(e, total);
-    if (rc == MK_OK && staged) rc = mk_res_reserve(e, e->h_cap);
-    if (rc == MK_OK) rc = staged ? mk_launch_dump(e, false, e->d_res_ids, e->d_res_cnt, e->res_cap) : mk_launch_dump(e, false);
+    if (rc == MK_OK) rc = mk_launch_dump(e, false);
     if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
     if (e->profiling) MK_HIP(e, hipEventRecord(ev.b, e->stream));
     MK_HIP(e, hipStreamSynchronize(e->stream));
   }
   if (e->profiling) e->ev_finish.push_back(ev);
-  if (staged) { /* everything the copy reads is final (the stream has been waited for): queue it beside whatever comes next */
-    if (total) {
-      MK_HIP(e, hipMemcpyAsync(e->h_ids, e->d_res_ids, total * 4, hipMemcpyDeviceToHost, e->res_stream));
-      if (koc) MK_HIP(e, hipMemcpyAsync(e->h_cnt, e->d_res_cnt, total * 2, hipMemcpyDeviceToHost, e->res_stream));
-    }
-    MK_HIP(e, hipEventRecord(e->ev_res, e->res_stream));
-    e->res_pending = true;
-    e->res_total = total;
-  }
   uint64_t at = 0;
   for (int c = 0; c < C; c++) {
     e->comps[c].n = e->h_comp_totals[c];

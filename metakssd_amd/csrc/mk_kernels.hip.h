@@ -1288,6 +1288,8 @@ struct mk_dump_args {
   const uint32_t *dirty_slot; /* sparse bookkeeping: one bit per MK_DUMP_CHUNK slots of the layout table, NULL = all chunks */
   uint32_t nchunks;
   uint64_t out_cap; /* entries the output arrays hold: the write kernels do nothing when the dump is larger (host grows, reruns) */
+  uint32_t *unset;  /* not NULL (== slot): every occupied slot is handed back EMPTY as it is written out, so that the layout table
+                     * is all-empty again behind the dump and the next sketch needs no fill (only where no rerun can be needed) */
 };
 
 __device__ __forceinline__ bool mk_dump_pred(const mk_dump_args &a, uint64_t n, uint32_t &idx) {
@@ -1366,6 +1368,7 @@ __global__ void __launch_bounds__(256) mk_dump_write_kernel(mk_dump_args a, cons
       out_ids[o] = (uint32_t)(a.d.key[idx] >> a.comp_code_bits);
       if (out_cnt) out_cnt[o] = (uint16_t)a.d.cnt[idx];
     }
+    if (a.unset && idx != MK_EMPTY32) a.unset[(uint64_t)chunk * MK_DUMP_CHUNK + it * 64u + lane] = MK_EMPTY32; /* (also keys the predicate drops) */
     off += (uint32_t)__popcll(m);
   }
 }
@@ -1476,6 +1479,7 @@ __global__ void __launch_bounds__(256) mk_dumpc_write_kernel(mk_dump_args a, con
       mk_wave_lds_fence();
       rest &= ~m;
     }
+    if (a.unset && idx != MK_EMPTY32) a.unset[(uint64_t)chunk * MK_DUMP_CHUNK + it * 64u + lane] = MK_EMPTY32;
   }
 }
 

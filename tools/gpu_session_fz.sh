@@ -3,7 +3,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 OUT=gpurun_out/fz_campaign.jsonl
-: > $OUT
+# every line carries the id of the kernel source it ran on (what bench.py reports as roofline.kernel_source_id)
+KID=$(python -c "import bench; print(bench.kernel_source_id())")
+echo "{\"kernel_source_id\": \"$KID\", \"what\": \"fuzz campaign over this build: engine vs oracle, command line vs the compiled reference, framers\"}" > $OUT
 for seed in 2001 2002 2003; do
   python tools/fuzz_parity.py --cases 3000 --seed $seed 2>&1 | tail -1 | python -c "import sys,json; print(json.dumps({'tool':'tools/fuzz_parity.py','seed':$seed,'result':sys.stdin.read().strip()}))" >> $OUT
 done
