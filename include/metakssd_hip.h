@@ -151,8 +151,10 @@ int mk_engine_destroy(mk_engine *e);
  *   MK_OPT_FRONT_BITS -1 / 0 / 3..28: a small accumulation table of 2^n slots in front of the hashsize-slot one, so that the
  *                   per-sketch passes (clear, compaction) cost what the sketch holds, not what the reference's table could
  *                   hold; -1 (default): about an eighth of hashsize, from 2^20 slots up (dense bookkeeping only), 0: none
+ *   MK_OPT_KEYLIST_CAP entries the distinct-key list holds now (sparse bookkeeping only: there the list starts at 32 M entries instead
+ *                   of hashsize -- 10.7 GB at L2K11 -- and the finish / export that counts more keys grows it and compacts again)
  * Results are bit-identical for every setting; the tests run both. */
-enum { MK_OPT_SPARSE = 1, MK_OPT_CAND_CAP = 2, MK_OPT_RESULT_CAP = 3, MK_OPT_DIRECT_HOST = 4, MK_OPT_FRONT_BITS = 5 };
+enum { MK_OPT_SPARSE = 1, MK_OPT_CAND_CAP = 2, MK_OPT_RESULT_CAP = 3, MK_OPT_DIRECT_HOST = 4, MK_OPT_FRONT_BITS = 5, MK_OPT_KEYLIST_CAP = 6 };
 int mk_engine_set_option(mk_engine *e, int option, int64_t value);
 int mk_engine_set_stream(mk_engine *e, void *hip_stream);
 int mk_engine_use_own_stream(mk_engine *e);

@@ -1718,10 +1718,11 @@ static void *shard_driver_run(void *arg) {
   }
 }
 
-typedef struct { pthread_t th; const mk_params *P; int device; mk_engine *eng; char err[512]; } second_engine_t;
+typedef struct { pthread_t th; const mk_params *P; int device; mk_engine *eng; int ready; char err[512]; } second_engine_t;
 static void *second_engine_run(void *arg) {
   second_engine_t *s = arg;
   if (mk_engine_create(s->P, s->device, &s->eng) != MK_OK) { s->eng = NULL; snprintf(s->err, sizeof s->err, "%s", mk_last_error(NULL)); }
+  __atomic_store_n(&s->ready, 1, __ATOMIC_RELEASE);
   return NULL;
 }
 
@@ -1940,16 +1941,30 @@ int main(int argc, char **argv) {
      * 160 us of kernels and 75 us of copy per 4 Mbase genome against 420 us per genome in steady state.) */
     ctx_t cx[2];
     cx[0] = c;
-    cx[1] = c;
     (void)engine_get(&cx[0]);
-    pthread_join(second_engine.th, NULL);
-    if (!second_engine.eng) die("mk_engine_create (second engine) failed: %s", second_engine.err);
-    cx[1].eng = second_engine.eng; cx[1].engs[0] = second_engine.eng; cx[1].ndev = 1; cx[1].multi = NULL;
+    cx[1] = cx[0];
     cx[1].io = NULL; cx[1].rows = NULL; cx[1].arena = NULL; cx[1].arena_bytes = 0; /* its own buffers for files that stream */
+    /* until the second engine is there (its 21 GB of tables at L2K11 take anything from 0.04 to 1 s beside a working GPU) the
+     * first one takes the files alone */
+    int first = 0;
+    while (first < files.n && !__atomic_load_n(&second_engine.ready, __ATOMIC_ACQUIRE)) {
+      mk_result res;
+      sketch_one_file(&cx[0], &jo, first, &res, &t_finish);
+      rc = mk_sketchdir_add(sd, files.v[first], &res);
+      if (rc != MK_OK) die("writing sketch for %s failed (%d)", files.v[first], rc);
+      mk_result_release(cx[0].eng, &res);
+      if (!quiet) printf("%d/%d decomposing %s\r", first + 1, files.n, files.v[first]);
+      first++;
+    }
+    if (first < files.n) {
+      pthread_join(second_engine.th, NULL);
+      if (!second_engine.eng) die("mk_engine_create (second engine) failed: %s", second_engine.err);
+      cx[1].eng = second_engine.eng; cx[1].engs[0] = second_engine.eng; cx[1].ndev = 1; cx[1].multi = NULL;
+    }
     int held[2] = {-1, -1};
-    for (int i = 0; i <= files.n; i++) {
+    for (int i = first; i <= files.n && first < files.n; i++) {
       if (i < files.n) sketch_file_push(&cx[i & 1], &jo, i, &held[i & 1]);
-      if (i > 0) {
+      if (i > first) {
         const int j = i - 1;
         mk_result res;
         sketch_file_finish(&cx[j & 1], &jo, j, held[j & 1], &res, &t_finish);

@@ -380,6 +380,17 @@ static int mk_config_front(mk_engine *e, int bits) {
   return MK_OK;
 }
 
+static int mk_dist_reserve(mk_engine *e, uint64_t cap) {
+  if (cap <= e->dist.cap && e->dist.key) return MK_OK;
+  hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
+  e->dist.key = nullptr; e->dist.ord = nullptr; e->dist.cnt = nullptr; e->dist.cap = 0;
+  MK_HIP(e, hipMalloc(&e->dist.key, cap * 8));
+  MK_HIP(e, hipMalloc(&e->dist.ord, cap * 8));
+  MK_HIP(e, hipMalloc(&e->dist.cnt, cap * 4));
+  e->dist.cap = cap;
+  return MK_OK;
+}
+
 static int mk_engine_init(mk_engine *e, const mk_params *p) {
 #ifdef MK_TUNING
   double tick_ = mk_tick_now();
@@ -459,10 +470,10 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
    * mk_engine_set_option(MK_OPT_SPARSE) forces it off/on (the tests run the small tables both ways) */
   { int rc = mk_config_sparse(e, S >= (1ull << 26)); if (rc) return rc; }
   { int rc = mk_config_front(e, -1); if (rc) return rc; }
-  e->dist.cap = S; /* hashlimit+1 entries suffice for KOC/SET; MK_MODE_OCC_SET may fill the table (fastq2co never aborts) */
-  MK_HIP(e, hipMalloc(&e->dist.key, e->dist.cap * 8));
-  MK_HIP(e, hipMalloc(&e->dist.ord, e->dist.cap * 8));
-  MK_HIP(e, hipMalloc(&e->dist.cnt, e->dist.cap * 4));
+  /* the distinct-key list: hashlimit+1 entries suffice for KOC/SET, MK_MODE_OCC_SET may fill the table (fastq2co never aborts).
+   * With sparse bookkeeping (537 M slots at L2K11: 10.7 GB of list for sketches of a few thousand keys) it starts at 32 M
+   * entries and grows when a compaction counts more (mk_dist_fit) */
+  { int rc = mk_dist_reserve(e, e->sparse && S > (32ull << 20) ? (32ull << 20) : S); if (rc) return rc; }
   e->nchunks = (uint32_t)((S + MK_DUMP_CHUNK - 1) / MK_DUMP_CHUNK);
   if (p->component_num > (int)MK_MAX_COMP) return mk_fail(e, MK_ERR_ARG, "component_num %d > %u", p->component_num, MK_MAX_COMP);
   MK_HIP(e, hipMalloc(&e->d_chunk, (size_t)e->nchunks * (size_t)p->component_num * sizeof(uint32_t)));
@@ -516,6 +527,7 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
     case MK_OPT_SPARSE: {
       if (value < -1 || value > 1) return mk_fail(e, MK_ERR_ARG, "MK_OPT_SPARSE takes -1 (by table size), 0 or 1");
       int rc = mk_config_sparse(e, value < 0 ? e->P.hashsize >= (1u << 26) : value != 0);
+      if (rc == MK_OK && !e->sparse) rc = mk_dist_reserve(e, e->kp.S); /* the dense passes do not grow the key list */
       return rc ? rc : mk_config_front(e, e->front_bits_opt);
     }
     case MK_OPT_FRONT_BITS:
@@ -528,6 +540,13 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
     case MK_OPT_DIRECT_HOST:
       e->direct_host = value != 0;
       return MK_OK;
+    case MK_OPT_KEYLIST_CAP: { /* sparse bookkeeping only: the list is grown by the finish / export that needs more */
+      if (!e->sparse) return mk_fail(e, MK_ERR_ARG, "MK_OPT_KEYLIST_CAP needs sparse bookkeeping (the dense passes do not grow the key list)");
+      if (value < 16 || (uint64_t)value > e->kp.S) return mk_fail(e, MK_ERR_ARG, "MK_OPT_KEYLIST_CAP takes 16 .. hashsize entries");
+      hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
+      e->dist.key = nullptr; e->dist.ord = nullptr; e->dist.cnt = nullptr; e->dist.cap = 0;
+      return mk_dist_reserve(e, (uint64_t)value);
+    }
     case MK_OPT_RESULT_CAP: {
       if (value < 1 || value > (int64_t)e->P.hashsize) return mk_fail(e, MK_ERR_ARG, "MK_OPT_RESULT_CAP takes 1 .. hashsize entries");
       if (e->h_ids) hipHostFree(e->h_ids);
@@ -1086,7 +1105,7 @@ static int mk_compact_launch(mk_engine *e) {
       mk_table ft = e->tab;
       ft.kc = e->front.kc1; ft.ordinv = e->front.ordinv1;
       ft.dirty = nullptr;
-      hipLaunchKernelGGL(mk_compact_kernel<MK_COMPACT_CHUNK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, ft, (uint32_t)e->front_slots,
+      hipLaunchKernelGGL(mk_compact_kernel<MK_SPARSE_BLOCK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, ft, (uint32_t)e->front_slots,
                          e->dist, e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr, big_used, 0u);
       hipLaunchKernelGGL(mk_front_fold_kernel, dim3(blocks), dim3(1024), 0, e->stream, e->tab, e->kp.S);
     }
@@ -1100,8 +1119,13 @@ static int mk_compact_launch(mk_engine *e) {
       const uint32_t *big_used = e->front.state + 1;
       mk_table ft = e->tab;
       ft.kc = e->front.kc1; ft.ordinv = e->front.ordinv1;
-      hipLaunchKernelGGL(mk_compact_kernel<MK_COMPACT_CHUNK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, ft, (uint32_t)e->front_slots,
-                         e->dist, e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr, big_used, 0u);
+      /* (a front table of 2^18 slots is 128 chunks of 2048: 128 busy waves.  512-slot chunks give the small ones 512) */
+      if (e->front_slots <= (1ull << 20))
+        hipLaunchKernelGGL(mk_compact_kernel<MK_SPARSE_BLOCK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, ft, (uint32_t)e->front_slots,
+                           e->dist, e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr, big_used, 0u);
+      else
+        hipLaunchKernelGGL(mk_compact_kernel<MK_COMPACT_CHUNK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, ft, (uint32_t)e->front_slots,
+                           e->dist, e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr, big_used, 0u);
       hipLaunchKernelGGL(mk_front_fold_kernel, dim3(blocks), dim3(1024), 0, e->stream, e->tab, e->kp.S);
       hipLaunchKernelGGL(mk_compact_kernel<MK_COMPACT_CHUNK>, dim3(blocks), dim3(MK_COMPACT_THREADS), 0, e->stream, e->tab, e->kp.S, e->dist,
                          e->d_counters, drop0, (const uint32_t *)nullptr, (const uint32_t *)nullptr, big_used, 1u);
@@ -1134,6 +1158,22 @@ static int mk_check_counters(mk_engine *e) {
   return MK_OK;
 }
 
+/* the compaction has counted e->D keys (counters on the host): a key list that starts small (sparse bookkeeping) may hold fewer.
+ * Then: a larger list and the compaction once more -- the table is untouched by a compaction, the list is all it writes */
+static int mk_dist_fit(mk_engine *e) {
+  if (e->D <= e->dist.cap) return MK_OK;
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  uint64_t cap = e->D + e->D / 4 + 1024;
+  if (cap > e->kp.S) cap = e->kp.S;
+  int rc = mk_dist_reserve(e, cap);
+  if (rc) return rc;
+  rc = mk_compact_launch(e);
+  if (rc) return rc;
+  MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  return mk_check_counters(e);
+}
+
 /* compaction with the key count brought to the host (the multi-GPU export needs it there) */
 static int mk_compact(mk_engine *e) {
   if (e->compacted && !e->region_open) return MK_OK;
@@ -1142,6 +1182,7 @@ static int mk_compact(mk_engine *e) {
   MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
   MK_HIP(e, hipStreamSynchronize(e->stream));
   rc = mk_check_counters(e);
+  if (rc == MK_OK) rc = mk_dist_fit(e);
   if (rc) return rc;
   e->compacted = true;
   return MK_OK;
@@ -1170,6 +1211,7 @@ extern "C" int mk_partial_count(mk_engine *e, uint64_t *n) {
     e->count_queued = false;
     MK_HIP(e, hipStreamSynchronize(e->stream));
     rc = mk_check_counters(e);
+    if (rc == MK_OK) rc = mk_dist_fit(e);
     if (rc == MK_OK) e->compacted = true;
   } else {
     rc = mk_compact(e);
@@ -1288,6 +1330,7 @@ static int mk_finish_keylist(mk_engine *e, mk_result *out, mk_evpair ev) {
   MK_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
   MK_HIP(e, hipStreamSynchronize(e->stream));
   int rc = mk_check_counters(e);
+  if (rc == MK_OK) rc = mk_dist_fit(e);
   if (rc) { e->begun = false; return bail(rc); }
   e->compacted = true;
   const uint64_t D = e->D;

@@ -1292,8 +1292,12 @@ struct mk_dump_args {
                      * is all-empty again behind the dump and the next sketch needs no fill (only where no rerun can be needed) */
 };
 
+__device__ __forceinline__ bool mk_dump_pred_idx(const mk_dump_args &a, uint32_t idx);
 __device__ __forceinline__ bool mk_dump_pred(const mk_dump_args &a, uint64_t n, uint32_t &idx) {
   idx = n < a.S ? a.slot[n] : MK_EMPTY32;
+  return mk_dump_pred_idx(a, idx);
+}
+__device__ __forceinline__ bool mk_dump_pred_idx(const mk_dump_args &a, uint32_t idx) {
   if (idx == MK_EMPTY32) return false;
   if (a.comp_num > 1 && (uint32_t)(a.d.key[idx] % a.comp_num) != a.comp) return false;
   if (a.cnt_lo > 1u || a.cnt_hi != 0xffffffffu) {
@@ -1312,10 +1316,16 @@ __global__ void __launch_bounds__(256) mk_dump_count_kernel(mk_dump_args a, uint
     return;
   }
   uint32_t total = 0;
-  for (uint32_t it = 0; it < MK_DUMP_CHUNK / 64u; it++) {
-    uint32_t idx;
-    bool p = mk_dump_pred(a, (uint64_t)chunk * MK_DUMP_CHUNK + it * 64u + lane, idx);
-    total += (uint32_t)__popcll(__ballot(p));
+  /* eight slot words in flight: a wave that walks its chunk one dependent load at a time takes 20 us for 16 KiB */
+  for (uint32_t it0 = 0; it0 < MK_DUMP_CHUNK / 64u; it0 += 8u) {
+    uint32_t idx[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; u++) {
+      const uint64_t n = (uint64_t)chunk * MK_DUMP_CHUNK + (it0 + u) * 64u + lane;
+      idx[u] = n < a.S ? a.slot[n] : MK_EMPTY32;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; u++) total += (uint32_t)__popcll(__ballot(mk_dump_pred_idx(a, idx[u])));
   }
   if (lane == 0) chunk_count[chunk] = total;
 }
@@ -1359,17 +1369,26 @@ __global__ void __launch_bounds__(256) mk_dump_write_kernel(mk_dump_args a, cons
   if (totals[0] > a.out_cap) return;
   if (a.dirty_slot && !((a.dirty_slot[chunk >> 5] >> (chunk & 31u)) & 1u)) return;
   uint32_t off = chunk_off[chunk];
-  for (uint32_t it = 0; it < MK_DUMP_CHUNK / 64u; it++) {
-    uint32_t idx;
-    bool p = mk_dump_pred(a, (uint64_t)chunk * MK_DUMP_CHUNK + it * 64u + lane, idx);
-    const uint64_t m = __ballot(p);
-    if (p) {
-      const uint32_t o = off + mk_mbcnt(m);
-      out_ids[o] = (uint32_t)(a.d.key[idx] >> a.comp_code_bits);
-      if (out_cnt) out_cnt[o] = (uint16_t)a.d.cnt[idx];
+  for (uint32_t it0 = 0; it0 < MK_DUMP_CHUNK / 64u; it0 += 8u) {
+    uint32_t idxs[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; u++) {
+      const uint64_t n = (uint64_t)chunk * MK_DUMP_CHUNK + (it0 + u) * 64u + lane;
+      idxs[u] = n < a.S ? a.slot[n] : MK_EMPTY32;
     }
-    if (a.unset && idx != MK_EMPTY32) a.unset[(uint64_t)chunk * MK_DUMP_CHUNK + it * 64u + lane] = MK_EMPTY32; /* (also keys the predicate drops) */
-    off += (uint32_t)__popcll(m);
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; u++) {
+      const uint32_t idx = idxs[u];
+      const bool p = mk_dump_pred_idx(a, idx);
+      const uint64_t m = __ballot(p);
+      if (p) {
+        const uint32_t o = off + mk_mbcnt(m);
+        out_ids[o] = (uint32_t)(a.d.key[idx] >> a.comp_code_bits);
+        if (out_cnt) out_cnt[o] = (uint16_t)a.d.cnt[idx];
+      }
+      if (a.unset && idx != MK_EMPTY32) a.unset[(uint64_t)chunk * MK_DUMP_CHUNK + (it0 + u) * 64u + lane] = MK_EMPTY32; /* (also keys the predicate drops) */
+      off += (uint32_t)__popcll(m);
+    }
   }
 }
 

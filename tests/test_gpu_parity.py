@@ -4,6 +4,7 @@ Oracle = oracle/kssd_oracle.c, pinned against the compiled reference (oracle/che
 Cases follow SURVEY.md 8c: collision-order (dense tables), counts, saturation, key 0, lower case, N resets,
 ragged and empty rows, FASTA windows (set / uniq), 16 components, crowded abort, multi-push and shard merge.
 """
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -281,6 +282,51 @@ def test_finish_in_two_halves_pipelined(capi, shufs, oracle_for, name, sparse):
         assert_same(eng.finish(), wants[0], "%s plain finish afterwards" % name)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("front", [None, 0, 5])
+def test_sparse_key_list_grows_on_demand(capi, shufs, oracle_for, front):
+    """engines with sparse bookkeeping start with a short distinct-key list (32 M entries instead of hashsize: 10.7 GB at L2K11);
+    a finish or an export that counts more keys than it holds grows it and compacts again (MK_OPT_KEYLIST_CAP makes that
+    happen on a small table); with and without a front table, whole and merged from two shards"""
+    rs = np.random.RandomState(52)
+    name = "L1K7"
+    eng = capi.Engine(shufs(name), 0, sparse=1, front_bits=front)
+    other = capi.Engine(shufs(name), 0, sparse=1, front_bits=front)
+    ora = oracle_for(shufs(name))
+    hip = C.CDLL("libamdhip64.so")
+    bufs = []
+    try:
+        rows = ui.rows_from_seqs(ui.pool_reads(rs, 100000, 8000), 160)
+        rc, want = ora.koc_from_rows(rows, 160)
+        assert rc == 0 and len(want[0][0]) > 1000
+        for e in (eng, other):
+            e.set_option(capi.MK_OPT_KEYLIST_CAP, 64)
+        eng.begin(capi.MK_MODE_KOC)
+        eng.push_reads(rows, 160, 0)
+        assert_same(eng.finish(), want, "grown inside finish")
+        # the same through an export of the second half into the first (export grows the exporting engine's list)
+        half = (rows.size // 160) // 2
+        for e in (eng, other):
+            e.set_option(capi.MK_OPT_KEYLIST_CAP, 64)
+        eng.begin(capi.MK_MODE_KOC)
+        other.begin(capi.MK_MODE_KOC)
+        eng.push_reads(rows[: half * 160], 160, 0)
+        other.push_reads(rows[half * 160:], 160, half)
+        d = other.partial_count()
+        assert d > 64
+        for nbytes in (8 * d, 4 * d, 8 * d):
+            p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+            bufs.append(p)
+        assert other.partial_export(bufs[0].value, bufs[1].value, bufs[2].value, d) == d
+        eng.partial_import(bufs[0].value, bufs[1].value, bufs[2].value, d)
+        assert_same(eng.finish(), want, "merged, both lists grown")
+    finally:
+        for p in bufs:
+            hip.hipFree(p)
+        eng.close()
+        other.close()
 
 
 def test_shard_merge_equals_single_engine(capi, shufs, oracle_for):
