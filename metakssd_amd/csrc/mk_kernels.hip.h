@@ -761,7 +761,13 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     if (m == 0) return;
     const uint32_t cnt = (uint32_t)__popcll(m);
     if (qn + cnt > a.cand_cap) { /* buffer full (dense tables only): resolve right here */
+#if defined(MK_TUNING) && defined(MK_ABL) && MK_ABL == 6
+      /* ablation 6: the overflow path without its call (records beyond the buffer are DROPPED: timing only) -- what the call
+       * site inside the hot loop costs the loop */
+      atomicOr(&a.tab.err[0], 16u);
+#else
       mk_resolve_inline(ka, hit, r, K != 0 ? nullptr : bitmap);
+#endif
       return;
     }
     if (hit) my_cand[qn + mk_mbcnt(m)] = r;
