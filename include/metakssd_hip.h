@@ -405,6 +405,9 @@ int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *index, uint32_t
                  const uint32_t **row_ids, const uint64_t **row_ends, uint64_t *nrows);
 /* rows [row0, row0 + nrows) of the dense mco.index.N of the last build (nrows <= 2^27 per call) into out[] (host) */
 int mk_mco_index_rows(mk_mco *m, uint64_t row0, uint64_t nrows, uint64_t *out);
+/* the stable sort of mk_mco_build on its own (hand-written LSD radix sort, mk_sort.hip.h): n < 2^32 (key, value) pairs in host
+ * arrays, sorted by key in place, equal keys in input order -- what combco2mco()'s append loop amounts to (co2mco.c:37-59) */
+int mk_mco_sort_pairs(mk_mco *m, uint32_t *keys, uint32_t *vals, uint64_t n);
 /* counting: begin zeroes a qry_num x ref_num matrix in HBM; every add handles one component; finish adds the matrix
  * into ct[qry_num * ref_num] (host).  For an add, gids[ngids] is the component's mco.N (NULL: the lists of the last
  * mk_mco_build, still on the device); the row of query id i is gids[ext_start[i] .. ext_end[i]) -- what the reference

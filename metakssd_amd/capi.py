@@ -158,6 +158,7 @@ def _load():
         "mk_mco_destroy": [vp],
         "mk_mco_build": [vp, vp, vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
         "mk_mco_index_rows": [vp, u64, u64, vp],
+        "mk_mco_sort_pairs": [vp, vp, vp, u64],
         "mk_mco_set_option": [vp, C.c_int, C.c_int64],
         "mk_mco_count_begin": [vp, u32, u32],
         "mk_mco_count_add": [vp, vp, u64, vp, vp, vp, vp, vp],
@@ -579,6 +580,14 @@ class Mco:
         def arr(p, ct, k):
             return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(k,)).copy() if k else np.zeros(0, ct)
         return arr(g, C.c_uint32, n.value), arr(ri, C.c_uint32, nr.value), arr(re_, C.c_uint64, nr.value)
+
+    def sort_pairs(self, keys, vals):
+        """stable sort of (u32 key, u32 value) pairs by key on the device (the sort inside build()); returns new arrays"""
+        k = np.ascontiguousarray(keys, dtype=np.uint32).copy()
+        v = np.ascontiguousarray(vals, dtype=np.uint32).copy()
+        assert k.size == v.size
+        self._check(lib.mk_mco_sort_pairs(self.h, k.ctypes.data if k.size else None, v.ctypes.data if v.size else None, k.size))
+        return k, v
 
     def index_rows(self, row0, nrows):
         out = np.empty(nrows, np.uint64)

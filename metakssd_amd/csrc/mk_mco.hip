@@ -7,9 +7,8 @@
  * atomic-bound, MFMA does not apply.
  *
  *   mk_mco_gid_kernel       position in combco.N -> genome number (binary search in combco.index.N)
- *   rocprim::radix_sort_pairs   (id, genome) by id, stable: a row keeps the genome order in which the reference appends.
- *                           The sort is the one library primitive on this path (a plain LSD radix sort, like a plain
- *                           GEMM would go to hipBLASLt); everything around it is written here
+ *   mk_radix_sort_pairs_u32 (mk_sort.hip.h)   (id, genome) by id, STABLE: a row keeps the genome order in which the reference
+ *                           appends.  Hand-written LSD radix sort, four passes of 8 bits (round 3; rocPRIM before)
  *   mk_mco_rowcount / rowscan / rowwrite   ordered compaction of the row ends: the non-empty rows and their cumulative ends
  *   mk_mco_index_kernel     a slab of the dense 2^32-entry mco.index.N filled from the row table
  *   mk_mco_extent_kernel    query id -> its row's extent (device row table; the CLI takes extents from the mmap'ed index)
@@ -19,7 +18,7 @@
  */
 #include <hip/hip_runtime.h>
 
-#include <rocprim/device/device_radix_sort.hpp>
+#include "mk_sort.hip.h"
 
 #include <cstdarg>
 #include <cstdint>
@@ -51,6 +50,7 @@ struct mk_mco {
   uint64_t pair_cap = 0;
   void *d_tmp = nullptr;
   size_t tmp_cap = 0;
+  uint32_t *h_sort_flag = nullptr; /* pinned: which passes of the radix sort moved anything */
   unsigned long long *d_index = nullptr;
   uint64_t index_cap = 0;
   uint32_t *d_chunk = nullptr;
@@ -364,6 +364,7 @@ extern "C" int mk_mco_destroy(mk_mco *m) {
   (void)hipFree(m->d_ct); (void)hipFree(m->d_gids); (void)hipFree(m->d_gids16); (void)hipFree(m->d_qids); (void)hipFree(m->d_es); (void)hipFree(m->d_ee);
   (void)hipFree(m->d_items);
   if (m->h_total) (void)hipHostFree(m->h_total);
+  if (m->h_sort_flag) (void)hipHostFree(m->h_sort_flag);
   if (m->h_gids) (void)hipHostFree(m->h_gids);
   if (m->h_row_ids) (void)hipHostFree(m->h_row_ids);
   if (m->h_row_ends) (void)hipHostFree(m->h_row_ends);
@@ -417,17 +418,26 @@ extern "C" int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *inde
     MK_MCO_HIP(m, hipMemcpyAsync(m->d_index, index, ((size_t)cofnum + 1) * 8, hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(mk_mco_gid_kernel, dim3(mk_mco_blocks(m, n, 256)), dim3(256), 0, m->stream, m->d_index, cofnum, n, m->d_val[0]);
     MK_MCO_HIP(m, hipGetLastError());
-    size_t tmp_bytes = 0;
-    MK_MCO_HIP(m, rocprim::radix_sort_pairs(nullptr, tmp_bytes, m->d_key[0], m->d_key[1], m->d_val[0], m->d_val[1], (size_t)n, 0u, 32u,
-                                            m->stream));
-    if (tmp_bytes > m->tmp_cap || !m->d_tmp) {
-      (void)hipFree(m->d_tmp);
-      m->d_tmp = nullptr; m->tmp_cap = 0;
-      MK_MCO_HIP(m, hipMalloc(&m->d_tmp, tmp_bytes + 256));
-      m->tmp_cap = tmp_bytes + 256;
+    /* stable sort by id: (key, value) ping-pong between the two buffer pairs; the sorted pair ends up as [1] */
+    {
+      const size_t tmp_bytes = (size_t)256 * MK_RS_MAXB * 4 + 256 * 8 + 64;
+      if (tmp_bytes > m->tmp_cap || !m->d_tmp) {
+        (void)hipFree(m->d_tmp);
+        m->d_tmp = nullptr; m->tmp_cap = 0;
+        MK_MCO_HIP(m, hipMalloc(&m->d_tmp, tmp_bytes));
+        m->tmp_cap = tmp_bytes;
+      }
+      if (!m->h_sort_flag) MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_sort_flag, 4 * sizeof(uint32_t), hipHostMallocDefault));
+      uint32_t *hist = (uint32_t *)m->d_tmp;
+      unsigned long long *tot = (unsigned long long *)((uint8_t *)m->d_tmp + (size_t)256 * MK_RS_MAXB * 4);
+      uint32_t *flag = (uint32_t *)((uint8_t *)m->d_tmp + (size_t)256 * MK_RS_MAXB * 4 + 256 * 8);
+      int where = 0;
+      MK_MCO_HIP(m, mk_radix_sort_pairs_u32(m->d_key, m->d_val, n, m->num_cu, hist, tot, flag, m->h_sort_flag, m->stream, &where));
+      if (where == 0) { /* the passes that moved anything were even in number: the result sits in pair 0 */
+        uint32_t *tk = m->d_key[0]; m->d_key[0] = m->d_key[1]; m->d_key[1] = tk;
+        uint32_t *tv = m->d_val[0]; m->d_val[0] = m->d_val[1]; m->d_val[1] = tv;
+      }
     }
-    MK_MCO_HIP(m, rocprim::radix_sort_pairs(m->d_tmp, tmp_bytes, m->d_key[0], m->d_key[1], m->d_val[0], m->d_val[1], (size_t)n, 0u, 32u,
-                                            m->stream));
     /* row ends */
     const uint64_t nchunks = (n + MK_MCO_CHUNK - 1) / MK_MCO_CHUNK;
     cap = m->chunk_cap;
@@ -466,6 +476,43 @@ extern "C" int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *inde
   m->built = true;
   *gids = m->h_gids; *n_out = n;
   *row_ids = m->h_row_ids; *row_ends = (const uint64_t *)m->h_row_ends; *nrows_out = total;
+  return MK_OK;
+}
+
+/* the sort of mk_mco_build on its own: n (key, value) pairs in host arrays, sorted by key in place, equal keys in input order */
+extern "C" int mk_mco_sort_pairs(mk_mco *m, uint32_t *keys, uint32_t *vals, uint64_t n) {
+  if (!m || (n && (!keys || !vals))) return MK_ERR_ARG;
+  if (n >= (1ull << 32)) return mk_mco_fail(m, MK_ERR_ARG, "mk_mco_sort_pairs: fewer than 2^32 pairs");
+  if (n == 0) return MK_OK;
+  MK_MCO_HIP(m, hipSetDevice(m->device));
+  int rc;
+  uint64_t cap = m->pair_cap;
+  for (int b = 0; b < 2; b++) {
+    cap = m->pair_cap;
+    if ((rc = mk_mco_grow(m, &m->d_key[b], &cap, n))) return rc;
+    cap = m->pair_cap;
+    if ((rc = mk_mco_grow(m, &m->d_val[b], &cap, n))) return rc;
+  }
+  m->pair_cap = cap;
+  m->built = false;
+  const size_t tmp_bytes = (size_t)256 * MK_RS_MAXB * 4 + 256 * 8 + 64;
+  if (tmp_bytes > m->tmp_cap || !m->d_tmp) {
+    (void)hipFree(m->d_tmp);
+    m->d_tmp = nullptr; m->tmp_cap = 0;
+    MK_MCO_HIP(m, hipMalloc(&m->d_tmp, tmp_bytes));
+    m->tmp_cap = tmp_bytes;
+  }
+  if (!m->h_sort_flag) MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_sort_flag, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  MK_MCO_HIP(m, hipMemcpyAsync(m->d_key[0], keys, n * 4, hipMemcpyHostToDevice, m->stream));
+  MK_MCO_HIP(m, hipMemcpyAsync(m->d_val[0], vals, n * 4, hipMemcpyHostToDevice, m->stream));
+  uint32_t *hist = (uint32_t *)m->d_tmp;
+  unsigned long long *tot = (unsigned long long *)((uint8_t *)m->d_tmp + (size_t)256 * MK_RS_MAXB * 4);
+  uint32_t *flag = (uint32_t *)((uint8_t *)m->d_tmp + (size_t)256 * MK_RS_MAXB * 4 + 256 * 8);
+  int where = 0;
+  MK_MCO_HIP(m, mk_radix_sort_pairs_u32(m->d_key, m->d_val, n, m->num_cu, hist, tot, flag, m->h_sort_flag, m->stream, &where));
+  MK_MCO_HIP(m, hipMemcpyAsync(keys, m->d_key[where], n * 4, hipMemcpyDeviceToHost, m->stream));
+  MK_MCO_HIP(m, hipMemcpyAsync(vals, m->d_val[where], n * 4, hipMemcpyDeviceToHost, m->stream));
+  MK_MCO_HIP(m, hipStreamSynchronize(m->stream));
   return MK_OK;
 }
 

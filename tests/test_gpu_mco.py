@@ -190,3 +190,33 @@ def test_count_kernel_variants_agree(mco, opts):
         for k in (1, 2):
             capi.lib.mk_mco_set_option(mco.h, k, 0)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 1024, 4095, 4096, 4097, 100003, 3000017])
+def test_radix_sort_pairs_is_stable_and_sorted(n):
+    """the hand-written LSD radix sort behind mk_mco_build (mk_sort.hip.h): against numpy's stable argsort on keys drawn so that
+    passes are skipped (few distinct top bytes), ties are long (few distinct keys), and every digit value occurs"""
+    from metakssd_amd import capi
+    rs = np.random.RandomState(1000 + n % 97)
+    mco = capi.Mco(0)
+    try:
+        for kind in ("uniform", "small range", "few keys", "one key", "top byte only", "descending"):
+            if kind == "uniform":
+                k = rs.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+            elif kind == "small range":
+                k = rs.randint(0, 70000, size=n).astype(np.uint32)
+            elif kind == "few keys":
+                k = rs.choice(np.array([0, 1, 255, 256, 65535, 65536, 2 ** 24, 2 ** 32 - 1], dtype=np.uint64), size=n).astype(np.uint32)
+            elif kind == "one key":
+                k = np.full(n, 123456789, np.uint32)
+            elif kind == "top byte only":
+                k = (rs.randint(0, 256, size=n).astype(np.uint64) << 24).astype(np.uint32)
+            else:
+                k = np.arange(n, 0, -1, dtype=np.uint64).astype(np.uint32) * np.uint32(3)
+            v = np.arange(n, dtype=np.uint32)  # the value is the input position: stability is visible in it
+            gk, gv = mco.sort_pairs(k, v)
+            order = np.argsort(k, kind="stable")
+            assert np.array_equal(gk, k[order]), (n, kind)
+            assert np.array_equal(gv, v[order]), (n, kind)
+    finally:
+        mco.close()
