@@ -8,11 +8,13 @@
  *   mk_rs_hist_kernel     B persistent workgroups, each over a contiguous range of 4096-element tiles: 256-bin histogram in LDS
  *                         -> hist[digit][workgroup]
  *   mk_rs_scan_kernel     one workgroup per digit: exclusive prefix over the workgroups (B <= 1024: one entry per thread), digit totals
- *   mk_rs_scatter_kernel  the same ranges again, tile by tile and inside a tile quarter by quarter (1024 consecutive elements, one
- *                         per thread): a wave finds, with eight ballots, which of its lanes hold the same digit (rank inside the
- *                         wave = lanes below with that digit); the waves' counts per digit go through LDS for the rank of the
- *                         wave; position = digit base + workgroup prefix + what earlier tiles / quarters / waves put there + rank
- *                         inside the wave.  Everything is taken in index order, so equal keys keep their order.
+ *   mk_rs_scatter_kernel  the same ranges again, tile by tile, 256 threads: a wave takes 1024 consecutive elements, 64 at a time; with
+ *                         eight ballots it finds which of its lanes hold the same digit (rank = lanes below with that digit + what
+ *                         the wave's earlier items hold of it, a running count per wave and digit in LDS); one wave then turns the
+ *                         waves' counts into prefixes and digit starts; place in the tile's sorted order = digit start + earlier
+ *                         waves + rank.  The tile is put into that order in LDS and stored from there, so that a wave's stores run
+ *                         along the digits' runs (position = digit base + workgroup prefix + earlier tiles + place).  Everything
+ *                         is taken in index order, so equal keys keep their order.
  * A pass in which every key has the same digit is skipped (its histogram says so).  Keys and values ping-pong between two
  * buffer pairs.  Bound: HBM, 16 B per pair and pass (read key + value, write key + value) plus the histogram pass's 4 B.
  */
@@ -23,6 +25,8 @@
 #define MK_RS_THREADS 1024u
 #define MK_RS_ITEMS 4u
 #define MK_RS_TILE (MK_RS_THREADS * MK_RS_ITEMS)
+#define MK_RS_SC_THREADS 256u /* the scatter kernel: four waves, sixteen items per thread, four workgroups per CU */
+#define MK_RS_SC_ITEMS 16u
 #define MK_RS_MAXB 1024u /* workgroups: the scan kernel takes one entry per thread */
 
 struct mk_rs_plan {
@@ -90,77 +94,129 @@ __global__ void __launch_bounds__(MK_RS_THREADS) mk_rs_scan_kernel(uint32_t *his
   }
 }
 
-__global__ void __launch_bounds__(MK_RS_THREADS) mk_rs_scatter_kernel(const uint32_t *key, const uint32_t *val, uint32_t *okey, uint32_t *oval,
-                                                                     mk_rs_plan p, uint32_t shift, const uint32_t *hist,
-                                                                     const unsigned long long *total, const uint32_t *flag) {
+__global__ void __launch_bounds__(MK_RS_SC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) mk_rs_scatter_kernel(const uint32_t *key, const uint32_t *val, uint32_t *okey, uint32_t *oval,
+                                                                        mk_rs_plan p, uint32_t shift, const uint32_t *hist,
+                                                                        const unsigned long long *total, const uint32_t *flag) {
   if (flag[0] == 0u) return; /* every key has the same digit here: this pass is the identity, the caller does not swap */
-  constexpr uint32_t WAVES = MK_RS_THREADS / 64, WP = WAVES + 1u; /* +1: bank spread */
-  __shared__ unsigned long long base[256];              /* where the next element with this digit goes */
-  __shared__ uint32_t wcount[MK_RS_ITEMS][256][WP];     /* [quarter][digit][wave]: counts, then exclusive prefixes over (quarter, wave) */
+  constexpr uint32_t WAVES = MK_RS_SC_THREADS / 64, PER_WAVE = 64u * MK_RS_SC_ITEMS;
+  static_assert(WAVES * PER_WAVE == MK_RS_TILE, "the scatter kernel's tile is the histogram kernel's");
+  __shared__ unsigned long long gofs[256];              /* this tile: output position of an element = gofs[digit] + its place in the tile's sorted order */
+  __shared__ uint32_t dstart[256];                      /* this tile: where the digit starts in the tile's sorted order */
+  __shared__ uint32_t wc[WAVES][256];                   /* per wave and digit: running count while the wave ranks its items, then the
+                                                           exclusive prefix over the waves */
+  __shared__ uint32_t lk[MK_RS_TILE], lv[MK_RS_TILE];   /* the tile in sorted order: its stores to HBM run along the digits' runs */
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  if (t < 256u) base[t] = total[t]; /* (borrowed: scanned below) */
-  __syncthreads();
-  if (t == 0) { /* exclusive scan over the 256 digit totals: once per workgroup, cheap */
-    unsigned long long run = 0;
-    for (uint32_t d = 0; d < 256u; d++) { const unsigned long long c = base[d]; base[d] = run; run += c; }
+  unsigned long long base[4] = {0, 0, 0, 0}; /* wave 0, digits 4 * lane + j: where the next tile's first element with the digit goes
+                                                (in registers: with it in LDS a fourth workgroup would not fit a CU) */
+  if (wave == 0u) { /* exclusive scan over the 256 digit totals (four per lane) + what the workgroups before this one hold */
+    unsigned long long c[4], sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) { c[j] = total[lane * 4u + j]; sum += c[j]; }
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long u = __shfl_up(incl, o);
+      if ((int)lane >= o) incl += u;
+    }
+    unsigned long long run = incl - sum;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) {
+      const uint32_t d = lane * 4u + j;
+      base[j] = run + hist[(size_t)d * p.B + blockIdx.x];
+      run += c[j];
+    }
   }
-  __syncthreads();
-  if (t < 256u) base[t] += hist[(size_t)t * p.B + blockIdx.x];
   const uint64_t t0 = (uint64_t)blockIdx.x * p.per, t1 = t0 + p.per < p.ntiles ? t0 + p.per : p.ntiles;
   const uint64_t below = lane ? (~0ull >> (64u - lane)) : 0ull;
   for (uint64_t tile = t0; tile < t1; tile++) {
     const uint64_t tb = tile * MK_RS_TILE;
-    uint32_t k[MK_RS_ITEMS], v[MK_RS_ITEMS], rank[MK_RS_ITEMS];
-    bool ok[MK_RS_ITEMS];
+    const uint32_t nvalid = p.n - tb < (uint64_t)MK_RS_TILE ? (uint32_t)(p.n - tb) : MK_RS_TILE;
+    uint32_t k[MK_RS_SC_ITEMS], v[MK_RS_SC_ITEMS], rank[MK_RS_SC_ITEMS];
+    /* fresh copies per tile: what the items derive from them is one OR each, and is not to be kept (spilled) across the loop */
+    uint32_t ln = lane, tt = t;
+    asm volatile("" : "+v"(ln), "+v"(tt));
+    const uint32_t wbase = (tt >> 6) * PER_WAVE + ln; /* the wave's first element + lane */
+    /* a wave takes 1024 consecutive elements, item i = the i-th 64 of them: (wave, item, lane) is index order */
+    const uint32_t *kt = key + tb, *vt = val + tb; /* (wave-uniform base + a 32-bit offset per item) */
 #pragma unroll
-    for (uint32_t i = 0; i < MK_RS_ITEMS; i++) { /* all loads of the tile in flight */
-      const uint64_t idx = tb + (uint64_t)i * MK_RS_THREADS + t;
-      ok[i] = idx < p.n;
-      k[i] = ok[i] ? key[idx] : 0xFFFFFFFFu;
-      v[i] = ok[i] ? val[idx] : 0u;
+    for (uint32_t i = 0; i < MK_RS_SC_ITEMS; i++) { /* all loads of the tile in flight; past the end: element 0 again, dropped below */
+      const uint32_t j = wbase + i * 64u, jj = j < nvalid ? j : 0u;
+      k[i] = kt[jj];
+      v[i] = vt[jj];
     }
-    for (uint32_t j = t; j < MK_RS_ITEMS * 256u * WP; j += MK_RS_THREADS) ((uint32_t *)wcount)[j] = 0u;
-    __syncthreads(); /* (also: the previous tile's readers of wcount and base are done) */
+    if (nvalid != MK_RS_TILE) {
 #pragma unroll
-    for (uint32_t i = 0; i < MK_RS_ITEMS; i++) { /* quarter i: elements tb + i * 1024 + [0, 1024) in thread order */
+      for (uint32_t i = 0; i < MK_RS_SC_ITEMS; i++)
+        if (wbase + i * 64u >= nvalid) k[i] = 0xFFFFFFFFu;
+    }
+    /* (the wave's own row: its readers in the other waves are behind the previous tile's barrier C) */
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) wc[wave][j * 64u + ln] = 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < MK_RS_SC_ITEMS; i++) {
+      const bool ok = wbase + i * 64u < nvalid;
       const uint32_t d = (k[i] >> shift) & 255u;
-      uint64_t same = __ballot(ok[i]); /* lanes of this wave with the same digit (and an element at all) */
+      uint64_t same = __ballot(ok); /* lanes of this wave with the same digit (and an element at all) */
 #pragma unroll
       for (uint32_t b = 0; b < 8u; b++) {
         const uint64_t m = __ballot((d >> b) & 1u);
         same &= ((d >> b) & 1u) ? m : ~m;
       }
-      rank[i] = (uint32_t)__popcll(same & below);
-      if (ok[i] && rank[i] == 0u) wcount[i][d][wave] = (uint32_t)__popcll(same);
+      const uint32_t r = (uint32_t)__popcll(same & below);
+      const uint32_t prev = wc[wave][d]; /* what the wave's earlier items hold of this digit (LDS is in order inside a wave) */
+      rank[i] = prev + r;
+      if (ok && r == 0u) wc[wave][d] = prev + (uint32_t)__popcll(same);
+      __builtin_amdgcn_sched_barrier(0); /* item by item: interleaved, the sixteen ballot chains do not fit the registers */
     }
-    __syncthreads();
-    { /* per digit: exclusive prefix over the tile's (quarter, wave) cells in that order; the digit's total moves its base */
-      const uint32_t d = t & 255u, q = t >> 8; /* four threads per digit, one quarter each */
-      uint32_t run = 0;
+    __syncthreads(); /* A */
+    if (wave == 0u) { /* four digits per lane: prefix over the waves, where the digit starts inside the tile, where it goes in HBM;
+                         the bases move on */
+      uint32_t c[4], sum = 0;
 #pragma unroll
-      for (uint32_t w = 0; w < WAVES; w++) { const uint32_t c = wcount[q][d][w]; wcount[q][d][w] = run; run += c; }
-      wcount[q][d][WAVES] = run; /* the quarter's total for this digit */
+      for (uint32_t j = 0; j < 4u; j++) {
+        const uint32_t d = lane * 4u + j;
+        uint32_t run = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < WAVES; w++) { const uint32_t x = wc[w][d]; wc[w][d] = run; run += x; }
+        c[j] = run;
+        sum += run;
+      }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o);
+        if ((int)lane >= o) incl += u;
+      }
+      uint32_t run = incl - sum;
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; j++) {
+        const uint32_t d = lane * 4u + j;
+        dstart[d] = run;
+        gofs[d] = base[j] - run; /* (mod 2^64: every use adds a place >= run) */
+        base[j] += c[j];
+        run += c[j];
+      }
     }
-    __syncthreads();
+    __syncthreads(); /* B */
 #pragma unroll
-    for (uint32_t i = 0; i < MK_RS_ITEMS; i++) {
-      if (!ok[i]) continue;
+    for (uint32_t i = 0; i < MK_RS_SC_ITEMS; i++) {
+      if (wbase + i * 64u >= nvalid) continue;
       const uint32_t d = (k[i] >> shift) & 255u;
-      uint32_t before = wcount[i][d][wave] + rank[i];
-#pragma unroll
-      for (uint32_t q = 0; q < MK_RS_ITEMS; q++) if (q < i) before += wcount[q][d][WAVES];
-      const unsigned long long pos = base[d] + before;
-      okey[pos] = k[i];
-      oval[pos] = v[i];
+      const uint32_t place = dstart[d] + wc[wave][d] + rank[i];
+      lk[place] = k[i];
+      lv[place] = v[i];
     }
-    __syncthreads();
-    if (t < 256u) {
-      uint32_t s = 0;
+    __syncthreads(); /* C */
 #pragma unroll
-      for (uint32_t q = 0; q < MK_RS_ITEMS; q++) s += wcount[q][t][WAVES];
-      base[t] += s;
+    for (uint32_t i = 0; i < MK_RS_SC_ITEMS; i++) {
+      const uint32_t j = i * MK_RS_SC_THREADS + tt;
+      if (j >= nvalid) continue;
+      const uint32_t kk = lk[j], vv = lv[j];
+      const unsigned long long pos = gofs[(kk >> shift) & 255u] + j;
+      okey[pos] = kk;
+      oval[pos] = vv;
     }
-    __syncthreads(); /* the totals have been read: the next tile may zero the cells */
+    /* (the next tile writes gofs / dstart after its barrier A and lk / lv after its barrier B: everyone is through here by then) */
   }
 }
 
@@ -178,7 +234,7 @@ static inline hipError_t mk_radix_sort_pairs_u32(uint32_t *key[2], uint32_t *val
       const uint32_t shift = 8u * pass;
       hipLaunchKernelGGL(mk_rs_hist_kernel, dim3(p.B), dim3(MK_RS_THREADS), 0, st, (const uint32_t *)key[cur], p, shift, hist);
       hipLaunchKernelGGL(mk_rs_scan_kernel, dim3(256), dim3(MK_RS_THREADS), 0, st, hist, p.B, total, n, flag + pass);
-      hipLaunchKernelGGL(mk_rs_scatter_kernel, dim3(p.B), dim3(MK_RS_THREADS), 0, st, (const uint32_t *)key[cur], (const uint32_t *)val[cur],
+      hipLaunchKernelGGL(mk_rs_scatter_kernel, dim3(p.B), dim3(MK_RS_SC_THREADS), 0, st, (const uint32_t *)key[cur], (const uint32_t *)val[cur],
                          key[cur ^ 1], val[cur ^ 1], p, shift, (const uint32_t *)hist, (const unsigned long long *)total,
                          (const uint32_t *)(flag + pass));
       r = hipGetLastError();
