@@ -568,8 +568,9 @@ class Mco:
         if rc:
             raise MkError(rc, (lib.mk_mco_last_error(self.h) or b"").decode())
 
-    def build(self, ids, index):
-        """ids: uint32 (one component's combco.N), index: uint64[cofnum + 1] -> (gids, row_ids, row_ends)"""
+    def build(self, ids, index, copy=True):
+        """ids: uint32 (one component's combco.N), index: uint64[cofnum + 1] -> (gids, row_ids, row_ends).
+        copy=False: views of the library's pinned result buffers, as the C caller gets them (valid until the next build / close)"""
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
         index = np.ascontiguousarray(index, dtype=np.uint64)
         g, ri, re_ = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -578,7 +579,10 @@ class Mco:
                                      C.byref(n), C.byref(ri), C.byref(re_), C.byref(nr)))
 
         def arr(p, ct, k):
-            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(k,)).copy() if k else np.zeros(0, ct)
+            if not k:
+                return np.zeros(0, ct)
+            a = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(k,))
+            return a.copy() if copy else a
         return arr(g, C.c_uint32, n.value), arr(ri, C.c_uint32, nr.value), arr(re_, C.c_uint64, nr.value)
 
     def sort_pairs(self, keys, vals):

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "metakssd_hip.h"
@@ -81,6 +82,7 @@ struct mk_mco {
   uint64_t item_cap = 0;
   bool lds_configured = false;
   uint32_t *h_stage[2] = {nullptr, nullptr};
+  hipEvent_t ev_stage[2] = {nullptr, nullptr}; /* a staging piece has crossed to the device */
   char err[256] = {0};
 };
 
@@ -368,8 +370,10 @@ extern "C" int mk_mco_destroy(mk_mco *m) {
   if (m->h_gids) (void)hipHostFree(m->h_gids);
   if (m->h_row_ids) (void)hipHostFree(m->h_row_ids);
   if (m->h_row_ends) (void)hipHostFree(m->h_row_ends);
-  for (int b = 0; b < 2; b++)
+  for (int b = 0; b < 2; b++) {
     if (m->h_stage[b]) (void)hipHostFree(m->h_stage[b]);
+    if (m->ev_stage[b]) (void)hipEventDestroy(m->ev_stage[b]);
+  }
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return MK_OK;
@@ -382,6 +386,52 @@ static unsigned mk_mco_blocks(const mk_mco *m, uint64_t n, unsigned per_block) {
   const uint64_t cap = (uint64_t)m->num_cu * 32u;
   if (b > cap) b = cap;
   return b ? (unsigned)b : 1u;
+}
+
+/* Host memory into HBM on m->stream.  Pinned memory (mk_host_alloc, a registered arena) goes as it is.  Pageable memory -- what a
+ * caller that read combco.N with fread() holds -- would cross through the runtime's bounce buffer at one core's memcpy rate
+ * (about 11 GB/s measured); here MK_MCO_COPY_THREADS threads copy slices of a 64 MiB piece into pinned staging while the piece
+ * before it crosses PCIe. */
+#define MK_MCO_COPY_THREADS 4u
+static int mk_mco_upload(mk_mco *m, void *dst, const void *src, size_t bytes) {
+  if (!bytes) return MK_OK;
+  hipPointerAttribute_t at;
+  const bool pinned = hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost;
+  (void)hipGetLastError();
+  const size_t piece = MK_MCO_STAGE_CELLS * 4;
+  if (pinned || bytes < piece / 8) {
+    MK_MCO_HIP(m, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, m->stream));
+    return MK_OK;
+  }
+  for (int b = 0; b < 2; b++) {
+    if (!m->h_stage[b]) MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_stage[b], piece, hipHostMallocDefault));
+    if (!m->ev_stage[b]) MK_MCO_HIP(m, hipEventCreateWithFlags(&m->ev_stage[b], hipEventDisableTiming));
+  }
+  /* (the staging pieces also carry mk_mco_count_finish's matrix: that call is over when it returns) */
+  uint32_t p = 0;
+  for (size_t off = 0; off < bytes; off += piece, p++) {
+    const size_t len = bytes - off < piece ? bytes - off : piece;
+    const int b = (int)(p & 1u);
+    MK_MCO_HIP(m, hipEventSynchronize(m->ev_stage[b])); /* the piece that went through this buffer before (also an earlier call's) */
+    uint8_t *to = (uint8_t *)m->h_stage[b];
+    const uint8_t *from = (const uint8_t *)src + off;
+    const size_t slice = ((len + MK_MCO_COPY_THREADS - 1) / MK_MCO_COPY_THREADS + 4095) & ~(size_t)4095;
+    std::thread th[MK_MCO_COPY_THREADS];
+    uint32_t started = 0;
+    for (uint32_t t = 1; t < MK_MCO_COPY_THREADS; t++) {
+      const size_t lo = slice * t;
+      if (lo >= len) break;
+      const size_t n = len - lo < slice ? len - lo : slice;
+      try { th[t] = std::thread([=] { memcpy(to + lo, from + lo, n); }); started |= 1u << t; }
+      catch (...) { memcpy(to + lo, from + lo, n); } /* no thread to be had: this one copies the slice */
+    }
+    memcpy(to, from, len < slice ? len : slice);
+    for (uint32_t t = 1; t < MK_MCO_COPY_THREADS; t++)
+      if (started & (1u << t)) th[t].join();
+    MK_MCO_HIP(m, hipMemcpyAsync((uint8_t *)dst + off, to, len, hipMemcpyHostToDevice, m->stream));
+    MK_MCO_HIP(m, hipEventRecord(m->ev_stage[b], m->stream));
+  }
+  return MK_OK;
 }
 
 extern "C" int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *index, uint32_t cofnum, const uint32_t **gids, uint64_t *n_out,
@@ -414,10 +464,10 @@ extern "C" int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *inde
     }
     m->pair_cap = cap;
     if ((rc = mk_mco_grow(m, &m->d_index, &m->index_cap, (uint64_t)cofnum + 1))) return rc;
-    MK_MCO_HIP(m, hipMemcpyAsync(m->d_key[0], ids, n * 4, hipMemcpyHostToDevice, m->stream));
     MK_MCO_HIP(m, hipMemcpyAsync(m->d_index, index, ((size_t)cofnum + 1) * 8, hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(mk_mco_gid_kernel, dim3(mk_mco_blocks(m, n, 256)), dim3(256), 0, m->stream, m->d_index, cofnum, n, m->d_val[0]);
     MK_MCO_HIP(m, hipGetLastError());
+    if ((rc = mk_mco_upload(m, m->d_key[0], ids, n * 4))) return rc; /* (after the launch: the gid kernel runs under the copy) */
     /* stable sort by id: (key, value) ping-pong between the two buffer pairs; the sorted pair ends up as [1] */
     {
       const size_t tmp_bytes = (size_t)256 * MK_RS_MAXB * 4 + 256 * 8 + 64;
@@ -503,8 +553,7 @@ extern "C" int mk_mco_sort_pairs(mk_mco *m, uint32_t *keys, uint32_t *vals, uint
     m->tmp_cap = tmp_bytes;
   }
   if (!m->h_sort_flag) MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_sort_flag, 4 * sizeof(uint32_t), hipHostMallocDefault));
-  MK_MCO_HIP(m, hipMemcpyAsync(m->d_key[0], keys, n * 4, hipMemcpyHostToDevice, m->stream));
-  MK_MCO_HIP(m, hipMemcpyAsync(m->d_val[0], vals, n * 4, hipMemcpyHostToDevice, m->stream));
+  if ((rc = mk_mco_upload(m, m->d_key[0], keys, n * 4)) || (rc = mk_mco_upload(m, m->d_val[0], vals, n * 4))) return rc;
   uint32_t *hist = (uint32_t *)m->d_tmp;
   unsigned long long *tot = (unsigned long long *)((uint8_t *)m->d_tmp + (size_t)256 * MK_RS_MAXB * 4);
   uint32_t *flag = (uint32_t *)((uint8_t *)m->d_tmp + (size_t)256 * MK_RS_MAXB * 4 + 256 * 8);
