@@ -647,7 +647,8 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   const uint32_t ntiles = (uint32_t)((nreads + 63u) >> 6);
   const uint32_t wave_global = blockIdx.x * WAVES + wave;
   const uint32_t nwaves = gridDim.x * WAVES;
-  uint4 *const my_cand = a.cand + (size_t)wave_global * a.cand_cap;
+  /* wave-uniform, and told so: the append below is then one store with a scalar base and a 32-bit offset */
+  uint4 *const my_cand = a.cand + (size_t)__builtin_amdgcn_readfirstlane(wave_global) * a.cand_cap;
   if (wave_global >= ntiles) {
     if (lane == 0) a.cand_count[wave_global] = 0u;
     return;
@@ -772,6 +773,13 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     }
     if (hit) my_cand[qn + mk_mbcnt(m)] = r;
     qn = __builtin_amdgcn_readfirstlane(qn + cnt);
+  };
+  /* the tuned loop's append: hm = __ballot(hit), not zero.  The byte offset is 32-bit (a wave's buffer is far below 4 GiB) */
+  auto push_pair = [&](const bool hit, const uint64_t hm, const uint4 r) {
+    const uint32_t cnt = (uint32_t)__popcll(hm);
+    if (qn + cnt > a.cand_cap) { mk_resolve_inline(ka, hit, r, nullptr); return; } /* buffer full (dense tables only) */
+    if (hit) *(uint4 *)((uint8_t *)my_cand + (qn + mk_mbcnt(hm)) * 16u) = r;
+    qn += cnt;
   };
   auto push = [&](bool hit, uint64_t fwd, uint32_t pos) { /* one k-mer: slow paths, generic kernel */
     const uint64_t ord = ord_row | (uint64_t)pos;
@@ -945,8 +953,9 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
           decode(w1, c1, x1);
         };
         /* roll, probe, hand hits over.  rollonly: nobody completes a k-mer in this pair (wave-uniform); jmin, e: first base
-         * with a complete k-mer and bases that count, scalar in A, per lane in B; live: this lane may have a hit */
-        auto pair_body = [&](const bool rollonly, const uint32_t jmin, const uint32_t e, const bool live) {
+         * with a complete k-mer and bases that count, scalar in A, per lane in B; live: this lane may have a hit, livem: the wave's
+         * lanes that may */
+        auto pair_body = [&](const bool rollonly, const uint32_t jmin, const uint32_t e, const bool live, const uint64_t livem) {
           const uint32_t fstart = flo;
           /* the eight codes of the pair packed big-endian into the top 16 bits of `lo` (one v_dot4_u32_u8 per dword:
            * weights 64,16,4,1; one v_perm_b32 to place the two bytes): the low word after base j is then ONE funnel
@@ -990,13 +999,14 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
             __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) once, instead of a staggered wait per probe */
             /* t == 0 <=> every bit of the pair's mask is set in its filter word */
             const uint32_t tt0 = mm[0] & ~dd[0], tt1 = mm[1] & ~dd[1], tt2 = mm[2] & ~dd[2], tt3 = mm[3] & ~dd[3];
-            const uint32_t ta = min(min(tt0, tt1), tt2), tb = tt3, tc = 0xFFFFFFFFu;
-            if (__any(min(min(ta, tb), tc) == 0u)) {
+            const bool fired = min(min(tt0, tt1), min(tt2, tt3)) == 0u;
+            const bool hit = fired && live;
+            const uint64_t hm = __builtin_amdgcn_ballot_w64(fired) & livem; /* (the ballot of `hit` itself goes through a 0/1 value and a second compare) */
+            if (hm) {
               /* some lane's filter test fired somewhere in this pair: those lanes append one pair record and the
                * resolve kernel, which holds the exact filter, finds the base */
               const uint32_t meta = ((col0 + 8u * p) >> 3) | (jmin << 9) | (e << 12);
-              push_record(min(min(ta, tb), tc) == 0u && live, /* (a lane without a say may have sent the wave here) */
-                          make_uint4(fstart, (lo & 0xFFFF0000u) | meta, hh, (uint32_t)(row0 + lane)));
+              push_pair(hit, hm, make_uint4(fstart, (lo & 0xFFFF0000u) | meta, hh, (uint32_t)(row0 + lane)));
             }
           }
           hh = __builtin_amdgcn_perm(hh, fstart, 0x05040100u); /* hh << 16 | fstart & 0xFFFF */
@@ -1005,18 +1015,31 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
         uint64_t donem = __ballot(done); /* finished lanes: their bytes do not count in A's validity test */
         for (;;) {
           if (step) { /* ---- A */
-            bool left = false;
-            for (;;) {
-              next_pair();
+            bool left = false, more = true;
+            auto pair_is_bases = [&]() -> bool { /* every byte of every live lane's pair is one of ACGTacgt */
               const uint64_t bad = ((uint64_t)x1 << 32) | x0; /* non-zero: a byte of this lane's pair is not ACGTacgt */
               /* tested BEFORE the probes go out: folding this test into the hit test (one branch per pair, probes
                * issued speculatively) measured 4 % slower */
               uint64_t lanes_ok; /* asm: the compiler splits the compare into an OR over a re-derived x0 and a 32-bit compare (two more VALU) */
               asm("v_cmp_eq_u64_e64 %0, 0, %1" : "=s"(lanes_ok) : "v"(bad));
-              if ((lanes_ok | donem) != __builtin_amdgcn_read_exec()) { left = true; break; }
-              pair_body(urun + 8u < TL, urun + 1u >= TL ? 0u : TL - 1u - urun, 8u, !done);
+              return (lanes_ok | donem) == __builtin_amdgcn_read_exec();
+            };
+            while (urun + 1u < TL) { /* the rows' heads: the window fills up (three pairs of a row at k = 11) */
+              next_pair();
+              if (!pair_is_bases()) { left = true; break; }
+              pair_body(urun + 8u < TL, TL - 1u - urun, 8u, !done, ~donem);
               urun += 8u;
-              if (p == npairs) break;
+              if (p == npairs) { more = false; break; }
+            }
+            if (!left && more) { /* every base completes a k-mer: no run length to keep, jmin = 0 */
+              const uint32_t p0 = p;
+              for (;;) {
+                next_pair();
+                if (!pair_is_bases()) { left = true; break; }
+                pair_body(false, 0u, 8u, !done, ~donem);
+                if (p == npairs) break;
+              }
+              urun += 8u * (p - p0);
             }
             run = urun; /* the lanes' own counters take over */
             if (!left) break; /* block exhausted */
@@ -1029,7 +1052,8 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                                 (mk_nonzero_bytes(w0 ^ 0x0A0A0A0Au) ^ 0x80808080u);             /* 0x80 per '\n' */
             const uint32_t e = inval ? (uint32_t)__builtin_ctzll(inval) >> 3 : 8u;
             const uint32_t jm = run + 1u >= TL ? 0u : TL - 1u - run; /* >= e: nothing of this lane counts here */
-            pair_body(false, jm & 7u, e, !done && jm < e);
+            const bool say = !done && jm < e;
+            pair_body(false, jm & 7u, e, say, __builtin_amdgcn_ballot_w64(say));
             run = inval ? (uint32_t)__builtin_clzll(inval) >> 3 : min(run + 8u, 0xFFFFu); /* bases behind the last byte that is none */
             done = done || nl != 0ull;
             donem = __ballot(done);
