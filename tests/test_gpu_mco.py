@@ -220,3 +220,21 @@ def test_radix_sort_pairs_is_stable_and_sorted(n):
             assert np.array_equal(gv, v[order]), (n, kind)
     finally:
         mco.close()
+
+
+def test_build_large_pageable_input_and_views(mco):
+    """ids that cross several 64 MiB staging pieces of the threaded upload (mk_mco_upload), twice in a row on one handle (the
+    second call reuses staging buffers the first one's copies went through); copy=False hands out the library's pinned buffers"""
+    rs = np.random.RandomState(77)
+    n = 40 * 1000 * 1000 + 12345                  # 160 MB of ids: two full pieces and a ragged third
+    nsk = 500
+    cuts = np.sort(rs.randint(0, n, size=nsk - 1))
+    index = np.concatenate([[0], cuts, [n]]).astype(np.uint64)
+    for rep in range(2):
+        ids = rs.randint(0, 2 ** 24, size=n, dtype=np.uint64).astype(np.uint32)   # 16 M rows: long lists
+        og, ori, ore = ob.mco_build(ids, index)
+        g, ri, re_ = mco.build(ids, index, copy=False)
+        assert g.size == n and np.array_equal(g, og), rep
+        assert np.array_equal(ri, ori) and np.array_equal(re_, ore), rep
+    g2, _, _ = mco.build(ids[:1000], np.array([0, 400, 1000], np.uint64))       # views of the last build are gone by contract
+    assert g2.size == 1000
