@@ -292,6 +292,8 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-legs", action="store_true", help="skip t_stream / t_e2e / config5 (N = 1 only anyway)")
+    ap.add_argument("--serial-finish", action="store_true",
+                    help="profiling aid: wait for every pass's result before the next pass starts (no side-stream work beside the scan)")
     ap.add_argument("--no-config5", action="store_true", help="skip the genome-directory leg (BASELINE config 5 through the command line)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo moves the lists through the host (debug)")
@@ -396,6 +398,8 @@ def main():
                 drain()
                 eng.finish_begin()
                 flags["pending"] = True
+                if args.serial_finish:
+                    drain()
         if world > 1 and tail["on"]:
             torch.cuda.synchronize()
             if rank == 0:
@@ -543,6 +547,7 @@ def main():
                        "total_reads": total_reads, "reads_on_rank0": n, "read_len": READ_LEN, "row_stride": STRIDE,
                        "distinct_keys": result.get("distinct"),
                        "table_load": (result.get("distinct") or 0) / float(eng.params.hashsize),
+                       "finish": "serial (--serial-finish: profiling aid)" if args.serial_finish else "result copy beside the next pass",
                        "parallelism": "reads sharded x%d, gather to rank 0" % world},
             "roofline": {"bound": "hbm", "kernel": "mk_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

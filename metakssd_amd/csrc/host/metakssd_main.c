@@ -1718,14 +1718,26 @@ static void *shard_driver_run(void *arg) {
   }
 }
 
-typedef struct { pthread_t th; const mk_params *P; int device; mk_engine *eng; int ready; char err[512]; } second_engine_t;
-static void *second_engine_run(void *arg) {
-  second_engine_t *s = arg;
-  if (mk_engine_create(s->P, s->device, &s->eng) != MK_OK) { s->eng = NULL; snprintf(s->err, sizeof s->err, "%s", mk_last_error(NULL)); }
-  __atomic_store_n(&s->ready, 1, __ATOMIC_RELEASE);
+/* engines beside the first one on the same GPU, created one after the other by a thread of their own; `ready` counts them */
+#define MAX_ENGINES_PER_GPU 4
+typedef struct { pthread_t th; const mk_params *P; int device, want; mk_engine *eng[MAX_ENGINES_PER_GPU - 1]; int ready, failed; char err[512]; } extra_engines_t;
+static void *extra_engines_run(void *arg) {
+  extra_engines_t *s = arg;
+  for (int k = 0; k < s->want; k++) {
+    if (mk_engine_create(s->P, s->device, &s->eng[k]) != MK_OK) {
+      s->eng[k] = NULL;
+      snprintf(s->err, sizeof s->err, "%s", mk_last_error(NULL));
+      __atomic_store_n(&s->failed, 1, __ATOMIC_RELEASE);
+      break;
+    }
+    __atomic_store_n(&s->ready, k + 1, __ATOMIC_RELEASE);
+  }
   return NULL;
 }
 
+#ifndef MK_DEFAULT_ENGINES
+#define MK_DEFAULT_ENGINES 2
+#endif
 int main(int argc, char **argv) {
   g_t0 = now_s();
   setvbuf(stdout, NULL, _IOLBF, 0);
@@ -1744,7 +1756,7 @@ int main(int argc, char **argv) {
   uint64_t chunk_bytes = (uint64_t)32 << 20; /* text per framing job = about 17 MiB of rows per host-to-device copy */
   int drop_pages = 1, inflight = 3, slow_exit = 0, direct_host = 0;
   int devs[64], ndev = 0; /* --devices 0-7 / 0,2,5 / 0,0 (the same GPU twice: two engines, for tests) */
-  int engines_per_gpu = 0; /* --engines 1|2: engines taking the files of a directory in turn on one GPU (default: two from eight files on) */
+  int engines_per_gpu = 0; /* --engines 1..4: engines taking the files of a directory in turn on one GPU (default: MK_DEFAULT_ENGINES from eight files on) */
   int allow_copies = 0;   /* --allow-device-copies: distinct GPUs whose RCCL does not come up exchange with peer copies instead of failing */
   int kmerocrs = 1, kmerqlty = 0; /* command_dist_wrapper.c:79-80 */
   const char *refpath = NULL, *skf = NULL;
@@ -1837,15 +1849,19 @@ int main(int argc, char **argv) {
   const double t_shuf = now_s() - t0;
 
   engine_params(&fut, &P);
-  /* a second engine on the same GPU for directories of many files (see the file loop), created beside the first.  Pays for the
-   * 21 GB geometries as well (1024 genomes at L2K11: 1 771 genomes/s against 1 537, tools/bench_config5_variants.py);
-   * --engines 1 turns it off */
-  const int two_engines = !shard_files && ndev <= 1 && files.n >= 8 && engines_per_gpu != 1;
-  second_engine_t second_engine;
-  memset(&second_engine, 0, sizeof second_engine);
+  /* more engines on the same GPU for directories of many files (see the file loop), created beside the first and joining as
+   * they come up.  Two by default, four at most: 1024 genomes of 4 Mbases at L3K10 go through at 3 750 genomes/s with one engine,
+   * 6 100-6 400 with two, 5 650-6 150 with three, 5 570-5 860 with four (from "engine ready" to "directory written", one box,
+   * tools/gpu_session_r3x.sh); at L2K11 (21 GB of tables per engine) at 2 600 / 4 450 / 2 100-4 700 / 1 700-2 000 -- creating 21 GB
+   * engines beside a working one takes 0.04 to 1 s each, two pay, more do not.  --engines 1 turns it off */
+  if (engines_per_gpu < 0 || engines_per_gpu > MAX_ENGINES_PER_GPU) die("--engines takes 1..%d", MAX_ENGINES_PER_GPU);
+  const int n_engines = (!shard_files && ndev <= 1 && files.n >= 8) ? (engines_per_gpu ? engines_per_gpu : MK_DEFAULT_ENGINES) : 1;
+  const int two_engines = n_engines > 1;
+  extra_engines_t extra;
+  memset(&extra, 0, sizeof extra);
   if (two_engines) {
-    second_engine.P = &P; second_engine.device = ndev ? devs[0] : device;
-    if (pthread_create(&second_engine.th, NULL, second_engine_run, &second_engine) != 0) die("cannot start a thread: %s", strerror(errno));
+    extra.P = &P; extra.device = ndev ? devs[0] : device; extra.want = n_engines - 1;
+    if (pthread_create(&extra.th, NULL, extra_engines_run, &extra) != 0) die("cannot start a thread: %s", strerror(errno));
   }
   ctx_t c;
   memset(&c, 0, sizeof c);
@@ -1878,6 +1894,7 @@ int main(int argc, char **argv) {
     pf.koc_until = abundance ? first_nonfq : 0; /* files in front of this index are read the mt_shortreads2koc way */
     pf.nbufs = nthreads < PF_MAX_BUFS ? nthreads : PF_MAX_BUFS;
     if (shard_files && pf.nbufs < ndev + 1) pf.nbufs = ndev + 1 < PF_MAX_BUFS ? ndev + 1 : PF_MAX_BUFS; /* every driver may hold one */
+    if (pf.nbufs < n_engines + 1) pf.nbufs = n_engines + 1; /* every engine in turn holds one while its file is in flight (4 + 1 <= PF_MAX_BUFS) */
     if (pf.nbufs > files.n) pf.nbufs = files.n;
     pf.slots = calloc(files.n, sizeof(pf_slot));
     pthread_mutex_init(&pf.mu, NULL);
@@ -1935,47 +1952,53 @@ int main(int argc, char **argv) {
     }
     for (int j = 0; j < ndev; j++) { pthread_join(drv[j].th, NULL); t_finish += drv[j].t_finish; c.nrows_total += drv[j].c.nrows_total; }
   } else if (two_engines) {
-    /* many files on one GPU: two engines take the files in turn and ONE thread drives both -- file i is begun and pushed on one
-     * engine (copy and kernels queued on its stream), then file i-1 is finished on the other: while the host waits there and
-     * writes the result, the GPU already works on file i.  (With a single engine the GPU idles through every host round trip:
-     * 160 us of kernels and 75 us of copy per 4 Mbase genome against 420 us per genome in steady state.) */
-    ctx_t cx[2];
+    /* many files on one GPU: up to four engines take the files in turn and ONE thread drives them all -- a file is begun and
+     * pushed on an engine that is free (copy and kernels queued on its stream); when none is free the oldest file in flight is
+     * finished on its engine: while the host waits there and writes the result, the GPU already works on the files behind it,
+     * and the small kernels of neighbouring files overlap.  (With a single engine the GPU idles through every host round trip:
+     * 160 us of kernels and 75 us of copy per 4 Mbase genome against 420 us per genome in steady state.)  Engines join as they
+     * come up (21 GB of tables at L2K11 take anything from 0.04 to 1 s each beside a working GPU): until then fewer take turns. */
+    ctx_t cx[MAX_ENGINES_PER_GPU];
     cx[0] = c;
     (void)engine_get(&cx[0]);
-    cx[1] = cx[0];
-    cx[1].io = NULL; cx[1].rows = NULL; cx[1].arena = NULL; cx[1].arena_bytes = 0; /* its own buffers for files that stream */
-    /* until the second engine is there (its 21 GB of tables at L2K11 take anything from 0.04 to 1 s beside a working GPU) the
-     * first one takes the files alone */
-    int first = 0;
-    while (first < files.n && !__atomic_load_n(&second_engine.ready, __ATOMIC_ACQUIRE)) {
-      mk_result res;
-      sketch_one_file(&cx[0], &jo, first, &res, &t_finish);
-      rc = mk_sketchdir_add(sd, files.v[first], &res);
-      if (rc != MK_OK) die("writing sketch for %s failed (%d)", files.v[first], rc);
-      mk_result_release(cx[0].eng, &res);
-      if (!quiet) printf("%d/%d decomposing %s\r", first + 1, files.n, files.v[first]);
-      first++;
-    }
-    if (first < files.n) {
-      pthread_join(second_engine.th, NULL);
-      if (!second_engine.eng) die("mk_engine_create (second engine) failed: %s", second_engine.err);
-      cx[1].eng = second_engine.eng; cx[1].engs[0] = second_engine.eng; cx[1].ndev = 1; cx[1].multi = NULL;
-    }
-    int held[2] = {-1, -1};
-    for (int i = first; i <= files.n && first < files.n; i++) {
-      if (i < files.n) sketch_file_push(&cx[i & 1], &jo, i, &held[i & 1]);
-      if (i > first) {
-        const int j = i - 1;
-        mk_result res;
-        sketch_file_finish(&cx[j & 1], &jo, j, held[j & 1], &res, &t_finish);
-        held[j & 1] = -1;
-        rc = mk_sketchdir_add(sd, files.v[j], &res);
-        if (rc != MK_OK) die("writing sketch for %s failed (%d)", files.v[j], rc);
-        mk_result_release(cx[j & 1].eng, &res);
-        if (!quiet) printf("%d/%d decomposing %s\r", j + 1, files.n, files.v[j]);
+    int have = 1; /* engines in use */
+    struct { int file, eng, held; } fly[MAX_ENGINES_PER_GPU]; /* files in flight, oldest first */
+    int nfly = 0, busy[MAX_ENGINES_PER_GPU] = {0, 0, 0, 0};
+    for (int i = 0; i < files.n || nfly; ) {
+      if (__atomic_load_n(&extra.failed, __ATOMIC_ACQUIRE)) die("mk_engine_create (engine %d of %d) failed: %s", have + 1, n_engines, extra.err);
+      const int ready = 1 + __atomic_load_n(&extra.ready, __ATOMIC_ACQUIRE);
+      while (have < ready) { /* a new engine: its own buffers for files that stream */
+        cx[have] = cx[0];
+        cx[have].io = NULL; cx[have].rows = NULL; cx[have].arena = NULL; cx[have].arena_bytes = 0; cx[have].nrows_total = 0;
+        cx[have].eng = extra.eng[have - 1]; cx[have].engs[0] = extra.eng[have - 1]; cx[have].ndev = 1; cx[have].multi = NULL;
+        have++;
       }
+      int e = -1;
+      if (i < files.n)
+        for (int k = 0; k < have; k++) if (!busy[k]) { e = k; break; }
+      if (e >= 0) {
+        fly[nfly].file = i; fly[nfly].eng = e; fly[nfly].held = -1;
+        sketch_file_push(&cx[e], &jo, i, &fly[nfly].held);
+        busy[e] = 1; nfly++; i++;
+        continue;
+      }
+      /* every engine has a file (or the files are out): the oldest comes home */
+      const int j = fly[0].file, ej = fly[0].eng;
+      mk_result res;
+      sketch_file_finish(&cx[ej], &jo, j, fly[0].held, &res, &t_finish);
+      rc = mk_sketchdir_add(sd, files.v[j], &res);
+      if (rc != MK_OK) die("writing sketch for %s failed (%d)", files.v[j], rc);
+      mk_result_release(cx[ej].eng, &res);
+      if (!quiet) printf("%d/%d decomposing %s\r", j + 1, files.n, files.v[j]);
+      busy[ej] = 0;
+      for (int k = 1; k < nfly; k++) fly[k - 1] = fly[k];
+      nfly--;
     }
-    c.nrows_total = cx[0].nrows_total + cx[1].nrows_total - c.nrows_total;
+    /* engines that come up after the last file are not used; the fast exit below does not wait for them */
+    if (slow_exit || stage2_after) pthread_join(extra.th, NULL);
+    uint64_t rows_all = 0;
+    for (int k = 0; k < have; k++) rows_all += cx[k].nrows_total;
+    c.nrows_total = rows_all;
     c.eng = cx[0].eng;
   } else {
     for (int i = 0; i < files.n; i++) {

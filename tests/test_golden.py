@@ -657,9 +657,10 @@ def test_cli_many_small_inputs_equal_one_by_one(shuf, flags, shuf_files, tmp_pat
     st, stnames = parse_stat(os.path.join(whole, "cofiles.stat"))
     assert st["infile_num"] == len(paths) and stnames == paths and st["ctx_ct"] == counts and (fastq or counts[2] == 0)
     # the same inputs dealt to three engines file by file (--devices with several files: whole files are the unit, results
-    # written in file order, command_dist.c:363-372), with one and with two engines taking the files in turn on the one GPU
+    # written in file order, command_dist.c:363-372), with one, two and four engines taking the files in turn on the one GPU
     # (the default above is two), and with the FASTA text windowed on the host
-    variants = [("sharded", ["--devices", "0,0,0", "-p", "6"]), ("engines1", ["--engines", "1", "-p", "6"]), ("engines2", ["--engines", "2", "-p", "3"])]
+    variants = [("sharded", ["--devices", "0,0,0", "-p", "6"]), ("engines1", ["--engines", "1", "-p", "6"]), ("engines2", ["--engines", "2", "-p", "3"]),
+                ("engines4", ["--engines", "4", "-p", "3"])]
     if not fastq:
         variants.append(("hostfasta", ["--host-fasta", "-p", "6"]))
     for tag, extra in variants:
