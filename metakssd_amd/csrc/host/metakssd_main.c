@@ -641,7 +641,7 @@ static int parse_devices(const char *s, int *out, int cap) {
 
 static void usage(void) {
   fprintf(stderr,
-          "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D | --devices 0-7] <fastq|fasta|dir>...\n"
+          "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D | --devices 0-7] [--engines 1..4] <fastq|fasta|dir>...\n"
           "       metakssd dist -o <mco dir> <sketch dir>                      (stage II: inverted index)\n"
           "       metakssd dist -L <file.shuf> -r <genomes> -o <db dir>         (stage I + II)\n"
           "       metakssd dist -r <mco dir> -o <outdir> [-M 0|1] [-O 0|1|2] [-N n] [-D d] [--correction 0|1] [--keepskf] [-f skf] <sketch dir>\n"
