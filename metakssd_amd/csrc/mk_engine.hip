@@ -115,6 +115,7 @@ struct mk_engine {
   mk_fa_sum *d_fa_sum = nullptr;
   size_t fa_sum_cap = 0;
   mk_fa_state *d_fa_state = nullptr, *h_fa_state = nullptr; /* device state + pinned mirror */
+  bool counter0_used = true; /* d_counters[0] may be non-zero: a compaction has run since the last mk_sketch_begin */
   uint64_t fa_tail = 0;      /* stream bytes carried from the last non-final push (exact: read back) */
   uint64_t fa_rows_done = 0; /* virtual rows scanned so far in this sketch = ordinal of the next one */
   bool fa_used = false, fa_final = false;
@@ -645,6 +646,7 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   /* the table clear the reference does with memset(co,0,..) (iseq2comem.c:223,663) */
+  bool clear_front = false;
   if (e->sparse && e->tables_tracked) {
     /* the accumulation table is empty except in the blocks the last sketch marked: clear those, and the marks.  The layout
      * table is empty already (the key-list dump hands every slot back); after a finish that went wrong it is filled anew */
@@ -656,7 +658,7 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
                          (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t)MK_DUMP_SHIFT);
       MK_HIP(e, hipGetLastError());
     }
-    if (e->tab.fr) { MK_HIP(e, hipMemsetAsync(e->d_front, 0, e->front_slots * 16, e->stream)); e->big_maybe_dirty = false; }
+    if (e->tab.fr) { clear_front = true; e->big_maybe_dirty = false; }
     if (!e->slot_clean) {
       MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)e->kp.S * sizeof(uint32_t), e->stream));
       e->slot_clean = true;
@@ -664,10 +666,7 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   } else {
     /* behind a front table the S-slot table is cleared only when the last sketch may have used it */
     if (!e->tab.fr || e->big_maybe_dirty) MK_HIP(e, hipMemsetAsync(e->d_tab, 0, e->tab_bytes, e->stream));
-    if (e->tab.fr) {
-      MK_HIP(e, hipMemsetAsync(e->d_front, 0, e->front_slots * 16, e->stream));
-      e->big_maybe_dirty = false;
-    }
+    if (e->tab.fr) { clear_front = true; e->big_maybe_dirty = false; }
     if (e->sparse) {
       MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)e->kp.S * sizeof(uint32_t), e->stream));
       MK_HIP(e, hipMemsetAsync(e->d_dirty_acc, 0, (size_t)e->acc_words * 4, e->stream));
@@ -676,7 +675,17 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
       e->slot_clean = true;
     }
   }
-  MK_HIP(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->stream));
+  { /* front table, counters and the FASTA stream's state in one launch */
+    const unsigned long long n16 = clear_front ? (unsigned long long)e->front_slots : 0ull;
+    unsigned long long blocks = (n16 + 1023u) / 1024u; /* four 16-byte stores a thread */
+    if (blocks > (unsigned long long)e->num_cu * 8u) blocks = (unsigned long long)e->num_cu * 8u;
+    if (blocks == 0) blocks = 1;
+    const bool fa = e->fa_used && e->d_fa_state;
+    hipLaunchKernelGGL(mk_begin_clear_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, (uint4 *)e->d_front, n16, e->d_counters,
+                       (uint32_t *)e->d_fa_state, fa ? (uint32_t)(sizeof(mk_fa_state) / 4u) : 0u);
+    MK_HIP(e, hipGetLastError());
+    e->counter0_used = false;
+  }
   if (e->profiling) { MK_HIP(e, hipEventRecord(ev.b, e->stream)); e->ev_clear.push_back(ev); }
   e->region_open = false; /* rows staged for a sketch that was never finished are dropped with it */
   e->mode = mode;
@@ -685,7 +694,6 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   e->compacted = false;
   e->count_queued = false;
   e->D = 0;
-  if (e->fa_used) MK_HIP(e, hipMemsetAsync(e->d_fa_state, 0, sizeof(mk_fa_state), e->stream));
   e->fa_used = false; e->fa_final = false; e->fa_tail = 0; e->fa_rows_done = 0; e->fa_pitch = 0;
   return MK_OK;
 }
@@ -1091,7 +1099,9 @@ static int mk_compact_launch(mk_engine *e) {
   if (e->res_pending) /* the key list of the previous sketch is still being laid out and dumped on the side stream */
     return mk_fail(e, MK_ERR_STATE, "the result of mk_sketch_finish_begin has not been taken yet (mk_sketch_finish_end)");
   { int rc = mk_flush_region(e); if (rc) return rc; } /* rows copied but not scanned yet */
-  MK_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(unsigned long long), e->stream));
+  /* the key counter: zero since mk_sketch_begin unless a compaction has run on this sketch already (partial counts, imports) */
+  if (e->counter0_used) MK_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(unsigned long long), e->stream));
+  e->counter0_used = true;
   /* co[n]=0 stays "empty" in the FASTA set flavours (iseq2comem.c:300-302); the FASTQ slot words carry a count
    * field, so key 0 is an ordinary key there (:398-399, :704-705) */
   const int drop0 = e->mode == MK_MODE_SET || e->mode == MK_MODE_UNIQ_SET;
