@@ -185,6 +185,7 @@ typedef struct {
   int drop_pages, inflight, direct_host;
   uint8_t *arena; /* pinned row-buffer pool of the FASTQ stream */
   size_t arena_bytes;
+  int arena_unpinned; /* mapped and being filled, pinned at the first push (the runtime was not up when it was made) */
 } ctx_t;
 
 #define CHECK(e, call)                                                  \
@@ -323,6 +324,10 @@ static void push_rows(ctx_t *c, const uint8_t *rows, uint32_t stride, uint64_t n
 static int cli_sink_push(void *ctx, const uint8_t *rows, uint32_t stride, uint64_t nrows, uint64_t ord, uint64_t *token) {
   ctx_t *c = ctx;
   (void)sketch_engine(c);
+  if (c->arena_unpinned) { /* the engine is there, i.e. the runtime is up: pin the pool the framers have been filling */
+    if (mk_host_register(c->arena, c->arena_bytes) != MK_OK) die("pinning the row buffers failed: %s", mk_last_error(NULL));
+    c->arena_unpinned = 0;
+  }
   if (c->t_first_push == 0) c->t_first_push = now_s() - g_t0;
   /* several GPUs: the row buffers are dealt round-robin, so that every GPU's PCIe link carries a share at any time;
    * ordinals are global, so it does not matter which engine sees which rows */
@@ -334,11 +339,58 @@ static int cli_sink_push(void *ctx, const uint8_t *rows, uint32_t stride, uint64
   return rc;
 }
 static int cli_sink_wait(void *ctx, uint64_t token) { return mk_sketch_push_wait(((ctx_t *)ctx)->engs[token % 64u], token / 64u); }
+/* the row-buffer pool while the HIP runtime is still coming up: the same mapping mk_host_arena_alloc makes (2 MiB granules,
+ * huge pages asked for, touched by eight threads), not pinned yet -- the framers fill it while the runtime and the engine start,
+ * and the first push pins it (cli_sink_push) */
+typedef struct { uint8_t *p; size_t n; } touch_job;
+static void *touch_run(void *arg) {
+  touch_job *j = arg;
+  for (size_t off = 0; off < j->n; off += 4096) j->p[off] = 0;
+  return NULL;
+}
+static uint8_t *arena_map_unpinned(size_t bytes, size_t *len_out) {
+  const size_t huge = (size_t)2 << 20;
+  const size_t len = (bytes + huge - 1) & ~(huge - 1);
+  uint8_t *m = mmap(NULL, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (m == MAP_FAILED) return NULL;
+#ifdef MADV_HUGEPAGE
+  (void)madvise(m, len, MADV_HUGEPAGE);
+#endif
+  enum { T = 8 };
+  touch_job job[T];
+  pthread_t th[T];
+  int started = 0;
+  for (int t = 0; t < T; t++) {
+    const size_t lo = len / T * (size_t)t, hi = t + 1 == T ? len : len / T * (size_t)(t + 1);
+    job[t].p = m + lo; job[t].n = hi - lo;
+    if (t + 1 < T && pthread_create(&th[t], NULL, touch_run, &job[t]) == 0) started |= 1 << t;
+    else touch_run(&job[t]);
+  }
+  for (int t = 0; t < T; t++) if (started & (1 << t)) pthread_join(th[t], NULL);
+  *len_out = len;
+  return m;
+}
+static int engine_is_ready(ctx_t *c) {
+  if (c->eng) return 1;
+  engine_future *f = c->fut;
+  pthread_mutex_lock(&f->mu);
+  const int done = f->done;
+  pthread_mutex_unlock(&f->mu);
+  return done;
+}
 static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) { /* the pinned arena is kept for the next file and goes with the process */
   ctx_t *c = ctx;
   if (c->arena && c->arena_bytes >= bytes) return c->arena;
-  if (c->arena) mk_host_arena_free(c->arena, c->arena_bytes);
-  c->arena = NULL; c->arena_bytes = 0;
+  if (c->arena && !c->arena_unpinned) mk_host_arena_free(c->arena, c->arena_bytes);
+  else if (c->arena) munmap(c->arena, c->arena_bytes);
+  c->arena = NULL; c->arena_bytes = 0; c->arena_unpinned = 0;
+  if (!engine_is_ready(c)) { /* first file of the process: do not wait for the runtime, frame into ordinary memory meanwhile */
+    size_t len = 0;
+    uint8_t *m = arena_map_unpinned(bytes, &len);
+    if (!m) return NULL;
+    c->arena = m; c->arena_bytes = len; c->arena_unpinned = 1;
+    return m;
+  }
   void *p = NULL;
   if (mk_host_arena_alloc(&p, bytes) != MK_OK) return NULL;
   c->arena = p; c->arena_bytes = bytes;
@@ -366,9 +418,9 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   o.drop_pages = c->drop_pages; /* a private read-only file mapping that is unmapped below */
   mk_rows_sink sink = {c, cli_sink_push, cli_sink_wait, cli_sink_alloc, cli_sink_release};
   mk_fastq_stats fs;
-  /* the engine first: its queue creation takes three times as long (45 ms instead of 14) when it runs into the driver
-   * together with the pinning of the row buffers, and no row can be pushed before it is there anyway */
-  (void)engine_get(c);
+  /* the framers start at once, into a pool that is pinned when the engine is there (cli_sink_alloc / cli_sink_push): the
+   * engine's queue creation takes three times as long (45 ms instead of 14) when it runs into the driver together with the
+   * pinning, so the pinning waits for it -- the framing does not */
   const int rc = mk_fastq_stream(map, size, &o, &sink, c->next_ordinal, &fs);
   if (rc == MK_ERR_ARG || rc == MK_ERR_FORMAT)
     die("%s: FASTQ line longer than the reference's fgets() width (%s): outside the framing contract", path,
