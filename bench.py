@@ -136,7 +136,7 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=4):
         runs = []
         for rep in range(reps + 1):  # the first run only warms the page cache of the fresh file and is not counted
             out = os.path.join(tmp, "out%d" % rep)
-            time.sleep(1.0)  # the driver is still tearing the previous GPU process down for a while after it has exited
+            time.sleep(2.5)  # the driver is still tearing the previous GPU process down for a while after it has exited
             m0 = time.monotonic()
             r = subprocess.run([cli, "dist", "-L", sp, "-A", "-o", out, "--quiet", "--timing", fq], stdout=subprocess.PIPE,
                                stderr=subprocess.PIPE)
@@ -230,7 +230,9 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=16, reps=3, ref_genomes=
             walls, fin = [], None
             for rep in range(reps + 1):
                 od = os.path.join(tmp, "out_%s_%d" % (name, rep))
-                time.sleep(0.5)
+                # outside the timed window: the driver is still taking the previous process's device memory back (two engines of
+                # 21 GB each at L2K11) for a while after it has exited, and the next process's allocations wait for that
+                time.sleep(2.5)
                 m0 = time.monotonic()
                 r = subprocess.run([cli, "dist", "-L", sp, "-p", str(threads)] + list(extra_flags) + ["-o", od, "--quiet", "--timing", gd],
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE)
