@@ -593,7 +593,20 @@ class Mco:
         self._check(lib.mk_mco_sort_pairs(self.h, k.ctypes.data if k.size else None, v.ctypes.data if v.size else None, k.size))
         return k, v
 
-    def index_rows(self, row0, nrows):
+    def index_rows(self, row0, nrows, pinned=False):
+        """rows [row0, row0 + nrows) of the dense index.  pinned=True: into a pinned buffer this object keeps (what the command line
+        does, mk_host_alloc), returned as a view that the next pinned call overwrites -- the slab then crosses at PCIe speed"""
+        if pinned and nrows:
+            if getattr(self, "_slab_cap", 0) < nrows:
+                if getattr(self, "_slab", None):
+                    lib.mk_host_free(self._slab)
+                self._slab, self._slab_cap = C.c_void_p(), 0
+                rc = lib.mk_host_alloc(C.byref(self._slab), nrows * 8)
+                if rc:
+                    raise MkError(rc, "mk_host_alloc")
+                self._slab_cap = nrows
+            self._check(lib.mk_mco_index_rows(self.h, row0, nrows, self._slab))
+            return np.ctypeslib.as_array(C.cast(self._slab, C.POINTER(C.c_uint64)), shape=(nrows,))
         out = np.empty(nrows, np.uint64)
         self._check(lib.mk_mco_index_rows(self.h, row0, nrows, out.ctypes.data if nrows else None))
         return out
@@ -625,6 +638,9 @@ class Mco:
 
     def close(self):
         if self.h:
+            if getattr(self, "_slab", None):
+                lib.mk_host_free(self._slab)
+                self._slab, self._slab_cap = None, 0
             lib.mk_mco_destroy(self.h)
             self.h = C.c_void_p()
 

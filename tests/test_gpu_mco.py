@@ -238,3 +238,11 @@ def test_build_large_pageable_input_and_views(mco):
         assert np.array_equal(ri, ori) and np.array_equal(re_, ore), rep
     g2, _, _ = mco.build(ids[:1000], np.array([0, 400, 1000], np.uint64))       # views of the last build are gone by contract
     assert g2.size == 1000
+
+
+def test_index_rows_pinned_equals_pageable(mco):
+    rs = np.random.RandomState(3)
+    ids, index = sketches(rs, 50, 100000, 1000, 20000)
+    mco.build(ids, index)
+    for row0, nrows in ((0, 1 << 16), (2 ** 31, 1 << 20), (2 ** 32 - 4096, 4096)):
+        assert np.array_equal(mco.index_rows(row0, nrows, pinned=True), mco.index_rows(row0, nrows))

@@ -55,10 +55,16 @@ def main():
     t = []
     for it in range(args.slabs + 1):
         t0 = time.perf_counter()
-        m.index_rows(it << 27, 1 << 27)
+        m.index_rows(it << 27, 1 << 27, pinned=True)    # as the command line: a pinned slab buffer
         t.append(time.perf_counter() - t0)
     out["index_slab_ms"] = 1e3 * min(t[1:])
     out["index_GBps_to_host"] = (8 << 27) / min(t[1:]) / 1e9
+    t = []
+    for it in range(2):
+        t0 = time.perf_counter()
+        m.index_rows(it << 27, 1 << 27)                 # into ordinary (pageable) memory
+        t.append(time.perf_counter() - t0)
+    out["index_slab_ms_pageable"] = 1e3 * min(t)
     t = []
     for it in range(args.steps + 1):
         t0 = time.perf_counter()
