@@ -127,7 +127,6 @@ __global__ void __launch_bounds__(MK_RS_SC_THREADS) __attribute__((amdgpu_waves_
     }
   }
   const uint64_t t0 = (uint64_t)blockIdx.x * p.per, t1 = t0 + p.per < p.ntiles ? t0 + p.per : p.ntiles;
-  const uint64_t below = lane ? (~0ull >> (64u - lane)) : 0ull;
   for (uint64_t tile = t0; tile < t1; tile++) {
     const uint64_t tb = tile * MK_RS_TILE;
     const uint32_t nvalid = p.n - tb < (uint64_t)MK_RS_TILE ? (uint32_t)(p.n - tb) : MK_RS_TILE;
@@ -156,16 +155,23 @@ __global__ void __launch_bounds__(MK_RS_SC_THREADS) __attribute__((amdgpu_waves_
     for (uint32_t i = 0; i < MK_RS_SC_ITEMS; i++) {
       const bool ok = wbase + i * 64u < nvalid;
       const uint32_t d = (k[i] >> shift) & 255u;
-      uint64_t same = __ballot(ok); /* lanes of this wave with the same digit (and an element at all) */
+      /* the lanes of this wave with the same digit (and an element at all), as two 32-bit halves.  Per bit: the lane's bit spread
+       * over a word (v_bfe_i32: 0 or ~0), the wave's lanes with the bit set (one compare into a scalar pair), and per half
+       * same &= ~(set ^ mine) -- four VALU instructions a bit; the plain C of it (select m or ~m per lane, 64 bits wide) compiled
+       * to ten */
+      const uint64_t has = __builtin_amdgcn_ballot_w64(ok);
+      uint32_t lo = (uint32_t)has, hi = (uint32_t)(has >> 32);
 #pragma unroll
       for (uint32_t b = 0; b < 8u; b++) {
-        const uint64_t m = __ballot((d >> b) & 1u);
-        same &= ((d >> b) & 1u) ? m : ~m;
+        const uint32_t mine = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1u);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(mine != 0u);
+        lo &= ~((uint32_t)m ^ mine);
+        hi &= ~((uint32_t)(m >> 32) ^ mine);
       }
-      const uint32_t r = (uint32_t)__popcll(same & below);
+      const uint32_t r = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u)); /* lanes below with the same digit */
       const uint32_t prev = wc[wave][d]; /* what the wave's earlier items hold of this digit (LDS is in order inside a wave) */
       rank[i] = prev + r;
-      if (ok && r == 0u) wc[wave][d] = prev + (uint32_t)__popcll(same);
+      if (ok && r == 0u) wc[wave][d] = prev + (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
       __builtin_amdgcn_sched_barrier(0); /* item by item: interleaved, the sixteen ballot chains do not fit the registers */
     }
     __syncthreads(); /* A */
