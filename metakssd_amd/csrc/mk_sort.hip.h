@@ -5,10 +5,10 @@
  * id, i.e. it produces (id, genome) sorted by id with the genomes of an id in input order -- a STABLE sort by the 32-bit id.
  *
  * Four passes of 8 bits.  Every pass is three launches:
- *   mk_rs_hist_kernel     B persistent workgroups, each over a contiguous range of 4096-element tiles: 256-bin histogram in LDS
+ *   mk_rs_hist_kernel     B persistent workgroups, each over a contiguous range of 8192-element tiles: 256-bin histogram in LDS
  *                         -> hist[digit][workgroup]
  *   mk_rs_scan_kernel     one workgroup per digit: exclusive prefix over the workgroups (B <= 1024: one entry per thread), digit totals
- *   mk_rs_scatter_kernel  the same ranges again, tile by tile, 256 threads: a wave takes 1024 consecutive elements, 64 at a time; with
+ *   mk_rs_scatter_kernel  the same ranges again, tile by tile, 512 threads: a wave takes 1024 consecutive elements, 64 at a time; with
  *                         eight ballots it finds which of its lanes hold the same digit (rank = lanes below with that digit + what
  *                         the wave's earlier items hold of it, a running count per wave and digit in LDS); one wave then turns the
  *                         waves' counts into prefixes and digit starts; place in the tile's sorted order = digit start + earlier
@@ -23,9 +23,13 @@
 #include <stdint.h>
 
 #define MK_RS_THREADS 1024u
-#define MK_RS_ITEMS 4u
+/* 8192-element tiles: 256 digits share a tile, so a digit's run in it is 32 elements = one whole 128-byte line on average.  With
+ * 4096 (256 threads, four workgroups a CU) the runs are half lines and the scatter takes 2.97 ms a pass for 400 M pairs instead of
+ * 2.18-2.38; 16384 (1024 threads, one workgroup a CU) gains nothing more (2.18) */
+#define MK_RS_ITEMS 8u
+#define MK_RS_SC_THREADS 512u /* the scatter kernel: eight waves, sixteen items per thread, two workgroups per CU */
+#define MK_RS_SC_WGS_PER_CU 2u
 #define MK_RS_TILE (MK_RS_THREADS * MK_RS_ITEMS)
-#define MK_RS_SC_THREADS 256u /* the scatter kernel: four waves, sixteen items per thread, four workgroups per CU */
 #define MK_RS_SC_ITEMS 16u
 #define MK_RS_MAXB 1024u /* workgroups: the scan kernel takes one entry per thread */
 
@@ -41,7 +45,7 @@ static inline mk_rs_plan mk_rs_make_plan(uint64_t n, int num_cu) {
   p.n = n;
   p.ntiles = (n + MK_RS_TILE - 1) / MK_RS_TILE;
   uint64_t B = p.ntiles;
-  const uint64_t cap = (uint64_t)num_cu * 4u < MK_RS_MAXB ? (uint64_t)num_cu * 4u : MK_RS_MAXB;
+  const uint64_t cap = (uint64_t)num_cu * MK_RS_SC_WGS_PER_CU < MK_RS_MAXB ? (uint64_t)num_cu * MK_RS_SC_WGS_PER_CU : MK_RS_MAXB;
   if (B > cap) B = cap;
   if (B == 0) B = 1;
   p.B = (uint32_t)B;

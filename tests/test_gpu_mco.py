@@ -192,7 +192,7 @@ def test_count_kernel_variants_agree(mco, opts):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 1024, 4095, 4096, 4097, 100003, 3000017])
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 1024, 4095, 4096, 4097, 8191, 8192, 8193, 16385, 100003, 3000017])
 def test_radix_sort_pairs_is_stable_and_sorted(n):
     """the hand-written LSD radix sort behind mk_mco_build (mk_sort.hip.h): against numpy's stable argsort on keys drawn so that
     passes are skipped (few distinct top bytes), ties are long (few distinct keys), and every digit value occurs"""
