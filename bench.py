@@ -138,7 +138,7 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=4):
             out = os.path.join(tmp, "out%d" % rep)
             time.sleep(2.5)  # the driver is still tearing the previous GPU process down for a while after it has exited
             m0 = time.monotonic()
-            r = subprocess.run([cli, "dist", "-L", sp, "-A", "-o", out, "--quiet", "--timing", fq], stdout=subprocess.PIPE,
+            r = subprocess.run([cli, "dist", "-L", sp, "-A", "-o", out, "--quiet", "--timing"] + os.environ.get("MK_E2E_FLAGS", "").split() + [fq], stdout=subprocess.PIPE,
                                stderr=subprocess.PIPE)
             m1 = time.monotonic()
             if r.returncode != 0:

@@ -294,7 +294,8 @@ typedef struct mk_fastq_opts {
                            pages of its chunk back (madvise MADV_DONTNEED) when it has framed them, so that the page-table
                            work of unmapping a multi-GB file is spread over the threads instead of landing in one munmap.
                            Never set it for anonymous memory (the text would read back as zeros). */
-  int32_t reserved;
+  int32_t ahead;        /* row buffers beyond threads + inflight + 1 (0..192): how far the framers may run ahead of the pushes, e.g. while
+                           the engine is still being created */
 } mk_fastq_opts;
 typedef struct mk_fastq_stats {
   uint64_t rows, records, chunks, chunks_discarded, serial_rows; /* discarded / serial: work redone on the calling thread */

@@ -64,7 +64,7 @@ class FastaStateC(C.Structure):
 
 class FastqOptsC(C.Structure):
     _fields_ = [("occ", C.c_int32), ("qmin", C.c_int32), ("TL", C.c_int32), ("nthreads", C.c_int32), ("inflight", C.c_int32),
-                ("chunk_bytes", C.c_uint64), ("drop_pages", C.c_int32), ("reserved", C.c_int32)]
+                ("chunk_bytes", C.c_uint64), ("drop_pages", C.c_int32), ("ahead", C.c_int32)]
 
 
 class FastqStatsC(C.Structure):

@@ -135,6 +135,10 @@ typedef struct {
 } engine_future;
 
 static double g_t0; /* process start (monotonic) */
+#ifndef MK_DEFAULT_AHEAD
+#define MK_DEFAULT_AHEAD 0
+#endif
+static int g_ahead = MK_DEFAULT_AHEAD; /* --ahead: row buffers the FASTQ stream's framers may run ahead of the pushes by */
 static int g_component_sz = 8; /* --component-sz: the reference's compile-time COMPONENT_SZ (global_basic.h:35-37) */
 
 /* libmetakssd_multi.so (it links librccl.so, 570 MB) is loaded only when --devices names several GPUs */
@@ -414,7 +418,7 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   mk_fastq_opts o;
   memset(&o, 0, sizeof o);
   o.occ = c->occ; o.qmin = c->qmin; o.TL = c->TL;
-  o.nthreads = c->nthreads; o.inflight = c->inflight; o.chunk_bytes = c->chunk_bytes;
+  o.nthreads = c->nthreads; o.inflight = c->inflight; o.chunk_bytes = c->chunk_bytes; o.ahead = g_ahead;
   o.drop_pages = c->drop_pages; /* a private read-only file mapping that is unmapped below */
   mk_rows_sink sink = {c, cli_sink_push, cli_sink_wait, cli_sink_alloc, cli_sink_release};
   mk_fastq_stats fs;
@@ -1838,6 +1842,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--timing")) timing = 1;
     else if (!strcmp(argv[i], "--chunk-mib") && i + 1 < argc) chunk_bytes = (uint64_t)atoi(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--inflight") && i + 1 < argc) inflight = atoi(argv[++i]); /* row buffers queued for copying */
+    else if (!strcmp(argv[i], "--ahead") && i + 1 < argc) g_ahead = atoi(argv[++i]); /* row buffers the framers may run ahead by */
     else if (!strcmp(argv[i], "--direct")) direct_host = 1; /* MK_OPT_DIRECT_HOST: scan pinned row buffers in place */
     else if (!strcmp(argv[i], "--slow-exit")) slow_exit = 1; /* destroy the engine and return from main() instead of _exit() */
     else if (!strcmp(argv[i], "--keep-pages")) drop_pages = 0; /* measurement: leave all unmapping to the final munmap */

@@ -209,7 +209,7 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
    * into six 4096-byte rows; a buffer below that made the range framer give up on the record with MK_ERR_ARG and the stream
    * reported a line beyond the reference's width */
   if (f.buf_bytes < (size_t)8 * 4096 + 8192) f.buf_bytes = (size_t)8 * 4096 + 8192;
-  f.nbufs = T + depth + 1;
+  f.nbufs = T + depth + 1 + (o->ahead < 0 ? 0 : o->ahead > 192 ? 192 : o->ahead);
   int rc = MK_OK;
   uint8_t *serial_buf = NULL;
   pthread_t *th = NULL;
