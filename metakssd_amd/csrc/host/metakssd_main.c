@@ -25,6 +25,7 @@
 #include <errno.h>
 #include <pthread.h>
 #include <signal.h>
+#include <spawn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,6 +36,8 @@
 #include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
+
+extern char **environ;
 
 #define PATHLEN 256 /* global_basic.h:32 */
 
@@ -245,6 +248,12 @@ static void engine_params(engine_future *f, const mk_params *P) {
   pthread_mutex_unlock(&f->mu);
 }
 
+/* the per-engine options of the command line, for every engine that is attached to a ctx (the start-up engine, the extra engines
+ * of --engines, the drivers' engines of --devices) */
+static void engine_apply_options(const ctx_t *c, mk_engine *e) {
+  if (c->direct_host) mk_engine_set_option(e, MK_OPT_DIRECT_HOST, 1);
+}
+
 static mk_engine *engine_get(ctx_t *c) {
   if (c->eng) return c->eng;
   engine_future *f = c->fut;
@@ -256,8 +265,7 @@ static mk_engine *engine_get(ctx_t *c) {
   c->multi = f->multi;
   c->ndev = f->multi ? f->ndev : 1;
   for (int i = 0; i < c->ndev; i++) c->engs[i] = f->multi ? g_multi.engine(f->multi, i) : f->eng;
-  for (int i = 0; i < c->ndev; i++)
-    if (c->direct_host) mk_engine_set_option(c->engs[i], MK_OPT_DIRECT_HOST, 1);
+  for (int i = 0; i < c->ndev; i++) engine_apply_options(c, c->engs[i]);
   return c->eng;
 }
 
@@ -287,14 +295,18 @@ static int open_input(const char *path, input_t *in) {
   if (!is_compressed(path)) { in->f = fopen(path, "rb"); return in->f != NULL; }
   int fd[2];
   if (pipe(fd) != 0) return 0;
-  const pid_t pid = fork();
-  if (pid < 0) { close(fd[0]); close(fd[1]); return 0; }
-  if (pid == 0) {
-    dup2(fd[1], 1);
-    close(fd[0]); close(fd[1]);
-    execlp("zcat", "zcat", "-fc", "--", path, (char *)NULL);
-    _exit(127);
-  }
+  /* posix_spawnp, not fork: the process is heavily threaded and holds a live HIP runtime by the time genomes are read (worker
+   * threads beside the engines); a spawned child takes none of that state along */
+  posix_spawn_file_actions_t fa;
+  if (posix_spawn_file_actions_init(&fa) != 0) { close(fd[0]); close(fd[1]); return 0; }
+  posix_spawn_file_actions_adddup2(&fa, fd[1], 1);
+  posix_spawn_file_actions_addclose(&fa, fd[0]);
+  posix_spawn_file_actions_addclose(&fa, fd[1]);
+  char *const zargv[] = {(char *)"zcat", (char *)"-fc", (char *)"--", (char *)path, NULL};
+  pid_t pid = 0;
+  const int src = posix_spawnp(&pid, "zcat", &fa, NULL, zargv, environ);
+  posix_spawn_file_actions_destroy(&fa);
+  if (src != 0) { close(fd[0]); close(fd[1]); errno = src; return 0; }
   close(fd[1]);
   in->pid = pid;
   in->f = fdopen(fd[0], "rb");
@@ -1754,6 +1766,7 @@ static void *shard_driver_run(void *arg) {
     if (rc != MK_OK) die("mk_engine_create on GPU %d failed (%d): %s", d->device, rc, mk_last_error(NULL));
     d->c.eng = e;
     d->c.engs[0] = e;
+    engine_apply_options(&d->c, e);
   }
   for (;;) {
     pthread_mutex_lock(d->mu);
@@ -2020,14 +2033,22 @@ int main(int argc, char **argv) {
     (void)engine_get(&cx[0]);
     int have = 1; /* engines in use */
     struct { int file, eng, held; } fly[MAX_ENGINES_PER_GPU]; /* files in flight, oldest first */
-    int nfly = 0, busy[MAX_ENGINES_PER_GPU] = {0, 0, 0, 0};
+    int nfly = 0, busy[MAX_ENGINES_PER_GPU] = {0, 0, 0, 0}, extra_warned = 0;
     for (int i = 0; i < files.n || nfly; ) {
-      if (__atomic_load_n(&extra.failed, __ATOMIC_ACQUIRE)) die("mk_engine_create (engine %d of %d) failed: %s", have + 1, n_engines, extra.err);
+      if (__atomic_load_n(&extra.failed, __ATOMIC_ACQUIRE) && !extra_warned) {
+        /* the extra engines are a speed-up that is on by default: one that does not come up (a smaller or shared GPU: an L2K11
+         * engine is 21 GB of tables) must not turn a run that works on one engine into an error -- unless --engines asked for them */
+        if (engines_per_gpu) die("mk_engine_create (engine %d of %d, --engines %d) failed: %s", have + 1, n_engines, engines_per_gpu, extra.err);
+        fprintf(stderr, "metakssd: warning: engine %d of %d did not come up (%s): going on with %d\n", 1 + __atomic_load_n(&extra.ready, __ATOMIC_ACQUIRE) + 1,
+                n_engines, extra.err, 1 + __atomic_load_n(&extra.ready, __ATOMIC_ACQUIRE));
+        extra_warned = 1;
+      }
       const int ready = 1 + __atomic_load_n(&extra.ready, __ATOMIC_ACQUIRE);
       while (have < ready) { /* a new engine: its own buffers for files that stream */
         cx[have] = cx[0];
         cx[have].io = NULL; cx[have].rows = NULL; cx[have].arena = NULL; cx[have].arena_bytes = 0; cx[have].nrows_total = 0;
         cx[have].eng = extra.eng[have - 1]; cx[have].engs[0] = extra.eng[have - 1]; cx[have].ndev = 1; cx[have].multi = NULL;
+        engine_apply_options(&cx[have], cx[have].eng);
         have++;
       }
       int e = -1;

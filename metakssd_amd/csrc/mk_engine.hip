@@ -522,8 +522,12 @@ static int mk_flush_region(mk_engine *e);
 extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
   if (!e) return MK_ERR_ARG;
   if (e->begun) return mk_fail(e, MK_ERR_STATE, "mk_engine_set_option inside a sketch (between begin and finish)");
+  /* the side stream still lays out and dumps the last sketch: the key list, the staging arrays and the pinned result arrays it
+   * works on are what several options free */
+  if (e->res_pending) return mk_fail(e, MK_ERR_STATE, "mk_engine_set_option while a result is outstanding (mk_sketch_finish_end first)");
   MK_HIP(e, hipSetDevice(e->device));
   MK_HIP(e, hipStreamSynchronize(e->stream));
+  if (e->res_stream) MK_HIP(e, hipStreamSynchronize(e->res_stream));
   switch (option) {
     case MK_OPT_SPARSE: {
       if (value < -1 || value > 1) return mk_fail(e, MK_ERR_ARG, "MK_OPT_SPARSE takes -1 (by table size), 0 or 1");
@@ -1544,8 +1548,17 @@ static int mk_finish_impl(mk_engine *e, mk_result *out, bool staged) {
     hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)e->num_cu * 16u), dim3(256), 0, rs, e->dist, (const unsigned long long *)e->d_snap,
                        (unsigned long long)mk_key_limit(e), e->d_slot, S, (uint32_t *)(e->d_snap + 2), (uint32_t *)nullptr, (uint32_t)MK_DUMP_SHIFT);
     MK_HIP(e, hipGetLastError());
+    /* an error from here on leaves work queued on the side stream: it is waited for, the sketch is over, and the layout table is
+     * filled anew by the next finish */
+    auto staged_bail = [&](int code) {
+      (void)hipStreamSynchronize(e->stream);
+      (void)hipStreamSynchronize(rs);
+      e->begun = false; e->slot_clean = false; e->compacted = false;
+      if (e->profiling) { e->ev_pool.push_back(ev); e->ev_pool.push_back(ev2); }
+      return code;
+    };
     rc = mk_launch_dump(e, true, e->d_res_ids, e->d_res_cnt, e->res_cap, rs, true);
-    if (rc) return rc;
+    if (rc) return staged_bail(rc);
     e->slot_clean = true; /* the write pass hands every slot back (a dump that held back, below, fills the table anew) */
     MK_HIP(e, hipStreamSynchronize(e->stream));
     rc = mk_check_counters(e);
@@ -1555,21 +1568,21 @@ static int mk_finish_impl(mk_engine *e, mk_result *out, bool staged) {
       if (e->profiling) { e->ev_pool.push_back(ev); e->ev_pool.push_back(ev2); }
       return rc;
     }
-    if (e->profiling) e->ev_finish.push_back(ev);
     const uint64_t D = e->D;
     rc = mk_result_capacity(e, D ? D : 1);
-    if (rc) return rc;
+    if (rc) return staged_bail(rc);
     if (D > e->res_cap) { /* the write pass held back (more keys than the staging arrays hold): larger arrays, layout and dump again */
       MK_HIP(e, hipStreamSynchronize(rs));
       rc = mk_res_reserve(e, D + D / 8 + 1024);
-      if (rc) return rc;
+      if (rc) return staged_bail(rc);
       MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), rs));
       hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)e->num_cu * 16u), dim3(256), 0, rs, e->dist, (const unsigned long long *)e->d_snap,
                          (unsigned long long)mk_key_limit(e), e->d_slot, S, (uint32_t *)(e->d_snap + 2), (uint32_t *)nullptr, (uint32_t)MK_DUMP_SHIFT);
       MK_HIP(e, hipGetLastError());
       rc = mk_launch_dump(e, true, e->d_res_ids, e->d_res_cnt, e->res_cap, rs, true);
-      if (rc) return rc;
+      if (rc) return staged_bail(rc);
     }
+    if (e->profiling) e->ev_finish.push_back(ev);
     if (D) { /* at most D entries come out (all of them with -A): the staging prefix in one copy each */
       MK_HIP(e, hipMemcpyAsync(e->h_ids, e->d_res_ids, D * 4, hipMemcpyDeviceToHost, rs));
       if (koc) MK_HIP(e, hipMemcpyAsync(e->h_cnt, e->d_res_cnt, D * 2, hipMemcpyDeviceToHost, rs));

@@ -439,6 +439,8 @@ extern "C" int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *inde
   if (!m || !index || !gids || !n_out || !row_ids || !row_ends || !nrows_out) return MK_ERR_ARG;
   const uint64_t n = index[cofnum];
   if (n && !ids) return MK_ERR_ARG;
+  /* the sort keeps its per-(digit, workgroup) prefixes in 32 bits (mk_sort.hip.h): as for mk_mco_sort_pairs */
+  if (n >= (1ull << 32)) return mk_mco_fail(m, MK_ERR_ARG, "mk_mco_build: a component of %llu ids (fewer than 2^32 are supported)", (unsigned long long)n);
   for (uint32_t j = 0; j < cofnum; j++)
     if (index[j] > index[j + 1]) return mk_mco_fail(m, MK_ERR_ARG, "combco.index not ascending at sketch %u", j);
   MK_MCO_HIP(m, hipSetDevice(m->device));

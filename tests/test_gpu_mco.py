@@ -153,6 +153,9 @@ def test_state_and_argument_errors(mco):
         m.index_rows(0, 16)                                   # before any build
     with pytest.raises(capi.MkError):
         m.build(np.arange(4, dtype=np.uint32), np.array([0, 3, 2, 4], np.uint64))   # index not ascending
+    with pytest.raises(capi.MkError) as big:                   # 2^32 ids and more: the sort's 32-bit prefixes would wrap
+        m.build(np.arange(4, dtype=np.uint32), np.array([0, 2 ** 32], np.uint64))
+    assert big.value.code == capi.MK_ERR_ARG and "2^32" in str(big.value)
     m.build(np.arange(4, dtype=np.uint32), np.array([0, 2, 4], np.uint64))
     with pytest.raises(capi.MkError):
         m.index_rows(2 ** 32 - 8, 16)                         # past the last row

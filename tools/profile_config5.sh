@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel statistics of a genome-directory run (config 5) at L2K11: what a finish consists of with sparse bookkeeping
+# kernel statistics of a genome-directory run (config 5: 256 genomes of 4 Mbases) at L2K11 and L3K10 -> gpurun_out/c5_<geometry>_kernel_stats.csv
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python - <<'PY'
@@ -20,6 +20,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for g in L2K11 L3K10; do
 rm -rf gpurun_out/c5_prof_$g
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/c5_prof_$g -- metakssd_amd/bin/metakssd dist -L /dev/shm/c5p/$g.shuf -p 32 -o /dev/shm/c5p/out_$g --quiet --slow-exit /dev/shm/c5p/genomes > gpurun_out/c5_$g.log 2>&1
-f=$(find gpurun_out/c5_prof_$g -name "*kernel_stats.csv" | head -1); echo "== $g"; head -16 $f | cut -c1-150
+# the NEWEST statistics file (a directory left by an earlier round holds older pids)
+f=$(ls -t $(find gpurun_out/c5_prof_$g -name "*kernel_stats.csv") | head -1); echo "== $g: $f"; head -16 $f | cut -c1-150
+cp $f gpurun_out/c5_${g}_kernel_stats.csv
 done
 rm -rf /dev/shm/c5p
