@@ -153,8 +153,11 @@ int mk_engine_destroy(mk_engine *e);
  *                   hold; -1 (default): about an eighth of hashsize, from 2^20 slots up (dense bookkeeping only), 0: none
  *   MK_OPT_KEYLIST_CAP entries the distinct-key list holds now (sparse bookkeeping only: there the list starts at 32 M entries instead
  *                   of hashsize -- 10.7 GB at L2K11 -- and the finish / export that counts more keys grows it and compacts again)
+ *   MK_OPT_BATCH_TAB_BITS 0 / 9..22: log2 of the slots every file's table gets in mk_sketch_batch_begin (default 0: about five times
+ *                   the keys the batch's largest file is expected to leave); a file whose table is too small is sketched alone
  * Results are bit-identical for every setting; the tests run both. */
-enum { MK_OPT_SPARSE = 1, MK_OPT_CAND_CAP = 2, MK_OPT_RESULT_CAP = 3, MK_OPT_DIRECT_HOST = 4, MK_OPT_FRONT_BITS = 5, MK_OPT_KEYLIST_CAP = 6 };
+enum { MK_OPT_SPARSE = 1, MK_OPT_CAND_CAP = 2, MK_OPT_RESULT_CAP = 3, MK_OPT_DIRECT_HOST = 4, MK_OPT_FRONT_BITS = 5, MK_OPT_KEYLIST_CAP = 6,
+       MK_OPT_BATCH_TAB_BITS = 7 };
 int mk_engine_set_option(mk_engine *e, int option, int64_t value);
 int mk_engine_set_stream(mk_engine *e, void *hip_stream);
 int mk_engine_use_own_stream(mk_engine *e);
@@ -209,6 +212,37 @@ int mk_sketch_finish_begin(mk_engine *e);
 int mk_sketch_finish_end(mk_engine *e, mk_result *out);
 int mk_result_release(mk_engine *e, mk_result *r);
 int mk_engine_sync(mk_engine *e);
+
+/* ---- many small inputs in one launch sequence (BASELINE config 5: a directory of genomes) ------------------------------------
+ * run_stageI() sketches one file per OpenMP thread, each thread with a table of its own (command_dist.c:344-348, :363-372:
+ * CO[tid], fasta2co() / uniq_fasta2co(), wrt_co2cmpn_use_inn_subctx()).  On the device a 4 Mbase genome alone is a dozen
+ * launches of a few microseconds each; here up to MK_BATCH_MAX_FILES files travel together: their text in one copy, the FASTA
+ * walk, the scan, the tables (one per file, side by side), the reference's slot order (a virtual hashsize-slot table per file)
+ * and the ordered dump in ONE launch sequence for all of them.  Every file's sketch is exactly what mk_sketch_begin(mode) +
+ * mk_sketch_push_stream(text, n, 1) + mk_sketch_finish give for it alone (a file the batch's tables cannot take is sketched that
+ * way by mk_sketch_batch_end itself).
+ *   mode: MK_MODE_SET or MK_MODE_UNIQ_SET.  files[i].text: the file's bytes (FASTA text as in the file), 1 <= nfiles <=
+ *   MK_BATCH_MAX_FILES, each at most MK_BATCH_FILE_MAX bytes, MK_BATCH_TEXT_MAX in all.  The texts must stay untouched until
+ *   the matching mk_sketch_batch_end has returned.  When every text starts a multiple of 1024 bytes behind files[0].text, in
+ *   ascending order (one pinned buffer filled file by file), the texts cross PCIe in ONE copy.
+ *   Two batches may be in flight: _begin queues everything and returns, _end waits for the OLDEST batch and hands out one
+ *   result per file -- status MK_OK, MK_ERR_FORMAT (the text ends inside a '>' line: the reference's abort, iseq2comem.c:259-271)
+ *   or MK_ERR_CROWDED; the arrays are the engine's and stay valid until the next mk_sketch_batch_end on it.
+ *   Not between mk_sketch_begin and mk_sketch_finish. */
+#define MK_BATCH_MAX_FILES 1024u
+#define MK_BATCH_FILE_MAX ((uint64_t)64 << 20)
+#define MK_BATCH_TEXT_MAX ((uint64_t)1 << 30)
+typedef struct mk_batch_file {
+  const uint8_t *text;
+  uint64_t n;
+} mk_batch_file;
+typedef struct mk_batch_result {
+  int32_t status;
+  int32_t alone; /* != 0: the file was sketched alone (its table in the batch was too small) */
+  mk_result r;
+} mk_batch_result;
+int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles);
+int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out /* [nfiles of the oldest batch] */);
 
 /* pinned host memory for the caller's read batches (hipHostMalloc) */
 int mk_host_alloc(void **p, size_t bytes);

@@ -16,7 +16,7 @@ MK_OK = 0
 MK_ERR_ARG, MK_ERR_NO_DEVICE, MK_ERR_HIP, MK_ERR_CROWDED = -1, -2, -3, -4
 MK_ERR_STATE, MK_ERR_IO, MK_ERR_FORMAT, MK_ERR_NOMEM = -5, -6, -7, -8
 MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET, MK_MODE_OCC_SET = 0, 1, 2, 3
-MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP, MK_OPT_DIRECT_HOST, MK_OPT_FRONT_BITS, MK_OPT_KEYLIST_CAP = 1, 2, 3, 4, 5, 6
+MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP, MK_OPT_DIRECT_HOST, MK_OPT_FRONT_BITS, MK_OPT_KEYLIST_CAP, MK_OPT_BATCH_TAB_BITS = 1, 2, 3, 4, 5, 6, 7
 
 
 class MkError(RuntimeError):
@@ -84,6 +84,10 @@ class RowsSinkC(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("push", _PUSH_FN), ("wait", _WAIT_FN), ("alloc", _ALLOC_FN), ("release", _RELEASE_FN)]
 
 
+class BatchFileC(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("n", C.c_uint64)]
+
+
 class DistOptsC(C.Structure):
     _fields_ = [("metric", C.c_int32), ("outfields", C.c_int32), ("correction", C.c_int32), ("num_neigb", C.c_int32),
                 ("dthreshold", C.c_double)]
@@ -116,6 +120,8 @@ def _load():
         "mk_sketch_push_stream": [vp, vp, u64, C.c_int],
         "mk_partial_count_begin": [vp],
         "mk_partial_export_async": [vp, vp, vp, vp, u64, C.POINTER(u64)],
+        "mk_sketch_batch_begin": [vp, C.c_int, vp, u32],
+        "mk_sketch_batch_end": [vp, vp],
         "mk_sketch_finish": [vp, C.POINTER(ResultC)],
         "mk_sketch_finish_begin": [vp],
         "mk_sketch_finish_end": [vp, C.POINTER(ResultC)],
@@ -444,6 +450,53 @@ class Engine:
         self.last_total = r.total
         lib.mk_result_release(self.h, C.byref(r))
         return out
+
+    def batch_begin(self, texts, mode=MK_MODE_SET, one_buffer=False):
+        """mk_sketch_batch_begin over a list of byte strings (FASTA texts).  one_buffer: lay the texts into ONE
+        buffer at 1 KiB-aligned offsets (the single-copy layout) instead of separate arrays.  The buffers are kept until batch_end()."""
+        arrs = []
+        if one_buffer:
+            offs, at = [], 0
+            for t in texts:
+                offs.append(at)
+                at += (len(t) + 1023) // 1024 * 1024
+            buf = np.zeros(max(at, 1024), dtype=np.uint8)  # (pageable here; the command line uses a pinned buffer)
+            for t, o in zip(texts, offs):
+                buf[o:o + len(t)] = np.frombuffer(bytes(t), dtype=np.uint8)
+            arrs = [buf[o:o + len(t)] for t, o in zip(texts, offs)]
+            keep = [buf]
+        else:
+            arrs = [np.frombuffer(bytes(t), dtype=np.uint8).copy() for t in texts]
+            keep = arrs
+        files = (BatchFileC * len(texts))()
+        for i, a in enumerate(arrs):
+            files[i].text = (keep[0].ctypes.data + offs[i]) if one_buffer else (a.ctypes.data if a.size else None)
+            files[i].n = a.size
+        _check(lib.mk_sketch_batch_begin(self.h, mode, C.cast(files, C.c_void_p), len(texts)), self.h)
+        self._batches = getattr(self, "_batches", [])
+        self._batches.append((keep, len(texts)))
+
+    def batch_end(self):
+        """-> per file (status, alone, [ids per component]) of the oldest batch in flight"""
+        if not getattr(self, "_batches", None):  # nothing in flight: let the library say so
+            _check(lib.mk_sketch_batch_end(self.h, C.cast((C.c_uint8 * 64)(), C.c_void_p)), self.h)
+            raise MkError(MK_ERR_STATE, "mk_sketch_batch_end returned MK_OK without a batch in flight")
+        keep, n = self._batches.pop(0)
+
+        class BatchResultC(C.Structure):
+            _fields_ = [("status", C.c_int32), ("alone", C.c_int32), ("r", ResultC)]
+        out = (BatchResultC * n)()
+        _check(lib.mk_sketch_batch_end(self.h, C.cast(out, C.c_void_p)), self.h)
+        res = []
+        for i in range(n):
+            comps = []
+            if out[i].status == MK_OK:
+                for c in range(out[i].r.component_num):
+                    comp = out[i].r.components[c]
+                    comps.append(np.ctypeslib.as_array(comp.ids, shape=(comp.n,)).copy() if comp.n else np.zeros(0, np.uint32))
+            res.append((out[i].status, out[i].alone, comps))
+        del keep
+        return res
 
     def finish_raw(self):
         r = ResultC()

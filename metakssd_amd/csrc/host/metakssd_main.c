@@ -709,7 +709,7 @@ static int parse_devices(const char *s, int *out, int cap) {
 
 static void usage(void) {
   fprintf(stderr,
-          "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D | --devices 0-7] [--engines 1..4] <fastq|fasta|dir>...\n"
+          "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D | --devices 0-7] [--engines 1..4] [--no-batch] <fastq|fasta|dir>...\n"
           "       metakssd dist -o <mco dir> <sketch dir>                      (stage II: inverted index)\n"
           "       metakssd dist -L <file.shuf> -r <genomes> -o <db dir>         (stage I + II)\n"
           "       metakssd dist -r <mco dir> -o <outdir> [-M 0|1] [-O 0|1|2] [-N n] [-D d] [--correction 0|1] [--keepskf] [-f skf] <sketch dir>\n"
@@ -1804,6 +1804,65 @@ static void *extra_engines_run(void *arg) {
   return NULL;
 }
 
+
+/* ---- a directory of genomes in batches (mk_sketch_batch_begin / _end) -------------------------------------------------------
+ * The reference sketches one file per OpenMP thread (command_dist.c:363-372).  Here consecutive small FASTA files travel to the
+ * device TOGETHER: reader threads lay the files of a batch into one pinned buffer at 1 KiB-aligned offsets (one host-to-device
+ * copy), the engine runs ONE launch sequence for all of them, and two batches are in flight while the readers fill the next.
+ * A file that cannot go that way (FASTQ, compressed, a pipe, larger than BATCH_FILE_MAX) is sketched alone, in its place in the
+ * input order.  --no-batch gives the file-by-file driver. */
+#define BATCH_FILE_MAX ((size_t)32 << 20)
+#define BATCH_BUFS 4
+static int g_no_batch = 0;
+static size_t g_batch_bytes = (size_t)128 << 20; /* --batch-mib: text per batch */
+static int g_batch_files = 256;                  /* --batch-files */
+
+typedef struct { int first, n, batch; } bjob;    /* files [first, first + n); batch: its number among the batches, -1 = one file alone */
+typedef struct {
+  strlist *files;
+  const uint64_t *fsize;
+  bjob *jobs; int njobs;
+  uint8_t *buf[BATCH_BUFS]; size_t bufcap;
+  uint64_t *foff;               /* offset of every file inside its batch's buffer */
+  int *left;                    /* per job: files not read yet */
+  int *failed;                  /* per file: errno of a failed read */
+  int released;                 /* batches whose buffer has been handed back */
+  int next_job, next_file;      /* reader cursor */
+  pthread_mutex_t mu;
+  pthread_cond_t cv_ready, cv_free;
+} breader;
+
+static void *breader_run(void *arg) {
+  breader *r = arg;
+  for (;;) {
+    pthread_mutex_lock(&r->mu);
+    while (r->next_job < r->njobs && (r->jobs[r->next_job].batch < 0 || r->next_file >= r->jobs[r->next_job].n)) { r->next_job++; r->next_file = 0; }
+    if (r->next_job >= r->njobs) { pthread_mutex_unlock(&r->mu); return NULL; }
+    const int j = r->next_job, k = r->next_file++;
+    const bjob *job = &r->jobs[j];
+    while (job->batch - r->released >= BATCH_BUFS) pthread_cond_wait(&r->cv_free, &r->mu); /* its buffer still belongs to an older batch */
+    pthread_mutex_unlock(&r->mu);
+    const int i = job->first + k;
+    uint8_t *dst = r->buf[job->batch % BATCH_BUFS] + r->foff[i];
+    int err = 0;
+    const int fd = open(r->files->v[i], O_RDONLY);
+    if (fd < 0) err = errno ? errno : EIO;
+    else {
+      uint64_t got = 0;
+      while (got < r->fsize[i]) {
+        const ssize_t n = pread(fd, dst + got, (size_t)(r->fsize[i] - got), (off_t)got);
+        if (n <= 0) { err = n < 0 && errno ? errno : EIO; break; } /* (a file that shrank since it was measured) */
+        got += (uint64_t)n;
+      }
+      close(fd);
+    }
+    pthread_mutex_lock(&r->mu);
+    r->failed[i] = err;
+    if (--r->left[j] == 0) pthread_cond_broadcast(&r->cv_ready);
+    pthread_mutex_unlock(&r->mu);
+  }
+}
+
 #ifndef MK_DEFAULT_ENGINES
 #define MK_DEFAULT_ENGINES 2
 #endif
@@ -1849,6 +1908,9 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--devices") && i + 1 < argc) ndev = parse_devices(argv[++i], devs, 64);
     else if (!strcmp(argv[i], "--engines") && i + 1 < argc) engines_per_gpu = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--allow-device-copies")) allow_copies = 1;
+    else if (!strcmp(argv[i], "--no-batch")) g_no_batch = 1; /* genome directories file by file (the driver of round 3) */
+    else if (!strcmp(argv[i], "--batch-mib") && i + 1 < argc) g_batch_bytes = (size_t)atoi(argv[++i]) << 20;
+    else if (!strcmp(argv[i], "--batch-files") && i + 1 < argc) g_batch_files = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--host-fasta")) g_host_fasta = 1; /* FASTA windows made on the host (mk_fasta_window), not on the device */
     else if (!strcmp(argv[i], "--quiet")) quiet = 1;
     else if (!strcmp(argv[i], "--component-sz") && i + 1 < argc) g_component_sz = atoi(argv[++i]);
@@ -1925,7 +1987,27 @@ int main(int argc, char **argv) {
    * tools/gpu_session_r3x.sh); at L2K11 (21 GB of tables per engine) at 2 600 / 4 450 / 2 100-4 700 / 1 700-2 000 -- creating 21 GB
    * engines beside a working one takes 0.04 to 1 s each, two pay, more do not.  --engines 1 turns it off */
   if (engines_per_gpu < 0 || engines_per_gpu > MAX_ENGINES_PER_GPU) die("--engines takes 1..%d", MAX_ENGINES_PER_GPU);
-  const int n_engines = (!shard_files && ndev <= 1 && files.n >= 8) ? (engines_per_gpu ? engines_per_gpu : MK_DEFAULT_ENGINES) : 1;
+  /* which inputs can travel in batches: plain FASTA files of moderate size, when the device parses the text and one engine works */
+  uint64_t *fsize = calloc((size_t)files.n, sizeof *fsize);
+  uint8_t *elig = calloc((size_t)files.n, 1);
+  if (!fsize || !elig) die("out of memory");
+  int n_elig = 0;
+  if (files.n > 1 && !g_no_batch && !g_host_fasta && !engines_per_gpu && !shard_files && ndev <= 1) {
+    if (g_batch_files < 1 || g_batch_files > (int)MK_BATCH_MAX_FILES) die("--batch-files takes 1..%u", MK_BATCH_MAX_FILES);
+    /* a batch's tables hold about five times the keys its files are expected to leave (text / 16^drlevel), 2^26 slots at most */
+    const size_t geo_cap = (((size_t)1 << 25) / 5u) << (4 * P.drlevel > 20 ? 20 : 4 * P.drlevel);
+    if (g_batch_bytes > geo_cap) g_batch_bytes = geo_cap;
+    if (g_batch_bytes > ((size_t)512 << 20)) g_batch_bytes = (size_t)512 << 20;
+    if (g_batch_bytes < ((size_t)1 << 20)) g_batch_bytes = (size_t)1 << 20;
+    for (int i = 0; i < files.n; i++) {
+      struct stat fst;
+      if (is_fastq(files.v[i]) || is_compressed(files.v[i]) || stat(files.v[i], &fst) != 0 || !S_ISREG(fst.st_mode)) continue;
+      if (fst.st_size <= 0 || (size_t)fst.st_size > BATCH_FILE_MAX || (size_t)fst.st_size > g_batch_bytes) continue;
+      fsize[i] = (uint64_t)fst.st_size; elig[i] = 1; n_elig++;
+    }
+  }
+  const int use_batch = n_elig >= 2;
+  const int n_engines = (!use_batch && !shard_files && ndev <= 1 && files.n >= 8) ? (engines_per_gpu ? engines_per_gpu : MK_DEFAULT_ENGINES) : 1;
   const int two_engines = n_engines > 1;
   extra_engines_t extra;
   memset(&extra, 0, sizeof extra);
@@ -1958,7 +2040,7 @@ int main(int argc, char **argv) {
   memset(&pf, 0, sizeof pf);
   pthread_t workers[PF_MAX_BUFS];
   int nworkers = 0;
-  if (files.n > 1 && nthreads > 1) {
+  if (files.n > 1 && nthreads > 1 && !use_batch) {
     pf.files = &files; pf.TL = P.TL;
     pf.qmin = kmerqlty;
     pf.koc_until = abundance ? first_nonfq : 0; /* files in front of this index are read the mt_shortreads2koc way */
@@ -1992,7 +2074,110 @@ int main(int argc, char **argv) {
   double t_finish = 0;
   job_opts jo = {&files, &P, abundance, uniq, first_nonfq, kmerocrs, kmerqlty, nthreads, quiet, &pf, nworkers};
   if (first_nonfq < files.n && abundance) printf("Warning: close abundance mode (-A) since non-fastq file input.\n");
-  if (shard_files) {
+  if (use_batch) {
+    /* jobs in input order: runs of eligible files cut into batches, every other file alone */
+    bjob *jobs = calloc((size_t)files.n, sizeof *jobs);
+    uint64_t *foff = calloc((size_t)files.n, sizeof *foff);
+    int *left = calloc((size_t)files.n, sizeof *left), *failed = calloc((size_t)files.n, sizeof *failed);
+    if (!jobs || !foff || !left || !failed) die("out of memory");
+    int njobs = 0, nbatches = 0;
+    size_t bufcap = 0;
+    for (int i = 0; i < files.n;) {
+      if (!elig[i]) { jobs[njobs].first = i; jobs[njobs].n = 1; jobs[njobs].batch = -1; njobs++; i++; continue; }
+      size_t at = 0;
+      int n = 0;
+      while (i + n < files.n && elig[i + n] && n < g_batch_files && (n == 0 || at + fsize[i + n] <= g_batch_bytes)) {
+        foff[i + n] = at;
+        at += ((size_t)fsize[i + n] + 1023u) & ~(size_t)1023u;
+        n++;
+      }
+      if (at > bufcap) bufcap = at;
+      jobs[njobs].first = i; jobs[njobs].n = n; jobs[njobs].batch = nbatches++; left[njobs] = n; njobs++;
+      i += n;
+    }
+    breader br;
+    memset(&br, 0, sizeof br);
+    br.files = &files; br.fsize = fsize; br.jobs = jobs; br.njobs = njobs; br.foff = foff; br.left = left; br.failed = failed;
+    br.bufcap = bufcap + 4096;
+    pthread_mutex_init(&br.mu, NULL);
+    pthread_cond_init(&br.cv_ready, NULL);
+    pthread_cond_init(&br.cv_free, NULL);
+    /* the buffers: mapped and touched now, so that the readers can start while the runtime and the engine come up; pinned when the
+     * first batch is handed over (see cli_sink_alloc) */
+    const int nbufs = nbatches < BATCH_BUFS ? nbatches : BATCH_BUFS;
+    size_t arena_len = 0;
+    uint8_t *arena = arena_map_unpinned((size_t)nbufs * br.bufcap, &arena_len);
+    if (!arena) die("out of memory (%zu bytes of batch buffers)", (size_t)nbufs * br.bufcap);
+    for (int b = 0; b < BATCH_BUFS; b++) br.buf[b] = arena + (size_t)(b % nbufs) * br.bufcap;
+    int arena_pinned = 0;
+    int nreaders = nthreads < 1 ? 1 : (nthreads > 64 ? 64 : nthreads);
+    pthread_t readers[64];
+    int started = 0;
+    for (int t = 0; t < nreaders; t++) if (pthread_create(&readers[started], NULL, breader_run, &br) == 0) started++;
+    if (!started) die("cannot start a thread: %s", strerror(errno));
+    c.nthreads = nthreads;
+    jo.nworkers = 0;
+    const int mode = uniq ? MK_MODE_UNIQ_SET : MK_MODE_SET;
+    mk_batch_file *bf = calloc((size_t)g_batch_files, sizeof *bf);
+    mk_batch_result *bres = calloc((size_t)g_batch_files, sizeof *bres);
+    if (!bf || !bres) die("out of memory");
+    int fly[2], nfly = 0, done_files = 0;
+    #define BATCH_END_OLDEST() do { \
+      const bjob *bj_ = &jobs[fly[0]]; \
+      const double tf_ = now_s(); \
+      rc = mk_sketch_batch_end(c.eng, bres); \
+      t_finish += now_s() - tf_; \
+      if (rc != MK_OK) die("mk_sketch_batch_end failed (%d): %s", rc, mk_last_error(c.eng)); \
+      for (int k_ = 0; k_ < bj_->n; k_++) { \
+        const char *path_ = files.v[bj_->first + k_]; \
+        if (bres[k_].status == MK_ERR_CROWDED) die("the context space is too crowd, try rerun the program using -k%d", P.k + 1); \
+        if (bres[k_].status == MK_ERR_FORMAT) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", path_); \
+        if (bres[k_].status != MK_OK) die("sketching %s failed (%d)", path_, bres[k_].status); \
+        rc = mk_sketchdir_add(sd, path_, &bres[k_].r); \
+        if (rc != MK_OK) die("writing sketch for %s failed (%d)", path_, rc); \
+        if (!quiet) printf("%d/%d decomposing %s\r", ++done_files, files.n, path_); \
+      } \
+      pthread_mutex_lock(&br.mu); br.released++; pthread_cond_broadcast(&br.cv_free); pthread_mutex_unlock(&br.mu); \
+      fly[0] = fly[1]; nfly--; \
+    } while (0)
+    for (int j = 0; j < njobs; j++) {
+      const bjob *bj = &jobs[j];
+      if (bj->batch < 0) { /* one file alone, in its place: everything in front of it comes home first */
+        while (nfly) BATCH_END_OLDEST();
+        mk_result res;
+        sketch_one_file(&c, &jo, bj->first, &res, &t_finish);
+        rc = mk_sketchdir_add(sd, files.v[bj->first], &res);
+        if (rc != MK_OK) die("writing sketch for %s failed (%d)", files.v[bj->first], rc);
+        mk_result_release(c.eng, &res);
+        if (!quiet) printf("%d/%d decomposing %s\r", ++done_files, files.n, files.v[bj->first]);
+        continue;
+      }
+      pthread_mutex_lock(&br.mu);
+      while (left[j] > 0) pthread_cond_wait(&br.cv_ready, &br.mu);
+      pthread_mutex_unlock(&br.mu);
+      for (int k = 0; k < bj->n; k++) {
+        const int i = bj->first + k;
+        if (failed[i]) die("%s: %s", files.v[i], strerror(failed[i]));
+        bf[k].text = br.buf[bj->batch % BATCH_BUFS] + foff[i];
+        bf[k].n = fsize[i];
+      }
+      (void)engine_get(&c);
+      if (!arena_pinned) { /* the runtime is up now */
+        if (mk_host_register(arena, arena_len) != MK_OK) die("pinning the batch buffers failed: %s", mk_last_error(NULL));
+        arena_pinned = 1;
+      }
+      if (nfly == 2) BATCH_END_OLDEST();
+      if (c.t_first_push == 0) c.t_first_push = now_s() - g_t0;
+      rc = mk_sketch_batch_begin(c.eng, mode, bf, (uint32_t)bj->n);
+      if (rc != MK_OK) die("mk_sketch_batch_begin failed (%d): %s", rc, mk_last_error(c.eng));
+      c.t_last_push = now_s() - g_t0;
+      fly[nfly++] = j;
+    }
+    while (nfly) BATCH_END_OLDEST();
+    #undef BATCH_END_OLDEST
+    for (int t = 0; t < started; t++) pthread_join(readers[t], NULL);
+    (void)engine_get(&c);
+  } else if (shard_files) {
     /* several engines, whole files each */
     shard_driver *drv = calloc((size_t)ndev, sizeof *drv);
     file_result *results = calloc((size_t)files.n, sizeof *results);

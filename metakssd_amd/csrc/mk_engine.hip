@@ -8,7 +8,9 @@
 #include "metakssd_hip.h"
 #include "mk_kernels.hip.h"
 #include "mk_stream.hip.h"
+#include "mk_batch.hip.h"
 
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -62,8 +64,8 @@ struct mk_engine {
   int front_bits_opt = -1;          /* MK_OPT_FRONT_BITS */
   bool big_maybe_dirty = true;      /* the S-slot table may hold keys: begin clears it (false: known to be all zero) */
   unsigned long long *h_counters = nullptr; /* pinned mirror */
-  unsigned long long *h_setup = nullptr, *d_setup = nullptr; /* start-up: number of accepted substrings found on the device */
-  uint32_t setup_expect = 0;
+  bool init_queued = true; /* mk_engine_create's uploads and kernels may still be running on own_stream (it does not wait for them) */
+  mk_accept_pair *d_pairs = nullptr;
   /* result arrays: pinned host memory that the dump kernels write directly (it is mapped into the device's address
    * space), so that a finish needs one host synchronisation and no separate result copy */
   uint32_t *h_ids = nullptr;
@@ -120,6 +122,13 @@ struct mk_engine {
   uint64_t fa_rows_done = 0; /* virtual rows scanned so far in this sketch = ordinal of the next one */
   bool fa_used = false, fa_final = false;
   uint32_t fa_pitch = 0;     /* this sketch's row step (0: not chosen yet) */
+
+  /* batches of small inputs (mk_sketch_batch_begin / _end): three contexts, two batches in flight, the third holds the results
+   * handed out last */
+  struct mk_bctx *bctx[3] = {nullptr, nullptr, nullptr};
+  uint64_t batch_begun = 0, batch_ended = 0;
+  int batch_tb_opt = 0;                /* MK_OPT_BATCH_TAB_BITS: 0 = by the largest file of the batch */
+  const mk_batch_dev *cur_batch = nullptr; /* set around the scan launches of a batch */
 
   int mode = -1;
   uint32_t min_occ = 1; /* MK_MODE_OCC_SET: dump keys seen at least this often */
@@ -241,52 +250,47 @@ static mk_evpair mk_ev_get(mk_engine *e) {
   return p;
 }
 
-/* the accept list and bitmap were made on the device from the uploaded table; a table that is not a permutation (the
- * reference uses such a table as it is) takes the general host pass */
-static int mk_setup_finish(mk_engine *e) {
-  const mk_params *p = &e->P;
-  const uint32_t found = (uint32_t)(e->h_setup[0] & 0xffffffffu);
-  if (found == e->setup_expect) { e->n_accept = found; return MK_OK; }
-  const uint64_t L = p->shuf_len;
-  const uint32_t dbits = 4u * (uint32_t)p->subk;
-  std::vector<uint32_t> acc;
-  std::vector<uint32_t> bits((size_t)((L + 31) / 32), 0u);
-  for (uint64_t d = 0; d < L; d++) {
-    int32_t v = p->shuf_table[d];
-    if (v >= p->dim_start && v < p->dim_end) {
-      bits[d >> 5] |= 1u << (d & 31u);
-      acc.push_back((uint32_t)d);
-      uint32_t n = ~(uint32_t)d, rr = 0; /* reverse the 2-bit groups of the complement within dbits */
-      for (uint32_t i = 0; i < dbits; i += 2) rr |= ((n >> i) & 3u) << (dbits - 2u - i);
-      acc.push_back(rr);
-    }
+/* the host's pass over the .shuf table: the inner substrings d with dim_start <= shuf[d] < dim_end (iseq2comem.c:693-694).  Any
+ * table is taken as it is (the reference does not require a permutation).  Runs on a few threads beside the runtime's start-up. */
+struct mk_accept_job {
+  const int32_t *t;
+  uint64_t lo, hi;
+  int32_t ds, de;
+  std::vector<mk_accept_pair> out;
+  pthread_t th;
+  bool started;
+};
+static void *mk_accept_run(void *arg) {
+  mk_accept_job *j = (mk_accept_job *)arg;
+  const int32_t *t = j->t;
+  const uint32_t ds = (uint32_t)j->ds, span = (uint32_t)(j->de - j->ds);
+  for (uint64_t d = j->lo; d < j->hi; d++) {
+    const int32_t v = t[d];
+    if ((uint32_t)v - ds < span) j->out.push_back(mk_accept_pair{(uint32_t)d, v}); /* ds <= v < de in one compare */
   }
-  e->n_accept = (uint32_t)acc.size();
-  hipFree(e->d_accept); e->d_accept = nullptr;
-  MK_HIP(e, hipMalloc(&e->d_accept, (acc.size() + 1) * sizeof(uint32_t)));
-  if (!acc.empty()) MK_HIP(e, hipMemcpy(e->d_accept, acc.data(), acc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  MK_HIP(e, hipMemcpy(e->d_accept_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  return MK_OK;
+  return nullptr;
 }
+
+static void mk_bctx_free(struct mk_bctx *c);
 
 extern "C" int mk_engine_destroy(mk_engine *e) {
   if (!e) return MK_ERR_ARG;
   hipSetDevice(e->device);
   hipDeviceSynchronize();
-  hipFree(e->d_setup);
+  hipFree(e->d_pairs);
   hipFree(e->d_cand); hipFree(e->d_cand_count);
   hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_accept_bits); hipFree(e->d_tab); hipFree(e->d_front); hipFree(e->d_front_desc); hipFree(e->d_slot);
   hipFree(e->d_dirty_acc); hipFree(e->d_dirty_slot); hipFree(e->d_list_acc); hipFree(e->d_list_slot); hipFree(e->d_nlist);
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters);
   hipFree(e->d_kl); hipFree(e->d_kl_buckets);
+  for (mk_bctx *c : e->bctx) mk_bctx_free(c);
   hipFree(e->d_res_ids); hipFree(e->d_res_cnt); hipFree(e->d_snap);
   if (e->h_snap) hipHostFree(e->h_snap);
   if (e->res_stream) hipStreamDestroy(e->res_stream);
   if (e->ev_res) hipEventDestroy(e->ev_res);
   hipFree(e->d_text); hipFree(e->d_stream); hipFree(e->d_stream_tmp); hipFree(e->d_fa_sum); hipFree(e->d_fa_state);
   if (e->h_fa_state) hipHostFree(e->h_fa_state);
-  if (e->h_comp_totals) hipHostFree(e->h_comp_totals);
   for (int i = 0; i < MK_TICKETS; i++) if (e->ev_ticket[i]) hipEventDestroy(e->ev_ticket[i]);
   if (e->h_counters) hipHostFree(e->h_counters);
   if (e->h_ids) hipHostFree(e->h_ids);
@@ -333,7 +337,9 @@ static int mk_config_cand(mk_engine *e, uint32_t cap) {
   e->cand_cap = cap;
   MK_HIP(e, hipMalloc(&e->d_cand, (size_t)e->cand_slots * (e->cand_cap + 1) * sizeof(uint4)));
   MK_HIP(e, hipMalloc(&e->d_cand_count, (size_t)e->cand_slots * sizeof(uint32_t)));
-  MK_HIP(e, hipMemset(e->d_cand_count, 0, (size_t)e->cand_slots * sizeof(uint32_t)));
+  /* (the scan kernel writes every count its resolve pass reads; the fill only keeps the unused ones defined) */
+  hipLaunchKernelGGL(mk_fill16_kernel, dim3(4), dim3(256), 0, e->stream, (uint4 *)e->d_cand_count, (unsigned long long)e->cand_slots / 4ull, 0u);
+  MK_HIP(e, hipGetLastError());
   return MK_OK;
 }
 
@@ -376,7 +382,8 @@ static int mk_config_front(mk_engine *e, int bits) {
   { uint32_t sb = 0; while ((1ull << sb) < S) sb++; e->front.shift = sb > (uint32_t)bits ? sb - (uint32_t)bits : 0u; } /* (S-1) >> shift < 2^bits */
   e->front.mask = (uint32_t)(e->front_slots - 1);
   e->front.limit = (uint32_t)(e->front_slots / 4); /* closed to new keys from a quarter full at the start of a launch */
-  MK_HIP(e, hipMemcpy(e->d_front_desc, &e->front, sizeof(mk_front), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(mk_front_store_kernel, dim3(1), dim3(1), 0, e->stream, e->d_front_desc, e->front); /* (by value: nothing of the host's is read later) */
+  MK_HIP(e, hipGetLastError());
   e->tab.fr = e->d_front_desc;
   return MK_OK;
 }
@@ -396,6 +403,40 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
 #ifdef MK_TUNING
   double tick_ = mk_tick_now();
 #endif
+  /* The accepted inner substrings are found on the host, by up to four threads, WHILE the runtime creates the engine's queue
+   * (20 ms of every start-up on this runtime): the pass over the 64 MiB table then costs nothing, and neither the table nor
+   * anything made from it has to be waited for -- mk_engine_create returns without a single stream synchronisation. */
+  const uint64_t L = p->shuf_len;
+  enum { NT = 4 };
+  mk_accept_job job[NT];
+  const int nt = L >= (1ull << 20) ? NT : 1;
+  for (int t = 0; t < nt; t++) {
+    job[t].t = p->shuf_table; job[t].lo = L / nt * (uint64_t)t; job[t].hi = t + 1 == nt ? L : L / nt * (uint64_t)(t + 1);
+    job[t].ds = p->dim_start; job[t].de = p->dim_end;
+    job[t].started = nt > 1 && pthread_create(&job[t].th, nullptr, mk_accept_run, &job[t]) == 0;
+  }
+  /* ... and one more thread makes the runtime load this library's code object for the device (4 ms at the first launch
+   * otherwise), also beside the queue creation */
+  struct warm_job { int device; pthread_t th; bool started; } warm{e->device, {}, false};
+  warm.started = pthread_create(&warm.th, nullptr, [](void *arg) -> void * {
+    warm_job *w = (warm_job *)arg;
+    hipFuncAttributes attr;
+    if (hipSetDevice(w->device) != hipSuccess || hipFuncGetAttributes(&attr, (const void *)mk_fill16_kernel) != hipSuccess) (void)hipGetLastError();
+    return nullptr;
+  }, &warm) == 0;
+  auto join_accept = [&]() {
+    for (int t = 0; t < nt; t++) {
+      if (job[t].started) { pthread_join(job[t].th, nullptr); job[t].started = false; }
+      else if (job[t].t) mk_accept_run(&job[t]); /* a small table, or a thread that did not start: here */
+      job[t].t = nullptr;
+    }
+  };
+  auto join_all = [&]() {
+    join_accept();
+    if (warm.started) { pthread_join(warm.th, nullptr); warm.started = false; }
+  };
+  struct joiner { decltype(join_all) &f; ~joiner() { f(); } } join_guard{join_all}; /* no thread outlives an early return */
+
   MK_HIP(e, hipSetDevice(e->device));
   MK_HIP(e, hipDeviceGetAttribute(&e->num_cu, hipDeviceAttributeMultiprocessorCount, e->device)); /* hipGetDeviceProperties takes 30 ms */
   MK_TICK("device");
@@ -426,35 +467,48 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   /* .shuf table + the filter list B = A u revcomp(A), A = accepted inner substrings (iseq2comem.c:693-694).
    * The inner substring (2*subk bases) sits in the middle of the k-mer, so the reverse-complement k-mer's
    * inner substring is the reverse complement of the forward one: see mk_kernels.hip.h, "LDS filter".
-   * The table goes up asynchronously out of the caller's memory (registered for the duration of the copy) and the list
-   * and the accept bitmap are made from it on the device: 64 MiB through a pageable copy plus a host pass over 16 M
-   * entries cost 50 ms of every start-up. */
-  const uint64_t L = p->shuf_len;
+   * Only the accepted (d, shuf[d]) pairs go to the device (mk_accept_scatter_kernel): the resolve kernel reads shuf[d] behind a
+   * set accept bit and nowhere else, so the rest of the device's table stays unwritten. */
   const uint32_t dbits = 4u * (uint32_t)p->subk;
-  const size_t bit_words = (size_t)((L + 31) / 32);
-  const uint32_t expect = 2u * (uint32_t)(p->dim_end - p->dim_start); /* a permutation has exactly this many */
+  const size_t bit_bytes = ((size_t)((L + 31) / 32) * sizeof(uint32_t) + 15u) & ~(size_t)15u;
   MK_HIP(e, hipMalloc(&e->d_shuf, L * sizeof(int32_t)));
-  MK_HIP(e, hipMalloc(&e->d_accept_bits, bit_words * sizeof(uint32_t)));
-  MK_HIP(e, hipMalloc(&e->d_accept, ((size_t)expect + 2) * sizeof(uint32_t)));
+  MK_HIP(e, hipMalloc(&e->d_accept_bits, bit_bytes));
   MK_HIP(e, hipMalloc(&e->d_counters, 8 * sizeof(unsigned long long)));
-  MK_HIP(e, hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->own_stream));
-  MK_HIP(e, hipMalloc(&e->d_setup, sizeof(unsigned long long)));
-  MK_HIP(e, hipHostMalloc((void **)&e->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault));
-  e->h_setup = e->h_counters + 8;
   MK_TICK("events + first allocs");
-  /* 1.2 ms when the caller has pinned the table (mk_host_register), about 20 ms through the runtime's staging buffers
-   * when it is ordinary memory; either way the table is free again when mk_engine_create returns */
-  MK_HIP(e, hipMemcpyAsync(e->d_shuf, p->shuf_table, L * sizeof(int32_t), hipMemcpyHostToDevice, e->own_stream));
-  MK_HIP(e, hipMemsetAsync(e->d_accept_bits, 0, bit_words * sizeof(uint32_t), e->own_stream));
-  MK_HIP(e, hipMemsetAsync(e->d_setup, 0, sizeof(unsigned long long), e->own_stream));
-  hipLaunchKernelGGL(mk_accept_build_kernel, dim3((unsigned)e->num_cu * 8u), dim3(256), 0, e->own_stream, (const int32_t *)e->d_shuf, L,
-                     p->dim_start, p->dim_end, dbits, e->d_accept, expect, (uint32_t *)e->d_setup, e->d_accept_bits);
+  join_accept();
+  size_t npairs = 0;
+  for (int t = 0; t < nt; t++) npairs += job[t].out.size();
+  if (npairs > (1u << 30)) return mk_fail(e, MK_ERR_ARG, "mk_engine_create: %zu accepted inner substrings", npairs);
+  e->n_accept = (uint32_t)(2u * npairs);
+  /* one pinned block: the counters' mirror, the component sizes, and the accepted pairs on their way up (a pageable source
+   * costs the first upload 8 ms of staging set-up) */
+  const size_t fixed = (16 + MK_MAX_COMP) * sizeof(unsigned long long);
+  MK_HIP(e, hipHostMalloc((void **)&e->h_counters, fixed + (npairs + 1) * sizeof(mk_accept_pair), hipHostMallocDefault));
+  e->h_comp_totals = e->h_counters + 16;
+  mk_accept_pair *hp = (mk_accept_pair *)((uint8_t *)e->h_counters + fixed);
+  {
+    size_t at = 0;
+    for (int t = 0; t < nt; t++) { if (!job[t].out.empty()) memcpy(hp + at, job[t].out.data(), job[t].out.size() * sizeof(mk_accept_pair)); at += job[t].out.size(); }
+  }
+  MK_TICK("accept pass joined + pinned block");
+  MK_HIP(e, hipMalloc(&e->d_accept, ((size_t)e->n_accept + 2) * sizeof(uint32_t)));
+  MK_HIP(e, hipMalloc(&e->d_pairs, (npairs + 1) * sizeof(mk_accept_pair)));
+  if (warm.started) { pthread_join(warm.th, nullptr); warm.started = false; }
+  MK_TICK("code object");
+  hipLaunchKernelGGL(mk_fill16_kernel, dim3((unsigned)e->num_cu * 2u), dim3(256), 0, e->own_stream, (uint4 *)e->d_accept_bits,
+                     (unsigned long long)(bit_bytes / 16u), 0u);
+  hipLaunchKernelGGL(mk_fill16_kernel, dim3(1), dim3(64), 0, e->own_stream, (uint4 *)e->d_counters, 4ull, 0u);
   MK_HIP(e, hipGetLastError());
-  MK_HIP(e, hipMemcpyAsync(e->h_setup, e->d_setup, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->own_stream));
-  MK_HIP(e, hipStreamSynchronize(e->own_stream));
-  e->setup_expect = expect;
-  { int rc = mk_setup_finish(e); if (rc) return rc; }
-  MK_TICK("shuf upload + accept");
+  MK_TICK("first launches");
+  if (npairs) {
+    MK_HIP(e, hipMemcpyAsync(e->d_pairs, hp, npairs * sizeof(mk_accept_pair), hipMemcpyHostToDevice, e->own_stream));
+    uint64_t blocks = (npairs + 255) / 256;
+    if (blocks > (uint64_t)e->num_cu * 8u) blocks = (uint64_t)e->num_cu * 8u;
+    hipLaunchKernelGGL(mk_accept_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, e->own_stream, (const mk_accept_pair *)e->d_pairs,
+                       (uint32_t)npairs, dbits, e->d_shuf, e->d_accept_bits, e->d_accept);
+    MK_HIP(e, hipGetLastError());
+  }
+  MK_TICK("accept upload + scatter");
   /* LDS filter: 2^bm_bits words of 32 bits indexed by the inner substring's bits 10.. (at most 64 KiB) */
   {
     int wb = 4 * p->subk - 10;
@@ -467,10 +521,12 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   e->tab.kc = (unsigned long long *)e->d_tab;
   e->tab.ordinv = e->tab.kc + S;
   MK_HIP(e, hipMalloc(&e->d_slot, S * sizeof(uint32_t)));
+  MK_TICK("table + layout table");
   /* sparse bookkeeping from 2^26 slots up (L2K11: 537 M slots for a genome's few thousand keys);
    * mk_engine_set_option(MK_OPT_SPARSE) forces it off/on (the tests run the small tables both ways) */
   { int rc = mk_config_sparse(e, S >= (1ull << 26)); if (rc) return rc; }
   { int rc = mk_config_front(e, -1); if (rc) return rc; }
+  MK_TICK("sparse + front");
   /* the distinct-key list: hashlimit+1 entries suffice for KOC/SET, MK_MODE_OCC_SET may fill the table (fastq2co never aborts).
    * With sparse bookkeeping (537 M slots at L2K11: 10.7 GB of list for sketches of a few thousand keys) it starts at 32 M
    * entries and grows when a compaction counts more (mk_dist_fit) */
@@ -479,11 +535,10 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   if (p->component_num > (int)MK_MAX_COMP) return mk_fail(e, MK_ERR_ARG, "component_num %d > %u", p->component_num, MK_MAX_COMP);
   MK_HIP(e, hipMalloc(&e->d_chunk, (size_t)e->nchunks * (size_t)p->component_num * sizeof(uint32_t)));
   MK_HIP(e, hipMalloc(&e->d_comp_totals, MK_MAX_COMP * sizeof(unsigned long long)));
-  MK_HIP(e, hipHostMalloc((void **)&e->h_comp_totals, MK_MAX_COMP * sizeof(unsigned long long), hipHostMallocDefault));
   e->tab.err = (uint32_t *)(e->d_counters + 2);
   e->comps.resize((size_t)p->component_num);
   e->cand_slots = (uint32_t)e->num_cu * 16u; /* at most 16 waves per workgroup, one workgroup per CU */
-  MK_TICK("tables");
+  MK_TICK("key list + dump tables");
   { int rc = mk_config_cand(e, 8192u); if (rc) return rc; }
   MK_TICK("candidate buffers");
   for (int i = 0; i < MK_TICKETS; i++) MK_HIP(e, hipEventCreateWithFlags(&e->ev_ticket[i], hipEventDisableTiming));
@@ -545,6 +600,11 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
     case MK_OPT_DIRECT_HOST:
       e->direct_host = value != 0;
       return MK_OK;
+    case MK_OPT_BATCH_TAB_BITS:
+      if (value != 0 && (value < 9 || value > 22)) return mk_fail(e, MK_ERR_ARG, "MK_OPT_BATCH_TAB_BITS takes 0 (by file size) or 9..22");
+      if (e->batch_begun != e->batch_ended) return mk_fail(e, MK_ERR_STATE, "MK_OPT_BATCH_TAB_BITS while a batch is in flight");
+      e->batch_tb_opt = (int)value;
+      return MK_OK;
     case MK_OPT_KEYLIST_CAP: { /* sparse bookkeeping only: the list is grown by the finish / export that needs more */
       if (!e->sparse) return mk_fail(e, MK_ERR_ARG, "MK_OPT_KEYLIST_CAP needs sparse bookkeeping (the dense passes do not grow the key list)");
       if (value < 16 || (uint64_t)value > e->kp.S) return mk_fail(e, MK_ERR_ARG, "MK_OPT_KEYLIST_CAP takes 16 .. hashsize entries");
@@ -572,6 +632,11 @@ extern "C" int mk_engine_set_stream(mk_engine *e, void *hip_stream) {
     MK_HIP(e, hipSetDevice(e->device));
     int rc = mk_flush_region(e);
     if (rc) return rc;
+  }
+  if (e->init_queued) { /* what mk_engine_create queued on the engine's own stream is not ordered with any other stream */
+    MK_HIP(e, hipSetDevice(e->device));
+    MK_HIP(e, hipStreamSynchronize(e->own_stream));
+    e->init_queued = false;
   }
   /* NULL is a real stream (HIP's default stream, which is what torch.cuda.current_stream() usually is): it must
    * not mean "keep the engine's own stream", or caller-side ordering silently disappears */
@@ -776,6 +841,8 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   a.kp = e->kp;
   a.tab = e->tab;
   a.cand = e->d_cand; a.cand_count = e->d_cand_count; a.cand_cap = e->cand_cap;
+  a.batch = e->cur_batch;
+  if (a.batch) a.tab.fr = nullptr; /* a batch has its own tables: nothing of this launch touches the engine's */
   /* one-pass staging needs exactly two equal column blocks (stride == 2*CB) on the 16-byte path */
   const bool onepass = e->tune_onepass && vec && a.ncb == 2 && stride == 2u * a.CB && a.ppr <= 5u;
   /* workgroup size: as many waves as the LDS budget (filter + per-wave tile and queue) admits */
@@ -800,7 +867,7 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   }
 #endif
 
-  e->big_maybe_dirty = true; /* until a counter copy says otherwise (mk_check_counters) */
+  if (!a.batch) e->big_maybe_dirty = true; /* until a counter copy says otherwise (mk_check_counters) */
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   hipError_t r;
@@ -843,7 +910,7 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
     MK_HIP(e, hipGetLastError());
     if (e->profiling) { MK_HIP(e, hipEventRecord(ev2.b, e->stream)); e->ev_resolve.push_back(ev2); }
   }
-  e->compacted = false; e->count_queued = false;
+  if (!a.batch) { e->compacted = false; e->count_queued = false; }
   return MK_OK;
 }
 
@@ -1662,4 +1729,312 @@ extern "C" int mk_synth_rows_device(int device, void *hip_stream, uint64_t seed,
                      stride, rows_dev);
   hipError_t r = hipGetLastError();
   return r == hipSuccess ? MK_OK : mk_fail(nullptr, MK_ERR_HIP, "synth launch: %s", hipGetErrorString(r));
+}
+
+/* ---- batches of small inputs (mk_batch.hip.h) -------------------------------------------------------------------------------
+ * run_stageI()'s team over files (command_dist.c:363-372) as ONE launch sequence per batch of files. */
+struct mk_dbuf { void *p = nullptr; size_t cap = 0; };
+struct mk_bctx {
+  mk_dbuf text, stream, sum, desc, zero, map, list, bcur;
+  void *h_desc = nullptr; size_t h_desc_cap = 0;   /* pinned: what goes up in one small copy (descriptor, files, seg0s, row0s) */
+  void *h_stat = nullptr; size_t h_stat_cap = 0;   /* pinned: what comes back first (per-file status, per-component sizes, totals) */
+  uint32_t *h_ids = nullptr; size_t h_ids_cap = 0; /* pinned: the ids */
+  hipEvent_t ev_stat = nullptr;
+  mk_batch_dev hb{};
+  int mode = 0;
+  uint32_t nfiles = 0;
+  size_t stat_bytes = 0;
+  std::vector<mk_batch_file> files;
+  std::vector<mk_component> comps;              /* [nfiles * component_num] */
+  std::vector<std::vector<uint32_t>> alone_ids; /* ids of the files that were sketched alone */
+};
+
+static int mk_dbuf_fit(mk_engine *e, mk_dbuf &b, size_t need) {
+  if (b.p && need <= b.cap) return MK_OK;
+  hipFree(b.p);
+  b.p = nullptr; b.cap = 0;
+  const size_t cap = need + need / 4 + 4096;
+  MK_HIP(e, hipMalloc(&b.p, cap));
+  b.cap = cap;
+  return MK_OK;
+}
+static int mk_pinned_fit(mk_engine *e, void **p, size_t *cap, size_t need) {
+  if (*p && need <= *cap) return MK_OK;
+  if (*p) hipHostFree(*p);
+  *p = nullptr; *cap = 0;
+  const size_t c = need + need / 4 + 4096;
+  MK_HIP(e, hipHostMalloc(p, c, hipHostMallocDefault));
+  *cap = c;
+  return MK_OK;
+}
+static void mk_bctx_free(mk_bctx *c) {
+  if (!c) return;
+  for (mk_dbuf *b : {&c->text, &c->stream, &c->sum, &c->desc, &c->zero, &c->map, &c->list, &c->bcur}) hipFree(b->p);
+  if (c->h_desc) hipHostFree(c->h_desc);
+  if (c->h_stat) hipHostFree(c->h_stat);
+  if (c->h_ids) hipHostFree(c->h_ids);
+  if (c->ev_stat) hipEventDestroy(c->ev_stat);
+  delete c;
+}
+static size_t mk_up16(size_t v) { return (v + 15u) & ~(size_t)15u; }
+
+/* rows one scan launch may take so that a scan wave's candidate buffer is expected to stay below half its capacity: the share
+ * of bases whose window passes the LDS filter is the accepted share of the subspace (both strands) plus the filter's false
+ * positives (three bits per entry in 32 * bm_words bits; the tuned kernels' pair filter: measured 2 % of the 8-base windows) */
+static uint64_t mk_rows_per_launch(const mk_engine *e, uint32_t row_bases, bool tuned) {
+  const double fill = 1.0 - exp(-3.0 * (double)e->n_accept / (32.0 * (double)(1u << e->bm_bits)));
+  const double per_base = tuned ? 0.02 / 8.0 : (double)e->n_accept / (double)e->P.shuf_len + fill * fill * fill;
+  const double per_row = per_base * row_bases + 1e-9;
+  const uint64_t waves = (uint64_t)e->num_cu * (uint64_t)(e->tune_threads / 64);
+  double rows = 0.5 * (double)e->cand_cap / per_row * (double)waves;
+  if (rows < 64.0 * (double)waves) rows = 64.0 * (double)waves;
+  if (rows > (double)(1ull << 30)) rows = (double)(1ull << 30);
+  return (uint64_t)rows / 64u * 64u;
+}
+
+extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles) {
+  if (!e || !files) return MK_ERR_ARG;
+  if (mode != MK_MODE_SET && mode != MK_MODE_UNIQ_SET) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: MK_MODE_SET or MK_MODE_UNIQ_SET");
+  if (nfiles < 1 || nfiles > MK_BATCH_MAX_FILES) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: 1 .. %u files", MK_BATCH_MAX_FILES);
+  if (e->begun) return mk_fail(e, MK_ERR_STATE, "mk_sketch_batch_begin inside a sketch (between begin and finish)");
+  if (e->batch_begun - e->batch_ended >= 2) return mk_fail(e, MK_ERR_STATE, "mk_sketch_batch_begin: two batches are in flight (mk_sketch_batch_end first)");
+  if (e->P.TL + MK_FA_PITCH > 4000u) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: k-mer too long for the stream rows");
+  uint64_t total = 0, nmax = 0;
+  for (uint32_t i = 0; i < nfiles; i++) {
+    if (!files[i].text && files[i].n) return MK_ERR_ARG;
+    if (files[i].n > MK_BATCH_FILE_MAX) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: file %u has %llu bytes (at most %llu)", i, (unsigned long long)files[i].n, (unsigned long long)MK_BATCH_FILE_MAX);
+    total += files[i].n;
+    if (files[i].n > nmax) nmax = files[i].n;
+  }
+  if (total > MK_BATCH_TEXT_MAX) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: %llu bytes of text (at most %llu)", (unsigned long long)total, (unsigned long long)MK_BATCH_TEXT_MAX);
+  MK_HIP(e, hipSetDevice(e->device));
+  const int ci = (int)(e->batch_begun % 3u);
+  if (!e->bctx[ci]) e->bctx[ci] = new mk_bctx();
+  mk_bctx *c = e->bctx[ci];
+  if (!c->ev_stat) MK_HIP(e, hipEventCreateWithFlags(&c->ev_stat, hipEventDisableTiming));
+  const uint32_t C = (uint32_t)e->P.component_num;
+  const uint32_t TL = (uint32_t)e->P.TL, pitch = MK_FA_PITCH_SMALL, rowlen = pitch + TL - 1u;
+  const uint32_t width = (rowlen + 1u + 15u) & ~15u;
+
+  /* ---- geometry of the batch: where every file's text, stream region, segments and rows lie */
+  /* one copy for all texts when they already lie at 1 KiB-aligned, ascending distances from the first (a pinned buffer filled file
+   * by file); otherwise they are packed file by file */
+  bool one_copy = true;
+  for (uint32_t i = 1; i < nfiles && one_copy; i++) {
+    if (files[i].text < files[i - 1].text + files[i - 1].n) one_copy = false;
+    else if ((size_t)(files[i].text - files[0].text) % MK_FA_SEG) one_copy = false;
+  }
+  if (one_copy && (uint64_t)(files[nfiles - 1].text - files[0].text) + files[nfiles - 1].n > total + (uint64_t)nfiles * MK_FA_SEG + ((uint64_t)64 << 20)) one_copy = false;
+  const size_t desc_bytes = mk_up16(sizeof(mk_batch_dev)) + mk_up16((size_t)nfiles * sizeof(mk_bfile)) + 2 * mk_up16(((size_t)nfiles + 1) * 4);
+  int rc = mk_pinned_fit(e, &c->h_desc, &c->h_desc_cap, desc_bytes);
+  if (rc) return rc;
+  rc = mk_dbuf_fit(e, c->desc, desc_bytes);
+  if (rc) return rc;
+  uint8_t *hd = (uint8_t *)c->h_desc, *dd = (uint8_t *)c->desc.p;
+  mk_batch_dev *hb = (mk_batch_dev *)hd;
+  mk_bfile *hf = (mk_bfile *)(hd + mk_up16(sizeof(mk_batch_dev)));
+  uint32_t *hseg0 = (uint32_t *)((uint8_t *)hf + mk_up16((size_t)nfiles * sizeof(mk_bfile)));
+  uint32_t *hrow0 = (uint32_t *)((uint8_t *)hseg0 + mk_up16(((size_t)nfiles + 1) * 4));
+  uint64_t toff = 0, soff = 0;
+  uint32_t seg = 0;
+  for (uint32_t i = 0; i < nfiles; i++) {
+    mk_bfile &f = hf[i];
+    f.text_off = one_copy ? (uint64_t)(files[i].text - files[0].text) : toff;
+    f.text_len = files[i].n;
+    toff = f.text_off + ((f.text_len + MK_FA_SEG - 1) / MK_FA_SEG) * MK_FA_SEG;
+    f.stream_off = soff;
+    f.stream_cap = (f.text_len + 1u + pitch - 1u) / pitch * pitch; /* > text_len: at least one '\n' closes the region */
+    soff += f.stream_cap;
+    f.seg0 = seg;
+    f.nseg = (uint32_t)((f.text_len + MK_FA_SEG - 1) / MK_FA_SEG);
+    if (f.nseg == 0) f.nseg = 1; /* an empty file still has a region to close */
+    seg += f.nseg;
+    f.row0 = (uint32_t)(f.stream_off / pitch);
+    f.nrow = (uint32_t)(f.stream_cap / pitch);
+    hseg0[i] = f.seg0;
+    hrow0[i] = f.row0;
+  }
+  const uint64_t text_span = one_copy ? (uint64_t)(files[nfiles - 1].text - files[0].text) + files[nfiles - 1].n : toff;
+  const uint64_t total_rows = soff / pitch;
+  const uint32_t nseg_total = seg;
+  hseg0[nfiles] = nseg_total;
+  hrow0[nfiles] = (uint32_t)total_rows;
+  if (total_rows >= (1ull << 31)) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: too many rows");
+
+  /* ---- tables: 2^tb slots per file, about five times the keys the largest file is expected to leave (its k-mers / 16^drlevel) */
+  uint32_t tb = 10;
+  {
+    const uint64_t est = (nmax >> (4u * (uint32_t)e->P.drlevel)) * 5u;
+    while (tb < 22u && (1ull << tb) < est) tb++;
+    if (e->batch_tb_opt) tb = (uint32_t)e->batch_tb_opt;
+    while (tb > 9u && ((uint64_t)nfiles << tb) > (1ull << 26)) tb--; /* (files that do not fit then are sketched alone) */
+  }
+  const uint64_t N = (uint64_t)nfiles << tb;
+  /* buckets of the ordered dump: about 2^tb / 32 per file, so that a bucket holds a few keys at the expected load */
+  uint32_t shift = 0, bpc = 0;
+  {
+    uint64_t want = ((1ull << tb) / 32u) / C;
+    if (want < 1) want = 1;
+    const uint64_t wd = (uint64_t)e->kp.S / want;
+    while (shift < 31u && (2ull << shift) <= wd) shift++;
+    bpc = (e->kp.S >> shift) + 1u;
+  }
+  const uint32_t bpf = bpc * C;
+  const uint64_t nb = (uint64_t)nfiles * bpf;
+  c->stat_bytes = mk_up16((size_t)nfiles * sizeof(mk_bstat)) + mk_up16((size_t)nfiles * C * 4) + 16;
+  const size_t zero_bytes = (size_t)N * 16 + mk_up16((size_t)(nb + 1) * 4) + c->stat_bytes;
+  if ((rc = mk_dbuf_fit(e, c->text, (size_t)text_span + 256))) return rc;
+  if ((rc = mk_dbuf_fit(e, c->stream, (size_t)soff + 8192))) return rc;
+  if ((rc = mk_dbuf_fit(e, c->sum, (size_t)nseg_total * sizeof(mk_fa_sum)))) return rc;
+  if ((rc = mk_dbuf_fit(e, c->zero, zero_bytes))) return rc;
+  if ((rc = mk_dbuf_fit(e, c->map, (size_t)N * 8))) return rc;
+  if ((rc = mk_dbuf_fit(e, c->list, (size_t)N * 40))) return rc;
+  if ((rc = mk_dbuf_fit(e, c->bcur, (size_t)nb * 4 + 16))) return rc;
+  if ((rc = mk_pinned_fit(e, &c->h_stat, &c->h_stat_cap, c->stat_bytes))) return rc;
+  {
+    uint8_t *z = (uint8_t *)c->zero.p;
+    hb->kc = (unsigned long long *)z;
+    hb->ordinv = hb->kc + N;
+    hb->bstart = (uint32_t *)(z + (size_t)N * 16);
+    uint8_t *st = z + (size_t)N * 16 + mk_up16((size_t)(nb + 1) * 4);
+    hb->stat = (mk_bstat *)st;
+    hb->ctot = (uint32_t *)(st + mk_up16((size_t)nfiles * sizeof(mk_bstat)));
+    hb->misc = (unsigned long long *)(st + mk_up16((size_t)nfiles * sizeof(mk_bstat)) + mk_up16((size_t)nfiles * C * 4));
+    hb->map = (unsigned long long *)c->map.p;
+    uint8_t *l = (uint8_t *)c->list.p;
+    hb->key = (unsigned long long *)l;
+    hb->ord = hb->key + N;
+    hb->tkey = hb->ord + N;
+    hb->cnt = (uint32_t *)(hb->tkey + N);
+    hb->gid = hb->cnt + N;
+    hb->tidx = hb->gid + N;
+    hb->out_ids = hb->tidx + N;
+    hb->list_cap = N; hb->out_cap = N;
+    hb->bcursor = (uint32_t *)c->bcur.p;
+    hb->files = (const mk_bfile *)(dd + mk_up16(sizeof(mk_batch_dev)));
+    hb->seg0s = (const uint32_t *)(dd + ((uint8_t *)hseg0 - hd));
+    hb->row0s = (const uint32_t *)(dd + ((uint8_t *)hrow0 - hd));
+    hb->nfiles = nfiles; hb->tb = tb;
+    const uint64_t half = 1ull << (tb - 1u);
+    hb->key_limit = (uint32_t)(half < e->P.hashlimit ? half : e->P.hashlimit);
+    hb->S = e->kp.S;
+    hb->comp_num = C; hb->comp_code_bits = (uint32_t)e->P.comp_code_bits;
+    hb->cnt_hi = mode == MK_MODE_UNIQ_SET ? 1u : 0xffffffffu;
+    hb->shift = shift; hb->bpc = bpc; hb->bpf = bpf;
+  }
+  c->hb = *hb;
+  c->mode = mode; c->nfiles = nfiles;
+  c->files.assign(files, files + nfiles);
+  const mk_batch_dev *dbatch = (const mk_batch_dev *)dd;
+  hipStream_t s = e->stream;
+
+  /* ---- the launch sequence */
+  MK_HIP(e, hipMemcpyAsync(c->desc.p, c->h_desc, desc_bytes, hipMemcpyHostToDevice, s));
+  if (one_copy) {
+    if (text_span) MK_HIP(e, hipMemcpyAsync(c->text.p, files[0].text, (size_t)text_span, hipMemcpyHostToDevice, s));
+  } else {
+    for (uint32_t i = 0; i < nfiles; i++)
+      if (files[i].n) MK_HIP(e, hipMemcpyAsync((uint8_t *)c->text.p + hf[i].text_off, files[i].text, (size_t)files[i].n, hipMemcpyHostToDevice, s));
+  }
+  const unsigned wide = (unsigned)e->num_cu * 8u;
+  hipLaunchKernelGGL(mk_b_clear_kernel, dim3(wide), dim3(256), 0, s, (uint4 *)c->zero.p, (unsigned long long)(zero_bytes / 16u), (uint4 *)c->map.p,
+                     (unsigned long long)(N / 2u), (uint4 *)nullptr, 0ull);
+  hipLaunchKernelGGL(mk_fab_summary_kernel, dim3((nseg_total + 3u) / 4u), dim3(256), 0, s, (const uint8_t *)c->text.p, c->hb, nseg_total, (mk_fa_sum *)c->sum.p);
+  hipLaunchKernelGGL(mk_fab_scan_kernel, dim3(nfiles), dim3(1024), 0, s, (mk_fa_sum *)c->sum.p, c->hb, TL, pitch);
+  hipLaunchKernelGGL(mk_fab_emit_kernel, dim3((nseg_total + 3u) / 4u), dim3(256), 0, s, (const uint8_t *)c->text.p, c->hb, nseg_total,
+                     (const mk_fa_sum *)c->sum.p, (uint8_t *)c->stream.p);
+  MK_HIP(e, hipGetLastError());
+  {
+    const bool tuned = e->P.subk == 6 && e->P.k >= 9 && e->P.k <= 11;
+    const uint64_t per = mk_rows_per_launch(e, rowlen, tuned);
+    e->cur_batch = dbatch;
+    for (uint64_t done = 0; done < total_rows && rc == MK_OK; done += per) {
+      const uint64_t n = total_rows - done < per ? total_rows - done : per;
+      /* (ordinals are rows of the batch: first_ord = the first row of the launch) */
+      rc = mk_launch_scan_ex(e, (const uint8_t *)c->stream.p + done * pitch, width, pitch, rowlen, n, nullptr, done);
+    }
+    e->cur_batch = nullptr;
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(mk_b_compact_kernel, dim3((unsigned)e->num_cu * 2u), dim3(1024), 0, s, c->hb);
+  hipLaunchKernelGGL(mk_b_layout_kernel, dim3(wide * 2u), dim3(256), 0, s, c->hb);
+  hipLaunchKernelGGL(mk_b_bucket_kernel, dim3(wide * 2u), dim3(256), 0, s, c->hb);
+  hipLaunchKernelGGL(mk_b_bscan_kernel, dim3(nfiles), dim3(1024), 0, s, c->hb);
+  hipLaunchKernelGGL(mk_b_scatter_kernel, dim3(wide * 2u), dim3(256), 0, s, c->hb);
+  hipLaunchKernelGGL(mk_b_emit_kernel, dim3(wide * 2u), dim3(256), 0, s, c->hb);
+  MK_HIP(e, hipGetLastError());
+  MK_HIP(e, hipMemcpyAsync(c->h_stat, hb->stat, c->stat_bytes, hipMemcpyDeviceToHost, s));
+  MK_HIP(e, hipEventRecord(c->ev_stat, s));
+  e->batch_begun++;
+  return MK_OK;
+}
+
+extern "C" int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out) {
+  if (!e || !out) return MK_ERR_ARG;
+  if (e->batch_begun == e->batch_ended) return mk_fail(e, MK_ERR_STATE, "mk_sketch_batch_end without a batch in flight");
+  if (e->begun) return mk_fail(e, MK_ERR_STATE, "mk_sketch_batch_end inside a sketch (between begin and finish)");
+  MK_HIP(e, hipSetDevice(e->device));
+  mk_bctx *c = e->bctx[e->batch_ended % 3u];
+  e->batch_ended++; /* whatever happens below, this batch is over */
+  MK_HIP(e, hipEventSynchronize(c->ev_stat));
+  const uint32_t nfiles = c->nfiles, C = c->hb.comp_num;
+  const mk_bstat *st = (const mk_bstat *)c->h_stat;
+  const uint32_t *ctot = (const uint32_t *)((const uint8_t *)c->h_stat + mk_up16((size_t)nfiles * sizeof(mk_bstat)));
+  const unsigned long long *misc = (const unsigned long long *)((const uint8_t *)ctot + mk_up16((size_t)nfiles * C * 4));
+  const uint64_t n_out = misc[1];
+  if (n_out > c->hb.out_cap || misc[0] > c->hb.list_cap) return mk_fail(e, MK_ERR_HIP, "batch: %llu keys, %llu ids for lists of %llu", misc[0], (unsigned long long)n_out, (unsigned long long)c->hb.list_cap);
+  int rc = mk_pinned_fit(e, (void **)&c->h_ids, &c->h_ids_cap, (size_t)(n_out ? n_out : 1) * 4);
+  if (rc) return rc;
+  if (n_out) {
+    MK_HIP(e, hipMemcpyAsync(c->h_ids, c->hb.out_ids, (size_t)n_out * 4, hipMemcpyDeviceToHost, e->stream));
+    MK_HIP(e, hipEventRecord(c->ev_stat, e->stream));
+  }
+  c->comps.assign((size_t)nfiles * C, mk_component{nullptr, nullptr, 0});
+  c->alone_ids.clear();
+  /* files the batch could not take: alone, through the ordinary path (their sketches are the same either way) */
+  size_t n_alone = 0;
+  for (uint32_t i = 0; i < nfiles; i++) if ((st[i].flags & MK_BF_REDO) && !(st[i].flags & MK_BF_HEADER_END)) n_alone++;
+  c->alone_ids.resize(n_alone);
+  size_t ai = 0;
+  for (uint32_t i = 0; i < nfiles; i++) {
+    out[i].status = MK_OK; out[i].alone = 0;
+    out[i].r.component_num = (int32_t)C; out[i].r.total = 0; out[i].r.components = c->comps.data() + (size_t)i * C;
+    if (st[i].flags & MK_BF_HEADER_END) { out[i].status = MK_ERR_FORMAT; continue; }
+    if (!(st[i].flags & MK_BF_REDO)) continue;
+    out[i].alone = 1;
+    mk_result r;
+    rc = mk_sketch_begin(e, c->mode);
+    if (rc == MK_OK) rc = mk_sketch_push_stream(e, c->files[i].text, c->files[i].n, 1);
+    if (rc == MK_OK) rc = mk_sketch_finish(e, &r);
+    else if (e->begun) { mk_result dummy; (void)mk_sketch_finish(e, &dummy); }
+    if (rc == MK_ERR_CROWDED || rc == MK_ERR_FORMAT) { out[i].status = rc; ai++; continue; }
+    if (rc) return rc;
+    std::vector<uint32_t> &v = c->alone_ids[ai++];
+    v.reserve((size_t)r.total);
+    for (uint32_t k = 0; k < C; k++) v.insert(v.end(), r.components[k].ids, r.components[k].ids + r.components[k].n);
+    size_t at = 0;
+    for (uint32_t k = 0; k < C; k++) {
+      mk_component &mc = c->comps[(size_t)i * C + k];
+      mc.n = r.components[k].n; mc.ids = v.data() + at; mc.counts = nullptr;
+      at += (size_t)r.components[k].n;
+    }
+    out[i].r.total = r.total;
+  }
+  if (n_out) MK_HIP(e, hipEventSynchronize(c->ev_stat));
+  /* the batch's ids lie file by file, component by component */
+  size_t at = 0;
+  for (uint32_t i = 0; i < nfiles; i++) {
+    uint64_t tot = 0;
+    for (uint32_t k = 0; k < C; k++) tot += ctot[(size_t)i * C + k];
+    if (tot != st[i].nout) return mk_fail(e, MK_ERR_HIP, "batch: file %u: component sizes do not add up", i);
+    if (out[i].alone || out[i].status != MK_OK) { at += (size_t)tot; continue; } /* (flagged files have no entries: tot == 0) */
+    for (uint32_t k = 0; k < C; k++) {
+      mk_component &mc = c->comps[(size_t)i * C + k];
+      mc.n = ctot[(size_t)i * C + k]; mc.ids = c->h_ids + at; mc.counts = nullptr;
+      at += (size_t)mc.n;
+    }
+    out[i].r.total = tot;
+  }
+  if (at != n_out) return mk_fail(e, MK_ERR_HIP, "batch: %zu ids accounted for, %llu written", at, (unsigned long long)n_out);
+  return MK_OK;
 }

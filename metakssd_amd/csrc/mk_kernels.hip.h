@@ -69,6 +69,9 @@ struct mk_front {
 };
 #define MK_FRONT_PROBES 16u
 
+struct mk_batch_dev; /* mk_batch.hip.h: many small inputs in one launch sequence, a table per file */
+__device__ __forceinline__ void mk_b_upsert(const mk_batch_dev &b, uint32_t row, uint64_t key, uint64_t ord);
+
 struct mk_scan_args {
   const uint8_t *rows;
   uint64_t nreads, first_ord;
@@ -103,6 +106,9 @@ struct mk_scan_args {
   uint4 *cand;
   uint32_t *cand_count;         /* [nslots] */
   uint32_t cand_cap;
+  /* not NULL: the rows are those of a batch of files (first_ord == 0) and an accepted k-mer goes to the table of the file its row
+   * belongs to (mk_b_upsert) instead of a.tab; read by the out-of-line resolve paths only */
+  const mk_batch_dev *batch;
 };
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -244,7 +250,8 @@ __device__ __forceinline__ void mk_resolve_one(const mk_scan_args &a, uint64_t s
   const int32_t pf = a.shuf[dim];
   if (pf >= a.kp.dim_start && pf < a.kp.dim_end) {
     const uint64_t key = mk_reduce_key(a.kp, uni, (uint64_t)(pf - a.kp.dim_start));
-    mk_upsert_big(a.tab, a.kp.S, key, ord, 1u); /* (overflow path of the scan kernel only: straight to the big table) */
+    if (a.batch) mk_b_upsert(*a.batch, (uint32_t)(ord >> 12), key, ord);
+    else mk_upsert_big(a.tab, a.kp.S, key, ord, 1u); /* (overflow path of the scan kernel only: straight to the big table) */
   }
 }
 
@@ -337,8 +344,11 @@ __device__ __noinline__ bool mk_resolve_accepted(const mk_scan_args *ka, bool on
   const uint64_t uni = ((uint64_t)v.y << 32) | v.x;
   const uint32_t dim = (uint32_t)((uni & a.kp.domask) >> a.kp.out2);
   const int32_t pf = a.shuf[dim];
-  if (pf >= a.kp.dim_start && pf < a.kp.dim_end)
-    return mk_upsert(a.tab, a.kp.S, mk_reduce_key(a.kp, uni, (uint64_t)(pf - a.kp.dim_start)), ((uint64_t)v.w << 32) | v.z, 1u, front_open);
+  if (pf >= a.kp.dim_start && pf < a.kp.dim_end) {
+    const uint64_t key = mk_reduce_key(a.kp, uni, (uint64_t)(pf - a.kp.dim_start)), ord = ((uint64_t)v.w << 32) | v.z;
+    if (a.batch) { mk_b_upsert(*a.batch, (uint32_t)(ord >> 12), key, ord); return false; }
+    return mk_upsert(a.tab, a.kp.S, key, ord, 1u, front_open);
+  }
   return false;
 }
 /* ring 1 -> ring 2: canonical k-mer (iseq2comem.c:691) and the accept bit of its inner substring */
@@ -1544,24 +1554,29 @@ __global__ void __launch_bounds__(256) mk_dumpc_write_kernel(mk_dump_args a, con
   }
 }
 
-/* ---- engine start-up: the accepted inner substrings of a .shuf table (iseq2comem.c:693-694) as the scan filter's source
- * list {d, revcomp(d)} and as a bitmap, straight from the uploaded table */
-__global__ void __launch_bounds__(256) mk_accept_build_kernel(const int32_t *shuf, uint64_t L, int32_t dim_start, int32_t dim_end,
-                                                              uint32_t dbits, uint32_t *accept, uint32_t cap, uint32_t *count,
-                                                              uint32_t *bits) {
-  for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < L; d += (uint64_t)gridDim.x * blockDim.x) {
-    const int32_t v = shuf[d];
-    if (v >= dim_start && v < dim_end) {
-      atomicOr(&bits[d >> 5], 1u << (d & 31u));
-      const uint32_t at = atomicAdd(count, 2u);
-      if (at + 2u <= cap) {
-        uint32_t n = ~(uint32_t)d, r = 0; /* reverse the 2-bit groups of the complement within dbits */
-        for (uint32_t i = 0; i < dbits; i += 2) r |= ((n >> i) & 3u) << (dbits - 2u - i);
-        accept[at] = (uint32_t)d;
-        accept[at + 1] = r;
-      }
-    }
+/* ---- engine start-up: the accepted inner substrings of a .shuf table (iseq2comem.c:693-694).  The host finds them while the
+ * runtime creates the engine's queue (a pass over the table on a few threads) and uploads the (d, shuf[d]) pairs: a few
+ * thousand of the 16^subk entries.  From them, on the device: the scan filter's source list {d, revcomp(d)}, the accept bitmap,
+ * and the ONLY entries of the device's .shuf table anybody reads (the resolve kernel looks at shuf[d] behind a set accept
+ * bit).  The 64 MiB table itself never crosses PCIe: 14 ms of every start-up. */
+struct mk_accept_pair { uint32_t d; int32_t pf; };
+__global__ void __launch_bounds__(256) mk_accept_scatter_kernel(const mk_accept_pair *pairs, uint32_t n, uint32_t dbits, int32_t *shuf,
+                                                                uint32_t *bits, uint32_t *accept) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t d = pairs[i].d;
+    shuf[d] = pairs[i].pf;
+    atomicOr(&bits[d >> 5], 1u << (d & 31u));
+    uint32_t c = ~d, r = 0; /* reverse the 2-bit groups of the complement within dbits */
+    for (uint32_t k = 0; k < dbits; k += 2) r |= ((c >> k) & 3u) << (dbits - 2u - k);
+    accept[2u * i] = d;
+    accept[2u * i + 1u] = r;
   }
+}
+__global__ void mk_front_store_kernel(mk_front *dst, const mk_front v) { *dst = v; }
+/* n16 16-byte units at p := v (the engine's own fill: hipMemset would bring the runtime's fill kernels in at start-up) */
+__global__ void __launch_bounds__(256) mk_fill16_kernel(uint4 *p, unsigned long long n16, uint32_t v) {
+  const uint4 z = make_uint4(v, v, v, v);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * blockDim.x) p[i] = z;
 }
 
 /* ---- synthetic reads: 16 bytes of one row per thread ------------------------------------------------- */

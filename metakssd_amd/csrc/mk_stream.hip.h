@@ -61,12 +61,8 @@ __device__ __forceinline__ uint64_t mk_fa_step(uint8_t ch, bool valid, uint32_t 
   return keep;
 }
 
-__global__ void __launch_bounds__(256) mk_fa_summary_kernel(const uint8_t *text, uint64_t n, mk_fa_sum *sum) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t seg = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t lo = seg * MK_FA_SEG;
-  if (lo >= n) return;
-  const uint64_t hi = lo + MK_FA_SEG < n ? lo + MK_FA_SEG : n;
+/* summary of the text bytes [lo, hi) (one wave): {state behind, bytes kept} for both entry states */
+__device__ __forceinline__ mk_fa_sum mk_fa_summarise(const uint8_t *text, uint64_t lo, uint64_t hi, uint32_t lane) {
   uint32_t s0 = 0u, s1 = 1u, c0 = 0u, c1 = 0u;
   for (uint64_t at0 = lo; at0 < hi; at0 += 256u) {
     uint8_t chs[4];
@@ -90,23 +86,31 @@ __global__ void __launch_bounds__(256) mk_fa_summary_kernel(const uint8_t *text,
       s0 = a; s1 = b;
     }
   }
-  if (lane == 0) {
-    mk_fa_sum r;
-    r.cnt[0] = c0; r.cnt[1] = c1; r.after = s0 | (s1 << 1); r.off = 0u;
-    sum[seg] = r;
-  }
+  mk_fa_sum r;
+  r.cnt[0] = c0; r.cnt[1] = c1; r.after = s0 | (s1 << 1); r.off = 0u;
+  return r;
 }
 
-/* Composes the summaries in segment order (one workgroup; a wave-shuffle scan of the transfer functions per 1024 segments).
- * Also: stream length behind this push, state behind the text, and the number of virtual rows the scan may take now --
- * with `final` every row that holds a complete k-mer, otherwise only rows that are complete (their last byte is known). */
-__global__ void __launch_bounds__(1024) mk_fa_scan_kernel(mk_fa_sum *sum, uint64_t nseg, mk_fa_state *st, uint8_t *stream, uint32_t pitch,
-                                                          uint32_t rowlen, uint32_t TL, int final, uint32_t *err) {
+__global__ void __launch_bounds__(256) mk_fa_summary_kernel(const uint8_t *text, uint64_t n, mk_fa_sum *sum) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t seg = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t lo = seg * MK_FA_SEG;
+  if (lo >= n) return;
+  const uint64_t hi = lo + MK_FA_SEG < n ? lo + MK_FA_SEG : n;
+  const mk_fa_sum r = mk_fa_summarise(text, lo, hi, lane);
+  if (lane == 0) sum[seg] = r;
+}
+
+/* Composes nseg summaries in segment order, entered in state `state0` (a workgroup of 1024 threads, all of them call; a
+ * wave-shuffle scan of the transfer functions per 1024 segments): sum[i].off := output offset of segment i (relative to the
+ * first) | its entry state << 31; kept := bytes kept in all, state := the state behind the last segment (in every thread). */
+__device__ __forceinline__ void mk_fa_compose(mk_fa_sum *sum, uint64_t nseg, uint32_t state0, unsigned long long &kept, uint32_t &state) {
   __shared__ uint32_t w_after[16], w_c0[16], w_c1[16];
   __shared__ uint32_t carry_state;
   __shared__ unsigned long long carry_off;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) { carry_state = st->in_header; carry_off = 0ull; }
+  __syncthreads(); /* (a second call in one kernel must not overwrite what the first one's threads still read) */
+  if (threadIdx.x == 0) { carry_state = state0; carry_off = 0ull; }
   __syncthreads();
   for (uint64_t base = 0; base < nseg; base += 1024u) {
     const uint64_t i = base + threadIdx.x;
@@ -148,11 +152,24 @@ __global__ void __launch_bounds__(1024) mk_fa_scan_kernel(mk_fa_sum *sum, uint64
     }
     __syncthreads();
   }
+  kept = carry_off;
+  state = carry_state;
+}
+
+/* Composes the summaries in segment order (one workgroup).  Also: stream length behind this push, state behind the text, and
+ * the number of virtual rows the scan may take now -- with `final` every row that holds a complete k-mer, otherwise only rows
+ * that are complete (their last byte is known). */
+__global__ void __launch_bounds__(1024) mk_fa_scan_kernel(mk_fa_sum *sum, uint64_t nseg, mk_fa_state *st, uint8_t *stream, uint32_t pitch,
+                                                          uint32_t rowlen, uint32_t TL, int final, uint32_t *err) {
+  unsigned long long kept;
+  uint32_t state;
+  mk_fa_compose(sum, nseg, st->in_header, kept, state);
+  __syncthreads(); /* (every thread has read st->in_header before thread 0 writes it) */
   if (threadIdx.x == 0) {
-    const unsigned long long len = st->len + carry_off;
+    const unsigned long long len = st->len + kept;
     st->len = len;
-    st->in_header = carry_state;
-    if (final && carry_state) atomicOr(err, 8u); /* the text ends inside a '>' line: the reference gives up (iseq2comem.c:259-271) */
+    st->in_header = state;
+    if (final && state) atomicOr(err, 8u); /* the text ends inside a '>' line: the reference gives up (iseq2comem.c:259-271) */
     unsigned long long rows = 0;
     if (final) {
       if (len >= TL) rows = (len - (TL - 1u) + pitch - 1u) / pitch; /* every row with a complete k-mer in it */
@@ -162,16 +179,11 @@ __global__ void __launch_bounds__(1024) mk_fa_scan_kernel(mk_fa_sum *sum, uint64
   }
 }
 
-__global__ void __launch_bounds__(256) mk_fa_emit_kernel(const uint8_t *text, uint64_t n, const mk_fa_sum *sum, uint8_t *stream,
-                                                         unsigned long long stream_len_before) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t seg = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t lo = seg * MK_FA_SEG;
-  if (lo >= n) return;
-  const uint64_t hi = lo + MK_FA_SEG < n ? lo + MK_FA_SEG : n;
-  const uint32_t o = sum[seg].off;
+/* the text bytes [lo, hi) once more with the entry state known (off: mk_fa_sum::off of the segment): kept bytes to
+ * stream[base + offset ..] (one wave) */
+__device__ __forceinline__ void mk_fa_emit_seg(const uint8_t *text, uint64_t lo, uint64_t hi, uint32_t o, uint8_t *stream, uint64_t base, uint32_t lane) {
   uint32_t s = o >> 31;
-  uint64_t off = stream_len_before + (o & 0x7FFFFFFFu);
+  uint64_t off = base + (o & 0x7FFFFFFFu);
   for (uint64_t at0 = lo; at0 < hi; at0 += 256u) {
     uint8_t chs[4];
 #pragma unroll
@@ -190,6 +202,16 @@ __global__ void __launch_bounds__(256) mk_fa_emit_kernel(const uint8_t *text, ui
       off += (uint64_t)__popcll(keep);
     }
   }
+}
+
+__global__ void __launch_bounds__(256) mk_fa_emit_kernel(const uint8_t *text, uint64_t n, const mk_fa_sum *sum, uint8_t *stream,
+                                                         unsigned long long stream_len_before) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t seg = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t lo = seg * MK_FA_SEG;
+  if (lo >= n) return;
+  const uint64_t hi = lo + MK_FA_SEG < n ? lo + MK_FA_SEG : n;
+  mk_fa_emit_seg(text, lo, hi, sum[seg].off, stream, stream_len_before, lane);
 }
 
 /* behind a scan of `rows_taken` rows (device value): the unscanned tail moves to the front of the stream buffer */

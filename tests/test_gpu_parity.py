@@ -243,6 +243,97 @@ def test_fasta_device_stream_rough_text(capi, engine_for, shufs, oracle_for, nam
     assert ei.value.code == capi.MK_ERR_FORMAT
 
 
+def _batch_texts(rs, big):
+    """a directory's worth of small FASTA texts: genomes of several contigs, repeats and reverse complements inside a file (keys seen
+    twice: -u), rough text, tiny and empty ones, one that is only a header, a file without a header line"""
+    g = ui.rand_seq(rs, 300000 if big else 24000)
+    L = len(g)
+    texts = []
+    for i in range(9):
+        a, b = (i * L) // 12, (i * L) // 12 + L // (4 if i % 3 else 9)
+        contigs = [g[a:b], ui.revcomp(g[a + 100:a + 100 + (b - a) // 3]), g[a:a + 57] + b"N" * (i + 1) + g[a + 57:a + 900]]
+        texts.append(ui.fasta_bytes(contigs))
+    texts.append(b">h1\r\n" + g[:1000] + b"\r\n" + g[1000:2000] + b"\r\n\r\n" + g[2000:5000] + b"\n>\n" + g[7000:9000].lower() + b"\n")
+    texts.append(b">x\n" + g[:700] + b">inline header to the end of this line\n" + g[700:1400] + b"\n")
+    texts.append(g[300:4000] + b"\n" + g[100:2000] + b"\n")            # no header at all
+    texts.append(b">only header\n")
+    texts.append(b"")                                                 # empty file: an empty sketch here (the command line refuses it earlier)
+    texts.append(b">h\n" + g[:21] + b"\n>g\n" + g[:22] + b"\n")
+    texts.append(b">h\n" + g[500:3000] + b"\n>t\n" + g[4000:5000])     # no newline at the end
+    texts.append(b">h\n" + b"\n".join(g[i:i + 7] for i in range(0, 3000, 7)) + b"\n")
+    return texts
+
+
+@pytest.mark.parametrize("uniq", [False, True])
+@pytest.mark.parametrize("name", ["L0K6", "L0K6z", "L1K7", "L3K10", "L3K11", "L2K11"])
+def test_batch_of_files_equals_oracle(capi, engine_for, shufs, oracle_for, name, uniq):
+    """mk_sketch_batch_begin / _end: many files in ONE launch sequence (the reference's team over files, command_dist.c:363-372) --
+    every file's sketch is the oracle's fasta2co() / uniq_fasta2co() sketch of that file alone; separate buffers and the
+    single-copy layout; two batches in flight"""
+    rs = np.random.RandomState(52)
+    texts = _batch_texts(rs, name in ("L3K10", "L3K11", "L2K11"))
+    ora = oracle_for(shufs(name))
+    want = []
+    for t in texts:
+        rc, w = ora.co_from_fasta(t, uniq=uniq) if t else (0, None)
+        assert rc == 0
+        want.append(w)
+    mode = capi.MK_MODE_UNIQ_SET if uniq else capi.MK_MODE_SET
+    eng = engine_for(name)
+    ncomp = eng.params.component_num
+
+    def check(res, texts_, want_, label):
+        assert len(res) == len(texts_)
+        for i, (st, alone, comps) in enumerate(res):
+            assert st == 0, "%s file %d: status %d" % (label, i, st)
+            if want_[i] is None:
+                assert all(len(c) == 0 for c in comps) and len(comps) == ncomp
+            else:
+                assert_same([(c, None) for c in comps], want_[i], "%s file %d (alone=%d)" % (label, i, alone))
+    for one_buffer in (False, True):
+        eng.batch_begin(texts, mode, one_buffer=one_buffer)
+        check(eng.batch_end(), texts, want, "%s uniq=%s one_buffer=%s" % (name, uniq, one_buffer))
+    # two batches in flight, of different sizes; then the engine's ordinary path still works
+    eng.batch_begin(texts[:5], mode)
+    eng.batch_begin(texts[5:], mode, one_buffer=True)
+    check(eng.batch_end(), texts[:5], want[:5], name + " first of two")
+    check(eng.batch_end(), texts[5:], want[5:], name + " second of two")
+    eng.begin(mode)
+    eng.push_stream(texts[0])
+    assert_same(eng.finish(), want[0], name + " alone after the batches")
+
+
+@pytest.mark.parametrize("name", ["L1K7", "L2K11"])
+def test_batch_small_tables_fall_back_to_alone(capi, shufs, oracle_for, name):
+    """MK_OPT_BATCH_TAB_BITS 9: 512 slots per file -- files with more than 256 keys (or a probe sequence that runs out) are flagged
+    on the device and sketched alone by mk_sketch_batch_end; the results do not change.  A text that ends inside a header line is
+    MK_ERR_FORMAT for that file only."""
+    rs = np.random.RandomState(53)
+    texts = _batch_texts(rs, name == "L2K11") + [b">h\n" + ui.rand_seq(rs, 500) + b"\n>cut off"]
+    ora = oracle_for(shufs(name))
+    eng = capi.Engine(shufs(name), 0)
+    try:
+        eng.set_option(capi.MK_OPT_BATCH_TAB_BITS, 9)
+        eng.batch_begin(texts, capi.MK_MODE_SET)
+        res = eng.batch_end()
+        assert res[-1][0] == capi.MK_ERR_FORMAT
+        n_alone = 0
+        for i, (st, alone, comps) in enumerate(res[:-1]):
+            assert st == 0
+            n_alone += alone
+            if texts[i]:
+                rc, w = ora.co_from_fasta(texts[i])
+                assert rc == 0
+                assert_same([(c, None) for c in comps], w, "%s file %d (alone=%d)" % (name, i, alone))
+        assert n_alone >= 3, "the small tables were meant to overflow"
+        with pytest.raises(capi.MkError):
+            eng.batch_end()                                  # nothing in flight
+        with pytest.raises(capi.MkError):
+            eng.batch_begin(texts, capi.MK_MODE_KOC)         # FASTA flavours only
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("name,sparse", [("L1K7", 0), ("L1K7", 1), ("L3K11", 0), ("L2K11", -1)])
 def test_finish_in_two_halves_pipelined(capi, shufs, oracle_for, name, sparse):
     """mk_sketch_finish_begin / _end: the result of sketch i is copied to the host while sketch i + 1 is already being scanned;
