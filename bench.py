@@ -330,6 +330,19 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    # what the exchange runs over, for the record: every rank reports its device, rank 0 prints what it saw
+    seen = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None),
+                "pci_device_id": getattr(props, "pci_device_id", None)}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        seen = {"transport": "RCCL (torch.distributed backend 'nccl': point-to-point isend/irecv of the key lists to rank 0)"
+                if args.backend == "nccl" else "gloo over host memory (debug)",
+                "world_size": world, "ranks_seen": sorted(r["rank"] for r in allr),
+                "distinct_devices": len({(r["local_rank"], r["pci_bus_id"], r["pci_device_id"]) for r in allr}), "ranks": allr}
+
     # ---- workload: contiguous global read ranges, rank-ordered ----
     if args.reads_per_gpu is not None:
         scaling, n, first, total_reads = "weak", args.reads_per_gpu, rank * args.reads_per_gpu, world * args.reads_per_gpu
@@ -365,7 +378,7 @@ def main():
 
     result = {}
     flags = {"keep": False}
-    tail = {"t": 0.0, "steps": 0, "on": False}
+    tail = {"t": 0.0, "t_pipe": 0.0, "steps": 0, "on": False}
 
     def step(push=None):
         eng.begin(capi.MK_MODE_KOC)
@@ -400,6 +413,8 @@ def main():
                 drain()
                 eng.finish_begin()
                 flags["pending"] = True
+                if world > 1 and tail["on"]:  # the next pass may begin here: layout, dump and the result's copy run beside it
+                    tail["t_pipe"] += time.perf_counter() - t0
                 if args.serial_finish:
                     drain()
         if world > 1 and tail["on"]:
@@ -562,10 +577,16 @@ def main():
                                    # layout + dump + copy of pass i on the side stream, beside clear + scan of pass i + 1
                                    "finish_side_stream": prof.get("finish_side_ms", 0.0) / args.steps},
         }
+        if seen is not None:
+            line["distributed"] = seen
         if world > 1 and tail["steps"]:
             line["rank0_tail_ms"] = tail["t"] / tail["steps"] * 1e3
             line["rank0_tail_what"] = "gather of the other ranks' key lists + one import launch + finish on rank 0, " \
                                       "from 3 separately fenced steps after the timed region"
+            line["rank0_tail_pipelined_ms"] = tail["t_pipe"] / tail["steps"] * 1e3
+            line["rank0_tail_pipelined_what"] = "the same up to the point where rank 0 may begin the next pass (mk_sketch_finish_begin has " \
+                                                "returned: compaction done, key count known); priority layout, dump and the copy of the result " \
+                                                "run on the side stream beside the next pass's scan -- what the timed region pays per step"
         if stream_n is not None:
             ns, sec = stream_n
             line["t_stream"] = {"gbases_s": world * ns * READ_LEN / sec / 1e9, "h2d_gb_s": world * ns * STRIDE / sec / 1e9,

@@ -43,8 +43,7 @@ struct mk_bstat { /* per file, made by the device */
   unsigned long long kept; /* bytes of its base stream */
   uint32_t flags;          /* MK_BF_* */
   uint32_t D;              /* distinct keys in its table */
-  uint32_t nout;           /* ids it contributes to the output (all components) */
-  uint32_t pad;
+  uint32_t pad[2];
 };
 
 struct mk_batch_dev {
@@ -53,6 +52,8 @@ struct mk_batch_dev {
   mk_bstat *stat;                /* [nfiles] */
   uint32_t *ctot;                /* [nfiles * comp_num]: ids per (file, component) */
   unsigned long long *misc;      /* [0] keys in the batch's list, [1] ids in the output */
+  uint32_t *nout;                /* [nfiles * 16]: ids a file contributes to the output, a 64-byte line per file (every wave of the bucket
+                                  * pass adds to it: kept away from the status words everybody reads) */
   uint32_t nfiles, tb;           /* every file's table and map have 1 << tb entries */
   unsigned long long *kc, *ordinv; /* [nfiles << tb]: the accumulation tables, slot format of mk_table */
   unsigned long long *map;       /* [nfiles << tb]: virtual slot << 32 | key index, ~0 = empty */
@@ -102,7 +103,8 @@ __global__ void __launch_bounds__(256) mk_fab_summary_kernel(const uint8_t *text
   const mk_bfile bf = b.files[f];
   const uint64_t lo = bf.text_off + (uint64_t)(seg - bf.seg0) * MK_FA_SEG, end = bf.text_off + bf.text_len;
   const uint64_t hi = lo + MK_FA_SEG < end ? lo + MK_FA_SEG : end;
-  const mk_fa_sum r = mk_fa_summarise(text, lo, hi > lo ? hi : lo, lane);
+  __shared__ uint4 seg_lds[MK_FA_WAVES][64];
+  const mk_fa_sum r = mk_fa_summarise(text, lo, hi > lo ? hi : lo, lane, seg_lds[threadIdx.x >> 6]);
   if (lane == 0) sum[seg] = r;
 }
 
@@ -131,7 +133,8 @@ __global__ void __launch_bounds__(256) mk_fab_emit_kernel(const uint8_t *text, c
   const mk_bfile bf = b.files[f];
   const uint64_t lo = bf.text_off + (uint64_t)(seg - bf.seg0) * MK_FA_SEG, end = bf.text_off + bf.text_len;
   const uint64_t hi = lo + MK_FA_SEG < end ? lo + MK_FA_SEG : end;
-  if (hi > lo) mk_fa_emit_seg(text, lo, hi, sum[seg].off, stream, bf.stream_off, lane);
+  __shared__ uint4 seg_lds[MK_FA_WAVES][64];
+  if (hi > lo) mk_fa_emit_seg(text, lo, hi, sum[seg].off, stream, bf.stream_off, lane, seg_lds[threadIdx.x >> 6]);
   /* this segment's share of the fill */
   const uint64_t kept = b.stat[f].kept, gap = bf.stream_cap - kept;
   const uint64_t j = seg - bf.seg0;
@@ -314,7 +317,7 @@ __global__ void __launch_bounds__(256) mk_b_bucket_kernel(const mk_batch_dev b) 
     if (on) atomicAdd(&b.bstart[bucket], 1u);
     /* a wave's 64 entries lie in one file's map (tb >= 9): one add per wave for the file's total */
     const uint64_t m = __ballot(on);
-    if (m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) atomicAdd(&b.stat[f].nout, (uint32_t)__popcll(m));
+    if (m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) atomicAdd(&b.nout[(size_t)f * 16u], (uint32_t)__popcll(m));
   }
 }
 
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(1024) mk_b_bscan_kernel(const mk_batch_dev b) 
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, f = blockIdx.x;
   /* ids of the files in front of this one */
   uint32_t part = 0;
-  for (uint32_t g = threadIdx.x; g < f; g += 1024u) part += b.stat[g].nout;
+  for (uint32_t g = threadIdx.x; g < f; g += 1024u) part += b.nout[(size_t)g * 16u];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
   if (lane == 0) wsum[wave] = part;

@@ -128,6 +128,12 @@ struct mk_engine {
   struct mk_bctx *bctx[3] = {nullptr, nullptr, nullptr};
   uint64_t batch_begun = 0, batch_ended = 0;
   int batch_tb_opt = 0;                /* MK_OPT_BATCH_TAB_BITS: 0 = by the largest file of the batch */
+  /* the texts of a batch go up on a queue of their own, beside the kernels of the batch in front of it.  A second queue costs
+   * 8-9 ms to make (20 + 8 for a process's first): a thread makes it while the first batches already run on the engine's one
+   * stream, and it is used from the batch on that finds it ready (bcopy_state: 0 not asked for, 1 being made, 2 ready, 3 failed) */
+  hipStream_t bcopy_stream = nullptr;
+  int bcopy_state = 0;
+  pthread_t bcopy_thread{};
   const mk_batch_dev *cur_batch = nullptr; /* set around the scan launches of a batch */
 
   int mode = -1;
@@ -284,6 +290,8 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters);
   hipFree(e->d_kl); hipFree(e->d_kl_buckets);
+  if (__atomic_load_n(&e->bcopy_state, __ATOMIC_ACQUIRE) != 0) pthread_join(e->bcopy_thread, nullptr);
+  if (e->bcopy_stream) hipStreamDestroy(e->bcopy_stream);
   for (mk_bctx *c : e->bctx) mk_bctx_free(c);
   hipFree(e->d_res_ids); hipFree(e->d_res_cnt); hipFree(e->d_snap);
   if (e->h_snap) hipHostFree(e->h_snap);
@@ -492,7 +500,6 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   }
   MK_TICK("accept pass joined + pinned block");
   MK_HIP(e, hipMalloc(&e->d_accept, ((size_t)e->n_accept + 2) * sizeof(uint32_t)));
-  MK_HIP(e, hipMalloc(&e->d_pairs, (npairs + 1) * sizeof(mk_accept_pair)));
   if (warm.started) { pthread_join(warm.th, nullptr); warm.started = false; }
   MK_TICK("code object");
   hipLaunchKernelGGL(mk_fill16_kernel, dim3((unsigned)e->num_cu * 2u), dim3(256), 0, e->own_stream, (uint4 *)e->d_accept_bits,
@@ -501,10 +508,10 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
   MK_HIP(e, hipGetLastError());
   MK_TICK("first launches");
   if (npairs) {
-    MK_HIP(e, hipMemcpyAsync(e->d_pairs, hp, npairs * sizeof(mk_accept_pair), hipMemcpyHostToDevice, e->own_stream));
+    /* the kernel reads the pairs out of the pinned block itself (it is mapped into the device): no copy command at start-up */
     uint64_t blocks = (npairs + 255) / 256;
     if (blocks > (uint64_t)e->num_cu * 8u) blocks = (uint64_t)e->num_cu * 8u;
-    hipLaunchKernelGGL(mk_accept_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, e->own_stream, (const mk_accept_pair *)e->d_pairs,
+    hipLaunchKernelGGL(mk_accept_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, e->own_stream, (const mk_accept_pair *)hp,
                        (uint32_t)npairs, dbits, e->d_shuf, e->d_accept_bits, e->d_accept);
     MK_HIP(e, hipGetLastError());
   }
@@ -768,12 +775,12 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
 }
 
 /* ---- scan launch -------------------------------------------------------------------------------------- */
-template <int K, bool V, int T, int NP, bool OP>
+template <int K, int SK, bool V, int T, int NP, bool OP>
 static hipError_t mk_launch_scan_t(mk_engine *e, const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
   /* the dynamic-LDS limit is a per-device attribute of the kernel.  What this engine has asked for is remembered in the
    * engine (one engine = one device; calls on one engine are serialised by the caller), so engines driven from
    * different host threads share no state here; asking again for another engine on the same device is harmless. */
-  const void *fn = (const void *)mk_scan_kernel<K, V, T, NP, OP>;
+  const void *fn = (const void *)mk_scan_kernel<K, SK, V, T, NP, OP>;
   size_t *granted = nullptr;
   for (auto &g : e->lds_granted) if (g.first == fn) granted = &g.second;
   if (!granted) { e->lds_granted.emplace_back(fn, 0); granted = &e->lds_granted.back().second; }
@@ -782,26 +789,33 @@ static hipError_t mk_launch_scan_t(mk_engine *e, const mk_scan_args &a, dim3 gri
     if (r != hipSuccess) return r;
     *granted = lds;
   }
-  hipLaunchKernelGGL((mk_scan_kernel<K, V, T, NP, OP>), grid, dim3(T), lds, s, a);
+  hipLaunchKernelGGL((mk_scan_kernel<K, SK, V, T, NP, OP>), grid, dim3(T), lds, s, a);
   return hipGetLastError();
 }
-template <int K, bool V>
+template <int K, int SK, bool V>
 static hipError_t mk_launch_scan_k(mk_engine *e, int threads, bool onepass, const mk_scan_args &a, dim3 grid, size_t lds, hipStream_t s) {
   /* piece registers: 16-byte path CB <= 80 -> 5 pieces, CB <= 128 -> 8; 4-byte path up to 32 */
   constexpr int NPBIG = V ? MK_MAX_PIECES : MK_MAX_CB / 4;
   constexpr int NPSMALL = V ? 5 : 20;
   const bool small = a.ppr <= (uint32_t)NPSMALL;
+#ifdef MK_HOT_ONLY /* experiment (make tuning VARIANT=-DMK_HOT_ONLY): what the size of this library's code object costs the first dispatch */
+  if constexpr (V && K != 0) {
+    if (threads == 1024 && small) return onepass ? mk_launch_scan_t<K, SK, V, 1024, NPSMALL, true>(e, a, grid, lds, s) : mk_launch_scan_t<K, SK, V, 1024, NPSMALL, false>(e, a, grid, lds, s);
+  }
+  return hipErrorInvalidValue;
+#else
   if constexpr (V) {
     if (onepass && small) /* one-pass staging: 2 x 5 pieces live */
-      return threads >= 1024 ? mk_launch_scan_t<K, V, 1024, NPSMALL, true>(e, a, grid, lds, s)
-             : threads >= 768 ? mk_launch_scan_t<K, V, 768, NPSMALL, true>(e, a, grid, lds, s)
-                              : mk_launch_scan_t<K, V, 512, NPSMALL, true>(e, a, grid, lds, s);
+      return threads >= 1024 ? mk_launch_scan_t<K, SK, V, 1024, NPSMALL, true>(e, a, grid, lds, s)
+             : threads >= 768 ? mk_launch_scan_t<K, SK, V, 768, NPSMALL, true>(e, a, grid, lds, s)
+                              : mk_launch_scan_t<K, SK, V, 512, NPSMALL, true>(e, a, grid, lds, s);
   }
   switch (threads) {
-    case 1024: return small ? mk_launch_scan_t<K, V, 1024, NPSMALL, false>(e, a, grid, lds, s) : mk_launch_scan_t<K, V, 1024, NPBIG, false>(e, a, grid, lds, s);
-    case 768: return small ? mk_launch_scan_t<K, V, 768, NPSMALL, false>(e, a, grid, lds, s) : mk_launch_scan_t<K, V, 768, NPBIG, false>(e, a, grid, lds, s);
-    default: return small ? mk_launch_scan_t<K, V, 512, NPSMALL, false>(e, a, grid, lds, s) : mk_launch_scan_t<K, V, 512, NPBIG, false>(e, a, grid, lds, s);
+    case 1024: return small ? mk_launch_scan_t<K, SK, V, 1024, NPSMALL, false>(e, a, grid, lds, s) : mk_launch_scan_t<K, SK, V, 1024, NPBIG, false>(e, a, grid, lds, s);
+    case 768: return small ? mk_launch_scan_t<K, SK, V, 768, NPSMALL, false>(e, a, grid, lds, s) : mk_launch_scan_t<K, SK, V, 768, NPBIG, false>(e, a, grid, lds, s);
+    default: return small ? mk_launch_scan_t<K, SK, V, 512, NPSMALL, false>(e, a, grid, lds, s) : mk_launch_scan_t<K, SK, V, 512, NPBIG, false>(e, a, grid, lds, s);
   }
+#endif
 }
 
 /* stride: bytes staged per row.  pitch: address step between rows (== stride for rows side by side; the overlapping virtual
@@ -818,7 +832,8 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   /* column blocks: fewest blocks of at most max_cb bytes, equal width, 16-byte (vec) / 4-byte granular -- 8-byte where the
    * tuned kernels can run (they take whole 8-base windows: a 152-byte row is 80 + 72, not 76 + 76, which fell to the generic
    * kernel at five times the time) */
-  const bool tuned_geom = e->P.subk == 6 && e->P.k >= 9 && e->P.k <= 11 && stride % 8u == 0;
+  const bool tuned_sk = (e->P.subk == 6 && e->P.k >= 9 && e->P.k <= 11) || (e->P.subk == 5 && e->P.k == 11); /* the tuned instantiations */
+  const bool tuned_geom = tuned_sk && stride % 8u == 0;
   const uint32_t g = vec ? 16u : (tuned_geom ? 8u : 4u);
   const uint32_t max_cb = e->tune_cb;
   a.ncb = (stride + max_cb - 1) / max_cb;
@@ -832,8 +847,10 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   a.bm_words = 1u << e->bm_bits;
   /* tuned kernels: 24-bit inner substring (subk 6), k in {9,10,11}, every column block a whole number of 8-base pairs; they
    * keep the pair filter's 256-entry mask table in front of the filter */
-  const int tuned_k = (e->P.subk == 6 && stride % 8u == 0 && a.CB % 8u == 0 && e->P.k >= 9 && e->P.k <= 11) ? e->P.k : 0;
-  a.mt_words = tuned_k ? MK_ZMASK_WORDS : 0u;
+  const int tuned_k = (tuned_sk && stride % 8u == 0 && a.CB % 8u == 0) ? e->P.k : 0;
+  a.mt_words = tuned_k && e->P.subk == 6 ? MK_ZMASK_WORDS : 0u;
+  a.pair_subk = tuned_k ? (uint32_t)e->P.subk : 0u;
+  if (tuned_k && e->P.subk == 5) a.bm_words = 16384u; /* the 2^19-bit membership bitmap of mk_build_xfilter, in both kernels */
   a.dimmask = (uint32_t)((1ull << (4 * e->P.subk)) - 1ull);
   a.accept = e->d_accept; a.n_accept = e->n_accept;
   a.shuf = e->d_shuf;
@@ -871,11 +888,12 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   hipError_t r;
-  switch (tuned_k) {
-    case 11: r = vec ? mk_launch_scan_k<11, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<11, false>(e, threads, false, a, grid, lds, e->stream); break;
-    case 10: r = vec ? mk_launch_scan_k<10, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<10, false>(e, threads, false, a, grid, lds, e->stream); break;
-    case 9: r = vec ? mk_launch_scan_k<9, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<9, false>(e, threads, false, a, grid, lds, e->stream); break;
-    default: r = vec ? mk_launch_scan_k<0, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<0, false>(e, threads, false, a, grid, lds, e->stream); break;
+  switch (tuned_k * 10 + (tuned_k ? e->P.subk : 0)) {
+    case 116: r = vec ? mk_launch_scan_k<11, 6, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<11, 6, false>(e, threads, false, a, grid, lds, e->stream); break;
+    case 106: r = vec ? mk_launch_scan_k<10, 6, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<10, 6, false>(e, threads, false, a, grid, lds, e->stream); break;
+    case 96: r = vec ? mk_launch_scan_k<9, 6, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<9, 6, false>(e, threads, false, a, grid, lds, e->stream); break;
+    case 115: r = vec ? mk_launch_scan_k<11, 5, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<11, 5, false>(e, threads, false, a, grid, lds, e->stream); break;
+    default: r = vec ? mk_launch_scan_k<0, 0, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<0, 0, false>(e, threads, false, a, grid, lds, e->stream); break;
   }
   if (r != hipSuccess) return mk_fail(e, MK_ERR_HIP, "scan launch: %s", hipGetErrorString(r));
   if (e->profiling) {
@@ -1739,7 +1757,7 @@ struct mk_bctx {
   void *h_desc = nullptr; size_t h_desc_cap = 0;   /* pinned: what goes up in one small copy (descriptor, files, seg0s, row0s) */
   void *h_stat = nullptr; size_t h_stat_cap = 0;   /* pinned: what comes back first (per-file status, per-component sizes, totals) */
   uint32_t *h_ids = nullptr; size_t h_ids_cap = 0; /* pinned: the ids */
-  hipEvent_t ev_stat = nullptr;
+  hipEvent_t ev_stat = nullptr, ev_h2d = nullptr;
   mk_batch_dev hb{};
   int mode = 0;
   uint32_t nfiles = 0;
@@ -1774,6 +1792,7 @@ static void mk_bctx_free(mk_bctx *c) {
   if (c->h_stat) hipHostFree(c->h_stat);
   if (c->h_ids) hipHostFree(c->h_ids);
   if (c->ev_stat) hipEventDestroy(c->ev_stat);
+  if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
   delete c;
 }
 static size_t mk_up16(size_t v) { return (v + 15u) & ~(size_t)15u; }
@@ -1781,9 +1800,11 @@ static size_t mk_up16(size_t v) { return (v + 15u) & ~(size_t)15u; }
 /* rows one scan launch may take so that a scan wave's candidate buffer is expected to stay below half its capacity: the share
  * of bases whose window passes the LDS filter is the accepted share of the subspace (both strands) plus the filter's false
  * positives (three bits per entry in 32 * bm_words bits; the tuned kernels' pair filter: measured 2 % of the 8-base windows) */
-static uint64_t mk_rows_per_launch(const mk_engine *e, uint32_t row_bases, bool tuned) {
+static uint64_t mk_rows_per_launch(const mk_engine *e, uint32_t row_bases, int tuned_subk) {
   const double fill = 1.0 - exp(-3.0 * (double)e->n_accept / (32.0 * (double)(1u << e->bm_bits)));
-  const double per_base = tuned ? 0.02 / 8.0 : (double)e->n_accept / (double)e->P.shuf_len + fill * fill * fill;
+  /* records per base: the tuned kernels append one record per flagged 8-base window (subk 6: 2 % of them; subk 5: a base in 64
+   * passes the half-size bitmap, 12 % of the windows), the generic kernel one per flagged base */
+  const double per_base = tuned_subk == 6 ? 0.02 / 8.0 : tuned_subk == 5 ? 0.125 / 8.0 : (double)e->n_accept / (double)e->P.shuf_len + fill * fill * fill;
   const double per_row = per_base * row_bases + 1e-9;
   const uint64_t waves = (uint64_t)e->num_cu * (uint64_t)(e->tune_threads / 64);
   double rows = 0.5 * (double)e->cand_cap / per_row * (double)waves;
@@ -1812,6 +1833,19 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
   if (!e->bctx[ci]) e->bctx[ci] = new mk_bctx();
   mk_bctx *c = e->bctx[ci];
   if (!c->ev_stat) MK_HIP(e, hipEventCreateWithFlags(&c->ev_stat, hipEventDisableTiming));
+  if (!c->ev_h2d) MK_HIP(e, hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
+  if (e->bcopy_state == 0) { /* the copy queue: made beside the first batches */
+    e->bcopy_state = 1;
+    if (pthread_create(&e->bcopy_thread, nullptr, [](void *arg) -> void * {
+          mk_engine *en = (mk_engine *)arg;
+          hipStream_t st = nullptr;
+          const bool ok = hipSetDevice(en->device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+          if (!ok) (void)hipGetLastError();
+          en->bcopy_stream = ok ? st : nullptr;
+          __atomic_store_n(&en->bcopy_state, ok ? 2 : 3, __ATOMIC_RELEASE);
+          return nullptr;
+        }, e) != 0) e->bcopy_state = 0; /* (no thread: asked for again at the next batch) */
+  }
   const uint32_t C = (uint32_t)e->P.component_num;
   const uint32_t TL = (uint32_t)e->P.TL, pitch = MK_FA_PITCH_SMALL, rowlen = pitch + TL - 1u;
   const uint32_t width = (rowlen + 1u + 15u) & ~15u;
@@ -1882,7 +1916,7 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
   const uint32_t bpf = bpc * C;
   const uint64_t nb = (uint64_t)nfiles * bpf;
   c->stat_bytes = mk_up16((size_t)nfiles * sizeof(mk_bstat)) + mk_up16((size_t)nfiles * C * 4) + 16;
-  const size_t zero_bytes = (size_t)N * 16 + mk_up16((size_t)(nb + 1) * 4) + c->stat_bytes;
+  const size_t zero_bytes = (size_t)N * 16 + mk_up16((size_t)(nb + 1) * 4) + c->stat_bytes + (size_t)nfiles * 64;
   if ((rc = mk_dbuf_fit(e, c->text, (size_t)text_span + 256))) return rc;
   if ((rc = mk_dbuf_fit(e, c->stream, (size_t)soff + 8192))) return rc;
   if ((rc = mk_dbuf_fit(e, c->sum, (size_t)nseg_total * sizeof(mk_fa_sum)))) return rc;
@@ -1900,6 +1934,7 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
     hb->stat = (mk_bstat *)st;
     hb->ctot = (uint32_t *)(st + mk_up16((size_t)nfiles * sizeof(mk_bstat)));
     hb->misc = (unsigned long long *)(st + mk_up16((size_t)nfiles * sizeof(mk_bstat)) + mk_up16((size_t)nfiles * C * 4));
+    hb->nout = (uint32_t *)(st + c->stat_bytes);
     hb->map = (unsigned long long *)c->map.p;
     uint8_t *l = (uint8_t *)c->list.p;
     hb->key = (unsigned long long *)l;
@@ -1928,24 +1963,29 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
   const mk_batch_dev *dbatch = (const mk_batch_dev *)dd;
   hipStream_t s = e->stream;
 
-  /* ---- the launch sequence */
-  MK_HIP(e, hipMemcpyAsync(c->desc.p, c->h_desc, desc_bytes, hipMemcpyHostToDevice, s));
+  /* ---- the launch sequence.  The copies on the copy queue when it is there (this context's buffers are free: its last batch has
+   * been handed out), the kernels behind an event */
+  const bool side = __atomic_load_n(&e->bcopy_state, __ATOMIC_ACQUIRE) == 2 && s == e->own_stream;
+  hipStream_t cs = side ? e->bcopy_stream : s;
+  MK_HIP(e, hipMemcpyAsync(c->desc.p, c->h_desc, desc_bytes, hipMemcpyHostToDevice, cs));
   if (one_copy) {
-    if (text_span) MK_HIP(e, hipMemcpyAsync(c->text.p, files[0].text, (size_t)text_span, hipMemcpyHostToDevice, s));
+    if (text_span) MK_HIP(e, hipMemcpyAsync(c->text.p, files[0].text, (size_t)text_span, hipMemcpyHostToDevice, cs));
   } else {
     for (uint32_t i = 0; i < nfiles; i++)
-      if (files[i].n) MK_HIP(e, hipMemcpyAsync((uint8_t *)c->text.p + hf[i].text_off, files[i].text, (size_t)files[i].n, hipMemcpyHostToDevice, s));
+      if (files[i].n) MK_HIP(e, hipMemcpyAsync((uint8_t *)c->text.p + hf[i].text_off, files[i].text, (size_t)files[i].n, hipMemcpyHostToDevice, cs));
   }
+  if (side) MK_HIP(e, hipEventRecord(c->ev_h2d, cs));
   const unsigned wide = (unsigned)e->num_cu * 8u;
   hipLaunchKernelGGL(mk_b_clear_kernel, dim3(wide), dim3(256), 0, s, (uint4 *)c->zero.p, (unsigned long long)(zero_bytes / 16u), (uint4 *)c->map.p,
                      (unsigned long long)(N / 2u), (uint4 *)nullptr, 0ull);
+  if (side) MK_HIP(e, hipStreamWaitEvent(s, c->ev_h2d, 0));
   hipLaunchKernelGGL(mk_fab_summary_kernel, dim3((nseg_total + 3u) / 4u), dim3(256), 0, s, (const uint8_t *)c->text.p, c->hb, nseg_total, (mk_fa_sum *)c->sum.p);
   hipLaunchKernelGGL(mk_fab_scan_kernel, dim3(nfiles), dim3(1024), 0, s, (mk_fa_sum *)c->sum.p, c->hb, TL, pitch);
   hipLaunchKernelGGL(mk_fab_emit_kernel, dim3((nseg_total + 3u) / 4u), dim3(256), 0, s, (const uint8_t *)c->text.p, c->hb, nseg_total,
                      (const mk_fa_sum *)c->sum.p, (uint8_t *)c->stream.p);
   MK_HIP(e, hipGetLastError());
   {
-    const bool tuned = e->P.subk == 6 && e->P.k >= 9 && e->P.k <= 11;
+    const int tuned = (e->P.subk == 6 && e->P.k >= 9 && e->P.k <= 11) ? 6 : (e->P.subk == 5 && e->P.k == 11) ? 5 : 0;
     const uint64_t per = mk_rows_per_launch(e, rowlen, tuned);
     e->cur_batch = dbatch;
     for (uint64_t done = 0; done < total_rows && rc == MK_OK; done += per) {
@@ -2026,7 +2066,6 @@ extern "C" int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out) {
   for (uint32_t i = 0; i < nfiles; i++) {
     uint64_t tot = 0;
     for (uint32_t k = 0; k < C; k++) tot += ctot[(size_t)i * C + k];
-    if (tot != st[i].nout) return mk_fail(e, MK_ERR_HIP, "batch: file %u: component sizes do not add up", i);
     if (out[i].alone || out[i].status != MK_OK) { at += (size_t)tot; continue; } /* (flagged files have no entries: tot == 0) */
     for (uint32_t k = 0; k < C; k++) {
       mk_component &mc = c->comps[(size_t)i * C + k];

@@ -87,7 +87,9 @@ struct mk_scan_args {
   uint32_t rowdw;     /* LDS dwords per staged row (odd => conflict-free row reads) */
   uint32_t wave_lds_dwords;
   uint32_t bm_words;  /* LDS filter words (power of two) */
-  uint32_t mt_words;  /* tuned kernels: the 256-entry mask table in front of the filter (LDS offset 0), else 0 */
+  uint32_t mt_words;  /* tuned kernels with subk 6: the 256-entry mask table in front of the filter (LDS offset 0), else 0 */
+  uint32_t pair_subk; /* 0: every candidate record is a single k-mer (generic kernel); 6 / 5: pair records of the tuned kernels for that
+                       * half_subctx_len -- the resolve kernel then holds the matching exact-side filter (mk_build_filter / mk_build_xfilter) */
   uint32_t dimmask;   /* 2^(4*subk)-1: the inner substring after uni >> out2 */
   const uint32_t *accept; /* inner substrings d with dim_start <= shuf[d] < dim_end */
   uint32_t n_accept;
@@ -264,7 +266,7 @@ __device__ __forceinline__ void mk_resolve_record(const mk_scan_args &a, const u
     mk_resolve_one(a, ((uint64_t)r.y << 32) | r.x, ((uint64_t)(r.w & 0x7FFFFFFFu) << 32) | r.z);
     return;
   }
-  const uint32_t K = a.kp.TL >> 1, SH = 2u * (K - 6u) - 2u;
+  const uint32_t SH = a.kp.out2 - 2u; /* the inner substring of the k-mer ending at base j: bits SH.. of the low word in front of base j */
   const uint32_t hm = (uint32_t)((1ull << (2u * a.kp.TL - 32u)) - 1ull); /* mk_kmer_hi<K>::HMASK */
   const uint32_t pos0 = (r.y & 0x1FFu) << 3, jmin = (r.y >> 9) & 7u, e = (r.y >> 12) & 15u;
   const uint32_t lo = r.y & 0xFFFF0000u, h2 = r.z & 0xFFFFu, h3 = r.z >> 16;
@@ -274,7 +276,7 @@ __device__ __forceinline__ void mk_resolve_record(const mk_scan_args &a, const u
   uint32_t before = r.x, hits = 0;
 #pragma unroll
   for (uint32_t j = 0; j < 8; j++) {
-    const uint32_t x = (before >> SH) & 0xFFFFFFu;
+    const uint32_t x = (before >> SH) & a.dimmask;
     if (j >= jmin && j < e && (!filter || (mk_filter_mask(x) & ~filter[(x >> 10) & (a.bm_words - 1u)]) == 0u)) hits |= 1u << j;
     before = __builtin_amdgcn_alignbit(r.x, lo, 30u - 2u * j);
   }
@@ -297,6 +299,7 @@ __device__ __noinline__ void mk_resolve_inline(const mk_scan_args *ka, bool hit,
 }
 
 __device__ __forceinline__ void mk_build_filter(uint32_t *bitmap, const mk_scan_args &a);
+__device__ __forceinline__ void mk_build_xfilter(uint32_t *bitmap, const mk_scan_args &a);
 
 /* ---- resolve kernel ----------------------------------------------------------------------------------------------------
  * Resolves the candidates the scan kernel appended.  A workgroup builds the exact per-base LDS filter once and walks
@@ -373,7 +376,8 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
   if (threadIdx.x == 0) wg_installed = 0u;
   const bool front_open = mk_front_open(a.tab);
   uint32_t installed = 0; /* wave-uniform: keys this wave put into the front table */
-  mk_build_filter(rlds, a);
+  if (a.pair_subk == 5u) mk_build_xfilter(rlds, a);
+  else mk_build_filter(rlds, a);
   const uint32_t lane = mk_lane(), wave = threadIdx.x >> 6;
   uint4 *rings = (uint4 *)(rlds + a.bm_words) + (size_t)wave * 2u * MK_RQ_CAP;
   mk_wring r1{rings, 0u, 0u}, r2{rings + MK_RQ_CAP, 0u, 0u};
@@ -397,8 +401,10 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
     }
   };
 
-  /* pair records only come from the tuned kernels (k = 9, 10, 11 with subk 6); for any other geometry every record is a single k-mer */
-  const uint32_t K = a.kp.TL >> 1, SH = K > 7u ? 2u * (K - 6u) - 2u : 0u;
+  /* pair records only come from the tuned kernels (k = 9, 10, 11 with subk 6; k = 11 with subk 5); for any other geometry every record
+   * is a single k-mer */
+  const uint32_t SH = a.pair_subk ? a.kp.out2 - 2u : 0u;
+  const bool x5 = a.pair_subk == 5u;
   const uint32_t hm = a.kp.TL > 16u ? (uint32_t)((1ull << (2u * a.kp.TL - 32u)) - 1ull) : 0u; /* mk_kmer_hi<K>::HMASK */
   const uint32_t wmask = a.bm_words - 1u;
 
@@ -437,7 +443,16 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
     const uint32_t jmin = (r.y >> 9) & 7u, e = single ? 0u : (r.y >> 12) & 15u;
     const uint32_t lo = r.y & 0xFFFF0000u;
     uint32_t hits = 0;
-    {
+    if (x5) { /* subk 5: the 2^20 substrings in 2^19 bits (mk_build_xfilter), the scan kernel's own test */
+      uint32_t before = r.x;
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t x = (before >> SH) & 0xFFFFFu;
+        if ((rlds[x >> 6] >> (x & 31u)) & 1u) hits |= 1u << j;
+        before = __builtin_amdgcn_alignbit(r.x, lo, 30u - 2u * j);
+      }
+      hits &= (0xFFu << jmin) & ~(0xFFFFFFFFu << e);
+    } else {
       uint32_t oh3 = 1u << ((r.x >> (SH + 6u)) & 31u), oh2 = 1u << ((r.x >> (SH + 4u)) & 31u), oh1 = 1u << ((r.x >> (SH + 2u)) & 31u);
       uint32_t before = r.x;
 #pragma unroll
@@ -602,6 +617,20 @@ __device__ __forceinline__ void mk_build_zfilter(uint32_t *masktab, uint32_t *bi
   __syncthreads();
 }
 
+/* subk 5 (L2K11): B has 8192 members among 2^20 substrings -- one in 128, sixteen times as dense as at subk 6, and a pair key
+ * (18 bits) would pass one pair in sixteen.  But 2^20 bits are 128 KiB: HALF of that fits the LDS beside the tiles, so the filter
+ * is the membership bitmap of B itself with bit 5 of the substring dropped -- word = x[6..19] (16384 words), bit = x[0..4] -- and a
+ * substring passes when it or its neighbour x ^ 32 is in B: one base in 64, no hash, no mask table, ONE LDS read per base. */
+__device__ __forceinline__ void mk_build_xfilter(uint32_t *bitmap, const mk_scan_args &a) {
+  for (uint32_t i = threadIdx.x; i < 16384u; i += blockDim.x) bitmap[i] = 0u;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < a.n_accept; i += blockDim.x) {
+    const uint32_t d = (uint32_t)mk_scan_to_ref_codes(a.accept[i]) & 0xFFFFFu; /* reference coding -> scan coding (same map) */
+    atomicOr(&bitmap[d >> 6], 1u << (d & 31u));
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ void mk_build_filter(uint32_t *bitmap, const mk_scan_args &a) {
   for (uint32_t i = threadIdx.x; i < a.bm_words; i += blockDim.x) bitmap[i] = 0u;
   __syncthreads();
@@ -615,8 +644,9 @@ __device__ __forceinline__ void mk_build_filter(uint32_t *bitmap, const mk_scan_
 /* ONEPASS (only with exactly two column blocks per row): the loads for BOTH blocks of a tile are issued together,
  * so every 64-byte sector of the rows is requested once -- two separate 80-byte passes re-fetch the sector the
  * halves share (+37 % HBM reads, tools/ubench_fetch.hip).  Costs NPIECES more piece registers. */
-template <int K, bool VEC16, int THREADS, int NPIECES, bool ONEPASS>
+template <int K, int SUBK, bool VEC16, int THREADS, int NPIECES, bool ONEPASS>
 __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) {
+  static_assert(K == 0 || SUBK == 6 || (SUBK == 5 && K == 11), "tuned instantiations: k 9..11 with subk 6, k 11 with subk 5");
   extern __shared__ __align__(16) uint32_t lds[];
   constexpr uint32_t WAVES = THREADS / 64;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -637,12 +667,14 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     }
   }
   /* both end with a barrier: the tables are visible to every wave */
-  if constexpr (K != 0) mk_build_zfilter(lds, bitmap, a);
+  if constexpr (K != 0 && SUBK == 6) mk_build_zfilter(lds, bitmap, a);
+  else if constexpr (K != 0) mk_build_xfilter(bitmap, a);
   else mk_build_filter(bitmap, a);
 
   /* the tuned loop addresses the mask table (LDS offset 0) and the filter (right behind it) absolutely */
   const uint32_t filter_base = (uint32_t)(uintptr_t)(mk_lds_cu32)bitmap;
-  if (K != 0 && (filter_base != MK_ZMASK_WORDS * 4u || a.mt_words != MK_ZMASK_WORDS || a.bm_words != 16384u || a.dimmask != 0xFFFFFFu)) {
+  constexpr uint32_t MTW = (K != 0 && SUBK == 6) ? MK_ZMASK_WORDS : 0u; /* mask table in front of the filter: the pair filter only */
+  if (K != 0 && (filter_base != MTW * 4u || a.mt_words != MTW || a.bm_words != 16384u || a.dimmask != (SUBK == 6 ? 0xFFFFFFu : 0xFFFFFu))) {
     if (threadIdx.x == 0) atomicOr(&a.tab.err[0], 4u);
     if (lane == 0) a.cand_count[blockIdx.x * WAVES + wave] = 0u; /* nothing for the resolve kernel to pick up */
     return;
@@ -928,16 +960,20 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
          * kernel, entered for the rest of the row: 50 M reads trimmed to 100..150 bases 4.6 -> 2.4 ms, an N in 1 % of the
          * reads 4.5 -> 2.24 ms, in 5 % 7.6 -> 2.5 ms, and the untouched rows 2.28 -> 2.14 ms on the same box (the kernel
          * lost the byte-wise path, its registers and its spills) (tools/probe_ragged_reads.py). */
-        constexpr uint32_t SH = 2u * (K - 6) - 2u; /* out2 - 2 */
+        constexpr uint32_t SH = 2u * (K - SUBK) - 2u; /* out2 - 2 */
         constexpr uint32_t HM = mk_kmer<K>::HMASK;
-        static_assert(SH + 24u <= 32u, "inner substring must lie inside flo(j-1)");
+        static_assert(SH + 4u * SUBK <= 32u, "inner substring must lie inside flo(j-1)");
         /* Pair probing (see mk_build_zfilter): bases (2t, 2t+1) of the 8-base window share the key z = x_{2t}[0..21],
          * which sits in bits SH+2.. of before_{2t+1} (the low word in front of base 2t+1).  Filter word z[8..21]:
          * bits SH+10.. of before_{2t+1}; mask-table entry z[0..7]: the low word D = (SH-2)/2 bases earlier holds
          * those bits at 2..9 -- a dword address after one AND.  pa[] carries those addresses out of before_{-D}..before_{-1}
          * (the previous window's last low words) for the pairs whose earlier word lies in front of this window. */
-        constexpr uint32_t D = (SH - 2u) / 2u;
-        static_assert(SH >= 4u && SH <= 8u, "pair probing: z[0..7] at bits 2..9 of a low word D bases earlier");
+        /* subk 5 (mk_build_xfilter): ONE probe per base.  The substring of base j is x = before_j[10..29]; its filter word x[6..19]
+         * sits in the top half of before_{j+1} = before_j << 2 | code (one SDWA AND makes the byte address), its bit x[0..4] in
+         * bits 8..12 of before_{j-1} (byte 1: the SDWA shift takes it from there) -- three VALU per base with the funnel shift. */
+        constexpr uint32_t D = SUBK == 6 ? (SH - 2u) / 2u : 1u;
+        static_assert(SUBK != 6 || (SH >= 4u && SH <= 8u), "pair probing: z[0..7] at bits 2..9 of a low word D bases earlier");
+        static_assert(SUBK != 5 || SH == 10u, "per-base probing: word address in WORD_1 of before_{j+1}, bit index in BYTE_1 of before_{j-1}");
         uint32_t urun = 0;
         auto in_step = [&]() -> bool { /* sets urun; needs a live lane */
           const uint32_t rc = min(run, TL);
@@ -950,8 +986,12 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
         uint32_t flo = km.flo;
         uint32_t pa[3] = {0u, 0u, 0u}; /* mask-table addresses out of before_{-D}..before_{-1}: carried ready for use (no move, no AND at the use) */
         auto oh_init = [&]() { /* before_{k-D} = flo >> 2(D-k): only bits 2..9 matter, and those are exact */
+          if constexpr (SUBK == 6) {
 #pragma unroll
-          for (uint32_t k = 0; k < D; k++) pa[k] = (flo >> (2u * (D - k))) & 0x3FCu;
+            for (uint32_t k = 0; k < D; k++) pa[k] = (flo >> (2u * (D - k))) & 0x3FCu;
+          } else {
+            pa[0] = flo >> 2; /* before_{-1}: its bits 8..12 (= flo[10..14]) are all that is read */
+          }
         };
         oh_init();
         uint32_t w0, w1, c0, x0, c1, x1;
@@ -981,35 +1021,60 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
             const uint32_t f4 = __builtin_amdgcn_alignbit(fstart, lo, 22), f5 = __builtin_amdgcn_alignbit(fstart, lo, 20);
             const uint32_t f6 = __builtin_amdgcn_alignbit(fstart, lo, 18), f7 = __builtin_amdgcn_alignbit(fstart, lo, 16);
             /* before_0 .. before_7; only the ones a probe names are ever computed (k = 11: f0, f2, f4, f6) */
-            const uint32_t bj[8] = {fstart, f0, f1, f2, f3, f4, f5, f6};
-            uint32_t mm[4], dd[4];
+            const uint32_t bj[9] = {fstart, f0, f1, f2, f3, f4, f5, f6, f7};
+            bool fired;
+            if constexpr (SUBK == 6) {
+              uint32_t mm[4], dd[4];
 #pragma unroll
-            for (uint32_t t = 0; t < 4; t++) {
-              const uint32_t wsrc = bj[2u * t + 1u];
+              for (uint32_t t = 0; t < 4; t++) {
+                const uint32_t wsrc = bj[2u * t + 1u];
 #if defined(MK_TUNING) && defined(MK_ABL)
-              /* ablation builds (make tuning VARIANT=-DMK_ABL=n): timing probes with WRONG results, never shipped
-               * (profiles/r03_a_scan_ablation.txt).  2: no mask reads; 3: mask reads at conflict-free addresses (bank := lane);
-               * 4: filter-word reads at conflict-free addresses; 5: both conflict-free */
-              uint32_t wa = ((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u;
-              uint32_t ma = 2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t];
-              const uint32_t lane4 = (lane & 31u) << 2;
-              if (MK_ABL == 3 || MK_ABL == 5) ma = (ma & ~0x7Cu) | lane4;
-              if (MK_ABL == 4 || MK_ABL == 5) wa = (wa & ~0x7Cu) | lane4;
-              dd[t] = *(mk_lds_cu32)(uintptr_t)wa;
-              if (MK_ABL == 2) mm[t] = ma | 0x80000000u; else mm[t] = *(mk_lds_cu32)(uintptr_t)ma;
+                /* ablation builds (make tuning VARIANT=-DMK_ABL=n): timing probes with WRONG results, never shipped
+                 * (profiles/r03_a_scan_ablation.txt).  2: no mask reads; 3: mask reads at conflict-free addresses (bank := lane);
+                 * 4: filter-word reads at conflict-free addresses; 5: both conflict-free */
+                uint32_t wa = ((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u;
+                uint32_t ma = 2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t];
+                const uint32_t lane4 = (lane & 31u) << 2;
+                if (MK_ABL == 3 || MK_ABL == 5) ma = (ma & ~0x7Cu) | lane4;
+                if (MK_ABL == 4 || MK_ABL == 5) wa = (wa & ~0x7Cu) | lane4;
+                dd[t] = *(mk_lds_cu32)(uintptr_t)wa;
+                if (MK_ABL == 2) mm[t] = ma | 0x80000000u; else mm[t] = *(mk_lds_cu32)(uintptr_t)ma;
 #else
-              dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u);
-              mm[t] = *(mk_lds_cu32)(uintptr_t)(2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t]);
+                dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u);
+                mm[t] = *(mk_lds_cu32)(uintptr_t)(2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t]);
 #endif
-            }
+              }
 #pragma unroll
-            for (uint32_t k = 0; k < D; k++) pa[k] = bj[8u - D + k] & 0x3FCu;
-            flo = f7;
-            __builtin_amdgcn_sched_barrier(0); /* all probes in flight before the first result is read */
-            __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) once, instead of a staggered wait per probe */
-            /* t == 0 <=> every bit of the pair's mask is set in its filter word */
-            const uint32_t tt0 = mm[0] & ~dd[0], tt1 = mm[1] & ~dd[1], tt2 = mm[2] & ~dd[2], tt3 = mm[3] & ~dd[3];
-            const bool fired = min(min(tt0, tt1), min(tt2, tt3)) == 0u;
+              for (uint32_t k = 0; k < D; k++) pa[k] = bj[8u - D + k] & 0x3FCu;
+              flo = f7;
+              __builtin_amdgcn_sched_barrier(0); /* all probes in flight before the first result is read */
+              __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) once, instead of a staggered wait per probe */
+              /* t == 0 <=> every bit of the pair's mask is set in its filter word */
+              const uint32_t tt0 = mm[0] & ~dd[0], tt1 = mm[1] & ~dd[1], tt2 = mm[2] & ~dd[2], tt3 = mm[3] & ~dd[3];
+              fired = min(min(tt0, tt1), min(tt2, tt3)) == 0u;
+            } else {
+              uint32_t wd[8];
+#pragma unroll
+              for (uint32_t j = 0; j < 8; j++) {
+                uint32_t addr; /* (before_{j+1} >> 16) & 0xFFFC = ((before_j >> 16) & 0x3FFF) << 2: byte address of word x[6..19] */
+                asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+                    : "=v"(addr) : "v"(bj[j + 1u]), "v"(0xFFFCu));
+                wd[j] = *(mk_lds_cu32)(uintptr_t)addr;
+              }
+              const uint32_t bprev = pa[0];
+              pa[0] = f6; /* before_7: the next window's before_{-1} */
+              flo = f7;
+              __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_s_waitcnt(0xC07F);
+              uint32_t sh[8];
+#pragma unroll
+              for (uint32_t j = 0; j < 8; j++) { /* word >> x[0..4]: the shift amount is byte 1 of before_{j-1} (its low five bits) */
+                const uint32_t src = j == 0 ? bprev : bj[j - 1u];
+                asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
+                    : "=v"(sh[j]) : "v"(src), "v"(wd[j]));
+              }
+              fired = (((sh[0] | sh[1] | sh[2]) | (sh[3] | sh[4] | sh[5]) | (sh[6] | sh[7])) & 1u) != 0u;
+            }
             const bool hit = fired && live;
             const uint64_t hm = __builtin_amdgcn_ballot_w64(fired) & livem; /* (the ballot of `hit` itself goes through a 0/1 value and a second compare) */
             if (hm) {

@@ -24,7 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define MK_FA_SEG 1024u /* text bytes per wave: 16 steps of 64 bytes, loaded four steps ahead (a 4 MB genome gives 4096 waves) */
+#define MK_FA_SEG 1024u /* text bytes per wave: 16 steps of 64 bytes (a 4 MB genome gives 4096 waves) */
 
 /* device-resident state of one engine's stream */
 struct mk_fa_state {
@@ -42,9 +42,11 @@ struct mk_fa_sum { /* per segment */
 
 /* one 64-byte step: which lanes' bytes are kept, for a step entered in state `st` (wave-uniform); returns the state behind it */
 __device__ __forceinline__ uint64_t mk_fa_step(uint8_t ch, bool valid, uint32_t lane, uint32_t &st) {
-  const uint64_t nl = __ballot(valid && ch == '\n');
   const uint64_t gt = __ballot(valid && ch == '>');
   const bool skipch = !valid || ch == '\n' || ch == '\r';
+  /* sequence lines only (no '>' in the step, not inside a header): every byte but the line ends stays -- nearly every step of a genome */
+  if (gt == 0ull && st == 0u) return __ballot(!skipch);
+  const uint64_t nl = __ballot(valid && ch == '\n');
   const uint64_t below = lane ? (~0ull >> (64u - lane)) : 0ull; /* lanes in front of this one */
   const uint64_t nlb = nl & below;
   /* bytes of this lane's line in front of it: behind the last '\n' below the lane (the whole step when there is none) */
@@ -61,22 +63,31 @@ __device__ __forceinline__ uint64_t mk_fa_step(uint8_t ch, bool valid, uint32_t 
   return keep;
 }
 
+/* A wave's segment of text, [lo, lo + MK_FA_SEG) with lo a multiple of 16, comes in with ONE 16-byte load per lane and is laid
+ * into the wave's 1 KiB of LDS; the walk then reads a byte per lane and step from there (64 consecutive bytes: conflict-free).  A
+ * byte load per lane and step from global memory instead is sixteen dependent round trips per segment: the two passes over a
+ * batch of 128 MB took 228 + 177 us that way (profiles/r04_a_config5_*).  Bytes from `hi` on are never looked at (the steps mask them);
+ * the buffers end in slack, so the load itself may run past `hi`. */
+#define MK_FA_WAVES 4u /* waves (segments) per workgroup of the summary and emit kernels */
+__device__ __forceinline__ const uint8_t *mk_fa_stage(const uint8_t *text, uint64_t lo, uint32_t lane, uint4 *seg_lds) {
+  seg_lds[lane] = *(const uint4 *)(text + lo + 16u * lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return (const uint8_t *)seg_lds;
+}
+
 /* summary of the text bytes [lo, hi) (one wave): {state behind, bytes kept} for both entry states */
-__device__ __forceinline__ mk_fa_sum mk_fa_summarise(const uint8_t *text, uint64_t lo, uint64_t hi, uint32_t lane) {
+__device__ __forceinline__ mk_fa_sum mk_fa_summarise(const uint8_t *text, uint64_t lo, uint64_t hi, uint32_t lane, uint4 *seg_lds) {
   uint32_t s0 = 0u, s1 = 1u, c0 = 0u, c1 = 0u;
-  for (uint64_t at0 = lo; at0 < hi; at0 += 256u) {
-    uint8_t chs[4];
+  if (hi > lo) {
+    const uint8_t *seg = mk_fa_stage(text, lo, lane, seg_lds);
+    const uint32_t n = (uint32_t)(hi - lo);
 #pragma unroll
-    for (uint32_t u = 0; u < 4u; u++) { /* four loads in flight: a wave walks its segment in dependent steps otherwise */
-      const uint64_t at = at0 + 64u * u;
-      chs[u] = at + lane < hi ? text[at + lane] : (uint8_t)'\n';
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < 4u; u++) {
-      const uint64_t at = at0 + 64u * u;
-      if (at >= hi) break;
-      const bool valid = at + lane < hi;
-      const uint8_t ch = chs[u];
+    for (uint32_t j = 0; j < MK_FA_SEG / 64u; j++) {
+      if (64u * j >= n) break;
+      const bool valid = 64u * j + lane < n;
+      const uint8_t ch = seg[64u * j + lane];
       uint32_t a = s0, b = s1;
       const uint64_t k0 = mk_fa_step(ch, valid, lane, a);
       const uint64_t k1 = s1 == s0 ? k0 : mk_fa_step(ch, valid, lane, b);
@@ -97,7 +108,8 @@ __global__ void __launch_bounds__(256) mk_fa_summary_kernel(const uint8_t *text,
   const uint64_t lo = seg * MK_FA_SEG;
   if (lo >= n) return;
   const uint64_t hi = lo + MK_FA_SEG < n ? lo + MK_FA_SEG : n;
-  const mk_fa_sum r = mk_fa_summarise(text, lo, hi, lane);
+  __shared__ uint4 seg_lds[MK_FA_WAVES][64];
+  const mk_fa_sum r = mk_fa_summarise(text, lo, hi, lane, seg_lds[threadIdx.x >> 6]);
   if (lane == 0) sum[seg] = r;
 }
 
@@ -181,26 +193,21 @@ __global__ void __launch_bounds__(1024) mk_fa_scan_kernel(mk_fa_sum *sum, uint64
 
 /* the text bytes [lo, hi) once more with the entry state known (off: mk_fa_sum::off of the segment): kept bytes to
  * stream[base + offset ..] (one wave) */
-__device__ __forceinline__ void mk_fa_emit_seg(const uint8_t *text, uint64_t lo, uint64_t hi, uint32_t o, uint8_t *stream, uint64_t base, uint32_t lane) {
+__device__ __forceinline__ void mk_fa_emit_seg(const uint8_t *text, uint64_t lo, uint64_t hi, uint32_t o, uint8_t *stream, uint64_t base, uint32_t lane,
+                                               uint4 *seg_lds) {
   uint32_t s = o >> 31;
   uint64_t off = base + (o & 0x7FFFFFFFu);
-  for (uint64_t at0 = lo; at0 < hi; at0 += 256u) {
-    uint8_t chs[4];
+  if (hi <= lo) return;
+  const uint8_t *seg = mk_fa_stage(text, lo, lane, seg_lds);
+  const uint32_t n = (uint32_t)(hi - lo);
 #pragma unroll
-    for (uint32_t u = 0; u < 4u; u++) {
-      const uint64_t at = at0 + 64u * u;
-      chs[u] = at + lane < hi ? text[at + lane] : (uint8_t)'\n';
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < 4u; u++) {
-      const uint64_t at = at0 + 64u * u;
-      if (at >= hi) break;
-      const bool valid = at + lane < hi;
-      const uint8_t ch = chs[u];
-      const uint64_t keep = mk_fa_step(ch, valid, lane, s);
-      if ((keep >> lane) & 1ull) stream[off + mk_mbcnt(keep)] = ch;
-      off += (uint64_t)__popcll(keep);
-    }
+  for (uint32_t j = 0; j < MK_FA_SEG / 64u; j++) {
+    if (64u * j >= n) break;
+    const bool valid = 64u * j + lane < n;
+    const uint8_t ch = seg[64u * j + lane];
+    const uint64_t keep = mk_fa_step(ch, valid, lane, s);
+    if ((keep >> lane) & 1ull) stream[off + mk_mbcnt(keep)] = ch;
+    off += (uint64_t)__popcll(keep);
   }
 }
 
@@ -211,7 +218,8 @@ __global__ void __launch_bounds__(256) mk_fa_emit_kernel(const uint8_t *text, ui
   const uint64_t lo = seg * MK_FA_SEG;
   if (lo >= n) return;
   const uint64_t hi = lo + MK_FA_SEG < n ? lo + MK_FA_SEG : n;
-  mk_fa_emit_seg(text, lo, hi, sum[seg].off, stream, stream_len_before, lane);
+  __shared__ uint4 seg_lds[MK_FA_WAVES][64];
+  mk_fa_emit_seg(text, lo, hi, sum[seg].off, stream, stream_len_before, lane, seg_lds[threadIdx.x >> 6]);
 }
 
 /* behind a scan of `rows_taken` rows (device value): the unscanned tail moves to the front of the stream buffer */

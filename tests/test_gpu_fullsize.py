@@ -60,7 +60,10 @@ def test_full_size_sketch_properties(capi, shufs, reads_dev):
         ids7, cnt7 = sketch(capi, e0, reads_dev, 7)
         assert np.array_equal(ids, ids7) and np.array_equal(cnt, cnt7)            # batching does not matter
         assert ids.size == np.unique(ids).size and cnt.min() >= 1
-        assert ids.size == 1573525                                                # bench.py's distinct_keys for this workload
+        # the COMPILED REFERENCE's key count for this workload: oracle/_ref/metakssd dist -A -p 256 over the same 50 M reads as a
+        # FASTQ file, whose (id, count) multiset the product's sketch equals (tools/check_fullsize_vs_ref.py,
+        # profiles/r04_fullsize_vs_reference.json)
+        assert ids.size == 1573525
         # expected accepted occurrences: 129 k-mers per read, 1/4096 of the inner substrings accepted
         total = int(cnt.astype(np.int64).sum())
         assert abs(total - N * 129 / 4096) < 5 * (N * 129 / 4096) ** 0.5
