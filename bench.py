@@ -105,11 +105,75 @@ def leg_stream(torch, capi, eng, reads_dev, n, reps=3):
         total = int(r.total)
         capi.lib.mk_result_release(eng.h, r)
         best = dt if best is None or dt < best else best
+    out = {"gbases_s": n * READ_LEN / best / 1e9, "h2d_gb_s": n * STRIDE / best / 1e9, "seconds": best, "reps": reps,
+           "distinct_keys": total,
+           "what": "%d reads as %d-byte rows in pinned host memory -> mk_sketch_push_reads (hipMemcpyAsync into 256 MiB staging "
+                   "regions, one scan launch per region) -> mk_sketch_finish; best of %d" % (n, STRIDE, reps)}
+    try:
+        out["packed_rows"] = leg_packed(torch, capi, eng, pinned, n, total, reps)
+    except Exception as ex:
+        out["packed_rows"] = {"what": "failed: %s" % ex}
     del pinned
-    return {"gbases_s": n * READ_LEN / best / 1e9, "h2d_gb_s": n * STRIDE / best / 1e9, "seconds": best, "reps": reps,
-            "distinct_keys": total,
-            "what": "%d reads as %d-byte rows in pinned host memory -> mk_sketch_push_reads (hipMemcpyAsync into 256 MiB staging "
-                    "regions, one scan launch per region) -> mk_sketch_finish; best of %d" % (n, STRIDE, reps)}
+    return out
+
+
+def leg_packed(torch, capi, eng, pinned_text_rows, n, distinct_text, reps=3):
+    """the same reads as 64-byte PACKED rows (MK_ROWS_PACKED: what the command line's framers make of reads of up to 152 bases):
+    (a) out of pinned host memory like t_stream, (b) resident in HBM -- mk_scan_packed_kernel's own time per launch"""
+    import ctypes
+    import threading
+    P = capi.MK_PACKED_PITCH
+    packed = torch.empty(n * P, dtype=torch.uint8, pin_memory=True)
+    T = min(32, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+
+    def work(k):
+        lo, hi = n * k // T, n * (k + 1) // T
+        rc = capi.lib.mk_pack_rows_host(ctypes.c_void_p(pinned_text_rows.data_ptr() + lo * STRIDE), STRIDE, hi - lo,
+                                        ctypes.c_void_p(packed.data_ptr() + lo * P))
+        assert rc == 0
+    th = [threading.Thread(target=work, args=(k,)) for k in range(T)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    t_pack = time.perf_counter() - t0
+    stride = P | capi.MK_ROWS_PACKED
+    best, total = None, 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        eng.begin(capi.MK_MODE_KOC)
+        capi._check(capi.lib.mk_sketch_push_reads(eng.h, packed.data_ptr(), stride, n, 0), eng.h)
+        r = eng.finish_raw()
+        dt = time.perf_counter() - t0
+        total = int(r.total)
+        capi.lib.mk_result_release(eng.h, r)
+        best = dt if best is None or dt < best else best
+    dev = torch.empty(n * P, dtype=torch.uint8, device="cuda")
+    dev.copy_(packed)
+    torch.cuda.synchronize()
+    eng.profile_enable(True)
+    eng.profile_reset()
+    steps = 20
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.begin(capi.MK_MODE_KOC)
+        eng.push_reads_device(dev.data_ptr(), stride, n, 0)
+        r = eng.finish_raw()
+        capi.lib.mk_result_release(eng.h, r)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    prof = eng.profile()
+    eng.profile_enable(False)
+    scan_ms = prof["scan_ms"] / max(1, prof["scan_launches"])
+    del dev, packed
+    return {"t_stream_gbases_s": n * READ_LEN / best / 1e9, "t_stream_h2d_gb_s": n * P / best / 1e9, "t_stream_seconds": best,
+            "resident_ms_per_step": dt * 1e3, "resident_gbases_s": n * READ_LEN / dt / 1e9,
+            "scan_ms_per_launch": scan_ms, "scan_bytes_per_launch": n * P,
+            "scan_gb_s_of_packed_bytes": n * P / (scan_ms * 1e-3) / 1e9 if scan_ms else None,
+            "resolve_ms_per_step": prof["resolve_ms"] / steps, "host_pack_s": t_pack, "host_pack_threads": T,
+            "distinct_keys": total, "sketch_size_equals_text_rows": total == distinct_text,
+            "what": "the workload as %d-byte packed rows (2 bits a base + 1 validity bit, mk_pack_rows_host on %d threads): pinned host memory "
+                    "-> mk_sketch_push_reads -> finish (best of %d), and resident in HBM -> mk_scan_packed_kernel (%d plain steps, each "
+                    "waited for; its time per launch from the engine's events).  NOT the headline: `value` is on text rows" % (P, T, reps, steps)}
 
 
 def leg_e2e(capi, shuf, n, resident_sketch, reps=4):

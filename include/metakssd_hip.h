@@ -180,6 +180,19 @@ int mk_sketch_begin_occ(mk_engine *e, int min_occurrence);
  * the sequential order whose table layout the result reproduces, so they must increase in file order.
  * Host variant: returns once `rows` may be reused (device copy done; the scan may still be running). */
 int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t stride, uint64_t nreads, uint64_t first_read_ordinal);
+/* PACKED rows: `stride` = MK_PACKED_PITCH | MK_ROWS_PACKED in any of the push calls.  A row is then 64 bytes for a read of up to
+ * MK_PACKED_MAX_BASES bases: 2 bits a base in the scan kernel's own coding ((byte >> 1) & 3: A0 C1 T2 G3) and one validity bit a
+ * base (is it one of ACGTacgt) -- what the scan kernel's first instructions make of an ASCII row, done by the framer thread
+ * instead, so that a 150-base read crosses PCIe as 64 bytes, not 160.  Little-endian dwords: [0] = bases | (every base valid) << 16;
+ * [1 + p] = the codes of bases 16p .. 16p + 15, first base in the top two bits; bytes 44 + w = validity of bases 8w .. 8w + 7 (bit j:
+ * base 8w + j).  The sketch is the one the ASCII rows give (a byte that is no base resets the k-mer window either way,
+ * iseq2comem.c:682-690).  Only the geometries with a tuned scan kernel take packed rows (mk_params_packed_ok); the library's FASTQ
+ * stream makes them with mk_fastq_opts.packed, mk_pack_rows_host converts ASCII rows. */
+#define MK_ROWS_PACKED 0x80000000u
+#define MK_PACKED_PITCH 64u
+#define MK_PACKED_MAX_BASES 152u
+int mk_params_packed_ok(const mk_params *p);
+int mk_pack_rows_host(const uint8_t *rows, uint32_t stride, uint64_t nrows, uint8_t *packed /* nrows * MK_PACKED_PITCH bytes */);
 int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev, uint32_t stride, uint64_t nreads,
                                 uint64_t first_read_ordinal);
 /* Asynchronous host variant: returns once the copies are queued; `rows` must stay untouched until
@@ -330,6 +343,8 @@ typedef struct mk_fastq_opts {
                            Never set it for anonymous memory (the text would read back as zeros). */
   int32_t ahead;        /* row buffers beyond threads + inflight + 1 (0..192): how far the framers may run ahead of the pushes, e.g. while
                            the engine is still being created */
+  int32_t packed;       /* != 0: buffers whose reads all have at most MK_PACKED_MAX_BASES bases are framed as PACKED rows (the sink
+                           gets stride = MK_PACKED_PITCH | MK_ROWS_PACKED for those), the others as ASCII rows */
 } mk_fastq_opts;
 typedef struct mk_fastq_stats {
   uint64_t rows, records, chunks, chunks_discarded, serial_rows; /* discarded / serial: work redone on the calling thread */

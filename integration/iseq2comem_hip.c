@@ -156,6 +156,7 @@ static void sketch_fastq(const char *who, mk_engine *e, const char *path, const 
   mk_fastq_opts o;
   memset(&o, 0, sizeof o);
   o.occ = occ; o.qmin = Q; o.TL = g_params.TL; o.nthreads = threads < 1 ? 1 : threads; o.inflight = 3;
+  o.packed = mk_params_packed_ok(&g_params); /* reads of up to 152 bases cross PCIe as 64-byte packed rows */
   if (plain_file(path, pipecmd, &map, &size)) {
     o.drop_pages = 1;
     const int rc = mk_sketch_push_fastq(e, map, size, &o, 0, NULL);

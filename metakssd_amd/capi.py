@@ -16,6 +16,7 @@ MK_OK = 0
 MK_ERR_ARG, MK_ERR_NO_DEVICE, MK_ERR_HIP, MK_ERR_CROWDED = -1, -2, -3, -4
 MK_ERR_STATE, MK_ERR_IO, MK_ERR_FORMAT, MK_ERR_NOMEM = -5, -6, -7, -8
 MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET, MK_MODE_OCC_SET = 0, 1, 2, 3
+MK_ROWS_PACKED, MK_PACKED_PITCH, MK_PACKED_MAX_BASES = 0x80000000, 64, 152
 MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP, MK_OPT_DIRECT_HOST, MK_OPT_FRONT_BITS, MK_OPT_KEYLIST_CAP, MK_OPT_BATCH_TAB_BITS = 1, 2, 3, 4, 5, 6, 7
 
 
@@ -64,7 +65,7 @@ class FastaStateC(C.Structure):
 
 class FastqOptsC(C.Structure):
     _fields_ = [("occ", C.c_int32), ("qmin", C.c_int32), ("TL", C.c_int32), ("nthreads", C.c_int32), ("inflight", C.c_int32),
-                ("chunk_bytes", C.c_uint64), ("drop_pages", C.c_int32), ("ahead", C.c_int32)]
+                ("chunk_bytes", C.c_uint64), ("drop_pages", C.c_int32), ("ahead", C.c_int32), ("packed", C.c_int32)]
 
 
 class FastqStatsC(C.Structure):
@@ -120,6 +121,8 @@ def _load():
         "mk_sketch_push_stream": [vp, vp, u64, C.c_int],
         "mk_partial_count_begin": [vp],
         "mk_partial_export_async": [vp, vp, vp, vp, u64, C.POINTER(u64)],
+        "mk_pack_rows_host": [vp, u32, u64, vp],
+        "mk_params_packed_ok": [C.POINTER(ParamsC)],
         "mk_sketch_batch_begin": [vp, C.c_int, vp, u32],
         "mk_sketch_batch_end": [vp, vp],
         "mk_sketch_finish": [vp, C.POINTER(ResultC)],
@@ -250,6 +253,17 @@ def synth_rows_host(seed, first_read, nreads, length, stride):
     return rows
 
 
+def pack_rows_host(rows, stride):
+    """ASCII rows -> 64-byte packed rows (mk_pack_rows_host); 16-byte aligned result"""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n = rows.size // stride
+    raw = np.zeros(n * MK_PACKED_PITCH + 64, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 64
+    out = raw[off:off + n * MK_PACKED_PITCH]
+    _check(lib.mk_pack_rows_host(rows.ctypes.data if n else None, stride, n, out.ctypes.data if n else None))
+    return out
+
+
 def fastq_frame(buf, stride, final=True, max_rows=None):
     """FASTQ bytes -> fixed-stride rows (numpy u8 [nrows*stride]); returns (rows, nrows, consumed, rc)"""
     b = np.frombuffer(buf, dtype=np.uint8)
@@ -284,7 +298,7 @@ def fastq_frame_mt(buf, stride, nthreads, occ=False, TL=22, qmin=0, final=True, 
     return rows[: n.value * stride], n.value, nrec.value, used.value, rc
 
 
-def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2, drop_pages=False):
+def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2, drop_pages=False, packed=False):
     """the whole-file FASTQ stream (mk_fastq_stream) into host memory: returns (list of (rows u8 array, stride, nrows,
     first ordinal) in push order, stats, rc).  Buffers come from malloc here; the engine-bound form is Engine.push_fastq."""
     b = np.frombuffer(buf, dtype=np.uint8)
@@ -295,8 +309,8 @@ def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first
     libc.free.argtypes = [C.c_void_p]
 
     def push(ctx, rows, stride, nrows, ord0, token):
-        a = np.ctypeslib.as_array(C.cast(rows, C.POINTER(C.c_uint8)), shape=(nrows * stride,)).copy()
-        pushes.append((a, stride, nrows, ord0))
+        a = np.ctypeslib.as_array(C.cast(rows, C.POINTER(C.c_uint8)), shape=(nrows * (stride & ~MK_ROWS_PACKED),)).copy()
+        pushes.append((a, stride, nrows, ord0))  # (stride & MK_ROWS_PACKED: 64-byte packed rows)
         token[0] = len(pushes)
         return 0
 
@@ -306,7 +320,7 @@ def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first
     sink = RowsSinkC(None, _PUSH_FN(push), _WAIT_FN(wait), _ALLOC_FN(lambda ctx, n: libc.malloc(n)),
                      _RELEASE_FN(lambda ctx, p, n: libc.free(p)))
     keep["sink"] = sink
-    o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 1 if drop_pages else 0, 0)
+    o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 1 if drop_pages else 0, 0, 1 if packed else 0)
     st = FastqStatsC()
     rc = lib.mk_fastq_stream(b.ctypes.data if len(b) else None, len(b), C.byref(o), C.byref(sink), first_ordinal, C.byref(st))
     return pushes, st, rc
@@ -389,18 +403,19 @@ class Engine:
         _check(lib.mk_sketch_begin_occ(self.h, min_occurrence), self.h)
 
     def push_reads(self, rows, stride, first_read_ordinal=0):
-        """rows: host numpy u8 array of nreads*stride bytes"""
+        """rows: host numpy u8 array of nreads*stride bytes (stride | MK_ROWS_PACKED: 64-byte packed rows)"""
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
-        assert rows.size % stride == 0
-        n = rows.size // stride
+        pitch = stride & ~MK_ROWS_PACKED
+        assert rows.size % pitch == 0
+        n = rows.size // pitch
         if n:
             _check(lib.mk_sketch_push_reads(self.h, rows.ctypes.data, stride, n, first_read_ordinal), self.h)
         return n
 
-    def push_fastq(self, buf, nthreads=8, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2):
+    def push_fastq(self, buf, nthreads=8, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2, packed=False):
         """whole FASTQ text (bytes / numpy u8 / mmap) -> framed by host threads and pushed (mk_sketch_push_fastq); returns stats"""
         b = np.frombuffer(buf, dtype=np.uint8)
-        o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 0, 0)
+        o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 0, 0, 1 if packed else 0)
         st = FastqStatsC()
         _check(lib.mk_sketch_push_fastq(self.h, b.ctypes.data if len(b) else None, len(b), C.byref(o), first_ordinal, C.byref(st)), self.h)
         return st

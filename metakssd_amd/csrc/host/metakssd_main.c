@@ -189,7 +189,7 @@ typedef struct {
   uint64_t chunk_bytes;
   mk_fastq_stats fq_stats;
   double t_first_push, t_last_push, t_unmapped, t_begin_s;
-  int drop_pages, inflight, direct_host;
+  int drop_pages, inflight, direct_host, packed;
   uint8_t *arena; /* pinned row-buffer pool of the FASTQ stream */
   size_t arena_bytes;
   int arena_unpinned; /* mapped and being filled, pinned at the first push (the runtime was not up when it was made) */
@@ -431,6 +431,7 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   memset(&o, 0, sizeof o);
   o.occ = c->occ; o.qmin = c->qmin; o.TL = c->TL;
   o.nthreads = c->nthreads; o.inflight = c->inflight; o.chunk_bytes = c->chunk_bytes; o.ahead = g_ahead;
+  o.packed = c->packed; /* reads of up to 152 bases cross PCIe as 64-byte packed rows (geometries with a tuned scan kernel) */
   o.drop_pages = c->drop_pages; /* a private read-only file mapping that is unmapped below */
   mk_rows_sink sink = {c, cli_sink_push, cli_sink_wait, cli_sink_alloc, cli_sink_release};
   mk_fastq_stats fs;
@@ -1882,7 +1883,7 @@ int main(int argc, char **argv) {
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 24) nthreads = 24; /* 20-24 framer threads keep PCIe busy; more only take memory bandwidth from the copies */
   uint64_t chunk_bytes = (uint64_t)32 << 20; /* text per framing job = about 17 MiB of rows per host-to-device copy */
-  int drop_pages = 1, inflight = 3, slow_exit = 0, direct_host = 0;
+  int drop_pages = 1, inflight = 3, slow_exit = 0, direct_host = 0, ascii_rows = 0;
   int devs[64], ndev = 0; /* --devices 0-7 / 0,2,5 / 0,0 (the same GPU twice: two engines, for tests) */
   int engines_per_gpu = 0; /* --engines 1..4: engines taking the files of a directory in turn on one GPU (default: MK_DEFAULT_ENGINES from eight files on) */
   int allow_copies = 0;   /* --allow-device-copies: distinct GPUs whose RCCL does not come up exchange with peer copies instead of failing */
@@ -1919,6 +1920,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--inflight") && i + 1 < argc) inflight = atoi(argv[++i]); /* row buffers queued for copying */
     else if (!strcmp(argv[i], "--ahead") && i + 1 < argc) g_ahead = atoi(argv[++i]); /* row buffers the framers may run ahead by */
     else if (!strcmp(argv[i], "--direct")) direct_host = 1; /* MK_OPT_DIRECT_HOST: scan pinned row buffers in place */
+    else if (!strcmp(argv[i], "--ascii-rows")) ascii_rows = 1; /* FASTQ rows as text (160 bytes per 150-base read) instead of packed (64) */
     else if (!strcmp(argv[i], "--slow-exit")) slow_exit = 1; /* destroy the engine and return from main() instead of _exit() */
     else if (!strcmp(argv[i], "--keep-pages")) drop_pages = 0; /* measurement: leave all unmapping to the final munmap */
     else if (!strcmp(argv[i], "-r") && i + 1 < argc) refpath = argv[++i];
@@ -2022,6 +2024,7 @@ int main(int argc, char **argv) {
   c.drop_pages = drop_pages;
   c.inflight = inflight;
   c.direct_host = direct_host;
+  c.packed = !ascii_rows && mk_params_packed_ok(&P);
 
   /* -A stays on only if every input is FASTQ: the reference switches it off when its file loop reaches the first
    * non-FASTQ input (command_dist.c:389-392) and then writes no combco.N.a at all (:427-431).  FASTQ files in front of

@@ -43,7 +43,7 @@ typedef struct {
   const uint8_t *text;
   size_t n, chunk;
   uint64_t nchunks;
-  int occ, qmin, TL, drop_pages;
+  int occ, qmin, TL, drop_pages, packed;
   size_t buf_bytes;
   int nbufs;
   uint8_t **bufs;
@@ -115,7 +115,27 @@ static uint32_t fs_sample_stride(const uint8_t *t, size_t n, size_t start, int o
 static void fs_frame_range(const fs_t *f, size_t start, size_t stop, int first_of_file, uint8_t *buf, fs_slot *s) {
   uint32_t stride = fs_sample_stride(f->text, f->n, start, f->occ);
   if (f->occ && stride < 2u * (uint32_t)f->TL + 4u) stride = fs_round_stride(2u * (size_t)f->TL + 4u);
+  /* packed rows (64 bytes a read, MK_ROWS_PACKED) when every read of the range has at most 152 bases; a longer one turns up as
+   * MK_ERR_ARG and the range is framed again as ASCII rows */
+  int packed = f->packed && stride <= MK_PACKED_MAX_BASES + 16u;
   for (;;) {
+    if (packed) {
+      uint64_t nrows = 0, nrec = 0;
+      size_t used = 0;
+      uint32_t need = 0;
+      int rc;
+      const uint32_t ps = MK_PACKED_PITCH | MK_ROWS_PACKED;
+      if (f->occ)
+        rc = mk_fastq_frame_q_range(f->text + start, f->n - start, stop - start, 1, f->qmin, f->TL, first_of_file ? 0 : 1, buf, ps,
+                                    f->buf_bytes / MK_PACKED_PITCH, &nrows, &nrec, &used, &need);
+      else {
+        rc = mk_fastq_frame_range(f->text + start, f->n - start, stop - start, 1, buf, ps, f->buf_bytes / MK_PACKED_PITCH, &nrows, &used, &need);
+        nrec = nrows;
+      }
+      if (rc == MK_ERR_ARG && need) { packed = 0; if (need > stride) stride = fs_round_stride((size_t)need + need / 8u); continue; }
+      s->start = start; s->end = start + used; s->nrows = nrows; s->nrec = nrec; s->stride = ps; s->rc = rc;
+      return;
+    }
     uint64_t nrows = 0, nrec = 0;
     size_t used = 0;
     uint32_t need = 0;
@@ -195,6 +215,7 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
   memset(&f, 0, sizeof f);
   f.text = text; f.n = n;
   f.occ = o->occ != 0; f.qmin = o->qmin; f.TL = o->TL;
+  f.packed = o->packed != 0;
   f.drop_pages = o->drop_pages != 0 && ((uintptr_t)text & 4095u) == 0;
   f.chunk = o->chunk_bytes ? (size_t)o->chunk_bytes : (size_t)32 << 20;
   if (f.chunk < 4096) f.chunk = 4096;

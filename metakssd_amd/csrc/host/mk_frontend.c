@@ -57,6 +57,108 @@ static inline void mk_rows_done(void) { /* streaming stores are weakly ordered: 
 #endif
 }
 
+/* ---- packed rows (MK_ROWS_PACKED, include/metakssd_hip.h): 2 bits a base + 1 validity bit a base, 64 bytes a read -------------
+ * What mk_scan_kernel's decode() does per dword on the device -- code = (byte >> 1) & 3 (A0 C1 T2 G3), valid <=> the byte folded
+ * to upper case is the letter of its code -- done here once, on the framer's thread, so that a 150-base read crosses PCIe as 64
+ * bytes instead of 160.  Layout of a row (little-endian dwords):
+ *   dword 0        : number of bases (bits 0..15) | flags (bit 16: every base valid)
+ *   dwords 1..10   : the codes, eight bases (a "window") in 16 bits, first base in the top two bits; windows 2p and 2p+1 in the high
+ *                    and low half of dword 1 + p -- the form the scan loop's funnel shift takes them in
+ *   bytes 44..63   : one validity byte per window, bit j = base 8w + j is one of ACGTacgt (bits behind the last base: 0) */
+#define MK_PACK_WINDOWS 19u /* 152 bases */
+
+static void mk_pack_block_scalar(const uint8_t *src, uint32_t n, uint32_t *codes2, uint32_t *valid) {
+  /* n <= 32 bases -> two code dwords (windows 0..3 of the block) and 32 validity bits */
+  uint32_t c[2] = {0, 0}, v = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t b = src[i], code = (b >> 1) & 3u;
+    const int ok = (b & 0xDFu) == (uint32_t)"ACTG"[code];
+    if (ok) { v |= 1u << i; c[i >> 4] |= code << (30u - 2u * (i & 15u)); }
+  }
+  codes2[0] = c[0]; codes2[1] = c[1]; *valid = v;
+}
+
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static void mk_pack_block_avx2(const uint8_t *src32, uint32_t n, uint32_t *codes2, uint32_t *valid) {
+  /* src32: 32 readable bytes; bases from n on are masked out */
+  const __m256i b = _mm256_loadu_si256((const __m256i *)src32);
+  const __m256i codes = _mm256_and_si256(_mm256_srli_epi16(b, 1), _mm256_set1_epi8(3));
+  const __m256i lut = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+  const __m256i ok = _mm256_cmpeq_epi8(_mm256_and_si256(b, _mm256_set1_epi8((char)0xDF)), _mm256_shuffle_epi8(lut, codes));
+  uint32_t v = (uint32_t)_mm256_movemask_epi8(ok);
+  if (n < 32u) v &= (1u << n) - 1u;
+  /* bytes of four codes each: c0 * 64 + c1 * 16 + c2 * 4 + c3, one per 32-bit lane */
+  const __m256i w = _mm256_setr_epi8(64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1);
+  const __m256i q = _mm256_madd_epi16(_mm256_maddubs_epi16(_mm256_and_si256(codes, ok), w), _mm256_set1_epi16(1));
+  /* the four quads of a 128-bit half, first one in the top byte */
+  const __m256i g = _mm256_shuffle_epi8(q, _mm256_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
+  uint32_t c0 = (uint32_t)_mm256_extract_epi32(g, 0), c1 = (uint32_t)_mm256_extract_epi32(g, 4);
+  if (n < 32u) { /* (the validity AND above used the unmasked compare: drop the codes of bytes behind the read) */
+    const uint64_t keep = n >= 32u ? ~0ull : ((1ull << (2u * n)) - 1ull) << (64u - 2u * n); /* the first n two-bit fields of {c0, c1} */
+    const uint64_t cc = (((uint64_t)c0 << 32) | c1) & (n ? keep : 0ull);
+    c0 = (uint32_t)(cc >> 32); c1 = (uint32_t)cc;
+  }
+  codes2[0] = c0; codes2[1] = c1; *valid = v;
+}
+static int mk_have_avx2(void) {
+  static int have = -1;
+  if (have < 0) have = __builtin_cpu_supports("avx2") && !getenv("MK_NO_AVX2") ? 1 : 0; /* (MK_NO_AVX2: the tests run the scalar form too) */
+  return have;
+}
+#else
+static int mk_have_avx2(void) { return 0; }
+#endif
+
+/* nb <= 152 bases at src -> the 64-byte packed row (16-byte aligned: streaming stores, see mk_row_store) */
+static inline void mk_row_pack(uint8_t *row, const uint8_t *src, size_t nb) {
+  uint32_t out[16] __attribute__((aligned(16)));
+  memset(out, 0, sizeof out);
+  uint8_t *vb = (uint8_t *)out + 44;
+  uint32_t allvalid = 1;
+  for (uint32_t at = 0; at < nb; at += 32u) {
+    const uint32_t n = nb - at < 32u ? (uint32_t)(nb - at) : 32u;
+    uint32_t c2[2], v;
+#if defined(__x86_64__) && defined(__GNUC__)
+    if (mk_have_avx2()) {
+      if (n == 32u) mk_pack_block_avx2(src + at, 32u, c2, &v);
+      else { uint8_t tmp[32]; memset(tmp, 0, sizeof tmp); memcpy(tmp, src + at, n); mk_pack_block_avx2(tmp, n, c2, &v); }
+    } else
+#endif
+      mk_pack_block_scalar(src + at, n, c2, &v);
+    out[1 + at / 16u] = c2[0];
+    if (at + 16u < nb) out[2 + at / 16u] = c2[1];
+    memcpy(vb + at / 8u, &v, (n + 7u) / 8u);
+    if (v != (n == 32u ? 0xFFFFFFFFu : (1u << n) - 1u)) allvalid = 0;
+  }
+  out[0] = (uint32_t)nb | (allvalid << 16);
+#if defined(__SSE2__)
+  if (((uintptr_t)row & 15u) == 0) {
+    for (int i = 0; i < 4; i++) _mm_stream_si128((__m128i *)(row + 16 * i), _mm_load_si128((const __m128i *)((const uint8_t *)out + 16 * i)));
+    return;
+  }
+#endif
+  memcpy(row, out, 64);
+}
+
+int mk_params_packed_ok(const mk_params *p) {
+  /* the geometries with a tuned scan kernel: their loop takes eight bases in 16 bits (mk_engine.hip) */
+  return p && ((p->subk == 6 && p->k >= 9 && p->k <= 11) || (p->subk == 5 && p->k == 11));
+}
+
+int mk_pack_rows_host(const uint8_t *rows, uint32_t stride, uint64_t nrows, uint8_t *packed) {
+  if ((!rows && nrows) || (!packed && nrows) || stride < 4 || stride > 4096) return MK_ERR_ARG;
+  for (uint64_t r = 0; r < nrows; r++) {
+    const uint8_t *row = rows + r * (uint64_t)stride;
+    const uint8_t *nl = (const uint8_t *)memchr(row, '\n', stride);
+    const size_t nb = nl ? (size_t)(nl - row) : stride;
+    if (nb > MK_PACKED_MAX_BASES) return MK_ERR_ARG;
+    mk_row_pack(packed + r * (uint64_t)MK_PACKED_PITCH, row, nb);
+  }
+  mk_rows_done();
+  return MK_OK;
+}
+
 #define MK_FQ_LEN 4096 /* iseq2comem.c:656: fgets() never returns more than FQ_LEN-1 characters */
 
 int mk_synth_rows_host(uint64_t seed, uint64_t first_read, uint64_t nreads, uint32_t len, uint32_t stride, uint8_t *rows) {
@@ -193,7 +295,10 @@ static size_t mk_line(const uint8_t *p, const uint8_t *end, int final) {
  * row must hold when MK_ERR_ARG reports a sequence line longer than the stride. */
 int mk_fastq_frame_range(const uint8_t *buf, size_t n, size_t stop, int final, uint8_t *rows, uint32_t stride, uint64_t max_rows,
                          uint64_t *nrows, size_t *consumed, uint32_t *need) {
+  const int packed = (stride & MK_ROWS_PACKED) != 0; /* 64-byte packed rows: a sequence line of more than 152 bases is MK_ERR_ARG */
+  if (packed) stride &= ~MK_ROWS_PACKED;
   if ((!buf && n) || !rows || !nrows || !consumed || stride < 4 || stride > 4096 || (stride & 3) || stop > n) return MK_ERR_ARG;
+  if (packed && stride != MK_PACKED_PITCH) return MK_ERR_ARG;
   const uint8_t *p = buf, *end = buf + n, *stop_at = buf + stop;
   uint64_t r = 0;
   int rc = MK_OK;
@@ -219,8 +324,9 @@ int mk_fastq_frame_range(const uint8_t *buf, size_t n, size_t stop, int final, u
       p = end;
       break;
     }
-    if (l2 > stride) { rc = MK_ERR_ARG; if (need) *need = (uint32_t)l2; break; } /* caller must re-frame from here with a larger stride */
-    mk_row_store(rows + r * (uint64_t)stride, s, l2, 0, stride);
+    if (packed ? l2 - 1 > MK_PACKED_MAX_BASES : l2 > stride) { rc = MK_ERR_ARG; if (need) *need = (uint32_t)l2; break; } /* caller must re-frame from here with a larger stride */
+    if (packed) mk_row_pack(rows + r * (uint64_t)stride, s, l2 - 1);
+    else mk_row_store(rows + r * (uint64_t)stride, s, l2, 0, stride);
     r++;
     p = t + l4;
   }
@@ -254,11 +360,14 @@ int mk_fastq_frame_q(const uint8_t *buf, size_t n, int final, int32_t qmin, int3
 int mk_fastq_frame_q_range(const uint8_t *buf, size_t n, size_t stop, int final, int32_t qmin, int32_t TL, uint64_t records_before,
                            uint8_t *rows, uint32_t stride, uint64_t max_rows, uint64_t *nrows, uint64_t *nrecords,
                            size_t *consumed, uint32_t *need_stride) {
+  const int packed = (stride & MK_ROWS_PACKED) != 0; /* 64-byte packed rows: a read of more than 152 bases is MK_ERR_ARG (no windows) */
+  if (packed) stride &= ~MK_ROWS_PACKED;
   if ((!buf && n) || !rows || !nrows || !nrecords || !consumed || stride > 4096 || (stride & 3) || TL < 2 || TL > 32 ||
       stride < 2u * (uint32_t)TL + 4 || stop > n)
     return MK_ERR_ARG;
+  if (packed && stride != MK_PACKED_PITCH) return MK_ERR_ARG;
   const uint8_t *p = buf, *end = buf + n, *stop_at = buf + stop;
-  const uint32_t cap = stride - 1;
+  const uint32_t cap = packed ? MK_PACKED_MAX_BASES : stride - 1;
   uint64_t r = 0, rec = 0;
   int rc = MK_OK;
   if (need_stride) *need_stride = 0;
@@ -284,7 +393,7 @@ int mk_fastq_frame_q_range(const uint8_t *buf, size_t n, size_t stop, int final,
     if (rc) break;
     size_t L = len[1];
     if (L && ln[1][L - 1] == '\n') L--;
-    if (L > cap && stride < 4096) { rc = MK_ERR_ARG; if (need_stride) *need_stride = (uint32_t)(L + 1 > 4096 ? 4096 : L + 1); break; } /* caller re-frames from here with wider rows */
+    if (L > cap && (stride < 4096 || packed)) { rc = MK_ERR_ARG; if (need_stride) *need_stride = (uint32_t)(L + 1 > 4096 ? 4096 : L + 1); break; } /* caller re-frames from here with wider rows */
     const uint64_t need = mk_rows_for(L, cap, (uint32_t)TL);
     if (r + need > max_rows) {
       if (r == 0) rc = MK_ERR_ARG;
@@ -296,14 +405,18 @@ int mk_fastq_frame_q_range(const uint8_t *buf, size_t n, size_t stop, int final,
     for (uint64_t w = 0; w < need; w++) {
       uint8_t *row = rows + (r + w) * (uint64_t)stride;
       size_t m = L - at < cap ? L - at : cap;
-      if (qmin <= -128) mk_row_store(row, sq + at, m, 1, stride); /* every signed quality byte passes */
+      if (qmin <= -128) { /* every signed quality byte passes */
+        if (packed) mk_row_pack(row, sq + at, m);
+        else mk_row_store(row, sq + at, m, 1, stride);
+      }
       else { /* a base whose quality byte is below -Q resets the window exactly like a non-ACGT byte (:367-379) */
         uint8_t masked[4096];
         for (size_t i = 0; i < m; i++) {
           const int qv = at + i < qn ? (int)(signed char)ql[at + i] : 0;
           masked[i] = qv >= qmin ? sq[at + i] : (uint8_t)'N';
         }
-        mk_row_store(row, masked, m, 1, stride);
+        if (packed) mk_row_pack(row, masked, m);
+        else mk_row_store(row, masked, m, 1, stride);
       }
       at += m;
       if (w + 1 < need) at -= (size_t)(TL - 1);

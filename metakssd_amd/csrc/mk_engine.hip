@@ -9,6 +9,7 @@
 #include "mk_kernels.hip.h"
 #include "mk_stream.hip.h"
 #include "mk_batch.hip.h"
+#include "mk_packed.hip.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -825,6 +826,8 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
                              const unsigned long long *nreads_dev, uint64_t first_ord) {
   if (nreads == 0) return MK_OK;
   if (nreads >= (1ull << 31)) return mk_fail(e, MK_ERR_ARG, "scan launch of %llu reads: the caller splits pushes below 2^31", (unsigned long long)nreads);
+  const bool packed = (stride & MK_ROWS_PACKED) != 0; /* 64-byte packed rows: mk_scan_packed_kernel, no column blocks, no LDS tiles */
+  if (packed) { stride &= ~MK_ROWS_PACKED; pitch = stride; }
   mk_scan_args a{};
   a.rows = rows_dev; a.nreads = nreads; a.first_ord = first_ord; a.stride = stride;
   a.pitch = pitch; a.rowlen = rowlen; a.nreads_dev = nreads_dev;
@@ -848,6 +851,7 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   /* tuned kernels: 24-bit inner substring (subk 6), k in {9,10,11}, every column block a whole number of 8-base pairs; they
    * keep the pair filter's 256-entry mask table in front of the filter */
   const int tuned_k = (tuned_sk && stride % 8u == 0 && a.CB % 8u == 0) ? e->P.k : 0;
+  if (packed && !tuned_k) return mk_fail(e, MK_ERR_ARG, "packed rows need a geometry with a tuned scan kernel");
   a.mt_words = tuned_k && e->P.subk == 6 ? MK_ZMASK_WORDS : 0u;
   a.pair_subk = tuned_k ? (uint32_t)e->P.subk : 0u;
   if (tuned_k && e->P.subk == 5) a.bm_words = 16384u; /* the 2^19-bit membership bitmap of mk_build_xfilter, in both kernels */
@@ -868,6 +872,7 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   for (;; threads -= 256) {
     lds = ((size_t)a.mt_words + (size_t)a.bm_words + (size_t)(threads / 64) * a.wave_lds_dwords) * 4u;
     if (vec) lds += 2u * (a.ppr <= 5u ? 5u : (uint32_t)MK_MAX_PIECES) * 64u * 4u; /* staging offset table of the 16-byte kernels: [2*NPIECES][64] */
+    if (packed) { threads = 1024; lds = ((size_t)a.mt_words + (size_t)a.bm_words) * 4u; } /* the filter, nothing else */
     if (lds <= 160u * 1024u || threads <= 512) break;
   }
   if (lds > 160u * 1024u) return mk_fail(e, MK_ERR_ARG, "scan: LDS budget exceeded (%zu bytes)", lds);
@@ -888,6 +893,27 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   hipError_t r;
+  if (packed) {
+    auto launch_packed = [&](auto kern) -> hipError_t {
+      const void *fn = (const void *)kern;
+      size_t *granted = nullptr;
+      for (auto &g : e->lds_granted) if (g.first == fn) granted = &g.second;
+      if (!granted) { e->lds_granted.emplace_back(fn, 0); granted = &e->lds_granted.back().second; }
+      if (lds > *granted) {
+        const hipError_t rr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (rr != hipSuccess) return rr;
+        *granted = lds;
+      }
+      hipLaunchKernelGGL(kern, grid, dim3(1024), lds, e->stream, a);
+      return hipGetLastError();
+    };
+    switch (tuned_k * 10 + e->P.subk) {
+      case 116: r = launch_packed(mk_scan_packed_kernel<11, 6>); break;
+      case 106: r = launch_packed(mk_scan_packed_kernel<10, 6>); break;
+      case 96: r = launch_packed(mk_scan_packed_kernel<9, 6>); break;
+      default: r = launch_packed(mk_scan_packed_kernel<11, 5>); break;
+    }
+  } else
   switch (tuned_k * 10 + (tuned_k ? e->P.subk : 0)) {
     case 116: r = vec ? mk_launch_scan_k<11, 6, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<11, 6, false>(e, threads, false, a, grid, lds, e->stream); break;
     case 106: r = vec ? mk_launch_scan_k<10, 6, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<10, 6, false>(e, threads, false, a, grid, lds, e->stream); break;
@@ -939,6 +965,12 @@ static int mk_launch_scan(mk_engine *e, const uint8_t *rows_dev, uint32_t stride
 static int mk_check_push(mk_engine *e, const void *rows, uint32_t stride) {
   if (!e) return MK_ERR_ARG;
   if (!e->begun) return mk_fail(e, MK_ERR_STATE, "push before mk_sketch_begin");
+  if (stride & MK_ROWS_PACKED) { /* 64-byte packed rows: the tuned geometries only (their loop takes eight bases in 16 bits) */
+    if (stride != (MK_PACKED_PITCH | MK_ROWS_PACKED)) return mk_fail(e, MK_ERR_ARG, "push: packed rows have a pitch of %u bytes", MK_PACKED_PITCH);
+    if (!mk_params_packed_ok(&e->P)) return mk_fail(e, MK_ERR_ARG, "push: packed rows need a geometry with a tuned scan kernel (mk_params_packed_ok)");
+    if ((uintptr_t)rows & 15u) return mk_fail(e, MK_ERR_ARG, "push: packed rows must be 16-byte aligned");
+    return MK_OK;
+  }
   if (!rows || stride < 4 || stride > 4096 || (stride & 3u)) return mk_fail(e, MK_ERR_ARG, "push: stride must be a multiple of 4 in 4..4096");
   return MK_OK;
 }
@@ -958,7 +990,7 @@ extern "C" int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev
   if (per > (1ull << 30)) per = 1ull << 30; /* 32-bit tile and row indices inside a launch */
   for (uint64_t done = 0; done < nreads; done += per) {
     const uint64_t n = nreads - done < per ? nreads - done : per;
-    int rc2 = mk_launch_scan(e, rows_dev + done * stride, stride, n, first_read_ordinal + done);
+    int rc2 = mk_launch_scan(e, rows_dev + done * (uint64_t)(stride & ~MK_ROWS_PACKED), stride, n, first_read_ordinal + done);
     if (rc2) return rc2;
   }
   return MK_OK;
@@ -1020,11 +1052,12 @@ extern "C" int mk_sketch_push_reads_async(mk_engine *e, const uint8_t *rows, uin
 #ifdef MK_TUNING
   if (first_push_) MK_TICK("push1: staging alloc");
 #endif
+  const uint32_t pitch = stride & ~MK_ROWS_PACKED; /* bytes per row; `stride` keeps the row format in its top bit */
   for (uint64_t done = 0; done < nreads;) {
     const uint64_t ord = first_read_ordinal + done;
     /* rows that do not continue the open region (another stride, a gap in the ordinals) start a new one */
     if (e->region_open && (stride != e->region_stride || ord != e->region_first_ord + e->region_rows ||
-                           e->region_fill + stride > e->stage_bytes)) {
+                           e->region_fill + pitch > e->stage_bytes)) {
       rc = mk_flush_region(e);
       if (rc) return rc;
     }
@@ -1035,17 +1068,17 @@ extern "C" int mk_sketch_push_reads_async(mk_engine *e, const uint8_t *rows, uin
       e->region_fill = 0; e->region_rows = 0;
       e->region_stride = stride; e->region_first_ord = ord;
     }
-    const uint64_t room = (e->stage_bytes - e->region_fill) / stride;
+    const uint64_t room = (e->stage_bytes - e->region_fill) / pitch;
     const uint64_t n = nreads - done < room ? nreads - done : room;
-    MK_HIP(e, hipMemcpyAsync(e->d_stage[e->stage_cur] + e->region_fill, rows + done * stride, n * stride, hipMemcpyHostToDevice,
+    MK_HIP(e, hipMemcpyAsync(e->d_stage[e->stage_cur] + e->region_fill, rows + done * pitch, n * pitch, hipMemcpyHostToDevice,
                              e->copy_stream));
 #ifdef MK_TUNING
     if (first_push_ && done == 0) MK_TICK("push1: first memcpyAsync");
 #endif
-    e->region_fill += n * stride;
+    e->region_fill += n * pitch;
     e->region_rows += n;
     done += n;
-    if (e->region_fill + stride > e->stage_bytes) { /* full: scan it while the next one fills */
+    if (e->region_fill + pitch > e->stage_bytes) { /* full: scan it while the next one fills */
       rc = mk_flush_region(e);
       if (rc) return rc;
     }

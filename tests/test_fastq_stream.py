@@ -188,3 +188,65 @@ def test_stream_row_pitch_avoids_multiples_of_128(capi, length, pitch):
     pushes, st, rc = capi.fastq_stream(data, nthreads=2, chunk_bytes=1 << 20, occ=0, TL=14, qmin=54, first_ordinal=0)
     assert rc == 0 and st.rows == 300
     assert {stride for _, stride, _, _ in pushes} == {pitch}
+
+
+# ---- packed rows out of the stream (mk_fastq_opts.packed) -----------------------------------------------------------------------
+def _bases_of_text(seq):
+    """a sequence line -> [(valid, code)]: what the scan kernel makes of its bytes ((byte >> 1) & 3, valid <=> ACGTacgt)"""
+    out = []
+    for b in seq:
+        code = (b >> 1) & 3
+        ok = (b & 0xDF) == b"ACTG"[code]
+        out.append((1, code) if ok else (0, 0))
+    return out
+
+
+def _bases_of_packed(row):
+    r = np.frombuffer(bytes(row), dtype=np.uint32)
+    nb = int(r[0] & 0xFFFF)
+    vb = bytes(row)[44:64]
+    out = []
+    for i in range(nb):
+        code = int(r[1 + i // 16] >> (30 - 2 * (i % 16))) & 3
+        ok = (vb[i // 8] >> (i % 8)) & 1
+        out.append((ok, code))
+    allv = int(r[0] >> 16) & 1
+    assert allv == int(all(v for v, _ in out)), "the row's all-valid flag"
+    return out
+
+
+@pytest.mark.parametrize("occ", [False, True])
+def test_stream_packed_rows_carry_the_serial_framers_bases(capi, occ):
+    """mk_fastq_opts.packed: buffers whose reads all fit 152 bases come as 64-byte packed rows -- base for base (code, validity) what the
+    serial framer's text rows hold; a buffer with a longer read comes as text rows; order and ordinals as ever"""
+    rs = np.random.RandomState(81)
+    seqs = []
+    for i in range(3000):
+        n = int(rs.randint(1, 153)) if i % 50 else int(rs.randint(0, 3))
+        s = bytearray(ui.rand_seq(rs, n))
+        if n and i % 7 == 0:
+            s[int(rs.randint(0, n))] = ord("N")
+        if i % 11 == 0:
+            s = bytearray(bytes(s).lower())
+        seqs.append(bytes(s))
+    seqs[1700] = ui.rand_seq(rs, 400)          # one long read: its buffer falls back to text rows
+    data = ui.fastq_bytes(seqs, quals=[bytes(rs.randint(44, 64, len(x)).astype(np.uint8)) for x in seqs])
+    want, nrec, rc = serial_rows(capi, data, occ)
+    assert rc == 0
+    want_bases = [_bases_of_text(w[:-1] if w.endswith(b"\n") else w) for w in want]
+    for T, chunk in ((1, 1 << 20), (3, 20000), (8, 4096 * 5)):
+        pushes, st, rc = capi.fastq_stream(data, nthreads=T, chunk_bytes=chunk, occ=occ, TL=14, qmin=54, first_ordinal=7, packed=True)
+        assert rc == 0
+        got, ord_expect, n_packed = [], 7, 0
+        for rows, stride, n, ord0 in pushes:
+            assert ord0 == ord_expect
+            ord_expect += n
+            if stride & capi.MK_ROWS_PACKED:
+                assert stride == (64 | capi.MK_ROWS_PACKED)
+                n_packed += n
+                got += [_bases_of_packed(rows[64 * i: 64 * i + 64]) for i in range(n)]
+            else:
+                got += [_bases_of_text(x[:-1] if x.endswith(b"\n") else x) for x in seqs_of_rows(rows, stride, n)]
+        assert st.records == nrec
+        assert got == want_bases, (T, chunk)
+        assert n_packed > 0 and (n_packed < len(got) or T == 1 and chunk >= len(data))

@@ -243,6 +243,92 @@ def test_fasta_device_stream_rough_text(capi, engine_for, shufs, oracle_for, nam
     assert ei.value.code == capi.MK_ERR_FORMAT
 
 
+@pytest.mark.parametrize("name", ["L3K11", "L3K10", "L3K9", "L2K11"])
+def test_packed_rows_equal_oracle(capi, engine_for, shufs, oracle_for, name):
+    """MK_ROWS_PACKED: 64-byte rows (2 bits a base + a validity bit a base, made by mk_pack_rows_host / the framers) through
+    mk_scan_packed_kernel -- the sketch of the same reads as text rows: fixed-length reads without N (every lane in step, no validity
+    test), ragged reads with N / lower case / other bytes (per-lane validity bytes), reads around the k-mer length, several pushes,
+    and the occurrence flavour"""
+    rs = np.random.RandomState(61)
+    ora = oracle_for(shufs(name))
+    eng = engine_for(name)
+    P = capi.MK_PACKED_PITCH | capi.MK_ROWS_PACKED
+    # A: the benchmark's rows (150 bases, uniform)
+    rows = capi.synth_rows_host(5, 0, 30000, 150, 160)
+    rc, want = ora.koc_from_rows(rows, 160)
+    assert rc == 0
+    packed = capi.pack_rows_host(rows, 160)
+    for pushes in (1, 3):
+        eng.begin(capi.MK_MODE_KOC)
+        n, per, done = 30000, (30000 + pushes - 1) // pushes, 0
+        while done < n:
+            m = min(per, n - done)
+            eng.push_reads(packed[done * 64:(done + m) * 64], P, done)
+            done += m
+        assert_same(eng.finish(), want, "%s packed uniform pushes=%d" % (name, pushes))
+    # B: a pool of reads (repeats: counts), reverse complements, N, lower case, odd bytes, every length 0..152
+    g = ui.rand_seq(rs, 60000)
+    seqs = []
+    for i in range(20000):
+        n = int(rs.randint(0, 153))
+        a = int(rs.randint(0, len(g) - 152))
+        q = bytearray(g[a:a + n])
+        if i % 3 == 0:
+            q = bytearray(ui.revcomp(bytes(q)))
+        if n and i % 9 == 0:
+            q[int(rs.randint(0, n))] = ord("N")
+        if n and i % 31 == 0:
+            q[int(rs.randint(0, n))] = int(rs.choice([ord("-"), ord("R"), 0x80 | ord("A"), ord("*")]))
+        if i % 13 == 0:
+            q = bytearray(bytes(q).lower())
+        seqs.append(bytes(q))
+    rows = np.zeros(len(seqs) * 160, dtype=np.uint8)
+    for i, q in enumerate(seqs):
+        rows[i * 160:i * 160 + len(q)] = np.frombuffer(q, np.uint8)
+        rows[i * 160 + len(q)] = 10
+    rc, want = ora.koc_from_rows(rows, 160)
+    assert rc == 0
+    packed = capi.pack_rows_host(rows, 160)
+    eng.begin(capi.MK_MODE_KOC)
+    eng.push_reads(packed, P, 0)
+    got = eng.finish()
+    assert_same(got, want, name + " packed ragged")
+    # ... and the same rows as text give the same sketch (the two kernels against each other)
+    eng.begin(capi.MK_MODE_KOC)
+    eng.push_reads(rows, 160, 0)
+    assert_same(eng.finish(), got, name + " text rows against packed rows")
+    # mixed in one sketch: text rows, then packed rows (ordinals go on)
+    half = len(seqs) // 2
+    eng.begin(capi.MK_MODE_KOC)
+    eng.push_reads(rows[:half * 160], 160, 0)
+    eng.push_reads(packed[half * 64:], P, half)
+    assert_same(eng.finish(), want, name + " text then packed")
+    # through the library's FASTQ stream with packed buffers: the -A flavour and the occurrence flavour (fastq2co, keys seen twice)
+    data = ui.fastq_bytes([q for q in seqs if b"\x0a" not in q])
+    TL = 2 * shufs(name).c.k
+    rc, wantq = ora.koc_from_fastq(data)
+    assert rc == 0
+    eng.begin(capi.MK_MODE_KOC)
+    eng.push_fastq(data, nthreads=4, chunk_bytes=1 << 18, packed=True)
+    assert_same(eng.finish(), wantq, name + " FASTQ stream, packed buffers")
+    rc, want2 = ora.co_from_fastq(data, Q=0, M=2)
+    assert rc == 0
+    eng.begin_occ(2)
+    eng.push_fastq(data, nthreads=4, chunk_bytes=1 << 18, occ=True, TL=TL, qmin=0, packed=True)
+    assert_same(eng.finish(), want2, name + " FASTQ stream, packed buffers, occurrence 2")
+
+
+def test_packed_rows_are_refused_where_no_tuned_kernel_exists(capi, shufs):
+    eng = capi.Engine(shufs("L1K7"), 0)
+    try:
+        eng.begin(capi.MK_MODE_KOC)
+        with pytest.raises(capi.MkError):
+            eng.push_reads(np.zeros(64, np.uint8), capi.MK_PACKED_PITCH | capi.MK_ROWS_PACKED, 0)
+        eng.finish()
+    finally:
+        eng.close()
+
+
 def _batch_texts(rs, big):
     """a directory's worth of small FASTA texts: genomes of several contigs, repeats and reverse complements inside a file (keys seen
     twice: -u), rough text, tiny and empty ones, one that is only a header, a file without a header line"""

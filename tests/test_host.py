@@ -494,3 +494,66 @@ def test_cli_combines_query_directories_like_the_reference(tmp_path):
         a, b = open(os.path.join(out, "cofiles.stat"), "rb").read(), open(os.path.join(out_ref, "cofiles.stat"), "rb").read()
         assert a[:4] == b[:4] and a[8:] == b[8:]  # bytes 4..7: koc + three padding bytes the reference leaves uninitialised
     shutil.rmtree(out)
+
+
+# ---- packed rows (MK_ROWS_PACKED): the host packer against a plain model of the layout in include/metakssd_hip.h ----------------
+def _pack_model(seq):
+    """bytes of one read -> the 64-byte packed row: dword 0 = bases | allvalid << 16, dwords 1..10 codes (first base in the top two
+    bits, (byte >> 1) & 3), bytes 44.. validity (bit j of byte w: base 8w + j is one of ACGTacgt)"""
+    out = np.zeros(16, dtype=np.uint32)
+    vb = np.zeros(20, dtype=np.uint8)
+    allv = 1
+    for i, b in enumerate(seq):
+        code = (b >> 1) & 3
+        ok = (b & 0xDF) == b"ACTG"[code]
+        if ok:
+            out[1 + i // 16] |= np.uint32(code << (30 - 2 * (i % 16)))
+            vb[i // 8] |= np.uint8(1 << (i % 8))
+        else:
+            allv = 0
+    out[0] = len(seq) | (allv << 16)
+    raw = out.view(np.uint8).copy()
+    raw[44:64] = vb
+    return raw
+
+
+@pytest.mark.parametrize("no_avx2", [False, True])
+def test_pack_rows_host_matches_the_layout(no_avx2):
+    import subprocess
+    import sys
+    if no_avx2:  # the scalar form: a fresh process, the choice is made once per process
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__ + "::test_pack_rows_host_matches_the_layout[False]"],
+                           env=dict(os.environ, MK_NO_AVX2="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        return
+    from metakssd_amd import capi
+    rs = np.random.RandomState(71)
+    alphabet = np.frombuffer(b"ACGTacgtNnRYxX-*0Z\r" + bytes([0, 255, 0x61 ^ 0x20, 0xC1, 0xE7]), dtype=np.uint8)
+    stride = 160
+    lens = list(range(0, 40)) + [63, 64, 65, 95, 96, 97, 127, 128, 129, 143, 144, 145, 150, 151, 152] + [int(x) for x in rs.randint(0, 153, 200)]
+    rows = np.zeros(len(lens) * stride, dtype=np.uint8)
+    seqs = []
+    for r, n in enumerate(lens):
+        if r % 3 == 0:
+            seq = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, n)]
+        elif r % 3 == 1:
+            seq = np.frombuffer(b"ACGTacgt", np.uint8)[rs.randint(0, 8, n)].copy()
+            if n:
+                seq[rs.randint(0, n, max(1, n // 30))] = ord("N")
+        else:
+            seq = alphabet[rs.randint(0, len(alphabet), n)]
+        seq = np.where(seq == 10, ord("N"), seq).astype(np.uint8)
+        seqs.append(bytes(seq))
+        rows[r * stride: r * stride + n] = seq
+        if n < stride:
+            rows[r * stride + n] = 10
+    packed = capi.pack_rows_host(rows, stride)
+    for r, seq in enumerate(seqs):
+        got = packed[r * 64:(r + 1) * 64]
+        want = _pack_model(seq)
+        assert np.array_equal(got, want), "read %d (%d bases): %s" % (r, len(seq), seq[:40])
+    # a row of 153 bases does not fit
+    long_rows = np.full(stride, ord("A"), dtype=np.uint8)
+    long_rows[153] = 10
+    with pytest.raises(capi.MkError):
+        capi.pack_rows_host(long_rows, stride)
