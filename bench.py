@@ -342,7 +342,7 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=16, reps=3, ref_genomes=
 
 def kernel_source_id():
     h = hashlib.sha256()
-    for f in ("mk_kernels.hip.h", "mk_engine.hip", "mk_stream.hip.h"):
+    for f in ("mk_kernels.hip.h", "mk_engine.hip", "mk_stream.hip.h", "mk_batch.hip.h", "mk_packed.hip.h"):
         h.update(open(os.path.join(ROOT, "metakssd_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -367,6 +367,9 @@ def main():
     ap.add_argument("--front-bits", type=int, default=None,
                     help="experiments: MK_OPT_FRONT_BITS of the engine (default: the engine's own choice; 0 = no front table)")
     ap.add_argument("--cand-cap", type=int, default=None, help="experiments: MK_OPT_CAND_CAP of the engine (records per scan wave)")
+    ap.add_argument("--rows160", type=int, default=None, choices=[0, 1],
+                    help="MK_OPT_ROWS160: 1 = the scan kernel that keeps a lane's 160-byte row in registers (no LDS tile), 0 = mk_scan_kernel; "
+                         "default: the library's")
     ap.add_argument("--verify", action="store_true",
                     help="after timing, rank 0 re-sketches ALL ranks' reads on one engine and compares with the merged result")
     args = ap.parse_args()
@@ -423,6 +426,8 @@ def main():
 
     shuf = capi.Shuf.generate(11, 6, 3, 11)  # L3K11 = {k=11, subk=6, drlevel=3}, same bytes as the tests' table
     eng = capi.Engine(shuf, local_rank, front_bits=args.front_bits, cand_cap=args.cand_cap)
+    if args.rows160 is not None:
+        eng.set_option(capi.MK_OPT_ROWS160, args.rows160)
     stream = torch.cuda.current_stream().cuda_stream
     eng.set_stream(stream)
 

@@ -1879,9 +1879,10 @@ int main(int argc, char **argv) {
   const char *shuf_path = NULL, *outdir = ".";
   int abundance = 0, uniq = 0, device = 0, quiet = 0, timing = 0;
   /* -p: host threads of the front end (reference default: every processor, command_dist_wrapper.c:284-293) */
-  int nthreads = (int)sysconf(_SC_NPROCESSORS_ONLN);
+  int nthreads = (int)sysconf(_SC_NPROCESSORS_ONLN), threads_given = 0;
   if (nthreads < 1) nthreads = 1;
-  if (nthreads > 24) nthreads = 24; /* 20-24 framer threads keep PCIe busy; more only take memory bandwidth from the copies */
+  const int ncpu = nthreads;
+  if (nthreads > 24) nthreads = 24; /* text rows: 20-24 framer threads keep PCIe busy; more only take memory bandwidth from the copies */
   uint64_t chunk_bytes = (uint64_t)32 << 20; /* text per framing job = about 17 MiB of rows per host-to-device copy */
   int drop_pages = 1, inflight = 3, slow_exit = 0, direct_host = 0, ascii_rows = 0;
   int devs[64], ndev = 0; /* --devices 0-7 / 0,2,5 / 0,0 (the same GPU twice: two engines, for tests) */
@@ -1895,7 +1896,7 @@ int main(int argc, char **argv) {
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "-L") && i + 1 < argc) shuf_path = argv[++i];
     else if (!strcmp(argv[i], "-o") && i + 1 < argc) outdir = argv[++i];
-    else if (!strcmp(argv[i], "-p") && i + 1 < argc) nthreads = atoi(argv[++i]); /* host front-end threads */
+    else if (!strcmp(argv[i], "-p") && i + 1 < argc) { nthreads = atoi(argv[++i]); threads_given = 1; } /* host front-end threads */
     else if (!strcmp(argv[i], "-A")) abundance = 1;
     else if (!strcmp(argv[i], "-u")) uniq = 1;
     else if (!strcmp(argv[i], "-n") && i + 1 < argc) { /* command_dist_wrapper.c:169-180 */
@@ -2025,6 +2026,9 @@ int main(int argc, char **argv) {
   c.inflight = inflight;
   c.direct_host = direct_host;
   c.packed = !ascii_rows && mk_params_packed_ok(&P);
+  /* packed rows are 64 bytes a read on PCIe instead of 160: the framers, not the link, bound a FASTQ file then, and 32 of them did
+   * better than 24 (50 M reads: 0.20-0.24 s against 0.22-0.26 from process start; 48 and more are slower again) */
+  if (c.packed && !threads_given && ncpu >= 32) nthreads = 32;
 
   /* -A stays on only if every input is FASTQ: the reference switches it off when its file loop reaches the first
    * non-FASTQ input (command_dist.c:389-392) and then writes no combco.N.a at all (:427-431).  FASTQ files in front of
@@ -2074,7 +2078,8 @@ int main(int argc, char **argv) {
     if (nworkers == 0) { free(pf.slots); pf.slots = NULL; }
   }
 
-  double t_finish = 0;
+  double t_finish = 0, t_batch_wait_read = 0, t_batch_pin = 0, t_batch_begin = 0;
+  int nbatches_done = 0;
   job_opts jo = {&files, &P, abundance, uniq, first_nonfq, kmerocrs, kmerqlty, nthreads, quiet, &pf, nworkers};
   if (first_nonfq < files.n && abundance) printf("Warning: close abundance mode (-A) since non-fastq file input.\n");
   if (use_batch) {
@@ -2156,9 +2161,13 @@ int main(int argc, char **argv) {
         if (!quiet) printf("%d/%d decomposing %s\r", ++done_files, files.n, files.v[bj->first]);
         continue;
       }
-      pthread_mutex_lock(&br.mu);
-      while (left[j] > 0) pthread_cond_wait(&br.cv_ready, &br.mu);
-      pthread_mutex_unlock(&br.mu);
+      {
+        const double tw = now_s();
+        pthread_mutex_lock(&br.mu);
+        while (left[j] > 0) pthread_cond_wait(&br.cv_ready, &br.mu);
+        pthread_mutex_unlock(&br.mu);
+        t_batch_wait_read += now_s() - tw;
+      }
       for (int k = 0; k < bj->n; k++) {
         const int i = bj->first + k;
         if (failed[i]) die("%s: %s", files.v[i], strerror(failed[i]));
@@ -2166,14 +2175,21 @@ int main(int argc, char **argv) {
         bf[k].n = fsize[i];
       }
       (void)engine_get(&c);
+      const double tp0 = now_s();
       if (!buf_pinned[bj->batch % nbufs]) { /* the runtime is up now.  Buffer by buffer: pinning takes 30 us per MiB, and only the first
                                                * buffer's share of that lies in front of the first batch */
         if (mk_host_register(br.buf[bj->batch % nbufs], br.bufcap) != MK_OK) die("pinning the batch buffers failed: %s", mk_last_error(NULL));
         buf_pinned[bj->batch % nbufs] = 1;
       }
+      t_batch_pin += now_s() - tp0;
       if (nfly == 2) BATCH_END_OLDEST();
       if (c.t_first_push == 0) c.t_first_push = now_s() - g_t0;
-      rc = mk_sketch_batch_begin(c.eng, mode, bf, (uint32_t)bj->n);
+      {
+        const double tb = now_s();
+        rc = mk_sketch_batch_begin(c.eng, mode, bf, (uint32_t)bj->n);
+        t_batch_begin += now_s() - tb;
+        nbatches_done++;
+      }
       if (rc != MK_OK) die("mk_sketch_batch_begin failed (%d): %s", rc, mk_last_error(c.eng));
       c.t_last_push = now_s() - g_t0;
       fly[nfly++] = j;
@@ -2287,12 +2303,14 @@ int main(int argc, char **argv) {
     printf("{\"timing\": {\"t0_abs\": %.6f, \"exit_abs\": %.6f, \"shuf_read\": %.4f, \"hip_ready\": %.4f, \"engine_ready\": %.4f, \"first_push\": %.4f, \"last_push\": %.4f, \"unmapped\": %.4f, "
            "\"written\": %.4f, \"finish_s\": %.4f, \"begin_s\": %.4f, \"rows\": %llu, \"threads\": %u, \"chunks\": %llu, \"chunks_discarded\": %llu, "
            "\"serial_rows\": %llu, \"stream_setup_s\": %.4f, \"stream_wait_frame_s\": %.4f, \"stream_push_s\": %.4f, \"stream_total_s\": %.4f, "
-           "\"push_call_s\": %.4f, \"wait_call_s\": %.4f, \"push_call_max_s\": %.4f, \"first_push_call_s\": %.4f, \"gpus\": %d, \"gather_ms\": %.3f, \"tail_ms\": %.3f, \"transport\": \"%s\"}}\n",
+           "\"push_call_s\": %.4f, \"wait_call_s\": %.4f, \"push_call_max_s\": %.4f, \"first_push_call_s\": %.4f, \"gpus\": %d, \"gather_ms\": %.3f, \"tail_ms\": %.3f, \"transport\": \"%s\", "
+           "\"batches\": %d, \"batch_wait_readers_s\": %.4f, \"batch_pin_s\": %.4f, \"batch_begin_s\": %.4f}}\n",
            g_t0, now_s(), t_shuf, fut.t_hip_ready, fut.t_ready, c.t_first_push, c.t_last_push, c.t_unmapped, t_written, t_finish, c.t_begin_s, (unsigned long long)c.nrows_total,
            c.fq_stats.threads, (unsigned long long)c.fq_stats.chunks, (unsigned long long)c.fq_stats.chunks_discarded,
            (unsigned long long)c.fq_stats.serial_rows, c.fq_stats.t_setup_s, c.fq_stats.t_wait_frame_s, c.fq_stats.t_push_s,
            c.fq_stats.t_total_s, c.fq_stats.t_push_call_s, c.fq_stats.t_wait_call_s, c.fq_stats.t_push_call_max_s,
-           c.fq_stats.t_first_push_call_s, c.ndev ? c.ndev : 1, c.gather_ms, c.tail_ms, c.multi ? g_multi.transport(c.multi) : "-");
+           c.fq_stats.t_first_push_call_s, c.ndev ? c.ndev : 1, c.gather_ms, c.tail_ms, c.multi ? g_multi.transport(c.multi) : "-",
+           nbatches_done, t_batch_wait_read, t_batch_pin, t_batch_begin);
   if (stage2_after) {
     if (c.rows) mk_host_free(c.rows);
     free(c.io);

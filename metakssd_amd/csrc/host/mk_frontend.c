@@ -80,26 +80,41 @@ static void mk_pack_block_scalar(const uint8_t *src, uint32_t n, uint32_t *codes
 
 #if defined(__x86_64__) && defined(__GNUC__)
 #include <immintrin.h>
-__attribute__((target("avx2"))) static void mk_pack_block_avx2(const uint8_t *src32, uint32_t n, uint32_t *codes2, uint32_t *valid) {
-  /* src32: 32 readable bytes; bases from n on are masked out */
-  const __m256i b = _mm256_loadu_si256((const __m256i *)src32);
-  const __m256i codes = _mm256_and_si256(_mm256_srli_epi16(b, 1), _mm256_set1_epi8(3));
+/* the whole row in one AVX2 function: five blocks of 32 bases written out, loads straight from the text where 32 bytes are readable
+ * (`avail`: bytes that may be read from src on; the FASTQ text behind a sequence line is its '+' and quality lines), bases behind the
+ * read masked by a sliding window over 32 x 0xFF, 32 x 0x00 */
+static const uint8_t mk_pack_lanes[64] __attribute__((aligned(64))) = {
+    255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255,
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__attribute__((target("avx2"))) static void mk_row_pack_avx2(uint8_t *row, const uint8_t *src, size_t nb, size_t avail) {
+  uint32_t out[16] __attribute__((aligned(16)));
+  memset(out, 0, sizeof out);
+  uint8_t *vb = (uint8_t *)out + 44;
+  const __m256i three = _mm256_set1_epi8(3), fold = _mm256_set1_epi8((char)0xDF), ones = _mm256_set1_epi16(1);
   const __m256i lut = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
-  const __m256i ok = _mm256_cmpeq_epi8(_mm256_and_si256(b, _mm256_set1_epi8((char)0xDF)), _mm256_shuffle_epi8(lut, codes));
-  uint32_t v = (uint32_t)_mm256_movemask_epi8(ok);
-  if (n < 32u) v &= (1u << n) - 1u;
-  /* bytes of four codes each: c0 * 64 + c1 * 16 + c2 * 4 + c3, one per 32-bit lane */
   const __m256i w = _mm256_setr_epi8(64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1);
-  const __m256i q = _mm256_madd_epi16(_mm256_maddubs_epi16(_mm256_and_si256(codes, ok), w), _mm256_set1_epi16(1));
-  /* the four quads of a 128-bit half, first one in the top byte */
-  const __m256i g = _mm256_shuffle_epi8(q, _mm256_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
-  uint32_t c0 = (uint32_t)_mm256_extract_epi32(g, 0), c1 = (uint32_t)_mm256_extract_epi32(g, 4);
-  if (n < 32u) { /* (the validity AND above used the unmasked compare: drop the codes of bytes behind the read) */
-    const uint64_t keep = n >= 32u ? ~0ull : ((1ull << (2u * n)) - 1ull) << (64u - 2u * n); /* the first n two-bit fields of {c0, c1} */
-    const uint64_t cc = (((uint64_t)c0 << 32) | c1) & (n ? keep : 0ull);
-    c0 = (uint32_t)(cc >> 32); c1 = (uint32_t)cc;
+  const __m256i gather = _mm256_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+  uint32_t allvalid = 1;
+  for (size_t at = 0; at < nb; at += 32u) {
+    const uint32_t n = nb - at < 32u ? (uint32_t)(nb - at) : 32u;
+    __m256i b;
+    if (at + 32u <= avail) b = _mm256_loadu_si256((const __m256i *)(src + at));
+    else { uint8_t tmp[32] __attribute__((aligned(32))) = {0}; memcpy(tmp, src + at, n); b = _mm256_load_si256((const __m256i *)tmp); }
+    const __m256i codes = _mm256_and_si256(_mm256_srli_epi16(b, 1), three);
+    __m256i ok = _mm256_cmpeq_epi8(_mm256_and_si256(b, fold), _mm256_shuffle_epi8(lut, codes));
+    ok = _mm256_and_si256(ok, _mm256_loadu_si256((const __m256i *)(mk_pack_lanes + 32u - n))); /* bytes behind the read do not count */
+    const uint32_t v = (uint32_t)_mm256_movemask_epi8(ok);
+    const __m256i q = _mm256_madd_epi16(_mm256_maddubs_epi16(_mm256_and_si256(codes, ok), w), ones);
+    const __m256i g = _mm256_shuffle_epi8(q, gather);
+    out[1 + at / 16u] = (uint32_t)_mm256_extract_epi32(g, 0);
+    if (at + 16u < nb) out[2 + at / 16u] = (uint32_t)_mm256_extract_epi32(g, 4);
+    memcpy(vb + at / 8u, &v, (n + 7u) / 8u);
+    if (v != (n == 32u ? 0xFFFFFFFFu : (1u << n) - 1u)) allvalid = 0;
   }
-  codes2[0] = c0; codes2[1] = c1; *valid = v;
+  out[0] = (uint32_t)nb | (allvalid << 16);
+  if (((uintptr_t)row & 15u) == 0)
+    for (int i = 0; i < 4; i++) _mm_stream_si128((__m128i *)(row + 16 * i), _mm_load_si128((const __m128i *)((const uint8_t *)out + 16 * i)));
+  else memcpy(row, out, 64);
 }
 static int mk_have_avx2(void) {
   static int have = -1;
@@ -110,8 +125,13 @@ static int mk_have_avx2(void) {
 static int mk_have_avx2(void) { return 0; }
 #endif
 
-/* nb <= 152 bases at src -> the 64-byte packed row (16-byte aligned: streaming stores, see mk_row_store) */
-static inline void mk_row_pack(uint8_t *row, const uint8_t *src, size_t nb) {
+/* nb <= 152 bases at src -> the 64-byte packed row (16-byte aligned: streaming stores, see mk_row_store); avail >= nb: bytes that
+ * may be read from src on */
+static inline void mk_row_pack(uint8_t *row, const uint8_t *src, size_t nb, size_t avail) {
+#if defined(__x86_64__) && defined(__GNUC__)
+  if (mk_have_avx2()) { mk_row_pack_avx2(row, src, nb, avail); return; }
+#endif
+  (void)avail;
   uint32_t out[16] __attribute__((aligned(16)));
   memset(out, 0, sizeof out);
   uint8_t *vb = (uint8_t *)out + 44;
@@ -119,12 +139,6 @@ static inline void mk_row_pack(uint8_t *row, const uint8_t *src, size_t nb) {
   for (uint32_t at = 0; at < nb; at += 32u) {
     const uint32_t n = nb - at < 32u ? (uint32_t)(nb - at) : 32u;
     uint32_t c2[2], v;
-#if defined(__x86_64__) && defined(__GNUC__)
-    if (mk_have_avx2()) {
-      if (n == 32u) mk_pack_block_avx2(src + at, 32u, c2, &v);
-      else { uint8_t tmp[32]; memset(tmp, 0, sizeof tmp); memcpy(tmp, src + at, n); mk_pack_block_avx2(tmp, n, c2, &v); }
-    } else
-#endif
       mk_pack_block_scalar(src + at, n, c2, &v);
     out[1 + at / 16u] = c2[0];
     if (at + 16u < nb) out[2 + at / 16u] = c2[1];
@@ -153,7 +167,7 @@ int mk_pack_rows_host(const uint8_t *rows, uint32_t stride, uint64_t nrows, uint
     const uint8_t *nl = (const uint8_t *)memchr(row, '\n', stride);
     const size_t nb = nl ? (size_t)(nl - row) : stride;
     if (nb > MK_PACKED_MAX_BASES) return MK_ERR_ARG;
-    mk_row_pack(packed + r * (uint64_t)MK_PACKED_PITCH, row, nb);
+    mk_row_pack(packed + r * (uint64_t)MK_PACKED_PITCH, row, nb, (size_t)stride);
   }
   mk_rows_done();
   return MK_OK;
@@ -285,10 +299,33 @@ int mk_synth_fastq_write_mt(const char *path, uint64_t seed, uint64_t first_read
 
 /* one text line starting at p: returns its length including the '\n' (or up to `end` when the file ends
  * without one, only if final); 0 = incomplete line, need more data */
-static size_t mk_line(const uint8_t *p, const uint8_t *end, int final) {
+/* length of the line at p including its '\n' (0: no '\n' in front of `end` and not final; final: the rest).  The lines of a FASTQ record
+ * are short (a header, 150 bases, "+", 150 quality bytes): four memchr() calls a record cost more in call overhead than in bytes,
+ * so where the CPU has AVX2 the first '\n' is looked for 32 bytes at a time in place */
+static size_t mk_line_generic(const uint8_t *p, const uint8_t *end, int final) {
   const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
   if (nl) return (size_t)(nl - p) + 1;
   return final ? (size_t)(end - p) : 0;
+}
+#if defined(__x86_64__) && defined(__GNUC__)
+__attribute__((target("avx2"))) static size_t mk_line_avx2(const uint8_t *p, const uint8_t *end, int final) {
+  const uint8_t *q = p;
+  const __m256i nl = _mm256_set1_epi8('\n');
+  while (end - q >= 32) {
+    const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)q), nl));
+    if (m) return (size_t)(q - p) + (size_t)__builtin_ctz(m) + 1u;
+    q += 32;
+  }
+  const uint8_t *x = (const uint8_t *)memchr(q, '\n', (size_t)(end - q));
+  if (x) return (size_t)(x - p) + 1;
+  return final ? (size_t)(end - p) : 0;
+}
+#endif
+static inline size_t mk_line(const uint8_t *p, const uint8_t *end, int final) {
+#if defined(__x86_64__) && defined(__GNUC__)
+  if (mk_have_avx2()) return mk_line_avx2(p, end, final);
+#endif
+  return mk_line_generic(p, end, final);
 }
 
 /* the framer proper: records that START in front of buf + stop (stop <= n; a record may end behind it).  *need = bytes a
@@ -325,7 +362,7 @@ int mk_fastq_frame_range(const uint8_t *buf, size_t n, size_t stop, int final, u
       break;
     }
     if (packed ? l2 - 1 > MK_PACKED_MAX_BASES : l2 > stride) { rc = MK_ERR_ARG; if (need) *need = (uint32_t)l2; break; } /* caller must re-frame from here with a larger stride */
-    if (packed) mk_row_pack(rows + r * (uint64_t)stride, s, l2 - 1);
+    if (packed) mk_row_pack(rows + r * (uint64_t)stride, s, l2 - 1, (size_t)(end - s));
     else mk_row_store(rows + r * (uint64_t)stride, s, l2, 0, stride);
     r++;
     p = t + l4;
@@ -406,7 +443,7 @@ int mk_fastq_frame_q_range(const uint8_t *buf, size_t n, size_t stop, int final,
       uint8_t *row = rows + (r + w) * (uint64_t)stride;
       size_t m = L - at < cap ? L - at : cap;
       if (qmin <= -128) { /* every signed quality byte passes */
-        if (packed) mk_row_pack(row, sq + at, m);
+        if (packed) mk_row_pack(row, sq + at, m, (size_t)(end - (sq + at)));
         else mk_row_store(row, sq + at, m, 1, stride);
       }
       else { /* a base whose quality byte is below -Q resets the window exactly like a non-ACGT byte (:367-379) */
@@ -415,7 +452,7 @@ int mk_fastq_frame_q_range(const uint8_t *buf, size_t n, size_t stop, int final,
           const int qv = at + i < qn ? (int)(signed char)ql[at + i] : 0;
           masked[i] = qv >= qmin ? sq[at + i] : (uint8_t)'N';
         }
-        if (packed) mk_row_pack(row, masked, m);
+        if (packed) mk_row_pack(row, masked, m, sizeof masked);
         else mk_row_store(row, masked, m, 1, stride);
       }
       at += m;

@@ -83,6 +83,7 @@ struct mk_engine {
   bool stage_two_streams[MK_REGIONS] = {}; /* the last scan of the region ran on another stream than the copies: ev_scanned is live */
   int stage_cur = 0;
   bool direct_host = false; /* MK_OPT_DIRECT_HOST */
+  int rows160 = 0;          /* MK_OPT_ROWS160: text rows of pitch 160 through mk_scan_rows160_kernel (rows in registers, no LDS tile) */
   bool region_open = false;
   size_t region_fill = 0;
   uint32_t region_stride = 0;
@@ -608,6 +609,9 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
     case MK_OPT_DIRECT_HOST:
       e->direct_host = value != 0;
       return MK_OK;
+    case MK_OPT_ROWS160:
+      e->rows160 = value != 0;
+      return MK_OK;
     case MK_OPT_BATCH_TAB_BITS:
       if (value != 0 && (value < 9 || value > 22)) return mk_fail(e, MK_ERR_ARG, "MK_OPT_BATCH_TAB_BITS takes 0 (by file size) or 9..22");
       if (e->batch_begun != e->batch_ended) return mk_fail(e, MK_ERR_STATE, "MK_OPT_BATCH_TAB_BITS while a batch is in flight");
@@ -893,7 +897,10 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   hipError_t r;
-  if (packed) {
+  /* text rows of pitch 160 (150-base reads) may take the kernel that keeps a lane's row in registers (MK_OPT_ROWS160) */
+  const bool r160 = !packed && e->rows160 && tuned_k && stride == 160u && pitch == 160u && rowlen == 0u && !nreads_dev && vec;
+  if (r160) { threads = 1024; lds = ((size_t)a.mt_words + (size_t)a.bm_words) * 4u; }
+  if (packed || r160) {
     auto launch_packed = [&](auto kern) -> hipError_t {
       const void *fn = (const void *)kern;
       size_t *granted = nullptr;
@@ -907,11 +914,16 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
       hipLaunchKernelGGL(kern, grid, dim3(1024), lds, e->stream, a);
       return hipGetLastError();
     };
-    switch (tuned_k * 10 + e->P.subk) {
+    if (packed) switch (tuned_k * 10 + e->P.subk) {
       case 116: r = launch_packed(mk_scan_packed_kernel<11, 6>); break;
       case 106: r = launch_packed(mk_scan_packed_kernel<10, 6>); break;
       case 96: r = launch_packed(mk_scan_packed_kernel<9, 6>); break;
       default: r = launch_packed(mk_scan_packed_kernel<11, 5>); break;
+    } else switch (tuned_k * 10 + e->P.subk) {
+      case 116: r = launch_packed(mk_scan_rows160_kernel<11, 6>); break;
+      case 106: r = launch_packed(mk_scan_rows160_kernel<10, 6>); break;
+      case 96: r = launch_packed(mk_scan_rows160_kernel<9, 6>); break;
+      default: r = launch_packed(mk_scan_rows160_kernel<11, 5>); break;
     }
   } else
   switch (tuned_k * 10 + (tuned_k ? e->P.subk : 0)) {

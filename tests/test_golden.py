@@ -145,6 +145,46 @@ REF_HIP = os.path.join(ROOT, "oracle", "_ref_hip", "metakssd")
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shuf,flags", [("L3K11", ["-A"]), ("L2K11", ["-A"]), ("L3K10", ["-n", "2", "-Q", "50"]), ("L1K7", ["-A"])])
+def test_product_cli_packed_rows_equal_text_rows(shuf, flags, shuf_files, tmp_path):
+    """the command line frames FASTQ reads of up to 152 bases as 64-byte packed rows where the geometry has a tuned kernel (the default)
+    and as text rows with --ascii-rows (and for L1K7, which has none): the sketch directories are the same byte for byte -- reads
+    with N, lower case, ragged lengths, a few reads beyond 152 bases (their buffers fall back to text rows), CRLF"""
+    import numpy as np
+    import util_inputs as ui
+    rs = np.random.RandomState(91)
+    g = ui.rand_seq(rs, 80000)
+    seqs = []
+    for i in range(30000):
+        n = int(rs.randint(0, 153)) if i % 400 else int(rs.randint(153, 400))
+        a = int(rs.randint(0, len(g) - 400))
+        q = bytearray(g[a:a + n])
+        if n and i % 9 == 0:
+            q[int(rs.randint(0, n))] = ord("N")
+        if i % 13 == 0:
+            q = bytearray(bytes(q).lower())
+        seqs.append(bytes(q))
+    quals = [bytes(rs.randint(44, 64, len(x)).astype(np.uint8)) for x in seqs]
+    outs = {}
+    for crlf in (False, True):
+        path = str(tmp_path / ("reads%d.fq" % crlf))
+        open(path, "wb").write(ui.fastq_bytes(seqs, crlf=crlf, quals=quals))
+        for tag, extra in (("packed", []), ("text", ["--ascii-rows"]), ("packed_small_chunks", ["--chunk-mib", "1", "-p", "5"])):
+            out = str(tmp_path / ("%s%d" % (tag, crlf)))
+            r = subprocess.run([PRODUCT_CLI, "dist", "-L", shuf_files(shuf)] + flags + extra + ["-o", out, path], stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr.decode()
+            outs[(tag, crlf)] = out
+        for tag in ("text", "packed_small_chunks"):
+            a, b = outs[("packed", crlf)], outs[(tag, crlf)]
+            names = sorted(f for f in os.listdir(a) if f.startswith("combco"))
+            assert names and names == sorted(f for f in os.listdir(b) if f.startswith("combco"))
+            for f in names:
+                assert filecmp.cmp(os.path.join(a, f), os.path.join(b, f), shallow=False), (tag, crlf, f)
+        assert "-A" not in flags or os.path.getsize(os.path.join(outs[("packed", crlf)], "combco.0")) >= 40
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", sorted(MANIFEST["cases"]))
 def test_reference_program_with_dropin_tu_reproduces_golden(case, shuf_files, tmp_path):
     """oracle/_ref_hip/metakssd = the reference's own translation units (its main, option parser, dist_dispatch, run_stageI

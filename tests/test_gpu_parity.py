@@ -318,6 +318,49 @@ def test_packed_rows_equal_oracle(capi, engine_for, shufs, oracle_for, name):
     assert_same(eng.finish(), want2, name + " FASTQ stream, packed buffers, occurrence 2")
 
 
+@pytest.mark.parametrize("name", ["L3K11", "L3K10", "L3K9", "L2K11"])
+def test_rows160_kernel_equals_oracle(capi, shufs, oracle_for, name):
+    """MK_OPT_ROWS160: text rows of pitch 160 through mk_scan_rows160_kernel (a lane loads its own row into registers, no LDS tile):
+    the benchmark's rows, ragged rows with N / lower case / odd bytes / rows of 159 and 160 bases (no newline), a last tile of
+    fewer than 64 rows, several pushes -- the oracle's sketch, and so mk_scan_kernel's"""
+    rs = np.random.RandomState(62)
+    ora = oracle_for(shufs(name))
+    eng = capi.Engine(shufs(name), 0)
+    try:
+        eng.set_option(capi.MK_OPT_ROWS160, 1)
+        rows = capi.synth_rows_host(6, 0, 30011, 150, 160)
+        rc, want = ora.koc_from_rows(rows, 160)
+        assert rc == 0
+        for pushes in (1, 4):
+            assert_same(run_koc(capi, eng, rows, 160, pushes), want, "%s rows160 uniform pushes=%d" % (name, pushes))
+        g = ui.rand_seq(rs, 50000)
+        n = 20037
+        rows = np.zeros(n * 160, dtype=np.uint8)
+        for i in range(n):
+            L = int(rs.choice([0, 1, 21, 22, 23, 60, 100, 149, 150, 151, 158, 159, 160])) if i % 5 else int(rs.randint(0, 161))
+            a = int(rs.randint(0, len(g) - 160))
+            q = bytearray(g[a:a + L])
+            if i % 3 == 0:
+                q = bytearray(ui.revcomp(bytes(q)))
+            if L and i % 7 == 0:
+                q[int(rs.randint(0, L))] = ord("N")
+            if L and i % 29 == 0:
+                q[int(rs.randint(0, L))] = int(rs.choice([ord("-"), ord("R"), 0x80 | ord("C"), 0]))
+            if i % 11 == 0:
+                q = bytearray(bytes(q).lower())
+            rows[i * 160:i * 160 + L] = np.frombuffer(bytes(q), np.uint8)
+            if L < 160:
+                rows[i * 160 + L] = 10
+        rc, want = ora.koc_from_rows(rows, 160)
+        assert rc == 0
+        assert_same(run_koc(capi, eng, rows, 160, 1), want, name + " rows160 ragged")
+        assert_same(run_koc(capi, eng, rows, 160, 3), want, name + " rows160 ragged, three pushes")
+        eng.set_option(capi.MK_OPT_ROWS160, 0)
+        assert_same(run_koc(capi, eng, rows, 160, 1), want, name + " the LDS-tile kernel on the same rows")
+    finally:
+        eng.close()
+
+
 def test_packed_rows_are_refused_where_no_tuned_kernel_exists(capi, shufs):
     eng = capi.Engine(shufs("L1K7"), 0)
     try:
