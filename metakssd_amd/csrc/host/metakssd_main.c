@@ -2131,11 +2131,13 @@ int main(int argc, char **argv) {
     mk_batch_result *bres = calloc((size_t)g_batch_files, sizeof *bres);
     if (!bf || !bres) die("out of memory");
     int fly[2], nfly = 0, done_files = 0;
+    const int btrace = getenv("MK_BATCH_TRACE") != NULL;
     #define BATCH_END_OLDEST() do { \
       const bjob *bj_ = &jobs[fly[0]]; \
       const double tf_ = now_s(); \
       rc = mk_sketch_batch_end(c.eng, bres); \
       t_finish += now_s() - tf_; \
+      if (btrace) fprintf(stderr, "[batch %d] end: called %.3f returned %.3f ms\n", bj_->batch, (tf_ - g_t0) * 1e3, (now_s() - g_t0) * 1e3); \
       if (rc != MK_OK) die("mk_sketch_batch_end failed (%d): %s", rc, mk_last_error(c.eng)); \
       for (int k_ = 0; k_ < bj_->n; k_++) { \
         const char *path_ = files.v[bj_->first + k_]; \
@@ -2189,6 +2191,7 @@ int main(int argc, char **argv) {
         rc = mk_sketch_batch_begin(c.eng, mode, bf, (uint32_t)bj->n);
         t_batch_begin += now_s() - tb;
         nbatches_done++;
+        if (btrace) fprintf(stderr, "[batch %d] begin: called %.3f returned %.3f ms\n", bj->batch, (tb - g_t0) * 1e3, (now_s() - g_t0) * 1e3);
       }
       if (rc != MK_OK) die("mk_sketch_batch_begin failed (%d): %s", rc, mk_last_error(c.eng));
       c.t_last_push = now_s() - g_t0;

@@ -130,12 +130,6 @@ struct mk_engine {
   struct mk_bctx *bctx[3] = {nullptr, nullptr, nullptr};
   uint64_t batch_begun = 0, batch_ended = 0;
   int batch_tb_opt = 0;                /* MK_OPT_BATCH_TAB_BITS: 0 = by the largest file of the batch */
-  /* the texts of a batch go up on a queue of their own, beside the kernels of the batch in front of it.  A second queue costs
-   * 8-9 ms to make (20 + 8 for a process's first): a thread makes it while the first batches already run on the engine's one
-   * stream, and it is used from the batch on that finds it ready (bcopy_state: 0 not asked for, 1 being made, 2 ready, 3 failed) */
-  hipStream_t bcopy_stream = nullptr;
-  int bcopy_state = 0;
-  pthread_t bcopy_thread{};
   const mk_batch_dev *cur_batch = nullptr; /* set around the scan launches of a batch */
 
   int mode = -1;
@@ -292,8 +286,6 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters);
   hipFree(e->d_kl); hipFree(e->d_kl_buckets);
-  if (__atomic_load_n(&e->bcopy_state, __ATOMIC_ACQUIRE) != 0) pthread_join(e->bcopy_thread, nullptr);
-  if (e->bcopy_stream) hipStreamDestroy(e->bcopy_stream);
   for (mk_bctx *c : e->bctx) mk_bctx_free(c);
   hipFree(e->d_res_ids); hipFree(e->d_res_cnt); hipFree(e->d_snap);
   if (e->h_snap) hipHostFree(e->h_snap);
@@ -1802,11 +1794,12 @@ struct mk_bctx {
   void *h_desc = nullptr; size_t h_desc_cap = 0;   /* pinned: what goes up in one small copy (descriptor, files, seg0s, row0s) */
   void *h_stat = nullptr; size_t h_stat_cap = 0;   /* pinned: what comes back first (per-file status, per-component sizes, totals) */
   uint32_t *h_ids = nullptr; size_t h_ids_cap = 0; /* pinned: the ids */
-  hipEvent_t ev_stat = nullptr, ev_h2d = nullptr;
+  hipEvent_t ev_stat = nullptr;
   mk_batch_dev hb{};
   int mode = 0;
   uint32_t nfiles = 0;
   size_t stat_bytes = 0;
+  uint64_t spec_ids = 0; /* ids copied to the host with the batch's own launch sequence (before their number is known there) */
   std::vector<mk_batch_file> files;
   std::vector<mk_component> comps;              /* [nfiles * component_num] */
   std::vector<std::vector<uint32_t>> alone_ids; /* ids of the files that were sketched alone */
@@ -1837,7 +1830,6 @@ static void mk_bctx_free(mk_bctx *c) {
   if (c->h_stat) hipHostFree(c->h_stat);
   if (c->h_ids) hipHostFree(c->h_ids);
   if (c->ev_stat) hipEventDestroy(c->ev_stat);
-  if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
   delete c;
 }
 static size_t mk_up16(size_t v) { return (v + 15u) & ~(size_t)15u; }
@@ -1878,19 +1870,6 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
   if (!e->bctx[ci]) e->bctx[ci] = new mk_bctx();
   mk_bctx *c = e->bctx[ci];
   if (!c->ev_stat) MK_HIP(e, hipEventCreateWithFlags(&c->ev_stat, hipEventDisableTiming));
-  if (!c->ev_h2d) MK_HIP(e, hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
-  if (e->bcopy_state == 0) { /* the copy queue: made beside the first batches */
-    e->bcopy_state = 1;
-    if (pthread_create(&e->bcopy_thread, nullptr, [](void *arg) -> void * {
-          mk_engine *en = (mk_engine *)arg;
-          hipStream_t st = nullptr;
-          const bool ok = hipSetDevice(en->device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
-          if (!ok) (void)hipGetLastError();
-          en->bcopy_stream = ok ? st : nullptr;
-          __atomic_store_n(&en->bcopy_state, ok ? 2 : 3, __ATOMIC_RELEASE);
-          return nullptr;
-        }, e) != 0) e->bcopy_state = 0; /* (no thread: asked for again at the next batch) */
-  }
   const uint32_t C = (uint32_t)e->P.component_num;
   const uint32_t TL = (uint32_t)e->P.TL, pitch = MK_FA_PITCH_SMALL, rowlen = pitch + TL - 1u;
   const uint32_t width = (rowlen + 1u + 15u) & ~15u;
@@ -2008,22 +1987,20 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
   const mk_batch_dev *dbatch = (const mk_batch_dev *)dd;
   hipStream_t s = e->stream;
 
-  /* ---- the launch sequence.  The copies on the copy queue when it is there (this context's buffers are free: its last batch has
-   * been handed out), the kernels behind an event */
-  const bool side = __atomic_load_n(&e->bcopy_state, __ATOMIC_ACQUIRE) == 2 && s == e->own_stream;
-  hipStream_t cs = side ? e->bcopy_stream : s;
-  MK_HIP(e, hipMemcpyAsync(c->desc.p, c->h_desc, desc_bytes, hipMemcpyHostToDevice, cs));
+  /* ---- the launch sequence, all of it on the engine's one stream.  (A copy queue of its own for the texts -- made by a thread beside
+   * the first batches, the kernels behind an event -- was built and measured: 1 024 genomes in 0.222-0.238 s with it, 0.199-0.213 s
+   * without, three runs each on one box: a batch's kernels are 0.4 ms beside 2.3-2.8 ms of copy, and the copy is no faster for
+   * running beside them.) */
+  MK_HIP(e, hipMemcpyAsync(c->desc.p, c->h_desc, desc_bytes, hipMemcpyHostToDevice, s));
   if (one_copy) {
-    if (text_span) MK_HIP(e, hipMemcpyAsync(c->text.p, files[0].text, (size_t)text_span, hipMemcpyHostToDevice, cs));
+    if (text_span) MK_HIP(e, hipMemcpyAsync(c->text.p, files[0].text, (size_t)text_span, hipMemcpyHostToDevice, s));
   } else {
     for (uint32_t i = 0; i < nfiles; i++)
-      if (files[i].n) MK_HIP(e, hipMemcpyAsync((uint8_t *)c->text.p + hf[i].text_off, files[i].text, (size_t)files[i].n, hipMemcpyHostToDevice, cs));
+      if (files[i].n) MK_HIP(e, hipMemcpyAsync((uint8_t *)c->text.p + hf[i].text_off, files[i].text, (size_t)files[i].n, hipMemcpyHostToDevice, s));
   }
-  if (side) MK_HIP(e, hipEventRecord(c->ev_h2d, cs));
   const unsigned wide = (unsigned)e->num_cu * 8u;
   hipLaunchKernelGGL(mk_b_clear_kernel, dim3(wide), dim3(256), 0, s, (uint4 *)c->zero.p, (unsigned long long)(zero_bytes / 16u), (uint4 *)c->map.p,
                      (unsigned long long)(N / 2u), (uint4 *)nullptr, 0ull);
-  if (side) MK_HIP(e, hipStreamWaitEvent(s, c->ev_h2d, 0));
   hipLaunchKernelGGL(mk_fab_summary_kernel, dim3((nseg_total + 3u) / 4u), dim3(256), 0, s, (const uint8_t *)c->text.p, c->hb, nseg_total, (mk_fa_sum *)c->sum.p);
   hipLaunchKernelGGL(mk_fab_scan_kernel, dim3(nfiles), dim3(1024), 0, s, (mk_fa_sum *)c->sum.p, c->hb, TL, pitch);
   hipLaunchKernelGGL(mk_fab_emit_kernel, dim3((nseg_total + 3u) / 4u), dim3(256), 0, s, (const uint8_t *)c->text.p, c->hb, nseg_total,
@@ -2049,6 +2026,12 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
   hipLaunchKernelGGL(mk_b_emit_kernel, dim3(wide * 2u), dim3(256), 0, s, c->hb);
   MK_HIP(e, hipGetLastError());
   MK_HIP(e, hipMemcpyAsync(c->h_stat, hb->stat, c->stat_bytes, hipMemcpyDeviceToHost, s));
+  /* the ids follow in the same sequence, as many as the batch can hold at most (half of every table; 8 M at most), before the host
+   * knows how many there are: a copy queued by mk_sketch_batch_end would stand behind the NEXT batch's kernels, and the host would
+   * hand every result out one batch late with the device idle meanwhile (4.1 instead of 2.8 ms a batch) */
+  c->spec_ids = N / 2u < ((uint64_t)8 << 20) ? N / 2u : ((uint64_t)8 << 20);
+  if ((rc = mk_pinned_fit(e, (void **)&c->h_ids, &c->h_ids_cap, (size_t)c->spec_ids * 4))) return rc;
+  MK_HIP(e, hipMemcpyAsync(c->h_ids, hb->out_ids, (size_t)c->spec_ids * 4, hipMemcpyDeviceToHost, s));
   MK_HIP(e, hipEventRecord(c->ev_stat, s));
   e->batch_begun++;
   return MK_OK;
@@ -2068,10 +2051,15 @@ extern "C" int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out) {
   const unsigned long long *misc = (const unsigned long long *)((const uint8_t *)ctot + mk_up16((size_t)nfiles * C * 4));
   const uint64_t n_out = misc[1];
   if (n_out > c->hb.out_cap || misc[0] > c->hb.list_cap) return mk_fail(e, MK_ERR_HIP, "batch: %llu keys, %llu ids for lists of %llu", misc[0], (unsigned long long)n_out, (unsigned long long)c->hb.list_cap);
-  int rc = mk_pinned_fit(e, (void **)&c->h_ids, &c->h_ids_cap, (size_t)(n_out ? n_out : 1) * 4);
-  if (rc) return rc;
-  if (n_out) {
-    MK_HIP(e, hipMemcpyAsync(c->h_ids, c->hb.out_ids, (size_t)n_out * 4, hipMemcpyDeviceToHost, e->stream));
+  int rc = MK_OK;
+  const bool more_ids = n_out > c->spec_ids; /* more than came with the batch's own sequence: the rest now */
+  if (more_ids) {
+    uint32_t *bigger = nullptr;
+    MK_HIP(e, hipHostMalloc((void **)&bigger, (size_t)n_out * 4 + 4096, hipHostMallocDefault));
+    memcpy(bigger, c->h_ids, (size_t)c->spec_ids * 4);
+    hipHostFree(c->h_ids);
+    c->h_ids = bigger; c->h_ids_cap = (size_t)n_out * 4 + 4096;
+    MK_HIP(e, hipMemcpyAsync(c->h_ids + c->spec_ids, c->hb.out_ids + c->spec_ids, (size_t)(n_out - c->spec_ids) * 4, hipMemcpyDeviceToHost, e->stream));
     MK_HIP(e, hipEventRecord(c->ev_stat, e->stream));
   }
   c->comps.assign((size_t)nfiles * C, mk_component{nullptr, nullptr, 0});
@@ -2105,7 +2093,7 @@ extern "C" int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out) {
     }
     out[i].r.total = r.total;
   }
-  if (n_out) MK_HIP(e, hipEventSynchronize(c->ev_stat));
+  if (more_ids) MK_HIP(e, hipEventSynchronize(c->ev_stat));
   /* the batch's ids lie file by file, component by component */
   size_t at = 0;
   for (uint32_t i = 0; i < nfiles; i++) {

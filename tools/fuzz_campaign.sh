@@ -9,7 +9,7 @@ echo "{\"kernel_source_id\": \"$KID\", \"what\": \"fuzz campaign over this build
 for seed in 2001 2002 2003; do
   python tools/fuzz_parity.py --cases 3000 --seed $seed 2>&1 | tail -1 | python -c "import sys,json; print(json.dumps({'tool':'tools/fuzz_parity.py','seed':$seed,'result':sys.stdin.read().strip()}))" >> $OUT
 done
-python tools/fuzz_parity.py --cases 600 --seed 2004 --big 2>&1 | tail -1 | python -c "import sys,json; print(json.dumps({'tool':'tools/fuzz_parity.py --big','seed':2004,'result':sys.stdin.read().strip()}))" >> $OUT
+python tools/fuzz_parity.py --cases 600 --seed 2004 --big --big-rate 0.3 2>&1 | tail -1 | python -c "import sys,json; print(json.dumps({'tool':'tools/fuzz_parity.py --big --big-rate 0.3','seed':2004,'result':sys.stdin.read().strip()}))" >> $OUT
 python tools/fuzz_parity.py --cases 1500 --seed 2005 --sparse 0 --front-bits 5 2>&1 | tail -1 | python -c "import sys,json; print(json.dumps({'tool':'tools/fuzz_parity.py --sparse 0 --front-bits 5','seed':2005,'result':sys.stdin.read().strip()}))" >> $OUT
 python tools/fuzz_parity.py --cases 1500 --seed 2006 --sparse 1 2>&1 | tail -1 | python -c "import sys,json; print(json.dumps({'tool':'tools/fuzz_parity.py --sparse 1','seed':2006,'result':sys.stdin.read().strip()}))" >> $OUT
 if [ -x oracle/_ref/metakssd ]; then

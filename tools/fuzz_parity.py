@@ -7,6 +7,7 @@ Every case draws a .shuf geometry, a sketch flavour (-A counted / FASTA set / FA
 a number of pushes and reads with random lengths, strands, lower case, N runs and odd bytes, and compares the engine's
 sketch with the oracle's, bit for bit.  Exits non-zero on the first difference and prints how to reproduce it."""
 import argparse
+import ctypes
 import os
 import sys
 
@@ -50,6 +51,7 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="also draw the 16-component L2K11 geometry (slow oracle)")
+    ap.add_argument("--big-rate", type=float, default=0.08, help="share of the cases that draw it (with --big)")
     ap.add_argument("--sparse", type=int, default=-1, help="MK_OPT_SPARSE: -1 by table size, 0 off, 1 on")
     ap.add_argument("--front-bits", type=int, default=None, help="MK_OPT_FRONT_BITS: front table of 2^n slots (with --sparse 0)")
     a = ap.parse_args()
@@ -60,7 +62,7 @@ def main():
     nonempty = total_ids = crowded = 0
     for case in range(a.cases):
         rs = np.random.RandomState(a.seed * 100003 + case)
-        k, subk, drl = GEOM_BIG if (a.big and rs.rand() < 0.08) else GEOM[rs.randint(0, len(GEOM))]
+        k, subk, drl = GEOM_BIG if (a.big and rs.rand() < a.big_rate) else GEOM[rs.randint(0, len(GEOM))]
         key = (k, subk, drl)
         if key not in shufs:
             shufs[key] = capi.Shuf.generate(k, subk, drl, 1000 + k * 100 + subk * 10 + drl)
@@ -80,12 +82,21 @@ def main():
             rows = ui.rows_from_seqs(seqs, stride)
             rc, want = ora.koc_from_rows(rows, stride)
             desc += " stride=%d" % stride
+            tuned = bool(capi.lib.mk_params_packed_ok(ctypes.byref(P)))
+            packed = tuned and need <= 153 and rs.rand() < 0.5   # 64-byte packed rows (mk_scan_packed_kernel)
+            r160 = tuned and not packed and rs.rand() < 0.5        # MK_OPT_ROWS160: takes effect on rows of pitch 160
+            eng.set_option(capi.MK_OPT_ROWS160, 1 if r160 else 0)
+            desc += " packed=%d rows160=%d" % (packed, r160)
             eng.begin(capi.MK_MODE_KOC)
             pushes = int(rs.choice([1, 2, 5]))
             n = len(seqs)
             per = (n + pushes - 1) // pushes
+            prows = capi.pack_rows_host(rows, stride) if packed else None
             for s0 in range(0, n, per):
-                eng.push_reads(rows[s0 * stride:(s0 + per) * stride], stride, s0)
+                if packed and rs.rand() < 0.8:  # (a sketch may mix the two row formats)
+                    eng.push_reads(prows[s0 * 64:(s0 + per) * 64], 64 | capi.MK_ROWS_PACKED, s0)
+                else:
+                    eng.push_reads(rows[s0 * stride:(s0 + per) * stride], stride, s0)
         elif flavour == "occ":
             M, Q = int(rs.choice([1, 2, 3, 7])), int(rs.choice([0, 40, 54]))
             quals = ui.random_quals(rs, seqs)
@@ -118,6 +129,38 @@ def main():
                 fa = b"\n".join(lines)
                 if rs.rand() < 0.3 and fa.endswith(b"\n"):
                     fa = fa[:-1]
+            if rs.rand() < 0.3:  # a BATCH of files (mk_sketch_batch_begin / _end): this text cut at header lines into 1..6 files
+                lines = fa.split(b"\n")
+                heads = [i for i, ln in enumerate(lines) if ln.startswith(b">")][1:]
+                cuts = sorted(set(int(x) for x in rs.choice(heads, size=min(len(heads), int(rs.randint(0, 6))), replace=False))) if heads else []
+                parts, prev = [], 0
+                for cpos in cuts + [len(lines)]:
+                    parts.append(b"\n".join(lines[prev:cpos]) + (b"\n" if cpos < len(lines) else b""))
+                    prev = cpos
+                parts = [x for x in parts if x] or [fa]
+                tb = int(rs.choice([0, 0, 9, 12]))
+                eng.set_option(capi.MK_OPT_BATCH_TAB_BITS, tb)
+                mode = capi.MK_MODE_UNIQ_SET if flavour == "uniq" else capi.MK_MODE_SET
+                eng.batch_begin(parts, mode, one_buffer=bool(rs.rand() < 0.5))
+                res = eng.batch_end()
+                eng.set_option(capi.MK_OPT_BATCH_TAB_BITS, 0)
+                desc += " batch of %d files tb=%d" % (len(parts), tb)
+                okb = True
+                for part, (st, alone, comps) in zip(parts, res):
+                    prc, pw = ora.co_from_fasta(part, uniq=flavour == "uniq")
+                    if prc == -5:
+                        okb = okb and st == capi.MK_ERR_FORMAT
+                    elif prc != 0:
+                        okb = okb and st != 0
+                    else:
+                        okb = okb and st == 0 and len(comps) == len(pw) and all(np.array_equal(g, w[0]) for g, w in zip(comps, pw))
+                        total_ids += sum(len(w[0]) for w in pw)
+                nonempty += 1
+                if not okb:
+                    bad += 1
+                    print("MISMATCH", desc)
+                    break
+                continue
             rc, want = ora.co_from_fasta(fa, uniq=flavour == "uniq")
             stride = int(rs.choice([64, 256, 512, 4096]))
             if stride < 2 * P.TL + 4:
