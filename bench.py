@@ -247,7 +247,7 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=4):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def leg_config5(capi, genomes=1024, mbases=4.0, threads=16, reps=3, ref_genomes=48, extra_flags=(), only=None):
+def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=3, ref_genomes=48, extra_flags=(), only=None):
     """BASELINE config 5: `metakssd dist -L <shuf> -o out <genome directory>` (no -A) on synthetic multi-FASTA genomes in
     /dev/shm, L3K10 and L2K11, whole command line by the parent's clock; the compiled reference on a few of the genomes"""
     import numpy as np
@@ -283,9 +283,11 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=16, reps=3, ref_genomes=
         cli = os.path.join(ROOT, "metakssd_amd", "bin", "metakssd")
         ref = os.path.join(ROOT, "oracle", "_ref", "metakssd")
         out = {"genomes": genomes, "bases_per_genome": bases_each, "threads": threads, "write_s": round(t_write, 2),
-               "what": "`metakssd dist -L <shuf> -p %d -o out --quiet <dir of %d multi-FASTA genomes of %.1f Mbases, 2 contigs, 70-column "
+               "what": "`metakssd dist -L <shuf>%s -o out --quiet <dir of %d multi-FASTA genomes of %.1f Mbases, 2 contigs, 70-column "
                        "lines, in /dev/shm>`: seconds = the parent's clock around the whole process, median of %d runs after one "
-                       "warm-up run; the FASTA text is parsed on the device (mk_sketch_push_stream)" % (threads, genomes, bases_each / 1e6, reps)}
+                       "warm-up run; batches of genomes (mk_sketch_batch_begin_rows: the reader threads walk the FASTA text and pack "
+                       "rows, the scan kernel reads them in pinned host memory); threads 0 = the command's default"
+                       % (" -p %d" % threads if threads else "", genomes, bases_each / 1e6, reps)}
         for name, (k, sk, l, seed) in (("L3K10", (10, 6, 3, 10)), ("L2K11", (11, 5, 2, 211))):
             if only and name != only:
                 continue
@@ -298,7 +300,7 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=16, reps=3, ref_genomes=
                 # 21 GB each at L2K11) for a while after it has exited, and the next process's allocations wait for that
                 time.sleep(2.5)
                 m0 = time.monotonic()
-                r = subprocess.run([cli, "dist", "-L", sp, "-p", str(threads)] + list(extra_flags) + ["-o", od, "--quiet", "--timing", gd],
+                r = subprocess.run([cli, "dist", "-L", sp] + (["-p", str(threads)] if threads else []) + list(extra_flags) + ["-o", od, "--quiet", "--timing", gd],
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE)
                 m1 = time.monotonic()
                 if r.returncode != 0:
@@ -320,7 +322,9 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=16, reps=3, ref_genomes=
                              "genomes_per_s_after_start": genomes / max(w - ready, 1e-9),
                              "all_runs_s": [round(x, 4) for x in walls],
                              "finish_ms_per_genome": (fin or {}).get("finish_s", 0.0) / genomes * 1e3,
-                             "engine_ready_s": (fin or {}).get("engine_ready")}
+                             "engine_ready_s": (fin or {}).get("engine_ready"),
+                             # the process's own clock (main() to the last file written), of the last run
+                             "written_s": (fin or {}).get("written"), "batches": (fin or {}).get("batches")}
                 if os.path.exists(ref) and ref_genomes:
                     sub = os.path.join(tmp, "few_" + name)
                     os.makedirs(sub)

@@ -124,6 +124,8 @@ def _load():
         "mk_pack_rows_host": [vp, u32, u64, vp],
         "mk_params_packed_ok": [C.POINTER(ParamsC)],
         "mk_sketch_batch_begin": [vp, C.c_int, vp, u32],
+        "mk_sketch_batch_begin_rows": [vp, C.c_int, vp, u32],
+        "mk_fasta_pack_rows": [vp, C.c_size_t, C.c_int32, vp, u64, C.POINTER(u64)],
         "mk_sketch_batch_end": [vp, vp],
         "mk_sketch_finish": [vp, C.POINTER(ResultC)],
         "mk_sketch_finish_begin": [vp],
@@ -191,6 +193,8 @@ def _load():
     lib.mk_setop_stream.restype = vp
     lib.mk_last_error.argtypes = [vp]
     lib.mk_last_error.restype = C.c_char_p
+    lib.mk_fasta_pack_bound.argtypes = [C.c_size_t, C.c_int32]
+    lib.mk_fasta_pack_bound.restype = u64
     return lib
 
 
@@ -262,6 +266,17 @@ def pack_rows_host(rows, stride):
     out = raw[off:off + n * MK_PACKED_PITCH]
     _check(lib.mk_pack_rows_host(rows.ctypes.data if n else None, stride, n, out.ctypes.data if n else None))
     return out
+
+
+def fasta_pack_rows(text, TL):
+    """a whole FASTA text -> its packed rows (mk_fasta_pack_rows); -> (rows u8 [nrows * 64], 16-byte aligned, rc)"""
+    b = np.frombuffer(bytes(text), dtype=np.uint8)
+    bound = int(lib.mk_fasta_pack_bound(len(b), TL))
+    raw = np.zeros(bound * MK_PACKED_PITCH + 64, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 64
+    n = C.c_uint64(0)
+    rc = lib.mk_fasta_pack_rows(b.ctypes.data if len(b) else None, len(b), TL, raw.ctypes.data + off, bound, C.byref(n))
+    return raw[off:off + n.value * MK_PACKED_PITCH], rc
 
 
 def fastq_frame(buf, stride, final=True, max_rows=None):
@@ -491,6 +506,38 @@ class Engine:
         self._batches = getattr(self, "_batches", [])
         self._batches.append((keep, len(texts)))
 
+    def batch_begin_rows(self, row_arrays, mode=MK_MODE_SET, pinned=False):
+        """mk_sketch_batch_begin_rows over the files' packed rows (fasta_pack_rows).  pinned: the rows are laid into ONE registered buffer,
+        file behind file with an empty row between them -- the layout the scan kernel reads in place; otherwise separate pageable arrays."""
+        n = len(row_arrays)
+        files = (BatchFileC * n)()
+        if pinned:
+            total = sum(a.size + MK_PACKED_PITCH for a in row_arrays) + 4096
+            raw = np.zeros(total + 4096, dtype=np.uint8)
+            off = (-raw.ctypes.data) % 4096
+            buf = raw[off:off + total]
+            at = 0
+            for i, a in enumerate(row_arrays):
+                buf[at:at + a.size] = a
+                files[i].text = buf.ctypes.data + at
+                files[i].n = a.size
+                at += a.size + MK_PACKED_PITCH
+            _check(lib.mk_host_register(buf.ctypes.data, total))
+            keep = ("registered", raw, buf.ctypes.data)
+        else:
+            arrs = []
+            for i, a in enumerate(row_arrays):
+                raw = np.zeros(a.size + 64, dtype=np.uint8)
+                off = (-raw.ctypes.data) % 64
+                raw[off:off + a.size] = a
+                arrs.append(raw)
+                files[i].text = (raw.ctypes.data + off) if a.size else None
+                files[i].n = a.size
+            keep = arrs
+        _check(lib.mk_sketch_batch_begin_rows(self.h, mode, C.cast(files, C.c_void_p), n), self.h)
+        self._batches = getattr(self, "_batches", [])
+        self._batches.append((keep, n))
+
     def batch_end(self):
         """-> per file (status, alone, [ids per component]) of the oldest batch in flight"""
         if not getattr(self, "_batches", None):  # nothing in flight: let the library say so
@@ -510,6 +557,8 @@ class Engine:
                     comp = out[i].r.components[c]
                     comps.append(np.ctypeslib.as_array(comp.ids, shape=(comp.n,)).copy() if comp.n else np.zeros(0, np.uint32))
             res.append((out[i].status, out[i].alone, comps))
+        if isinstance(keep, tuple) and keep[0] == "registered":
+            lib.mk_host_unregister(keep[2])
         del keep
         return res
 

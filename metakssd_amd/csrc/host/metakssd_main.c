@@ -710,7 +710,7 @@ static int parse_devices(const char *s, int *out, int cap) {
 
 static void usage(void) {
   fprintf(stderr,
-          "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D | --devices 0-7] [--engines 1..4] [--no-batch] <fastq|fasta|dir>...\n"
+          "usage: metakssd dist -L <file.shuf> [-A] [-u] [-n minocc] [-Q minqual] [-o outdir] [-p N] [--device D | --devices 0-7] [--engines 1..4] [--no-batch | --batch-text] <fastq|fasta|dir>...\n"
           "       metakssd dist -o <mco dir> <sketch dir>                      (stage II: inverted index)\n"
           "       metakssd dist -L <file.shuf> -r <genomes> -o <db dir>         (stage I + II)\n"
           "       metakssd dist -r <mco dir> -o <outdir> [-M 0|1] [-O 0|1|2] [-N n] [-D d] [--correction 0|1] [--keepskf] [-f skf] <sketch dir>\n"
@@ -1807,9 +1807,11 @@ static void *extra_engines_run(void *arg) {
 
 
 /* ---- a directory of genomes in batches (mk_sketch_batch_begin / _end) -------------------------------------------------------
- * The reference sketches one file per OpenMP thread (command_dist.c:363-372).  Here consecutive small FASTA files travel to the
- * device TOGETHER: reader threads lay the files of a batch into one pinned buffer at 1 KiB-aligned offsets (one host-to-device
- * copy), the engine runs ONE launch sequence for all of them, and two batches are in flight while the readers fill the next.
+ * The reference sketches one file per OpenMP thread (command_dist.c:363-372).  Here consecutive small FASTA files go to the
+ * device TOGETHER: the reader threads do the FASTA walk and leave the files of a batch as PACKED ROWS in one pinned buffer
+ * (mk_fasta_pack_rows; the scan kernel reads them there), the engine runs ONE launch sequence for all of them, and two batches are
+ * in flight while the readers fill the next.  (--batch-text, and every geometry without a scan kernel for packed rows: the files'
+ * TEXT at 1 KiB-aligned offsets, one host-to-device copy, the walk on the device.)
  * A file that cannot go that way (FASTQ, compressed, a pipe, larger than BATCH_FILE_MAX) is sketched alone, in its place in the
  * input order.  --no-batch gives the file-by-file driver. */
 #define BATCH_FILE_MAX ((size_t)32 << 20)
@@ -1817,6 +1819,7 @@ static void *extra_engines_run(void *arg) {
 static int g_no_batch = 0;
 static size_t g_batch_bytes = (size_t)128 << 20; /* --batch-mib: text per batch */
 static int g_batch_files = 256;                  /* --batch-files */
+static int g_batch_text = 0;                     /* --batch-text: the files' TEXT goes to the device (which then does the FASTA walk too) */
 
 typedef struct { int first, n, batch; } bjob;    /* files [first, first + n); batch: its number among the batches, -1 = one file alone */
 typedef struct {
@@ -1825,6 +1828,8 @@ typedef struct {
   bjob *jobs; int njobs;
   uint8_t *buf[BATCH_BUFS]; size_t bufcap;
   uint64_t *foff;               /* offset of every file inside its batch's buffer */
+  int rows_TL;                  /* != 0: the readers do the FASTA walk and leave PACKED ROWS in the buffer (mk_fasta_pack_rows) ... */
+  uint64_t *slot_rows, *nrows;  /* ... per file: rows its place in the buffer holds / rows it got */
   int *left;                    /* per job: files not read yet */
   int *failed;                  /* per file: errno of a failed read */
   int released;                 /* batches whose buffer has been handed back */
@@ -1835,19 +1840,32 @@ typedef struct {
 
 static void *breader_run(void *arg) {
   breader *r = arg;
+  uint8_t *txt = NULL; /* rows: the file's text, here only */
+  size_t txt_cap = 0;
   for (;;) {
     pthread_mutex_lock(&r->mu);
     while (r->next_job < r->njobs && (r->jobs[r->next_job].batch < 0 || r->next_file >= r->jobs[r->next_job].n)) { r->next_job++; r->next_file = 0; }
-    if (r->next_job >= r->njobs) { pthread_mutex_unlock(&r->mu); return NULL; }
+    if (r->next_job >= r->njobs) { pthread_mutex_unlock(&r->mu); free(txt); return NULL; }
     const int j = r->next_job, k = r->next_file++;
     const bjob *job = &r->jobs[j];
     while (job->batch - r->released >= BATCH_BUFS) pthread_cond_wait(&r->cv_free, &r->mu); /* its buffer still belongs to an older batch */
     pthread_mutex_unlock(&r->mu);
     const int i = job->first + k;
-    uint8_t *dst = r->buf[job->batch % BATCH_BUFS] + r->foff[i];
+    uint8_t *const place = r->buf[job->batch % BATCH_BUFS] + r->foff[i];
+    uint8_t *dst = place;
     int err = 0;
-    const int fd = open(r->files->v[i], O_RDONLY);
-    if (fd < 0) err = errno ? errno : EIO;
+    if (r->rows_TL) {
+      if (txt_cap < r->fsize[i] + 64) {
+        free(txt);
+        txt_cap = (size_t)r->fsize[i] + ((size_t)1 << 20);
+        txt = malloc(txt_cap);
+        if (!txt) { txt_cap = 0; err = ENOMEM; }
+      }
+      dst = txt;
+    }
+    const int fd = err ? -1 : open(r->files->v[i], O_RDONLY);
+    if (err) ;
+    else if (fd < 0) err = errno ? errno : EIO;
     else {
       uint64_t got = 0;
       while (got < r->fsize[i]) {
@@ -1856,6 +1874,18 @@ static void *breader_run(void *arg) {
         got += (uint64_t)n;
       }
       close(fd);
+    }
+    if (r->rows_TL && !err) {
+      /* the walk and the packing here, on this thread; what the file leaves free of its place stays EMPTY rows (the scan kernel reads
+       * the whole stretch where it lies) */
+      uint64_t got_rows = 0;
+      const int prc = mk_fasta_pack_rows(txt, (size_t)r->fsize[i], r->rows_TL, place, r->slot_rows[i], &got_rows);
+      if (prc == MK_ERR_FORMAT) err = -MK_ERR_FORMAT + 100000; /* (no errno: the text ends inside a '>' line) */
+      else if (prc != MK_OK) err = EIO;
+      else {
+        r->nrows[i] = got_rows;
+        memset(place + got_rows * MK_PACKED_PITCH, 0, (size_t)(r->slot_rows[i] - got_rows) * MK_PACKED_PITCH);
+      }
     }
     pthread_mutex_lock(&r->mu);
     r->failed[i] = err;
@@ -1911,6 +1941,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--engines") && i + 1 < argc) engines_per_gpu = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--allow-device-copies")) allow_copies = 1;
     else if (!strcmp(argv[i], "--no-batch")) g_no_batch = 1; /* genome directories file by file (the driver of round 3) */
+    else if (!strcmp(argv[i], "--batch-text")) g_batch_text = 1; /* batches of FASTA TEXT (the device walks it) instead of rows packed by the readers */
     else if (!strcmp(argv[i], "--batch-mib") && i + 1 < argc) g_batch_bytes = (size_t)atoi(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--batch-files") && i + 1 < argc) g_batch_files = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--host-fasta")) g_host_fasta = 1; /* FASTA windows made on the host (mk_fasta_window), not on the device */
@@ -2087,16 +2118,25 @@ int main(int argc, char **argv) {
     bjob *jobs = calloc((size_t)files.n, sizeof *jobs);
     uint64_t *foff = calloc((size_t)files.n, sizeof *foff);
     int *left = calloc((size_t)files.n, sizeof *left), *failed = calloc((size_t)files.n, sizeof *failed);
-    if (!jobs || !foff || !left || !failed) die("out of memory");
+    /* the readers do the FASTA walk and pack (0.48 bytes a base cross PCIe instead of 1.01, and the scan kernel reads them where the
+     * readers left them) wherever there is a scan kernel for packed rows; --batch-text: the text travels and the device walks it */
+    const int batch_rows = !g_batch_text && mk_params_packed_ok(&P);
+    uint64_t *slot_rows = calloc((size_t)files.n, sizeof *slot_rows), *nrows_of = calloc((size_t)files.n, sizeof *nrows_of);
+    if (!jobs || !foff || !left || !failed || !slot_rows || !nrows_of) die("out of memory");
     int njobs = 0, nbatches = 0;
     size_t bufcap = 0;
     for (int i = 0; i < files.n;) {
       if (!elig[i]) { jobs[njobs].first = i; jobs[njobs].n = 1; jobs[njobs].batch = -1; njobs++; i++; continue; }
       size_t at = 0;
       int n = 0;
-      while (i + n < files.n && elig[i + n] && n < g_batch_files && (n == 0 || at + fsize[i + n] <= g_batch_bytes)) {
+      size_t text_at = 0;
+      while (i + n < files.n && elig[i + n] && n < g_batch_files && (n == 0 || text_at + fsize[i + n] <= g_batch_bytes)) {
         foff[i + n] = at;
-        at += ((size_t)fsize[i + n] + 1023u) & ~(size_t)1023u;
+        if (batch_rows) { /* its place: the rows its text can give at most, and one that stays empty */
+          slot_rows[i + n] = mk_fasta_pack_bound((size_t)fsize[i + n], P.TL) + 1u;
+          at += (size_t)slot_rows[i + n] * MK_PACKED_PITCH;
+        } else at += ((size_t)fsize[i + n] + 1023u) & ~(size_t)1023u;
+        text_at += ((size_t)fsize[i + n] + 1023u) & ~(size_t)1023u;
         n++;
       }
       if (at > bufcap) bufcap = at;
@@ -2106,6 +2146,7 @@ int main(int argc, char **argv) {
     breader br;
     memset(&br, 0, sizeof br);
     br.files = &files; br.fsize = fsize; br.jobs = jobs; br.njobs = njobs; br.foff = foff; br.left = left; br.failed = failed;
+    br.rows_TL = batch_rows ? P.TL : 0; br.slot_rows = slot_rows; br.nrows = nrows_of;
     br.bufcap = (bufcap + 4096 + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1); /* whole 2 MiB granules: every buffer is pinned on its own */
     pthread_mutex_init(&br.mu, NULL);
     pthread_cond_init(&br.cv_ready, NULL);
@@ -2172,9 +2213,10 @@ int main(int argc, char **argv) {
       }
       for (int k = 0; k < bj->n; k++) {
         const int i = bj->first + k;
+        if (failed[i] == -MK_ERR_FORMAT + 100000) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", files.v[i]);
         if (failed[i]) die("%s: %s", files.v[i], strerror(failed[i]));
         bf[k].text = br.buf[bj->batch % BATCH_BUFS] + foff[i];
-        bf[k].n = fsize[i];
+        bf[k].n = batch_rows ? nrows_of[i] * MK_PACKED_PITCH : fsize[i];
       }
       (void)engine_get(&c);
       const double tp0 = now_s();
@@ -2188,7 +2230,7 @@ int main(int argc, char **argv) {
       if (c.t_first_push == 0) c.t_first_push = now_s() - g_t0;
       {
         const double tb = now_s();
-        rc = mk_sketch_batch_begin(c.eng, mode, bf, (uint32_t)bj->n);
+        rc = batch_rows ? mk_sketch_batch_begin_rows(c.eng, mode, bf, (uint32_t)bj->n) : mk_sketch_batch_begin(c.eng, mode, bf, (uint32_t)bj->n);
         t_batch_begin += now_s() - tb;
         nbatches_done++;
         if (btrace) fprintf(stderr, "[batch %d] begin: called %.3f returned %.3f ms\n", bj->batch, (tb - g_t0) * 1e3, (now_s() - g_t0) * 1e3);

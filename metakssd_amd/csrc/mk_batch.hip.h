@@ -399,3 +399,16 @@ __global__ void __launch_bounds__(256) mk_b_emit_kernel(const mk_batch_dev b) {
     b.out_ids[lo + rank] = (uint32_t)(b.key[b.tidx[j]] >> b.comp_code_bits);
   }
 }
+
+/* the batch's results to the host's pinned blocks, by the device itself: the per-file block (flags, component sizes, totals) and
+ * the ids there are -- min(n_out, ids_cap) of them, 16 bytes a lane (the lists end in slack; ids_cap is a multiple of four) */
+__global__ void __launch_bounds__(256) mk_b_home_kernel(const mk_batch_dev b, uint4 *h_stat, uint32_t stat16, uint4 *h_ids, unsigned long long ids_cap) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
+  const uint4 *st = (const uint4 *)b.stat;
+  for (uint64_t i = tid; i < stat16; i += nthreads) h_stat[i] = st[i];
+  unsigned long long n = b.misc[1];
+  if (n > b.out_cap) return;
+  if (n > ids_cap) n = ids_cap;
+  const uint4 *ids = (const uint4 *)b.out_ids;
+  for (uint64_t i = tid; i < (n + 3u) / 4u; i += nthreads) h_ids[i] = ids[i];
+}

@@ -345,9 +345,9 @@ static int mk_config_cand(mk_engine *e, uint32_t cap) {
   return MK_OK;
 }
 
-#ifdef MK_TUNING
 #include <time.h>
 static double mk_tick_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+#ifdef MK_TUNING
 #define MK_TICK(label) do { if (getenv("MK_DEBUG")) { double n_ = mk_tick_now(); fprintf(stderr, "[engine create] %-22s %.4f s\n", label, n_ - tick_); tick_ = n_; } } while (0)
 #else
 #define MK_TICK(label) do { } while (0)
@@ -1799,7 +1799,8 @@ struct mk_bctx {
   int mode = 0;
   uint32_t nfiles = 0;
   size_t stat_bytes = 0;
-  uint64_t spec_ids = 0; /* ids copied to the host with the batch's own launch sequence (before their number is known there) */
+  bool rows = false;     /* the files are packed rows (mk_sketch_batch_begin_rows) */
+  uint64_t spec_ids = 0; /* ids the pinned block holds: written there by the batch's own launch sequence */
   std::vector<mk_batch_file> files;
   std::vector<mk_component> comps;              /* [nfiles * component_num] */
   std::vector<std::vector<uint32_t>> alone_ids; /* ids of the files that were sketched alone */
@@ -1850,16 +1851,22 @@ static uint64_t mk_rows_per_launch(const mk_engine *e, uint32_t row_bases, int t
   return (uint64_t)rows / 64u * 64u;
 }
 
-extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles) {
+/* rows: the files are PACKED ROWS already (mk_fasta_pack_rows on the reader's thread: the FASTA walk done by the host) -- no text,
+ * no mk_fab_* kernels; where the rows lie in ONE stretch of pinned memory the scan kernel reads them THERE, through the mapping
+ * (tools/probe_hostread.hip: a kernel reads registered host memory at 55.5 GB/s, the copy engine moves it at 57.0 and costs 7.7 ms
+ * of set-up at the first copy of a process) */
+static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles, const bool rows) {
   if (!e || !files) return MK_ERR_ARG;
   if (mode != MK_MODE_SET && mode != MK_MODE_UNIQ_SET) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: MK_MODE_SET or MK_MODE_UNIQ_SET");
   if (nfiles < 1 || nfiles > MK_BATCH_MAX_FILES) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: 1 .. %u files", MK_BATCH_MAX_FILES);
   if (e->begun) return mk_fail(e, MK_ERR_STATE, "mk_sketch_batch_begin inside a sketch (between begin and finish)");
   if (e->batch_begun - e->batch_ended >= 2) return mk_fail(e, MK_ERR_STATE, "mk_sketch_batch_begin: two batches are in flight (mk_sketch_batch_end first)");
   if (e->P.TL + MK_FA_PITCH > 4000u) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: k-mer too long for the stream rows");
+  if (rows && !mk_params_packed_ok(&e->P)) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin_rows: no scan kernel for packed rows at k %d, subk %d", e->P.k, e->P.subk);
   uint64_t total = 0, nmax = 0;
   for (uint32_t i = 0; i < nfiles; i++) {
     if (!files[i].text && files[i].n) return MK_ERR_ARG;
+    if (rows && ((files[i].n % MK_PACKED_PITCH) || ((uintptr_t)files[i].text & 15u))) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin_rows: file %u: rows of 64 bytes, 16-byte aligned", i);
     if (files[i].n > MK_BATCH_FILE_MAX) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: file %u has %llu bytes (at most %llu)", i, (unsigned long long)files[i].n, (unsigned long long)MK_BATCH_FILE_MAX);
     total += files[i].n;
     if (files[i].n > nmax) nmax = files[i].n;
@@ -1880,7 +1887,7 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
   bool one_copy = true;
   for (uint32_t i = 1; i < nfiles && one_copy; i++) {
     if (files[i].text < files[i - 1].text + files[i - 1].n) one_copy = false;
-    else if ((size_t)(files[i].text - files[0].text) % MK_FA_SEG) one_copy = false;
+    else if ((size_t)(files[i].text - files[0].text) % (rows ? MK_PACKED_PITCH : MK_FA_SEG)) one_copy = false;
   }
   if (one_copy && (uint64_t)(files[nfiles - 1].text - files[0].text) + files[nfiles - 1].n > total + (uint64_t)nfiles * MK_FA_SEG + ((uint64_t)64 << 20)) one_copy = false;
   const size_t desc_bytes = mk_up16(sizeof(mk_batch_dev)) + mk_up16((size_t)nfiles * sizeof(mk_bfile)) + 2 * mk_up16(((size_t)nfiles + 1) * 4);
@@ -1895,7 +1902,18 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
   uint32_t *hrow0 = (uint32_t *)((uint8_t *)hseg0 + mk_up16(((size_t)nfiles + 1) * 4));
   uint64_t toff = 0, soff = 0;
   uint32_t seg = 0;
-  for (uint32_t i = 0; i < nfiles; i++) {
+  for (uint32_t i = 0; i < nfiles && rows; i++) { /* the files' rows as they lie (one stretch), or side by side */
+    mk_bfile &f = hf[i];
+    f.text_off = 0; f.text_len = 0; f.seg0 = 0; f.nseg = 0;
+    f.stream_off = one_copy ? (uint64_t)(files[i].text - files[0].text) : soff;
+    f.stream_cap = files[i].n;
+    soff = f.stream_off + f.stream_cap;
+    f.row0 = (uint32_t)(f.stream_off / MK_PACKED_PITCH);
+    f.nrow = (uint32_t)(f.stream_cap / MK_PACKED_PITCH);
+    hseg0[i] = 0;
+    hrow0[i] = f.row0;
+  }
+  for (uint32_t i = 0; i < nfiles && !rows; i++) {
     mk_bfile &f = hf[i];
     f.text_off = one_copy ? (uint64_t)(files[i].text - files[0].text) : toff;
     f.text_len = files[i].n;
@@ -1912,8 +1930,17 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
     hseg0[i] = f.seg0;
     hrow0[i] = f.row0;
   }
-  const uint64_t text_span = one_copy ? (uint64_t)(files[nfiles - 1].text - files[0].text) + files[nfiles - 1].n : toff;
-  const uint64_t total_rows = soff / pitch;
+  const uint64_t text_span = rows ? 0 : one_copy ? (uint64_t)(files[nfiles - 1].text - files[0].text) + files[nfiles - 1].n : toff;
+  const uint64_t total_rows = soff / (rows ? MK_PACKED_PITCH : pitch);
+  /* rows in one stretch of memory the device can read are scanned where they lie */
+  const uint8_t *rows_dev = nullptr;
+  if (rows && one_copy && soff) {
+    hipPointerAttribute_t pa;
+    void *dp = nullptr;
+    if (hipPointerGetAttributes(&pa, files[0].text) == hipSuccess && pa.type == hipMemoryTypeHost &&
+        hipHostGetDevicePointer(&dp, (void *)files[0].text, 0) == hipSuccess) rows_dev = (const uint8_t *)dp;
+    else (void)hipGetLastError();
+  }
   const uint32_t nseg_total = seg;
   hseg0[nfiles] = nseg_total;
   hrow0[nfiles] = (uint32_t)total_rows;
@@ -1922,7 +1949,9 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
   /* ---- tables: 2^tb slots per file, about five times the keys the largest file is expected to leave (its k-mers / 16^drlevel) */
   uint32_t tb = 10;
   {
-    const uint64_t est = (nmax >> (4u * (uint32_t)e->P.drlevel)) * 5u;
+    /* (bases of the largest file: its text, or its rows' 153 - TL new bases each) */
+    const uint64_t nbases = rows ? nmax / MK_PACKED_PITCH * (MK_PACKED_MAX_BASES + 1u - TL) : nmax;
+    const uint64_t est = (nbases >> (4u * (uint32_t)e->P.drlevel)) * 5u;
     while (tb < 22u && (1ull << tb) < est) tb++;
     if (e->batch_tb_opt) tb = (uint32_t)e->batch_tb_opt;
     while (tb > 9u && ((uint64_t)nfiles << tb) > (1ull << 26)) tb--; /* (files that do not fit then are sketched alone) */
@@ -1941,14 +1970,17 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
   const uint64_t nb = (uint64_t)nfiles * bpf;
   c->stat_bytes = mk_up16((size_t)nfiles * sizeof(mk_bstat)) + mk_up16((size_t)nfiles * C * 4) + 16;
   const size_t zero_bytes = (size_t)N * 16 + mk_up16((size_t)(nb + 1) * 4) + c->stat_bytes + (size_t)nfiles * 64;
-  if ((rc = mk_dbuf_fit(e, c->text, (size_t)text_span + 256))) return rc;
-  if ((rc = mk_dbuf_fit(e, c->stream, (size_t)soff + 8192))) return rc;
-  if ((rc = mk_dbuf_fit(e, c->sum, (size_t)nseg_total * sizeof(mk_fa_sum)))) return rc;
+  static const bool trace = getenv("MK_BATCH_TRACE") != nullptr;
+  const double tr0 = trace ? mk_tick_now() : 0.0;
+  if (!rows && (rc = mk_dbuf_fit(e, c->text, (size_t)text_span + 256))) return rc;
+  if (!rows_dev && (rc = mk_dbuf_fit(e, c->stream, (size_t)soff + 8192))) return rc;
+  if (!rows && (rc = mk_dbuf_fit(e, c->sum, (size_t)nseg_total * sizeof(mk_fa_sum)))) return rc;
   if ((rc = mk_dbuf_fit(e, c->zero, zero_bytes))) return rc;
   if ((rc = mk_dbuf_fit(e, c->map, (size_t)N * 8))) return rc;
   if ((rc = mk_dbuf_fit(e, c->list, (size_t)N * 40))) return rc;
   if ((rc = mk_dbuf_fit(e, c->bcur, (size_t)nb * 4 + 16))) return rc;
   if ((rc = mk_pinned_fit(e, &c->h_stat, &c->h_stat_cap, c->stat_bytes))) return rc;
+  const double tr1 = trace ? mk_tick_now() : 0.0;
   {
     uint8_t *z = (uint8_t *)c->zero.p;
     hb->kc = (unsigned long long *)z;
@@ -1982,7 +2014,7 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
     hb->shift = shift; hb->bpc = bpc; hb->bpf = bpf;
   }
   c->hb = *hb;
-  c->mode = mode; c->nfiles = nfiles;
+  c->mode = mode; c->nfiles = nfiles; c->rows = rows;
   c->files.assign(files, files + nfiles);
   const mk_batch_dev *dbatch = (const mk_batch_dev *)dd;
   hipStream_t s = e->stream;
@@ -1991,33 +2023,56 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
    * the first batches, the kernels behind an event -- was built and measured: 1 024 genomes in 0.222-0.238 s with it, 0.199-0.213 s
    * without, three runs each on one box: a batch's kernels are 0.4 ms beside 2.3-2.8 ms of copy, and the copy is no faster for
    * running beside them.) */
+  double trk = tr1;
+  auto tick = [&](const char *what) {
+    if (!trace || e->batch_begun) return;
+    const double n = mk_tick_now();
+    fprintf(stderr, "[mk batch 0]   %-28s %.3f ms\n", what, (n - trk) * 1e3);
+    trk = n;
+  };
+  tick("descriptors built");
   MK_HIP(e, hipMemcpyAsync(c->desc.p, c->h_desc, desc_bytes, hipMemcpyHostToDevice, s));
-  if (one_copy) {
+  tick("descriptor copy queued");
+  if (rows) {
+    if (!rows_dev) {
+      if (one_copy) { if (soff) MK_HIP(e, hipMemcpyAsync(c->stream.p, files[0].text, (size_t)soff, hipMemcpyHostToDevice, s)); }
+      else
+        for (uint32_t i = 0; i < nfiles; i++)
+          if (files[i].n) MK_HIP(e, hipMemcpyAsync((uint8_t *)c->stream.p + hf[i].stream_off, files[i].text, (size_t)files[i].n, hipMemcpyHostToDevice, s));
+    }
+  } else if (one_copy) {
     if (text_span) MK_HIP(e, hipMemcpyAsync(c->text.p, files[0].text, (size_t)text_span, hipMemcpyHostToDevice, s));
   } else {
     for (uint32_t i = 0; i < nfiles; i++)
       if (files[i].n) MK_HIP(e, hipMemcpyAsync((uint8_t *)c->text.p + hf[i].text_off, files[i].text, (size_t)files[i].n, hipMemcpyHostToDevice, s));
   }
+  tick("text copy queued");
   const unsigned wide = (unsigned)e->num_cu * 8u;
   hipLaunchKernelGGL(mk_b_clear_kernel, dim3(wide), dim3(256), 0, s, (uint4 *)c->zero.p, (unsigned long long)(zero_bytes / 16u), (uint4 *)c->map.p,
                      (unsigned long long)(N / 2u), (uint4 *)nullptr, 0ull);
-  hipLaunchKernelGGL(mk_fab_summary_kernel, dim3((nseg_total + 3u) / 4u), dim3(256), 0, s, (const uint8_t *)c->text.p, c->hb, nseg_total, (mk_fa_sum *)c->sum.p);
-  hipLaunchKernelGGL(mk_fab_scan_kernel, dim3(nfiles), dim3(1024), 0, s, (mk_fa_sum *)c->sum.p, c->hb, TL, pitch);
-  hipLaunchKernelGGL(mk_fab_emit_kernel, dim3((nseg_total + 3u) / 4u), dim3(256), 0, s, (const uint8_t *)c->text.p, c->hb, nseg_total,
-                     (const mk_fa_sum *)c->sum.p, (uint8_t *)c->stream.p);
+  if (!rows) {
+    hipLaunchKernelGGL(mk_fab_summary_kernel, dim3((nseg_total + 3u) / 4u), dim3(256), 0, s, (const uint8_t *)c->text.p, c->hb, nseg_total, (mk_fa_sum *)c->sum.p);
+    hipLaunchKernelGGL(mk_fab_scan_kernel, dim3(nfiles), dim3(1024), 0, s, (mk_fa_sum *)c->sum.p, c->hb, TL, pitch);
+    hipLaunchKernelGGL(mk_fab_emit_kernel, dim3((nseg_total + 3u) / 4u), dim3(256), 0, s, (const uint8_t *)c->text.p, c->hb, nseg_total,
+                       (const mk_fa_sum *)c->sum.p, (uint8_t *)c->stream.p);
+  }
+  tick("clear + FASTA walk queued");
   MK_HIP(e, hipGetLastError());
   {
     const int tuned = (e->P.subk == 6 && e->P.k >= 9 && e->P.k <= 11) ? 6 : (e->P.subk == 5 && e->P.k == 11) ? 5 : 0;
-    const uint64_t per = mk_rows_per_launch(e, rowlen, tuned);
+    const uint64_t per = mk_rows_per_launch(e, rows ? MK_PACKED_MAX_BASES : rowlen, tuned);
+    const uint8_t *src = rows_dev ? rows_dev : (const uint8_t *)c->stream.p;
     e->cur_batch = dbatch;
     for (uint64_t done = 0; done < total_rows && rc == MK_OK; done += per) {
       const uint64_t n = total_rows - done < per ? total_rows - done : per;
       /* (ordinals are rows of the batch: first_ord = the first row of the launch) */
-      rc = mk_launch_scan_ex(e, (const uint8_t *)c->stream.p + done * pitch, width, pitch, rowlen, n, nullptr, done);
+      if (rows) rc = mk_launch_scan_ex(e, src + done * MK_PACKED_PITCH, MK_PACKED_PITCH | MK_ROWS_PACKED, MK_PACKED_PITCH | MK_ROWS_PACKED, 0u, n, nullptr, done);
+      else rc = mk_launch_scan_ex(e, src + done * pitch, width, pitch, rowlen, n, nullptr, done);
     }
     e->cur_batch = nullptr;
     if (rc) return rc;
   }
+  tick("scan queued");
   hipLaunchKernelGGL(mk_b_compact_kernel, dim3((unsigned)e->num_cu * 2u), dim3(1024), 0, s, c->hb);
   hipLaunchKernelGGL(mk_b_layout_kernel, dim3(wide * 2u), dim3(256), 0, s, c->hb);
   hipLaunchKernelGGL(mk_b_bucket_kernel, dim3(wide * 2u), dim3(256), 0, s, c->hb);
@@ -2025,17 +2080,28 @@ extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file
   hipLaunchKernelGGL(mk_b_scatter_kernel, dim3(wide * 2u), dim3(256), 0, s, c->hb);
   hipLaunchKernelGGL(mk_b_emit_kernel, dim3(wide * 2u), dim3(256), 0, s, c->hb);
   MK_HIP(e, hipGetLastError());
-  MK_HIP(e, hipMemcpyAsync(c->h_stat, hb->stat, c->stat_bytes, hipMemcpyDeviceToHost, s));
-  /* the ids follow in the same sequence, as many as the batch can hold at most (half of every table; 8 M at most), before the host
-   * knows how many there are: a copy queued by mk_sketch_batch_end would stand behind the NEXT batch's kernels, and the host would
-   * hand every result out one batch late with the device idle meanwhile (4.1 instead of 2.8 ms a batch) */
+  tick("finish queued");
+  /* the results go home in the same sequence, written by a kernel into the pinned blocks: the counts per file and component and
+   * exactly the ids there are (a copy queued by mk_sketch_batch_end would stand behind the NEXT batch's kernels, and the host would
+   * hand every result out one batch late with the device idle meanwhile; a copy COMMAND here would have to guess the count, and be
+   * the process's first use of the copy engine where the rows are read in place).  The block holds half of every table, 8 M ids at
+   * most; a batch with more -- none so far -- gets the rest by a copy in mk_sketch_batch_end. */
   c->spec_ids = N / 2u < ((uint64_t)8 << 20) ? N / 2u : ((uint64_t)8 << 20);
   if ((rc = mk_pinned_fit(e, (void **)&c->h_ids, &c->h_ids_cap, (size_t)c->spec_ids * 4))) return rc;
-  MK_HIP(e, hipMemcpyAsync(c->h_ids, hb->out_ids, (size_t)c->spec_ids * 4, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(mk_b_home_kernel, dim3((unsigned)e->num_cu), dim3(256), 0, s, c->hb, (uint4 *)c->h_stat, (uint32_t)(c->stat_bytes / 16u), (uint4 *)c->h_ids,
+                     (unsigned long long)c->spec_ids);
+  MK_HIP(e, hipGetLastError());
   MK_HIP(e, hipEventRecord(c->ev_stat, s));
+  tick("copies home queued");
+  if (trace)
+    fprintf(stderr, "[mk batch %llu] device buffers %.3f ms, commands queued in %.3f ms (N %llu, %u ids come home with the batch)\n", (unsigned long long)e->batch_begun,
+            (tr1 - tr0) * 1e3, (mk_tick_now() - tr1) * 1e3, (unsigned long long)N, (unsigned)c->spec_ids);
   e->batch_begun++;
   return MK_OK;
 }
+
+extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles) { return mk_batch_begin_impl(e, mode, files, nfiles, false); }
+extern "C" int mk_sketch_batch_begin_rows(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles) { return mk_batch_begin_impl(e, mode, files, nfiles, true); }
 
 extern "C" int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out) {
   if (!e || !out) return MK_ERR_ARG;
@@ -2077,7 +2143,8 @@ extern "C" int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out) {
     out[i].alone = 1;
     mk_result r;
     rc = mk_sketch_begin(e, c->mode);
-    if (rc == MK_OK) rc = mk_sketch_push_stream(e, c->files[i].text, c->files[i].n, 1);
+    if (rc == MK_OK) rc = c->rows ? mk_sketch_push_reads(e, c->files[i].text, MK_PACKED_PITCH | MK_ROWS_PACKED, c->files[i].n / MK_PACKED_PITCH, 0)
+                                  : mk_sketch_push_stream(e, c->files[i].text, c->files[i].n, 1);
     if (rc == MK_OK) rc = mk_sketch_finish(e, &r);
     else if (e->begun) { mk_result dummy; (void)mk_sketch_finish(e, &dummy); }
     if (rc == MK_ERR_CROWDED || rc == MK_ERR_FORMAT) { out[i].status = rc; ai++; continue; }

@@ -145,6 +145,48 @@ REF_HIP = os.path.join(ROOT, "oracle", "_ref_hip", "metakssd")
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shuf,flags", [("L3K10", []), ("L2K11", ["-u"]), ("L1K7", [])])
+def test_product_cli_batches_with_files_that_cannot_travel_in_one(shuf, flags, shuf_files, tmp_path):
+    """a directory whose FASTA files go to the device in batches, with files in between that cannot (a .gz genome, a FASTQ file):
+    those are sketched alone in their place in the input order; the directory is the one `--no-batch` (file by file) writes, also
+    with batches of two files and of 1 MiB"""
+    import gzip
+    import numpy as np
+    import util_inputs as ui
+    rs = np.random.RandomState(93)
+    d = tmp_path / "dir"
+    d.mkdir()
+    for i in range(14):
+        n = [90000, 700, 30000, 250000][i % 4]
+        fa = ui.fasta_bytes([ui.rand_seq(rs, n // 2 + 40), ui.rand_seq(rs, n - n // 2)])
+        if i == 4:
+            with gzip.open(str(d / ("g%02d.fna.gz" % i)), "wb") as f:
+                f.write(fa)
+        elif i == 9:
+            open(str(d / ("g%02d.fq" % i)), "wb").write(ui.fastq_bytes(ui.pool_reads(rs, 20000, 300)))
+        else:
+            open(str(d / ("g%02d.fna" % i)), "wb").write(fa)
+    base = [PRODUCT_CLI, "dist", "-L", shuf_files(shuf)] + flags
+    outs = {}
+    for tag, extra in (("batches", []), ("file_by_file", ["--no-batch"]), ("pairs", ["--batch-files", "2"]), ("one_mib", ["--batch-mib", "1", "-p", "3"]),
+                       ("text", ["--batch-text"])):
+        out = str(tmp_path / tag)
+        r = subprocess.run(base + extra + ["-o", out, str(d)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        outs[tag] = out
+    ref = outs["file_by_file"]
+    for tag in ("batches", "pairs", "one_mib", "text"):
+        assert sorted(os.listdir(outs[tag])) == sorted(os.listdir(ref)), tag
+        for f in sorted(os.listdir(ref)):
+            if f == "cofiles.stat":
+                assert parse_stat(os.path.join(outs[tag], f)) == parse_stat(os.path.join(ref, f)), tag
+            else:
+                assert filecmp.cmp(os.path.join(outs[tag], f), os.path.join(ref, f), shallow=False), (tag, f)
+    st, names = parse_stat(os.path.join(ref, "cofiles.stat"))
+    assert st["infile_num"] == 14 and sum(st["ctx_ct"]) > 50
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shuf,flags", [("L3K11", ["-A"]), ("L2K11", ["-A"]), ("L3K10", ["-n", "2", "-Q", "50"]), ("L1K7", ["-A"])])
 def test_product_cli_packed_rows_equal_text_rows(shuf, flags, shuf_files, tmp_path):
     """the command line frames FASTQ reads of up to 152 bases as 64-byte packed rows where the geometry has a tuned kernel (the default)

@@ -557,3 +557,91 @@ def test_pack_rows_host_matches_the_layout(no_avx2):
     long_rows[153] = 10
     with pytest.raises(capi.MkError):
         capi.pack_rows_host(long_rows, stride)
+
+
+def _fasta_stream_model(text):
+    """the base stream of a FASTA text (iseq2comem.c:240-279 as mk_fasta_window / the device walk keep it): line ends dropped, a '>'
+    line reduced to its '>'; -> (stream bytes, ends inside a header)"""
+    out = bytearray()
+    hdr = False
+    for ch in text:
+        if hdr:
+            if ch == 10:
+                hdr = False
+            continue
+        if ch in (10, 13):
+            continue
+        if ch == 62:
+            hdr = True
+        out.append(ch)
+    return bytes(out), hdr
+
+
+def _rough_fasta(rs, n_contigs, approx_len, width=70, crlf=False, rough=True):
+    parts = []
+    for c in range(n_contigs):
+        parts.append(b">contig_%d some description > with a second angle\n" % c if rough else b">c%d\n" % c)
+        n = int(rs.randint(approx_len // 2, approx_len + 1))
+        seq = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, n)].copy()
+        if rough and n:
+            seq[rs.randint(0, n, n // 200 + 1)] = ord("N")
+            lo = int(rs.randint(0, n))
+            seq[lo:lo + 37] |= 0x20  # lower case
+            if n > 500:
+                a = int(rs.randint(0, n - 400))
+                seq[a:a + int(rs.randint(1, 300))] = ord("N")
+        w = width if c % 3 else int(rs.randint(1, 200))
+        lines = [bytes(seq[i:i + w]) for i in range(0, n, w)]
+        if rough and len(lines) > 4:
+            lines.insert(len(lines) // 2, b"")          # an empty line inside a contig
+            lines[1] = lines[1][:5] + b">tail of this line is header\r" + b"X"  # a '>' in the middle of a sequence line
+        parts.append((b"\r\n" if crlf else b"\n").join(lines))
+        parts.append(b"\r\n" if crlf else b"\n")
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("no_avx2", [False, True])
+def test_fasta_pack_rows_is_the_walk_cut_into_rows(no_avx2):
+    """mk_fasta_pack_rows == the reference's walk (modelled above, and mk_fasta_window's rows hold the same stream) cut into rows of 152
+    stream bytes at a distance of 153 - TL, each packed as _pack_model says"""
+    import subprocess
+    import sys
+    if no_avx2:
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__ + "::test_fasta_pack_rows_is_the_walk_cut_into_rows[False]"],
+                           env=dict(os.environ, MK_NO_AVX2="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        return
+    from metakssd_amd import capi
+    rs = np.random.RandomState(17)
+    texts = [b"", b"\n", b">only a header\n", b"ACGT", b"ACGTACGTACGTACGTACGTACGTACGTACGT", b">h\nACGTACGTACGTACGTACGTACGTACGTAC\n>h2\nAC",
+             b"no header at all\nACGTTGCA" * 40, b">x\n" + b"ACGT" * 38 + b"\n", b">x\n" + b"ACGT" * 38, b">x\r\n" + b"ACGTN" * 61 + b"\r\n",
+             _rough_fasta(rs, 3, 900), _rough_fasta(rs, 5, 3000, crlf=True), _rough_fasta(rs, 2, 70000), _rough_fasta(rs, 1, 33000, rough=False),
+             _rough_fasta(rs, 40, 60, width=7), (b">a\n" + b"A" * 32765 + b"\n" + b"C" * 100 + b"\n")]
+    for TL in (4, 14, 20, 22, 32):
+        step = 153 - TL
+        for ti, text in enumerate(texts):
+            stream, hdr = _fasta_stream_model(text)
+            rows, rc = capi.fasta_pack_rows(text, TL)
+            assert rc == (capi.MK_ERR_FORMAT if hdr else capi.MK_OK), (TL, ti)
+            if hdr:
+                continue
+            want_rows = (len(stream) - TL) // step + 1 if len(stream) >= TL else 0
+            assert rows.size == 64 * want_rows, (TL, ti, rows.size // 64, want_rows)
+            assert want_rows <= capi.lib.mk_fasta_pack_bound(len(text), TL)
+            check = range(want_rows) if want_rows < 60 else sorted(set([0, 1, 2, want_rows - 3, want_rows - 2, want_rows - 1] + [int(x) for x in rs.randint(0, want_rows, 40)]))
+            for r in check:
+                seq = stream[r * step: r * step + 152]
+                assert np.array_equal(rows[64 * r: 64 * r + 64], _pack_model(seq)), (TL, ti, r)
+    # a text that ends inside a '>' line: the reference gives up
+    for bad in (b">x\nACGT\n>trailing header", b">"):
+        assert capi.fasta_pack_rows(bad, 20)[1] == capi.MK_ERR_FORMAT
+    # the host walker's rows carry the same stream (pitch-free comparison: concatenate what each row adds)
+    text = _rough_fasta(rs, 4, 5000)
+    stream, _ = _fasta_stream_model(text)
+    TL, stride = 20, 160
+    wrows = capi.fasta_windows(text, TL, stride)
+    got = bytearray()
+    for r in range(wrows.size // stride):
+        row = bytes(wrows[r * stride:(r + 1) * stride]).split(b"\n")[0]
+        got += row if r == 0 else row[TL - 1:]
+    assert bytes(got) == stream
