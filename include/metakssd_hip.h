@@ -197,12 +197,19 @@ int mk_params_packed_ok(const mk_params *p);
 int mk_pack_rows_host(const uint8_t *rows, uint32_t stride, uint64_t nrows, uint8_t *packed /* nrows * MK_PACKED_PITCH bytes */);
 /* A whole FASTA file -> packed rows on the host: the reference's walk (iseq2comem.c:240-279: '\n' and '\r' skipped without a reset,
  * a '>' line skipped and a reset, any other byte that is no base a reset) gives the base stream, which is cut into overlapping rows
- * of MK_PACKED_MAX_BASES stream bytes at a distance of MK_PACKED_MAX_BASES + 1 - TL, so that every TL-byte window starts in exactly
- * one row, in file order: pushed as packed rows with ascending ordinals (or handed to mk_sketch_batch_begin_rows) they give the
- * sketch mk_sketch_push_stream gives for the text.  mk_fasta_pack_bound(n, TL) rows always suffice for n bytes of text.
- * MK_ERR_FORMAT: the text ends inside a '>' line (the reference's abort, :259-271).  `rows` 16-byte aligned.  Host code only. */
-uint64_t mk_fasta_pack_bound(size_t n, int32_t TL);
-int mk_fasta_pack_rows(const uint8_t *text, size_t n, int32_t TL, uint8_t *rows, uint64_t max_rows, uint64_t *nrows);
+ * of CAP stream bytes at a distance of CAP + 1 - TL, so that every TL-byte window starts in exactly one row, in file order.
+ *   format MK_ROWS_PACKED: CAP = MK_PACKED_MAX_BASES; the rows of the push calls (pushed with ascending ordinals they give the sketch
+ *                          mk_sketch_push_stream gives for the text).
+ *   format MK_ROWS_WIDE:   CAP = MK_WIDE_MAX_BASES (240) in the same 64 bytes: dword 0 = bases | every base valid << 16 | an extension
+ *                          row follows << 17, dwords 1..15 the codes; a row with a byte that is no base is followed by its EXTENSION
+ *                          ROW (dword 0 = 1 << 18, i.e. zero bases; bytes 16..45 = the validity bytes of the row in front).  0.31
+ *                          bytes a base on PCIe.  Taken by mk_sketch_batch_begin_rows only.
+ * mk_fasta_pack_bound(n, TL, format) rows always suffice for n bytes of text.  MK_ERR_FORMAT: the text ends inside a '>' line (the
+ * reference's abort, :259-271).  `rows` 16-byte aligned.  Host code only. */
+#define MK_ROWS_WIDE 0x40000000u
+#define MK_WIDE_MAX_BASES 240u
+uint64_t mk_fasta_pack_bound(size_t n, int32_t TL, uint32_t format);
+int mk_fasta_pack_rows(const uint8_t *text, size_t n, int32_t TL, uint32_t format, uint8_t *rows, uint64_t max_rows, uint64_t *nrows);
 int mk_sketch_push_reads_device(mk_engine *e, const uint8_t *rows_dev, uint32_t stride, uint64_t nreads,
                                 uint64_t first_read_ordinal);
 /* Asynchronous host variant: returns once the copies are queued; `rows` must stay untouched until
@@ -265,14 +272,14 @@ typedef struct mk_batch_result {
   mk_result r;
 } mk_batch_result;
 int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles);
-/* The same for files whose FASTA walk the HOST has done already: files[i].text = the file's PACKED ROWS (mk_fasta_pack_rows below:
- * 64 bytes a row, 16-byte aligned), files[i].n = their bytes.  No text crosses PCIe (0.48 bytes a base instead of 1.01) and no
- * mk_fab_* kernel runs.  When the files' rows lie in ONE stretch of pinned memory (hipHostMalloc / mk_host_register / mk_host_arena_alloc),
- * in ascending order, the scan kernel reads them WHERE THEY LIE, through the mapping -- no copy command at all; every 64-byte row
- * from files[0].text to the end of the last file is then looked at, so rows between two files must be empty (first dword 0).
- * Anywhere else the rows are copied first.  Only for geometries with mk_params_packed_ok().  Results: mk_sketch_batch_end as above
- * (a file the batch's tables cannot take is sketched alone from its rows). */
-int mk_sketch_batch_begin_rows(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles);
+/* The same for files whose FASTA walk the HOST has done already: files[i].text = the file's rows as mk_fasta_pack_rows made them
+ * (format MK_ROWS_PACKED or MK_ROWS_WIDE; 64 bytes a row, 16-byte aligned), files[i].n = their bytes.  No text crosses PCIe (0.48 /
+ * 0.31 bytes a base instead of 1.01) and no mk_fab_* kernel runs.  When the files' rows lie in ONE stretch of pinned memory
+ * (hipHostMalloc / mk_host_register / mk_host_arena_alloc) in ascending order -- with room between them or not -- the scan kernel
+ * reads them WHERE THEY LIE, through the mapping: no copy command at all, and what lies between two files is never touched.  Anywhere
+ * else the rows are copied first.  Only for geometries with mk_params_packed_ok().  Results: mk_sketch_batch_end as above (a file the
+ * batch's tables cannot take is sketched alone from its rows). */
+int mk_sketch_batch_begin_rows(mk_engine *e, int mode, uint32_t format, const mk_batch_file *files, uint32_t nfiles);
 int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out /* [nfiles of the oldest batch] */);
 
 /* pinned host memory for the caller's read batches (hipHostMalloc) */

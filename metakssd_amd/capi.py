@@ -17,6 +17,7 @@ MK_ERR_ARG, MK_ERR_NO_DEVICE, MK_ERR_HIP, MK_ERR_CROWDED = -1, -2, -3, -4
 MK_ERR_STATE, MK_ERR_IO, MK_ERR_FORMAT, MK_ERR_NOMEM = -5, -6, -7, -8
 MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET, MK_MODE_OCC_SET = 0, 1, 2, 3
 MK_ROWS_PACKED, MK_PACKED_PITCH, MK_PACKED_MAX_BASES = 0x80000000, 64, 152
+MK_ROWS_WIDE, MK_WIDE_MAX_BASES = 0x40000000, 240
 MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP, MK_OPT_DIRECT_HOST, MK_OPT_FRONT_BITS, MK_OPT_KEYLIST_CAP, MK_OPT_BATCH_TAB_BITS, MK_OPT_ROWS160 = 1, 2, 3, 4, 5, 6, 7, 8
 
 
@@ -124,8 +125,8 @@ def _load():
         "mk_pack_rows_host": [vp, u32, u64, vp],
         "mk_params_packed_ok": [C.POINTER(ParamsC)],
         "mk_sketch_batch_begin": [vp, C.c_int, vp, u32],
-        "mk_sketch_batch_begin_rows": [vp, C.c_int, vp, u32],
-        "mk_fasta_pack_rows": [vp, C.c_size_t, C.c_int32, vp, u64, C.POINTER(u64)],
+        "mk_sketch_batch_begin_rows": [vp, C.c_int, u32, vp, u32],
+        "mk_fasta_pack_rows": [vp, C.c_size_t, C.c_int32, u32, vp, u64, C.POINTER(u64)],
         "mk_sketch_batch_end": [vp, vp],
         "mk_sketch_finish": [vp, C.POINTER(ResultC)],
         "mk_sketch_finish_begin": [vp],
@@ -193,7 +194,7 @@ def _load():
     lib.mk_setop_stream.restype = vp
     lib.mk_last_error.argtypes = [vp]
     lib.mk_last_error.restype = C.c_char_p
-    lib.mk_fasta_pack_bound.argtypes = [C.c_size_t, C.c_int32]
+    lib.mk_fasta_pack_bound.argtypes = [C.c_size_t, C.c_int32, u32]
     lib.mk_fasta_pack_bound.restype = u64
     return lib
 
@@ -268,14 +269,15 @@ def pack_rows_host(rows, stride):
     return out
 
 
-def fasta_pack_rows(text, TL):
-    """a whole FASTA text -> its packed rows (mk_fasta_pack_rows); -> (rows u8 [nrows * 64], 16-byte aligned, rc)"""
+def fasta_pack_rows(text, TL, fmt=None):
+    """a whole FASTA text -> its packed rows (mk_fasta_pack_rows; fmt MK_ROWS_PACKED or MK_ROWS_WIDE); -> (rows u8 [nrows * 64], 16-byte aligned, rc)"""
+    fmt = MK_ROWS_PACKED if fmt is None else fmt
     b = np.frombuffer(bytes(text), dtype=np.uint8)
-    bound = int(lib.mk_fasta_pack_bound(len(b), TL))
+    bound = int(lib.mk_fasta_pack_bound(len(b), TL, fmt))
     raw = np.zeros(bound * MK_PACKED_PITCH + 64, dtype=np.uint8)
     off = (-raw.ctypes.data) % 64
     n = C.c_uint64(0)
-    rc = lib.mk_fasta_pack_rows(b.ctypes.data if len(b) else None, len(b), TL, raw.ctypes.data + off, bound, C.byref(n))
+    rc = lib.mk_fasta_pack_rows(b.ctypes.data if len(b) else None, len(b), TL, fmt, raw.ctypes.data + off, bound, C.byref(n))
     return raw[off:off + n.value * MK_PACKED_PITCH], rc
 
 
@@ -506,14 +508,14 @@ class Engine:
         self._batches = getattr(self, "_batches", [])
         self._batches.append((keep, len(texts)))
 
-    def batch_begin_rows(self, row_arrays, mode=MK_MODE_SET, pinned=False):
+    def batch_begin_rows(self, row_arrays, mode=MK_MODE_SET, pinned=False, fmt=MK_ROWS_PACKED, gap=MK_PACKED_PITCH):
         """mk_sketch_batch_begin_rows over the files' packed rows (fasta_pack_rows).  pinned: the rows are laid into ONE registered buffer,
-        file behind file with an empty row between them -- the layout the scan kernel reads in place; otherwise separate pageable arrays."""
+        file behind file with `gap` bytes of 0xA5 between them (never looked at) -- the layout the scan kernel reads in place; otherwise separate pageable arrays."""
         n = len(row_arrays)
         files = (BatchFileC * n)()
         if pinned:
-            total = sum(a.size + MK_PACKED_PITCH for a in row_arrays) + 4096
-            raw = np.zeros(total + 4096, dtype=np.uint8)
+            total = sum(a.size + gap for a in row_arrays) + 4096
+            raw = np.full(total + 4096, 0xA5, dtype=np.uint8)
             off = (-raw.ctypes.data) % 4096
             buf = raw[off:off + total]
             at = 0
@@ -521,7 +523,7 @@ class Engine:
                 buf[at:at + a.size] = a
                 files[i].text = buf.ctypes.data + at
                 files[i].n = a.size
-                at += a.size + MK_PACKED_PITCH
+                at += a.size + gap
             _check(lib.mk_host_register(buf.ctypes.data, total))
             keep = ("registered", raw, buf.ctypes.data)
         else:
@@ -534,7 +536,7 @@ class Engine:
                 files[i].text = (raw.ctypes.data + off) if a.size else None
                 files[i].n = a.size
             keep = arrs
-        _check(lib.mk_sketch_batch_begin_rows(self.h, mode, C.cast(files, C.c_void_p), n), self.h)
+        _check(lib.mk_sketch_batch_begin_rows(self.h, mode, fmt, C.cast(files, C.c_void_p), n), self.h)
         self._batches = getattr(self, "_batches", [])
         self._batches.append((keep, n))
 

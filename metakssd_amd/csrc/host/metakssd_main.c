@@ -364,7 +364,7 @@ static void *touch_run(void *arg) {
   for (size_t off = 0; off < j->n; off += 4096) j->p[off] = 0;
   return NULL;
 }
-static uint8_t *arena_map_unpinned(size_t bytes, size_t *len_out) {
+static uint8_t *arena_map_untouched(size_t bytes, size_t *len_out) {
   const size_t huge = (size_t)2 << 20;
   const size_t len = (bytes + huge - 1) & ~(huge - 1);
   uint8_t *m = mmap(NULL, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
@@ -372,6 +372,13 @@ static uint8_t *arena_map_unpinned(size_t bytes, size_t *len_out) {
 #ifdef MADV_HUGEPAGE
   (void)madvise(m, len, MADV_HUGEPAGE);
 #endif
+  *len_out = len;
+  return m;
+}
+static uint8_t *arena_map_unpinned(size_t bytes, size_t *len_out) {
+  size_t len = 0;
+  uint8_t *m = arena_map_untouched(bytes, &len);
+  if (!m) return NULL;
   enum { T = 8 };
   touch_job job[T];
   pthread_t th[T];
@@ -1815,10 +1822,12 @@ static void *extra_engines_run(void *arg) {
  * A file that cannot go that way (FASTQ, compressed, a pipe, larger than BATCH_FILE_MAX) is sketched alone, in its place in the
  * input order.  --no-batch gives the file-by-file driver. */
 #define BATCH_FILE_MAX ((size_t)32 << 20)
-#define BATCH_BUFS 4
+#define BATCH_BUFS 4      /* buffers of text batches; packed rows: as many as 2 GiB hold, BATCH_BUFS_MAX at most */
+#define BATCH_BUFS_MAX 64
 static int g_no_batch = 0;
 static size_t g_batch_bytes = (size_t)128 << 20; /* --batch-mib: text per batch */
 static int g_batch_files = 256;                  /* --batch-files */
+static int g_batch_narrow = 0;                   /* --batch-narrow: rows of 152 bases (the FASTQ rows) instead of wide rows of 240 */
 static int g_batch_text = 0;                     /* --batch-text: the files' TEXT goes to the device (which then does the FASTA walk too) */
 
 typedef struct { int first, n, batch; } bjob;    /* files [first, first + n); batch: its number among the batches, -1 = one file alone */
@@ -1826,13 +1835,16 @@ typedef struct {
   strlist *files;
   const uint64_t *fsize;
   bjob *jobs; int njobs;
-  uint8_t *buf[BATCH_BUFS]; size_t bufcap;
+  uint8_t *buf[BATCH_BUFS_MAX]; size_t bufcap; int nbufs;
   uint64_t *foff;               /* offset of every file inside its batch's buffer */
+  uint32_t rows_format;         /* MK_ROWS_PACKED / MK_ROWS_WIDE */
   int rows_TL;                  /* != 0: the readers do the FASTA walk and leave PACKED ROWS in the buffer (mk_fasta_pack_rows) ... */
   uint64_t *slot_rows, *nrows;  /* ... per file: rows its place in the buffer holds / rows it got */
+  uint8_t **priv;               /* ... per file: rows that did not fit its place (wide rows: more extension rows than the place allows for) */
   int *left;                    /* per job: files not read yet */
   int *failed;                  /* per file: errno of a failed read */
   int released;                 /* batches whose buffer has been handed back */
+  double cpu_read, cpu_pack, cpu_blocked; /* summed over the readers: seconds in pread(), in mk_fasta_pack_rows(), waiting for a free buffer */
   int next_job, next_file;      /* reader cursor */
   pthread_mutex_t mu;
   pthread_cond_t cv_ready, cv_free;
@@ -1848,10 +1860,14 @@ static void *breader_run(void *arg) {
     if (r->next_job >= r->njobs) { pthread_mutex_unlock(&r->mu); free(txt); return NULL; }
     const int j = r->next_job, k = r->next_file++;
     const bjob *job = &r->jobs[j];
-    while (job->batch - r->released >= BATCH_BUFS) pthread_cond_wait(&r->cv_free, &r->mu); /* its buffer still belongs to an older batch */
+    const double tb0 = now_s();
+    while (job->batch - r->released >= r->nbufs) pthread_cond_wait(&r->cv_free, &r->mu); /* its buffer still belongs to an older batch */
+    r->cpu_blocked += now_s() - tb0;
     pthread_mutex_unlock(&r->mu);
+    const double tr0 = now_s();
+    double tr1 = tr0;
     const int i = job->first + k;
-    uint8_t *const place = r->buf[job->batch % BATCH_BUFS] + r->foff[i];
+    uint8_t *const place = r->buf[job->batch % r->nbufs] + r->foff[i];
     uint8_t *dst = place;
     int err = 0;
     if (r->rows_TL) {
@@ -1875,19 +1891,26 @@ static void *breader_run(void *arg) {
       }
       close(fd);
     }
+    tr1 = now_s();
     if (r->rows_TL && !err) {
-      /* the walk and the packing here, on this thread; what the file leaves free of its place stays EMPTY rows (the scan kernel reads
-       * the whole stretch where it lies) */
+      /* the walk and the packing here, on this thread (what the file leaves free of its place is never looked at) */
       uint64_t got_rows = 0;
-      const int prc = mk_fasta_pack_rows(txt, (size_t)r->fsize[i], r->rows_TL, place, r->slot_rows[i], &got_rows);
+      int prc = mk_fasta_pack_rows(txt, (size_t)r->fsize[i], r->rows_TL, r->rows_format, place, r->slot_rows[i], &got_rows);
+      if (prc == MK_ERR_ARG) { /* more rows than its place holds: into memory of its own (the batch's rows are then copied to the device) */
+        const uint64_t full = mk_fasta_pack_bound((size_t)r->fsize[i], r->rows_TL, r->rows_format);
+        void *own = NULL;
+        if (posix_memalign(&own, 64, (size_t)(full ? full : 1) * MK_PACKED_PITCH) != 0) { prc = MK_ERR_NOMEM; }
+        else {
+          prc = mk_fasta_pack_rows(txt, (size_t)r->fsize[i], r->rows_TL, r->rows_format, own, full, &got_rows);
+          if (prc == MK_OK) r->priv[i] = own; else free(own);
+        }
+      }
       if (prc == MK_ERR_FORMAT) err = -MK_ERR_FORMAT + 100000; /* (no errno: the text ends inside a '>' line) */
       else if (prc != MK_OK) err = EIO;
-      else {
-        r->nrows[i] = got_rows;
-        memset(place + got_rows * MK_PACKED_PITCH, 0, (size_t)(r->slot_rows[i] - got_rows) * MK_PACKED_PITCH);
-      }
+      else r->nrows[i] = got_rows;
     }
     pthread_mutex_lock(&r->mu);
+    r->cpu_read += tr1 - tr0; r->cpu_pack += now_s() - tr1;
     r->failed[i] = err;
     if (--r->left[j] == 0) pthread_cond_broadcast(&r->cv_ready);
     pthread_mutex_unlock(&r->mu);
@@ -1941,6 +1964,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--engines") && i + 1 < argc) engines_per_gpu = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--allow-device-copies")) allow_copies = 1;
     else if (!strcmp(argv[i], "--no-batch")) g_no_batch = 1; /* genome directories file by file (the driver of round 3) */
+    else if (!strcmp(argv[i], "--batch-narrow")) g_batch_narrow = 1; /* rows of 152 bases (the FASTQ framers' format) instead of wide rows of 240 */
     else if (!strcmp(argv[i], "--batch-text")) g_batch_text = 1; /* batches of FASTA TEXT (the device walks it) instead of rows packed by the readers */
     else if (!strcmp(argv[i], "--batch-mib") && i + 1 < argc) g_batch_bytes = (size_t)atoi(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--batch-files") && i + 1 < argc) g_batch_files = atoi(argv[++i]);
@@ -2109,7 +2133,7 @@ int main(int argc, char **argv) {
     if (nworkers == 0) { free(pf.slots); pf.slots = NULL; }
   }
 
-  double t_finish = 0, t_batch_wait_read = 0, t_batch_pin = 0, t_batch_begin = 0;
+  double t_finish = 0, t_batch_wait_read = 0, t_batch_pin = 0, t_batch_begin = 0, t_readers_read = 0, t_readers_pack = 0, t_readers_blocked = 0;
   int nbatches_done = 0;
   job_opts jo = {&files, &P, abundance, uniq, first_nonfq, kmerocrs, kmerqlty, nthreads, quiet, &pf, nworkers};
   if (first_nonfq < files.n && abundance) printf("Warning: close abundance mode (-A) since non-fastq file input.\n");
@@ -2121,8 +2145,10 @@ int main(int argc, char **argv) {
     /* the readers do the FASTA walk and pack (0.48 bytes a base cross PCIe instead of 1.01, and the scan kernel reads them where the
      * readers left them) wherever there is a scan kernel for packed rows; --batch-text: the text travels and the device walks it */
     const int batch_rows = !g_batch_text && mk_params_packed_ok(&P);
+    const uint32_t rows_format = g_batch_narrow ? MK_ROWS_PACKED : MK_ROWS_WIDE;
     uint64_t *slot_rows = calloc((size_t)files.n, sizeof *slot_rows), *nrows_of = calloc((size_t)files.n, sizeof *nrows_of);
-    if (!jobs || !foff || !left || !failed || !slot_rows || !nrows_of) die("out of memory");
+    uint8_t **priv = calloc((size_t)files.n, sizeof *priv);
+    if (!jobs || !foff || !left || !failed || !slot_rows || !nrows_of || !priv) die("out of memory");
     int njobs = 0, nbatches = 0;
     size_t bufcap = 0;
     for (int i = 0; i < files.n;) {
@@ -2132,8 +2158,11 @@ int main(int argc, char **argv) {
       size_t text_at = 0;
       while (i + n < files.n && elig[i + n] && n < g_batch_files && (n == 0 || text_at + fsize[i + n] <= g_batch_bytes)) {
         foff[i + n] = at;
-        if (batch_rows) { /* its place: the rows its text can give at most, and one that stays empty */
-          slot_rows[i + n] = mk_fasta_pack_bound((size_t)fsize[i + n], P.TL) + 1u;
+        if (batch_rows) { /* its place: the rows its text can give at most */
+          /* (wide rows: an extension row for one row in sixteen -- a genome has them at contig ends and runs of N; a file with
+           * more gets memory of its own, breader_run) */
+          const uint64_t full = mk_fasta_pack_bound((size_t)fsize[i + n], P.TL, rows_format);
+          slot_rows[i + n] = rows_format == MK_ROWS_WIDE ? full / 2u + full / 32u + 8u : full;
           at += (size_t)slot_rows[i + n] * MK_PACKED_PITCH;
         } else at += ((size_t)fsize[i + n] + 1023u) & ~(size_t)1023u;
         text_at += ((size_t)fsize[i + n] + 1023u) & ~(size_t)1023u;
@@ -2146,21 +2175,37 @@ int main(int argc, char **argv) {
     breader br;
     memset(&br, 0, sizeof br);
     br.files = &files; br.fsize = fsize; br.jobs = jobs; br.njobs = njobs; br.foff = foff; br.left = left; br.failed = failed;
-    br.rows_TL = batch_rows ? P.TL : 0; br.slot_rows = slot_rows; br.nrows = nrows_of;
+    br.rows_TL = batch_rows ? P.TL : 0; br.rows_format = rows_format; br.slot_rows = slot_rows; br.nrows = nrows_of; br.priv = priv;
     br.bufcap = (bufcap + 4096 + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1); /* whole 2 MiB granules: every buffer is pinned on its own */
     pthread_mutex_init(&br.mu, NULL);
     pthread_cond_init(&br.cv_ready, NULL);
     pthread_cond_init(&br.cv_free, NULL);
     /* the buffers: mapped and touched now, so that the readers can start while the runtime and the engine come up; pinned when the
      * first batch is handed over (see cli_sink_alloc) */
-    const int nbufs = nbatches < BATCH_BUFS ? nbatches : BATCH_BUFS;
+    /* Rows: the readers may run AHEAD by as many batches as 2 GiB of buffers hold -- the 75 ms the runtime and the engine's queue
+     * take to come up are time to walk and pack in (1 024 genomes of 4 Mbases are 2 GB of rows: all of them are packed by then, and
+     * what is left is the link's time); the pages are touched by the readers as they write.  Text: four buffers, touched here. */
+    int want_bufs = BATCH_BUFS;
+    if (batch_rows) {
+      want_bufs = (int)((((size_t)2 << 30) + br.bufcap - 1) / br.bufcap);
+      if (want_bufs < BATCH_BUFS) want_bufs = BATCH_BUFS;
+      if (want_bufs > BATCH_BUFS_MAX) want_bufs = BATCH_BUFS_MAX;
+    }
+    const int nbufs = nbatches < want_bufs ? nbatches : want_bufs;
+    br.nbufs = nbufs;
     size_t arena_len = 0;
-    uint8_t *arena = arena_map_unpinned((size_t)nbufs * br.bufcap, &arena_len);
+    uint8_t *arena = batch_rows && !getenv("MK_BATCH_PRETOUCH") ? arena_map_untouched((size_t)nbufs * br.bufcap, &arena_len) : arena_map_unpinned((size_t)nbufs * br.bufcap, &arena_len);
     (void)arena_len;
     if (!arena) die("out of memory (%zu bytes of batch buffers)", (size_t)nbufs * br.bufcap);
-    for (int b = 0; b < BATCH_BUFS; b++) br.buf[b] = arena + (size_t)(b % nbufs) * br.bufcap;
-    int buf_pinned[BATCH_BUFS] = {0, 0, 0, 0};
+    for (int b = 0; b < nbufs; b++) br.buf[b] = arena + (size_t)b * br.bufcap;
+    int buf_pinned[BATCH_BUFS_MAX];
+    memset(buf_pinned, 0, sizeof buf_pinned);
+    /* (rows: 16 readers by default.  On the 64-core host 1 024 genomes of 4 Mbases took 0.108-0.113 s with 16, 0.114-0.118 with 24,
+     * 0.120-0.132 with 32 and up to 0.23 with 48: 16 pack the directory inside the runtime's start-up (5-6 GB/s of text each), and every
+     * further thread is memory traffic beside that start-up -- the engine is ready at 0.078-0.084 s with 16 readers, 0.088-0.093 with
+     * 24, 0.095-0.107 with 32) */
     int nreaders = nthreads < 1 ? 1 : (nthreads > 64 ? 64 : nthreads);
+    if (batch_rows && !threads_given && nreaders > 16) nreaders = 16;
     pthread_t readers[64];
     int started = 0;
     for (int t = 0; t < nreaders; t++) if (pthread_create(&readers[started], NULL, breader_run, &br) == 0) started++;
@@ -2182,6 +2227,7 @@ int main(int argc, char **argv) {
       if (rc != MK_OK) die("mk_sketch_batch_end failed (%d): %s", rc, mk_last_error(c.eng)); \
       for (int k_ = 0; k_ < bj_->n; k_++) { \
         const char *path_ = files.v[bj_->first + k_]; \
+        if (priv[bj_->first + k_]) { free(priv[bj_->first + k_]); priv[bj_->first + k_] = NULL; } \
         if (bres[k_].status == MK_ERR_CROWDED) die("the context space is too crowd, try rerun the program using -k%d", P.k + 1); \
         if (bres[k_].status == MK_ERR_FORMAT) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", path_); \
         if (bres[k_].status != MK_OK) die("sketching %s failed (%d)", path_, bres[k_].status); \
@@ -2215,13 +2261,14 @@ int main(int argc, char **argv) {
         const int i = bj->first + k;
         if (failed[i] == -MK_ERR_FORMAT + 100000) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", files.v[i]);
         if (failed[i]) die("%s: %s", files.v[i], strerror(failed[i]));
-        bf[k].text = br.buf[bj->batch % BATCH_BUFS] + foff[i];
+        bf[k].text = priv[i] ? priv[i] : br.buf[bj->batch % nbufs] + foff[i];
         bf[k].n = batch_rows ? nrows_of[i] * MK_PACKED_PITCH : fsize[i];
       }
       (void)engine_get(&c);
       const double tp0 = now_s();
-      if (!buf_pinned[bj->batch % nbufs]) { /* the runtime is up now.  Buffer by buffer: pinning takes 30 us per MiB, and only the first
-                                               * buffer's share of that lies in front of the first batch */
+      if (!buf_pinned[bj->batch % nbufs]) { /* the runtime is up now.  Buffer by buffer: only the first buffer's pinning lies in front
+                                               * of the first batch, every other buffer is pinned behind the begin of the batch in front
+                                               * of it (below), while the device works */
         if (mk_host_register(br.buf[bj->batch % nbufs], br.bufcap) != MK_OK) die("pinning the batch buffers failed: %s", mk_last_error(NULL));
         buf_pinned[bj->batch % nbufs] = 1;
       }
@@ -2230,7 +2277,7 @@ int main(int argc, char **argv) {
       if (c.t_first_push == 0) c.t_first_push = now_s() - g_t0;
       {
         const double tb = now_s();
-        rc = batch_rows ? mk_sketch_batch_begin_rows(c.eng, mode, bf, (uint32_t)bj->n) : mk_sketch_batch_begin(c.eng, mode, bf, (uint32_t)bj->n);
+        rc = batch_rows ? mk_sketch_batch_begin_rows(c.eng, mode, rows_format, bf, (uint32_t)bj->n) : mk_sketch_batch_begin(c.eng, mode, bf, (uint32_t)bj->n);
         t_batch_begin += now_s() - tb;
         nbatches_done++;
         if (btrace) fprintf(stderr, "[batch %d] begin: called %.3f returned %.3f ms\n", bj->batch, (tb - g_t0) * 1e3, (now_s() - g_t0) * 1e3);
@@ -2238,10 +2285,17 @@ int main(int argc, char **argv) {
       if (rc != MK_OK) die("mk_sketch_batch_begin failed (%d): %s", rc, mk_last_error(c.eng));
       c.t_last_push = now_s() - g_t0;
       fly[nfly++] = j;
+      if (bj->batch + 1 < nbatches && !buf_pinned[(bj->batch + 1) % nbufs]) { /* the next batch's buffer, beside this batch's kernels */
+        const double tp1 = now_s();
+        if (mk_host_register(br.buf[(bj->batch + 1) % nbufs], br.bufcap) != MK_OK) die("pinning the batch buffers failed: %s", mk_last_error(NULL));
+        buf_pinned[(bj->batch + 1) % nbufs] = 1;
+        t_batch_pin += now_s() - tp1;
+      }
     }
     while (nfly) BATCH_END_OLDEST();
     #undef BATCH_END_OLDEST
     for (int t = 0; t < started; t++) pthread_join(readers[t], NULL);
+    t_readers_read = br.cpu_read; t_readers_pack = br.cpu_pack; t_readers_blocked = br.cpu_blocked;
     (void)engine_get(&c);
   } else if (shard_files) {
     /* several engines, whole files each */
@@ -2349,13 +2403,14 @@ int main(int argc, char **argv) {
            "\"written\": %.4f, \"finish_s\": %.4f, \"begin_s\": %.4f, \"rows\": %llu, \"threads\": %u, \"chunks\": %llu, \"chunks_discarded\": %llu, "
            "\"serial_rows\": %llu, \"stream_setup_s\": %.4f, \"stream_wait_frame_s\": %.4f, \"stream_push_s\": %.4f, \"stream_total_s\": %.4f, "
            "\"push_call_s\": %.4f, \"wait_call_s\": %.4f, \"push_call_max_s\": %.4f, \"first_push_call_s\": %.4f, \"gpus\": %d, \"gather_ms\": %.3f, \"tail_ms\": %.3f, \"transport\": \"%s\", "
-           "\"batches\": %d, \"batch_wait_readers_s\": %.4f, \"batch_pin_s\": %.4f, \"batch_begin_s\": %.4f}}\n",
+           "\"batches\": %d, \"batch_wait_readers_s\": %.4f, \"batch_pin_s\": %.4f, \"batch_begin_s\": %.4f, "
+           "\"readers_read_cpu_s\": %.4f, \"readers_pack_cpu_s\": %.4f, \"readers_blocked_s\": %.4f}}\n",
            g_t0, now_s(), t_shuf, fut.t_hip_ready, fut.t_ready, c.t_first_push, c.t_last_push, c.t_unmapped, t_written, t_finish, c.t_begin_s, (unsigned long long)c.nrows_total,
            c.fq_stats.threads, (unsigned long long)c.fq_stats.chunks, (unsigned long long)c.fq_stats.chunks_discarded,
            (unsigned long long)c.fq_stats.serial_rows, c.fq_stats.t_setup_s, c.fq_stats.t_wait_frame_s, c.fq_stats.t_push_s,
            c.fq_stats.t_total_s, c.fq_stats.t_push_call_s, c.fq_stats.t_wait_call_s, c.fq_stats.t_push_call_max_s,
            c.fq_stats.t_first_push_call_s, c.ndev ? c.ndev : 1, c.gather_ms, c.tail_ms, c.multi ? g_multi.transport(c.multi) : "-",
-           nbatches_done, t_batch_wait_read, t_batch_pin, t_batch_begin);
+           nbatches_done, t_batch_wait_read, t_batch_pin, t_batch_begin, t_readers_read, t_readers_pack, t_readers_blocked);
   if (stage2_after) {
     if (c.rows) mk_host_free(c.rows);
     free(c.io);

@@ -155,6 +155,77 @@ static inline void mk_row_pack(uint8_t *row, const uint8_t *src, size_t nb, size
   memcpy(row, out, 64);
 }
 
+/* ---- WIDE packed rows (MK_ROWS_WIDE): 240 bases in the same 64 bytes -- the codes take dwords 1..15, and the validity bits, which
+ * nearly no row of a genome needs, live in an EXTENSION ROW behind the rows that do: dword 0 = bases | every base valid << 16 | an
+ * extension row follows << 17; the extension row has dword 0 = 1 << 18 (zero bases: as a row it is empty) and the validity bytes of
+ * the row in front of it at bytes 16..45.  Made by mk_fasta_pack_rows, taken by mk_sketch_batch_begin_rows only. */
+#if defined(__x86_64__) && defined(__GNUC__)
+/* the whole row in one AVX2 function, as mk_row_pack_avx2: eight blocks of 32 bases, row and extension row built in locals and
+ * written out with streaming stores; returns the rows written */
+__attribute__((target("avx2"))) static unsigned mk_wide_pack_avx2(uint8_t *row, const uint8_t *src, size_t nb, size_t avail) {
+  uint32_t out[32] __attribute__((aligned(32)));
+  memset(out, 0, sizeof out);
+  uint32_t vv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const __m256i three = _mm256_set1_epi8(3), fold = _mm256_set1_epi8((char)0xDF), ones = _mm256_set1_epi16(1);
+  const __m256i lut = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+  const __m256i w = _mm256_setr_epi8(64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1, 64, 16, 4, 1);
+  const __m256i gather = _mm256_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+  uint32_t bad = 0;
+  for (size_t at = 0, k = 0; at < nb; at += 32u, k++) {
+    const uint32_t n = nb - at < 32u ? (uint32_t)(nb - at) : 32u;
+    __m256i b;
+    if (at + 32u <= avail) b = _mm256_loadu_si256((const __m256i *)(src + at));
+    else { uint8_t tmp[32] __attribute__((aligned(32))) = {0}; memcpy(tmp, src + at, n); b = _mm256_load_si256((const __m256i *)tmp); }
+    const __m256i codes = _mm256_and_si256(_mm256_srli_epi16(b, 1), three);
+    __m256i ok = _mm256_cmpeq_epi8(_mm256_and_si256(b, fold), _mm256_shuffle_epi8(lut, codes));
+    ok = _mm256_and_si256(ok, _mm256_loadu_si256((const __m256i *)(mk_pack_lanes + 32u - n))); /* bytes behind the row do not count */
+    const uint32_t v = (uint32_t)_mm256_movemask_epi8(ok);
+    const __m256i q = _mm256_madd_epi16(_mm256_maddubs_epi16(_mm256_and_si256(codes, ok), w), ones);
+    const __m256i g = _mm256_shuffle_epi8(q, gather);
+    out[1 + 2 * k] = (uint32_t)_mm256_extract_epi32(g, 0);
+    if (2 * k + 2 < 16) out[2 + 2 * k] = (uint32_t)_mm256_extract_epi32(g, 4); /* (bases 240..255 do not exist) */
+    vv[k] = v;
+    bad |= v ^ (n == 32u ? 0xFFFFFFFFu : (1u << n) - 1u);
+  }
+  const uint32_t allvalid = bad == 0u;
+  out[0] = (uint32_t)nb | (allvalid << 16) | ((allvalid ^ 1u) << 17);
+  /* ordinary stores: streaming stores made this 3 x slower on an EPYC 9575F (115 ns a row against 36: scratch measurement with the
+   * three store forms), where they help the narrow rows' packer */
+  _mm256_store_si256((__m256i *)row, _mm256_load_si256((const __m256i *)out));
+  _mm256_store_si256((__m256i *)(row + 32), _mm256_load_si256((const __m256i *)(out + 8)));
+  if (allvalid) return 1u;
+  /* the extension row: dword 0 = 1 << 18, the validity bytes at 16..45 */
+  _mm256_store_si256((__m256i *)(row + 64), _mm256_setr_epi32(1 << 18, 0, 0, 0, (int)vv[0], (int)vv[1], (int)vv[2], (int)vv[3]));
+  _mm256_store_si256((__m256i *)(row + 96), _mm256_setr_epi32((int)vv[4], (int)vv[5], (int)vv[6], (int)vv[7], 0, 0, 0, 0));
+  return 2u;
+}
+#endif
+/* nb <= 240 bases at src -> one wide row, or a wide row and its extension row; returns the rows written (row: 32-byte aligned for the
+ * vector form's stores, else the scalar form) */
+static inline unsigned mk_wide_pack(uint8_t *row, const uint8_t *src, size_t nb, size_t avail) {
+#if defined(__x86_64__) && defined(__GNUC__)
+  if (mk_have_avx2() && ((uintptr_t)row & 31u) == 0) return mk_wide_pack_avx2(row, src, nb, avail);
+#endif
+  (void)avail;
+  uint32_t out[32] __attribute__((aligned(16)));
+  memset(out, 0, sizeof out);
+  unsigned allvalid = 1;
+  uint8_t *vb = (uint8_t *)out + 64 + 16;
+  for (size_t at = 0; at < nb; at += 32u) {
+    const uint32_t n = nb - at < 32u ? (uint32_t)(nb - at) : 32u;
+    uint32_t c2[2], v;
+    mk_pack_block_scalar(src + at, n, c2, &v);
+    out[1 + at / 16u] = c2[0];
+    if (at + 16u < nb) out[2 + at / 16u] = c2[1];
+    memcpy(vb + at / 8u, &v, (n + 7u) / 8u);
+    if (v != (n == 32u ? 0xFFFFFFFFu : (1u << n) - 1u)) allvalid = 0;
+  }
+  out[0] = (uint32_t)nb | (allvalid << 16) | ((allvalid ^ 1u) << 17);
+  out[16] = 1u << 18;
+  memcpy(row, out, allvalid ? 64u : 128u);
+  return allvalid ? 1u : 2u;
+}
+
 int mk_params_packed_ok(const mk_params *p) {
   /* the geometries with a tuned scan kernel: their loop takes eight bases in 16 bits (mk_engine.hip) */
   return p && ((p->subk == 6 && p->k >= 9 && p->k <= 11) || (p->subk == 5 && p->k == 11));
@@ -620,14 +691,15 @@ int mk_fastq_frame_mt(const uint8_t *buf, size_t n, int final, int occ, int32_t 
 /* ---- a whole FASTA file -> packed rows (MK_ROWS_PACKED), on the reader's thread -------------------------------------------------
  * The same base stream as mk_fasta_window / the device's mk_fa_* kernels make (kept: every byte that is neither '\n' nor '\r' nor
  * inside a '>' line; a '>' line leaves its '>' as ONE byte, which is no base and so resets the window: iseq2comem.c:240-279), cut
- * into overlapping rows of 152 stream bytes at a distance of 153 - TL: every TL-byte window of the stream starts in exactly one
- * row, in file order.  Two vector passes over pieces that stay in the cache: (1) text -> stream, 32 bytes a step up to the next
- * '\n' / '\r' / '>'; (2) stream -> rows with the FASTQ framers' packer.  A genome of 4 Mbases crosses PCIe as 1.9 MB this way
- * instead of 4.06 MB of text. */
-uint64_t mk_fasta_pack_bound(size_t n, int32_t TL) {
-  if (TL < 2 || TL > 32) return 0;
-  const size_t step = MK_PACKED_MAX_BASES + 1u - (size_t)TL;
-  return n < (size_t)TL ? 0 : (n - (size_t)TL) / step + 1u; /* the stream is no longer than the text */
+ * into overlapping rows of 152 (MK_ROWS_PACKED) or 240 (MK_ROWS_WIDE) stream bytes at a distance of that + 1 - TL: every TL-byte
+ * window of the stream starts in exactly one row, in file order.  Two vector passes over pieces that stay in the cache: (1) text -> stream, 32 bytes a step up to the next
+ * '\n' / '\r' / '>'; (2) stream -> rows with the FASTQ framers' packer.  A genome of 4 Mbases crosses PCIe as 1.9 MB
+ * (wide rows: 1.2 MB) this way instead of 4.06 MB of text. */
+uint64_t mk_fasta_pack_bound(size_t n, int32_t TL, uint32_t format) {
+  if (TL < 2 || TL > 32 || (format != MK_ROWS_PACKED && format != MK_ROWS_WIDE)) return 0;
+  const size_t cap = format == MK_ROWS_WIDE ? MK_WIDE_MAX_BASES : MK_PACKED_MAX_BASES, step = cap + 1u - (size_t)TL;
+  const uint64_t rows = n < (size_t)TL ? 0 : (n - (size_t)TL) / step + 1u; /* the stream is no longer than the text */
+  return format == MK_ROWS_WIDE ? 2u * rows : rows;                      /* (every wide row may have an extension row) */
 }
 
 /* stream bytes of text[0, n) to out (room: n + 32 bytes); *hdr: inside a '>' line (in: at text[0]; out: behind text[n-1]) */
@@ -672,11 +744,13 @@ __attribute__((target("avx2"))) static size_t mk_fasta_keep_avx2(const uint8_t *
 }
 #endif
 
-int mk_fasta_pack_rows(const uint8_t *text, size_t n, int32_t TL, uint8_t *rows, uint64_t max_rows, uint64_t *nrows) {
+int mk_fasta_pack_rows(const uint8_t *text, size_t n, int32_t TL, uint32_t format, uint8_t *rows, uint64_t max_rows, uint64_t *nrows) {
   if ((!text && n) || !nrows || TL < 2 || TL > 32 || (!rows && max_rows) || ((uintptr_t)rows & 15u)) return MK_ERR_ARG;
+  if (format != MK_ROWS_PACKED && format != MK_ROWS_WIDE) return MK_ERR_ARG;
   enum { PIECE = 32768 };
-  uint8_t sbuf[PIECE + MK_PACKED_MAX_BASES + 64] __attribute__((aligned(64)));
-  const size_t step = MK_PACKED_MAX_BASES + 1u - (size_t)TL;
+  uint8_t sbuf[PIECE + MK_WIDE_MAX_BASES + 64] __attribute__((aligned(64)));
+  const int wide = format == MK_ROWS_WIDE;
+  const size_t cap = wide ? MK_WIDE_MAX_BASES : MK_PACKED_MAX_BASES, step = cap + 1u - (size_t)TL;
   size_t fill = 0;
   uint64_t r = 0;
   int hdr = 0;
@@ -689,18 +763,20 @@ int mk_fasta_pack_rows(const uint8_t *text, size_t n, int32_t TL, uint8_t *rows,
 #endif
       fill += mk_fasta_keep_scalar(text + at, m, sbuf + fill, &hdr);
     size_t s = 0;
-    for (; fill - s >= MK_PACKED_MAX_BASES; s += step) {
-      if (r == max_rows) return MK_ERR_ARG;
-      mk_row_pack(rows + r++ * (uint64_t)MK_PACKED_PITCH, sbuf + s, MK_PACKED_MAX_BASES, fill - s + 32u);
+    for (; fill - s >= cap; s += step) {
+      if (r + (wide ? 2u : 1u) > max_rows) return MK_ERR_ARG;
+      if (wide) r += mk_wide_pack(rows + r * (uint64_t)MK_PACKED_PITCH, sbuf + s, cap, fill - s + 32u);
+      else mk_row_pack(rows + r++ * (uint64_t)MK_PACKED_PITCH, sbuf + s, cap, fill - s + 32u);
     }
     memmove(sbuf, sbuf + s, fill - s);
     fill -= s;
   }
   if (hdr) return MK_ERR_FORMAT; /* the text ends inside a '>' line: the reference gives up (iseq2comem.c:259-271) */
   if (fill >= (size_t)TL) { /* what is left holds a whole window: one shorter row */
-    if (r == max_rows) return MK_ERR_ARG;
+    if (r + (wide ? 2u : 1u) > max_rows) return MK_ERR_ARG;
     memset(sbuf + fill, 0, 32);
-    mk_row_pack(rows + r++ * (uint64_t)MK_PACKED_PITCH, sbuf, fill, fill + 32u);
+    if (wide) r += mk_wide_pack(rows + r * (uint64_t)MK_PACKED_PITCH, sbuf, fill, fill + 32u);
+    else mk_row_pack(rows + r++ * (uint64_t)MK_PACKED_PITCH, sbuf, fill, fill + 32u);
   }
   mk_rows_done();
   *nrows = r;

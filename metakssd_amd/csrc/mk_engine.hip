@@ -822,8 +822,9 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
                              const unsigned long long *nreads_dev, uint64_t first_ord) {
   if (nreads == 0) return MK_OK;
   if (nreads >= (1ull << 31)) return mk_fail(e, MK_ERR_ARG, "scan launch of %llu reads: the caller splits pushes below 2^31", (unsigned long long)nreads);
-  const bool packed = (stride & MK_ROWS_PACKED) != 0; /* 64-byte packed rows: mk_scan_packed_kernel, no column blocks, no LDS tiles */
-  if (packed) { stride &= ~MK_ROWS_PACKED; pitch = stride; }
+  const bool wide = (stride & MK_ROWS_WIDE) != 0;     /* wide packed rows (batches of rows only): 240 bases in the 64 bytes */
+  const bool packed = (stride & (MK_ROWS_PACKED | MK_ROWS_WIDE)) != 0; /* 64-byte packed rows: mk_scan_packed_kernel, no column blocks, no LDS tiles */
+  if (packed) { stride &= ~(MK_ROWS_PACKED | MK_ROWS_WIDE); pitch = stride; }
   mk_scan_args a{};
   a.rows = rows_dev; a.nreads = nreads; a.first_ord = first_ord; a.stride = stride;
   a.pitch = pitch; a.rowlen = rowlen; a.nreads_dev = nreads_dev;
@@ -906,7 +907,12 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
       hipLaunchKernelGGL(kern, grid, dim3(1024), lds, e->stream, a);
       return hipGetLastError();
     };
-    if (packed) switch (tuned_k * 10 + e->P.subk) {
+    if (wide) switch (tuned_k * 10 + e->P.subk) {
+      case 116: r = launch_packed(mk_scan_packed_kernel<11, 6, true>); break;
+      case 106: r = launch_packed(mk_scan_packed_kernel<10, 6, true>); break;
+      case 96: r = launch_packed(mk_scan_packed_kernel<9, 6, true>); break;
+      default: r = launch_packed(mk_scan_packed_kernel<11, 5, true>); break;
+    } else if (packed) switch (tuned_k * 10 + e->P.subk) {
       case 116: r = launch_packed(mk_scan_packed_kernel<11, 6>); break;
       case 106: r = launch_packed(mk_scan_packed_kernel<10, 6>); break;
       case 96: r = launch_packed(mk_scan_packed_kernel<9, 6>); break;
@@ -1800,6 +1806,9 @@ struct mk_bctx {
   uint32_t nfiles = 0;
   size_t stat_bytes = 0;
   bool rows = false;     /* the files are packed rows (mk_sketch_batch_begin_rows) */
+  uint32_t format = 0;   /* MK_ROWS_PACKED / MK_ROWS_WIDE then */
+  const uint8_t *rows_src = nullptr; /* where the device reads them: the caller's pinned stretch, or this context's copy */
+  std::vector<uint64_t> row_off;     /* per file: bytes from rows_src to its rows */
   uint64_t spec_ids = 0; /* ids the pinned block holds: written there by the batch's own launch sequence */
   std::vector<mk_batch_file> files;
   std::vector<mk_component> comps;              /* [nfiles * component_num] */
@@ -1855,8 +1864,11 @@ static uint64_t mk_rows_per_launch(const mk_engine *e, uint32_t row_bases, int t
  * no mk_fab_* kernels; where the rows lie in ONE stretch of pinned memory the scan kernel reads them THERE, through the mapping
  * (tools/probe_hostread.hip: a kernel reads registered host memory at 55.5 GB/s, the copy engine moves it at 57.0 and costs 7.7 ms
  * of set-up at the first copy of a process) */
-static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles, const bool rows) {
+static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles, const uint32_t format) {
   if (!e || !files) return MK_ERR_ARG;
+  if (format != 0u && format != MK_ROWS_PACKED && format != MK_ROWS_WIDE) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin_rows: format MK_ROWS_PACKED or MK_ROWS_WIDE");
+  const bool rows = format != 0u;
+  const uint32_t row_bases = format == MK_ROWS_WIDE ? MK_WIDE_MAX_BASES : MK_PACKED_MAX_BASES;
   if (mode != MK_MODE_SET && mode != MK_MODE_UNIQ_SET) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: MK_MODE_SET or MK_MODE_UNIQ_SET");
   if (nfiles < 1 || nfiles > MK_BATCH_MAX_FILES) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: 1 .. %u files", MK_BATCH_MAX_FILES);
   if (e->begun) return mk_fail(e, MK_ERR_STATE, "mk_sketch_batch_begin inside a sketch (between begin and finish)");
@@ -1902,6 +1914,7 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   uint32_t *hrow0 = (uint32_t *)((uint8_t *)hseg0 + mk_up16(((size_t)nfiles + 1) * 4));
   uint64_t toff = 0, soff = 0;
   uint32_t seg = 0;
+  if (rows) c->row_off.assign(nfiles, 0);
   for (uint32_t i = 0; i < nfiles && rows; i++) { /* the files' rows as they lie (one stretch), or side by side */
     mk_bfile &f = hf[i];
     f.text_off = 0; f.text_len = 0; f.seg0 = 0; f.nseg = 0;
@@ -1912,6 +1925,7 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
     f.nrow = (uint32_t)(f.stream_cap / MK_PACKED_PITCH);
     hseg0[i] = 0;
     hrow0[i] = f.row0;
+    c->row_off[i] = f.stream_off;
   }
   for (uint32_t i = 0; i < nfiles && !rows; i++) {
     mk_bfile &f = hf[i];
@@ -1950,7 +1964,7 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   uint32_t tb = 10;
   {
     /* (bases of the largest file: its text, or its rows' 153 - TL new bases each) */
-    const uint64_t nbases = rows ? nmax / MK_PACKED_PITCH * (MK_PACKED_MAX_BASES + 1u - TL) : nmax;
+    const uint64_t nbases = rows ? nmax / MK_PACKED_PITCH * (row_bases + 1u - TL) : nmax;
     const uint64_t est = (nbases >> (4u * (uint32_t)e->P.drlevel)) * 5u;
     while (tb < 22u && (1ull << tb) < est) tb++;
     if (e->batch_tb_opt) tb = (uint32_t)e->batch_tb_opt;
@@ -2014,7 +2028,7 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
     hb->shift = shift; hb->bpc = bpc; hb->bpf = bpf;
   }
   c->hb = *hb;
-  c->mode = mode; c->nfiles = nfiles; c->rows = rows;
+  c->mode = mode; c->nfiles = nfiles; c->rows = rows; c->format = format; c->rows_src = rows ? (rows_dev ? rows_dev : (const uint8_t *)c->stream.p) : nullptr;
   c->files.assign(files, files + nfiles);
   const mk_batch_dev *dbatch = (const mk_batch_dev *)dd;
   hipStream_t s = e->stream;
@@ -2060,13 +2074,13 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   MK_HIP(e, hipGetLastError());
   {
     const int tuned = (e->P.subk == 6 && e->P.k >= 9 && e->P.k <= 11) ? 6 : (e->P.subk == 5 && e->P.k == 11) ? 5 : 0;
-    const uint64_t per = mk_rows_per_launch(e, rows ? MK_PACKED_MAX_BASES : rowlen, tuned);
+    const uint64_t per = mk_rows_per_launch(e, rows ? row_bases : rowlen, tuned);
     const uint8_t *src = rows_dev ? rows_dev : (const uint8_t *)c->stream.p;
     e->cur_batch = dbatch;
     for (uint64_t done = 0; done < total_rows && rc == MK_OK; done += per) {
       const uint64_t n = total_rows - done < per ? total_rows - done : per;
       /* (ordinals are rows of the batch: first_ord = the first row of the launch) */
-      if (rows) rc = mk_launch_scan_ex(e, src + done * MK_PACKED_PITCH, MK_PACKED_PITCH | MK_ROWS_PACKED, MK_PACKED_PITCH | MK_ROWS_PACKED, 0u, n, nullptr, done);
+      if (rows) rc = mk_launch_scan_ex(e, src + done * MK_PACKED_PITCH, MK_PACKED_PITCH | format, MK_PACKED_PITCH | format, 0u, n, nullptr, done);
       else rc = mk_launch_scan_ex(e, src + done * pitch, width, pitch, rowlen, n, nullptr, done);
     }
     e->cur_batch = nullptr;
@@ -2100,8 +2114,11 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   return MK_OK;
 }
 
-extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles) { return mk_batch_begin_impl(e, mode, files, nfiles, false); }
-extern "C" int mk_sketch_batch_begin_rows(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles) { return mk_batch_begin_impl(e, mode, files, nfiles, true); }
+extern "C" int mk_sketch_batch_begin(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles) { return mk_batch_begin_impl(e, mode, files, nfiles, 0u); }
+extern "C" int mk_sketch_batch_begin_rows(mk_engine *e, int mode, uint32_t format, const mk_batch_file *files, uint32_t nfiles) {
+  if (format != MK_ROWS_PACKED && format != MK_ROWS_WIDE) return e ? mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin_rows: format MK_ROWS_PACKED or MK_ROWS_WIDE") : MK_ERR_ARG;
+  return mk_batch_begin_impl(e, mode, files, nfiles, format);
+}
 
 extern "C" int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out) {
   if (!e || !out) return MK_ERR_ARG;
@@ -2143,8 +2160,13 @@ extern "C" int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out) {
     out[i].alone = 1;
     mk_result r;
     rc = mk_sketch_begin(e, c->mode);
-    if (rc == MK_OK) rc = c->rows ? mk_sketch_push_reads(e, c->files[i].text, MK_PACKED_PITCH | MK_ROWS_PACKED, c->files[i].n / MK_PACKED_PITCH, 0)
-                                  : mk_sketch_push_stream(e, c->files[i].text, c->files[i].n, 1);
+    if (rc == MK_OK && c->rows) { /* its rows where the batch's scan read them (wide rows keep their extension rows beside them there) */
+      const uint64_t nr = c->files[i].n / MK_PACKED_PITCH, per = mk_rows_per_launch(e, c->format == MK_ROWS_WIDE ? MK_WIDE_MAX_BASES : MK_PACKED_MAX_BASES,
+                                                                                 e->P.subk == 6 ? 6 : 5);
+      for (uint64_t done = 0; done < nr && rc == MK_OK; done += per)
+        rc = mk_launch_scan_ex(e, c->rows_src + c->row_off[i] + done * MK_PACKED_PITCH, MK_PACKED_PITCH | c->format, MK_PACKED_PITCH | c->format, 0u,
+                               nr - done < per ? nr - done : per, nullptr, done);
+    } else if (rc == MK_OK) rc = mk_sketch_push_stream(e, c->files[i].text, c->files[i].n, 1);
     if (rc == MK_OK) rc = mk_sketch_finish(e, &r);
     else if (e->begun) { mk_result dummy; (void)mk_sketch_finish(e, &dummy); }
     if (rc == MK_ERR_CROWDED || rc == MK_ERR_FORMAT) { out[i].status = rc; ai++; continue; }

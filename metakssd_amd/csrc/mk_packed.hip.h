@@ -15,6 +15,7 @@
  */
 #pragma once
 #include "mk_kernels.hip.h"
+#include "mk_batch.hip.h"
 
 #include <utility>
 
@@ -78,10 +79,15 @@ __device__ __forceinline__ void mk_unrolled_windows(F &&body, std::integer_seque
   (body(std::integral_constant<uint32_t, P>{}), ...);
 }
 
-template <int K, int SUBK>
+/* WIDE: MK_ROWS_WIDE rows (mk_fasta_pack_rows, mk_frontend.c) -- 240 bases, thirty windows, the codes in dwords 1..15; the validity
+ * bytes of the few rows that have a byte that is no base come from the EXTENSION ROW behind them (bytes 16..45 of the next 64 bytes;
+ * as a row it holds zero bases), every other row's validity is its length.
+ * In a batch (a.batch) a row that lies in no file's range -- what a file left free of its place -- is not loaded at all. */
+template <int K, int SUBK, bool WIDE = false>
 __global__ void __launch_bounds__(1024) mk_scan_packed_kernel(const mk_scan_args a) {
   extern __shared__ __align__(16) uint32_t lds[];
   constexpr uint32_t WAVES = 16u;
+  constexpr uint32_t NWIN = WIDE ? 30u : MK_PACKED_WINDOWS;
   constexpr uint32_t MTW = SUBK == 6 ? MK_ZMASK_WORDS : 0u;
   constexpr uint32_t SH = 2u * (K - SUBK) - 2u;
   constexpr uint32_t D = SUBK == 6 ? (SH - 2u) / 2u : 1u;
@@ -115,7 +121,13 @@ __global__ void __launch_bounds__(1024) mk_scan_packed_kernel(const mk_scan_args
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   auto load_row = [&](uint32_t tile, uint4 (&r)[4]) {
     const uint64_t row = ((uint64_t)tile << 6) + lane;
-    if (row < nreads) {
+    bool there = row < nreads;
+    if (a.batch && there) { /* (wave-uniform test; the search is a dozen loads out of a table of at most 4 KiB, once per tile) */
+      const mk_batch_dev &b = *a.batch;
+      const uint32_t grow = (uint32_t)(a.first_ord + row), f = mk_b_find(b.row0s, b.nfiles, grow);
+      there = grow - b.row0s[f] < b.files[f].nrow;
+    }
+    if (there) {
       const uint4 *p = (const uint4 *)(a.rows + row * MK_PACKED_PITCH_DEV);
       r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3];
     } else { r[0] = zero4; r[1] = zero4; r[2] = zero4; r[3] = zero4; } /* no read: zero bases */
@@ -125,9 +137,26 @@ __global__ void __launch_bounds__(1024) mk_scan_packed_kernel(const mk_scan_args
   for (uint32_t tile = wave_global; tile < ntiles; tile += nwaves) {
     const uint4 r0 = nx[0], r1 = nx[1], r2 = nx[2], r3 = nx[3];
     if (tile + nwaves < ntiles) load_row(tile + nwaves, nx); /* the next tile's rows are on their way while this one is walked */
-    const uint32_t cw[10] = {r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z};
-    const uint32_t vw[5] = {r2.w, r3.x, r3.y, r3.z, r3.w};
+    const uint32_t cw[15] = {r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w}; /* (narrow rows: ten of them) */
     const uint32_t nb = r0.x & 0xFFFFu;
+    /* validity bytes, four windows a dword: narrow rows carry them; a wide row has them in its extension row, or needs none */
+    uint32_t vw[8] = {r2.w, r3.x, r3.y, r3.z, r3.w, 0u, 0u, 0u};
+    if constexpr (WIDE) {
+      const bool ext = (r0.x & 0x20000u) != 0u;
+      uint4 e0 = zero4, e1 = zero4;
+      if (ext) {
+        const uint4 *p = (const uint4 *)(a.rows + (((uint64_t)tile << 6) + lane + 1u) * MK_PACKED_PITCH_DEV);
+        e0 = p[1]; e1 = p[2];
+      }
+      const uint32_t ev[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+      for (uint32_t q = 0; q < 8u; q++) {
+        /* no extension row: bases 32q .. 32q + 31 are valid as far as the row reaches */
+        const uint32_t have = nb > 32u * q ? nb - 32u * q : 0u;
+        const uint32_t len = have >= 32u ? 0xFFFFFFFFu : (1u << have) - 1u;
+        vw[q] = ext ? ev[q] : len;
+      }
+    }
     const uint32_t nb0 = __builtin_amdgcn_readfirstlane(nb);
     const bool uniform = __all(nb == nb0 && (r0.x & 0x10000u) != 0u);
     const uint32_t rowidx = (tile << 6) + lane;
@@ -154,7 +183,7 @@ __global__ void __launch_bounds__(1024) mk_scan_packed_kernel(const mk_scan_args
     };
     /* the nineteen windows written out (the row's registers are indexed by constants): a window past the longest read is skipped */
     auto for_windows = [&](auto &&body) {
-      mk_unrolled_windows(body, std::make_integer_sequence<uint32_t, MK_PACKED_WINDOWS>{});
+      mk_unrolled_windows(body, std::make_integer_sequence<uint32_t, NWIN>{});
     };
     if (uniform) { /* ---- A: one length, every base valid */
       for_windows([&](auto pc) {

@@ -159,6 +159,10 @@ def test_product_cli_batches_with_files_that_cannot_travel_in_one(shuf, flags, s
     for i in range(14):
         n = [90000, 700, 30000, 250000][i % 4]
         fa = ui.fasta_bytes([ui.rand_seq(rs, n // 2 + 40), ui.rand_seq(rs, n - n // 2)])
+        if i in (6, 7):  # an N in every row the readers pack: wide rows then all have extension rows, more than the file's place in the
+            sq = bytearray(ui.rand_seq(rs, 200000))  # batch buffer allows for -- the rows go to memory of their own (breader_run)
+            sq[::97] = b"N" * len(sq[::97])
+            fa = ui.fasta_bytes([bytes(sq)])
         if i == 4:
             with gzip.open(str(d / ("g%02d.fna.gz" % i)), "wb") as f:
                 f.write(fa)
@@ -169,13 +173,13 @@ def test_product_cli_batches_with_files_that_cannot_travel_in_one(shuf, flags, s
     base = [PRODUCT_CLI, "dist", "-L", shuf_files(shuf)] + flags
     outs = {}
     for tag, extra in (("batches", []), ("file_by_file", ["--no-batch"]), ("pairs", ["--batch-files", "2"]), ("one_mib", ["--batch-mib", "1", "-p", "3"]),
-                       ("text", ["--batch-text"])):
+                       ("text", ["--batch-text"]), ("narrow", ["--batch-narrow"])):
         out = str(tmp_path / tag)
         r = subprocess.run(base + extra + ["-o", out, str(d)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0, r.stderr.decode()
         outs[tag] = out
     ref = outs["file_by_file"]
-    for tag in ("batches", "pairs", "one_mib", "text"):
+    for tag in ("batches", "pairs", "one_mib", "text", "narrow"):
         assert sorted(os.listdir(outs[tag])) == sorted(os.listdir(ref)), tag
         for f in sorted(os.listdir(ref)):
             if f == "cofiles.stat":

@@ -432,12 +432,15 @@ def test_batch_of_files_equals_oracle(capi, engine_for, shufs, oracle_for, name,
     assert_same(eng.finish(), want[0], name + " alone after the batches")
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("uniq", [False, True])
 @pytest.mark.parametrize("name", ["L3K10", "L3K11", "L2K11", "L3K9"])
-def test_batch_of_packed_rows_equals_oracle(capi, engine_for, shufs, oracle_for, name, uniq):
+def test_batch_of_packed_rows_equals_oracle(capi, engine_for, shufs, oracle_for, name, uniq, wide):
     """mk_sketch_batch_begin_rows: the FASTA walk done by the host (mk_fasta_pack_rows), the files' packed rows sketched in one launch
     sequence -- read in place from one registered buffer (no copy command), or copied from separate arrays; every file's sketch is
-    the oracle's fasta2co() / uniq_fasta2co() sketch of its TEXT; batches of rows and of texts in flight together"""
+    the oracle's fasta2co() / uniq_fasta2co() sketch of its TEXT; batches of rows and of texts in flight together.  wide: rows of 240 bases
+    with extension rows (MK_ROWS_WIDE)"""
+    fmt = capi.MK_ROWS_WIDE if wide else capi.MK_ROWS_PACKED
     rs = np.random.RandomState(54)
     texts = _batch_texts(rs, True)
     ora = oracle_for(shufs(name))
@@ -448,11 +451,13 @@ def test_batch_of_packed_rows_equals_oracle(capi, engine_for, shufs, oracle_for,
         rc, w = ora.co_from_fasta(t, uniq=uniq) if t else (0, None)
         assert rc == 0
         want.append(w)
-        r, rc = capi.fasta_pack_rows(t, TL)
+        r, rc = capi.fasta_pack_rows(t, TL, fmt)
         assert rc == 0
         rows.append(r)
     mode = capi.MK_MODE_UNIQ_SET if uniq else capi.MK_MODE_SET
     ncomp = eng.params.component_num
+    if wide:
+        assert any(int(r[:4].view(np.uint32)[0]) & 0x20000 for r in rows if r.size), "no extension row in the inputs"
 
     def check(res, want_, label):
         assert len(res) == len(want_)
@@ -462,13 +467,21 @@ def test_batch_of_packed_rows_equals_oracle(capi, engine_for, shufs, oracle_for,
                 assert all(len(c) == 0 for c in comps) and len(comps) == ncomp
             else:
                 assert_same([(c, None) for c in comps], want_[i], "%s file %d (alone=%d)" % (label, i, alone))
-    for pinned in (True, False):
-        eng.batch_begin_rows(rows, mode, pinned=pinned)
-        check(eng.batch_end(), want, "%s uniq=%s pinned=%s" % (name, uniq, pinned))
-    eng.batch_begin_rows(rows[:4], mode, pinned=True)
+    for pinned, gap in ((True, 64), (True, 4096 + 192), (False, 0)):
+        eng.batch_begin_rows(rows, mode, pinned=pinned, fmt=fmt, gap=gap)
+        check(eng.batch_end(), want, "%s uniq=%s pinned=%s gap=%d" % (name, uniq, pinned, gap))
+    eng.batch_begin_rows(rows[:4], mode, pinned=True, fmt=fmt)
     eng.batch_begin(texts[4:], mode, one_buffer=True)
     check(eng.batch_end(), want[:4], name + " rows, first of two")
     check(eng.batch_end(), want[4:], name + " texts, second of two")
+    if wide:
+        eng.begin(mode)
+        try:
+            with pytest.raises(capi.MkError):                                           # wide rows are for batches only
+                capi._check(capi.lib.mk_sketch_push_reads(eng.h, rows[1].ctypes.data, capi.MK_PACKED_PITCH | capi.MK_ROWS_WIDE, rows[1].size // 64, 0), eng.h)
+        finally:
+            eng.finish()
+        return
     # pushed as ordinary packed rows the same rows give the same sketch
     big = max(range(len(texts)), key=lambda i: len(texts[i]))
     eng.begin(mode)
@@ -476,7 +489,8 @@ def test_batch_of_packed_rows_equals_oracle(capi, engine_for, shufs, oracle_for,
     assert_same(eng.finish(), want[big], name + " the largest file's rows pushed alone")
 
 
-def test_batch_of_packed_rows_small_tables_and_refusals(capi, shufs, oracle_for):
+@pytest.mark.parametrize("wide", [False, True])
+def test_batch_of_packed_rows_small_tables_and_refusals(capi, shufs, oracle_for, wide):
     """512 slots per file: the flagged files are sketched alone FROM THEIR ROWS by mk_sketch_batch_end; geometries without a packed
     scan kernel and rows that are no multiple of 64 bytes are refused"""
     rs = np.random.RandomState(55)
@@ -485,20 +499,24 @@ def test_batch_of_packed_rows_small_tables_and_refusals(capi, shufs, oracle_for)
     eng = capi.Engine(shufs("L2K11"), 0)
     try:
         eng.set_option(capi.MK_OPT_BATCH_TAB_BITS, 9)
-        rows = [capi.fasta_pack_rows(t, 22)[0] for t in texts]
-        eng.batch_begin_rows(rows, capi.MK_MODE_SET, pinned=True)
-        res = eng.batch_end()
-        n_alone = 0
-        for i, (st, alone, comps) in enumerate(res):
-            assert st == 0
-            n_alone += alone
-            if texts[i]:
-                rc, w = ora.co_from_fasta(texts[i])
-                assert rc == 0
-                assert_same([(c, None) for c in comps], w, "file %d (alone=%d)" % (i, alone))
-        assert n_alone >= 3, "the small tables were meant to overflow"
+        fmt = capi.MK_ROWS_WIDE if wide else capi.MK_ROWS_PACKED
+        rows = [capi.fasta_pack_rows(t, 22, fmt)[0] for t in texts]
+        for pinned in (True, False):
+            eng.batch_begin_rows(rows, capi.MK_MODE_SET, pinned=pinned, fmt=fmt)
+            res = eng.batch_end()
+            n_alone = 0
+            for i, (st, alone, comps) in enumerate(res):
+                assert st == 0
+                n_alone += alone
+                if texts[i]:
+                    rc, w = ora.co_from_fasta(texts[i])
+                    assert rc == 0
+                    assert_same([(c, None) for c in comps], w, "file %d (alone=%d, pinned=%s)" % (i, alone, pinned))
+            assert n_alone >= 3, "the small tables were meant to overflow"
         with pytest.raises(capi.MkError):
-            eng.batch_begin_rows([rows[0][:100]], capi.MK_MODE_SET)
+            eng.batch_begin_rows([rows[0][:100]], capi.MK_MODE_SET, fmt=fmt)
+        with pytest.raises(capi.MkError):
+            eng.batch_begin_rows([rows[0]], capi.MK_MODE_SET, fmt=0x10000000)
     finally:
         eng.close()
     eng = capi.Engine(shufs("L1K7"), 0)

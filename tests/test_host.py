@@ -559,6 +559,26 @@ def test_pack_rows_host_matches_the_layout(no_avx2):
         capi.pack_rows_host(long_rows, stride)
 
 
+def _wide_model(seq):
+    """bytes of up to 240 stream bytes -> the wide row (and its extension row when a byte is no base): dword 0 = bases | allvalid << 16 |
+    extension follows << 17, dwords 1..15 codes; extension row: dword 0 = 1 << 18, bytes 16..45 the validity bytes"""
+    out = np.zeros(32, dtype=np.uint32)
+    vb = np.zeros(30, dtype=np.uint8)
+    allv = 1
+    for i, b in enumerate(seq):
+        code = (b >> 1) & 3
+        if (b & 0xDF) == b"ACTG"[code]:
+            out[1 + i // 16] |= np.uint32(code << (30 - 2 * (i % 16)))
+            vb[i // 8] |= np.uint8(1 << (i % 8))
+        else:
+            allv = 0
+    out[0] = len(seq) | (allv << 16) | ((1 - allv) << 17)
+    out[16] = 1 << 18
+    raw = out.view(np.uint8).copy()
+    raw[64 + 16:64 + 46] = vb
+    return raw[:64] if allv else raw
+
+
 def _fasta_stream_model(text):
     """the base stream of a FASTA text (iseq2comem.c:240-279 as mk_fasta_window / the device walk keep it): line ends dropped, a '>'
     line reduced to its '>'; -> (stream bytes, ends inside a header)"""
@@ -627,11 +647,26 @@ def test_fasta_pack_rows_is_the_walk_cut_into_rows(no_avx2):
                 continue
             want_rows = (len(stream) - TL) // step + 1 if len(stream) >= TL else 0
             assert rows.size == 64 * want_rows, (TL, ti, rows.size // 64, want_rows)
-            assert want_rows <= capi.lib.mk_fasta_pack_bound(len(text), TL)
+            assert want_rows <= capi.lib.mk_fasta_pack_bound(len(text), TL, capi.MK_ROWS_PACKED)
             check = range(want_rows) if want_rows < 60 else sorted(set([0, 1, 2, want_rows - 3, want_rows - 2, want_rows - 1] + [int(x) for x in rs.randint(0, want_rows, 40)]))
             for r in check:
                 seq = stream[r * step: r * step + 152]
                 assert np.array_equal(rows[64 * r: 64 * r + 64], _pack_model(seq)), (TL, ti, r)
+            # wide rows: 240 stream bytes at a distance of 241 - TL, an extension row behind every row with a byte that is no base
+            wrows, rc = capi.fasta_pack_rows(text, TL, capi.MK_ROWS_WIDE)
+            assert rc == capi.MK_OK
+            wstep = 241 - TL
+            n_wide = (len(stream) - TL) // wstep + 1 if len(stream) >= TL else 0
+            assert wrows.size // 64 <= capi.lib.mk_fasta_pack_bound(len(text), TL, capi.MK_ROWS_WIDE)
+            at = 0
+            for r in range(n_wide):
+                want = _wide_model(stream[r * wstep: r * wstep + 240]) if (n_wide < 40 or r % 7 == 0 or r >= n_wide - 2) else None
+                hdr0 = int(wrows[at:at + 4].view(np.uint32)[0])
+                nrow = 2 if hdr0 & 0x20000 else 1
+                if want is not None:
+                    assert np.array_equal(wrows[at:at + 64 * nrow], want), (TL, ti, r)
+                at += 64 * nrow
+            assert at == wrows.size, (TL, ti)
     # a text that ends inside a '>' line: the reference gives up
     for bad in (b">x\nACGT\n>trailing header", b">"):
         assert capi.fasta_pack_rows(bad, 20)[1] == capi.MK_ERR_FORMAT

@@ -141,10 +141,26 @@ def main():
                 tb = int(rs.choice([0, 0, 9, 12]))
                 eng.set_option(capi.MK_OPT_BATCH_TAB_BITS, tb)
                 mode = capi.MK_MODE_UNIQ_SET if flavour == "uniq" else capi.MK_MODE_SET
-                eng.batch_begin(parts, mode, one_buffer=bool(rs.rand() < 0.5))
-                res = eng.batch_end()
+                how = int(rs.randint(0, 3)) if capi.lib.mk_params_packed_ok(ctypes.byref(P)) else 0
+                if how == 0:    # the texts; the device walks them
+                    eng.batch_begin(parts, mode, one_buffer=bool(rs.rand() < 0.5))
+                    live = list(range(len(parts)))
+                else:           # the host walks them (mk_fasta_pack_rows): narrow or wide rows, read in place or copied
+                    fmt = capi.MK_ROWS_PACKED if how == 1 else capi.MK_ROWS_WIDE
+                    packed = [capi.fasta_pack_rows(x, P.TL, fmt) for x in parts]
+                    live = [i for i, (_, prc_) in enumerate(packed) if prc_ == 0]   # (a text ending inside a header is refused by the packer: checked below)
+                    if live:
+                        eng.batch_begin_rows([packed[i][0] for i in live], mode, pinned=bool(rs.rand() < 0.6), fmt=fmt, gap=int(rs.choice([0, 64, 6400])))
+                res_live = eng.batch_end() if (how == 0 or live) else []
+                res = [None] * len(parts)
+                for i, r_ in zip(live, res_live):
+                    res[i] = r_
+                if how:
+                    for i, (_, prc_) in enumerate(packed):
+                        if prc_ != 0:
+                            res[i] = (prc_, 0, [])
                 eng.set_option(capi.MK_OPT_BATCH_TAB_BITS, 0)
-                desc += " batch of %d files tb=%d" % (len(parts), tb)
+                desc += " batch of %d files tb=%d %s" % (len(parts), tb, ["texts", "narrow rows", "wide rows"][how])
                 okb = True
                 for part, (st, alone, comps) in zip(parts, res):
                     prc, pw = ora.co_from_fasta(part, uniq=flavour == "uniq")
