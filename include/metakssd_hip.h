@@ -253,8 +253,8 @@ int mk_engine_sync(mk_engine *e);
  * way by mk_sketch_batch_end itself).
  *   mode: MK_MODE_SET or MK_MODE_UNIQ_SET.  files[i].text: the file's bytes (FASTA text as in the file), 1 <= nfiles <=
  *   MK_BATCH_MAX_FILES, each at most MK_BATCH_FILE_MAX bytes, MK_BATCH_TEXT_MAX in all.  The texts must stay untouched until
- *   the matching mk_sketch_batch_end has returned.  When every text starts a multiple of 1024 bytes behind files[0].text, in
- *   ascending order (one pinned buffer filled file by file), the texts cross PCIe in ONE copy.
+ *   the matching mk_sketch_batch_end has returned.  When every text starts where the one in front of it ends, rounded up to
+ *   a multiple of 1024 bytes (one pinned buffer filled file by file), the texts cross PCIe in ONE copy.
  *   Two batches may be in flight: _begin queues everything and returns, _end waits for the OLDEST batch and hands out one
  *   result per file -- status MK_OK, MK_ERR_FORMAT (the text ends inside a '>' line: the reference's abort, iseq2comem.c:259-271)
  *   or MK_ERR_CROWDED; the arrays are the engine's and stay valid until the next mk_sketch_batch_end on it.
@@ -286,7 +286,9 @@ int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out /* [nfiles of the old
 int mk_host_alloc(void **p, size_t bytes);
 int mk_host_free(void *p);
 /* pin memory the caller already owns (hipHostRegister / hipHostUnregister): row buffers, or the .shuf table before
- * mk_engine_create (its upload then takes 1 ms instead of 20) */
+ * mk_engine_create (its upload then takes 1 ms instead of 20).  Whole mappings of the caller's own (mmap, aligned_alloc of whole
+ * pages) that stay mapped while registered -- not pieces of the malloc heap: registering and unregistering those left this runtime
+ * with stale pinned ranges, and a later copy out of ordinary memory faulted on the device. */
 int mk_host_register(void *p, size_t bytes);
 int mk_host_unregister(void *p);
 /* a large pinned block the quick way (anonymous mapping touched by several threads, then one hipHostRegister): a quarter of

@@ -514,18 +514,21 @@ class Engine:
         n = len(row_arrays)
         files = (BatchFileC * n)()
         if pinned:
+            # (hipHostMalloc, not hipHostRegister on a numpy array: registering and unregistering pieces of the malloc heap left the
+            # runtime with stale pinned ranges -- a pageable copy 44 fuzz cases later faulted on the device, tools/fuzz_parity.py seed 2010)
             total = sum(a.size + gap for a in row_arrays) + 4096
-            raw = np.full(total + 4096, 0xA5, dtype=np.uint8)
-            off = (-raw.ctypes.data) % 4096
-            buf = raw[off:off + total]
+            p = C.c_void_p()
+            _check(lib.mk_host_alloc(C.byref(p), total))
+            buf = np.ctypeslib.as_array((C.c_uint8 * total).from_address(p.value))
+            buf[:] = 0xA5
             at = 0
             for i, a in enumerate(row_arrays):
                 buf[at:at + a.size] = a
-                files[i].text = buf.ctypes.data + at
+                files[i].text = p.value + at
                 files[i].n = a.size
                 at += a.size + gap
-            _check(lib.mk_host_register(buf.ctypes.data, total))
-            keep = ("registered", raw, buf.ctypes.data)
+            del buf
+            keep = ("pinned", None, p.value)
         else:
             arrs = []
             for i, a in enumerate(row_arrays):
@@ -559,8 +562,8 @@ class Engine:
                     comp = out[i].r.components[c]
                     comps.append(np.ctypeslib.as_array(comp.ids, shape=(comp.n,)).copy() if comp.n else np.zeros(0, np.uint32))
             res.append((out[i].status, out[i].alone, comps))
-        if isinstance(keep, tuple) and keep[0] == "registered":
-            lib.mk_host_unregister(keep[2])
+        if isinstance(keep, tuple) and keep[0] == "pinned":
+            lib.mk_host_free(keep[2])
         del keep
         return res
 

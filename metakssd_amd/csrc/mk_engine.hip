@@ -1894,14 +1894,30 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   const uint32_t width = (rowlen + 1u + 15u) & ~15u;
 
   /* ---- geometry of the batch: where every file's text, stream region, segments and rows lie */
-  /* one copy for all texts when they already lie at 1 KiB-aligned, ascending distances from the first (a pinned buffer filled file
-   * by file); otherwise they are packed file by file */
+  /* Texts: one copy for all of them when each starts where the one in front ends, rounded up to 1 KiB (a buffer filled file by file:
+   * nothing but the texts and their padding is read); otherwise they are packed file by file.
+   * Rows: read where they lie when they are in ascending order, 64 bytes apart, inside memory the device has mapped (both ends are
+   * asked for: what lies between two files is never touched, but it must be the caller's ONE pinned stretch); anything else --
+   * separate arrays that merely happen to lie in ascending order, pageable memory -- is copied file by file. */
   bool one_copy = true;
+  const uint8_t *rows_dev = nullptr;
   for (uint32_t i = 1; i < nfiles && one_copy; i++) {
-    if (files[i].text < files[i - 1].text + files[i - 1].n) one_copy = false;
-    else if ((size_t)(files[i].text - files[0].text) % (rows ? MK_PACKED_PITCH : MK_FA_SEG)) one_copy = false;
+    if (rows) {
+      if (files[i].text < files[i - 1].text + files[i - 1].n || (size_t)(files[i].text - files[0].text) % MK_PACKED_PITCH) one_copy = false;
+    } else if (files[i].text != files[i - 1].text + (files[i - 1].n + MK_FA_SEG - 1) / MK_FA_SEG * MK_FA_SEG) one_copy = false;
   }
-  if (one_copy && (uint64_t)(files[nfiles - 1].text - files[0].text) + files[nfiles - 1].n > total + (uint64_t)nfiles * MK_FA_SEG + ((uint64_t)64 << 20)) one_copy = false;
+  if (rows && one_copy) {
+    const uint64_t span = (uint64_t)(files[nfiles - 1].text - files[0].text) + files[nfiles - 1].n;
+    if (!files[0].text || span == 0 || span > 2 * total + (uint64_t)nfiles * 4096u + ((uint64_t)64 << 20)) one_copy = false;
+    else {
+      hipPointerAttribute_t pa0, pa1;
+      void *dp = nullptr;
+      if (hipPointerGetAttributes(&pa0, files[0].text) == hipSuccess && pa0.type == hipMemoryTypeHost &&
+          hipPointerGetAttributes(&pa1, files[0].text + span - 1) == hipSuccess && pa1.type == hipMemoryTypeHost &&
+          hipHostGetDevicePointer(&dp, (void *)files[0].text, 0) == hipSuccess && dp) rows_dev = (const uint8_t *)dp;
+      else { (void)hipGetLastError(); one_copy = false; }
+    }
+  }
   const size_t desc_bytes = mk_up16(sizeof(mk_batch_dev)) + mk_up16((size_t)nfiles * sizeof(mk_bfile)) + 2 * mk_up16(((size_t)nfiles + 1) * 4);
   int rc = mk_pinned_fit(e, &c->h_desc, &c->h_desc_cap, desc_bytes);
   if (rc) return rc;
@@ -1946,15 +1962,6 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   }
   const uint64_t text_span = rows ? 0 : one_copy ? (uint64_t)(files[nfiles - 1].text - files[0].text) + files[nfiles - 1].n : toff;
   const uint64_t total_rows = soff / (rows ? MK_PACKED_PITCH : pitch);
-  /* rows in one stretch of memory the device can read are scanned where they lie */
-  const uint8_t *rows_dev = nullptr;
-  if (rows && one_copy && soff) {
-    hipPointerAttribute_t pa;
-    void *dp = nullptr;
-    if (hipPointerGetAttributes(&pa, files[0].text) == hipSuccess && pa.type == hipMemoryTypeHost &&
-        hipHostGetDevicePointer(&dp, (void *)files[0].text, 0) == hipSuccess) rows_dev = (const uint8_t *)dp;
-    else (void)hipGetLastError();
-  }
   const uint32_t nseg_total = seg;
   hseg0[nfiles] = nseg_total;
   hrow0[nfiles] = (uint32_t)total_rows;
@@ -2048,12 +2055,9 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   MK_HIP(e, hipMemcpyAsync(c->desc.p, c->h_desc, desc_bytes, hipMemcpyHostToDevice, s));
   tick("descriptor copy queued");
   if (rows) {
-    if (!rows_dev) {
-      if (one_copy) { if (soff) MK_HIP(e, hipMemcpyAsync(c->stream.p, files[0].text, (size_t)soff, hipMemcpyHostToDevice, s)); }
-      else
-        for (uint32_t i = 0; i < nfiles; i++)
-          if (files[i].n) MK_HIP(e, hipMemcpyAsync((uint8_t *)c->stream.p + hf[i].stream_off, files[i].text, (size_t)files[i].n, hipMemcpyHostToDevice, s));
-    }
+    if (!rows_dev) /* (not one mapped stretch: file by file, side by side) */
+      for (uint32_t i = 0; i < nfiles; i++)
+        if (files[i].n) MK_HIP(e, hipMemcpyAsync((uint8_t *)c->stream.p + hf[i].stream_off, files[i].text, (size_t)files[i].n, hipMemcpyHostToDevice, s));
   } else if (one_copy) {
     if (text_span) MK_HIP(e, hipMemcpyAsync(c->text.p, files[0].text, (size_t)text_span, hipMemcpyHostToDevice, s));
   } else {

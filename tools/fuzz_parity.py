@@ -50,6 +50,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--start", type=int, default=0, help="first case (every case draws from its own stream: --start N --cases 1 replays case N)")
+    ap.add_argument("--trace", action="store_true", help="print every case's number before it runs and its description behind it")
     ap.add_argument("--big", action="store_true", help="also draw the 16-component L2K11 geometry (slow oracle)")
     ap.add_argument("--big-rate", type=float, default=0.08, help="share of the cases that draw it (with --big)")
     ap.add_argument("--sparse", type=int, default=-1, help="MK_OPT_SPARSE: -1 by table size, 0 off, 1 on")
@@ -60,7 +62,9 @@ def main():
     engines, oracles, shufs = {}, {}, {}
     bad = 0
     nonempty = total_ids = crowded = 0
-    for case in range(a.cases):
+    for case in range(a.start, a.start + a.cases):
+        if a.trace:
+            print("case", case, flush=True)
         rs = np.random.RandomState(a.seed * 100003 + case)
         k, subk, drl = GEOM_BIG if (a.big and rs.rand() < a.big_rate) else GEOM[rs.randint(0, len(GEOM))]
         key = (k, subk, drl)
@@ -142,6 +146,8 @@ def main():
                 eng.set_option(capi.MK_OPT_BATCH_TAB_BITS, tb)
                 mode = capi.MK_MODE_UNIQ_SET if flavour == "uniq" else capi.MK_MODE_SET
                 how = int(rs.randint(0, 3)) if capi.lib.mk_params_packed_ok(ctypes.byref(P)) else 0
+                if a.trace:
+                    print(desc, "batch how=%d tb=%d parts=%s" % (how, tb, [len(x) for x in parts]), flush=True)
                 if how == 0:    # the texts; the device walks them
                     eng.batch_begin(parts, mode, one_buffer=bool(rs.rand() < 0.5))
                     live = list(range(len(parts)))
