@@ -189,8 +189,8 @@ __attribute__((target("avx2"))) static unsigned mk_wide_pack_avx2(uint8_t *row, 
   }
   const uint32_t allvalid = bad == 0u;
   out[0] = (uint32_t)nb | (allvalid << 16) | ((allvalid ^ 1u) << 17);
-  /* ordinary stores: streaming stores made this 3 x slower on an EPYC 9575F (115 ns a row against 36: scratch measurement with the
-   * three store forms), where they help the narrow rows' packer */
+  /* ordinary stores: with streaming stores this ran 3 x slower on an EPYC 9575F (115 ns a row against 36: the three store forms in
+   * profiles/r04_probe_wide_pack_stores.txt) */
   _mm256_store_si256((__m256i *)row, _mm256_load_si256((const __m256i *)out));
   _mm256_store_si256((__m256i *)(row + 32), _mm256_load_si256((const __m256i *)(out + 8)));
   if (allvalid) return 1u;
