@@ -247,7 +247,7 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=4):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=3, ref_genomes=48, extra_flags=(), only=None):
+def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=48, extra_flags=(), only=None):
     """BASELINE config 5: `metakssd dist -L <shuf> -o out <genome directory>` (no -A) on synthetic multi-FASTA genomes in
     /dev/shm, L3K10 and L2K11, whole command line by the parent's clock; the compiled reference on a few of the genomes"""
     import numpy as np
