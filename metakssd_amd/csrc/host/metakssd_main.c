@@ -250,8 +250,10 @@ static void engine_params(engine_future *f, const mk_params *P) {
 
 /* the per-engine options of the command line, for every engine that is attached to a ctx (the start-up engine, the extra engines
  * of --engines, the drivers' engines of --devices) */
+static int g_batch_queues = 0; /* --batch-queues 1|2: MK_OPT_BATCH_QUEUES (0: the library's default, 2) */
 static void engine_apply_options(const ctx_t *c, mk_engine *e) {
   if (c->direct_host) mk_engine_set_option(e, MK_OPT_DIRECT_HOST, 1);
+  if (g_batch_queues) mk_engine_set_option(e, MK_OPT_BATCH_QUEUES, g_batch_queues);
 }
 
 static mk_engine *engine_get(ctx_t *c) {
@@ -1964,6 +1966,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--engines") && i + 1 < argc) engines_per_gpu = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--allow-device-copies")) allow_copies = 1;
     else if (!strcmp(argv[i], "--no-batch")) g_no_batch = 1; /* genome directories file by file (the driver of round 3) */
+    else if (!strcmp(argv[i], "--batch-queues") && i + 1 < argc) { g_batch_queues = atoi(argv[++i]); if (g_batch_queues != 1 && g_batch_queues != 2) die("--batch-queues takes 1 or 2"); }
     else if (!strcmp(argv[i], "--batch-narrow")) g_batch_narrow = 1; /* rows of 152 bases (the FASTQ framers' format) instead of wide rows of 240 */
     else if (!strcmp(argv[i], "--batch-text")) g_batch_text = 1; /* batches of FASTA TEXT (the device walks it) instead of rows packed by the readers */
     else if (!strcmp(argv[i], "--batch-mib") && i + 1 < argc) g_batch_bytes = (size_t)atoi(argv[++i]) << 20;

@@ -130,6 +130,21 @@ struct mk_engine {
   struct mk_bctx *bctx[3] = {nullptr, nullptr, nullptr};
   uint64_t batch_begun = 0, batch_ended = 0;
   int batch_tb_opt = 0;                /* MK_OPT_BATCH_TAB_BITS: 0 = by the largest file of the batch */
+  /* a second queue for every other batch (MK_OPT_BATCH_QUEUES 2; default 1): the scan of batch i + 1 reads its rows over the link
+   * while the table / layout / dump kernels of batch i run -- on one queue the link idles behind every scan.  Made by a thread of
+   * its own at the first batch (8-9 ms: tools/probe_second_queue.hip), used from the batch at which it is there; candidate buffers
+   * of its own.  Built, parity-green and MEASURED SLOWER (profiles/r04_d_config5_two_queues.txt: 1 024 genomes in 0.116-0.131 s
+   * against 0.103-0.109 at L3K10, 0.137-0.151 against 0.130-0.136 at L2K11): in pairs the batches still take 0.8 ms each -- two
+   * scans share the link, and what the second queue hides of the other kernels it costs in being made beside the first batches
+   * (their begins take 17-24 ms instead of 2) -- so it stays an option. */
+  int batch_queues_opt = 1;
+  hipStream_t lane_stream = nullptr;
+  uint4 *lane_cand = nullptr;
+  uint32_t *lane_cand_count = nullptr;
+  uint32_t lane_cand_cap = 0;
+  pthread_t lane_th;
+  bool lane_th_started = false;
+  int lane_state = 0;                  /* 0 not asked for, 1 being made, 2 there, 3 failed (atomic accesses) */
   const mk_batch_dev *cur_batch = nullptr; /* set around the scan launches of a batch */
 
   int mode = -1;
@@ -278,7 +293,10 @@ static void mk_bctx_free(struct mk_bctx *c);
 extern "C" int mk_engine_destroy(mk_engine *e) {
   if (!e) return MK_ERR_ARG;
   hipSetDevice(e->device);
+  if (e->lane_th_started) { pthread_join(e->lane_th, nullptr); e->lane_th_started = false; }
   hipDeviceSynchronize();
+  if (e->lane_stream) hipStreamDestroy(e->lane_stream);
+  hipFree(e->lane_cand); hipFree(e->lane_cand_count);
   hipFree(e->d_pairs);
   hipFree(e->d_cand); hipFree(e->d_cand_count);
   hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_accept_bits); hipFree(e->d_tab); hipFree(e->d_front); hipFree(e->d_front_desc); hipFree(e->d_slot);
@@ -597,12 +615,18 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
       return mk_config_front(e, e->front_bits_opt);
     case MK_OPT_CAND_CAP:
       if (value < 0 || value > (1 << 20)) return mk_fail(e, MK_ERR_ARG, "MK_OPT_CAND_CAP takes 0 .. 2^20 records per scan wave");
+      if (e->batch_begun != e->batch_ended) return mk_fail(e, MK_ERR_STATE, "MK_OPT_CAND_CAP while a batch is in flight");
       return mk_config_cand(e, (uint32_t)value);
     case MK_OPT_DIRECT_HOST:
       e->direct_host = value != 0;
       return MK_OK;
     case MK_OPT_ROWS160:
       e->rows160 = value != 0;
+      return MK_OK;
+    case MK_OPT_BATCH_QUEUES:
+      if (value != 1 && value != 2) return mk_fail(e, MK_ERR_ARG, "MK_OPT_BATCH_QUEUES takes 1 or 2");
+      if (e->batch_begun != e->batch_ended) return mk_fail(e, MK_ERR_STATE, "MK_OPT_BATCH_QUEUES while a batch is in flight");
+      e->batch_queues_opt = (int)value;
       return MK_OK;
     case MK_OPT_BATCH_TAB_BITS:
       if (value != 0 && (value < 9 || value > 22)) return mk_fail(e, MK_ERR_ARG, "MK_OPT_BATCH_TAB_BITS takes 0 (by file size) or 9..22");
@@ -664,6 +688,7 @@ extern "C" int mk_engine_sync(mk_engine *e) {
   { int rc = mk_flush_region(e); if (rc) return rc; }
   if (e->copy_stream != e->stream) MK_HIP(e, hipStreamSynchronize(e->copy_stream));
   MK_HIP(e, hipStreamSynchronize(e->stream));
+  if (__atomic_load_n(&e->lane_state, __ATOMIC_ACQUIRE) == 2) MK_HIP(e, hipStreamSynchronize(e->lane_stream));
   return MK_OK;
 }
 
@@ -1805,6 +1830,7 @@ struct mk_bctx {
   int mode = 0;
   uint32_t nfiles = 0;
   size_t stat_bytes = 0;
+  hipStream_t used_stream = nullptr; /* the queue this batch's launch sequence went to */
   bool rows = false;     /* the files are packed rows (mk_sketch_batch_begin_rows) */
   uint32_t format = 0;   /* MK_ROWS_PACKED / MK_ROWS_WIDE then */
   const uint8_t *rows_src = nullptr; /* where the device reads them: the caller's pinned stretch, or this context's copy */
@@ -1858,6 +1884,31 @@ static uint64_t mk_rows_per_launch(const mk_engine *e, uint32_t row_bases, int t
   if (rows < 64.0 * (double)waves) rows = 64.0 * (double)waves;
   if (rows > (double)(1ull << 30)) rows = (double)(1ull << 30);
   return (uint64_t)rows / 64u * 64u;
+}
+
+/* the second queue and its candidate buffers (mk_engine::lane_*), made beside the first batches */
+static void *mk_lane_make(void *arg) {
+  mk_engine *e = (mk_engine *)arg;
+  hipStream_t s = nullptr;
+  uint4 *cand = nullptr;
+  uint32_t *cnt = nullptr;
+  const uint32_t cap = e->cand_cap, slots = e->cand_slots;
+  bool ok = hipSetDevice(e->device) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess &&
+            hipMalloc((void **)&cand, (size_t)slots * (cap + 1) * sizeof(uint4)) == hipSuccess && hipMalloc((void **)&cnt, (size_t)slots * sizeof(uint32_t)) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(mk_fill16_kernel, dim3(4), dim3(256), 0, s, (uint4 *)cnt, (unsigned long long)slots / 4ull, 0u);
+    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    if (s) hipStreamDestroy(s);
+    hipFree(cand); hipFree(cnt);
+    __atomic_store_n(&e->lane_state, 3, __ATOMIC_RELEASE);
+    return nullptr;
+  }
+  e->lane_stream = s; e->lane_cand = cand; e->lane_cand_count = cnt; e->lane_cand_cap = cap;
+  __atomic_store_n(&e->lane_state, 2, __ATOMIC_RELEASE);
+  return nullptr;
 }
 
 /* rows: the files are PACKED ROWS already (mk_fasta_pack_rows on the reader's thread: the FASTA walk done by the host) -- no text,
@@ -2038,7 +2089,23 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   c->mode = mode; c->nfiles = nfiles; c->rows = rows; c->format = format; c->rows_src = rows ? (rows_dev ? rows_dev : (const uint8_t *)c->stream.p) : nullptr;
   c->files.assign(files, files + nfiles);
   const mk_batch_dev *dbatch = (const mk_batch_dev *)dd;
+  /* every other batch on the second queue, once it is there (the engine's own stream only: a caller's stream orders the caller's work) */
+  bool lane = false;
+  if (e->batch_queues_opt == 2 && e->stream == e->own_stream) {
+    const int st = __atomic_load_n(&e->lane_state, __ATOMIC_ACQUIRE);
+    if (st == 0) {
+      __atomic_store_n(&e->lane_state, 1, __ATOMIC_RELEASE);
+      if (pthread_create(&e->lane_th, nullptr, mk_lane_make, e) == 0) e->lane_th_started = true;
+      else __atomic_store_n(&e->lane_state, 3, __ATOMIC_RELEASE);
+    } else if (st == 2 && e->lane_cand_cap == e->cand_cap && (e->batch_begun & 1u)) lane = true;
+  }
+  struct lane_swap { /* the launch helpers below take queue and candidate buffers from the engine: swapped for this batch, put back on every way out */
+    mk_engine *e; hipStream_t s; uint4 *c; uint32_t *n; bool on;
+    ~lane_swap() { if (on) { e->stream = s; e->copy_stream = s; e->d_cand = c; e->d_cand_count = n; } }
+  } swap_back{e, e->stream, e->d_cand, e->d_cand_count, lane};
+  if (lane) { e->stream = e->lane_stream; e->copy_stream = e->lane_stream; e->d_cand = e->lane_cand; e->d_cand_count = e->lane_cand_count; }
   hipStream_t s = e->stream;
+  c->used_stream = s;
 
   /* ---- the launch sequence, all of it on the engine's one stream.  (A copy queue of its own for the texts -- made by a thread beside
    * the first batches, the kernels behind an event -- was built and measured: 1 024 genomes in 0.222-0.238 s with it, 0.199-0.213 s
@@ -2146,8 +2213,8 @@ extern "C" int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out) {
     memcpy(bigger, c->h_ids, (size_t)c->spec_ids * 4);
     hipHostFree(c->h_ids);
     c->h_ids = bigger; c->h_ids_cap = (size_t)n_out * 4 + 4096;
-    MK_HIP(e, hipMemcpyAsync(c->h_ids + c->spec_ids, c->hb.out_ids + c->spec_ids, (size_t)(n_out - c->spec_ids) * 4, hipMemcpyDeviceToHost, e->stream));
-    MK_HIP(e, hipEventRecord(c->ev_stat, e->stream));
+    MK_HIP(e, hipMemcpyAsync(c->h_ids + c->spec_ids, c->hb.out_ids + c->spec_ids, (size_t)(n_out - c->spec_ids) * 4, hipMemcpyDeviceToHost, c->used_stream));
+    MK_HIP(e, hipEventRecord(c->ev_stat, c->used_stream));
   }
   c->comps.assign((size_t)nfiles * C, mk_component{nullptr, nullptr, 0});
   c->alone_ids.clear();

@@ -489,6 +489,67 @@ def test_batch_of_packed_rows_equals_oracle(capi, engine_for, shufs, oracle_for,
     assert_same(eng.finish(), want[big], name + " the largest file's rows pushed alone")
 
 
+@pytest.mark.parametrize("queues", [2, 1])
+@pytest.mark.parametrize("name", ["L3K10", "L2K11"])
+def test_batches_alternate_between_two_queues(capi, shufs, oracle_for, name, queues):
+    """MK_OPT_BATCH_QUEUES: with 2 every other batch goes to a second queue once that is there, so that a batch's scan
+    runs beside the table / layout / dump kernels of the batch in front; twelve batches of rows and texts, two in flight, every file's
+    sketch the oracle's; a file that is sketched alone in between; 1 (the default): everything on the engine's queue"""
+    import time
+    rs = np.random.RandomState(56)
+    texts = _batch_texts(rs, True)
+    ora = oracle_for(shufs(name))
+    eng = capi.Engine(shufs(name), 0)
+    try:
+        eng.set_option(capi.MK_OPT_BATCH_QUEUES, queues)
+        TL = 2 * eng.params.k
+        want = []
+        for t in texts:
+            rc, w = ora.co_from_fasta(t) if t else (0, None)
+            assert rc == 0
+            want.append(w)
+        wide = [capi.fasta_pack_rows(t, TL, capi.MK_ROWS_WIDE)[0] for t in texts]
+        ncomp = eng.params.component_num
+
+        def check(res, idx, label):
+            assert len(res) == len(idx)
+            for (st, alone, comps), i in zip(res, idx):
+                assert st == 0, (label, i)
+                if want[i] is None:
+                    assert all(len(c) == 0 for c in comps) and len(comps) == ncomp
+                else:
+                    assert_same([(c, None) for c in comps], want[i], "%s file %d (alone=%d)" % (label, i, alone))
+        eng.batch_begin_rows([wide[0]], capi.MK_MODE_SET, pinned=True, fmt=capi.MK_ROWS_WIDE)   # (the second queue is asked for here)
+        check(eng.batch_end(), [0], "first")
+        time.sleep(0.1)                                                                                # ... and is there now
+        order = list(range(len(texts)))
+        pending = []
+        for b in range(12):
+            rs.shuffle(order)
+            idx = order[: 1 + b % len(order)]
+            if b % 3 == 2:
+                eng.batch_begin([texts[i] for i in idx], capi.MK_MODE_SET, one_buffer=bool(b & 1))
+            else:
+                eng.batch_begin_rows([wide[i] for i in idx], capi.MK_MODE_SET, pinned=bool(b % 2 == 0), fmt=capi.MK_ROWS_WIDE)
+            pending.append((list(idx), "batch %d" % b))
+            if len(pending) == 2:
+                i0, l0 = pending.pop(0)
+                check(eng.batch_end(), i0, l0)
+            if b == 6:   # an ordinary sketch between batches, one batch still in flight
+                big = max(range(len(texts)), key=lambda i: len(texts[i]))
+                assert len(pending) == 1
+                eng.begin(capi.MK_MODE_SET)
+                eng.push_stream(texts[big])
+                assert_same(eng.finish(), want[big], "alone between the batches")
+        while pending:
+            i0, l0 = pending.pop(0)
+            check(eng.batch_end(), i0, l0)
+        with pytest.raises(capi.MkError):
+            eng.set_option(capi.MK_OPT_BATCH_QUEUES, 3)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("wide", [False, True])
 def test_batch_of_packed_rows_small_tables_and_refusals(capi, shufs, oracle_for, wide):
     """512 slots per file: the flagged files are sketched alone FROM THEIR ROWS by mk_sketch_batch_end; geometries without a packed
