@@ -2197,7 +2197,7 @@ int main(int argc, char **argv) {
     const int nbufs = nbatches < want_bufs ? nbatches : want_bufs;
     br.nbufs = nbufs;
     size_t arena_len = 0;
-    uint8_t *arena = batch_rows && !getenv("MK_BATCH_PRETOUCH") ? arena_map_untouched((size_t)nbufs * br.bufcap, &arena_len) : arena_map_unpinned((size_t)nbufs * br.bufcap, &arena_len);
+    uint8_t *arena = batch_rows ? arena_map_untouched((size_t)nbufs * br.bufcap, &arena_len) : arena_map_unpinned((size_t)nbufs * br.bufcap, &arena_len);
     (void)arena_len;
     if (!arena) die("out of memory (%zu bytes of batch buffers)", (size_t)nbufs * br.bufcap);
     for (int b = 0; b < nbufs; b++) br.buf[b] = arena + (size_t)b * br.bufcap;
