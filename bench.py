@@ -293,7 +293,7 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=4
                 continue
             sp = os.path.join(tmp, name + ".shuf")
             capi.Shuf.generate(k, sk, l, seed).write(sp)
-            walls, fin = [], None
+            walls, fins, fin = [], [], None
             for rep in range(reps + 1):
                 od = os.path.join(tmp, "out_%s_%d" % (name, rep))
                 # outside the timed window: the driver is still taking the previous process's device memory back (two engines of
@@ -311,19 +311,21 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=4
                         fin = json.loads(ln)["timing"]
                 if rep:
                     walls.append(m1 - m0)
+                    fins.append(fin)
                 if rep < reps:
                     shutil.rmtree(od, ignore_errors=True)
             else:
                 w = statistics.median(walls)
+                fin = fins[sorted(range(len(walls)), key=lambda i: walls[i])[len(walls) // 2]]  # the timeline of the median run
                 ready = (fin or {}).get("engine_ready") or 0.0
                 out[name] = {"genomes_per_s": genomes / w, "gbases_s": genomes * bases_each / w / 1e9, "seconds": w,
                              # the same without the process's fixed start (HIP runtime + engine tables: engine_ready_s after process
-                             # start, of the last run): what a longer directory converges to
+                             # start, of the median run): what a longer directory converges to
                              "genomes_per_s_after_start": genomes / max(w - ready, 1e-9),
                              "all_runs_s": [round(x, 4) for x in walls],
                              "finish_ms_per_genome": (fin or {}).get("finish_s", 0.0) / genomes * 1e3,
                              "engine_ready_s": (fin or {}).get("engine_ready"),
-                             # the process's own clock (main() to the last file written), of the last run
+                             # the process's own clock (main() to the last file written), of the median run
                              "written_s": (fin or {}).get("written"), "batches": (fin or {}).get("batches")}
                 if os.path.exists(ref) and ref_genomes:
                     sub = os.path.join(tmp, "few_" + name)
