@@ -1827,7 +1827,7 @@ static void *extra_engines_run(void *arg) {
 #define BATCH_BUFS 4      /* buffers of text batches; packed rows: as many as 2 GiB hold, BATCH_BUFS_MAX at most */
 #define BATCH_BUFS_MAX 64
 static int g_no_batch = 0;
-static size_t g_batch_bytes = (size_t)128 << 20; /* --batch-mib: text per batch */
+static size_t g_batch_bytes = 0;                 /* --batch-mib: text per batch (0: 256 MiB where the readers pack rows, 128 MiB of text) */
 static int g_batch_files = 256;                  /* --batch-files */
 static int g_batch_narrow = 0;                   /* --batch-narrow: rows of 152 bases (the FASTQ rows) instead of wide rows of 240 */
 static int g_batch_text = 0;                     /* --batch-text: the files' TEXT goes to the device (which then does the FASTA walk too) */
@@ -2057,6 +2057,11 @@ int main(int argc, char **argv) {
     if (g_batch_files < 1 || g_batch_files > (int)MK_BATCH_MAX_FILES) die("--batch-files takes 1..%u", MK_BATCH_MAX_FILES);
     /* a batch's tables hold about five times the keys its files are expected to leave (text / 16^drlevel), 2^26 slots at most */
     const size_t geo_cap = (((size_t)1 << 25) / 5u) << (4 * P.drlevel > 20 ? 20 : 4 * P.drlevel);
+    /* rows, small sketches (drlevel >= 3: a key in 4 096 k-mers): 256 MiB of text a batch -- the kernels behind a batch's scan (tables,
+     * layout, dump: 0.15-0.2 ms during which the link idles) come half as often as with 128 MiB: 1 024 genomes 3 ms sooner at L3K10.
+     * Larger sketches (L2K11: a key in 256) keep 128 MiB: their tables and dumps grow with the batch, 256 MiB was 0-5 ms slower there,
+     * 512 MiB 15 ms */
+    if (!g_batch_bytes) g_batch_bytes = (!g_batch_text && mk_params_packed_ok(&P) && P.drlevel >= 3) ? (size_t)256 << 20 : (size_t)128 << 20;
     if (g_batch_bytes > geo_cap) g_batch_bytes = geo_cap;
     if (g_batch_bytes > ((size_t)512 << 20)) g_batch_bytes = (size_t)512 << 20;
     if (g_batch_bytes < ((size_t)1 << 20)) g_batch_bytes = (size_t)1 << 20;
