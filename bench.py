@@ -247,6 +247,23 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=4):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _sketch_blocks(d):
+    """a sketch directory (no -A) -> {basename of the input file: [ids of component 0, 1, ...]} from cofiles.stat (32-byte header, the
+    per-file key counts, 256-byte names: command_dist.c:433-452) and combco.index.N / combco.N"""
+    import struct
+    import numpy as np
+    b = open(os.path.join(d, "cofiles.stat"), "rb").read()
+    comp_num, infile_num = struct.unpack_from("<ii", b, 16)
+    names = [b[32 + 4 * infile_num + 256 * i: 32 + 4 * infile_num + 256 * (i + 1)].split(b"\0", 1)[0].decode() for i in range(infile_num)]
+    out = {os.path.basename(n): [] for n in names}
+    for c in range(comp_num):
+        idx = np.fromfile(os.path.join(d, "combco.index.%d" % c), dtype=np.uint64)
+        ids = np.fromfile(os.path.join(d, "combco.%d" % c), dtype=np.uint32)
+        for i, n in enumerate(names):
+            out[os.path.basename(n)].append(ids[int(idx[i]):int(idx[i + 1])])
+    return out
+
+
 def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=48, extra_flags=(), only=None):
     """BASELINE config 5: `metakssd dist -L <shuf> -o out <genome directory>` (no -A) on synthetic multi-FASTA genomes in
     /dev/shm, L3K10 and L2K11, whole command line by the parent's clock; the compiled reference on a few of the genomes"""
@@ -341,6 +358,15 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=4
                         out[name]["cpu_baseline"] = {"genomes_per_s": ref_genomes / dt, "gbases_s": ref_genomes * bases_each / dt / 1e9,
                                                      "cores": cores, "kind": "reference",
                                                      "sample": "%d of the genomes, oracle/_ref/metakssd dist -p %d" % (ref_genomes, cores)}
+                        try:  # the product's blocks of those genomes (the last timed run's directory) against the reference's, id for id
+                            import numpy as np
+                            rb, pb = _sketch_blocks(os.path.join(tmp, "ref_" + name)), _sketch_blocks(od)
+                            same = all(k in pb and len(pb[k]) == len(v) and all(np.array_equal(x, y) for x, y in zip(pb[k], v)) for k, v in rb.items())
+                            out[name]["cpu_baseline"]["gpu_blocks_equal_reference"] = bool(same and len(rb) == ref_genomes)
+                            out[name]["cpu_baseline"]["ids_compared"] = int(sum(sum(x.size for x in v) for v in rb.values()))
+                        except Exception as ex:  # noqa: BLE001
+                            out[name]["cpu_baseline"]["gpu_blocks_equal_reference"] = None
+                            out[name]["cpu_baseline"]["compare_error"] = str(ex)[:200]
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
