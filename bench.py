@@ -372,6 +372,42 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=4
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def self_launch(args):
+    """`python3 bench.py --gpus N` (N > 1) without torch.distributed.run around it: run
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>`
+    as a child process, stdout and stderr inherited (rank 0's JSON line is this process's line), and return its exit code.
+    With fewer visible GPUs than ranks the ranks share GPU 0 and exchange through gloo -- a DEBUG transport, flagged in the line's
+    `config.parallelism` and `distributed.transport`: it exercises the whole N-rank flow, it measures nothing about xGMI."""
+    import socket
+    argv = sys.argv[1:]
+    try:
+        import torch  # device_count() does not initialise the GPU on this image; nothing else of torch.cuda is touched here
+        visible = torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        visible = 0
+    if visible < args.gpus and not args.same_device:
+        sys.stderr.write("bench.py: %d rank(s) asked for, %d GPU(s) visible: the ranks share GPU 0 and exchange through gloo "
+                         "(debug transport, flagged in the JSON line)\n" % (args.gpus, visible))
+        out, skip = [], False
+        for a in argv:  # drop a --backend given on the command line: RCCL needs a device per rank
+            if skip:
+                skip = False
+            elif a == "--backend":
+                skip = True
+            elif not a.startswith("--backend="):
+                out.append(a)
+        argv = out + ["--backend", "gloo", "--same-device"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
 def kernel_source_id():
     h = hashlib.sha256()
     for f in ("mk_kernels.hip.h", "mk_engine.hip", "mk_stream.hip.h", "mk_batch.hip.h", "mk_packed.hip.h"):
@@ -399,12 +435,14 @@ def main():
     ap.add_argument("--front-bits", type=int, default=None,
                     help="experiments: MK_OPT_FRONT_BITS of the engine (default: the engine's own choice; 0 = no front table)")
     ap.add_argument("--cand-cap", type=int, default=None, help="experiments: MK_OPT_CAND_CAP of the engine (records per scan wave)")
-    ap.add_argument("--rows160", type=int, default=None, choices=[0, 1],
-                    help="MK_OPT_ROWS160: 1 = the scan kernel that keeps a lane's 160-byte row in registers (no LDS tile), 0 = mk_scan_kernel; "
-                         "default: the library's")
     ap.add_argument("--verify", action="store_true",
                     help="after timing, rank 0 re-sketches ALL ranks' reads on one engine and compares with the merged result")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start the N ranks ourselves, as a CHILD process, before this process has imported torch or
+        # touched HIP (a process that has initialised the GPU must never be replaced by another program on this pool)
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -458,8 +496,6 @@ def main():
 
     shuf = capi.Shuf.generate(11, 6, 3, 11)  # L3K11 = {k=11, subk=6, drlevel=3}, same bytes as the tests' table
     eng = capi.Engine(shuf, local_rank, front_bits=args.front_bits, cand_cap=args.cand_cap)
-    if args.rows160 is not None:
-        eng.set_option(capi.MK_OPT_ROWS160, args.rows160)
     stream = torch.cuda.current_stream().cuda_stream
     eng.set_stream(stream)
 

@@ -155,15 +155,12 @@ int mk_engine_destroy(mk_engine *e);
  *                   of hashsize -- 10.7 GB at L2K11 -- and the finish / export that counts more keys grows it and compacts again)
  *   MK_OPT_BATCH_TAB_BITS 0 / 9..22: log2 of the slots every file's table gets in mk_sketch_batch_begin (default 0: about five times
  *                   the keys the batch's largest file is expected to leave); a file whose table is too small is sketched alone
- *   MK_OPT_BATCH_QUEUES 1 (default) / 2: with 2, batches (mk_sketch_batch_begin*) alternate between the engine's queue and a second one,
- *                   made by a thread of its own beside the first batches, so that the scan of one batch runs beside the table and
- *                   dump kernels of the batch in front (engine's own stream only).  Measured slower on one MI355X (two scans share
- *                   the link; making the queue disturbs the first batches): an option, not the default
- *   MK_OPT_ROWS160  0 / 1: text rows of pitch 160 (150-base reads) are scanned by mk_scan_rows160_kernel -- every lane loads its own row
- *                   into registers, no LDS tile -- instead of mk_scan_kernel (tuned geometries only)
+ *   (8 and 9 were MK_OPT_ROWS160 and MK_OPT_BATCH_QUEUES in round 4: a scan kernel that kept a lane's text row in registers and a
+ *   second queue for every other batch.  Both measured slower than what they replaced -- profiles/r04_b_kernel_stats_rows160_variant.csv,
+ *   profiles/r04_d_config5_two_queues.txt -- and were removed in round 5; the numbers stay retired.)
  * Results are bit-identical for every setting; the tests run both. */
 enum { MK_OPT_SPARSE = 1, MK_OPT_CAND_CAP = 2, MK_OPT_RESULT_CAP = 3, MK_OPT_DIRECT_HOST = 4, MK_OPT_FRONT_BITS = 5, MK_OPT_KEYLIST_CAP = 6,
-       MK_OPT_BATCH_TAB_BITS = 7, MK_OPT_ROWS160 = 8, MK_OPT_BATCH_QUEUES = 9 };
+       MK_OPT_BATCH_TAB_BITS = 7 };
 int mk_engine_set_option(mk_engine *e, int option, int64_t value);
 int mk_engine_set_stream(mk_engine *e, void *hip_stream);
 int mk_engine_use_own_stream(mk_engine *e);

@@ -18,8 +18,7 @@ MK_ERR_STATE, MK_ERR_IO, MK_ERR_FORMAT, MK_ERR_NOMEM = -5, -6, -7, -8
 MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET, MK_MODE_OCC_SET = 0, 1, 2, 3
 MK_ROWS_PACKED, MK_PACKED_PITCH, MK_PACKED_MAX_BASES = 0x80000000, 64, 152
 MK_ROWS_WIDE, MK_WIDE_MAX_BASES = 0x40000000, 240
-MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP, MK_OPT_DIRECT_HOST, MK_OPT_FRONT_BITS, MK_OPT_KEYLIST_CAP, MK_OPT_BATCH_TAB_BITS, MK_OPT_ROWS160 = 1, 2, 3, 4, 5, 6, 7, 8
-MK_OPT_BATCH_QUEUES = 9
+MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP, MK_OPT_DIRECT_HOST, MK_OPT_FRONT_BITS, MK_OPT_KEYLIST_CAP, MK_OPT_BATCH_TAB_BITS = 1, 2, 3, 4, 5, 6, 7
 
 
 class MkError(RuntimeError):

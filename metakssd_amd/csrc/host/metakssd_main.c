@@ -250,10 +250,11 @@ static void engine_params(engine_future *f, const mk_params *P) {
 
 /* the per-engine options of the command line, for every engine that is attached to a ctx (the start-up engine, the extra engines
  * of --engines, the drivers' engines of --devices) */
-static int g_batch_queues = 0; /* --batch-queues 1|2: MK_OPT_BATCH_QUEUES (0: the library's default, 2) */
 static void engine_apply_options(const ctx_t *c, mk_engine *e) {
   if (c->direct_host) mk_engine_set_option(e, MK_OPT_DIRECT_HOST, 1);
-  if (g_batch_queues) mk_engine_set_option(e, MK_OPT_BATCH_QUEUES, g_batch_queues);
+  /* test hook: MK_BATCH_TAB_BITS=<9..22> gives every file of a batch a table of that size (MK_OPT_BATCH_TAB_BITS), so that files
+   * overflow it and take the sketched-alone path of mk_sketch_batch_end */
+  if (getenv("MK_BATCH_TAB_BITS")) mk_engine_set_option(e, MK_OPT_BATCH_TAB_BITS, atoi(getenv("MK_BATCH_TAB_BITS")));
 }
 
 static mk_engine *engine_get(ctx_t *c) {
@@ -1835,7 +1836,8 @@ static int g_batch_text = 0;                     /* --batch-text: the files' TEX
 typedef struct { int first, n, batch; } bjob;    /* files [first, first + n); batch: its number among the batches, -1 = one file alone */
 typedef struct {
   strlist *files;
-  const uint64_t *fsize;
+  uint64_t *fsize;              /* per file: size when the batches were planned; a reader that meets EOF earlier writes what it got */
+  uint8_t *grew;                /* per file: there are bytes behind that size -- the file is sketched alone, from all of its text */
   bjob *jobs; int njobs;
   uint8_t *buf[BATCH_BUFS_MAX]; size_t bufcap; int nbufs;
   uint64_t *foff;               /* offset of every file inside its batch's buffer */
@@ -1885,16 +1887,26 @@ static void *breader_run(void *arg) {
     if (err) ;
     else if (fd < 0) err = errno ? errno : EIO;
     else {
+      /* to EOF, like the reference and the file-by-file driver (zcat -fc | fread: iseq2comem.c:226-233), within the file's place:
+       * a file that SHRANK since the batches were planned is what it is now; one that GREW cannot travel in its place and is
+       * sketched alone (the batch carries its first bytes along, their result is dropped) */
       uint64_t got = 0;
       while (got < r->fsize[i]) {
         const ssize_t n = pread(fd, dst + got, (size_t)(r->fsize[i] - got), (off_t)got);
-        if (n <= 0) { err = n < 0 && errno ? errno : EIO; break; } /* (a file that shrank since it was measured) */
+        if (n < 0) { if (errno == EINTR) continue; err = errno ? errno : EIO; break; }
+        if (n == 0) break;
         got += (uint64_t)n;
+      }
+      if (!err) {
+        uint8_t probe;
+        if (got < r->fsize[i]) r->fsize[i] = got;
+        else if (pread(fd, &probe, 1, (off_t)got) > 0) { r->grew[i] = 1; r->fsize[i] = 0; } /* an empty member of its batch */
       }
       close(fd);
     }
     tr1 = now_s();
-    if (r->rows_TL && !err) {
+    if (r->rows_TL && !err && r->grew[i]) r->nrows[i] = 0;
+    else if (r->rows_TL && !err) {
       /* the walk and the packing here, on this thread (what the file leaves free of its place is never looked at) */
       uint64_t got_rows = 0;
       int prc = mk_fasta_pack_rows(txt, (size_t)r->fsize[i], r->rows_TL, r->rows_format, place, r->slot_rows[i], &got_rows);
@@ -1966,7 +1978,6 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--engines") && i + 1 < argc) engines_per_gpu = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--allow-device-copies")) allow_copies = 1;
     else if (!strcmp(argv[i], "--no-batch")) g_no_batch = 1; /* genome directories file by file (the driver of round 3) */
-    else if (!strcmp(argv[i], "--batch-queues") && i + 1 < argc) { g_batch_queues = atoi(argv[++i]); if (g_batch_queues != 1 && g_batch_queues != 2) die("--batch-queues takes 1 or 2"); }
     else if (!strcmp(argv[i], "--batch-narrow")) g_batch_narrow = 1; /* rows of 152 bases (the FASTQ framers' format) instead of wide rows of 240 */
     else if (!strcmp(argv[i], "--batch-text")) g_batch_text = 1; /* batches of FASTA TEXT (the device walks it) instead of rows packed by the readers */
     else if (!strcmp(argv[i], "--batch-mib") && i + 1 < argc) g_batch_bytes = (size_t)atoi(argv[++i]) << 20;
@@ -2071,6 +2082,14 @@ int main(int argc, char **argv) {
       if (fst.st_size <= 0 || (size_t)fst.st_size > BATCH_FILE_MAX || (size_t)fst.st_size > g_batch_bytes) continue;
       fsize[i] = (uint64_t)fst.st_size; elig[i] = 1; n_elig++;
     }
+    /* test hook (tests/test_golden.py): MK_TEST_PLAN_SKEW="<m>:<d>" plans every m-th file with a size off by d bytes, i.e. as if
+     * the file had grown (d < 0) or shrunk (d > 0) between this stat() and the readers' pread() */
+    if (getenv("MK_TEST_PLAN_SKEW")) {
+      int m = 0; long d = 0;
+      if (sscanf(getenv("MK_TEST_PLAN_SKEW"), "%d:%ld", &m, &d) == 2 && m > 0)
+        for (int i = 0; i < files.n; i += m)
+          if (elig[i] && (d > 0 || fsize[i] > (uint64_t)(-d))) fsize[i] = (uint64_t)((long)fsize[i] + d);
+    }
   }
   const int use_batch = n_elig >= 2;
   const int n_engines = (!use_batch && !shard_files && ndev <= 1 && files.n >= 8) ? (engines_per_gpu ? engines_per_gpu : MK_DEFAULT_ENGINES) : 1;
@@ -2150,13 +2169,14 @@ int main(int argc, char **argv) {
     bjob *jobs = calloc((size_t)files.n, sizeof *jobs);
     uint64_t *foff = calloc((size_t)files.n, sizeof *foff);
     int *left = calloc((size_t)files.n, sizeof *left), *failed = calloc((size_t)files.n, sizeof *failed);
+    uint8_t *grew = calloc((size_t)files.n + 1, 1);
     /* the readers do the FASTA walk and pack (0.48 bytes a base cross PCIe instead of 1.01, and the scan kernel reads them where the
      * readers left them) wherever there is a scan kernel for packed rows; --batch-text: the text travels and the device walks it */
     const int batch_rows = !g_batch_text && mk_params_packed_ok(&P);
     const uint32_t rows_format = g_batch_narrow ? MK_ROWS_PACKED : MK_ROWS_WIDE;
     uint64_t *slot_rows = calloc((size_t)files.n, sizeof *slot_rows), *nrows_of = calloc((size_t)files.n, sizeof *nrows_of);
     uint8_t **priv = calloc((size_t)files.n, sizeof *priv);
-    if (!jobs || !foff || !left || !failed || !slot_rows || !nrows_of || !priv) die("out of memory");
+    if (!jobs || !foff || !left || !failed || !slot_rows || !nrows_of || !priv || !grew) die("out of memory");
     int njobs = 0, nbatches = 0;
     size_t bufcap = 0;
     for (int i = 0; i < files.n;) {
@@ -2182,7 +2202,7 @@ int main(int argc, char **argv) {
     }
     breader br;
     memset(&br, 0, sizeof br);
-    br.files = &files; br.fsize = fsize; br.jobs = jobs; br.njobs = njobs; br.foff = foff; br.left = left; br.failed = failed;
+    br.files = &files; br.fsize = fsize; br.grew = grew; br.jobs = jobs; br.njobs = njobs; br.foff = foff; br.left = left; br.failed = failed;
     br.rows_TL = batch_rows ? P.TL : 0; br.rows_format = rows_format; br.slot_rows = slot_rows; br.nrows = nrows_of; br.priv = priv;
     br.bufcap = (bufcap + 4096 + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1); /* whole 2 MiB granules: every buffer is pinned on its own */
     pthread_mutex_init(&br.mu, NULL);
@@ -2236,6 +2256,15 @@ int main(int argc, char **argv) {
       for (int k_ = 0; k_ < bj_->n; k_++) { \
         const char *path_ = files.v[bj_->first + k_]; \
         if (priv[bj_->first + k_]) { free(priv[bj_->first + k_]); priv[bj_->first + k_] = NULL; } \
+        if (grew[bj_->first + k_]) { /* longer than its place: alone, from the whole file, where it stands in the order */ \
+          mk_result res_; \
+          sketch_one_file(&c, &jo, bj_->first + k_, &res_, &t_finish); \
+          rc = mk_sketchdir_add(sd, path_, &res_); \
+          if (rc != MK_OK) die("writing sketch for %s failed (%d)", path_, rc); \
+          mk_result_release(c.eng, &res_); \
+          if (!quiet) printf("%d/%d decomposing %s\r", ++done_files, files.n, path_); \
+          continue; \
+        } \
         if (bres[k_].status == MK_ERR_CROWDED) die("the context space is too crowd, try rerun the program using -k%d", P.k + 1); \
         if (bres[k_].status == MK_ERR_FORMAT) die("fasta2co(): can not find seqences head start from '>' 0 (%s ends inside a header line)", path_); \
         if (bres[k_].status != MK_OK) die("sketching %s failed (%d)", path_, bres[k_].status); \

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) mk_b_layout_kernel(const mk_batch_dev b) 
       /* the map entry of virtual slot n: found, or made (with this key in it) from the first free entry of its probe sequence */
       uint32_t e = mk_b_maphash(n, b.tb);
       unsigned long long v = 0;
-      bool taken = false;
+      bool taken = false, found = false; /* found: v is the entry of virtual slot n (a legitimate entry may be 0: slot 0 held by key 0) */
       for (uint32_t pr = 0; pr <= mask; pr++) {
         v = __hip_atomic_load(&map[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v == ~0ull) {
@@ -269,12 +269,11 @@ __global__ void __launch_bounds__(256) mk_b_layout_kernel(const mk_batch_dev b) 
           if (prev == ~0ull) { taken = true; break; } /* the virtual slot was empty: this key has its place */
           v = prev;
         }
-        if ((uint32_t)(v >> 32) == n) break;
+        if ((uint32_t)(v >> 32) == n) { found = true; break; }
         e = (e + 1u) & mask;
-        v = 0;
       }
       if (taken) break;
-      if ((uint32_t)(v >> 32) != n || v == 0) { atomicOr(&b.stat[f].flags, MK_BF_REDO); break; } /* (a full map: cannot happen below key_limit) */
+      if (!found) { atomicOr(&b.stat[f].flags, MK_BF_REDO); break; } /* (a full map: cannot happen below key_limit) */
       /* occupied: judge the occupant the word names; after a failed CAS the value IT returned (see mk_layout_kernel on stale
        * first looks: occupants only ever get earlier) */
       for (;;) {
@@ -402,10 +401,18 @@ __global__ void __launch_bounds__(256) mk_b_emit_kernel(const mk_batch_dev b) {
 
 /* the batch's results to the host's pinned blocks, by the device itself: the per-file block (flags, component sizes, totals) and
  * the ids there are -- min(n_out, ids_cap) of them, 16 bytes a lane (the lists end in slack; ids_cap is a multiple of four) */
-__global__ void __launch_bounds__(256) mk_b_home_kernel(const mk_batch_dev b, uint4 *h_stat, uint32_t stat16, uint4 *h_ids, unsigned long long ids_cap) {
+/* The last 16 bytes of the status block are not the batch's: they take the ENGINE's error flags home (mk_table::err, set by a scan
+ * kernel that bailed out -- a filter that is not where the tuned loop addresses it --, which mk_sketch_batch_end would otherwise
+ * never see: it reads this block only). */
+__global__ void __launch_bounds__(256) mk_b_home_kernel(const mk_batch_dev b, uint4 *h_stat, uint32_t stat16, uint4 *h_ids, unsigned long long ids_cap,
+                                                        const uint32_t *engine_err) {
   const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
   const uint4 *st = (const uint4 *)b.stat;
-  for (uint64_t i = tid; i < stat16; i += nthreads) h_stat[i] = st[i];
+  for (uint64_t i = tid; i < stat16; i += nthreads) {
+    uint4 v = st[i];
+    if (i == stat16 - 1u) v = make_uint4(engine_err[0], 0u, 0u, 0u);
+    h_stat[i] = v;
+  }
   unsigned long long n = b.misc[1];
   if (n > b.out_cap) return;
   if (n > ids_cap) n = ids_cap;

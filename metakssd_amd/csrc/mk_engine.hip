@@ -83,7 +83,6 @@ struct mk_engine {
   bool stage_two_streams[MK_REGIONS] = {}; /* the last scan of the region ran on another stream than the copies: ev_scanned is live */
   int stage_cur = 0;
   bool direct_host = false; /* MK_OPT_DIRECT_HOST */
-  int rows160 = 0;          /* MK_OPT_ROWS160: text rows of pitch 160 through mk_scan_rows160_kernel (rows in registers, no LDS tile) */
   bool region_open = false;
   size_t region_fill = 0;
   uint32_t region_stride = 0;
@@ -130,21 +129,6 @@ struct mk_engine {
   struct mk_bctx *bctx[3] = {nullptr, nullptr, nullptr};
   uint64_t batch_begun = 0, batch_ended = 0;
   int batch_tb_opt = 0;                /* MK_OPT_BATCH_TAB_BITS: 0 = by the largest file of the batch */
-  /* a second queue for every other batch (MK_OPT_BATCH_QUEUES 2; default 1): the scan of batch i + 1 reads its rows over the link
-   * while the table / layout / dump kernels of batch i run -- on one queue the link idles behind every scan.  Made by a thread of
-   * its own at the first batch (8-9 ms: tools/probe_second_queue.hip), used from the batch at which it is there; candidate buffers
-   * of its own.  Built, parity-green and MEASURED SLOWER (profiles/r04_d_config5_two_queues.txt: 1 024 genomes in 0.116-0.131 s
-   * against 0.103-0.109 at L3K10, 0.137-0.151 against 0.130-0.136 at L2K11): in pairs the batches still take 0.8 ms each -- two
-   * scans share the link, and what the second queue hides of the other kernels it costs in being made beside the first batches
-   * (their begins take 17-24 ms instead of 2) -- so it stays an option. */
-  int batch_queues_opt = 1;
-  hipStream_t lane_stream = nullptr;
-  uint4 *lane_cand = nullptr;
-  uint32_t *lane_cand_count = nullptr;
-  uint32_t lane_cand_cap = 0;
-  pthread_t lane_th;
-  bool lane_th_started = false;
-  int lane_state = 0;                  /* 0 not asked for, 1 being made, 2 there, 3 failed (atomic accesses) */
   const mk_batch_dev *cur_batch = nullptr; /* set around the scan launches of a batch */
 
   int mode = -1;
@@ -293,10 +277,7 @@ static void mk_bctx_free(struct mk_bctx *c);
 extern "C" int mk_engine_destroy(mk_engine *e) {
   if (!e) return MK_ERR_ARG;
   hipSetDevice(e->device);
-  if (e->lane_th_started) { pthread_join(e->lane_th, nullptr); e->lane_th_started = false; }
   hipDeviceSynchronize();
-  if (e->lane_stream) hipStreamDestroy(e->lane_stream);
-  hipFree(e->lane_cand); hipFree(e->lane_cand_count);
   hipFree(e->d_pairs);
   hipFree(e->d_cand); hipFree(e->d_cand_count);
   hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_accept_bits); hipFree(e->d_tab); hipFree(e->d_front); hipFree(e->d_front_desc); hipFree(e->d_slot);
@@ -620,14 +601,6 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
     case MK_OPT_DIRECT_HOST:
       e->direct_host = value != 0;
       return MK_OK;
-    case MK_OPT_ROWS160:
-      e->rows160 = value != 0;
-      return MK_OK;
-    case MK_OPT_BATCH_QUEUES:
-      if (value != 1 && value != 2) return mk_fail(e, MK_ERR_ARG, "MK_OPT_BATCH_QUEUES takes 1 or 2");
-      if (e->batch_begun != e->batch_ended) return mk_fail(e, MK_ERR_STATE, "MK_OPT_BATCH_QUEUES while a batch is in flight");
-      e->batch_queues_opt = (int)value;
-      return MK_OK;
     case MK_OPT_BATCH_TAB_BITS:
       if (value != 0 && (value < 9 || value > 22)) return mk_fail(e, MK_ERR_ARG, "MK_OPT_BATCH_TAB_BITS takes 0 (by file size) or 9..22");
       if (e->batch_begun != e->batch_ended) return mk_fail(e, MK_ERR_STATE, "MK_OPT_BATCH_TAB_BITS while a batch is in flight");
@@ -688,7 +661,6 @@ extern "C" int mk_engine_sync(mk_engine *e) {
   { int rc = mk_flush_region(e); if (rc) return rc; }
   if (e->copy_stream != e->stream) MK_HIP(e, hipStreamSynchronize(e->copy_stream));
   MK_HIP(e, hipStreamSynchronize(e->stream));
-  if (__atomic_load_n(&e->lane_state, __ATOMIC_ACQUIRE) == 2) MK_HIP(e, hipStreamSynchronize(e->lane_stream));
   return MK_OK;
 }
 
@@ -915,10 +887,7 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   hipError_t r;
-  /* text rows of pitch 160 (150-base reads) may take the kernel that keeps a lane's row in registers (MK_OPT_ROWS160) */
-  const bool r160 = !packed && e->rows160 && tuned_k && stride == 160u && pitch == 160u && rowlen == 0u && !nreads_dev && vec;
-  if (r160) { threads = 1024; lds = ((size_t)a.mt_words + (size_t)a.bm_words) * 4u; }
-  if (packed || r160) {
+  if (packed) {
     auto launch_packed = [&](auto kern) -> hipError_t {
       const void *fn = (const void *)kern;
       size_t *granted = nullptr;
@@ -937,16 +906,11 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
       case 106: r = launch_packed(mk_scan_packed_kernel<10, 6, true>); break;
       case 96: r = launch_packed(mk_scan_packed_kernel<9, 6, true>); break;
       default: r = launch_packed(mk_scan_packed_kernel<11, 5, true>); break;
-    } else if (packed) switch (tuned_k * 10 + e->P.subk) {
+    } else switch (tuned_k * 10 + e->P.subk) {
       case 116: r = launch_packed(mk_scan_packed_kernel<11, 6>); break;
       case 106: r = launch_packed(mk_scan_packed_kernel<10, 6>); break;
       case 96: r = launch_packed(mk_scan_packed_kernel<9, 6>); break;
       default: r = launch_packed(mk_scan_packed_kernel<11, 5>); break;
-    } else switch (tuned_k * 10 + e->P.subk) {
-      case 116: r = launch_packed(mk_scan_rows160_kernel<11, 6>); break;
-      case 106: r = launch_packed(mk_scan_rows160_kernel<10, 6>); break;
-      case 96: r = launch_packed(mk_scan_rows160_kernel<9, 6>); break;
-      default: r = launch_packed(mk_scan_rows160_kernel<11, 5>); break;
     }
   } else
   switch (tuned_k * 10 + (tuned_k ? e->P.subk : 0)) {
@@ -1003,6 +967,7 @@ static int mk_check_push(mk_engine *e, const void *rows, uint32_t stride) {
   if (stride & MK_ROWS_PACKED) { /* 64-byte packed rows: the tuned geometries only (their loop takes eight bases in 16 bits) */
     if (stride != (MK_PACKED_PITCH | MK_ROWS_PACKED)) return mk_fail(e, MK_ERR_ARG, "push: packed rows have a pitch of %u bytes", MK_PACKED_PITCH);
     if (!mk_params_packed_ok(&e->P)) return mk_fail(e, MK_ERR_ARG, "push: packed rows need a geometry with a tuned scan kernel (mk_params_packed_ok)");
+    if (!rows) return mk_fail(e, MK_ERR_ARG, "push: rows == NULL");
     if ((uintptr_t)rows & 15u) return mk_fail(e, MK_ERR_ARG, "push: packed rows must be 16-byte aligned");
     return MK_OK;
   }
@@ -1170,7 +1135,10 @@ static int mk_fa_reserve(mk_engine *e, size_t n) {
     MK_HIP(e, hipMemset(e->d_fa_state, 0, sizeof(mk_fa_state)));
     MK_HIP(e, hipHostMalloc((void **)&e->h_fa_state, sizeof(mk_fa_state), hipHostMallocDefault));
   }
-  if (n > e->text_cap || !e->d_stream) { /* (also the first piece of all being empty: the buffers must exist) */
+  /* whole segments: the last wave of a piece loads MK_FA_SEG bytes from its segment's start (mk_fa_stage), so the text buffer holds
+   * the piece rounded up to a segment */
+  const size_t nround = ((n + MK_FA_SEG - 1) / MK_FA_SEG) * MK_FA_SEG;
+  if (nround > e->text_cap || !e->d_stream) { /* (also the first piece of all being empty: the buffers must exist) */
     MK_HIP(e, hipStreamSynchronize(e->stream)); /* kernels of earlier pieces may still read the old buffers */
     const size_t cap = n + n / 4 + ((size_t)1 << 20);
     uint8_t *nt = nullptr, *ns = nullptr, *ntmp = nullptr;
@@ -1886,34 +1854,9 @@ static uint64_t mk_rows_per_launch(const mk_engine *e, uint32_t row_bases, int t
   return (uint64_t)rows / 64u * 64u;
 }
 
-/* the second queue and its candidate buffers (mk_engine::lane_*), made beside the first batches */
-static void *mk_lane_make(void *arg) {
-  mk_engine *e = (mk_engine *)arg;
-  hipStream_t s = nullptr;
-  uint4 *cand = nullptr;
-  uint32_t *cnt = nullptr;
-  const uint32_t cap = e->cand_cap, slots = e->cand_slots;
-  bool ok = hipSetDevice(e->device) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess &&
-            hipMalloc((void **)&cand, (size_t)slots * (cap + 1) * sizeof(uint4)) == hipSuccess && hipMalloc((void **)&cnt, (size_t)slots * sizeof(uint32_t)) == hipSuccess;
-  if (ok) {
-    hipLaunchKernelGGL(mk_fill16_kernel, dim3(4), dim3(256), 0, s, (uint4 *)cnt, (unsigned long long)slots / 4ull, 0u);
-    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-  }
-  if (!ok) {
-    (void)hipGetLastError();
-    if (s) hipStreamDestroy(s);
-    hipFree(cand); hipFree(cnt);
-    __atomic_store_n(&e->lane_state, 3, __ATOMIC_RELEASE);
-    return nullptr;
-  }
-  e->lane_stream = s; e->lane_cand = cand; e->lane_cand_count = cnt; e->lane_cand_cap = cap;
-  __atomic_store_n(&e->lane_state, 2, __ATOMIC_RELEASE);
-  return nullptr;
-}
-
 /* rows: the files are PACKED ROWS already (mk_fasta_pack_rows on the reader's thread: the FASTA walk done by the host) -- no text,
  * no mk_fab_* kernels; where the rows lie in ONE stretch of pinned memory the scan kernel reads them THERE, through the mapping
- * (tools/probe_hostread.hip: a kernel reads registered host memory at 55.5 GB/s, the copy engine moves it at 57.0 and costs 7.7 ms
+ * (tools/attic/probe_hostread.hip: a kernel reads registered host memory at 55.5 GB/s, the copy engine moves it at 57.0 and costs 7.7 ms
  * of set-up at the first copy of a process) */
 static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles, const uint32_t format) {
   if (!e || !files) return MK_ERR_ARG;
@@ -2040,11 +1983,12 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   }
   const uint32_t bpf = bpc * C;
   const uint64_t nb = (uint64_t)nfiles * bpf;
-  c->stat_bytes = mk_up16((size_t)nfiles * sizeof(mk_bstat)) + mk_up16((size_t)nfiles * C * 4) + 16;
+  c->stat_bytes = mk_up16((size_t)nfiles * sizeof(mk_bstat)) + mk_up16((size_t)nfiles * C * 4) + 16 + 16; /* .. | misc[2] | the engine's error flags (mk_b_home_kernel) */
   const size_t zero_bytes = (size_t)N * 16 + mk_up16((size_t)(nb + 1) * 4) + c->stat_bytes + (size_t)nfiles * 64;
   static const bool trace = getenv("MK_BATCH_TRACE") != nullptr;
   const double tr0 = trace ? mk_tick_now() : 0.0;
-  if (!rows && (rc = mk_dbuf_fit(e, c->text, (size_t)text_span + 256))) return rc;
+  /* whole segments: a wave stages MK_FA_SEG bytes with one load per lane whatever the segment's last byte is (mk_fa_stage) */
+  if (!rows && (rc = mk_dbuf_fit(e, c->text, (((size_t)text_span + MK_FA_SEG - 1) / MK_FA_SEG) * MK_FA_SEG + 256))) return rc;
   if (!rows_dev && (rc = mk_dbuf_fit(e, c->stream, (size_t)soff + 8192))) return rc;
   if (!rows && (rc = mk_dbuf_fit(e, c->sum, (size_t)nseg_total * sizeof(mk_fa_sum)))) return rc;
   if ((rc = mk_dbuf_fit(e, c->zero, zero_bytes))) return rc;
@@ -2089,21 +2033,6 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   c->mode = mode; c->nfiles = nfiles; c->rows = rows; c->format = format; c->rows_src = rows ? (rows_dev ? rows_dev : (const uint8_t *)c->stream.p) : nullptr;
   c->files.assign(files, files + nfiles);
   const mk_batch_dev *dbatch = (const mk_batch_dev *)dd;
-  /* every other batch on the second queue, once it is there (the engine's own stream only: a caller's stream orders the caller's work) */
-  bool lane = false;
-  if (e->batch_queues_opt == 2 && e->stream == e->own_stream) {
-    const int st = __atomic_load_n(&e->lane_state, __ATOMIC_ACQUIRE);
-    if (st == 0) {
-      __atomic_store_n(&e->lane_state, 1, __ATOMIC_RELEASE);
-      if (pthread_create(&e->lane_th, nullptr, mk_lane_make, e) == 0) e->lane_th_started = true;
-      else __atomic_store_n(&e->lane_state, 3, __ATOMIC_RELEASE);
-    } else if (st == 2 && e->lane_cand_cap == e->cand_cap && (e->batch_begun & 1u)) lane = true;
-  }
-  struct lane_swap { /* the launch helpers below take queue and candidate buffers from the engine: swapped for this batch, put back on every way out */
-    mk_engine *e; hipStream_t s; uint4 *c; uint32_t *n; bool on;
-    ~lane_swap() { if (on) { e->stream = s; e->copy_stream = s; e->d_cand = c; e->d_cand_count = n; } }
-  } swap_back{e, e->stream, e->d_cand, e->d_cand_count, lane};
-  if (lane) { e->stream = e->lane_stream; e->copy_stream = e->lane_stream; e->d_cand = e->lane_cand; e->d_cand_count = e->lane_cand_count; }
   hipStream_t s = e->stream;
   c->used_stream = s;
 
@@ -2174,7 +2103,7 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   c->spec_ids = N / 2u < ((uint64_t)8 << 20) ? N / 2u : ((uint64_t)8 << 20);
   if ((rc = mk_pinned_fit(e, (void **)&c->h_ids, &c->h_ids_cap, (size_t)c->spec_ids * 4))) return rc;
   hipLaunchKernelGGL(mk_b_home_kernel, dim3((unsigned)e->num_cu), dim3(256), 0, s, c->hb, (uint4 *)c->h_stat, (uint32_t)(c->stat_bytes / 16u), (uint4 *)c->h_ids,
-                     (unsigned long long)c->spec_ids);
+                     (unsigned long long)c->spec_ids, (const uint32_t *)e->tab.err);
   MK_HIP(e, hipGetLastError());
   MK_HIP(e, hipEventRecord(c->ev_stat, s));
   tick("copies home queued");
@@ -2204,6 +2133,9 @@ extern "C" int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out) {
   const uint32_t *ctot = (const uint32_t *)((const uint8_t *)c->h_stat + mk_up16((size_t)nfiles * sizeof(mk_bstat)));
   const unsigned long long *misc = (const unsigned long long *)((const uint8_t *)ctot + mk_up16((size_t)nfiles * C * 4));
   const uint64_t n_out = misc[1];
+  /* a scan kernel of this batch gave up (it sets mk_table::err and returns: the sketches would be empty or partial) */
+  if ((uint32_t)misc[2] & 4u) return mk_fail(e, MK_ERR_HIP, "batch: scan kernel: LDS filter not at offset 0");
+  if ((uint32_t)misc[2] & ~(1u | 2u | 8u)) return mk_fail(e, MK_ERR_HIP, "batch: a kernel of the batch reported error flags 0x%x", (unsigned)misc[2]);
   if (n_out > c->hb.out_cap || misc[0] > c->hb.list_cap) return mk_fail(e, MK_ERR_HIP, "batch: %llu keys, %llu ids for lists of %llu", misc[0], (unsigned long long)n_out, (unsigned long long)c->hb.list_cap);
   int rc = MK_OK;
   const bool more_ids = n_out > c->spec_ids; /* more than came with the batch's own sequence: the rest now */

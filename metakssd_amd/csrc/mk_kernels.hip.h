@@ -643,7 +643,7 @@ __device__ __forceinline__ void mk_build_filter(uint32_t *bitmap, const mk_scan_
 
 /* ONEPASS (only with exactly two column blocks per row): the loads for BOTH blocks of a tile are issued together,
  * so every 64-byte sector of the rows is requested once -- two separate 80-byte passes re-fetch the sector the
- * halves share (+37 % HBM reads, tools/ubench_fetch.hip).  Costs NPIECES more piece registers. */
+ * halves share (+37 % HBM reads, tools/attic/ubench_fetch.hip).  Costs NPIECES more piece registers. */
 template <int K, int SUBK, bool VEC16, int THREADS, int NPIECES, bool ONEPASS>
 __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) {
   static_assert(K == 0 || SUBK == 6 || (SUBK == 5 && K == 11), "tuned instantiations: k 9..11 with subk 6, k 11 with subk 5");
@@ -959,7 +959,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
          * TL bytes up to it are bases of one row.  The first version of B was the byte-wise predicated path of the generic
          * kernel, entered for the rest of the row: 50 M reads trimmed to 100..150 bases 4.6 -> 2.4 ms, an N in 1 % of the
          * reads 4.5 -> 2.24 ms, in 5 % 7.6 -> 2.5 ms, and the untouched rows 2.28 -> 2.14 ms on the same box (the kernel
-         * lost the byte-wise path, its registers and its spills) (tools/probe_ragged_reads.py). */
+         * lost the byte-wise path, its registers and its spills) (tools/attic/probe_ragged_reads.py). */
         constexpr uint32_t SH = 2u * (K - SUBK) - 2u; /* out2 - 2 */
         constexpr uint32_t HM = mk_kmer<K>::HMASK;
         static_assert(SH + 4u * SUBK <= 32u, "inner substring must lie inside flo(j-1)");

@@ -222,150 +222,3 @@ __global__ void __launch_bounds__(1024) mk_scan_packed_kernel(const mk_scan_args
   }
   if (lane == 0) a.cand_count[wave_global] = qn;
 }
-
-/* ---- text rows of 160 bytes WITHOUT the LDS tile: mk_scan_rows160_kernel ---------------------------------------------------------
- * What mk_scan_packed_kernel showed (1.38 ms per 50 M reads against 2.02 ms for the text kernel): a third of the text kernel's time
- * goes into getting a row in front of its lane -- coalesced 16-byte loads, 40 ds_write_b32 and 15 offset reads a tile, an odd row
- * pitch in LDS, a ds_read2_b32 per window.  Here a lane loads ITS row itself, ten 16-byte pieces at 160-byte distance (every byte
- * a lane fetches is its own: the 128-byte lines are shared by the ten loads of one or two lanes, not across the wave), five
- * pieces -- an 80-byte half row, ten 8-base windows -- at a time in registers while the next five are on their way.  No LDS for the
- * rows at all, the filter alone is resident.  The windows' logic is mk_scan_kernel's tuned loop one to one (iseq2comem.c:682-690 per
- * lane): body A while the live lanes are in step and every byte of the window is a base, body B per lane otherwise; written out per
- * window because the row's registers are named by constants.  Rows: pitch 160, '\n'-terminated or 160 bytes long. */
-#define MK_R160_PITCH 160u
-
-template <int K, int SUBK>
-__global__ void __launch_bounds__(1024) mk_scan_rows160_kernel(const mk_scan_args a) {
-  extern __shared__ __align__(16) uint32_t lds[];
-  constexpr uint32_t WAVES = 16u;
-  constexpr uint32_t MTW = SUBK == 6 ? MK_ZMASK_WORDS : 0u;
-  constexpr uint32_t SH = 2u * (K - SUBK) - 2u;
-  constexpr uint32_t D = SUBK == 6 ? (SH - 2u) / 2u : 1u;
-  constexpr uint32_t TL = 2u * K;
-  uint32_t *bitmap = lds + MTW;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if constexpr (SUBK == 6) mk_build_zfilter(lds, bitmap, a);
-  else mk_build_xfilter(bitmap, a);
-  const uint32_t wave_global = blockIdx.x * WAVES + wave, nwaves = gridDim.x * WAVES;
-  const uint32_t filter_base = (uint32_t)(uintptr_t)(mk_lds_cu32)bitmap;
-  if (filter_base != MTW * 4u || a.mt_words != MTW || a.bm_words != 16384u || a.dimmask != (SUBK == 6 ? 0xFFFFFFu : 0xFFFFFu)) {
-    if (threadIdx.x == 0) atomicOr(&a.tab.err[0], 4u);
-    if (lane == 0) a.cand_count[wave_global] = 0u;
-    return;
-  }
-  const mk_scan_args *ka = (const mk_scan_args *)__builtin_amdgcn_kernarg_segment_ptr();
-  const uint64_t nreads = a.nreads;
-  const uint32_t ntiles = (uint32_t)((nreads + 63u) >> 6);
-  uint4 *const my_cand = a.cand + (size_t)__builtin_amdgcn_readfirstlane(wave_global) * a.cand_cap;
-  if (wave_global >= ntiles) {
-    if (lane == 0) a.cand_count[wave_global] = 0u;
-    return;
-  }
-  uint32_t qn = 0;
-  auto push_pair = [&](const bool hit, const uint64_t hm, const uint4 r) {
-    const uint32_t cnt = (uint32_t)__popcll(hm);
-    if (qn + cnt > a.cand_cap) { mk_resolve_inline(ka, hit, r, nullptr); return; }
-    if (hit) *(uint4 *)((uint8_t *)my_cand + (qn + mk_mbcnt(hm)) * 16u) = r;
-    qn += cnt;
-  };
-  /* unit u = half `u & 1` of tile wave_global + (u >> 1) * nwaves; a row that does not exist reads as newlines */
-  const uint4 nl4 = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
-  auto load_half = [&](uint32_t tile, uint32_t half, uint4 (&r)[5]) {
-    const uint64_t row = ((uint64_t)tile << 6) + lane;
-    if (row < nreads) {
-      const uint4 *p = (const uint4 *)(a.rows + row * MK_R160_PITCH + half * 80u);
-#pragma unroll
-      for (int i = 0; i < 5; i++) r[i] = p[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 5; i++) r[i] = nl4;
-    }
-  };
-  uint4 nx[5];
-  load_half(wave_global, 0u, nx);
-  uint32_t flo = 0u, hh = 0u, run = 0u, urun = 0u;
-  uint32_t pa[3] = {0u, 0u, 0u};
-  bool done = false, step = true;
-  uint64_t donem = 0ull;
-  for (uint32_t tile = wave_global; tile < ntiles; tile += nwaves) {
-    const uint32_t rowidx = (tile << 6) + lane;
-#pragma unroll 1
-    for (uint32_t half = 0; half < 2u; half++) {
-      const uint4 c0 = nx[0], c1 = nx[1], c2 = nx[2], c3 = nx[3], c4 = nx[4];
-      if (half == 0u) load_half(tile, 1u, nx);
-      else if (tile + nwaves < ntiles) load_half(tile + nwaves, 0u, nx);
-      const uint32_t dw[20] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w, c4.x, c4.y, c4.z, c4.w};
-      auto oh_init = [&]() {
-        if constexpr (SUBK == 6) {
-#pragma unroll
-          for (uint32_t k = 0; k < D; k++) pa[k] = (flo >> (2u * (D - k))) & 0x3FCu;
-        } else pa[0] = flo >> 2;
-      };
-      auto in_step = [&]() -> bool { /* sets urun; needs a live lane */
-        const uint32_t rc = min(run, TL);
-        urun = __builtin_amdgcn_readlane(rc, (int)__builtin_ctzll(~donem & __builtin_amdgcn_read_exec()));
-        return __all(done || rc == urun);
-      };
-      if (half == 0u) { /* a new row */
-        flo = 0u; hh = 0u; run = 0u; urun = 0u;
-        done = (uint64_t)rowidx >= nreads;
-        donem = __ballot(done);
-        step = true; /* every live lane starts with an empty window */
-        oh_init();
-      }
-      if (donem == __builtin_amdgcn_read_exec()) continue;
-      mk_unrolled_windows([&](auto pc) {
-        constexpr uint32_t p = decltype(pc)::value;
-        if (donem != __builtin_amdgcn_read_exec()) {
-          const uint32_t w0 = dw[2u * p], w1 = dw[2u * p + 1u];
-          /* decode(): scan coding (byte >> 1) & 3; a byte is a base <=> folded to upper case it is the letter of its code */
-          const uint32_t cd0 = (w0 >> 1) & 0x03030303u, cd1 = (w1 >> 1) & 0x03030303u;
-          const uint32_t x0 = (w0 & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, cd0);
-          const uint32_t x1 = (w1 & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, cd1);
-          const uint32_t lo = __builtin_amdgcn_perm(__builtin_amdgcn_udot4(cd0, 0x01041040u, 0u, false),
-                                                    __builtin_amdgcn_udot4(cd1, 0x01041040u, 0u, false), 0x04000C0Cu);
-          const uint32_t pos8 = half * 10u + p; /* window index in the row: its first base is byte 8 * pos8 */
-          auto body = [&](const bool rollonly, const uint32_t jmin, const uint32_t e, const bool live, const uint64_t livem) {
-            const uint32_t fstart = flo;
-            if (rollonly) {
-              flo = __builtin_amdgcn_alignbit(fstart, lo, 16);
-              oh_init();
-            } else {
-              const bool fired = mk_probe8<K, SUBK>(fstart, lo, pa, flo);
-              const bool hit = fired && live;
-              const uint64_t hm = __builtin_amdgcn_ballot_w64(fired) & livem;
-              if (hm) push_pair(hit, hm, make_uint4(fstart, (lo & 0xFFFF0000u) | pos8 | (jmin << 9) | (e << 12), hh, rowidx));
-            }
-            hh = __builtin_amdgcn_perm(hh, fstart, 0x05040100u);
-          };
-          bool in_a = false;
-          if (step) { /* ---- A: the live lanes in step, every byte of the window a base */
-            const uint64_t bad = ((uint64_t)x1 << 32) | x0;
-            uint64_t lanes_ok;
-            asm("v_cmp_eq_u64_e64 %0, 0, %1" : "=s"(lanes_ok) : "v"(bad));
-            if ((lanes_ok | donem) == __builtin_amdgcn_read_exec()) {
-              in_a = true;
-              const bool full = urun + 1u >= TL;
-              body(!full && urun + 8u < TL, full ? 0u : (TL - 1u - urun) & 7u, 8u, !done, ~donem);
-              urun = urun + 8u > 0xFFFFu ? 0xFFFFu : urun + 8u;
-            } else run = urun; /* the lanes' own counters take over */
-          }
-          if (!in_a) { /* ---- B: per lane */
-            const uint64_t inval = ((uint64_t)mk_nonzero_bytes(x1) << 32) | mk_nonzero_bytes(x0);
-            const uint64_t nlm = ((uint64_t)(mk_nonzero_bytes(w1 ^ 0x0A0A0A0Au) ^ 0x80808080u) << 32) | (mk_nonzero_bytes(w0 ^ 0x0A0A0A0Au) ^ 0x80808080u);
-            const uint32_t e = inval ? (uint32_t)__builtin_ctzll(inval) >> 3 : 8u;
-            const uint32_t jm = run + 1u >= TL ? 0u : TL - 1u - run;
-            const bool say = !done && jm < e;
-            body(false, jm & 7u, e, say, __builtin_amdgcn_ballot_w64(say));
-            run = inval ? (uint32_t)__builtin_clzll(inval) >> 3 : min(run + 8u, 0xFFFFu);
-            done = done || nlm != 0ull;
-            donem = __ballot(done);
-            if (donem != __builtin_amdgcn_read_exec()) step = in_step();
-          }
-        }
-      }, std::make_integer_sequence<uint32_t, 10u>{});
-      if (step && donem != __builtin_amdgcn_read_exec()) run = urun; /* (kept consistent across the halves) */
-    }
-  }
-  if (lane == 0) a.cand_count[wave_global] = qn;
-}

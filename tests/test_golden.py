@@ -149,7 +149,10 @@ REF_HIP = os.path.join(ROOT, "oracle", "_ref_hip", "metakssd")
 def test_product_cli_batches_with_files_that_cannot_travel_in_one(shuf, flags, shuf_files, tmp_path):
     """a directory whose FASTA files go to the device in batches, with files in between that cannot (a .gz genome, a FASTQ file):
     those are sketched alone in their place in the input order; the directory is the one `--no-batch` (file by file) writes, also
-    with batches of two files and of 1 MiB"""
+    with batches of two files and of 1 MiB; with files that GREW or SHRANK between the planning stat() and the readers' pread()
+    (MK_TEST_PLAN_SKEW: a grown file is sketched alone from all of its text, a shrunk one is what it is now -- both read to EOF like
+    the reference's zcat -fc | fread, iseq2comem.c:226-233); and with 512-slot tables per file (MK_BATCH_TAB_BITS=9), which send most
+    files to the sketched-alone path of mk_sketch_batch_end while the next batch is queued"""
     import gzip
     import numpy as np
     import util_inputs as ui
@@ -172,14 +175,18 @@ def test_product_cli_batches_with_files_that_cannot_travel_in_one(shuf, flags, s
             open(str(d / ("g%02d.fna" % i)), "wb").write(fa)
     base = [PRODUCT_CLI, "dist", "-L", shuf_files(shuf)] + flags
     outs = {}
-    for tag, extra in (("batches", []), ("file_by_file", ["--no-batch"]), ("pairs", ["--batch-files", "2"]), ("one_mib", ["--batch-mib", "1", "-p", "3"]),
-                       ("text", ["--batch-text"]), ("narrow", ["--batch-narrow"])):
+    variants = (("batches", [], {}), ("file_by_file", ["--no-batch"], {}), ("pairs", ["--batch-files", "2"], {}), ("one_mib", ["--batch-mib", "1", "-p", "3"], {}),
+                ("text", ["--batch-text"], {}), ("narrow", ["--batch-narrow"], {}),
+                ("grew", ["--batch-files", "3"], {"MK_TEST_PLAN_SKEW": "2:-301"}), ("grew_text", ["--batch-text"], {"MK_TEST_PLAN_SKEW": "3:-17"}),
+                ("shrank", [], {"MK_TEST_PLAN_SKEW": "2:4099"}), ("shrank_text", ["--batch-text", "--batch-files", "4"], {"MK_TEST_PLAN_SKEW": "3:1000"}),
+                ("tiny_tables", ["--batch-files", "3"], {"MK_BATCH_TAB_BITS": "9"}), ("tiny_tables_text", ["--batch-text", "--batch-files", "4"], {"MK_BATCH_TAB_BITS": "9"}))
+    for tag, extra, env in variants:
         out = str(tmp_path / tag)
-        r = subprocess.run(base + extra + ["-o", out, str(d)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        assert r.returncode == 0, r.stderr.decode()
+        r = subprocess.run(base + extra + ["-o", out, str(d)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert r.returncode == 0, (tag, r.stderr.decode())
         outs[tag] = out
     ref = outs["file_by_file"]
-    for tag in ("batches", "pairs", "one_mib", "text", "narrow"):
+    for tag in [v[0] for v in variants if v[0] != "file_by_file"]:
         assert sorted(os.listdir(outs[tag])) == sorted(os.listdir(ref)), tag
         for f in sorted(os.listdir(ref)):
             if f == "cofiles.stat":

@@ -319,20 +319,18 @@ def test_packed_rows_equal_oracle(capi, engine_for, shufs, oracle_for, name):
 
 
 @pytest.mark.parametrize("name", ["L3K11", "L3K10", "L3K9", "L2K11"])
-def test_rows160_kernel_equals_oracle(capi, shufs, oracle_for, name):
-    """MK_OPT_ROWS160: text rows of pitch 160 through mk_scan_rows160_kernel (a lane loads its own row into registers, no LDS tile):
-    the benchmark's rows, ragged rows with N / lower case / odd bytes / rows of 159 and 160 bases (no newline), a last tile of
-    fewer than 64 rows, several pushes -- the oracle's sketch, and so mk_scan_kernel's"""
+def test_text_rows_pitch160_ragged_equal_oracle(capi, shufs, oracle_for, name):
+    """text rows of pitch 160 (the benchmark's layout) through mk_scan_kernel: the benchmark's rows, ragged rows with N / lower case /
+    odd bytes / rows of 159 and 160 bases (no newline), a last tile of fewer than 64 rows, several pushes -- the oracle's sketch"""
     rs = np.random.RandomState(62)
     ora = oracle_for(shufs(name))
     eng = capi.Engine(shufs(name), 0)
     try:
-        eng.set_option(capi.MK_OPT_ROWS160, 1)
         rows = capi.synth_rows_host(6, 0, 30011, 150, 160)
         rc, want = ora.koc_from_rows(rows, 160)
         assert rc == 0
         for pushes in (1, 4):
-            assert_same(run_koc(capi, eng, rows, 160, pushes), want, "%s rows160 uniform pushes=%d" % (name, pushes))
+            assert_same(run_koc(capi, eng, rows, 160, pushes), want, "%s pitch 160 uniform pushes=%d" % (name, pushes))
         g = ui.rand_seq(rs, 50000)
         n = 20037
         rows = np.zeros(n * 160, dtype=np.uint8)
@@ -353,10 +351,8 @@ def test_rows160_kernel_equals_oracle(capi, shufs, oracle_for, name):
                 rows[i * 160 + L] = 10
         rc, want = ora.koc_from_rows(rows, 160)
         assert rc == 0
-        assert_same(run_koc(capi, eng, rows, 160, 1), want, name + " rows160 ragged")
-        assert_same(run_koc(capi, eng, rows, 160, 3), want, name + " rows160 ragged, three pushes")
-        eng.set_option(capi.MK_OPT_ROWS160, 0)
-        assert_same(run_koc(capi, eng, rows, 160, 1), want, name + " the LDS-tile kernel on the same rows")
+        assert_same(run_koc(capi, eng, rows, 160, 1), want, name + " pitch 160 ragged")
+        assert_same(run_koc(capi, eng, rows, 160, 3), want, name + " pitch 160 ragged, three pushes")
     finally:
         eng.close()
 
@@ -489,19 +485,14 @@ def test_batch_of_packed_rows_equals_oracle(capi, engine_for, shufs, oracle_for,
     assert_same(eng.finish(), want[big], name + " the largest file's rows pushed alone")
 
 
-@pytest.mark.parametrize("queues", [2, 1])
 @pytest.mark.parametrize("name", ["L3K10", "L2K11"])
-def test_batches_alternate_between_two_queues(capi, shufs, oracle_for, name, queues):
-    """MK_OPT_BATCH_QUEUES: with 2 every other batch goes to a second queue once that is there, so that a batch's scan
-    runs beside the table / layout / dump kernels of the batch in front; twelve batches of rows and texts, two in flight, every file's
-    sketch the oracle's; a file that is sketched alone in between; 1 (the default): everything on the engine's queue"""
-    import time
+def test_twelve_batches_two_in_flight_rows_and_texts(capi, shufs, oracle_for, name):
+    """twelve batches of rows and texts, two in flight, every file's sketch the oracle's; a file that is sketched alone in between"""
     rs = np.random.RandomState(56)
     texts = _batch_texts(rs, True)
     ora = oracle_for(shufs(name))
     eng = capi.Engine(shufs(name), 0)
     try:
-        eng.set_option(capi.MK_OPT_BATCH_QUEUES, queues)
         TL = 2 * eng.params.k
         want = []
         for t in texts:
@@ -519,9 +510,8 @@ def test_batches_alternate_between_two_queues(capi, shufs, oracle_for, name, que
                     assert all(len(c) == 0 for c in comps) and len(comps) == ncomp
                 else:
                     assert_same([(c, None) for c in comps], want[i], "%s file %d (alone=%d)" % (label, i, alone))
-        eng.batch_begin_rows([wide[0]], capi.MK_MODE_SET, pinned=True, fmt=capi.MK_ROWS_WIDE)   # (the second queue is asked for here)
+        eng.batch_begin_rows([wide[0]], capi.MK_MODE_SET, pinned=True, fmt=capi.MK_ROWS_WIDE)
         check(eng.batch_end(), [0], "first")
-        time.sleep(0.1)                                                                                # ... and is there now
         order = list(range(len(texts)))
         pending = []
         for b in range(12):
@@ -545,7 +535,7 @@ def test_batches_alternate_between_two_queues(capi, shufs, oracle_for, name, que
             i0, l0 = pending.pop(0)
             check(eng.batch_end(), i0, l0)
         with pytest.raises(capi.MkError):
-            eng.set_option(capi.MK_OPT_BATCH_QUEUES, 3)
+            eng.set_option(9, 2)   # (MK_OPT_BATCH_QUEUES of round 4: retired, an unknown option now)
     finally:
         eng.close()
 

@@ -88,9 +88,7 @@ def main():
             desc += " stride=%d" % stride
             tuned = bool(capi.lib.mk_params_packed_ok(ctypes.byref(P)))
             packed = tuned and need <= 153 and rs.rand() < 0.5   # 64-byte packed rows (mk_scan_packed_kernel)
-            r160 = tuned and not packed and rs.rand() < 0.5        # MK_OPT_ROWS160: takes effect on rows of pitch 160
-            eng.set_option(capi.MK_OPT_ROWS160, 1 if r160 else 0)
-            desc += " packed=%d rows160=%d" % (packed, r160)
+            desc += " packed=%d" % packed
             eng.begin(capi.MK_MODE_KOC)
             pushes = int(rs.choice([1, 2, 5]))
             n = len(seqs)
