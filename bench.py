@@ -408,6 +408,62 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def leg_inproc_multi(torch, capi, shuf, devices, total_reads, steps, merge, reference_sketch):
+    """the C product's own multi-GPU path in THIS process: libmetakssd_multi.so (what `metakssd dist --devices` runs on) -- one engine
+    per listed GPU, every engine scans its contiguous read range out of its GPU's HBM, mk_multi_finish merges (RCCL grouped
+    send / recv between distinct GPUs) and finishes on the first engine"""
+    import numpy as np
+    from metakssd_amd.shard import shard_range
+    n = len(devices)
+    m = capi.Multi(shuf, devices)
+    try:
+        if merge != "auto":
+            m.set_merge(capi.MK_MULTI_MERGE_GATHER if merge == "gather" else capi.MK_MULTI_MERGE_SLICES)
+        shards = []
+        for i, d in enumerate(devices):
+            lo, hi = shard_range(total_reads, i, n)
+            t = torch.empty((hi - lo) * STRIDE, dtype=torch.uint8, device=torch.device("cuda", d))
+            capi.synth_rows_device(d, None, SEED, lo, hi - lo, READ_LEN, STRIDE, t.data_ptr())
+            shards.append((t, lo, hi - lo))
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+
+        def one():
+            m.begin(capi.MK_MODE_KOC)
+            for i, (t, lo, cnt) in enumerate(shards):
+                m.push_reads_device(i, t.data_ptr(), STRIDE, cnt, lo)
+            return m.finish_raw()
+        for _ in range(2):
+            one()
+        phases, gathers, tails = {}, [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r, g, tl = one()
+            gathers.append(g)
+            tails.append(tl)
+            for k, v in m.last_times().items():
+                phases[k] = phases.get(k, 0.0) + v
+        dt = (time.perf_counter() - t0) / steps
+        same = None
+        if reference_sketch is not None:  # the last result against the torch.distributed flow's merged sketch, ids and counts in order
+            comp = r.components[0]
+            ids = np.ctypeslib.as_array(comp.ids, shape=(comp.n,)) if comp.n else np.zeros(0, np.uint32)
+            cnt = np.ctypeslib.as_array(comp.counts, shape=(comp.n,)) if comp.n else np.zeros(0, np.uint16)
+            same = bool(r.component_num == len(reference_sketch) and np.array_equal(ids, reference_sketch[0][0]) and
+                        np.array_equal(cnt, reference_sketch[0][1]))
+        return {"gbases_s": total_reads * READ_LEN / dt / 1e9, "ms_per_step": dt * 1e3, "steps": steps, "engines": n, "devices": list(devices),
+                "transport": m.transport(), "merge": m.last_merge(), "distinct_keys": int(r.total),
+                "gather_ms": sum(gathers) / len(gathers), "tail_ms": sum(tails) / len(tails),
+                "tail_phases_ms": {k: v / steps for k, v in phases.items()},
+                "equals_process_per_gpu_sketch": same,
+                "what": "libmetakssd_multi.so in rank 0's process: mk_multi_begin, mk_sketch_push_reads_device of every engine's contiguous read "
+                        "range (resident in that GPU's HBM, global ordinals), mk_multi_finish (export, exchange over `transport`, fold, layout + dump "
+                        "on engine 0; no pipelining across steps: every step waits for its result); wall clock over `steps` steps; the other "
+                        "ranks wait on the rendezvous store, off their GPUs"}
+    finally:
+        m.close()
+
+
 def kernel_source_id():
     h = hashlib.sha256()
     for f in ("mk_kernels.hip.h", "mk_engine.hip", "mk_stream.hip.h", "mk_batch.hip.h", "mk_packed.hip.h"):
@@ -435,6 +491,14 @@ def main():
     ap.add_argument("--front-bits", type=int, default=None,
                     help="experiments: MK_OPT_FRONT_BITS of the engine (default: the engine's own choice; 0 = no front table)")
     ap.add_argument("--cand-cap", type=int, default=None, help="experiments: MK_OPT_CAND_CAP of the engine (records per scan wave)")
+    ap.add_argument("--merge", default="auto", choices=["auto", "gather", "slices"],
+                    help="N > 1: how the ranks' partial sketches are merged.  gather: every list to rank 0, one import there.  slices: "
+                         "SURVEY.md 8e's alternative -- all-to-all by key %% N, every rank folds a key slice, the reduced slices are rank 0's "
+                         "key list.  auto (default): gather below four ranks, slices from four on (what libmetakssd_multi.so does)")
+    ap.add_argument("--inproc-multi", action="store_true",
+                    help="N > 1: after the timed region rank 0 ALSO drives the C product's own multi-GPU path in its process -- "
+                         "libmetakssd_multi.so on devices 0..N-1 (mk_multi_create, one engine per GPU, RCCL group send/recv, "
+                         "mk_multi_finish) -- on the same workload while the other ranks wait off the GPU; reported as `inproc_multi`")
     ap.add_argument("--verify", action="store_true",
                     help="after timing, rank 0 re-sketches ALL ranks' reads on one engine and compares with the merged result")
     args = ap.parse_args()
@@ -447,7 +511,7 @@ def main():
     import torch
     import torch.distributed as dist
     from metakssd_amd import capi
-    from metakssd_amd.shard import gather_partials_concat, shard_range
+    from metakssd_amd.shard import exchange_slices, gather_partials_concat, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -512,10 +576,23 @@ def main():
             rk = torch.empty(cap, dtype=torch.int64, device=xdev)
             rc_ = torch.empty(cap, dtype=torch.int32, device=xdev)
             ro = torch.empty(cap, dtype=torch.int64, device=xdev)
+    merge = args.merge if args.merge != "auto" else ("slices" if world >= 4 else "gather")
+    if world > 1 and merge == "slices":  # what this rank receives of the others' parts (key % world == rank)
+        sk = torch.empty(cap, dtype=torch.int64, device=xdev)
+        sc = torch.empty(cap, dtype=torch.int32, device=xdev)
+        so = torch.empty(cap, dtype=torch.int64, device=xdev)
 
     result = {}
     flags = {"keep": False}
-    tail = {"t": 0.0, "t_pipe": 0.0, "steps": 0, "on": False}
+    tail = {"t": 0.0, "t_pipe": 0.0, "steps": 0, "on": False, "phases": {}}
+
+    def mark(name, t_prev):  # instrumented steps only: rank 0's phases, each fenced (the pipelined flow has no such fences)
+        if not tail["on"]:
+            return t_prev
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        tail["phases"][name] = tail["phases"].get(name, 0.0) + (now - t_prev)
+        return now
 
     def step(push=None):
         eng.begin(capi.MK_MODE_KOC)
@@ -528,16 +605,47 @@ def main():
                 torch.cuda.synchronize()
                 dist.barrier()
                 t0 = time.perf_counter()
-            if rank != 0:
+            tp = t0 if tail["on"] else 0.0
+            if merge == "slices":
+                # every rank: its list cut by key % world, tables emptied, part g to rank g, its own slice folded and listed again
+                d, parts = eng.partial_export_split(world, pk.data_ptr(), pc.data_ptr(), po.data_ptr(), cap)
+                eng.partial_restart()
+                tp = mark("export_split", tp)
+                n_in, _ = exchange_slices(pk[:d].to(xdev), pc[:d].to(xdev), po[:d].to(xdev), parts, out=(sk, sc, so))
+                tp = mark("all_to_all", tp)
+                own_at, own = sum(parts[:rank]), parts[rank]
+                if own:
+                    eng.partial_import(pk.data_ptr() + 8 * own_at, pc.data_ptr() + 4 * own_at, po.data_ptr() + 8 * own_at, own)
+                if n_in:
+                    k, c, o = (sk[:n_in].to(dev), sc[:n_in].to(dev), so[:n_in].to(dev)) if xdev != dev else (sk, sc, so)
+                    eng.partial_import(k.data_ptr(), c.data_ptr(), o.data_ptr(), n_in)
+                    result["_alive_s"] = (k, c, o)
+                if rank != 0:
+                    m = eng.partial_export(pk.data_ptr(), pc.data_ptr(), po.data_ptr(), cap)  # the reduced slice
+                    gather_partials_concat(pk[:m].to(xdev), pc[:m].to(xdev), po[:m].to(xdev), m, dst=0)
+                else:
+                    r0 = eng.partial_count()  # rank 0's own slice: entries [0, r0) of its engine's key list already
+                    tp = mark("fold_slice", tp)
+                    total_in = gather_partials_concat(pk[:0].to(xdev), pc[:0].to(xdev), po[:0].to(xdev), 0, dst=0, out=(rk, rc_, ro))
+                    tp = mark("gather_slices", tp)
+                    if total_in:
+                        k, c, o = (rk[:total_in].to(dev), rc_[:total_in].to(dev), ro[:total_in].to(dev)) if xdev != dev else (rk, rc_, ro)
+                        eng.partial_list_adopt(k.data_ptr(), c.data_ptr(), o.data_ptr(), total_in, r0)
+                        result["_alive"] = (k, c, o)
+                    eng.partial_list_commit(r0 + total_in)  # disjoint slices: this IS the list of distinct keys, nothing to fold
+                    tp = mark("adopt", tp)
+            elif rank != 0:
                 m = eng.partial_export(pk.data_ptr(), pc.data_ptr(), po.data_ptr(), cap)
                 gather_partials_concat(pk[:m].to(xdev), pc[:m].to(xdev), po[:m].to(xdev), m, dst=0)
             else:
                 total_in = gather_partials_concat(pk[:0].to(xdev), pc[:0].to(xdev), po[:0].to(xdev), 0, dst=0, out=(rk, rc_, ro))
+                tp = mark("gather", tp)
                 if total_in:
                     k, c, o = (rk[:total_in].to(dev), rc_[:total_in].to(dev), ro[:total_in].to(dev)) if xdev != dev else (rk, rc_, ro)
                     # the engine runs on torch's current stream: the import is ordered after the receives / copies
                     eng.partial_import(k.data_ptr(), c.data_ptr(), o.data_ptr(), total_in)
                     result["_alive"] = (k, c, o)  # until the next step's fence
+                tp = mark("import", tp)
         if rank == 0:
             if flags["keep"]:
                 drain()
@@ -557,7 +665,9 @@ def main():
         if world > 1 and tail["on"]:
             torch.cuda.synchronize()
             if rank == 0:
-                tail["t"] += time.perf_counter() - t0
+                now = time.perf_counter()
+                tail["phases"]["finish"] = tail["phases"].get("finish", 0.0) + (now - tp)
+                tail["t"] += now - t0
                 tail["steps"] += 1
 
     def drain():
@@ -620,7 +730,7 @@ def main():
         del pinned
 
     verified = None
-    need_sketch = args.verify or (world == 1 and not args.no_host_legs)
+    need_sketch = args.verify or (world == 1 and not args.no_host_legs) or (world > 1 and args.inproc_multi)
     if need_sketch:
         flags["keep"] = True
         step()
@@ -650,6 +760,24 @@ def main():
                 result["verify_detail"] = {"n_single": int(len(a[0])), "n_merged": int(len(b[0])),
                                            "same_multiset": bool(len(ka) == len(kb) and np.array_equal(ka, kb))}
             del allreads
+
+    inproc = None
+    if world > 1 and args.inproc_multi:
+        # the other ranks wait on the rendezvous store (a host-side wait: a collective's kernel would spin on their GPUs beside the
+        # engines rank 0 puts there)
+        import datetime
+        store = dist.distributed_c10d._get_default_store()
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            try:
+                devs = [0] * world if args.same_device else list(range(world))
+                inproc = leg_inproc_multi(torch, capi, shuf, devs, total_reads, max(3, min(args.steps, 20)), args.merge, result.get("sketch"))
+            except Exception as ex:  # noqa: BLE001
+                inproc = {"gbases_s": None, "what": "failed: %s" % ex}
+            store.set("mk_inproc_multi_done", "1")
+        else:
+            store.wait(["mk_inproc_multi_done"], datetime.timedelta(seconds=3600))
 
     if rank == 0:
         bases_per_step = float(total_reads) * READ_LEN
@@ -718,8 +846,11 @@ def main():
             line["distributed"] = seen
         if world > 1 and tail["steps"]:
             line["rank0_tail_ms"] = tail["t"] / tail["steps"] * 1e3
-            line["rank0_tail_what"] = "gather of the other ranks' key lists + one import launch + finish on rank 0, " \
-                                      "from 3 separately fenced steps after the timed region"
+            line["rank0_tail_what"] = ("gather of the other ranks' key lists + one import launch + finish on rank 0" if merge == "gather" else
+                                       "key slices: split + all-to-all + fold of rank 0's slice + gather of the reduced slices + finish from the list") + \
+                                      ", from 3 separately fenced steps after the timed region"
+            line["rank0_tail_phases_ms"] = {k: v / tail["steps"] * 1e3 for k, v in tail["phases"].items()}
+            line["merge"] = merge
             line["rank0_tail_pipelined_ms"] = tail["t_pipe"] / tail["steps"] * 1e3
             line["rank0_tail_pipelined_what"] = "the same up to the point where rank 0 may begin the next pass (mk_sketch_finish_begin has " \
                                                 "returned: compaction done, key count known); priority layout, dump and the copy of the result " \
@@ -731,6 +862,8 @@ def main():
                                 "what": "every rank: %d of its reads as %d-byte rows in pinned host memory -> mk_sketch_push_reads over "
                                         "its own PCIe link -> export, gather to rank 0, one import, finish on rank 0; mean of 3 fenced "
                                         "steps, max over ranks; aggregate over %d ranks" % (ns, STRIDE, world)}
+        if inproc is not None:
+            line["inproc_multi"] = inproc
         if verified is not None:
             line["merged_equals_single_engine"] = bool(verified)
             if "verify_detail" in result:

@@ -292,6 +292,7 @@ int mk_host_free(void *p);
  * with stale pinned ranges, and a later copy out of ordinary memory faulted on the device. */
 int mk_host_register(void *p, size_t bytes);
 int mk_host_unregister(void *p);
+int mk_host_register_on(int device, void *p, size_t bytes); /* the same from a thread that has not used `device` yet */
 /* a large pinned block the quick way (anonymous mapping touched by several threads, then one hipHostRegister): a quarter of
  * mk_host_alloc's time for hundreds of MiB; free with the same `bytes` */
 int mk_host_arena_alloc(void **p, size_t bytes);
@@ -313,6 +314,39 @@ int mk_partial_export_async(mk_engine *e, uint64_t *keys_dev, uint32_t *counts_d
 /* fold another shard's export (DEVICE buffers) into this engine: counts add, first ordinals take min */
 int mk_partial_import(mk_engine *e, const uint64_t *keys_dev, const uint32_t *counts_dev, const uint64_t *ords_dev,
                       uint64_t n);
+
+/* ---- the same merge by key slices ("all-to-all by key % G so each GPU reduces a key slice, then gather reduced
+ * slices"): with G shards the gather above makes ONE engine fold G - 1 whole lists into its table; here every engine folds a G-th
+ * of every list, and the one that finishes receives G - 1 lists of DISTINCT keys, which need no folding at all.
+ *   every shard:     mk_partial_export_split   its list, cut into G parts by key % G (part sizes to the host)
+ *                    mk_partial_restart        the same sketch goes on with empty tables
+ *                    [exchange: part g of every shard goes to shard g]
+ *                    mk_partial_import         the parts it received and its own part g  ->  its table holds slice g, reduced
+ *                    mk_partial_count / mk_partial_list_reserve(e, n_g, ..)  the reduced slice: n_g keys and where they are
+ *   finishing shard: mk_partial_list_reserve(e, sum of n_g, ..)  room behind its own slice; [gather: the other slices land there]
+ *                    mk_partial_list_commit(e, sum)  /  mk_partial_list_adopt for lists that arrived somewhere else
+ *                    mk_sketch_finish          layout + dump straight from the list: the slices are disjoint, so their
+ *                                              concatenation IS the sketch's list of distinct keys (the table is not consulted)
+ * Results are those of the gather, of one engine scanning everything, and of the reference's sequential run. */
+/* mk_partial_export with the list cut into nparts (1..16) parts by key % nparts: part g starts at the sum of the parts in front of
+ * it; order inside a part is arbitrary.  Everything is queued on the engine's stream (mk_engine_sync waits): the buffers are
+ * complete and part_counts[0..nparts) -- HOST memory, pinned preferred -- are valid after it.  n_out = all parts together. */
+int mk_partial_export_split_async(mk_engine *e, uint32_t nparts, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t *ords_dev,
+                                  uint64_t capacity, uint64_t *part_counts, uint64_t *n_out);
+int mk_partial_export_split(mk_engine *e, uint32_t nparts, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t *ords_dev,
+                            uint64_t capacity, uint64_t *part_counts, uint64_t *n_out);
+/* the sketch in progress continues with empty tables (flavour and occurrence threshold kept): what was pushed so far lives on only
+ * in what the caller exported */
+int mk_partial_restart(mk_engine *e);
+/* the engine's own key list as DEVICE arrays with room for n entries.  After mk_partial_count said D keys, entries [0, D) are
+ * those keys and stay (also when the arrays have to grow); a caller fills [D, n) -- with keys that are DISTINCT from those and
+ * from one another -- and commits. */
+int mk_partial_list_reserve(mk_engine *e, uint64_t n, uint64_t **keys_dev, uint32_t **counts_dev, uint64_t **ords_dev);
+/* the first n entries of the key list are this sketch's distinct keys: mk_sketch_finish lays them out and dumps them */
+int mk_partial_list_commit(mk_engine *e, uint64_t n);
+/* copies n entries from the caller's DEVICE arrays to [offset, offset + n) of the key list (reserve + copy; commit separately) */
+int mk_partial_list_adopt(mk_engine *e, const uint64_t *keys_dev, const uint32_t *counts_dev, const uint64_t *ords_dev, uint64_t n,
+                          uint64_t offset);
 
 /* ---- profiling --------------------------------------------------------------------------------- */
 int mk_profile_enable(mk_engine *e, int on);
@@ -373,6 +407,15 @@ typedef struct mk_fastq_opts {
                            the engine is still being created */
   int32_t packed;       /* != 0: buffers whose reads all have at most MK_PACKED_MAX_BASES bases are framed as PACKED rows (the sink
                            gets stride = MK_PACKED_PITCH | MK_ROWS_PACKED for those), the others as ASCII rows */
+  int32_t reserved;
+  uint64_t pool_bytes;  /* 0: threads + inflight + 1 + ahead buffers, each with room for a chunk's text rows.  Otherwise a budget for all
+                           row buffers together: with `packed` and a file whose first records are short enough for packed rows the
+                           buffers are sized for PACKED rows (a fifth of the text), and there are as many as the budget holds, at most
+                           one per chunk -- with one per chunk no framer ever waits for a buffer, so a file is framed at the threads'
+                           pace from the first moment on, e.g. while the HIP runtime and the engine are still coming up.  Buffers are
+                           handed to the chunks in address order (chunk c frames into buffer c until buffers come back), which lets a
+                           sink pin its block piece by piece in front of the pushes.  A chunk whose rows do not fit its buffer ends
+                           early and the rest is framed on the calling thread, as ever: sizes only ever cost speed */
 } mk_fastq_opts;
 typedef struct mk_fastq_stats {
   uint64_t rows, records, chunks, chunks_discarded, serial_rows; /* discarded / serial: work redone on the calling thread */
@@ -386,6 +429,10 @@ typedef struct mk_rows_sink {
   int (*wait)(void *ctx, uint64_t token);       /* NULL: push is synchronous, the buffer is free when it returns */
   uint8_t *(*alloc)(void *ctx, size_t bytes);   /* called once: one block for all row buffers (pinned for an engine) */
   void (*release)(void *ctx, uint8_t *p, size_t bytes);
+  /* NULL, or: called by a FRAMER thread (any of them, in any order) when the buffer at `rows` has been written and will not be
+   * touched again before it is pushed -- a sink that pins its block piece by piece (pages that have been written pin fast, fresh
+   * ones slowly) learns here what may be pinned; `bytes` = the room of the buffer, not what was used of it */
+  void (*ready)(void *ctx, const uint8_t *rows, size_t bytes);
 } mk_rows_sink;
 int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const mk_rows_sink *sink, uint64_t first_ordinal,
                     mk_fastq_stats *st);

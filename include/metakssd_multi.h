@@ -47,6 +47,21 @@ int mk_multi_begin_occ(mk_multi *m, int min_occurrence);
  * wall time of the exchange alone and of everything in this call */
 int mk_multi_finish(mk_multi *m, mk_result *out, double *gather_ms, double *tail_ms);
 
+/* How mk_multi_finish merges (same result either way):
+ *   GATHER  the lists of engines 1.. go to engine 0, which folds them into its table with one import launch (above)
+ *   SLICES  SURVEY.md 8e's alternative: every engine cuts its list into n parts by key % n, part g goes to engine g (all-to-all),
+ *           every engine folds its slice at the same time, the reduced slices -- disjoint key sets -- go to engine 0 and are its key
+ *           list as they stand: engine 0 folds an n-th of what it folds under GATHER and runs layout + dump
+ *   AUTO    (default) GATHER below four engines, SLICES from four on */
+enum { MK_MULTI_MERGE_AUTO = 0, MK_MULTI_MERGE_GATHER = 1, MK_MULTI_MERGE_SLICES = 2 };
+int mk_multi_set_merge(mk_multi *m, int how);
+const char *mk_multi_last_merge(const mk_multi *m); /* "gather" or "slices": what the last mk_multi_finish did */
+/* wall-clock phases of the last mk_multi_finish, milliseconds.  GATHER: export (compaction + copies on engines 1..), exchange,
+ * import (queued), 0, finish.  SLICES: export (compaction + split on every engine), exchange (all-to-all), import (fold +
+ * compaction of the slices, waited for), gather (reduced slices to engine 0), finish (layout + dump on engine 0) */
+typedef struct { double export_ms, exchange_ms, import_ms, gather_ms, finish_ms, total_ms; } mk_multi_times;
+int mk_multi_last_times(const mk_multi *m, mk_multi_times *t);
+
 #ifdef __cplusplus
 }
 #endif

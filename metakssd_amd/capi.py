@@ -66,7 +66,8 @@ class FastaStateC(C.Structure):
 
 class FastqOptsC(C.Structure):
     _fields_ = [("occ", C.c_int32), ("qmin", C.c_int32), ("TL", C.c_int32), ("nthreads", C.c_int32), ("inflight", C.c_int32),
-                ("chunk_bytes", C.c_uint64), ("drop_pages", C.c_int32), ("ahead", C.c_int32), ("packed", C.c_int32)]
+                ("chunk_bytes", C.c_uint64), ("drop_pages", C.c_int32), ("ahead", C.c_int32), ("packed", C.c_int32), ("reserved", C.c_int32),
+                ("pool_bytes", C.c_uint64)]
 
 
 class FastqStatsC(C.Structure):
@@ -80,10 +81,12 @@ _PUSH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, 
 _WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
+_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class RowsSinkC(C.Structure):
-    _fields_ = [("ctx", C.c_void_p), ("push", _PUSH_FN), ("wait", _WAIT_FN), ("alloc", _ALLOC_FN), ("release", _RELEASE_FN)]
+    _fields_ = [("ctx", C.c_void_p), ("push", _PUSH_FN), ("wait", _WAIT_FN), ("alloc", _ALLOC_FN), ("release", _RELEASE_FN),
+                ("ready", C.c_void_p)]
 
 
 class BatchFileC(C.Structure):
@@ -142,6 +145,12 @@ def _load():
         "mk_partial_count": [vp, C.POINTER(u64)],
         "mk_partial_export": [vp, vp, vp, vp, u64, C.POINTER(u64)],
         "mk_partial_import": [vp, vp, vp, vp, u64],
+        "mk_partial_export_split": [vp, u32, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)],
+        "mk_partial_export_split_async": [vp, u32, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)],
+        "mk_partial_restart": [vp],
+        "mk_partial_list_reserve": [vp, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
+        "mk_partial_list_commit": [vp, u64],
+        "mk_partial_list_adopt": [vp, vp, vp, vp, u64, u64],
         "mk_profile_enable": [vp, C.c_int],
         "mk_profile_reset": [vp],
         "mk_profile_get": [vp, C.POINTER(ProfileC)],
@@ -315,7 +324,8 @@ def fastq_frame_mt(buf, stride, nthreads, occ=False, TL=22, qmin=0, final=True, 
     return rows[: n.value * stride], n.value, nrec.value, used.value, rc
 
 
-def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2, drop_pages=False, packed=False):
+def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2, drop_pages=False, packed=False, pool_bytes=0,
+                 ready_log=None):
     """the whole-file FASTQ stream (mk_fastq_stream) into host memory: returns (list of (rows u8 array, stride, nrows,
     first ordinal) in push order, stats, rc).  Buffers come from malloc here; the engine-bound form is Engine.push_fastq."""
     b = np.frombuffer(buf, dtype=np.uint8)
@@ -334,10 +344,23 @@ def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first
     def wait(ctx, token):
         return 0
 
-    sink = RowsSinkC(None, _PUSH_FN(push), _WAIT_FN(wait), _ALLOC_FN(lambda ctx, n: libc.malloc(n)),
-                     _RELEASE_FN(lambda ctx, p, n: libc.free(p)))
-    keep["sink"] = sink
-    o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 1 if drop_pages else 0, 0, 1 if packed else 0)
+    blocks = []
+
+    def alloc(ctx, n):
+        p = libc.malloc(n)
+        blocks.append((p, n))
+        return p
+
+    def ready(ctx, rows, n):  # called on the framers' threads: a buffer has been written and waits for its push
+        if ready_log is not None:
+            ready_log.append((rows - blocks[-1][0], n))
+    ready_fn = _READY_FN(ready)
+    sink = RowsSinkC(None, _PUSH_FN(push), _WAIT_FN(wait), _ALLOC_FN(alloc), _RELEASE_FN(lambda ctx, p, n: libc.free(p)),
+                     C.cast(ready_fn, C.c_void_p) if ready_log is not None else None)
+    keep["sink"] = (sink, ready_fn)
+    o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 1 if drop_pages else 0, 0, 1 if packed else 0, 0, pool_bytes)
+    if ready_log is not None:
+        ready_log.append(blocks)
     st = FastqStatsC()
     rc = lib.mk_fastq_stream(b.ctypes.data if len(b) else None, len(b), C.byref(o), C.byref(sink), first_ordinal, C.byref(st))
     return pushes, st, rc
@@ -612,6 +635,30 @@ class Engine:
     def partial_import(self, keys_ptr, counts_ptr, ords_ptr, n):
         _check(lib.mk_partial_import(self.h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), C.c_void_p(ords_ptr), n), self.h)
 
+    # ---- the merge by key slices (include/metakssd_hip.h) ----
+    def partial_export_split(self, nparts, keys_ptr, counts_ptr, ords_ptr, capacity):
+        """the distinct list cut into nparts parts by key % nparts -> (n, [part sizes])"""
+        n = C.c_uint64(0)
+        parts = (C.c_uint64 * 16)()
+        _check(lib.mk_partial_export_split(self.h, nparts, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), C.c_void_p(ords_ptr), capacity,
+                                           parts, C.byref(n)), self.h)
+        return n.value, [int(parts[g]) for g in range(nparts)]
+
+    def partial_restart(self):
+        _check(lib.mk_partial_restart(self.h), self.h)
+
+    def partial_list_reserve(self, n):
+        """device pointers (keys, counts, ords) of the engine's own key list, room for n entries"""
+        k, c, o = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib.mk_partial_list_reserve(self.h, n, C.byref(k), C.byref(c), C.byref(o)), self.h)
+        return k.value, c.value, o.value
+
+    def partial_list_adopt(self, keys_ptr, counts_ptr, ords_ptr, n, offset):
+        _check(lib.mk_partial_list_adopt(self.h, C.c_void_p(keys_ptr), C.c_void_p(counts_ptr), C.c_void_p(ords_ptr), n, offset), self.h)
+
+    def partial_list_commit(self, n):
+        _check(lib.mk_partial_list_commit(self.h, n), self.h)
+
     def profile_enable(self, on=True):
         _check(lib.mk_profile_enable(self.h, 1 if on else 0), self.h)
 
@@ -626,6 +673,125 @@ class Engine:
 
 def synth_rows_device(device, stream, seed, first_read, nreads, length, stride, dev_ptr):
     _check(lib.mk_synth_rows_device(device, C.c_void_p(stream), seed, first_read, nreads, length, stride, C.c_void_p(dev_ptr)))
+
+
+# ---- libmetakssd_multi.so (include/metakssd_multi.h): several engines in ONE process, the product's own exchange (RCCL) ----
+MK_MULTI_ALLOW_DEVICE_COPIES, MK_MULTI_FORCE_DEVICE_COPIES = 1, 2
+MK_MULTI_MERGE_AUTO, MK_MULTI_MERGE_GATHER, MK_MULTI_MERGE_SLICES = 0, 1, 2
+MULTI_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmetakssd_multi.so")
+_mlib = None
+
+
+class MultiTimesC(C.Structure):
+    _fields_ = [(f, C.c_double) for f in ("export_ms", "exchange_ms", "import_ms", "gather_ms", "finish_ms", "total_ms")]
+
+
+def _load_multi():
+    global _mlib
+    if _mlib is not None:
+        return _mlib
+    if not os.path.exists(MULTI_LIB_PATH):
+        raise ImportError("%s not built (needs rccl/rccl.h and librccl.so: make -C metakssd_amd/csrc)" % MULTI_LIB_PATH)
+    m = C.CDLL(MULTI_LIB_PATH)  # (pulls in librccl.so: only callers of Multi pay for that)
+    vp = C.c_void_p
+    m.mk_multi_create_ex.argtypes = [C.POINTER(ParamsC), C.POINTER(C.c_int), C.c_int, C.c_uint, C.POINTER(vp)]
+    m.mk_multi_destroy.argtypes = [vp]
+    m.mk_multi_last_error.argtypes = [vp]
+    m.mk_multi_last_error.restype = C.c_char_p
+    m.mk_multi_count.argtypes = [vp]
+    m.mk_multi_engine.argtypes = [vp, C.c_int]
+    m.mk_multi_engine.restype = vp
+    m.mk_multi_transport.argtypes = [vp]
+    m.mk_multi_transport.restype = C.c_char_p
+    m.mk_multi_begin.argtypes = [vp, C.c_int]
+    m.mk_multi_begin_occ.argtypes = [vp, C.c_int]
+    m.mk_multi_finish.argtypes = [vp, C.POINTER(ResultC), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    m.mk_multi_set_merge.argtypes = [vp, C.c_int]
+    m.mk_multi_last_merge.argtypes = [vp]
+    m.mk_multi_last_merge.restype = C.c_char_p
+    m.mk_multi_last_times.argtypes = [vp, C.POINTER(MultiTimesC)]
+    _mlib = m
+    return m
+
+
+class Multi:
+    """one sketch over several engines of ONE process (mk_multi_*): what `metakssd dist --devices a,b,..` runs on"""
+
+    def __init__(self, shuf, devices, flags=0, component_sz=8):
+        self.m = _load_multi()
+        self.params = shuf.params(component_sz)
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.m.mk_multi_create_ex(C.byref(self.params), arr, len(devices), flags, C.byref(h))
+        if rc != MK_OK:
+            raise MkError(rc, self.m.mk_multi_last_error(None).decode(errors="replace"))
+        self.h = h
+        self.n = len(devices)
+        self.devices = list(devices)
+
+    def _check(self, rc):
+        if rc != MK_OK:
+            raise (CrowdedError if rc == MK_ERR_CROWDED else MkError)(rc, self.m.mk_multi_last_error(self.h).decode(errors="replace"))
+
+    def engine(self, i):
+        return self.m.mk_multi_engine(self.h, i)
+
+    def transport(self):
+        return self.m.mk_multi_transport(self.h).decode()
+
+    def set_merge(self, how):
+        self._check(self.m.mk_multi_set_merge(self.h, how))
+
+    def begin(self, mode=MK_MODE_KOC):
+        self._check(self.m.mk_multi_begin(self.h, mode))
+
+    def begin_occ(self, min_occurrence):
+        self._check(self.m.mk_multi_begin_occ(self.h, min_occurrence))
+
+    def push_reads_device(self, i, dev_ptr, stride, nreads, first_read_ordinal):
+        e = self.engine(i)
+        _check(lib.mk_sketch_push_reads_device(e, C.c_void_p(dev_ptr), stride, nreads, first_read_ordinal), e)
+
+    def push_reads(self, i, rows, stride, first_read_ordinal):
+        e = self.engine(i)
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        _check(lib.mk_sketch_push_reads(e, rows.ctypes.data_as(C.c_void_p), stride, rows.size // stride, first_read_ordinal), e)
+
+    def finish_raw(self):
+        """-> (ResultC of engine 0, gather_ms, tail_ms)"""
+        r = ResultC()
+        g, t = C.c_double(0), C.c_double(0)
+        self._check(self.m.mk_multi_finish(self.h, C.byref(r), C.byref(g), C.byref(t)))
+        return r, g.value, t.value
+
+    def finish(self):
+        r, g, t = self.finish_raw()
+        out = []
+        for c in range(r.component_num):
+            comp = r.components[c]
+            ids = np.ctypeslib.as_array(comp.ids, shape=(comp.n,)).copy() if comp.n else np.zeros(0, np.uint32)
+            cnt = (np.ctypeslib.as_array(comp.counts, shape=(comp.n,)).copy() if comp.n else np.zeros(0, np.uint16)) if comp.counts else None
+            out.append((ids, cnt))
+        return out
+
+    def last_merge(self):
+        return self.m.mk_multi_last_merge(self.h).decode()
+
+    def last_times(self):
+        t = MultiTimesC()
+        self._check(self.m.mk_multi_last_times(self.h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in MultiTimesC._fields_}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.m.mk_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 MK_SET_UNION, MK_SET_UNIQ_UNION = 0, 1

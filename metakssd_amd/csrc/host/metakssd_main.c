@@ -141,6 +141,7 @@ static double g_t0; /* process start (monotonic) */
 #ifndef MK_DEFAULT_AHEAD
 #define MK_DEFAULT_AHEAD 0
 #endif
+static uint64_t g_pool_bytes = (uint64_t)6 << 30; /* --pool-mib: room for the FASTQ stream's row buffers (mk_fastq_opts::pool_bytes; 0: a few buffers, reused) */
 static int g_ahead = MK_DEFAULT_AHEAD; /* --ahead: row buffers the FASTQ stream's framers may run ahead of the pushes by */
 static int g_component_sz = 8; /* --component-sz: the reference's compile-time COMPONENT_SZ (global_basic.h:35-37) */
 
@@ -190,9 +191,9 @@ typedef struct {
   mk_fastq_stats fq_stats;
   double t_first_push, t_last_push, t_unmapped, t_begin_s;
   int drop_pages, inflight, direct_host, packed;
-  uint8_t *arena; /* pinned row-buffer pool of the FASTQ stream */
+  uint8_t *arena; /* row-buffer pool of the FASTQ stream: an anonymous mapping, pinned piece by piece behind the framers (pin_*) */
   size_t arena_bytes;
-  int arena_unpinned; /* mapped and being filled, pinned at the first push (the runtime was not up when it was made) */
+  struct pinner *pin;
 } ctx_t;
 
 #define CHECK(e, call)                                                  \
@@ -339,14 +340,112 @@ static void push_rows(ctx_t *c, const uint8_t *rows, uint32_t stride, uint64_t n
   c->nrows_total += nrows;
 }
 
+/* ---- the row-buffer arena is pinned PIECE BY PIECE, behind the framers and in front of the pushes -----------------------------
+ * The arena has room for the whole file's rows (mk_fastq_opts::pool_bytes), so that the framers run at their own pace from the first
+ * moment -- also through the 80-110 ms in which the HIP runtime and the engine come up and nothing can be pinned or pushed.  Pinning
+ * all of it up front would cost more than it saves (fresh pages pin at 5 GB/s, and pinning beside the creation of the engine's queue
+ * makes that three times as long); pages the framers have WRITTEN pin at over 100 GB/s.  So: a framer reports a finished buffer
+ * (mk_rows_sink::ready), which marks its 2 MiB granules; a pinner thread -- idle until the engine is there -- registers runs of marked
+ * granules (up to 256 MiB a call); a push waits until its buffer's granules are pinned.  The pinner is twice as fast as the link, so
+ * after the first call it stays in front of the pushes. */
+#define PIN_GRANULE ((size_t)2 << 20)
+#define PIN_RUN_MAX 128 /* granules per hipHostRegister */
+typedef struct pinner {
+  uint8_t *base;
+  size_t ngran;
+  uint8_t *state;   /* per granule: 0 fresh, 1 written (may be pinned), 2 pinned */
+  void **regs; int nregs, regs_cap; /* bases of the registrations made (to undo them) */
+  int device, go, stop, started;
+  pthread_t th;
+  pthread_mutex_t mu;
+  pthread_cond_t cv_work, cv_pinned;
+  double t_pin_s; int calls; size_t pinned_bytes;
+} pinner;
+static void *pinner_run(void *arg) {
+  pinner *p = arg;
+  pthread_mutex_lock(&p->mu);
+  for (;;) {
+    size_t g0 = p->ngran;
+    if (p->go) for (size_t g = 0; g < p->ngran; g++) if (p->state[g] == 1) { g0 = g; break; }
+    if (p->stop) break;
+    if (g0 == p->ngran) { pthread_cond_wait(&p->cv_work, &p->mu); continue; }
+    size_t g1 = g0;
+    while (g1 < p->ngran && g1 - g0 < PIN_RUN_MAX && p->state[g1] == 1) g1++;
+    pthread_mutex_unlock(&p->mu);
+    const double t0 = now_s();
+    if (mk_host_register_on(p->device, p->base + g0 * PIN_GRANULE, (g1 - g0) * PIN_GRANULE) != MK_OK)
+      die("pinning the row buffers failed: %s", mk_last_error(NULL));
+    const double dt = now_s() - t0;
+    pthread_mutex_lock(&p->mu);
+    for (size_t g = g0; g < g1; g++) p->state[g] = 2;
+    if (p->nregs == p->regs_cap) {
+      p->regs_cap = p->regs_cap ? 2 * p->regs_cap : 64;
+      p->regs = realloc(p->regs, sizeof(void *) * (size_t)p->regs_cap);
+      if (!p->regs) die("out of memory");
+    }
+    p->regs[p->nregs++] = p->base + g0 * PIN_GRANULE;
+    p->t_pin_s += dt; p->calls++; p->pinned_bytes += (g1 - g0) * PIN_GRANULE;
+    pthread_cond_broadcast(&p->cv_pinned);
+  }
+  pthread_mutex_unlock(&p->mu);
+  return NULL;
+}
+static void pin_mark(pinner *p, const uint8_t *at, size_t bytes) { /* [at, at + bytes) has been written: its granules may be pinned */
+  if (!p || at < p->base || bytes == 0) return;
+  size_t g0 = (size_t)(at - p->base) / PIN_GRANULE, g1 = ((size_t)(at - p->base) + bytes + PIN_GRANULE - 1) / PIN_GRANULE;
+  if (g1 > p->ngran) g1 = p->ngran;
+  pthread_mutex_lock(&p->mu);
+  int any = 0;
+  for (size_t g = g0; g < g1; g++) if (p->state[g] == 0) { p->state[g] = 1; any = 1; }
+  if (any && p->go) pthread_cond_signal(&p->cv_work);
+  pthread_mutex_unlock(&p->mu);
+}
+static void pin_wait(pinner *p, const uint8_t *at, size_t bytes) { /* returns when [at, at + bytes) is pinned; lets the pinner loose */
+  if (!p || at < p->base || bytes == 0) return;
+  size_t g0 = (size_t)(at - p->base) / PIN_GRANULE, g1 = ((size_t)(at - p->base) + bytes + PIN_GRANULE - 1) / PIN_GRANULE;
+  if (g1 > p->ngran) g1 = p->ngran;
+  pthread_mutex_lock(&p->mu);
+  for (size_t g = g0; g < g1; g++) if (p->state[g] == 0) p->state[g] = 1;
+  if (!p->go) p->go = 1;
+  pthread_cond_signal(&p->cv_work);
+  for (;;) {
+    int all = 1;
+    for (size_t g = g0; g < g1; g++) if (p->state[g] != 2) { all = 0; break; }
+    if (all) break;
+    pthread_cond_wait(&p->cv_pinned, &p->mu);
+  }
+  pthread_mutex_unlock(&p->mu);
+}
+static void pin_destroy(pinner *p) { /* registrations undone, thread gone (the mapping is the caller's) */
+  if (!p) return;
+  pthread_mutex_lock(&p->mu);
+  p->stop = 1;
+  pthread_cond_broadcast(&p->cv_work);
+  pthread_mutex_unlock(&p->mu);
+  if (p->started) pthread_join(p->th, NULL);
+  for (int i = 0; i < p->nregs; i++) mk_host_unregister(p->regs[i]);
+  free(p->regs); free(p->state);
+  pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_work); pthread_cond_destroy(&p->cv_pinned);
+  free(p);
+}
+static pinner *pin_create(uint8_t *base, size_t bytes, int device) {
+  pinner *p = calloc(1, sizeof *p);
+  if (!p) return NULL;
+  p->base = base; p->ngran = bytes / PIN_GRANULE; p->device = device;
+  p->state = calloc(p->ngran ? p->ngran : 1, 1);
+  pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->cv_work, NULL); pthread_cond_init(&p->cv_pinned, NULL);
+  if (!p->state || pthread_create(&p->th, NULL, pinner_run, p) != 0) { free(p->state); free(p); return NULL; }
+  p->started = 1;
+  return p;
+}
+
 /* ---- sink of the whole-file FASTQ stream: pinned buffers, asynchronous pushes, the engine awaited at the first push ---- */
+static void cli_sink_ready(void *ctx, const uint8_t *rows, size_t bytes) { pin_mark(((ctx_t *)ctx)->pin, rows, bytes); }
 static int cli_sink_push(void *ctx, const uint8_t *rows, uint32_t stride, uint64_t nrows, uint64_t ord, uint64_t *token) {
   ctx_t *c = ctx;
   (void)sketch_engine(c);
-  if (c->arena_unpinned) { /* the engine is there, i.e. the runtime is up: pin the pool the framers have been filling */
-    if (mk_host_register(c->arena, c->arena_bytes) != MK_OK) die("pinning the row buffers failed: %s", mk_last_error(NULL));
-    c->arena_unpinned = 0;
-  }
+  /* the engine is there, i.e. the runtime is up: the pinner may work; this buffer's pages before anything else */
+  pin_wait(c->pin, rows, (size_t)nrows * (stride & ~MK_ROWS_PACKED));
   if (c->t_first_push == 0) c->t_first_push = now_s() - g_t0;
   /* several GPUs: the row buffers are dealt round-robin, so that every GPU's PCIe link carries a share at any time;
    * ordinals are global, so it does not matter which engine sees which rows */
@@ -396,31 +495,21 @@ static uint8_t *arena_map_unpinned(size_t bytes, size_t *len_out) {
   *len_out = len;
   return m;
 }
-static int engine_is_ready(ctx_t *c) {
-  if (c->eng) return 1;
-  engine_future *f = c->fut;
-  pthread_mutex_lock(&f->mu);
-  const int done = f->done;
-  pthread_mutex_unlock(&f->mu);
-  return done;
-}
-static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) { /* the pinned arena is kept for the next file and goes with the process */
+static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) { /* the arena (and what is pinned of it) is kept for the next file and goes with the process */
   ctx_t *c = ctx;
   if (c->arena && c->arena_bytes >= bytes) return c->arena;
-  if (c->arena && !c->arena_unpinned) mk_host_arena_free(c->arena, c->arena_bytes);
-  else if (c->arena) munmap(c->arena, c->arena_bytes);
-  c->arena = NULL; c->arena_bytes = 0; c->arena_unpinned = 0;
-  if (!engine_is_ready(c)) { /* first file of the process: do not wait for the runtime, frame into ordinary memory meanwhile */
-    size_t len = 0;
-    uint8_t *m = arena_map_unpinned(bytes, &len);
-    if (!m) return NULL;
-    c->arena = m; c->arena_bytes = len; c->arena_unpinned = 1;
-    return m;
-  }
-  void *p = NULL;
-  if (mk_host_arena_alloc(&p, bytes) != MK_OK) return NULL;
-  c->arena = p; c->arena_bytes = bytes;
-  return p;
+  if (c->pin) { pin_destroy(c->pin); c->pin = NULL; }
+  if (c->arena) munmap(c->arena, c->arena_bytes);
+  c->arena = NULL; c->arena_bytes = 0;
+  /* an untouched anonymous mapping (2 MiB granules, huge pages asked for): the framers' stores bring the pages in, the pinner
+   * registers them once they are written -- nothing here waits for the runtime or costs anything for room that is never used */
+  size_t len = 0;
+  uint8_t *m = arena_map_untouched(bytes, &len);
+  if (!m) return NULL;
+  c->pin = pin_create(m, len, c->fut ? (c->fut->ndev > 1 ? c->fut->devs[0] : c->fut->device) : 0);
+  if (!c->pin) { munmap(m, len); return NULL; }
+  c->arena = m; c->arena_bytes = len;
+  return m;
 }
 static void cli_sink_release(void *ctx, uint8_t *p, size_t bytes) { (void)ctx; (void)p; (void)bytes; }
 
@@ -443,7 +532,8 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   o.nthreads = c->nthreads; o.inflight = c->inflight; o.chunk_bytes = c->chunk_bytes; o.ahead = g_ahead;
   o.packed = c->packed; /* reads of up to 152 bases cross PCIe as 64-byte packed rows (geometries with a tuned scan kernel) */
   o.drop_pages = c->drop_pages; /* a private read-only file mapping that is unmapped below */
-  mk_rows_sink sink = {c, cli_sink_push, cli_sink_wait, cli_sink_alloc, cli_sink_release};
+  o.pool_bytes = g_pool_bytes;
+  mk_rows_sink sink = {c, cli_sink_push, cli_sink_wait, cli_sink_alloc, cli_sink_release, cli_sink_ready};
   mk_fastq_stats fs;
   /* the framers start at once, into a pool that is pinned when the engine is there (cli_sink_alloc / cli_sink_push): the
    * engine's queue creation takes three times as long (45 ms instead of 14) when it runs into the driver together with the
@@ -1988,6 +2078,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--timing")) timing = 1;
     else if (!strcmp(argv[i], "--chunk-mib") && i + 1 < argc) chunk_bytes = (uint64_t)atoi(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--inflight") && i + 1 < argc) inflight = atoi(argv[++i]); /* row buffers queued for copying */
+    else if (!strcmp(argv[i], "--pool-mib") && i + 1 < argc) g_pool_bytes = (uint64_t)atoll(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--ahead") && i + 1 < argc) g_ahead = atoi(argv[++i]); /* row buffers the framers may run ahead by */
     else if (!strcmp(argv[i], "--direct")) direct_host = 1; /* MK_OPT_DIRECT_HOST: scan pinned row buffers in place */
     else if (!strcmp(argv[i], "--ascii-rows")) ascii_rows = 1; /* FASTQ rows as text (160 bytes per 150-base read) instead of packed (64) */
@@ -2441,13 +2532,15 @@ int main(int argc, char **argv) {
            "\"serial_rows\": %llu, \"stream_setup_s\": %.4f, \"stream_wait_frame_s\": %.4f, \"stream_push_s\": %.4f, \"stream_total_s\": %.4f, "
            "\"push_call_s\": %.4f, \"wait_call_s\": %.4f, \"push_call_max_s\": %.4f, \"first_push_call_s\": %.4f, \"gpus\": %d, \"gather_ms\": %.3f, \"tail_ms\": %.3f, \"transport\": \"%s\", "
            "\"batches\": %d, \"batch_wait_readers_s\": %.4f, \"batch_pin_s\": %.4f, \"batch_begin_s\": %.4f, "
-           "\"readers_read_cpu_s\": %.4f, \"readers_pack_cpu_s\": %.4f, \"readers_blocked_s\": %.4f}}\n",
+           "\"readers_read_cpu_s\": %.4f, \"readers_pack_cpu_s\": %.4f, \"readers_blocked_s\": %.4f, "
+           "\"pin_calls\": %d, \"pin_s\": %.4f, \"pinned_mib\": %.1f, \"pool_mib\": %.1f}}\n",
            g_t0, now_s(), t_shuf, fut.t_hip_ready, fut.t_ready, c.t_first_push, c.t_last_push, c.t_unmapped, t_written, t_finish, c.t_begin_s, (unsigned long long)c.nrows_total,
            c.fq_stats.threads, (unsigned long long)c.fq_stats.chunks, (unsigned long long)c.fq_stats.chunks_discarded,
            (unsigned long long)c.fq_stats.serial_rows, c.fq_stats.t_setup_s, c.fq_stats.t_wait_frame_s, c.fq_stats.t_push_s,
            c.fq_stats.t_total_s, c.fq_stats.t_push_call_s, c.fq_stats.t_wait_call_s, c.fq_stats.t_push_call_max_s,
            c.fq_stats.t_first_push_call_s, c.ndev ? c.ndev : 1, c.gather_ms, c.tail_ms, c.multi ? g_multi.transport(c.multi) : "-",
-           nbatches_done, t_batch_wait_read, t_batch_pin, t_batch_begin, t_readers_read, t_readers_pack, t_readers_blocked);
+           nbatches_done, t_batch_wait_read, t_batch_pin, t_batch_begin, t_readers_read, t_readers_pack, t_readers_blocked,
+           c.pin ? c.pin->calls : 0, c.pin ? c.pin->t_pin_s : 0.0, c.pin ? (double)c.pin->pinned_bytes / 1048576.0 : 0.0, (double)c.arena_bytes / 1048576.0);
   if (stage2_after) {
     if (c.rows) mk_host_free(c.rows);
     free(c.io);

@@ -51,6 +51,7 @@ typedef struct {
   fs_slot *slots;
   uint64_t next;
   int stop;
+  const mk_rows_sink *sink;
   pthread_mutex_t mu;
   pthread_cond_t cv_buf, cv_ready;
 } fs_t;
@@ -156,6 +157,28 @@ static void fs_frame_range(const fs_t *f, size_t start, size_t stop, int first_o
   }
 }
 
+/* the first records of the file: mean bytes per record and the longest sequence line (with its '\n'); 0 records: nothing to go by */
+static int fs_sample_records(const uint8_t *t, size_t n, size_t *rec_bytes, size_t *seq_max) {
+  size_t p = 0, longest = 0;
+  int rec = 0;
+  for (; rec < 64 && p < n; rec++) {
+    size_t q = p;
+    int line = 0;
+    for (; line < 4 && q < n; line++) {
+      const uint8_t *nl = memchr(t + q, '\n', n - q);
+      if (!nl) { q = n; break; }
+      const size_t len = (size_t)(nl - t) + 1 - q;
+      if (line == 1 && len > longest) longest = len;
+      q = (size_t)(nl - t) + 1;
+    }
+    if (line < 4) break; /* an incomplete record at the end */
+    p = q;
+  }
+  *rec_bytes = rec ? p / (size_t)rec : 0;
+  *seq_max = longest;
+  return rec;
+}
+
 static void *fs_worker(void *arg) {
   fs_t *f = arg;
   for (;;) {
@@ -185,6 +208,7 @@ static void *fs_worker(void *arg) {
       if (b2 > a) madvise((void *)(f->text + a), b2 - a, MADV_DONTNEED);
     }
 
+    if (s.nrows && f->sink && f->sink->ready) f->sink->ready(f->sink->ctx, f->bufs[b], f->buf_bytes);
     pthread_mutex_lock(&f->mu);
     if (s.nrows == 0) { f->freelist[f->nfree++] = b; s.buf = -1; pthread_cond_broadcast(&f->cv_buf); }
     s.ready = 1;
@@ -214,6 +238,7 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
   fs_t f;
   memset(&f, 0, sizeof f);
   f.text = text; f.n = n;
+  f.sink = sink;
   f.occ = o->occ != 0; f.qmin = o->qmin; f.TL = o->TL;
   f.packed = o->packed != 0;
   f.drop_pages = o->drop_pages != 0 && ((uintptr_t)text & 4095u) == 0;
@@ -231,6 +256,21 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
    * reported a line beyond the reference's width */
   if (f.buf_bytes < (size_t)8 * 4096 + 8192) f.buf_bytes = (size_t)8 * 4096 + 8192;
   f.nbufs = T + depth + 1 + (o->ahead < 0 ? 0 : o->ahead > 192 ? 192 : o->ahead);
+  if (o->pool_bytes) {
+    /* a budget for all buffers: packed rows where the file's first records allow them (buffers a fifth of the text), and as many
+     * buffers as the budget holds -- one per chunk at most, then nobody ever waits for one */
+    size_t rec_bytes = 0, seq_max = 0;
+    if (f.packed && fs_sample_records(text, n, &rec_bytes, &seq_max) >= 4 && seq_max && seq_max <= MK_PACKED_MAX_BASES + 1u && rec_bytes >= 8) {
+      const size_t rows = f.chunk / rec_bytes + f.chunk / rec_bytes / 8u + 256u; /* (the header lines grow with the read number: a record does not shrink) */
+      f.buf_bytes = rows * MK_PACKED_PITCH + 8192;
+      if (f.buf_bytes < (size_t)8 * 4096 + 8192) f.buf_bytes = (size_t)8 * 4096 + 8192;
+    }
+    const size_t bb = (f.buf_bytes + 4095) & ~(size_t)4095;
+    uint64_t fit = o->pool_bytes / bb;
+    fit = fit > 1 ? fit - 1 : 0; /* (one more for the serial fallback) */
+    if (fit > f.nchunks) fit = f.nchunks;
+    if (fit > (uint64_t)f.nbufs) f.nbufs = (int)(fit > 65536 ? 65536 : fit);
+  }
   int rc = MK_OK;
   uint8_t *serial_buf = NULL;
   pthread_t *th = NULL;
@@ -255,14 +295,14 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
   pool_bytes = f.buf_bytes * (size_t)(f.nbufs + 1);
   pool = sink->alloc(sink->ctx, pool_bytes);
   if (!pool) { rc = MK_ERR_NOMEM; goto out; }
+  /* the serial fallback's buffer first, then the framers' in address order; the freelist is popped from its end, so chunk c takes
+   * buffer c until buffers come back (mk_fastq_opts::pool_bytes: a sink may pin its block piece by piece in that order) */
+  serial_buf = pool;
   pthread_mutex_lock(&f.mu);
-  for (int b = 0; b < f.nbufs; b++) {
-    f.bufs[b] = pool + (size_t)b * f.buf_bytes;
-    f.freelist[f.nfree++] = b;
-  }
+  for (int b = 0; b < f.nbufs; b++) f.bufs[b] = pool + (size_t)(b + 1) * f.buf_bytes;
+  for (int b = f.nbufs - 1; b >= 0; b--) f.freelist[f.nfree++] = b;
   pthread_cond_broadcast(&f.cv_buf);
   pthread_mutex_unlock(&f.mu);
-  serial_buf = pool + (size_t)f.nbufs * f.buf_bytes;
   stats.t_setup_s = fs_now() - t0;
 
   {
@@ -279,6 +319,7 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
         fs_frame_range(&f, sp_, sto_, sp_ == 0, serial_buf, &ss_);                                                 \
         if (ss_.nrows) {                                                                                           \
           uint64_t tok_ = 0;                                                                                       \
+          if (sink->ready) sink->ready(sink->ctx, serial_buf, f.buf_bytes);                                        \
           rc = sink->push(sink->ctx, serial_buf, ss_.stride, ss_.nrows, ord, &tok_);                               \
           if (rc == MK_OK && sink->wait) rc = sink->wait(sink->ctx, tok_);                                         \
           ord += ss_.nrows; stats.rows += ss_.nrows; stats.records += ss_.nrec; stats.serial_rows += ss_.nrows;    \

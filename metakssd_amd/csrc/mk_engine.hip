@@ -118,6 +118,7 @@ struct mk_engine {
   mk_fa_sum *d_fa_sum = nullptr;
   size_t fa_sum_cap = 0;
   mk_fa_state *d_fa_state = nullptr, *h_fa_state = nullptr; /* device state + pinned mirror */
+  unsigned long long *d_split = nullptr; /* mk_partial_export_split: [0..16) part totals, [16..32) cursors */
   bool counter0_used = true; /* d_counters[0] may be non-zero: a compaction has run since the last mk_sketch_begin */
   uint64_t fa_tail = 0;      /* stream bytes carried from the last non-final push (exact: read back) */
   uint64_t fa_rows_done = 0; /* virtual rows scanned so far in this sketch = ordinal of the next one */
@@ -237,6 +238,10 @@ extern "C" int mk_host_register(void *p, size_t bytes) {
   if (r != hipSuccess) { (void)hipGetLastError(); return mk_fail(nullptr, MK_ERR_HIP, "hipHostRegister(%zu): %s", bytes, hipGetErrorString(r)); }
   return MK_OK;
 }
+extern "C" int mk_host_register_on(int device, void *p, size_t bytes) {
+  if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return mk_fail(nullptr, MK_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device); }
+  return mk_host_register(p, bytes);
+}
 extern "C" int mk_host_unregister(void *p) {
   if (hipHostUnregister(p) == hipSuccess) return MK_OK;
   (void)hipGetLastError();
@@ -283,7 +288,7 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_accept_bits); hipFree(e->d_tab); hipFree(e->d_front); hipFree(e->d_front_desc); hipFree(e->d_slot);
   hipFree(e->d_dirty_acc); hipFree(e->d_dirty_slot); hipFree(e->d_list_acc); hipFree(e->d_list_slot); hipFree(e->d_nlist);
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
-  hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters);
+  hipFree(e->d_chunk); hipFree(e->d_comp_totals); hipFree(e->d_counters); hipFree(e->d_split);
   hipFree(e->d_kl); hipFree(e->d_kl_buckets);
   for (mk_bctx *c : e->bctx) mk_bctx_free(c);
   hipFree(e->d_res_ids); hipFree(e->d_res_cnt); hipFree(e->d_snap);
@@ -1399,6 +1404,107 @@ extern "C" int mk_partial_import(mk_engine *e, const uint64_t *keys_dev, const u
                      (const unsigned long long *)keys_dev, counts_dev, (const unsigned long long *)ords_dev, n);
   MK_HIP(e, hipGetLastError());
   e->compacted = false; e->count_queued = false;
+  return MK_OK;
+}
+
+/* ---- the merge by key slices (include/metakssd_hip.h, "the same merge by key slices") --------------------- */
+extern "C" int mk_partial_export_split_async(mk_engine *e, uint32_t nparts, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t *ords_dev,
+                                             uint64_t capacity, uint64_t *part_counts, uint64_t *n_out) {
+  if (!e || !n_out || !part_counts) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "partial_export_split before mk_sketch_begin");
+  if (nparts < 1 || nparts > MK_SPLIT_MAX) return mk_fail(e, MK_ERR_ARG, "partial_export_split: 1..%u parts", MK_SPLIT_MAX);
+  MK_HIP(e, hipSetDevice(e->device));
+  uint64_t d = 0;
+  int rc = mk_partial_count(e, &d);
+  if (rc) return rc;
+  *n_out = d;
+  for (uint32_t g = 0; g < nparts; g++) part_counts[g] = 0;
+  if (d > capacity) return mk_fail(e, MK_ERR_ARG, "partial_export_split: capacity %llu < %llu keys", (unsigned long long)capacity, (unsigned long long)d);
+  if (d == 0) return MK_OK;
+  if (!keys_dev || !counts_dev || !ords_dev) return MK_ERR_ARG;
+  if (!e->d_split) MK_HIP(e, hipMalloc(&e->d_split, 2 * MK_SPLIT_MAX * sizeof(unsigned long long)));
+  MK_HIP(e, hipMemsetAsync(e->d_split, 0, 2 * MK_SPLIT_MAX * sizeof(unsigned long long), e->stream));
+  uint64_t blocks = (d + 1023) / 1024;
+  if (blocks > (uint64_t)e->num_cu * 2) blocks = (uint64_t)e->num_cu * 2;
+  hipLaunchKernelGGL(mk_split_count_kernel, dim3((unsigned)blocks), dim3(1024), 0, e->stream, e->dist, (const unsigned long long *)e->d_counters, nparts, e->d_split);
+  hipLaunchKernelGGL(mk_split_offsets_kernel, dim3(1), dim3(1), 0, e->stream, (const unsigned long long *)e->d_split, e->d_split + MK_SPLIT_MAX, nparts);
+  hipLaunchKernelGGL(mk_split_scatter_kernel, dim3((unsigned)blocks), dim3(1024), 0, e->stream, e->dist, (const unsigned long long *)e->d_counters, nparts,
+                     e->d_split + MK_SPLIT_MAX, (unsigned long long *)keys_dev, counts_dev, (unsigned long long *)ords_dev, capacity);
+  MK_HIP(e, hipGetLastError());
+  MK_HIP(e, hipMemcpyAsync(part_counts, e->d_split, nparts * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+  return MK_OK;
+}
+
+extern "C" int mk_partial_export_split(mk_engine *e, uint32_t nparts, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t *ords_dev,
+                                       uint64_t capacity, uint64_t *part_counts, uint64_t *n_out) {
+  int rc = mk_partial_export_split_async(e, nparts, keys_dev, counts_dev, ords_dev, capacity, part_counts, n_out);
+  if (rc) return rc;
+  MK_HIP(e, hipStreamSynchronize(e->stream));
+  return MK_OK;
+}
+
+extern "C" int mk_partial_restart(mk_engine *e) {
+  if (!e) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "partial_restart before mk_sketch_begin");
+  const int mode = e->mode;
+  const uint32_t occ = e->min_occ;
+  { int rc = mk_flush_region(e); if (rc) return rc; } /* (rows staged and not scanned yet belong to what the caller exported: scanned, then dropped) */
+  int rc = mk_sketch_begin(e, mode);
+  if (rc == MK_OK) e->min_occ = occ;
+  return rc;
+}
+
+extern "C" int mk_partial_list_reserve(mk_engine *e, uint64_t n, uint64_t **keys_dev, uint32_t **counts_dev, uint64_t **ords_dev) {
+  if (!e || !keys_dev || !counts_dev || !ords_dev) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "partial_list_reserve before mk_sketch_begin");
+  if (e->res_pending) return mk_fail(e, MK_ERR_STATE, "partial_list_reserve while the side stream works on the key list (mk_sketch_finish_end first)");
+  MK_HIP(e, hipSetDevice(e->device));
+  if (n > e->dist.cap || !e->dist.key) { /* grow, keeping what a compaction has listed */
+    const uint64_t keep = e->compacted ? (e->D < e->dist.cap ? e->D : e->dist.cap) : 0;
+    MK_HIP(e, hipStreamSynchronize(e->stream));
+    const uint64_t cap = n + n / 8 + 1024;
+    unsigned long long *nk = nullptr, *no = nullptr;
+    uint32_t *nc = nullptr;
+    MK_HIP(e, hipMalloc(&nk, cap * 8));
+    MK_HIP(e, hipMalloc(&no, cap * 8));
+    MK_HIP(e, hipMalloc(&nc, cap * 4));
+    if (keep) {
+      MK_HIP(e, hipMemcpy(nk, e->dist.key, keep * 8, hipMemcpyDeviceToDevice));
+      MK_HIP(e, hipMemcpy(no, e->dist.ord, keep * 8, hipMemcpyDeviceToDevice));
+      MK_HIP(e, hipMemcpy(nc, e->dist.cnt, keep * 4, hipMemcpyDeviceToDevice));
+    }
+    hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
+    e->dist.key = nk; e->dist.ord = no; e->dist.cnt = nc; e->dist.cap = cap;
+  }
+  *keys_dev = (uint64_t *)e->dist.key; *counts_dev = e->dist.cnt; *ords_dev = (uint64_t *)e->dist.ord;
+  return MK_OK;
+}
+
+extern "C" int mk_partial_list_adopt(mk_engine *e, const uint64_t *keys_dev, const uint32_t *counts_dev, const uint64_t *ords_dev, uint64_t n,
+                                     uint64_t offset) {
+  if (!e) return MK_ERR_ARG;
+  uint64_t *k = nullptr, *o = nullptr;
+  uint32_t *c = nullptr;
+  int rc = mk_partial_list_reserve(e, offset + n, &k, &c, &o);
+  if (rc || n == 0) return rc;
+  if (!keys_dev || !counts_dev || !ords_dev) return MK_ERR_ARG;
+  MK_HIP(e, hipMemcpyAsync(k + offset, keys_dev, n * 8, hipMemcpyDeviceToDevice, e->stream));
+  MK_HIP(e, hipMemcpyAsync(c + offset, counts_dev, n * 4, hipMemcpyDeviceToDevice, e->stream));
+  MK_HIP(e, hipMemcpyAsync(o + offset, ords_dev, n * 8, hipMemcpyDeviceToDevice, e->stream));
+  return MK_OK;
+}
+
+extern "C" int mk_partial_list_commit(mk_engine *e, uint64_t n) {
+  if (!e) return MK_ERR_ARG;
+  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "partial_list_commit before mk_sketch_begin");
+  if (n > e->dist.cap) return mk_fail(e, MK_ERR_ARG, "partial_list_commit: %llu entries, the list holds %llu (mk_partial_list_reserve)", (unsigned long long)n, (unsigned long long)e->dist.cap);
+  MK_HIP(e, hipSetDevice(e->device));
+  { int rc = mk_flush_region(e); if (rc) return rc; }
+  hipLaunchKernelGGL(mk_set_counter_kernel, dim3(1), dim3(1), 0, e->stream, e->d_counters, (unsigned long long)n);
+  MK_HIP(e, hipGetLastError());
+  e->counter0_used = true;
+  e->D = n;
+  e->compacted = true; e->count_queued = false; /* the finish starts from this list: no compaction of the table */
   return MK_OK;
 }
 

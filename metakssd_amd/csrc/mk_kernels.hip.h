@@ -1214,6 +1214,50 @@ struct mk_dist {
   uint64_t cap;
 };
 
+/* ---- multi-GPU, merge by key slices: the distinct list cut into nparts parts by key % nparts ---------------------------------
+ * count: per-part totals (LDS histogram, one global add per part and workgroup); offsets: exclusive prefix -> cursors;
+ * scatter: a workgroup reserves room for its entries of part g with one add on cursor g and writes them there. */
+#define MK_SPLIT_MAX 16u
+__global__ void __launch_bounds__(1024) mk_split_count_kernel(mk_dist d, const unsigned long long *Dp, uint32_t nparts, unsigned long long *hist) {
+  __shared__ uint32_t h[MK_SPLIT_MAX];
+  if (threadIdx.x < MK_SPLIT_MAX) h[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint64_t D = *Dp;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += (uint64_t)gridDim.x * blockDim.x)
+    atomicAdd(&h[(uint32_t)(d.key[i] % nparts)], 1u);
+  __syncthreads();
+  if (threadIdx.x < nparts && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+__global__ void mk_split_offsets_kernel(const unsigned long long *hist, unsigned long long *cursor, uint32_t nparts) {
+  unsigned long long at = 0;
+  for (uint32_t g = 0; g < nparts; g++) { cursor[g] = at; at += hist[g]; }
+}
+__global__ void __launch_bounds__(1024) mk_split_scatter_kernel(mk_dist d, const unsigned long long *Dp, uint32_t nparts, unsigned long long *cursor,
+                                                                unsigned long long *okey, uint32_t *ocnt, unsigned long long *oord, uint64_t ocap) {
+  __shared__ uint32_t h[MK_SPLIT_MAX];
+  __shared__ unsigned long long base[MK_SPLIT_MAX];
+  const uint64_t D = *Dp;
+  const uint64_t tiles = (D + blockDim.x - 1) / blockDim.x;
+  for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    if (threadIdx.x < MK_SPLIT_MAX) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint64_t i = t * blockDim.x + threadIdx.x;
+    unsigned long long k = 0;
+    uint32_t g = 0, r = 0;
+    if (i < D) { k = d.key[i]; g = (uint32_t)(k % nparts); r = atomicAdd(&h[g], 1u); }
+    __syncthreads();
+    if (threadIdx.x < nparts) base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)h[threadIdx.x]) : 0ull;
+    __syncthreads();
+    if (i < D) {
+      const unsigned long long o = base[g] + r;
+      if (o < ocap) { okey[o] = k; ocnt[o] = d.cnt[i]; oord[o] = d.ord[i]; }
+    }
+    __syncthreads();
+  }
+}
+__global__ void mk_set_counter_kernel(unsigned long long *counter, unsigned long long v) { counter[0] = v; }
+
+
 /* ---- sparse bookkeeping for large tables --------------------------------------------------------------------------
  * mk_dirty_list_kernel: bitmap -> list of set block indices (any order), one workgroup.
  * mk_dirty_clear_kernel: re-establishes "all empty" on the listed blocks of the accumulation table (zero) and, with the

@@ -35,6 +35,14 @@ struct mk_multi {
   unsigned long long *rk = nullptr, *ro = nullptr;
   uint32_t *rc = nullptr;
   uint64_t rcap = 0;
+  /* merge by key slices: what engine g receives of the others' parts g, on its own device; part sizes in pinned host memory */
+  std::vector<unsigned long long *> sk, so;
+  std::vector<uint32_t *> sc;
+  std::vector<uint64_t> scap;
+  uint64_t *h_parts = nullptr; /* [n][16] */
+  int merge = 0;               /* MK_MULTI_MERGE_* */
+  const char *last_merge = "gather";
+  mk_multi_times times{};
 };
 
 static int mm_fail(mk_multi *m, int code, const char *fmt, ...) {
@@ -74,6 +82,9 @@ extern "C" int mk_multi_destroy(mk_multi *m) {
     if ((size_t)i < m->xk.size()) { hipFree(m->xk[(size_t)i]); hipFree(m->xc[(size_t)i]); hipFree(m->xo[(size_t)i]); }
     if ((size_t)i < m->xs.size() && m->xs[(size_t)i]) hipStreamDestroy(m->xs[(size_t)i]);
   }
+  for (int i = 0; i < m->n; i++)
+    if ((size_t)i < m->sk.size() && m->sk[(size_t)i]) { hipSetDevice(m->dev[(size_t)i]); hipFree(m->sk[(size_t)i]); hipFree(m->sc[(size_t)i]); hipFree(m->so[(size_t)i]); }
+  if (m->h_parts) hipHostFree(m->h_parts);
   if (!m->dev.empty()) { hipSetDevice(m->dev[0]); hipFree(m->rk); hipFree(m->rc); hipFree(m->ro); }
   for (auto c : m->comm) if (c) ncclCommDestroy(c);
   for (auto e : m->eng) if (e) mk_engine_destroy(e);
@@ -143,7 +154,11 @@ extern "C" int mk_multi_create_ex(const mk_params *p, const int *devices, int n,
       }
     }
   }
-  if (n > 1) fprintf(stderr, "metakssd multi: %d engines, exchange transport: %s\n", n, m->rccl ? "rccl" : "device copies");
+  if (const char *mg = getenv("MK_MULTI_MERGE")) /* "gather" / "slices": mk_multi_set_merge for callers that cannot call it (the command line's --devices) */
+    m->merge = !strcmp(mg, "gather") ? MK_MULTI_MERGE_GATHER : !strcmp(mg, "slices") ? MK_MULTI_MERGE_SLICES : MK_MULTI_MERGE_AUTO;
+  if (n > 1)
+    fprintf(stderr, "metakssd multi: %d engines, exchange transport: %s, merge: %s\n", n, m->rccl ? "rccl" : "device copies",
+            m->merge == MK_MULTI_MERGE_GATHER || (m->merge == MK_MULTI_MERGE_AUTO && n < 4) ? "gather to engine 0" : "key slices (all-to-all, then gather)");
   *out = m;
   return MK_OK;
 }
@@ -172,8 +187,182 @@ extern "C" int mk_multi_begin_occ(mk_multi *m, int min_occurrence) {
   return MK_OK;
 }
 
+/* ---- moving lists between the engines' devices: RCCL point-to-point inside ONE group call, or device copies ------------------- */
+struct mm_xfer { int src, dst; const void *from; void *to; size_t bytes; };
+static int mm_move(mk_multi *m, const std::vector<mm_xfer> &x) {
+  if (x.empty()) return MK_OK;
+  if (m->rccl) {
+    ncclResult_t r = ncclGroupStart();
+    for (size_t i = 0; i < x.size() && r == ncclSuccess; i++) {
+      if (!x[i].bytes) continue;
+      /* matched pairwise in order: the k-th send of rank a to rank b meets the k-th receive of b from a */
+      r = ncclSend(x[i].from, x[i].bytes, ncclUint8, x[i].dst, m->comm[(size_t)x[i].src], m->xs[(size_t)x[i].src]);
+      if (r == ncclSuccess) r = ncclRecv(x[i].to, x[i].bytes, ncclUint8, x[i].src, m->comm[(size_t)x[i].dst], m->xs[(size_t)x[i].dst]);
+    }
+    const ncclResult_t r2 = ncclGroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess) return mm_fail(m, MK_ERR_HIP, "RCCL exchange: %s", ncclGetErrorString(r != ncclSuccess ? r : r2));
+  } else {
+    for (size_t i = 0; i < x.size(); i++) {
+      if (!x[i].bytes) continue;
+      MM_HIP(m, hipSetDevice(m->dev[(size_t)x[i].dst]));
+      MM_HIP(m, hipMemcpyPeerAsync(x[i].to, m->dev[(size_t)x[i].dst], x[i].from, m->dev[(size_t)x[i].src], x[i].bytes, m->xs[(size_t)x[i].dst]));
+    }
+  }
+  for (int i = 0; i < m->n; i++) {
+    MM_HIP(m, hipSetDevice(m->dev[(size_t)i]));
+    MM_HIP(m, hipStreamSynchronize(m->xs[(size_t)i]));
+  }
+  return MK_OK;
+}
+static int mm_fit3(mk_multi *m, int dev, unsigned long long **k, uint32_t **c, unsigned long long **o, uint64_t *cap, uint64_t need) {
+  if (need <= *cap && *k) return MK_OK;
+  MM_HIP(m, hipSetDevice(dev));
+  hipFree(*k); hipFree(*c); hipFree(*o);
+  *k = nullptr; *c = nullptr; *o = nullptr; *cap = 0;
+  const uint64_t want = need + need / 8 + 1024;
+  MM_HIP(m, hipMalloc(k, want * 8));
+  MM_HIP(m, hipMalloc(c, want * 4));
+  MM_HIP(m, hipMalloc(o, want * 8));
+  *cap = want;
+  return MK_OK;
+}
+
+extern "C" int mk_multi_set_merge(mk_multi *m, int how) {
+  if (!m || how < MK_MULTI_MERGE_AUTO || how > MK_MULTI_MERGE_SLICES) return MK_ERR_ARG;
+  m->merge = how;
+  return MK_OK;
+}
+extern "C" const char *mk_multi_last_merge(const mk_multi *m) { return m ? m->last_merge : ""; }
+extern "C" int mk_multi_last_times(const mk_multi *m, mk_multi_times *t) {
+  if (!m || !t) return MK_ERR_ARG;
+  *t = m->times;
+  return MK_OK;
+}
+
+/* The merge by key slices (SURVEY.md 8e's alternative; include/metakssd_hip.h "the same merge by key slices"): with n engines the
+ * gather makes engine 0 fold n - 1 whole lists into its table (14 M random atomics at n = 8 for BASELINE config 4); here every
+ * engine folds an n-th of every list at the same time and engine 0 receives lists of keys that are distinct already. */
+static int mm_finish_slices(mk_multi *m, mk_result *out, double *gather_ms, double *tail_ms) {
+  const double t0 = mm_now();
+  const int n = m->n;
+  const uint32_t G = (uint32_t)n;
+  if (!m->h_parts) MM_HIP(m, hipHostMalloc((void **)&m->h_parts, (size_t)n * 16 * sizeof(uint64_t), hipHostMallocDefault));
+  if (m->sk.empty()) { m->sk.assign((size_t)n, nullptr); m->sc.assign((size_t)n, nullptr); m->so.assign((size_t)n, nullptr); m->scap.assign((size_t)n, 0); }
+  /* 1. every engine: compaction (all queued first), then its list cut into n parts by key % n, in its exchange buffers */
+  for (int i = 0; i < n; i++) {
+    const int rc = mk_partial_count_begin(m->eng[(size_t)i]);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(m->eng[(size_t)i]));
+  }
+  std::vector<uint64_t> D((size_t)n, 0);
+  for (int i = 0; i < n; i++) {
+    mk_engine *e = m->eng[(size_t)i];
+    int rc = mk_partial_count(e, &D[(size_t)i]);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(e));
+    rc = mm_fit3(m, m->dev[(size_t)i], &m->xk[(size_t)i], &m->xc[(size_t)i], &m->xo[(size_t)i], &m->xcap[(size_t)i], D[(size_t)i]);
+    if (rc) return rc;
+    uint64_t got = 0;
+    rc = mk_partial_export_split_async(e, G, (uint64_t *)m->xk[(size_t)i], m->xc[(size_t)i], (uint64_t *)m->xo[(size_t)i], m->xcap[(size_t)i],
+                                       m->h_parts + (size_t)i * 16, &got);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(e));
+  }
+  for (int i = 0; i < n; i++) {
+    const int rc = mk_engine_sync(m->eng[(size_t)i]);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(m->eng[(size_t)i]));
+  }
+  const double t1 = mm_now();
+  /* 2. tables cleared for the slices (queued; runs beside the exchange), part g of every engine to engine g */
+  for (int i = 0; i < n; i++) {
+    const int rc = mk_partial_restart(m->eng[(size_t)i]);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", i, mk_last_error(m->eng[(size_t)i]));
+  }
+  std::vector<uint64_t> incoming((size_t)n, 0);
+  std::vector<mm_xfer> xf;
+  for (int g = 0; g < n; g++) {
+    uint64_t need = 0;
+    for (int i = 0; i < n; i++) if (i != g) need += m->h_parts[(size_t)i * 16 + (size_t)g];
+    incoming[(size_t)g] = need;
+    const int rc = mm_fit3(m, m->dev[(size_t)g], &m->sk[(size_t)g], &m->sc[(size_t)g], &m->so[(size_t)g], &m->scap[(size_t)g], need ? need : 1);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < n; i++) {
+    uint64_t src_at = 0;
+    for (int g = 0; g < n; g++) {
+      const uint64_t c = m->h_parts[(size_t)i * 16 + (size_t)g];
+      if (i != g && c) {
+        uint64_t dst_at = 0;
+        for (int j = 0; j < i; j++) if (j != g) dst_at += m->h_parts[(size_t)j * 16 + (size_t)g];
+        xf.push_back({i, g, m->xk[(size_t)i] + src_at, m->sk[(size_t)g] + dst_at, (size_t)c * 8});
+        xf.push_back({i, g, m->xc[(size_t)i] + src_at, m->sc[(size_t)g] + dst_at, (size_t)c * 4});
+        xf.push_back({i, g, m->xo[(size_t)i] + src_at, m->so[(size_t)g] + dst_at, (size_t)c * 8});
+      }
+      src_at += c;
+    }
+  }
+  int rc = mm_move(m, xf);
+  if (rc) return rc;
+  const double t2 = mm_now();
+  /* 3. every engine folds its slice: its own part (where the export left it) and what it received; then the slice's list */
+  for (int g = 0; g < n; g++) {
+    mk_engine *e = m->eng[(size_t)g];
+    uint64_t own_at = 0;
+    for (int j = 0; j < g; j++) own_at += m->h_parts[(size_t)g * 16 + (size_t)j];
+    const uint64_t own = m->h_parts[(size_t)g * 16 + (size_t)g];
+    if (own) rc = mk_partial_import(e, (const uint64_t *)(m->xk[(size_t)g] + own_at), m->xc[(size_t)g] + own_at, (const uint64_t *)(m->xo[(size_t)g] + own_at), own);
+    if (rc == MK_OK && incoming[(size_t)g])
+      rc = mk_partial_import(e, (const uint64_t *)m->sk[(size_t)g], m->sc[(size_t)g], (const uint64_t *)m->so[(size_t)g], incoming[(size_t)g]);
+    if (rc == MK_OK) rc = mk_partial_count_begin(e);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", g, mk_last_error(e));
+  }
+  std::vector<uint64_t> R((size_t)n, 0);
+  uint64_t total = 0;
+  for (int g = 0; g < n; g++) {
+    rc = mk_partial_count(m->eng[(size_t)g], &R[(size_t)g]);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", g, mk_last_error(m->eng[(size_t)g]));
+    total += R[(size_t)g];
+  }
+  const double t3 = mm_now();
+  /* 4. the reduced slices to engine 0, behind its own in its key list: disjoint key sets, so that list is the sketch's */
+  mk_engine *e0 = m->eng[0];
+  uint64_t *k0 = nullptr, *o0 = nullptr;
+  uint32_t *c0 = nullptr;
+  rc = mk_partial_list_reserve(e0, total, &k0, &c0, &o0);
+  if (rc) return mm_fail(m, rc, "engine 0: %s", mk_last_error(e0));
+  xf.clear();
+  uint64_t at = R[0];
+  for (int g = 1; g < n; g++) {
+    uint64_t *kg = nullptr, *og = nullptr;
+    uint32_t *cg = nullptr;
+    rc = mk_partial_list_reserve(m->eng[(size_t)g], R[(size_t)g], &kg, &cg, &og);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", g, mk_last_error(m->eng[(size_t)g]));
+    if (R[(size_t)g]) {
+      xf.push_back({g, 0, kg, k0 + at, (size_t)R[(size_t)g] * 8});
+      xf.push_back({g, 0, cg, c0 + at, (size_t)R[(size_t)g] * 4});
+      xf.push_back({g, 0, og, o0 + at, (size_t)R[(size_t)g] * 8});
+    }
+    at += R[(size_t)g];
+  }
+  for (int g = 0; g < n; g++) { /* the slices' lists are complete on their engines' streams */
+    rc = mk_engine_sync(m->eng[(size_t)g]);
+    if (rc) return mm_fail(m, rc, "engine %d: %s", g, mk_last_error(m->eng[(size_t)g]));
+  }
+  rc = mm_move(m, xf);
+  if (rc) return rc;
+  const double t4 = mm_now();
+  rc = mk_partial_list_commit(e0, total);
+  if (rc == MK_OK) rc = mk_sketch_finish(e0, out);
+  if (rc) return mm_fail(m, rc, "%s", mk_last_error(e0));
+  const double t5 = mm_now();
+  m->times = mk_multi_times{t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0};
+  m->last_merge = "slices";
+  if (gather_ms) *gather_ms = (t2 - t1) + (t4 - t3);
+  if (tail_ms) *tail_ms = t5 - t0;
+  return MK_OK;
+}
+
 extern "C" int mk_multi_finish(mk_multi *m, mk_result *out, double *gather_ms, double *tail_ms) {
   if (!m || !out) return MK_ERR_ARG;
+  /* which merge: the slices pay from four engines on (the fold on engine 0 shrinks by n - 1, two more exchange steps come in) */
+  if (m->n > 1 && (m->merge == MK_MULTI_MERGE_SLICES || (m->merge == MK_MULTI_MERGE_AUTO && m->n >= 4))) return mm_finish_slices(m, out, gather_ms, tail_ms);
   const double t0 = mm_now();
   const int n = m->n;
   std::vector<uint64_t> cnt((size_t)n, 0), off((size_t)n, 0);
@@ -263,10 +452,14 @@ extern "C" int mk_multi_finish(mk_multi *m, mk_result *out, double *gather_ms, d
     int rc = mk_partial_import(e0, (const uint64_t *)m->rk, m->rc, (const uint64_t *)m->ro, total);
     if (rc) return mm_fail(m, rc, "import: %s", mk_last_error(e0));
   }
+  const double t3 = mm_now();
   int rc = mk_sketch_finish(e0, out);
   if (rc) return mm_fail(m, rc, "%s", mk_last_error(e0));
   /* the other engines' sketches are spent: leave them ready for the next begin */
+  const double t4 = mm_now();
+  m->times = mk_multi_times{t1 - t0, t2 - t1, t3 - t2, 0.0, t4 - t3, t4 - t0};
+  m->last_merge = "gather";
   if (gather_ms) *gather_ms = t2 - t1;
-  if (tail_ms) *tail_ms = mm_now() - t0;
+  if (tail_ms) *tail_ms = t4 - t0;
   return MK_OK;
 }

@@ -3,7 +3,9 @@
 Reads shard as contiguous ranges with GLOBAL ordinals; each rank keeps a private table, so there is no
 data-path collective during the scan.  The only exchange is a gather of the per-rank distinct-key lists
 {key u64, count u32 (clamped to 65535), first ordinal u64} to rank 0, which folds them into its table
-(counts add, first ordinals take min) and rebuilds the sequential layout.  With the "nccl" backend this is
+(counts add, first ordinals take min) and rebuilds the sequential layout -- or, from four ranks on, SURVEY.md 8e's alternative:
+an all-to-all by key % world (exchange_slices), every rank folds a key slice, and the gather moves REDUCED slices, which are
+rank 0's key list as they stand.  With the "nccl" backend this is
 RCCL point-to-point over xGMI: every sender has its own link to rank 0, lists are a few MB to tens of MB.
 The same code runs over gloo with CPU tensors (tests).
 """
@@ -79,6 +81,50 @@ def gather_partials_concat(keys, counts, ords, n, dst=0, group=None, out=None):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return total
+
+
+# ---- SURVEY.md 8e's alternative exchange: all-to-all by key % world, every rank reduces a key slice, gather of the reduced slices ----
+def exchange_slices(keys, counts, ords, part_sizes, group=None, out=None):
+    """This rank's distinct list arrives CUT INTO world PARTS by key % world (mk_partial_export_split: part g starts at
+    sum(part_sizes[:g])).  Part g of every rank goes to rank g.  Returns (n_received, (keys, counts, ords)): the parts this rank
+    received from the OTHER ranks, back to back in rank order, in `out` when given (tensors of the exchange device with room for
+    them) or in fresh tensors.  The rank's own part stays where it is (the caller folds it in from there).  One exchange: an
+    all-gather of the world x world part sizes, then batched isend / irecv (RCCL point-to-point with the "nccl" backend)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = keys.device
+    assert len(part_sizes) == world
+    mine = torch.tensor([int(x) for x in part_sizes], dtype=torch.int64, device=dev)
+    allp = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(allp, mine, group=group)
+    sizes = [[int(v) for v in t.tolist()] for t in allp]  # sizes[r][g]: what rank r holds for rank g
+    incoming = sum(sizes[r][rank] for r in range(world) if r != rank)
+    if out is None:
+        out = (torch.empty(incoming, dtype=torch.int64, device=dev), torch.empty(incoming, dtype=torch.int32, device=dev),
+               torch.empty(incoming, dtype=torch.int64, device=dev))
+    rk, rc, ro = out
+    if incoming > rk.numel():
+        raise ValueError("exchange_slices: %d incoming entries, room for %d" % (incoming, rk.numel()))
+    ops, at = [], 0
+    for r in range(world):  # receives in rank order
+        n = sizes[r][rank]
+        if r == rank or n == 0:
+            continue
+        ops += [dist.P2POp(dist.irecv, rk[at:at + n], r, group), dist.P2POp(dist.irecv, rc[at:at + n], r, group),
+                dist.P2POp(dist.irecv, ro[at:at + n], r, group)]
+        at += n
+    off = 0
+    for g in range(world):
+        n = sizes[rank][g]
+        if g != rank and n:
+            ops += [dist.P2POp(dist.isend, keys[off:off + n].contiguous(), g, group),
+                    dist.P2POp(dist.isend, counts[off:off + n].contiguous(), g, group),
+                    dist.P2POp(dist.isend, ords[off:off + n].contiguous(), g, group)]
+        off += n
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return incoming, out
 
 
 # ---- config 5 (SURVEY.md 8e): whole input files are the unit -- no reduction, only a gather in file order -----------

@@ -2,7 +2,9 @@
 
 Each rank sketches its contiguous read range with GLOBAL ordinals (here with the oracle's shard model, because the
 product's scan needs a GPU), the product's gather_partials() moves the lists to rank 0, rank 0 merges and lays out.
-Checked: (1) shard ranges tile the input, (2) the exchange delivers every list intact, (3) merged == sequential."""
+Checked: (1) shard ranges tile the input, (2) the exchange delivers every list intact, (3) merged == sequential;
+(4) the same through SURVEY.md 8e's alternative exchange (exchange_slices: all-to-all by key % world, every rank folds a key
+slice, gather of the reduced slices): every rank receives exactly its slice, the concatenated slices == sequential."""
 import os
 import sys
 
@@ -69,6 +71,38 @@ def main():
         open(os.environ["MK_DIST_RESULT"], "w").write("OK %d" % len(want[0][0]) if ok else "MISMATCH")
     else:
         assert got == []
+
+    # ---- SURVEY.md 8e's alternative: all-to-all by key % world, every rank reduces a key slice, gather of the reduced slices ----
+    from metakssd_amd.shard import exchange_slices
+    order = np.argsort(keys % np.uint64(world), kind="stable")  # the list cut into parts by key % world (mk_partial_export_split)
+    sk, sc, so = keys[order], cnts[order], ords[order]
+    part_sizes = [int(np.sum(keys % np.uint64(world) == g)) for g in range(world)]
+    n_in, (rk, rc_, ro) = exchange_slices(torch.from_numpy(sk.view(np.int64).copy()), torch.from_numpy(sc.view(np.int32).copy()),
+                                          torch.from_numpy(so.view(np.int64).copy()), part_sizes)
+    own0 = sum(part_sizes[:rank])
+    ak = np.concatenate([sk[own0:own0 + part_sizes[rank]], rk[:n_in].numpy().view(np.uint64)])
+    ac = np.concatenate([sc[own0:own0 + part_sizes[rank]], rc_[:n_in].numpy().view(np.uint32)])
+    ao = np.concatenate([so[own0:own0 + part_sizes[rank]], ro[:n_in].numpy().view(np.uint64)])
+    assert np.all(ak % np.uint64(world) == rank)  # this rank's slice, and nothing else
+    # fold the slice: counts add (clamped), first ordinals take the minimum -- what mk_partial_import does in the table
+    uk, inv = np.unique(ak, return_inverse=True)
+    uc = np.minimum(np.bincount(inv, weights=ac.astype(np.float64), minlength=len(uk)), 65535).astype(np.uint32)
+    uo = np.full(len(uk), np.iinfo(np.uint64).max, np.uint64)
+    np.minimum.at(uo, inv, ao)
+    tk2, tc2, to2 = torch.from_numpy(uk.view(np.int64).copy()), torch.from_numpy(uc.view(np.int32).copy()), torch.from_numpy(uo.view(np.int64).copy())
+    if rank == 0:
+        tot = gather_partials_concat(tk2[:0], tc2[:0], to2[:0], 0, dst=0, out=outbuf)
+        # the slices are disjoint key sets: their concatenation is the sketch's list of distinct keys, nothing left to fold
+        lk = np.concatenate([uk, outbuf[0][:tot].numpy().view(np.uint64)])
+        lc = np.concatenate([uc, outbuf[1][:tot].numpy().view(np.uint32)])
+        lo_ = np.concatenate([uo, outbuf[2][:tot].numpy().view(np.uint64)])
+        ok2 = len(np.unique(lk)) == len(lk)
+        merged2 = Oracle(shuf.c.id, 6, 3, 0, shuf.table).layout_from_partials([(lk, lc, lo_)])
+        ok2 &= np.array_equal(merged2[0][0], want[0][0]) and np.array_equal(merged2[0][1], want[0][1])
+        if not ok2:
+            open(os.environ["MK_DIST_RESULT"], "w").write("MISMATCH (slices)")
+    else:
+        assert gather_partials_concat(tk2, tc2, to2, len(uk), dst=0) == 0
     dist.barrier()
     dist.destroy_process_group()
 

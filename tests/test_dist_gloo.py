@@ -8,8 +8,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_sketch_merge_over_gloo(world, tmp_path):
+    """both exchanges of SURVEY.md 8e: the gather of whole lists to rank 0, and the all-to-all by key % world with the gather of
+    reduced slices (tests/dist_worker.py)"""
     result = str(tmp_path / "result.txt")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MK_DIST_RESULT=result)
     port = 29500 + (os.getpid() % 2000) + world

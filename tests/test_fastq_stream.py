@@ -216,6 +216,50 @@ def _bases_of_packed(row):
 
 
 @pytest.mark.parametrize("occ", [False, True])
+def test_stream_with_a_budgeted_pool_equals_serial_framer(capi, occ):
+    """mk_fastq_opts.pool_bytes: buffers sized for PACKED rows from the file's first records, as many as the budget holds (one per chunk
+    at most), handed out in address order, every finished buffer reported to the sink (mk_rows_sink.ready) -- rows, order and ordinals
+    stay the serial framer's: with room for every chunk, with a budget of a few buffers (reuse), and on a file whose LATER records are
+    much shorter than the first ones (more rows a chunk than its buffer holds: those chunks end early, the calling thread frames the rest)"""
+    rs = np.random.RandomState(83)
+    uniform = [ui.rand_seq(rs, 150) for _ in range(6000)]
+    shrinking = [ui.rand_seq(rs, 150) for _ in range(1500)] + [ui.rand_seq(rs, int(rs.randint(1, 12))) for _ in range(20000)]
+    for name, seqs in (("uniform", uniform), ("shrinking", shrinking)):
+        data = ui.fastq_bytes(seqs, quals=[bytes(rs.randint(44, 64, len(x)).astype(np.uint8)) for x in seqs])
+        want, nrec, rc = serial_rows(capi, data, occ)
+        assert rc == 0
+        want_bases = [_bases_of_text(w[:-1] if w.endswith(b"\n") else w) for w in want]
+        for T, chunk, pool in ((4, 1 << 16, 1 << 30), (3, 20000, 200000), (8, 1 << 15, 1 << 30), (1, 1 << 20, 1 << 22)):
+            log = []
+            pushes, st, rc = capi.fastq_stream(data, nthreads=T, chunk_bytes=chunk, occ=occ, TL=14, qmin=54, first_ordinal=3, packed=True, pool_bytes=pool,
+                                               ready_log=log)
+            assert rc == 0, (name, T, chunk, pool)
+            got, ord_expect = [], 3
+            for rows, stride, n, ord0 in pushes:
+                assert ord0 == ord_expect
+                ord_expect += n
+                if stride & capi.MK_ROWS_PACKED:
+                    got += [_bases_of_packed(rows[64 * i: 64 * i + 64]) for i in range(n)]
+                else:
+                    got += [_bases_of_text(x[:-1] if x.endswith(b"\n") else x) for x in seqs_of_rows(rows, stride, n)]
+            assert got == want_bases, (name, T, chunk, pool)
+            assert st.records == nrec
+            blocks, ready = log[0], log[1:]
+            assert len(blocks) == 1 and len(ready) >= st.chunks - st.chunks_discarded - 1 - (1 if st.serial_rows else 0) or st.serial_rows
+            assert all(0 <= off and off + n <= blocks[0][1] for off, n in ready), "every reported buffer lies inside the sink's block"
+            if name == "uniform" and pool == 1 << 30:
+                nchunks = (len(data) + chunk - 1) // chunk
+                assert len({off for off, n in ready}) >= min(nchunks, len(ready)) - 1, "no buffer is reused while there is one per chunk"
+                offs = [off for off, n in ready]
+                assert len(set(n for off, n in ready)) == 1 and min(offs) == ready[0][1], "buffer 0 is the serial fallback's; the framers' follow it"
+            if name == "uniform" and chunk == 1 << 20:
+                # packed sizing: a buffer holds about a fifth of its chunk's text (text rows: all of it and an eighth more)
+                assert ready[0][1] < 0.3 * chunk, ready[0][1]
+            if name == "shrinking":
+                assert st.serial_rows > 0 or pool < (1 << 23)
+
+
+@pytest.mark.parametrize("occ", [False, True])
 def test_stream_packed_rows_carry_the_serial_framers_bases(capi, occ):
     """mk_fastq_opts.packed: buffers whose reads all fit 152 bases come as 64-byte packed rows -- base for base (code, validity) what the
     serial framer's text rows hold; a buffer with a longer read comes as text rows; order and ordinals as ever"""

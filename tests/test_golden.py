@@ -655,7 +655,9 @@ def test_cli_several_engines_equal_one(shuf, flags, shuf_files, tmp_path):
     """`metakssd dist --devices a,b,..` (libmetakssd_multi.so): the FASTQ stream's row buffers are dealt round-robin to one
     engine per listed GPU, mk_multi_finish gathers the partial sketches on the first one (RCCL between distinct GPUs; on
     this one-GPU box the list names GPU 0 several times and the lists move with device copies), one import launch, finish.
-    The sketch directory is byte-identical to the single-engine run -- SURVEY.md 8e's merge algebra through the C product."""
+    The sketch directory is byte-identical to the single-engine run -- SURVEY.md 8e's merge algebra through the C product.
+    Both merges: the gather to engine 0 (default below four engines) and SURVEY.md 8e's key slices (all-to-all by key % n, every
+    engine folds its slice, the reduced slices are engine 0's key list: default from four engines on; MK_MULTI_MERGE forces one)."""
     import numpy as np
     import util_inputs as ui
     rs = np.random.RandomState(5)
@@ -664,16 +666,22 @@ def test_cli_several_engines_equal_one(shuf, flags, shuf_files, tmp_path):
     open(fq, "wb").write(ui.fastq_bytes(seqs, quals=ui.random_quals(rs, seqs)))
     assert os.path.getsize(fq) > 2 << 20  # several 1 MiB chunks
     outs = []
-    for devs in (None, "0,0", "0,0,0"):
-        out = str(tmp_path / ("out_" + (devs or "single").replace(",", "_")))
+    for devs, merge in ((None, None), ("0,0", None), ("0,0,0", None), ("0,0", "slices"), ("0,0,0", "slices"), ("0,0,0,0,0", None), ("0,0,0,0", "gather")):
+        out = str(tmp_path / ("out_" + (devs or "single").replace(",", "_") + (merge or "")))
         cmd = [PRODUCT_CLI, "dist", "-L", shuf_files(shuf)] + flags + ["-p", "4", "--chunk-mib", "1", "--timing", "-o", out]
         if devs:
             cmd += ["--devices", devs]
-        r = subprocess.run(cmd + [fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        env = dict(os.environ)
+        env.pop("MK_MULTI_MERGE", None)
+        if merge:
+            env["MK_MULTI_MERGE"] = merge
+        r = subprocess.run(cmd + [fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert r.returncode == 0, r.stderr.decode()
         if devs:
             tm = [json.loads(ln)["timing"] for ln in r.stdout.decode().splitlines() if ln.startswith('{"timing"')][0]
             assert tm["gpus"] == len(devs.split(",")) and tm["transport"] == "device copies"
+            want_merge = merge or ("slices" if len(devs.split(",")) >= 4 else "gather")
+            assert ("key slices" in r.stderr.decode()) == (want_merge == "slices"), r.stderr.decode()
         outs.append(out)
     names = sorted(f for f in os.listdir(outs[0]) if f.startswith("combco"))
     assert names and os.path.getsize(os.path.join(outs[0], "combco.0")) > 4000

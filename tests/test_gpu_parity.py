@@ -735,6 +735,140 @@ def test_shard_merge_equals_single_engine(capi, shufs, oracle_for):
     assert n == 5000
 
 
+@pytest.mark.parametrize("name,flavour", [("L0K6", "koc"), ("L1K7", "koc"), ("L3K9", "occ2"), ("L2K11", "koc")])
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_slice_merge_equals_oracle(capi, shufs, oracle_for, name, flavour, G):
+    """SURVEY 8e's alternative exchange through the engine's C ABI: G engines sketch contiguous read ranges with global ordinals; every
+    engine cuts its list into G parts by key % G (mk_partial_export_split), starts over with empty tables (mk_partial_restart) and
+    folds part g of every list (mk_partial_import); the reduced slices -- disjoint key sets -- are laid behind one another in the
+    first engine's own key list (mk_partial_list_reserve / _adopt / _commit) and finished from there WITHOUT touching its table.
+    The result is the oracle's sequential sketch, ids and counts in the same order."""
+    import ctypes as C
+    if name == "L2K11" and G != 3:
+        pytest.skip("21 GB engines: one value of G is enough for the 16-component dump")
+    hip = C.CDLL("libamdhip64.so")
+    shuf = shufs(name)
+    rs = np.random.RandomState(77 + G)
+    seqs = ui.pool_reads(rs, 30000, 9000) + ui.ragged_reads(rs, 200)
+    stride = 304
+    if flavour == "occ2":  # fastq2co's rows: the reader's record rule and quality masking applied (mk_fastq_frame_q)
+        data = ui.fastq_bytes(seqs)
+        rows, n, nrec, used, rc = capi.fastq_frame_q(data, stride, 2 * shuf.c.k, qmin=0)
+        assert rc == 0 and used == len(data) and n > 8000
+    else:
+        rows = ui.rows_from_seqs(seqs, stride)
+        n = len(seqs)
+    cuts = [n * g // G for g in range(G + 1)]
+    engines = [capi.Engine(shuf, 0) for _ in range(1 if name == "L2K11" else G)]
+    allocs = []
+
+    def dmalloc(nbytes):
+        q = C.c_void_p()
+        assert hip.hipMalloc(C.byref(q), C.c_size_t(max(16, nbytes))) == 0
+        allocs.append(q)
+        return q.value
+
+    def begin(e):
+        e.begin_occ(2) if flavour == "occ2" else e.begin(capi.MK_MODE_KOC)
+    try:
+        # 1. every shard's list, cut by key % G  (with one engine for all shards -- the 21 GB geometry -- shard after shard)
+        exported = []  # per shard: (keys, counts, ords pointers, part sizes)
+        for g in range(G):
+            e = engines[g % len(engines)]
+            begin(e)
+            e.push_reads(rows[cuts[g] * stride:cuts[g + 1] * stride], stride, cuts[g])
+            d = e.partial_count()
+            bk, bc, bo = dmalloc(8 * d), dmalloc(4 * d), dmalloc(8 * d)
+            got, parts = e.partial_export_split(G, bk, bc, bo, d)
+            assert got == d and sum(parts) == d and len(parts) == G
+            k = np.zeros(d, np.uint64)
+            assert hip.hipMemcpy(C.c_void_p(k.ctypes.data), C.c_void_p(bk), C.c_size_t(8 * d), 2) == 0
+            at = 0
+            for gg in range(G):  # part gg holds exactly the keys with key % G == gg
+                assert np.all(k[at:at + parts[gg]] % np.uint64(G) == gg), (g, gg)
+                at += parts[gg]
+            assert len(np.unique(k)) == d
+            exported.append((bk, bc, bo, parts))
+        # 2. slice g: part g of every shard folded into empty tables; the slice's reduced list
+        e0 = engines[0]
+        slices = []
+        for g in range(G):
+            e = engines[g % len(engines)]
+            if len(engines) == 1:
+                begin(e)
+            else:
+                e.partial_restart()
+            for (bk, bc, bo, parts) in exported:
+                off = sum(parts[:g])
+                if parts[g]:
+                    e.partial_import(bk + 8 * off, bc + 4 * off, bo + 8 * off, parts[g])
+            r = e.partial_count()
+            lk, lc, lo = e.partial_list_reserve(r)
+            ck, cc, co = dmalloc(8 * r), dmalloc(4 * r), dmalloc(8 * r)
+            e.sync()
+            for dst, src, w in ((ck, lk, 8), (cc, lc, 4), (co, lo, 8)):
+                assert hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(w * r), 3) == 0
+            slices.append((ck, cc, co, r))
+        # 3. the first engine: all slices behind one another in its key list, finished from the list
+        if len(engines) == 1:
+            begin(e0)
+        else:  # its own slice is in front already: the others go behind it
+            assert slices[0][3] == e0.partial_count()
+        total = sum(s_[3] for s_ in slices)
+        at = 0
+        for g, (ck, cc, co, r) in enumerate(slices):
+            if not (g == 0 and len(engines) > 1):
+                e0.partial_list_adopt(ck, cc, co, r, at)
+            at += r
+        e0.partial_list_commit(total)
+        merged = e0.finish()
+    finally:
+        for q in allocs:
+            hip.hipFree(q)
+        for e in engines:
+            e.close()
+    ora = oracle_for(shuf)
+    if flavour == "occ2":
+        rc, want = ora.co_from_fastq(data, Q=0, M=2)
+    else:
+        rc, want = ora.koc_from_rows(rows, stride)
+    assert rc == 0
+    assert_same(merged, want, "%s G=%d" % (name, G))
+
+
+@pytest.mark.parametrize("merge", ["gather", "slices"])
+@pytest.mark.parametrize("ndev", [2, 5])
+def test_multi_library_both_merges_equal_oracle(capi, shufs, oracle_for, ndev, merge):
+    """libmetakssd_multi.so in this process (capi.Multi; several engines on GPU 0, device copies instead of RCCL): rows dealt
+    round-robin in pieces with global ordinals, mk_multi_finish with the gather and with the key slices -- the oracle's sketch;
+    twice in a row on the same object (buffers reused), the phases' times reported"""
+    shuf = shufs("L1K7")
+    rs = np.random.RandomState(99)
+    seqs = ui.pool_reads(rs, 40000, 12000) + ui.ragged_reads(rs, 100)
+    stride = 304
+    rows = ui.rows_from_seqs(seqs, stride)
+    n = len(seqs)
+    rc, want = oracle_for(shuf).koc_from_rows(rows, stride)
+    assert rc == 0
+    m = capi.Multi(shuf, [0] * ndev)
+    try:
+        assert m.transport() == "device copies"
+        m.set_merge(capi.MK_MULTI_MERGE_GATHER if merge == "gather" else capi.MK_MULTI_MERGE_SLICES)
+        for rep in range(2):
+            m.begin(capi.MK_MODE_KOC)
+            piece = 777
+            for i, a in enumerate(range(0, n, piece)):
+                b = min(n, a + piece)
+                m.push_reads(i % ndev, rows[a * stride:b * stride], stride, a)
+            got = m.finish()
+            assert_same(got, want, "multi %s x%d rep %d" % (merge, ndev, rep))
+            assert m.last_merge() == merge
+            t = m.last_times()
+            assert t["total_ms"] > 0 and (merge == "gather") == (t["gather_ms"] == 0.0)
+    finally:
+        m.close()
+
+
 def test_device_resident_push_and_device_synth(capi, engine_for, shufs, oracle_for):
     """bench path: reads generated on the device, pushed from HBM; bytes identical to the host generator"""
     import ctypes as C
@@ -804,6 +938,54 @@ def test_bench_two_rank_flow_merged_equals_single(capi):
     assert d["n_gpus"] == 2 and d["merged_equals_single_engine"] is True
     assert d["config"]["distinct_keys"] > 50000
     assert d["t_stream"]["reads_per_rank"] == 1000000 and d["t_stream"]["gbases_s"] > 0 and "rank0_tail_ms" in d
+
+
+@pytest.mark.parametrize("world,merge", [(2, "gather"), (3, "gather"), (3, "slices"), (4, "slices")])
+def test_engine_export_import_across_processes(capi, world, merge, tmp_path):
+    """the engine's export / import (and the key-slice variant's split, restart, adopt, commit) with every rank a PROCESS of its own
+    holding its own engine on GPU 0, lists produced by the real scan, moved by shard.py over gloo, merged on rank 0 and checked there
+    against the oracle's sequential sketch (tests/dist_gpu_worker.py)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    result = str(tmp_path / "result.txt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MK_DIST_RESULT=result, MK_DIST_MERGE=merge)
+    port = 35500 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker.py")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    assert open(result).read().startswith("OK")
+
+
+@pytest.mark.parametrize("ranks,merge", [(2, "auto"), (4, "auto"), (3, "slices")])
+def test_bench_launches_its_own_ranks(capi, ranks, merge):
+    """`python3 bench.py --gpus N` exactly as a driver without a launcher would start it: no torch.distributed.run around it, no
+    WORLD_SIZE.  bench.py starts its N ranks itself as a child process; on this one-GPU box they share GPU 0 and exchange through
+    gloo, which the line must SAY (debug transport).  Both merges (gather below four ranks, key slices from four on), the merged
+    sketch equal to one engine's, and the C product's own multi-GPU path (libmetakssd_multi.so, --inproc-multi) on the same workload
+    with the same sketch"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--reads-per-gpu", "600000", "--steps", "2", "--warmup", "1",
+           "--no-host-legs", "--verify", "--inproc-multi", "--merge", merge]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    want_merge = merge if merge != "auto" else ("slices" if ranks >= 4 else "gather")
+    assert d["n_gpus"] == ranks and d["merged_equals_single_engine"] is True and d["merge"] == want_merge
+    assert "debug transport: gloo, same device" in d["config"]["parallelism"] and d["distributed"]["distinct_devices"] == 1
+    assert d["distributed"]["ranks_seen"] == list(range(ranks))
+    assert set(d["rank0_tail_phases_ms"]) >= ({"gather", "import", "finish"} if want_merge == "gather" else {"export_split", "all_to_all", "fold_slice", "gather_slices", "adopt", "finish"})
+    im = d["inproc_multi"]
+    assert im["engines"] == ranks and im["transport"] == "device copies" and im["merge"] == want_merge
+    assert im["equals_process_per_gpu_sketch"] is True and im["distinct_keys"] == d["config"]["distinct_keys"] and im["gbases_s"] > 0
 
 
 # ---- FASTQ without -A (SURVEY 8f N1): fastq2co + write_fqco2file through MK_MODE_OCC_SET -----------------------

@@ -38,9 +38,10 @@ def main():
         ref_hash = None
         combos = [(chunk, T, v) for v in a.variants.split(";") for chunk in [int(x) for x in a.chunks.split(",")]
                   for T in [int(x) for x in a.threads.split(",")]]
-        for chunk, T, variant in combos:
-            if True:
-                for rep in range(a.reps):
+        for rep in range(a.reps):  # repetitions outermost: the configurations take turns, so that a drifting box touches all alike
+            for chunk, T, variant in combos:
+                if True:
+                    time.sleep(1.5)  # (the driver is still taking the previous process's device memory back)
                     out = os.path.join(tmp, "out")
                     shutil.rmtree(out, ignore_errors=True)
                     m0 = time.monotonic()
