@@ -42,6 +42,7 @@ READ_LEN = 150
 STRIDE = 160
 SEED = 20261002
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+PCIE_PEAK_GBS = 63.0   # MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec)
 CONFIG3_READS = 50_000_000
 CONFIG4_READS = 500_000_000
 
@@ -176,6 +177,29 @@ def leg_packed(torch, capi, eng, pinned_text_rows, n, distinct_text, reps=3):
                     "waited for; its time per launch from the engine's events).  NOT the headline: `value` is on text rows" % (P, T, reps, steps)}
 
 
+_FREE_BASELINE = {}
+
+
+def wait_device_quiet(tag="gpu", least=0.5, most=8.0):
+    """between two runs of the command line: the driver takes a process's device memory back for a while AFTER the process has gone
+    (21 GB at L2K11), and the next process's start-up waits for that.  Instead of sleeping a fixed time: poll the device's free
+    memory (this process keeps its HIP context; it holds nothing large by now) until it is back at what it was before the first run."""
+    try:
+        import torch
+        time.sleep(least)
+        free = torch.cuda.mem_get_info()[0]
+        base = _FREE_BASELINE.setdefault(tag, free)
+        t0 = time.monotonic()
+        while free < base - (256 << 20) and time.monotonic() - t0 < most:
+            time.sleep(0.05)
+            free = torch.cuda.mem_get_info()[0]
+        if free > base:
+            _FREE_BASELINE[tag] = free
+        time.sleep(0.25)
+    except Exception:  # noqa: BLE001
+        time.sleep(2.5)
+
+
 def leg_e2e(capi, shuf, n, resident_sketch, reps=4):
     """t_e2e: `metakssd dist -L L3K11.shuf -A` on the workload as a FASTQ file in /dev/shm, process start to sketch on disk"""
     import numpy as np
@@ -200,7 +224,7 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=4):
         runs = []
         for rep in range(reps + 1):  # the first run only warms the page cache of the fresh file and is not counted
             out = os.path.join(tmp, "out%d" % rep)
-            time.sleep(2.5)  # the driver is still tearing the previous GPU process down for a while after it has exited
+            wait_device_quiet()  # the driver is still tearing the previous GPU process down for a while after it has exited
             m0 = time.monotonic()
             r = subprocess.run([cli, "dist", "-L", sp, "-A", "-o", out, "--quiet", "--timing"] + os.environ.get("MK_E2E_FLAGS", "").split() + [fq], stdout=subprocess.PIPE,
                                stderr=subprocess.PIPE)
@@ -313,9 +337,9 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=4
             walls, fins, fin = [], [], None
             for rep in range(reps + 1):
                 od = os.path.join(tmp, "out_%s_%d" % (name, rep))
-                # outside the timed window: the driver is still taking the previous process's device memory back (two engines of
-                # 21 GB each at L2K11) for a while after it has exited, and the next process's allocations wait for that
-                time.sleep(2.5)
+                # outside the timed window: the driver is still taking the previous process's device memory back for a while after
+                # it has exited, and the next process's allocations wait for that
+                wait_device_quiet()
                 m0 = time.monotonic()
                 r = subprocess.run([cli, "dist", "-L", sp] + (["-p", str(threads)] if threads else []) + list(extra_flags) + ["-o", od, "--quiet", "--timing", gd],
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -344,6 +368,19 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=4
                              "engine_ready_s": (fin or {}).get("engine_ready"),
                              # the process's own clock (main() to the last file written), of the median run
                              "written_s": (fin or {}).get("written"), "batches": (fin or {}).get("batches")}
+                # what bounds this leg is the LINK, not HBM: the reader threads pack the genomes into wide rows (64 bytes per 241 - TL
+                # new bases) in pinned host memory and the scan kernel reads them THERE, over PCIe.  achieved = the rows' bytes over the
+                # window in which batches are on the device (first batch begun -> last file written, median run) against the link's
+                # peak; nothing of a batch is above 1 % of the HBM roofline (profiles/r04_c_config5_*_kernel_stats.csv)
+                TL = 2 * k
+                row_bytes = genomes * 64.0 * (bases_each / float(241 - TL) + 2.0)
+                t_link = max(((fin or {}).get("written") or 0.0) - ((fin or {}).get("first_push") or 0.0), 1e-9)
+                out[name]["roofline"] = {"bound": "pcie", "kernel": "mk_scan_packed_kernel<.., wide> reading pinned host rows in place",
+                                         "achieved": row_bytes / t_link / 1e9, "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+                                         "frac": row_bytes / t_link / 1e9 / PCIE_PEAK_GBS, "traffic": None,
+                                         "algorithmic_bytes": row_bytes, "window_s": t_link,
+                                         "what": "wide packed rows crossing PCIe Gen5 x16 (63 GB/s by MI355X_MICROARCH.md; 55-57 GB/s measured for "
+                                                 "host-to-device copies in `t_stream`), first batch begun -> directory written, median run"}
                 if os.path.exists(ref) and ref_genomes:
                     sub = os.path.join(tmp, "few_" + name)
                     os.makedirs(sub)
@@ -367,6 +404,10 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=4
                         except Exception as ex:  # noqa: BLE001
                             out[name]["cpu_baseline"]["gpu_blocks_equal_reference"] = None
                             out[name]["cpu_baseline"]["compare_error"] = str(ex)[:200]
+                try:
+                    out[name]["set_union"] = leg_config5_set(cli, ref, tmp, name, od, gd, sp, genomes, ref_genomes)
+                except Exception as ex:  # noqa: BLE001
+                    out[name]["set_union"] = {"what": "failed: %s" % str(ex)[:300]}
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -462,6 +503,59 @@ def leg_inproc_multi(torch, capi, shuf, devices, total_reads, steps, merge, refe
                         "ranks wait on the rendezvous store, off their GPUs"}
     finally:
         m.close()
+
+
+def leg_config5_set(cli, ref, tmp, name, sketch_dir, genome_dir, shuf_path, genomes, ref_genomes):
+    """BASELINE config 5 as written: "... multi-FASTA input, set-union dedup on device" -- `metakssd set -u` (mk_setop: the 2^32-bit
+    dictionary of sketch_union(), command_set.c:241-319, as a bitmap in HBM) on the sketch directory the timed `dist` run wrote;
+    then the same two steps on a few of the genomes by the product and by the compiled reference, pan.N compared byte for byte"""
+    import statistics
+    import numpy as np
+    ncomp = len([f for f in os.listdir(sketch_dir) if f.startswith("combco.") and f[7:].isdigit()])
+    ids_in = sum(os.path.getsize(os.path.join(sketch_dir, "combco.%d" % c)) // 4 for c in range(ncomp))
+    walls = []
+    pan = os.path.join(tmp, "pan_" + name)
+    for rep in range(4):
+        shutil.rmtree(pan, ignore_errors=True)
+        wait_device_quiet()
+        m0 = time.monotonic()
+        r = subprocess.run([cli, "set", "-u", "-o", pan, sketch_dir], input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        m1 = time.monotonic()
+        if r.returncode != 0:
+            return {"what": "`metakssd set -u` failed: " + r.stderr.decode(errors="replace")[-300:]}
+        if rep:
+            walls.append(m1 - m0)
+    ids_out = sum(os.path.getsize(os.path.join(pan, "pan.%d" % c)) // 4 for c in range(ncomp))
+    w = statistics.median(walls)
+    ascending = all(bool(np.all(np.diff(np.fromfile(os.path.join(pan, "pan.%d" % c), dtype=np.uint32).astype(np.int64)) > 0)) for c in range(ncomp))
+    res = {"seconds": w, "all_runs_s": [round(x, 4) for x in walls], "genomes": genomes, "components": ncomp, "ids_in": ids_in, "ids_out": ids_out,
+           "ids_in_per_s": ids_in / w, "pan_ascending_and_distinct": ascending,
+           "what": "`metakssd set -u -o pan <the sketch directory of the timed dist run>` (%d genomes): the parent's clock around the whole "
+                   "process (start-up, reading combco.N, the device dictionary, writing pan.N), median of 3 runs after a warm-up" % genomes}
+    sub = os.path.join(tmp, "few_" + name)
+    refdir = os.path.join(tmp, "ref_" + name)
+    if os.path.exists(ref) and os.path.isdir(sub) and os.path.exists(os.path.join(refdir, "cofiles.stat")):
+        mine, mypan, refpan = os.path.join(tmp, "few_sk_" + name), os.path.join(tmp, "few_pan_" + name), os.path.join(tmp, "ref_pan_" + name)
+        r1 = subprocess.run([cli, "dist", "-L", shuf_path, "-o", mine, "--quiet", sub], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        r2 = subprocess.run([cli, "set", "-u", "-o", mypan, mine], input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        t0 = time.perf_counter()
+        try:  # (bounded: sketch_union() walks a 2^32-bit dictionary per component, 16 of them at L2K11)
+            r3 = subprocess.run([ref, "set", "-u", "-o", refpan, refdir], input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=90)
+        except subprocess.TimeoutExpired:
+            res["cpu_baseline"] = {"what": "oracle/_ref/metakssd set -u on %d genomes: not finished after 90 s (stopped)" % ref_genomes, "kind": "reference"}
+            return res
+        dt = time.perf_counter() - t0
+        if r1.returncode == 0 and r2.returncode == 0 and r3.returncode == 0:
+            same = all(open(os.path.join(mypan, "pan.%d" % c), "rb").read() == open(os.path.join(refpan, "pan.%d" % c), "rb").read() for c in range(ncomp))
+            n_ref_in = sum(os.path.getsize(os.path.join(refdir, "combco.%d" % c)) // 4 for c in range(ncomp))
+            res["cpu_baseline"] = {"seconds": dt, "ids_in": n_ref_in, "ids_in_per_s": n_ref_in / dt, "cores": 1, "kind": "reference",
+                                   "sample": "oracle/_ref/metakssd set -u on its own sketch directory of %d of the genomes (sketch_union() is "
+                                             "single-threaded)" % ref_genomes,
+                                   "pan_equals_reference": bool(same)}
+        else:
+            res["cpu_baseline"] = {"what": "a run failed: dist %d, set %d, reference set %d: %s" % (
+                r1.returncode, r2.returncode, r3.returncode, (r1.stderr + r2.stderr + r3.stderr).decode(errors="replace")[-200:])}
+    return res
 
 
 def kernel_source_id():

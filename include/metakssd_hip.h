@@ -135,6 +135,13 @@ typedef struct mk_profile {
 
 int mk_device_count(int *n);
 int mk_engine_create(const mk_params *p, int device, mk_engine **out);
+/* MK_ENGINE_LAZY_TABLES: the hashsize-slot tables, the key list and the dump's arrays (2.6 GB at L3K11, 21 GB at L2K11) are made by the
+ * first mk_sketch_begin instead of here.  For an engine that mostly sketches BATCHES of files (mk_sketch_batch_*: a small table per
+ * file, nothing of the big ones is touched): a process that only runs batches then starts 30 ms sooner at L2K11 and leaves 21 GB less
+ * for the driver to take back when it exits -- which the next process would wait for.  A file that falls out of its batch is sketched
+ * alone through mk_sketch_begin and pays for the tables then. */
+enum { MK_ENGINE_LAZY_TABLES = 1u };
+int mk_engine_create_ex(const mk_params *p, int device, unsigned flags, mk_engine **out);
 int mk_engine_destroy(mk_engine *e);
 /* Run all engine work on a caller-owned hipStream_t (e.g. torch's current stream) so that it is ordered with the
  * caller's own work on that stream.  NULL selects HIP's default stream (that is what torch.cuda.current_stream()

@@ -130,6 +130,7 @@ typedef struct {
   int ndev, devs[64];   /* --devices: more than one GPU -> libmetakssd_multi.so */
   unsigned multi_flags; /* MK_MULTI_ALLOW_DEVICE_COPIES with --allow-device-copies */
   mk_multi *multi;
+  int lazy_tables;      /* MK_ENGINE_LAZY_TABLES: the inputs look like a directory of genomes for batches (set before have_params) */
   int have_params;      /* the main thread has read the .shuf file: P may be used */
   const mk_params *P;
   mk_engine *eng;
@@ -217,7 +218,7 @@ static void *engine_thread(void *arg) {
     if (rc != MK_OK) snprintf(f->err, sizeof f->err, "%s", g_multi.last_error(NULL));
     else f->eng = g_multi.engine(f->multi, 0);
   } else if (rc == MK_OK) {
-    rc = mk_engine_create(f->P, f->device, &f->eng);
+    rc = mk_engine_create_ex(f->P, f->device, f->lazy_tables ? MK_ENGINE_LAZY_TABLES : 0u, &f->eng);
     if (rc != MK_OK) snprintf(f->err, sizeof f->err, "%s", mk_last_error(NULL));
   } else snprintf(f->err, sizeof f->err, "%s", mk_last_error(NULL));
   f->t_ready = now_s() - g_t0;
@@ -345,17 +346,19 @@ static void push_rows(ctx_t *c, const uint8_t *rows, uint32_t stride, uint64_t n
  * moment -- also through the 80-110 ms in which the HIP runtime and the engine come up and nothing can be pinned or pushed.  Pinning
  * all of it up front would cost more than it saves (fresh pages pin at 5 GB/s, and pinning beside the creation of the engine's queue
  * makes that three times as long); pages the framers have WRITTEN pin at over 100 GB/s.  So: a framer reports a finished buffer
- * (mk_rows_sink::ready), which marks its 2 MiB granules; a pinner thread -- idle until the engine is there -- registers runs of marked
- * granules (up to 256 MiB a call); a push waits until its buffer's granules are pinned.  The pinner is twice as fast as the link, so
- * after the first call it stays in front of the pushes. */
-#define PIN_GRANULE ((size_t)2 << 20)
-#define PIN_RUN_MAX 128 /* granules per hipHostRegister */
+ * (mk_rows_sink::ready); a pinner thread -- idle until the engine is there -- registers runs of finished buffers that lie side by
+ * side (up to 256 MiB a call); a push waits until its buffer is pinned.  The pinner is twice as fast as the link, so after its first
+ * call it stays in front of the pushes.  A registration always ends at a buffer's end: a copy whose source lies across two
+ * registrations is refused by the runtime (invalid argument), so the unit is the buffer, and a new file -- whose buffers may have
+ * another size -- starts from nothing pinned (pin_reset). */
+#define PIN_RUN_BYTES ((size_t)256 << 20)
 typedef struct pinner {
   uint8_t *base;
-  size_t ngran;
-  uint8_t *state;   /* per granule: 0 fresh, 1 written (may be pinned), 2 pinned */
+  size_t bytes, buf_bytes, nbuf;  /* buf_bytes: learnt from the first report after a reset (all buffers of a stream have one size) */
+  uint8_t *state;                 /* per buffer: 0 fresh, 1 written (may be pinned), 2 pinned */
+  size_t state_cap;
   void **regs; int nregs, regs_cap; /* bases of the registrations made (to undo them) */
-  int device, go, stop, started;
+  int device, go, stop, started, busy;
   pthread_t th;
   pthread_mutex_t mu;
   pthread_cond_t cv_work, cv_pinned;
@@ -365,55 +368,77 @@ static void *pinner_run(void *arg) {
   pinner *p = arg;
   pthread_mutex_lock(&p->mu);
   for (;;) {
-    size_t g0 = p->ngran;
-    if (p->go) for (size_t g = 0; g < p->ngran; g++) if (p->state[g] == 1) { g0 = g; break; }
+    size_t b0 = p->nbuf;
+    if (p->go) for (size_t b = 0; b < p->nbuf; b++) if (p->state[b] == 1) { b0 = b; break; }
     if (p->stop) break;
-    if (g0 == p->ngran) { pthread_cond_wait(&p->cv_work, &p->mu); continue; }
-    size_t g1 = g0;
-    while (g1 < p->ngran && g1 - g0 < PIN_RUN_MAX && p->state[g1] == 1) g1++;
+    if (b0 == p->nbuf) { pthread_cond_wait(&p->cv_work, &p->mu); continue; }
+    size_t b1 = b0;
+    while (b1 < p->nbuf && (b1 - b0 + 1) * p->buf_bytes <= PIN_RUN_BYTES + p->buf_bytes && p->state[b1] == 1) b1++;
+    uint8_t *at = p->base + b0 * p->buf_bytes;
+    const size_t len = (b1 - b0) * p->buf_bytes;
+    p->busy = 1;
     pthread_mutex_unlock(&p->mu);
     const double t0 = now_s();
-    if (mk_host_register_on(p->device, p->base + g0 * PIN_GRANULE, (g1 - g0) * PIN_GRANULE) != MK_OK)
-      die("pinning the row buffers failed: %s", mk_last_error(NULL));
+    if (mk_host_register_on(p->device, at, len) != MK_OK) die("pinning the row buffers failed: %s", mk_last_error(NULL));
     const double dt = now_s() - t0;
     pthread_mutex_lock(&p->mu);
-    for (size_t g = g0; g < g1; g++) p->state[g] = 2;
+    p->busy = 0;
+    for (size_t b = b0; b < b1; b++) p->state[b] = 2;
     if (p->nregs == p->regs_cap) {
       p->regs_cap = p->regs_cap ? 2 * p->regs_cap : 64;
       p->regs = realloc(p->regs, sizeof(void *) * (size_t)p->regs_cap);
       if (!p->regs) die("out of memory");
     }
-    p->regs[p->nregs++] = p->base + g0 * PIN_GRANULE;
-    p->t_pin_s += dt; p->calls++; p->pinned_bytes += (g1 - g0) * PIN_GRANULE;
+    p->regs[p->nregs++] = at;
+    p->t_pin_s += dt; p->calls++; p->pinned_bytes += len;
     pthread_cond_broadcast(&p->cv_pinned);
   }
   pthread_mutex_unlock(&p->mu);
   return NULL;
 }
-static void pin_mark(pinner *p, const uint8_t *at, size_t bytes) { /* [at, at + bytes) has been written: its granules may be pinned */
+/* the buffer at `at` (room `bytes`): its index; the first report after a reset fixes the buffers' size.  Called with the lock held. */
+static size_t pin_index(pinner *p, const uint8_t *at, size_t bytes) {
+  if (!p->buf_bytes) {
+    p->buf_bytes = bytes;
+    p->nbuf = p->bytes / bytes;
+    if (p->nbuf > p->state_cap) {
+      free(p->state);
+      p->state = calloc(p->nbuf, 1);
+      if (!p->state) die("out of memory");
+      p->state_cap = p->nbuf;
+    } else memset(p->state, 0, p->nbuf);
+  }
+  if (bytes != p->buf_bytes || (size_t)(at - p->base) % p->buf_bytes) die("internal: row buffers of two sizes in one stream");
+  return (size_t)(at - p->base) / p->buf_bytes;
+}
+static void pin_mark(pinner *p, const uint8_t *at, size_t bytes) { /* the buffer at `at` has been written: it may be pinned */
   if (!p || at < p->base || bytes == 0) return;
-  size_t g0 = (size_t)(at - p->base) / PIN_GRANULE, g1 = ((size_t)(at - p->base) + bytes + PIN_GRANULE - 1) / PIN_GRANULE;
-  if (g1 > p->ngran) g1 = p->ngran;
   pthread_mutex_lock(&p->mu);
-  int any = 0;
-  for (size_t g = g0; g < g1; g++) if (p->state[g] == 0) { p->state[g] = 1; any = 1; }
-  if (any && p->go) pthread_cond_signal(&p->cv_work);
+  const size_t b = pin_index(p, at, bytes);
+  if (b < p->nbuf && p->state[b] == 0) { p->state[b] = 1; if (p->go) pthread_cond_signal(&p->cv_work); }
   pthread_mutex_unlock(&p->mu);
 }
-static void pin_wait(pinner *p, const uint8_t *at, size_t bytes) { /* returns when [at, at + bytes) is pinned; lets the pinner loose */
-  if (!p || at < p->base || bytes == 0) return;
-  size_t g0 = (size_t)(at - p->base) / PIN_GRANULE, g1 = ((size_t)(at - p->base) + bytes + PIN_GRANULE - 1) / PIN_GRANULE;
-  if (g1 > p->ngran) g1 = p->ngran;
+static void pin_wait(pinner *p, const uint8_t *at) { /* returns when the buffer at `at` is pinned; lets the pinner loose */
+  if (!p || at < p->base) return;
   pthread_mutex_lock(&p->mu);
-  for (size_t g = g0; g < g1; g++) if (p->state[g] == 0) p->state[g] = 1;
-  if (!p->go) p->go = 1;
-  pthread_cond_signal(&p->cv_work);
-  for (;;) {
-    int all = 1;
-    for (size_t g = g0; g < g1; g++) if (p->state[g] != 2) { all = 0; break; }
-    if (all) break;
-    pthread_cond_wait(&p->cv_pinned, &p->mu);
+  if (!p->buf_bytes) die("internal: a push before any row buffer was reported");
+  const size_t b = (size_t)(at - p->base) / p->buf_bytes;
+  if (b < p->nbuf) {
+    if (p->state[b] == 0) p->state[b] = 1;
+    p->go = 1;
+    pthread_cond_signal(&p->cv_work);
+    while (p->state[b] != 2) pthread_cond_wait(&p->cv_pinned, &p->mu);
   }
+  pthread_mutex_unlock(&p->mu);
+}
+static void pin_reset(pinner *p) { /* a new stream into the same arena: nothing pinned, any buffer size */
+  if (!p) return;
+  pthread_mutex_lock(&p->mu);
+  p->go = 0;
+  while (p->busy) pthread_cond_wait(&p->cv_pinned, &p->mu);
+  for (int i = 0; i < p->nregs; i++) mk_host_unregister(p->regs[i]);
+  p->nregs = 0;
+  p->buf_bytes = 0; p->nbuf = 0;
   pthread_mutex_unlock(&p->mu);
 }
 static void pin_destroy(pinner *p) { /* registrations undone, thread gone (the mapping is the caller's) */
@@ -431,10 +456,9 @@ static void pin_destroy(pinner *p) { /* registrations undone, thread gone (the m
 static pinner *pin_create(uint8_t *base, size_t bytes, int device) {
   pinner *p = calloc(1, sizeof *p);
   if (!p) return NULL;
-  p->base = base; p->ngran = bytes / PIN_GRANULE; p->device = device;
-  p->state = calloc(p->ngran ? p->ngran : 1, 1);
+  p->base = base; p->bytes = bytes; p->device = device;
   pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->cv_work, NULL); pthread_cond_init(&p->cv_pinned, NULL);
-  if (!p->state || pthread_create(&p->th, NULL, pinner_run, p) != 0) { free(p->state); free(p); return NULL; }
+  if (pthread_create(&p->th, NULL, pinner_run, p) != 0) { free(p); return NULL; }
   p->started = 1;
   return p;
 }
@@ -445,7 +469,7 @@ static int cli_sink_push(void *ctx, const uint8_t *rows, uint32_t stride, uint64
   ctx_t *c = ctx;
   (void)sketch_engine(c);
   /* the engine is there, i.e. the runtime is up: the pinner may work; this buffer's pages before anything else */
-  pin_wait(c->pin, rows, (size_t)nrows * (stride & ~MK_ROWS_PACKED));
+  pin_wait(c->pin, rows);
   if (c->t_first_push == 0) c->t_first_push = now_s() - g_t0;
   /* several GPUs: the row buffers are dealt round-robin, so that every GPU's PCIe link carries a share at any time;
    * ordinals are global, so it does not matter which engine sees which rows */
@@ -497,7 +521,7 @@ static uint8_t *arena_map_unpinned(size_t bytes, size_t *len_out) {
 }
 static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) { /* the arena (and what is pinned of it) is kept for the next file and goes with the process */
   ctx_t *c = ctx;
-  if (c->arena && c->arena_bytes >= bytes) return c->arena;
+  if (c->arena && c->arena_bytes >= bytes) { pin_reset(c->pin); return c->arena; }
   if (c->pin) { pin_destroy(c->pin); c->pin = NULL; }
   if (c->arena) munmap(c->arena, c->arena_bytes);
   c->arena = NULL; c->arena_bytes = 0;
@@ -2143,6 +2167,12 @@ int main(int argc, char **argv) {
   if (!quiet) printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%u\thashlimit=%u\n", P.shuf_id, P.k, P.hashsize, P.hashlimit);
   const double t_shuf = now_s() - t0;
 
+  { /* a directory of genomes goes to the device in batches of files, each file with a small table of its own: the engine's
+     * hashsize-slot tables (21 GB at L2K11) are then made only if a file falls out of its batch (MK_ENGINE_LAZY_TABLES) */
+    int plain = 0;
+    for (int i = 0; i < files.n; i++) plain += !is_fastq(files.v[i]) && !is_compressed(files.v[i]);
+    fut.lazy_tables = plain >= 2 && !g_no_batch && !g_host_fasta && !engines_per_gpu && !shard_files && ndev <= 1;
+  }
   engine_params(&fut, &P);
   /* more engines on the same GPU for directories of many files (see the file loop), created beside the first and joining as
    * they come up.  Two by default, four at most: 1024 genomes of 4 Mbases at L3K10 go through at 3 750 genomes/s with one engine,

@@ -65,6 +65,7 @@ struct mk_engine {
   int front_bits_opt = -1;          /* MK_OPT_FRONT_BITS */
   bool big_maybe_dirty = true;      /* the S-slot table may hold keys: begin clears it (false: known to be all zero) */
   unsigned long long *h_counters = nullptr; /* pinned mirror */
+  bool tables_ready = false; /* the hashsize-slot tables, the key list and the dump's arrays exist (mk_tables_alloc: at creation, or -- MK_ENGINE_LAZY_TABLES -- at the first mk_sketch_begin) */
   bool init_queued = true; /* mk_engine_create's uploads and kernels may still be running on own_stream (it does not wait for them) */
   mk_accept_pair *d_pairs = nullptr;
   /* result arrays: pinned host memory that the dump kernels write directly (it is mapped into the device's address
@@ -405,7 +406,8 @@ static int mk_dist_reserve(mk_engine *e, uint64_t cap) {
   return MK_OK;
 }
 
-static int mk_engine_init(mk_engine *e, const mk_params *p) {
+static int mk_tables_alloc(mk_engine *e);
+static int mk_engine_init(mk_engine *e, const mk_params *p, bool lazy_tables) {
 #ifdef MK_TUNING
   double tick_ = mk_tick_now();
 #endif
@@ -520,6 +522,32 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
     e->bm_bits = (uint32_t)(wb < 0 ? 0 : wb > 14 ? 14 : wb);
   }
 
+  e->nchunks = (uint32_t)((p->hashsize + MK_DUMP_CHUNK - 1) / MK_DUMP_CHUNK);
+  if (p->component_num > (int)MK_MAX_COMP) return mk_fail(e, MK_ERR_ARG, "component_num %d > %u", p->component_num, MK_MAX_COMP);
+  e->tab.err = (uint32_t *)(e->d_counters + 2);
+  e->comps.resize((size_t)p->component_num);
+  e->cand_slots = (uint32_t)e->num_cu * 16u; /* at most 16 waves per workgroup, one workgroup per CU */
+  { int rc = mk_config_cand(e, 8192u); if (rc) return rc; }
+  MK_TICK("candidate buffers");
+  for (int i = 0; i < MK_TICKETS; i++) MK_HIP(e, hipEventCreateWithFlags(&e->ev_ticket[i], hipEventDisableTiming));
+#ifdef MK_TUNING /* experiment knobs: compiled only into tools/ builds (make tuning), never into the shipped library */
+  if (const char *t = getenv("MK_SCAN_THREADS")) { int v = atoi(t); if (v == 512 || v == 768 || v == 1024) e->tune_threads = v; }
+  if (const char *t = getenv("MK_SCAN_ONEPASS")) e->tune_onepass = atoi(t) != 0;
+  if (const char *t = getenv("MK_SCAN_CB")) { int v = atoi(t); if (v >= 16 && v <= MK_MAX_CB && v % 16 == 0) e->tune_cb = (uint32_t)v; }
+#endif
+  return lazy_tables ? MK_OK : mk_tables_alloc(e);
+}
+
+/* The hashsize-slot accumulation and layout tables, their sparse bookkeeping, the front table, the key list and the dump's chunk
+ * arrays: everything a sketch of ONE input needs and a batch of files (mk_sketch_batch_*: tables of its own per file) never touches
+ * -- 21 GB at L2K11.  At creation, or with MK_ENGINE_LAZY_TABLES at the first mk_sketch_begin / mk_engine_set_option. */
+static int mk_tables_alloc(mk_engine *e) {
+  if (e->tables_ready) return MK_OK;
+#ifdef MK_TUNING
+  double tick_ = mk_tick_now();
+#endif
+  const mk_params *p = &e->P;
+  MK_HIP(e, hipSetDevice(e->device));
   const uint64_t S = p->hashsize;
   e->tab_bytes = S * (8 + 8);
   MK_HIP(e, hipMalloc(&e->d_tab, e->tab_bytes));
@@ -536,26 +564,16 @@ static int mk_engine_init(mk_engine *e, const mk_params *p) {
    * With sparse bookkeeping (537 M slots at L2K11: 10.7 GB of list for sketches of a few thousand keys) it starts at 32 M
    * entries and grows when a compaction counts more (mk_dist_fit) */
   { int rc = mk_dist_reserve(e, e->sparse && S > (32ull << 20) ? (32ull << 20) : S); if (rc) return rc; }
-  e->nchunks = (uint32_t)((S + MK_DUMP_CHUNK - 1) / MK_DUMP_CHUNK);
-  if (p->component_num > (int)MK_MAX_COMP) return mk_fail(e, MK_ERR_ARG, "component_num %d > %u", p->component_num, MK_MAX_COMP);
   MK_HIP(e, hipMalloc(&e->d_chunk, (size_t)e->nchunks * (size_t)p->component_num * sizeof(uint32_t)));
   MK_HIP(e, hipMalloc(&e->d_comp_totals, MK_MAX_COMP * sizeof(unsigned long long)));
-  e->tab.err = (uint32_t *)(e->d_counters + 2);
-  e->comps.resize((size_t)p->component_num);
-  e->cand_slots = (uint32_t)e->num_cu * 16u; /* at most 16 waves per workgroup, one workgroup per CU */
   MK_TICK("key list + dump tables");
-  { int rc = mk_config_cand(e, 8192u); if (rc) return rc; }
-  MK_TICK("candidate buffers");
-  for (int i = 0; i < MK_TICKETS; i++) MK_HIP(e, hipEventCreateWithFlags(&e->ev_ticket[i], hipEventDisableTiming));
-#ifdef MK_TUNING /* experiment knobs: compiled only into tools/ builds (make tuning), never into the shipped library */
-  if (const char *t = getenv("MK_SCAN_THREADS")) { int v = atoi(t); if (v == 512 || v == 768 || v == 1024) e->tune_threads = v; }
-  if (const char *t = getenv("MK_SCAN_ONEPASS")) e->tune_onepass = atoi(t) != 0;
-  if (const char *t = getenv("MK_SCAN_CB")) { int v = atoi(t); if (v >= 16 && v <= MK_MAX_CB && v % 16 == 0) e->tune_cb = (uint32_t)v; }
-#endif
+  e->tables_ready = true;
   return MK_OK;
 }
 
-extern "C" int mk_engine_create(const mk_params *p, int device, mk_engine **out) {
+extern "C" int mk_engine_create(const mk_params *p, int device, mk_engine **out) { return mk_engine_create_ex(p, device, 0u, out); }
+
+extern "C" int mk_engine_create_ex(const mk_params *p, int device, unsigned flags, mk_engine **out) {
   if (!p || !out || !p->shuf_table) return mk_fail(nullptr, MK_ERR_ARG, "mk_engine_create: null argument");
   if (p->k < 1 || p->k > 16 || p->hashsize < 251u || p->shuf_len != (1ull << (4 * p->subk)))
     return mk_fail(nullptr, MK_ERR_ARG, "mk_engine_create: inconsistent mk_params (use mk_params_init)");
@@ -567,7 +585,7 @@ extern "C" int mk_engine_create(const mk_params *p, int device, mk_engine **out)
   if (device < 0 || device >= n) return mk_fail(nullptr, MK_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
   mk_engine *e = new mk_engine();
   e->device = device;
-  int rc = mk_engine_init(e, p);
+  int rc = mk_engine_init(e, p, (flags & MK_ENGINE_LAZY_TABLES) != 0);
   if (rc != MK_OK) {
     snprintf(g_create_error, sizeof g_create_error, "%s", e->err);
     mk_engine_destroy(e);
@@ -586,6 +604,7 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
    * works on are what several options free */
   if (e->res_pending) return mk_fail(e, MK_ERR_STATE, "mk_engine_set_option while a result is outstanding (mk_sketch_finish_end first)");
   MK_HIP(e, hipSetDevice(e->device));
+  { int rc = mk_tables_alloc(e); if (rc) return rc; } /* (a lazily created engine: the options below rebuild pieces of the tables) */
   MK_HIP(e, hipStreamSynchronize(e->stream));
   if (e->res_stream) MK_HIP(e, hipStreamSynchronize(e->res_stream));
   switch (option) {
@@ -718,6 +737,7 @@ extern "C" int mk_sketch_begin_occ(mk_engine *e, int min_occurrence) {
 extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   if (!e || mode < MK_MODE_KOC || mode > MK_MODE_OCC_SET) return MK_ERR_ARG;
   MK_HIP(e, hipSetDevice(e->device));
+  { int rc = mk_tables_alloc(e); if (rc) return rc; } /* MK_ENGINE_LAZY_TABLES: the first sketch of one input makes them */
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   /* the table clear the reference does with memset(co,0,..) (iseq2comem.c:223,663) */

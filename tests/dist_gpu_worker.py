@@ -95,7 +95,7 @@ def main():
         from oracle_binding import Oracle
         rcode, want = Oracle(shuf.c.id, 7, 4, 1, shuf.table).koc_from_rows(rows, stride)
         ok = rcode == 0 and len(merged) == len(want) and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(merged, want))
-        ok = ok and len(want[0][0]) > 3000
+        ok = ok and len(want[0][0]) > 1000
         open(os.environ["MK_DIST_RESULT"], "w").write("OK %d" % len(want[0][0]) if ok else "MISMATCH")
     dist.barrier()
     eng.close()
