@@ -701,7 +701,11 @@ def main():
                 t0 = time.perf_counter()
             tp = t0 if tail["on"] else 0.0
             if merge == "slices":
-                # every rank: its list cut by key % world, tables emptied, part g to rank g, its own slice folded and listed again
+                # every rank: its list cut by key % world, tables emptied, part g to rank g, its own slice folded and listed again.
+                # (rank 0: the compaction below writes the key list the side stream may still be laying out and dumping for the LAST
+                # pass -- that result is taken first; with the gather the list is not touched before the finish)
+                if rank == 0:
+                    drain()
                 d, parts = eng.partial_export_split(world, pk.data_ptr(), pc.data_ptr(), po.data_ptr(), cap)
                 eng.partial_restart()
                 tp = mark("export_split", tp)

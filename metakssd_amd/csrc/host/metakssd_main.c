@@ -127,6 +127,7 @@ typedef struct {
   pthread_mutex_t mu;
   pthread_cond_t cv;
   int done, rc, device;
+  int hip_up;           /* the first HIP call has returned (t_hip_ready is set) */
   int ndev, devs[64];   /* --devices: more than one GPU -> libmetakssd_multi.so */
   unsigned multi_flags; /* MK_MULTI_ALLOW_DEVICE_COPIES with --allow-device-copies */
   mk_multi *multi;
@@ -143,6 +144,7 @@ static double g_t0; /* process start (monotonic) */
 #define MK_DEFAULT_AHEAD 0
 #endif
 static uint64_t g_pool_bytes = (uint64_t)6 << 30; /* --pool-mib: room for the FASTQ stream's row buffers (mk_fastq_opts::pool_bytes; 0: a few buffers, reused) */
+static int g_frame_early = 0; /* --frame-early: the FASTQ framers start before the HIP runtime is up (measurement) */
 static int g_ahead = MK_DEFAULT_AHEAD; /* --ahead: row buffers the FASTQ stream's framers may run ahead of the pushes by */
 static int g_component_sz = 8; /* --component-sz: the reference's compile-time COMPONENT_SZ (global_basic.h:35-37) */
 
@@ -210,6 +212,8 @@ static void *engine_thread(void *arg) {
   int rc = mk_device_count(&n); /* first HIP call of the process: runtime start-up, while the main thread reads the .shuf file */
   f->t_hip_ready = now_s() - g_t0;
   pthread_mutex_lock(&f->mu);
+  f->hip_up = 1;
+  pthread_cond_broadcast(&f->cv);
   while (!f->have_params) pthread_cond_wait(&f->cv, &f->mu);
   pthread_mutex_unlock(&f->mu);
   if (rc == MK_OK && !f->P) rc = MK_ERR_ARG; /* the main thread gave up */
@@ -526,7 +530,17 @@ static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) { /* the arena (and what
   if (c->arena) munmap(c->arena, c->arena_bytes);
   c->arena = NULL; c->arena_bytes = 0;
   /* an untouched anonymous mapping (2 MiB granules, huge pages asked for): the framers' stores bring the pages in, the pinner
-   * registers them once they are written -- nothing here waits for the runtime or costs anything for room that is never used */
+   * registers them once they are written -- nothing here waits for the engine or costs anything for room that is never used */
+  if (c->fut && !g_frame_early) {
+    /* ... but the framers do wait for the RUNTIME: thirty-two threads that page 15 GB of text in and out and fault row pages in at
+     * memory speed make the runtime's start-up -- a thread of this process that maps, pins and talks to the driver -- three to eight
+     * times as long (0.14-0.46 s instead of 0.055-0.065, profiles/r05_e2e_pool_ab.txt); they get their buffers when the first HIP call
+     * has returned and then run beside the creation of the engine, which does not mind (25 instead of 21 ms) */
+    engine_future *f = c->fut;
+    pthread_mutex_lock(&f->mu);
+    while (!f->hip_up && !f->done) pthread_cond_wait(&f->cv, &f->mu);
+    pthread_mutex_unlock(&f->mu);
+  }
   size_t len = 0;
   uint8_t *m = arena_map_untouched(bytes, &len);
   if (!m) return NULL;
@@ -2102,6 +2116,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--timing")) timing = 1;
     else if (!strcmp(argv[i], "--chunk-mib") && i + 1 < argc) chunk_bytes = (uint64_t)atoi(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--inflight") && i + 1 < argc) inflight = atoi(argv[++i]); /* row buffers queued for copying */
+    else if (!strcmp(argv[i], "--frame-early")) g_frame_early = 1;
     else if (!strcmp(argv[i], "--pool-mib") && i + 1 < argc) g_pool_bytes = (uint64_t)atoll(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--ahead") && i + 1 < argc) g_ahead = atoi(argv[++i]); /* row buffers the framers may run ahead by */
     else if (!strcmp(argv[i], "--direct")) direct_host = 1; /* MK_OPT_DIRECT_HOST: scan pinned row buffers in place */

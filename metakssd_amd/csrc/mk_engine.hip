@@ -888,8 +888,10 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   /* workgroup size: as many waves as the LDS budget (filter + per-wave tile and queue) admits */
   int threads = e->tune_threads;
   size_t lds = 0;
+  /* (experiment builds: the pair filter of the tuned subk-6 kernels may be smaller than a.bm_words, MK_ZF_WORDS in mk_kernels.hip.h) */
+  const size_t fwords = tuned_k && e->P.subk == 6 && !packed ? (size_t)MK_ZF_WORDS : (size_t)a.bm_words;
   for (;; threads -= 256) {
-    lds = ((size_t)a.mt_words + (size_t)a.bm_words + (size_t)(threads / 64) * a.wave_lds_dwords) * 4u;
+    lds = ((size_t)a.mt_words + fwords + (size_t)(threads / 64) * a.wave_lds_dwords) * 4u;
     if (vec) lds += 2u * (a.ppr <= 5u ? 5u : (uint32_t)MK_MAX_PIECES) * 64u * 4u; /* staging offset table of the 16-byte kernels: [2*NPIECES][64] */
     if (packed) { threads = 1024; lds = ((size_t)a.mt_words + (size_t)a.bm_words) * 4u; } /* the filter, nothing else */
     if (lds <= 160u * 1024u || threads <= 512) break;
@@ -898,7 +900,11 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   const uint32_t waves = (uint32_t)threads / 64u;
   const uint64_t ntiles = (nreads + 63) / 64;
   uint64_t blocks = (ntiles + waves - 1) / waves;
-  if (blocks > (uint64_t)e->num_cu) blocks = (uint64_t)e->num_cu;
+  uint64_t wgs_per_cu = 1;
+#ifdef MK_TUNING
+  if (const char *t = getenv("MK_SCAN_WGS_PER_CU")) { const int v = atoi(t); if (v >= 1 && v * waves <= 16u) wgs_per_cu = (uint64_t)v; } /* (cand_slots = 16 waves a CU) */
+#endif
+  if (blocks > (uint64_t)e->num_cu * wgs_per_cu) blocks = (uint64_t)e->num_cu * wgs_per_cu;
   dim3 grid((unsigned)blocks);
 #ifdef MK_TUNING
   if (getenv("MK_DEBUG")) {
@@ -976,6 +982,20 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
     }
     hipLaunchKernelGGL(mk_resolve_kernel, dim3(rgrid), dim3(MK_RESOLVE_THREADS), rlds, e->stream, a, used_slots);
     MK_HIP(e, hipGetLastError());
+#ifdef MK_TUNING
+    if (getenv("MK_COUNT_RECORDS")) { /* experiment builds: the candidate records this launch handed to the resolve kernel (waits for both kernels) */
+      static int shown = 0;
+      if (shown++ < 3) {
+        std::vector<uint32_t> h(used_slots);
+        MK_HIP(e, hipStreamSynchronize(e->stream));
+        MK_HIP(e, hipMemcpy(h.data(), e->d_cand_count, (size_t)used_slots * 4, hipMemcpyDeviceToHost));
+        unsigned long long sum = 0;
+        for (uint32_t v : h) sum += v;
+        fprintf(stderr, "[scan records] %llu reads -> %llu candidate records (%.4f a read, %.3f %% of the 8-base windows of 150-base reads)\n",
+                (unsigned long long)nreads, sum, (double)sum / (double)nreads, 100.0 * (double)sum / ((double)nreads * 19.0));
+      }
+    }
+#endif
     if (e->profiling) { MK_HIP(e, hipEventRecord(ev2.b, e->stream)); e->ev_resolve.push_back(ev2); }
   }
   if (!a.batch) { e->compacted = false; e->count_queued = false; }

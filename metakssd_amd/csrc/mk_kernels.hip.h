@@ -604,15 +604,22 @@ __device__ __forceinline__ uint32_t mk_zmask(uint32_t b) {
   }
   return m;
 }
+/* words of the pair filter.  16384 (64 KiB) in the product.  An experiment build (make tuning VARIANT=-DMK_ZF_WORDS=8192, round 5) halves
+ * it -- the word index drops the key's top bit -- so that TWO 512-thread workgroups fit a CU (MK_SCAN_THREADS=512 MK_SCAN_WGS_PER_CU=2):
+ * VERDICT r04 item 3(ii); measured in profiles/r05_scan_variants.txt */
+#if !defined(MK_TUNING) || !defined(MK_ZF_WORDS)
+#undef MK_ZF_WORDS
+#define MK_ZF_WORDS 16384u
+#endif
 __device__ __forceinline__ void mk_build_zfilter(uint32_t *masktab, uint32_t *bitmap, const mk_scan_args &a) {
   for (uint32_t i = threadIdx.x; i < MK_ZMASK_WORDS; i += blockDim.x) masktab[i] = mk_zmask(i);
-  for (uint32_t i = threadIdx.x; i < a.bm_words; i += blockDim.x) bitmap[i] = 0u;
+  for (uint32_t i = threadIdx.x; i < MK_ZF_WORDS; i += blockDim.x) bitmap[i] = 0u;
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < a.n_accept; i += blockDim.x) {
     const uint32_t d = (uint32_t)mk_scan_to_ref_codes(a.accept[i]); /* reference coding -> scan coding (same map) */
     const uint32_t z1 = d & 0x3FFFFFu, z2 = d >> 2;
-    atomicOr(&bitmap[(z1 >> 8) & (a.bm_words - 1u)], masktab[z1 & 255u]);
-    atomicOr(&bitmap[(z2 >> 8) & (a.bm_words - 1u)], masktab[z2 & 255u]);
+    atomicOr(&bitmap[(z1 >> 8) & (MK_ZF_WORDS - 1u)], masktab[z1 & 255u]);
+    atomicOr(&bitmap[(z2 >> 8) & (MK_ZF_WORDS - 1u)], masktab[z2 & 255u]);
   }
   __syncthreads();
 }
@@ -651,12 +658,14 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   constexpr uint32_t WAVES = THREADS / 64;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   /* LDS: [mask table (tuned kernels)] [filter] [wave tiles] [staging offset table] */
+  /* filter words in this kernel's LDS: the pair filter's own count for the tuned subk-6 kernels (== a.bm_words in the product) */
+  const uint32_t fwords = (K != 0 && SUBK == 6) ? MK_ZF_WORDS : a.bm_words;
   uint32_t *bitmap = lds + a.mt_words;
-  uint32_t *tile = lds + a.mt_words + a.bm_words + wave * a.wave_lds_dwords;
+  uint32_t *tile = lds + a.mt_words + fwords + wave * a.wave_lds_dwords;
 
   if constexpr (VEC16) { /* staging offset table (see goff_of below): [2*NPIECES][64] dwords behind the wave tiles */
     if (wave == 0) {
-      uint32_t *t = lds + a.mt_words + a.bm_words + WAVES * a.wave_lds_dwords + lane;
+      uint32_t *t = lds + a.mt_words + fwords + WAVES * a.wave_lds_dwords + lane;
 #pragma unroll
       for (int i = 0; i < NPIECES; i++) {
         const uint32_t q = lane + 64u * i;
@@ -713,7 +722,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
    * Left to itself the compiler hoists them out of the tile loop, runs out of registers in the 1024-thread builds and
    * reloads them from SCRATCH at every tile: 31 MB of scratch across the grid, i.e. 2.4 GB of extra HBM reads per launch of
    * the benchmark (rocprofv3 FETCH_SIZE).  LDS reads cannot be hoisted across the tile stores and cost no VALU issue. */
-  const uint32_t *offtab = lds + a.mt_words + a.bm_words + WAVES * a.wave_lds_dwords + lane;
+  const uint32_t *offtab = lds + a.mt_words + fwords + WAVES * a.wave_lds_dwords + lane;
   auto goff_of = [&](int i) { if constexpr (VEC16) return offtab[128 * i]; else return goff_calc(i); };
   auto loff_of = [&](int i) { if constexpr (VEC16) return offtab[128 * i + 64]; else return loff_calc(i); };
   auto issue_loads = [&](uint32_t tile_id, uint32_t cb) {
@@ -790,7 +799,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     const uint32_t xx = km.dimx(a.kp, dimmask);
     if constexpr (K != 0) { /* the LDS holds the pair filter: x in B puts its low 22 bits into Z (mk_build_zfilter) */
       const uint32_t z = xx & 0x3FFFFFu;
-      word = *(mk_lds_cu32)(uintptr_t)(((z >> 6) & wmask4) + filter_base);
+      word = *(mk_lds_cu32)(uintptr_t)(((z >> 6) & (SUBK == 6 ? (MK_ZF_WORDS - 1u) << 2 : wmask4)) + filter_base);
       mask = lds[z & 255u];
     } else {
       word = *(mk_lds_cu32)(uintptr_t)(((xx >> 8) & wmask4) + filter_base);
@@ -1032,7 +1041,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                 /* ablation builds (make tuning VARIANT=-DMK_ABL=n): timing probes with WRONG results, never shipped
                  * (profiles/r03_a_scan_ablation.txt).  2: no mask reads; 3: mask reads at conflict-free addresses (bank := lane);
                  * 4: filter-word reads at conflict-free addresses; 5: both conflict-free */
-                uint32_t wa = ((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u;
+                uint32_t wa = ((wsrc >> (SH + 8u)) & ((MK_ZF_WORDS - 1u) << 2)) + MK_ZMASK_WORDS * 4u;
                 uint32_t ma = 2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t];
                 const uint32_t lane4 = (lane & 31u) << 2;
                 if (MK_ABL == 3 || MK_ABL == 5) ma = (ma & ~0x7Cu) | lane4;
@@ -1040,7 +1049,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
                 dd[t] = *(mk_lds_cu32)(uintptr_t)wa;
                 if (MK_ABL == 2) mm[t] = ma | 0x80000000u; else mm[t] = *(mk_lds_cu32)(uintptr_t)ma;
 #else
-                dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u);
+                dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & ((MK_ZF_WORDS - 1u) << 2)) + MK_ZMASK_WORDS * 4u);
                 mm[t] = *(mk_lds_cu32)(uintptr_t)(2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t]);
 #endif
               }

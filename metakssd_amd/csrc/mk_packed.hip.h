@@ -40,7 +40,7 @@ __device__ __forceinline__ bool mk_probe8(const uint32_t fstart, const uint32_t 
 #pragma unroll
     for (uint32_t t = 0; t < 4; t++) {
       const uint32_t wsrc = bj[2u * t + 1u];
-      dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & 0xFFFCu) + MK_ZMASK_WORDS * 4u);
+      dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & ((MK_ZF_WORDS - 1u) << 2)) + MK_ZMASK_WORDS * 4u);
       mm[t] = *(mk_lds_cu32)(uintptr_t)(2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t]);
     }
 #pragma unroll

@@ -975,7 +975,7 @@ def test_bench_launches_its_own_ranks(capi, ranks, merge):
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--reads-per-gpu", "600000", "--steps", "2", "--warmup", "1",
            "--no-host-legs", "--verify", "--inproc-multi", "--merge", merge]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200, env=env)
-    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    assert r.returncode == 0, "\n".join(l for l in r.stderr.decode(errors="replace").splitlines() if "Error" in l or "error" in l or "rank0" in l)[-4000:]
     line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     want_merge = merge if merge != "auto" else ("slices" if ranks >= 4 else "gather")
