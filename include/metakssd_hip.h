@@ -414,7 +414,11 @@ typedef struct mk_fastq_opts {
                            the engine is still being created */
   int32_t packed;       /* != 0: buffers whose reads all have at most MK_PACKED_MAX_BASES bases are framed as PACKED rows (the sink
                            gets stride = MK_PACKED_PITCH | MK_ROWS_PACKED for those), the others as ASCII rows */
-  int32_t reserved;
+  int32_t fd;           /* > 0 and text == NULL: the text is the first `n` bytes of this file descriptor, read with pread() -- every framer
+                           thread preads pieces of 1 MiB into a buffer of its own and frames them there.  Nothing of the file is mapped
+                           into the process: no page-table work for 15 GB of text, no madvise(), no TLB shoot-downs beside the rest of
+                           the process (the HIP runtime's start-up takes 3-8 times as long beside framers that populate and drop the
+                           pages of a mapping, profiles/r05_e2e_*).  drop_pages is ignored.  Rows, order, errors: as from a mapping */
   uint64_t pool_bytes;  /* 0: threads + inflight + 1 + ahead buffers, each with room for a chunk's text rows.  Otherwise a budget for all
                            row buffers together: with `packed` and a file whose first records are short enough for packed rows the
                            buffers are sized for PACKED rows (a fifth of the text), and there are as many as the budget holds, at most

@@ -66,7 +66,7 @@ class FastaStateC(C.Structure):
 
 class FastqOptsC(C.Structure):
     _fields_ = [("occ", C.c_int32), ("qmin", C.c_int32), ("TL", C.c_int32), ("nthreads", C.c_int32), ("inflight", C.c_int32),
-                ("chunk_bytes", C.c_uint64), ("drop_pages", C.c_int32), ("ahead", C.c_int32), ("packed", C.c_int32), ("reserved", C.c_int32),
+                ("chunk_bytes", C.c_uint64), ("drop_pages", C.c_int32), ("ahead", C.c_int32), ("packed", C.c_int32), ("fd", C.c_int32),
                 ("pool_bytes", C.c_uint64)]
 
 
@@ -325,7 +325,7 @@ def fastq_frame_mt(buf, stride, nthreads, occ=False, TL=22, qmin=0, final=True, 
 
 
 def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2, drop_pages=False, packed=False, pool_bytes=0,
-                 ready_log=None):
+                 ready_log=None, via_fd=False):
     """the whole-file FASTQ stream (mk_fastq_stream) into host memory: returns (list of (rows u8 array, stride, nrows,
     first ordinal) in push order, stats, rc).  Buffers come from malloc here; the engine-bound form is Engine.push_fastq."""
     b = np.frombuffer(buf, dtype=np.uint8)
@@ -358,11 +358,19 @@ def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first
     sink = RowsSinkC(None, _PUSH_FN(push), _WAIT_FN(wait), _ALLOC_FN(alloc), _RELEASE_FN(lambda ctx, p, n: libc.free(p)),
                      C.cast(ready_fn, C.c_void_p) if ready_log is not None else None)
     keep["sink"] = (sink, ready_fn)
-    o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 1 if drop_pages else 0, 0, 1 if packed else 0, 0, pool_bytes)
+    fd = -1
+    if via_fd:  # the same bytes through a file descriptor: the framers pread pieces instead of reading a mapping (mk_fastq_opts.fd)
+        import tempfile
+        tf = tempfile.TemporaryFile()
+        tf.write(bytes(buf))
+        tf.flush()
+        fd = tf.fileno()
+        keep["file"] = tf
+    o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 1 if drop_pages else 0, 0, 1 if packed else 0, fd if via_fd else 0, pool_bytes)
     if ready_log is not None:
         ready_log.append(blocks)
     st = FastqStatsC()
-    rc = lib.mk_fastq_stream(b.ctypes.data if len(b) else None, len(b), C.byref(o), C.byref(sink), first_ordinal, C.byref(st))
+    rc = lib.mk_fastq_stream(None if via_fd or not len(b) else b.ctypes.data, len(b), C.byref(o), C.byref(sink), first_ordinal, C.byref(st))
     return pushes, st, rc
 
 

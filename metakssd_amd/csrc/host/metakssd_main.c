@@ -144,6 +144,7 @@ static double g_t0; /* process start (monotonic) */
 #define MK_DEFAULT_AHEAD 0
 #endif
 static uint64_t g_pool_bytes = (uint64_t)6 << 30; /* --pool-mib: room for the FASTQ stream's row buffers (mk_fastq_opts::pool_bytes; 0: a few buffers, reused) */
+static int g_mmap_input = 0;  /* --mmap-input: the FASTQ file is mapped and the framers read the mapping (rounds 2-4) instead of pread()ing pieces */
 static int g_frame_early = 0; /* --frame-early: the FASTQ framers start before the HIP runtime is up (measurement) */
 static int g_ahead = MK_DEFAULT_AHEAD; /* --ahead: row buffers the FASTQ stream's framers may run ahead of the pushes by */
 static int g_component_sz = 8; /* --component-sz: the reference's compile-time COMPONENT_SZ (global_basic.h:35-37) */
@@ -531,8 +532,8 @@ static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) { /* the arena (and what
   c->arena = NULL; c->arena_bytes = 0;
   /* an untouched anonymous mapping (2 MiB granules, huge pages asked for): the framers' stores bring the pages in, the pinner
    * registers them once they are written -- nothing here waits for the engine or costs anything for room that is never used */
-  if (c->fut && !g_frame_early) {
-    /* ... but the framers do wait for the RUNTIME: thirty-two threads that page 15 GB of text in and out and fault row pages in at
+  if (c->fut && g_mmap_input && !g_frame_early) {
+    /* ... but framers that read a MAPPING do wait for the RUNTIME: thirty-two threads that page 15 GB of text in and out and fault row pages in at
      * memory speed make the runtime's start-up -- a thread of this process that maps, pins and talks to the driver -- three to eight
      * times as long (0.14-0.46 s instead of 0.055-0.065, profiles/r05_e2e_pool_ab.txt); they get their buffers when the first HIP call
      * has returned and then run beside the creation of the engine, which does not mind (25 instead of 21 ms) */
@@ -561,9 +562,16 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   struct stat st;
   if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) { close(fd); return 0; }
   const size_t size = (size_t)st.st_size;
-  const uint8_t *map = mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
-  close(fd);
-  if (map == MAP_FAILED) return 0;
+  /* the framers pread the file piece by piece (mk_fastq_opts::fd): nothing of it is mapped into this process, so thirty-two threads
+   * at memory speed cause no page-table work and no TLB shoot-downs beside the HIP runtime's start-up.  --mmap-input: the mapping of
+   * rounds 2-4 (populated and dropped chunk by chunk by the framers), for comparison */
+  const uint8_t *map = NULL;
+  if (g_mmap_input) {
+    map = mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    fd = -1;
+    if (map == MAP_FAILED) return 0;
+  }
   mk_fastq_opts o;
   memset(&o, 0, sizeof o);
   o.occ = c->occ; o.qmin = c->qmin; o.TL = c->TL;
@@ -571,6 +579,7 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   o.packed = c->packed; /* reads of up to 152 bases cross PCIe as 64-byte packed rows (geometries with a tuned scan kernel) */
   o.drop_pages = c->drop_pages; /* a private read-only file mapping that is unmapped below */
   o.pool_bytes = g_pool_bytes;
+  o.fd = map ? 0 : fd;
   mk_rows_sink sink = {c, cli_sink_push, cli_sink_wait, cli_sink_alloc, cli_sink_release, cli_sink_ready};
   mk_fastq_stats fs;
   /* the framers start at once, into a pool that is pinned when the engine is there (cli_sink_alloc / cli_sink_push): the
@@ -588,7 +597,8 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   c->nrows_total += fs.rows;
   c->fq_stats = fs;
   c->t_last_push = now_s() - g_t0;
-  munmap((void *)map, size);
+  if (map) munmap((void *)map, size);
+  else close(fd);
   c->t_unmapped = now_s() - g_t0;
   return 1;
 }
@@ -2117,6 +2127,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--chunk-mib") && i + 1 < argc) chunk_bytes = (uint64_t)atoi(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--inflight") && i + 1 < argc) inflight = atoi(argv[++i]); /* row buffers queued for copying */
     else if (!strcmp(argv[i], "--frame-early")) g_frame_early = 1;
+    else if (!strcmp(argv[i], "--mmap-input")) g_mmap_input = 1;
     else if (!strcmp(argv[i], "--pool-mib") && i + 1 < argc) g_pool_bytes = (uint64_t)atoll(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--ahead") && i + 1 < argc) g_ahead = atoi(argv[++i]); /* row buffers the framers may run ahead by */
     else if (!strcmp(argv[i], "--direct")) direct_host = 1; /* MK_OPT_DIRECT_HOST: scan pinned row buffers in place */

@@ -21,12 +21,14 @@
 #include "metakssd_hip.h"
 #include "mk_host_internal.h"
 
+#include <errno.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <time.h>
+#include <unistd.h>
 
 #define FS_NONE ((size_t)-1)
 
@@ -39,8 +41,17 @@ typedef struct {
   int rc;
 } fs_slot;
 
+/* Where the text comes from.  A mapping (text != NULL): the framers read it in place.  A file descriptor (text == NULL,
+ * mk_fastq_opts::fd): every thread preads PIECES of FS_PIECE bytes into a buffer of its own that stays in its core's cache and frames
+ * the complete records of each piece -- no page of the file is ever mapped into the process, so there is no page-table work, no
+ * madvise() and no TLB shoot-down beside whatever else the process is doing (the HIP runtime coming up: profiles/r05_e2e_*). */
+#define FS_PIECE ((size_t)1 << 20)
+typedef struct { const uint8_t *p; size_t avail; int eof; } fs_view;
+
 typedef struct {
   const uint8_t *text;
+  int fd;
+  size_t piece; /* bytes per pread (FS_PIECE; MK_FS_PIECE in the environment for tests: never below a maximal record) */
   size_t n, chunk;
   uint64_t nchunks;
   int occ, qmin, TL, drop_pages, packed;
@@ -55,6 +66,23 @@ typedef struct {
   pthread_mutex_t mu;
   pthread_cond_t cv_buf, cv_ready;
 } fs_t;
+
+/* the text from offset `off` on: all of it (mapping), or the next piece (descriptor; `scratch` holds FS_PIECE bytes) */
+static fs_view fs_fetch(const fs_t *f, size_t off, uint8_t *scratch) {
+  fs_view v = {NULL, 0, 1};
+  if (off >= f->n) return v;
+  if (f->text) { v.p = f->text + off; v.avail = f->n - off; return v; }
+  const size_t want = f->n - off < f->piece ? f->n - off : f->piece;
+  size_t got = 0;
+  while (got < want) {
+    const ssize_t r = pread(f->fd, scratch + got, want - got, (off_t)(off + got));
+    if (r < 0) { if (errno == EINTR) continue; break; }
+    if (r == 0) break;
+    got += (size_t)r;
+  }
+  v.p = scratch; v.avail = got; v.eof = off + got >= f->n;
+  return v;
+}
 
 static double fs_now(void) {
   struct timespec ts;
@@ -112,47 +140,56 @@ static uint32_t fs_sample_stride(const uint8_t *t, size_t n, size_t start, int o
   return fs_round_stride(longest ? longest : 32);
 }
 
-/* frames the records starting in [start, stop) into `buf`; grows the stride and starts over when a read does not fit */
-static void fs_frame_range(const fs_t *f, size_t start, size_t stop, int first_of_file, uint8_t *buf, fs_slot *s) {
-  uint32_t stride = fs_sample_stride(f->text, f->n, start, f->occ);
+/* frames the records starting in [start, stop) into `buf`; grows the stride and starts over when a read does not fit.  The text
+ * comes in views (fs_fetch): one for a mapping; for a descriptor piece after piece, the complete records of each (a record cut by a
+ * piece's end is framed from the next piece, which starts at it).  `scratch`: the calling thread's piece buffer (descriptor only). */
+static void fs_frame_range(const fs_t *f, size_t start, size_t stop, int first_of_file, uint8_t *buf, fs_slot *s, uint8_t *scratch) {
+  uint32_t stride;
+  {
+    const fs_view v0 = fs_fetch(f, start, scratch);
+    stride = fs_sample_stride(v0.p, v0.avail, 0, f->occ);
+  }
   if (f->occ && stride < 2u * (uint32_t)f->TL + 4u) stride = fs_round_stride(2u * (size_t)f->TL + 4u);
   /* packed rows (64 bytes a read, MK_ROWS_PACKED) when every read of the range has at most 152 bases; a longer one turns up as
    * MK_ERR_ARG and the range is framed again as ASCII rows */
   int packed = f->packed && stride <= MK_PACKED_MAX_BASES + 16u;
   for (;;) {
-    if (packed) {
-      uint64_t nrows = 0, nrec = 0;
+    const uint32_t sarg = packed ? (MK_PACKED_PITCH | MK_ROWS_PACKED) : stride;
+    const uint32_t pitch = packed ? MK_PACKED_PITCH : stride;
+    const uint64_t max_rows = f->buf_bytes / pitch;
+    uint64_t rows = 0, recs = 0;
+    size_t pos = start;
+    int rc = MK_OK, again = 0;
+    while (pos < stop && rows < max_rows) {
+      const fs_view v = fs_fetch(f, pos, scratch);
+      if (!v.avail) break;
+      const size_t st = stop - pos < v.avail ? stop - pos : v.avail;
+      uint64_t nr = 0, nrec = 0;
       size_t used = 0;
       uint32_t need = 0;
-      int rc;
-      const uint32_t ps = MK_PACKED_PITCH | MK_ROWS_PACKED;
       if (f->occ)
-        rc = mk_fastq_frame_q_range(f->text + start, f->n - start, stop - start, 1, f->qmin, f->TL, first_of_file ? 0 : 1, buf, ps,
-                                    f->buf_bytes / MK_PACKED_PITCH, &nrows, &nrec, &used, &need);
+        rc = mk_fastq_frame_q_range(v.p, v.avail, st, v.eof, f->qmin, f->TL, first_of_file && pos == 0 ? 0 : 1, buf + rows * pitch, sarg,
+                                    max_rows - rows, &nr, &nrec, &used, &need);
       else {
-        rc = mk_fastq_frame_range(f->text + start, f->n - start, stop - start, 1, buf, ps, f->buf_bytes / MK_PACKED_PITCH, &nrows, &used, &need);
-        nrec = nrows;
+        rc = mk_fastq_frame_range(v.p, v.avail, st, v.eof, buf + rows * pitch, sarg, max_rows - rows, &nr, &used, &need);
+        nrec = nr;
       }
-      if (rc == MK_ERR_ARG && need) { packed = 0; if (need > stride) stride = fs_round_stride((size_t)need + need / 8u); continue; }
-      s->start = start; s->end = start + used; s->nrows = nrows; s->nrec = nrec; s->stride = ps; s->rc = rc;
-      return;
+      rows += nr; recs += nrec; pos += used;
+      if (rc == MK_ERR_ARG && need && packed) { packed = 0; if (need > stride) stride = fs_round_stride((size_t)need + need / 8u); again = 1; break; }
+      if (rc == MK_ERR_ARG && need > stride && stride < 4096 && !packed) { /* a longer read than sampled: wider rows, frame the range again */
+        stride = fs_round_stride((size_t)need + need / 8u);
+        again = 1;
+        break;
+      }
+      if (rc == MK_ERR_ARG && !need && rows > 0 && nr == 0) { rc = MK_OK; break; } /* the next record's rows do not fit what is left of the buffer: full */
+      if (rc != MK_OK) break;
+      if (used == 0) { /* no complete record in this view */
+        if (!v.eof && rows < max_rows) rc = MK_ERR_FORMAT; /* a record longer than a piece: beyond any line width the reference reads */
+        break;
+      }
     }
-    uint64_t nrows = 0, nrec = 0;
-    size_t used = 0;
-    uint32_t need = 0;
-    int rc;
-    if (f->occ)
-      rc = mk_fastq_frame_q_range(f->text + start, f->n - start, stop - start, 1, f->qmin, f->TL, first_of_file ? 0 : 1, buf, stride,
-                                  f->buf_bytes / stride, &nrows, &nrec, &used, &need);
-    else {
-      rc = mk_fastq_frame_range(f->text + start, f->n - start, stop - start, 1, buf, stride, f->buf_bytes / stride, &nrows, &used, &need);
-      nrec = nrows;
-    }
-    if (rc == MK_ERR_ARG && need > stride && stride < 4096) { /* a longer read than sampled: wider rows, frame the range again */
-      stride = fs_round_stride((size_t)need + need / 8u);
-      continue;
-    }
-    s->start = start; s->end = start + used; s->nrows = nrows; s->nrec = nrec; s->stride = stride; s->rc = rc;
+    if (again) continue;
+    s->start = start; s->end = pos; s->nrows = rows; s->nrec = recs; s->stride = sarg; s->rc = rc;
     return;
   }
 }
@@ -179,12 +216,29 @@ static int fs_sample_records(const uint8_t *t, size_t n, size_t *rec_bytes, size
   return rec;
 }
 
+/* guessed record start in [lo, hi) through a view (descriptor: within the first piece -- a chunk whose first record start lies
+ * further in than that is framed by the calling thread, like every chunk without a usable guess) */
+static size_t fs_guess_start_at(const fs_t *f, size_t lo, size_t hi, uint8_t *scratch) {
+  if (f->text) return fs_guess_start(f->text, f->n, lo, hi);
+  const size_t from = lo ? lo - 1 : 0; /* the byte in front of lo says whether lo is a line start */
+  const fs_view v = fs_fetch(f, from, scratch);
+  if (!v.avail) return FS_NONE;
+  const size_t rel_hi = hi - from < v.avail ? hi - from : v.avail;
+  const size_t g = fs_guess_start(v.p, v.avail, lo - from, rel_hi);
+  return g == FS_NONE ? FS_NONE : from + g;
+}
+
 static void *fs_worker(void *arg) {
   fs_t *f = arg;
+  uint8_t *scratch = NULL;
+  if (!f->text) { /* this thread's piece buffer, touched here: it lives in the core's cache from the first pread on */
+    scratch = malloc(f->piece + 64);
+    if (scratch) memset(scratch, 0, f->piece + 64);
+  }
   for (;;) {
     pthread_mutex_lock(&f->mu);
     while (!f->stop && f->next < f->nchunks && f->nfree == 0) pthread_cond_wait(&f->cv_buf, &f->mu);
-    if (f->stop || f->next >= f->nchunks) { pthread_mutex_unlock(&f->mu); return NULL; }
+    if (f->stop || f->next >= f->nchunks) { pthread_mutex_unlock(&f->mu); free(scratch); return NULL; }
     const uint64_t c = f->next++;
     const int b = f->freelist[--f->nfree]; /* taken together with the chunk number: the lowest open chunk always has a buffer */
     pthread_mutex_unlock(&f->mu);
@@ -194,13 +248,13 @@ static void *fs_worker(void *arg) {
     s.buf = b;
     const size_t lo = (size_t)c * f->chunk, hi = lo + f->chunk < f->n ? lo + f->chunk : f->n;
 #ifdef MADV_POPULATE_READ
-    if (f->drop_pages) /* a file mapping: map the chunk's pages with one call instead of a fault per 64 KiB (Linux 5.14+; ignored elsewhere) */
+    if (f->drop_pages && f->text) /* a file mapping: map the chunk's pages with one call instead of a fault per 64 KiB (Linux 5.14+; ignored elsewhere) */
       (void)madvise((void *)(f->text + (lo & ~(size_t)4095)), hi - (lo & ~(size_t)4095), MADV_POPULATE_READ);
 #endif
-    const size_t start = c == 0 ? 0 : fs_guess_start(f->text, f->n, lo, hi);
+    const size_t start = !f->text && !scratch ? FS_NONE : c == 0 ? 0 : fs_guess_start_at(f, lo, hi, scratch);
     if (start == FS_NONE) { s.start = s.end = FS_NONE; }
-    else fs_frame_range(f, start, hi, c == 0, f->bufs[b], &s);
-    if (f->drop_pages && hi - lo > ((size_t)256 << 10)) {
+    else fs_frame_range(f, start, hi, c == 0, f->bufs[b], &s, scratch);
+    if (f->drop_pages && f->text && hi - lo > ((size_t)256 << 10)) {
       /* this chunk's text is done with, except its first 128 KiB, which the previous chunk's last record may still reach
        * into (a record is at most 4 lines of 20000 characters).  Dropping a page somebody still reads is harmless -- it
        * faults back in from the page cache -- but costs time. */
@@ -230,7 +284,8 @@ typedef struct { uint64_t token; int buf; } fs_inflight;
 
 int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const mk_rows_sink *sink, uint64_t first_ordinal,
                     mk_fastq_stats *st) {
-  if ((!text && n) || !o || !sink || !sink->push || !sink->alloc || !sink->release) return MK_ERR_ARG;
+  if (!o || !sink || !sink->push || !sink->alloc || !sink->release) return MK_ERR_ARG;
+  if (!text && n && o->fd <= 0) return MK_ERR_ARG; /* a mapping, or a descriptor to pread from (mk_fastq_opts::fd) */
   if (o->occ && (o->TL < 2 || o->TL > 32)) return MK_ERR_ARG;
   mk_fastq_stats stats;
   memset(&stats, 0, sizeof stats);
@@ -238,6 +293,9 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
   fs_t f;
   memset(&f, 0, sizeof f);
   f.text = text; f.n = n;
+  f.fd = text ? -1 : o->fd;
+  f.piece = FS_PIECE;
+  if (getenv("MK_FS_PIECE")) { const long v = atol(getenv("MK_FS_PIECE")); if (v >= 4 * 20000 + 4096) f.piece = (size_t)v; } /* (four lines of fastq2co's fgets width) */
   f.sink = sink;
   f.occ = o->occ != 0; f.qmin = o->qmin; f.TL = o->TL;
   f.packed = o->packed != 0;
@@ -260,7 +318,11 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
     /* a budget for all buffers: packed rows where the file's first records allow them (buffers a fifth of the text), and as many
      * buffers as the budget holds -- one per chunk at most, then nobody ever waits for one */
     size_t rec_bytes = 0, seq_max = 0;
-    if (f.packed && fs_sample_records(text, n, &rec_bytes, &seq_max) >= 4 && seq_max && seq_max <= MK_PACKED_MAX_BASES + 1u && rec_bytes >= 8) {
+    uint8_t *first = text ? NULL : malloc(f.piece + 64);
+    const fs_view v0 = text || first ? fs_fetch(&f, 0, first) : (fs_view){NULL, 0, 1};
+    const int sampled = f.packed && v0.avail ? fs_sample_records(v0.p, v0.avail, &rec_bytes, &seq_max) : 0;
+    free(first);
+    if (sampled >= 4 && seq_max && seq_max <= MK_PACKED_MAX_BASES + 1u && rec_bytes >= 8) {
       const size_t rows = f.chunk / rec_bytes + f.chunk / rec_bytes / 8u + 256u; /* (the header lines grow with the read number: a record does not shrink) */
       f.buf_bytes = rows * MK_PACKED_PITCH + 8192;
       if (f.buf_bytes < (size_t)8 * 4096 + 8192) f.buf_bytes = (size_t)8 * 4096 + 8192;
@@ -272,13 +334,14 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
     if (fit > (uint64_t)f.nbufs) f.nbufs = (int)(fit > 65536 ? 65536 : fit);
   }
   int rc = MK_OK;
-  uint8_t *serial_buf = NULL;
+  uint8_t *serial_buf = NULL, *serial_scratch = NULL;
   pthread_t *th = NULL;
   int nth = 0;
   fs_inflight fifo[8];
   int nfifo = 0;
   uint8_t *pool = NULL;
   size_t pool_bytes = 0;
+  if (!text && n) { serial_scratch = malloc(f.piece + 64); if (!serial_scratch) { rc = MK_ERR_NOMEM; goto out_nothreads; } }
   f.bufs = calloc((size_t)f.nbufs, sizeof *f.bufs);
   f.freelist = calloc((size_t)f.nbufs, sizeof *f.freelist);
   f.slots = calloc((size_t)(f.nchunks ? f.nchunks : 1), sizeof *f.slots);
@@ -316,7 +379,7 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
       while (rc == MK_OK && sp_ < sto_) {                                                                          \
         fs_slot ss_;                                                                                               \
         memset(&ss_, 0, sizeof ss_);                                                                               \
-        fs_frame_range(&f, sp_, sto_, sp_ == 0, serial_buf, &ss_);                                                 \
+        fs_frame_range(&f, sp_, sto_, sp_ == 0, serial_buf, &ss_, serial_scratch);                                 \
         if (ss_.nrows) {                                                                                           \
           uint64_t tok_ = 0;                                                                                       \
           if (sink->ready) sink->ready(sink->ctx, serial_buf, f.buf_bytes);                                        \
@@ -396,7 +459,7 @@ out:
   pthread_cond_destroy(&f.cv_buf);
   pthread_cond_destroy(&f.cv_ready);
 out_nothreads:
-  free(f.bufs); free(f.freelist); free(f.slots); free(th);
+  free(f.bufs); free(f.freelist); free(f.slots); free(th); free(serial_scratch);
   stats.threads = (uint32_t)nth;
   stats.t_total_s = fs_now() - t0;
   if (st) *st = stats;
