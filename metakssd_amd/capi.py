@@ -67,7 +67,7 @@ class FastaStateC(C.Structure):
 class FastqOptsC(C.Structure):
     _fields_ = [("occ", C.c_int32), ("qmin", C.c_int32), ("TL", C.c_int32), ("nthreads", C.c_int32), ("inflight", C.c_int32),
                 ("chunk_bytes", C.c_uint64), ("drop_pages", C.c_int32), ("ahead", C.c_int32), ("packed", C.c_int32), ("fd", C.c_int32),
-                ("pool_bytes", C.c_uint64)]
+                ("early_chunks", C.c_int32), ("reserved2", C.c_int32), ("pool_bytes", C.c_uint64)]
 
 
 class FastqStatsC(C.Structure):
@@ -325,7 +325,7 @@ def fastq_frame_mt(buf, stride, nthreads, occ=False, TL=22, qmin=0, final=True, 
 
 
 def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first_ordinal=0, inflight=2, drop_pages=False, packed=False, pool_bytes=0,
-                 ready_log=None, via_fd=False):
+                 ready_log=None, via_fd=False, early_chunks=0):
     """the whole-file FASTQ stream (mk_fastq_stream) into host memory: returns (list of (rows u8 array, stride, nrows,
     first ordinal) in push order, stats, rc).  Buffers come from malloc here; the engine-bound form is Engine.push_fastq."""
     b = np.frombuffer(buf, dtype=np.uint8)
@@ -366,7 +366,7 @@ def fastq_stream(buf, nthreads=4, chunk_bytes=0, occ=False, TL=22, qmin=0, first
         tf.flush()
         fd = tf.fileno()
         keep["file"] = tf
-    o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 1 if drop_pages else 0, 0, 1 if packed else 0, fd if via_fd else 0, pool_bytes)
+    o = FastqOptsC(1 if occ else 0, qmin, TL, nthreads, inflight, chunk_bytes, 1 if drop_pages else 0, 0, 1 if packed else 0, fd if via_fd else 0, early_chunks, 0, pool_bytes)
     if ready_log is not None:
         ready_log.append(blocks)
     st = FastqStatsC()

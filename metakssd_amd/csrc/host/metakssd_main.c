@@ -145,7 +145,8 @@ static double g_t0; /* process start (monotonic) */
 #endif
 static uint64_t g_pool_bytes = (uint64_t)6 << 30; /* --pool-mib: room for the FASTQ stream's row buffers (mk_fastq_opts::pool_bytes; 0: a few buffers, reused) */
 static int g_mmap_input = 0;  /* --mmap-input: the FASTQ file is mapped and the framers read the mapping (rounds 2-4) instead of pread()ing pieces */
-static int g_frame_early = 0; /* --frame-early: the FASTQ framers start before the HIP runtime is up (measurement) */
+static int g_early_chunks = 16; /* --early-chunks: chunks of a FASTQ file framed before the engine is there (mk_fastq_opts::early_chunks) */
+static int g_frame_early = 0; /* --frame-early: every chunk of a FASTQ file may be framed at once, also while the runtime and the engine come up (measurement) */
 static int g_ahead = MK_DEFAULT_AHEAD; /* --ahead: row buffers the FASTQ stream's framers may run ahead of the pushes by */
 static int g_component_sz = 8; /* --component-sz: the reference's compile-time COMPONENT_SZ (global_basic.h:35-37) */
 
@@ -532,16 +533,6 @@ static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) { /* the arena (and what
   c->arena = NULL; c->arena_bytes = 0;
   /* an untouched anonymous mapping (2 MiB granules, huge pages asked for): the framers' stores bring the pages in, the pinner
    * registers them once they are written -- nothing here waits for the engine or costs anything for room that is never used */
-  if (c->fut && g_mmap_input && !g_frame_early) {
-    /* ... but framers that read a MAPPING do wait for the RUNTIME: thirty-two threads that page 15 GB of text in and out and fault row pages in at
-     * memory speed make the runtime's start-up -- a thread of this process that maps, pins and talks to the driver -- three to eight
-     * times as long (0.14-0.46 s instead of 0.055-0.065, profiles/r05_e2e_pool_ab.txt); they get their buffers when the first HIP call
-     * has returned and then run beside the creation of the engine, which does not mind (25 instead of 21 ms) */
-    engine_future *f = c->fut;
-    pthread_mutex_lock(&f->mu);
-    while (!f->hip_up && !f->done) pthread_cond_wait(&f->cv, &f->mu);
-    pthread_mutex_unlock(&f->mu);
-  }
   size_t len = 0;
   uint8_t *m = arena_map_untouched(bytes, &len);
   if (!m) return NULL;
@@ -580,6 +571,9 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   o.drop_pages = c->drop_pages; /* a private read-only file mapping that is unmapped below */
   o.pool_bytes = g_pool_bytes;
   o.fd = map ? 0 : fd;
+  /* while the HIP runtime and the engine come up only a handful of chunks are framed (thirty-two framers at memory speed make that
+   * start-up two to eight times as long, profiles/r05_e2e_*); the rest from the moment the first buffer has been pushed */
+  o.early_chunks = g_frame_early ? 0 : g_early_chunks;
   mk_rows_sink sink = {c, cli_sink_push, cli_sink_wait, cli_sink_alloc, cli_sink_release, cli_sink_ready};
   mk_fastq_stats fs;
   /* the framers start at once, into a pool that is pinned when the engine is there (cli_sink_alloc / cli_sink_push): the
@@ -2127,6 +2121,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--chunk-mib") && i + 1 < argc) chunk_bytes = (uint64_t)atoi(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--inflight") && i + 1 < argc) inflight = atoi(argv[++i]); /* row buffers queued for copying */
     else if (!strcmp(argv[i], "--frame-early")) g_frame_early = 1;
+    else if (!strcmp(argv[i], "--early-chunks") && i + 1 < argc) g_early_chunks = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--mmap-input")) g_mmap_input = 1;
     else if (!strcmp(argv[i], "--pool-mib") && i + 1 < argc) g_pool_bytes = (uint64_t)atoll(argv[++i]) << 20;
     else if (!strcmp(argv[i], "--ahead") && i + 1 < argc) g_ahead = atoi(argv[++i]); /* row buffers the framers may run ahead by */

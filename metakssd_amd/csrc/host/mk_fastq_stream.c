@@ -62,6 +62,8 @@ typedef struct {
   fs_slot *slots;
   uint64_t next;
   int stop;
+  uint64_t early;  /* chunks that may be framed before the first push has returned (mk_fastq_opts::early_chunks); go: it has */
+  int go;
   const mk_rows_sink *sink;
   pthread_mutex_t mu;
   pthread_cond_t cv_buf, cv_ready;
@@ -237,7 +239,7 @@ static void *fs_worker(void *arg) {
   }
   for (;;) {
     pthread_mutex_lock(&f->mu);
-    while (!f->stop && f->next < f->nchunks && f->nfree == 0) pthread_cond_wait(&f->cv_buf, &f->mu);
+    while (!f->stop && f->next < f->nchunks && (f->nfree == 0 || (!f->go && f->next >= f->early))) pthread_cond_wait(&f->cv_buf, &f->mu);
     if (f->stop || f->next >= f->nchunks) { pthread_mutex_unlock(&f->mu); free(scratch); return NULL; }
     const uint64_t c = f->next++;
     const int b = f->freelist[--f->nfree]; /* taken together with the chunk number: the lowest open chunk always has a buffer */
@@ -294,6 +296,8 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
   memset(&f, 0, sizeof f);
   f.text = text; f.n = n;
   f.fd = text ? -1 : o->fd;
+  f.early = o->early_chunks > 0 ? (uint64_t)o->early_chunks : 0;
+  f.go = o->early_chunks > 0 ? 0 : 1;
   f.piece = FS_PIECE;
   if (getenv("MK_FS_PIECE")) { const long v = atol(getenv("MK_FS_PIECE")); if (v >= 4 * 20000 + 4096) f.piece = (size_t)v; } /* (four lines of fastq2co's fgets width) */
   f.sink = sink;
@@ -397,6 +401,7 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
     for (uint64_t c = 0; c < f.nchunks && rc == MK_OK; c++) {
       const double tw = fs_now();
       pthread_mutex_lock(&f.mu);
+      if (!f.go && c >= f.early) { f.go = 1; pthread_cond_broadcast(&f.cv_buf); } /* (every early chunk came to nothing: nobody else would let the framers go) */
       while (!f.slots[c].ready) pthread_cond_wait(&f.cv_ready, &f.mu);
       const fs_slot s = f.slots[c];
       pthread_mutex_unlock(&f.mu);
@@ -421,6 +426,12 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
           if (stats.t_push_call_s == 0) stats.t_first_push_call_s = d;
           stats.t_push_call_s += d;
           if (d > stats.t_push_call_max_s) stats.t_push_call_max_s = d;
+        }
+        if (!f.go) { /* the sink has taken its first buffer: whatever it waited for is there, the framers may run freely */
+          pthread_mutex_lock(&f.mu);
+          f.go = 1;
+          pthread_cond_broadcast(&f.cv_buf);
+          pthread_mutex_unlock(&f.mu);
         }
         if (rc != MK_OK) { fs_release(&f, s.buf); break; }
         ord += s.nrows; stats.rows += s.nrows; stats.records += s.nrec;

@@ -99,6 +99,16 @@ def test_stream_through_a_descriptor_in_small_pieces(capi, occ, monkeypatch):
     assert len(data) > 20 * 84100
     want = check(capi, data, occ, threads=(1, 5), chunks=(200000, 1 << 20, 1 << 22))
     assert len(want) >= len(seqs) - 1
+    # mk_fastq_opts.early_chunks: only the first chunks are framed before the sink has taken a buffer -- the same rows; also when every
+    # early chunk comes to nothing (a file that starts with 300 KB of blank lines: no record start in the first chunks)
+    for blob in (data, b"\n" * 300001 + data):
+        w2, nrec2, rc = serial_rows(capi, blob, occ)
+        assert rc == 0
+        for early in (1, 3):
+            pushes, st, rc = capi.fastq_stream(blob, nthreads=4, chunk_bytes=100000, occ=occ, TL=14, qmin=54, first_ordinal=0, early_chunks=early, via_fd=True)
+            assert rc == 0
+            got = [x for rows, stride, n, ord0 in pushes for x in seqs_of_rows(rows, stride, n)]
+            assert got == w2 and st.records == nrec2, (early, len(got), len(w2))
 
 
 @pytest.mark.parametrize("occ", [False, True])

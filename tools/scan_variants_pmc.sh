@@ -12,4 +12,4 @@ pmc() { # tag, library dir, extra env
 }
 pmc base base
 pmc abl3 abl3
-pmc zf8192_2x512 zf8192 MK_SCAN_THREADS=512 MK_SCAN_WGS_PER_CU=2
+pmc zf8192_2x512 zf8192 MK_SCAN_THREADS=512 MK_SCAN_WGS_PER_CU=2 "MK_BENCH_FLAGS=--cand-cap 32768"
