@@ -558,6 +558,50 @@ def leg_config5_set(cli, ref, tmp, name, sketch_dir, genome_dir, shuf_path, geno
     return res
 
 
+def leg_traffic(reads_per_launch):
+    """roofline.traffic measured IN THIS RUN: HBM bytes of one mk_scan_kernel launch from the TCC counters, as MI355X_MICROARCH.md's HBM
+    section prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (they do not fit one), kernel-trace only, each pass
+    a child `rocprofv3 .. -- python3 bench.py --steps 2 ..` of this process; bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (on gfx950
+    FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes; WRITE_SIZE is exact for 16-byte stores)."""
+    import csv
+    import glob
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="mktraffic_", dir="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+                env.pop(k, None)
+            r = subprocess.run([prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                                "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-host-legs"], cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d): %s" % (ctr, r.returncode, r.stderr.decode(errors="replace")[-200:])
+            per, names = {}, {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == ctr:
+                    per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                    names[row["Dispatch_Id"]] = row["Kernel_Name"]
+            v = [per[k] for k in per if "mk_scan_kernel" in names[k]]
+            if not v:
+                return None, "no mk_scan_kernel dispatch in the %s pass" % ctr
+            vals[ctr] = sum(v) / len(v)
+        return 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0, (
+            "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate child runs of this bench "
+            "(--steps 2, %d reads a launch), mean over the mk_scan_kernel dispatches; bytes = 2 x FETCH_SIZE KB x 1024 + WRITE_SIZE KB x 1024 "
+            "(gfx950: FETCH_SIZE counts the 128-byte requests of wide coalesced reads at 64 bytes, MI355X_MICROARCH.md; FETCH_SIZE %.0f KB, "
+            "WRITE_SIZE %.0f KB)" % (reads_per_launch, vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
+    except Exception as ex:  # noqa: BLE001
+        return None, "traffic passes failed: %s" % str(ex)[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def kernel_source_id():
     h = hashlib.sha256()
     for f in ("mk_kernels.hip.h", "mk_engine.hip", "mk_stream.hip.h", "mk_batch.hip.h", "mk_packed.hip.h"):
@@ -578,6 +622,7 @@ def main():
     ap.add_argument("--no-host-legs", action="store_true", help="skip t_stream / t_e2e / config5 (N = 1 only anyway)")
     ap.add_argument("--serial-finish", action="store_true",
                     help="profiling aid: wait for every pass's result before the next pass starts (no side-stream work beside the scan)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic (N = 1, host legs on)")
     ap.add_argument("--no-config5", action="store_true", help="skip the genome-directory leg (BASELINE config 5 through the command line)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo moves the lists through the host (debug)")
@@ -889,16 +934,20 @@ def main():
         scan_ms = prof["scan_ms"] / launches
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         traffic, traffic_source = None, None
+        if world == 1 and not args.no_host_legs and not args.no_traffic and total_reads == CONFIG3_READS:
+            traffic, traffic_source = leg_traffic(int(reads_per_launch))
         tfile = os.path.join(ROOT, "profiles", "scan_traffic.json")
-        if os.path.exists(tfile):
+        if traffic is None and os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 if tj.get("reads_per_launch") == int(reads_per_launch) and tj.get("kernel_source_id") == kernel_source_id():
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = "profiles/scan_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel source " \
-                                     "in separate runs (tools/pmc_traffic.sh), not measured inside this run"
+                                     "in separate runs (tools/pmc_traffic.sh), not measured inside this run" + (
+                                         " (%s)" % traffic_source if traffic_source else "")
                 else:
-                    traffic_source = "none for this kernel source / launch size (profiles/scan_traffic.json is for another build)"
+                    traffic_source = "none for this kernel source / launch size (profiles/scan_traffic.json is for another build)" + (
+                        "; %s" % traffic_source if traffic_source else "")
             except Exception:
                 traffic = None
         # a measured ceiling beside the nominal 8 TB/s: device-to-device copy of 2 GiB of the rows, read + write bytes

@@ -145,7 +145,7 @@ static double g_t0; /* process start (monotonic) */
 #endif
 static uint64_t g_pool_bytes = (uint64_t)6 << 30; /* --pool-mib: room for the FASTQ stream's row buffers (mk_fastq_opts::pool_bytes; 0: a few buffers, reused) */
 static int g_mmap_input = 0;  /* --mmap-input: the FASTQ file is mapped and the framers read the mapping (rounds 2-4) instead of pread()ing pieces */
-static int g_early_chunks = 16; /* --early-chunks: chunks of a FASTQ file framed before the engine is there (mk_fastq_opts::early_chunks) */
+static int g_early_chunks = 96; /* --early-chunks: chunks of a FASTQ file framed before the engine is there (mk_fastq_opts::early_chunks) */
 static int g_frame_early = 0; /* --frame-early: every chunk of a FASTQ file may be framed at once, also while the runtime and the engine come up (measurement) */
 static int g_ahead = MK_DEFAULT_AHEAD; /* --ahead: row buffers the FASTQ stream's framers may run ahead of the pushes by */
 static int g_component_sz = 8; /* --component-sz: the reference's compile-time COMPONENT_SZ (global_basic.h:35-37) */
