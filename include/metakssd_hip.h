@@ -418,11 +418,11 @@ typedef struct mk_fastq_opts {
                            thread preads pieces of 1 MiB into a buffer of its own and frames them there.  Nothing of the file is mapped
                            into the process: no page-table work for 15 GB of text, no madvise(), no TLB shoot-downs beside the rest of
                            the process (the HIP runtime's start-up takes 3-8 times as long beside framers that populate and drop the
-                           pages of a mapping, profiles/r05_e2e_*).  drop_pages is ignored.  Rows, order, errors: as from a mapping */
+                           pages of a mapping, profiles/r05_e2e_front_end.txt).  drop_pages is ignored.  Rows, order, errors: as from a mapping */
   int32_t early_chunks; /* 0: every chunk is framed as soon as a thread and a buffer are free.  n > 0: only the first n chunks are; the others
                            wait until the sink's first push has returned -- for a sink whose first push waits for something that the
                            framers would disturb: thirty-two threads framing at memory speed make the HIP runtime's start-up and the
-                           creation of the engine two to eight times as long (profiles/r05_e2e_*), which costs more than the framing
+                           creation of the engine two to eight times as long (profiles/r05_e2e_front_end.txt), which costs more than the framing
                            done meanwhile saves */
   int32_t reserved2;
   uint64_t pool_bytes;  /* 0: threads + inflight + 1 + ahead buffers, each with room for a chunk's text rows.  Otherwise a budget for all

@@ -572,7 +572,7 @@ static int sketch_fastq_mapped(ctx_t *c, const char *path) {
   o.pool_bytes = g_pool_bytes;
   o.fd = map ? 0 : fd;
   /* while the HIP runtime and the engine come up only a handful of chunks are framed (thirty-two framers at memory speed make that
-   * start-up two to eight times as long, profiles/r05_e2e_*); the rest from the moment the first buffer has been pushed */
+   * start-up two to eight times as long, profiles/r05_e2e_front_end.txt); the rest from the moment the first buffer has been pushed */
   o.early_chunks = g_frame_early ? 0 : g_early_chunks;
   mk_rows_sink sink = {c, cli_sink_push, cli_sink_wait, cli_sink_alloc, cli_sink_release, cli_sink_ready};
   mk_fastq_stats fs;

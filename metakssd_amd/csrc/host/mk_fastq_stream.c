@@ -44,7 +44,7 @@ typedef struct {
 /* Where the text comes from.  A mapping (text != NULL): the framers read it in place.  A file descriptor (text == NULL,
  * mk_fastq_opts::fd): every thread preads PIECES of FS_PIECE bytes into a buffer of its own that stays in its core's cache and frames
  * the complete records of each piece -- no page of the file is ever mapped into the process, so there is no page-table work, no
- * madvise() and no TLB shoot-down beside whatever else the process is doing (the HIP runtime coming up: profiles/r05_e2e_*). */
+ * madvise() and no TLB shoot-down beside whatever else the process is doing (the HIP runtime coming up: profiles/r05_e2e_front_end.txt). */
 #define FS_PIECE ((size_t)1 << 20)
 typedef struct { const uint8_t *p; size_t avail; int eof; } fs_view;
 
