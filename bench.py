@@ -180,7 +180,7 @@ def leg_packed(torch, capi, eng, pinned_text_rows, n, distinct_text, reps=3):
 _FREE_BASELINE = {}
 
 
-def wait_device_quiet(tag="gpu", least=0.5, most=8.0):
+def wait_device_quiet(tag="gpu", least=2.0, most=8.0):
     """between two runs of the command line: the driver takes a process's device memory back for a while AFTER the process has gone
     (21 GB at L2K11), and the next process's start-up waits for that.  Instead of sleeping a fixed time: poll the device's free
     memory (this process keeps its HIP context; it holds nothing large by now) until it is back at what it was before the first run."""

@@ -266,7 +266,12 @@ int mk_engine_sync(mk_engine *e);
  *   Two batches may be in flight: _begin queues everything and returns, _end waits for the OLDEST batch and hands out one
  *   result per file -- status MK_OK, MK_ERR_FORMAT (the text ends inside a '>' line: the reference's abort, iseq2comem.c:259-271)
  *   or MK_ERR_CROWDED; the arrays are the engine's and stay valid until the next mk_sketch_batch_end on it.
- *   Not between mk_sketch_begin and mk_sketch_finish. */
+ *   Not between mk_sketch_begin and mk_sketch_finish.
+ *   The slow path, for the record: a file that falls out of its batch (its table too small, more keys than half of it, a layout that
+ *   runs out of steps) is sketched alone INSIDE mk_sketch_batch_end, on the engine's queue -- behind the next batch when one has
+ *   been begun already, so that call then returns a batch's time later than it would have; and with MK_ENGINE_LAZY_TABLES the first
+ *   such file also pays for the engine's big tables.  Results do not change (tests: 512-slot tables per file with several batches
+ *   in flight, through the ABI and through the command line). */
 #define MK_BATCH_MAX_FILES 1024u
 #define MK_BATCH_FILE_MAX ((uint64_t)64 << 20)
 #define MK_BATCH_TEXT_MAX ((uint64_t)1 << 30)
