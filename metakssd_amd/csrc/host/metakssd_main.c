@@ -361,6 +361,7 @@ static void push_rows(ctx_t *c, const uint8_t *rows, uint32_t stride, uint64_t n
 typedef struct pinner {
   uint8_t *base;
   size_t bytes, buf_bytes, nbuf;  /* buf_bytes: learnt from the first report after a reset (all buffers of a stream have one size) */
+  size_t kept_buf_bytes;          /* the size the standing registrations and states were made for */
   uint8_t *state;                 /* per buffer: 0 fresh, 1 written (may be pinned), 2 pinned */
   size_t state_cap;
   void **regs; int nregs, regs_cap; /* bases of the registrations made (to undo them) */
@@ -404,7 +405,15 @@ static void *pinner_run(void *arg) {
 }
 /* the buffer at `at` (room `bytes`): its index; the first report after a reset fixes the buffers' size.  Called with the lock held. */
 static size_t pin_index(pinner *p, const uint8_t *at, size_t bytes) {
+  if (!p->buf_bytes && bytes == p->kept_buf_bytes && p->nbuf) { /* the same layout as the last stream's: its pins stand */
+    p->buf_bytes = bytes;
+    for (size_t b = 0; b < p->nbuf; b++) if (p->state[b] == 1) p->state[b] = 0; /* (written by the last stream, never pushed: to be written again) */
+  }
   if (!p->buf_bytes) {
+    /* another layout: a registration must not lie across a buffer's end, so the old ones go (the pinner is idle: go == 0) */
+    for (int i = 0; i < p->nregs; i++) mk_host_unregister(p->regs[i]);
+    p->nregs = 0;
+    p->kept_buf_bytes = bytes;
     p->buf_bytes = bytes;
     p->nbuf = p->bytes / bytes;
     if (p->nbuf > p->state_cap) {
@@ -437,14 +446,12 @@ static void pin_wait(pinner *p, const uint8_t *at) { /* returns when the buffer 
   }
   pthread_mutex_unlock(&p->mu);
 }
-static void pin_reset(pinner *p) { /* a new stream into the same arena: nothing pinned, any buffer size */
+static void pin_reset(pinner *p) { /* a new stream into the same arena: its buffers may have another size (pin_index decides) */
   if (!p) return;
   pthread_mutex_lock(&p->mu);
   p->go = 0;
   while (p->busy) pthread_cond_wait(&p->cv_pinned, &p->mu);
-  for (int i = 0; i < p->nregs; i++) mk_host_unregister(p->regs[i]);
-  p->nregs = 0;
-  p->buf_bytes = 0; p->nbuf = 0;
+  p->buf_bytes = 0;
   pthread_mutex_unlock(&p->mu);
 }
 static void pin_destroy(pinner *p) { /* registrations undone, thread gone (the mapping is the caller's) */

@@ -46,7 +46,7 @@ typedef struct {
  * the complete records of each piece -- no page of the file is ever mapped into the process, so there is no page-table work, no
  * madvise() and no TLB shoot-down beside whatever else the process is doing (the HIP runtime coming up: profiles/r05_e2e_front_end.txt). */
 #define FS_PIECE ((size_t)1 << 20)
-typedef struct { const uint8_t *p; size_t avail; int eof; } fs_view;
+typedef struct { const uint8_t *p; size_t avail; int eof, err; } fs_view;
 
 typedef struct {
   const uint8_t *text;
@@ -71,15 +71,15 @@ typedef struct {
 
 /* the text from offset `off` on: all of it (mapping), or the next piece (descriptor; `scratch` holds FS_PIECE bytes) */
 static fs_view fs_fetch(const fs_t *f, size_t off, uint8_t *scratch) {
-  fs_view v = {NULL, 0, 1};
+  fs_view v = {NULL, 0, 1, 0};
   if (off >= f->n) return v;
   if (f->text) { v.p = f->text + off; v.avail = f->n - off; return v; }
   const size_t want = f->n - off < f->piece ? f->n - off : f->piece;
   size_t got = 0;
   while (got < want) {
     const ssize_t r = pread(f->fd, scratch + got, want - got, (off_t)(off + got));
-    if (r < 0) { if (errno == EINTR) continue; break; }
-    if (r == 0) break;
+    if (r < 0) { if (errno == EINTR) continue; v.err = 1; break; }
+    if (r == 0) { v.err = 1; break; } /* the file is shorter than the caller said */
     got += (size_t)r;
   }
   v.p = scratch; v.avail = got; v.eof = off + got >= f->n;
@@ -164,6 +164,7 @@ static void fs_frame_range(const fs_t *f, size_t start, size_t stop, int first_o
     int rc = MK_OK, again = 0;
     while (pos < stop && rows < max_rows) {
       const fs_view v = fs_fetch(f, pos, scratch);
+      if (v.err) { rc = MK_ERR_IO; break; }
       if (!v.avail) break;
       const size_t st = stop - pos < v.avail ? stop - pos : v.avail;
       uint64_t nr = 0, nrec = 0;
@@ -323,11 +324,12 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
      * buffers as the budget holds -- one per chunk at most, then nobody ever waits for one */
     size_t rec_bytes = 0, seq_max = 0;
     uint8_t *first = text ? NULL : malloc(f.piece + 64);
-    const fs_view v0 = text || first ? fs_fetch(&f, 0, first) : (fs_view){NULL, 0, 1};
+    const fs_view v0 = text || first ? fs_fetch(&f, 0, first) : (fs_view){NULL, 0, 1, 0};
     const int sampled = f.packed && v0.avail ? fs_sample_records(v0.p, v0.avail, &rec_bytes, &seq_max) : 0;
     free(first);
     if (sampled >= 4 && seq_max && seq_max <= MK_PACKED_MAX_BASES + 1u && rec_bytes >= 8) {
-      const size_t rows = f.chunk / rec_bytes + f.chunk / rec_bytes / 8u + 256u; /* (the header lines grow with the read number: a record does not shrink) */
+      size_t rows = f.chunk / rec_bytes + f.chunk / rec_bytes / 8u + 256u; /* (the header lines grow with the read number: a record does not shrink) */
+      rows = (rows + 16383u) & ~(size_t)16383u; /* whole MiB: files of about the same record length get buffers of the same size (a sink that pins them keeps its pins) */
       f.buf_bytes = rows * MK_PACKED_PITCH + 8192;
       if (f.buf_bytes < (size_t)8 * 4096 + 8192) f.buf_bytes = (size_t)8 * 4096 + 8192;
     }

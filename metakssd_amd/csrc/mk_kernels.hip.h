@@ -387,7 +387,12 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
       uint4 v;
       const bool on = mk_wring_pop(r2, lane, v);
       mk_wave_lds_fence();
+#if defined(MK_TUNING) && defined(MK_ABL_R) && MK_ABL_R >= 1
+      /* ablation builds (timing only, results WRONG): the .shuf look-up and the table update left out */
+      if (on && v.x == 0xDEADBEEFu && v.y == 0x12345u) atomicOr(&a.tab.err[0], 32u);
+#else
       installed += (uint32_t)__popcll(__ballot(mk_resolve_accepted(ka, on, v, front_open)));
+#endif
     }
   };
   auto drain1 = [&](uint32_t least) {
@@ -395,7 +400,12 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
       uint4 v;
       const bool on = mk_wring_pop(r1, lane, v);
       mk_wave_lds_fence();
+#if defined(MK_TUNING) && defined(MK_ABL_R) && MK_ABL_R >= 2
+      /* ablation: no canonical k-mer, no accept-bit look-up: every 64th candidate goes on so that ring 2 still works */
+      mk_wring_push(r2, on && (v.x & 63u) == 0u, v);
+#else
       mk_resolve_candidate(a, on, v, r2);
+#endif
       mk_wave_lds_fence();
       drain2(64u);
     }
@@ -432,6 +442,11 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
   };
 
   auto process = [&](const uint4 r) {
+#if defined(MK_TUNING) && defined(MK_ABL_R) && MK_ABL_R >= 3
+    /* ablation: the records are fetched and looked at, nothing else */
+    if (__any(r.x == 0xDEADBEEFu && r.y == 0x12345u && r.z == 7u)) atomicOr(&a.tab.err[0], 32u);
+    return;
+#endif
     const bool single = (r.w & 0x80000000u) != 0u;
     if (__any(single)) { /* slow tiers and the generic kernel hand over whole k-mers */
       mk_wring_push(r1, single, make_uint4(r.x, r.y, r.z, r.w & 0x7FFFFFFFu));
