@@ -329,7 +329,11 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
     free(first);
     if (sampled >= 4 && seq_max && seq_max <= MK_PACKED_MAX_BASES + 1u && rec_bytes >= 8) {
       size_t rows = f.chunk / rec_bytes + f.chunk / rec_bytes / 8u + 256u; /* (the header lines grow with the read number: a record does not shrink) */
-      rows = (rows + 16383u) & ~(size_t)16383u; /* whole MiB: files of about the same record length get buffers of the same size (a sink that pins them keeps its pins) */
+      { /* three significant bits: files of about the same record length get buffers of the same size (a sink that pins them keeps its pins) */
+        size_t g = 1;
+        while ((g << 4) <= rows) g <<= 1;
+        rows = (rows + g - 1) & ~(g - 1);
+      }
       f.buf_bytes = rows * MK_PACKED_PITCH + 8192;
       if (f.buf_bytes < (size_t)8 * 4096 + 8192) f.buf_bytes = (size_t)8 * 4096 + 8192;
     }
