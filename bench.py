@@ -620,8 +620,6 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-legs", action="store_true", help="skip t_stream / t_e2e / config5 (N = 1 only anyway)")
-    ap.add_argument("--waiting-finish", action="store_true",
-                    help="mk_sketch_finish_begin (the host waits for every pass's compaction and key count) instead of mk_sketch_finish_queue")
     ap.add_argument("--serial-finish", action="store_true",
                     help="profiling aid: wait for every pass's result before the next pass starts (no side-stream work beside the scan)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic (N = 1, host legs on)")
@@ -801,7 +799,7 @@ def main():
                 # stream of its own) runs beside the table clear and the scan of pass i + 1, and is waited for before pass
                 # i + 1 is finished -- every pass pays for all of its work inside the timed region, the last one before the fence
                 drain()
-                eng.finish_begin() if args.waiting_finish else eng.finish_queue()  # (queue: not even the key count is waited for)
+                eng.finish_begin()
                 flags["pending"] = True
                 if world > 1 and tail["on"]:  # the next pass may begin here: layout, dump and the result's copy run beside it
                     tail["t_pipe"] += time.perf_counter() - t0
@@ -978,8 +976,7 @@ def main():
                        "total_reads": total_reads, "reads_on_rank0": n, "read_len": READ_LEN, "row_stride": STRIDE,
                        "distinct_keys": result.get("distinct"),
                        "table_load": (result.get("distinct") or 0) / float(eng.params.hashsize),
-                       "finish": "serial (--serial-finish: profiling aid)" if args.serial_finish else
-                                 "result copy beside the next pass" + ("" if args.waiting_finish else ", nothing waited for (mk_sketch_finish_queue)"),
+                       "finish": "serial (--serial-finish: profiling aid)" if args.serial_finish else "result copy beside the next pass",
                        "parallelism": "reads sharded x%d, gather to rank 0" % world},
             "roofline": {"bound": "hbm", "kernel": "mk_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

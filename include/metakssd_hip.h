@@ -247,13 +247,6 @@ int mk_sketch_finish(mk_engine *e, mk_result *out);
  * mk_sketch_finish_begin / mk_partial_* on the engine.  Errors of the sketch (MK_ERR_CROWDED, MK_ERR_FORMAT) are returned by
  * _begin. */
 int mk_sketch_finish_begin(mk_engine *e);
-/* the same with NOTHING waited for: also the compaction's key count and the sketch's flags stay on the device until mk_sketch_finish_end,
- * which then reports what mk_sketch_finish_begin reports when it returns (MK_ERR_CROWDED, MK_ERR_FORMAT) and, when the result turns out
- * larger than the result arrays, grows them and lays out and dumps a second time (the key list is untouched until then).  The host never
- * waits on the engine's stream: the next sketch's clear and scan are queued while this one's compaction still runs (0.08 ms a pass in
- * bench.py, where the host's wake-up and launch calls used to leave the device idle).  Engines with sparse bookkeeping take
- * mk_sketch_finish_begin's path. */
-int mk_sketch_finish_queue(mk_engine *e);
 int mk_sketch_finish_end(mk_engine *e, mk_result *out);
 int mk_result_release(mk_engine *e, mk_result *r);
 int mk_engine_sync(mk_engine *e);

@@ -133,7 +133,6 @@ def _load():
         "mk_sketch_batch_end": [vp, vp],
         "mk_sketch_finish": [vp, C.POINTER(ResultC)],
         "mk_sketch_finish_begin": [vp],
-        "mk_sketch_finish_queue": [vp],
         "mk_sketch_finish_end": [vp, C.POINTER(ResultC)],
         "mk_result_release": [vp, C.POINTER(ResultC)],
         "mk_engine_sync": [vp],
@@ -607,10 +606,6 @@ class Engine:
     def finish_begin(self):
         """first half of a finish: when it returns the next sketch may be begun and pushed; finish_end() hands out the result"""
         _check(lib.mk_sketch_finish_begin(self.h), self.h)
-
-    def finish_queue(self):
-        """finish_begin without any host wait: errors and the key count surface in finish_end"""
-        _check(lib.mk_sketch_finish_queue(self.h), self.h)
 
     def finish_end_raw(self):
         r = ResultC()

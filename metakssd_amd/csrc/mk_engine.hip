@@ -104,9 +104,6 @@ struct mk_engine {
   bool res_koc = false;
   uint64_t res_D = 0;
   bool res_pending = false, res_side = false; /* res_side: layout and dump of the outstanding result run on res_stream */
-  bool res_queued = false;  /* mk_sketch_finish_queue: the host has not seen this result's key count or flags yet (mk_sketch_finish_end will) */
-  int res_mode = 0; uint32_t res_min_occ = 1; uint64_t res_limit = 0; /* ... and the sketch's flavour, for a second layout + dump there */
-  bool big_unknown = false; /* whether the hashsize-slot table holds keys is known to the device only (mk_cond_clear_kernel decides) */
   uint64_t res_total = 0;
   unsigned long long *d_snap = nullptr, *h_snap = nullptr; /* key count and flags of the sketch being finished on the side stream */
   std::vector<mk_evpair> ev_finish_side;
@@ -763,12 +760,7 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
     }
   } else {
     /* behind a front table the S-slot table is cleared only when the last sketch may have used it */
-    if (e->tab.fr && e->big_unknown) { /* (the last finish was queued, not waited for: the device knows, mk_front::state[1]) */
-      hipLaunchKernelGGL(mk_cond_clear_kernel, dim3((unsigned)e->num_cu * 8u), dim3(256), 0, e->stream, (uint4 *)e->d_tab, (unsigned long long)(e->tab_bytes / 16u),
-                         (const uint32_t *)(e->front.state + 1));
-      MK_HIP(e, hipGetLastError());
-    } else if (!e->tab.fr || e->big_maybe_dirty) MK_HIP(e, hipMemsetAsync(e->d_tab, 0, e->tab_bytes, e->stream));
-    e->big_unknown = false;
+    if (!e->tab.fr || e->big_maybe_dirty) MK_HIP(e, hipMemsetAsync(e->d_tab, 0, e->tab_bytes, e->stream));
     if (e->tab.fr) { clear_front = true; e->big_maybe_dirty = false; }
     if (e->sparse) {
       MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)e->kp.S * sizeof(uint32_t), e->stream));
@@ -1720,8 +1712,8 @@ static int mk_res_reserve(mk_engine *e, uint64_t want) {
   if (want <= e->res_cap && e->d_res_ids) return MK_OK;
   hipFree(e->d_res_ids); hipFree(e->d_res_cnt);
   e->d_res_ids = nullptr; e->d_res_cnt = nullptr; e->res_cap = 0;
-  MK_HIP(e, hipMalloc(&e->d_res_ids, want * 4 + 64)); /* (+ slack: mk_res_home_kernel reads 16 bytes a lane) */
-  MK_HIP(e, hipMalloc(&e->d_res_cnt, want * 2 + 64));
+  MK_HIP(e, hipMalloc(&e->d_res_ids, want * 4));
+  MK_HIP(e, hipMalloc(&e->d_res_cnt, want * 2));
   e->res_cap = want;
   return MK_OK;
 }
@@ -1746,109 +1738,12 @@ extern "C" int mk_sketch_finish_begin(mk_engine *e) {
   return mk_finish_impl(e, &r, true);
 }
 
-/* mk_sketch_finish_begin without a single host wait: compaction on the engine's stream; layout, dump and the result's way home on
- * the side stream, all sized and decided on the device (the key count from a snapshot, the copy by mk_res_home_kernel, the next
- * sketch's table clear by mk_cond_clear_kernel).  What mk_sketch_finish_begin reports when it returns -- a crowded table, a stream that
- * ended inside a header, results larger than the arrays -- mk_sketch_finish_end reports (or repairs) for a queued finish.  Dense
- * bookkeeping only; an engine with sparse bookkeeping takes the waiting path. */
-extern "C" int mk_sketch_finish_queue(mk_engine *e) {
-  if (!e) return MK_ERR_ARG;
-  if (e->res_pending) return mk_fail(e, MK_ERR_STATE, "mk_sketch_finish_queue: take the previous result first (mk_sketch_finish_end)");
-  if (!e->begun) return mk_fail(e, MK_ERR_STATE, "finish before mk_sketch_begin");
-  if (e->sparse) { mk_result r; return mk_finish_impl(e, &r, true); }
-  MK_HIP(e, hipSetDevice(e->device));
-  mk_evpair ev{};
-  if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
-  int rc = MK_OK;
-  if (!e->compacted || e->region_open) rc = mk_compact_launch(e);
-  if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
-  const uint32_t S = e->kp.S;
-  const int C = e->P.component_num;
-  const bool koc = e->mode == MK_MODE_KOC;
-  if (!e->h_ids) {
-    const uint64_t lim = mk_key_limit(e) + 1;
-    rc = mk_result_capacity(e, lim < (2u << 20) ? lim : (2u << 20));
-  }
-  if (rc == MK_OK) rc = mk_res_reserve(e, e->res_cap ? e->res_cap : e->h_cap);
-  if (rc) { if (e->profiling) e->ev_pool.push_back(ev); return rc; }
-  hipStream_t rs = e->res_stream;
-  MK_HIP(e, hipMemcpyAsync(e->d_snap, e->d_counters, 6 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, e->stream));
-  if (e->profiling) MK_HIP(e, hipEventRecord(ev.b, e->stream));
-  MK_HIP(e, hipEventRecord(e->ev_res, e->stream));
-  MK_HIP(e, hipStreamWaitEvent(rs, e->ev_res, 0));
-  mk_evpair ev2{};
-  if (e->profiling) { ev2 = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev2.a, rs)); }
-  if (!e->slot_clean) MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)S * sizeof(uint32_t), rs));
-  hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)e->num_cu * 16u), dim3(256), 0, rs, e->dist, (const unsigned long long *)e->d_snap,
-                     (unsigned long long)mk_key_limit(e), e->d_slot, S, (uint32_t *)(e->d_snap + 2), (uint32_t *)nullptr, (uint32_t)MK_DUMP_SHIFT);
-  MK_HIP(e, hipGetLastError());
-  rc = mk_launch_dump(e, true, e->d_res_ids, e->d_res_cnt, e->res_cap, rs, true);
-  if (rc == MK_OK) {
-    hipLaunchKernelGGL(mk_res_home_kernel, dim3((unsigned)e->num_cu * 2u), dim3(256), 0, rs, (const uint4 *)e->d_res_ids, (const uint4 *)e->d_res_cnt,
-                       (const unsigned long long *)e->d_comp_totals, (uint32_t)C, (uint4 *)e->h_ids, koc ? (uint4 *)e->h_cnt : nullptr,
-                       (unsigned long long)e->h_cap, (unsigned long long)e->res_cap);
-    if (hipGetLastError() != hipSuccess) rc = mk_fail(e, MK_ERR_HIP, "mk_res_home_kernel launch");
-  }
-  if (rc) { /* work is queued on the side stream: waited for, the sketch is over */
-    (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(rs);
-    e->begun = false; e->slot_clean = false; e->compacted = false;
-    if (e->profiling) { e->ev_pool.push_back(ev); e->ev_pool.push_back(ev2); }
-    return rc;
-  }
-  e->slot_clean = true; /* (a dump that held back leaves the layout in the table: mk_sketch_finish_end fills it anew) */
-  MK_HIP(e, hipMemcpyAsync(e->h_comp_totals, e->d_comp_totals, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, rs));
-  MK_HIP(e, hipMemcpyAsync(e->h_snap, e->d_snap, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, rs));
-  if (e->profiling) { MK_HIP(e, hipEventRecord(ev2.b, rs)); e->ev_finish_side.push_back(ev2); e->ev_finish.push_back(ev); }
-  MK_HIP(e, hipEventRecord(e->ev_res, rs));
-  e->res_pending = true; e->res_side = true; e->res_queued = true;
-  e->res_koc = koc; e->res_mode = e->mode; e->res_min_occ = e->min_occ; e->res_limit = mk_key_limit(e);
-  e->big_unknown = true; /* the next begin lets the device decide about the hashsize-slot table */
-  e->compacted = false;
-  e->begun = false;
-  return MK_OK;
-}
-
 extern "C" int mk_sketch_finish_end(mk_engine *e, mk_result *out) {
   if (!e || !out) return MK_ERR_ARG;
   if (!e->res_pending) return mk_fail(e, MK_ERR_STATE, "mk_sketch_finish_end without mk_sketch_finish_begin");
   MK_HIP(e, hipSetDevice(e->device));
   MK_HIP(e, hipEventSynchronize(e->ev_res));
   e->res_pending = false;
-  if (e->res_queued) { /* what mk_sketch_finish_begin sees when it returns, seen here */
-    e->res_queued = false;
-    const uint32_t flags = (uint32_t)(e->h_snap[2] & 0xffffffffu);
-    const uint64_t D = e->h_snap[0];
-    e->res_D = D;
-    if (flags & 4u) { e->res_side = false; return mk_fail(e, MK_ERR_HIP, "scan kernel: LDS filter not at offset 0"); }
-    if (flags & 8u) { e->res_side = false; return mk_fail(e, MK_ERR_FORMAT, "fasta2co(): can not find seqences head start from '>' (the stream ends inside a header line)"); }
-    if ((flags & 1u) || D > e->res_limit) {
-      e->res_side = false;
-      return mk_fail(e, MK_ERR_CROWDED, "the context space is too crowd (%llu distinct keys > limit %llu), try k=%d", (unsigned long long)D,
-                     (unsigned long long)e->res_limit, e->P.k + 1);
-    }
-    const int C = e->P.component_num;
-    uint64_t total = 0;
-    for (int c = 0; c < C; c++) total += e->h_comp_totals[c];
-    if (total > e->res_cap || total > e->h_cap) {
-      /* the write pass or the copy held back: larger arrays, then layout and dump once more from the key list, which nobody has
-       * touched since (the next sketch's compaction needs this result taken first; its clear, scan and resolve touch neither the
-       * list nor the layout table), straight into the pinned arrays */
-      int rc = mk_result_capacity(e, total);
-      if (rc) return rc;
-      const int mode_now = e->mode; const uint32_t occ_now = e->min_occ;
-      e->mode = e->res_mode; e->min_occ = e->res_min_occ;
-      MK_HIP(e, hipMemsetAsync(e->d_slot, 0xFF, (size_t)e->kp.S * sizeof(uint32_t), e->res_stream));
-      hipLaunchKernelGGL(mk_layout_kernel, dim3((unsigned)e->num_cu * 16u), dim3(256), 0, e->res_stream, e->dist, (const unsigned long long *)e->d_snap,
-                         (unsigned long long)e->res_limit, e->d_slot, e->kp.S, (uint32_t *)(e->d_snap + 2), (uint32_t *)nullptr, (uint32_t)MK_DUMP_SHIFT);
-      rc = mk_launch_dump(e, true, nullptr, nullptr, 0, e->res_stream, true);
-      e->mode = mode_now; e->min_occ = occ_now;
-      if (rc) return rc;
-      MK_HIP(e, hipMemcpyAsync(e->h_comp_totals, e->d_comp_totals, (size_t)C * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->res_stream));
-      MK_HIP(e, hipMemcpyAsync(e->h_snap, e->d_snap, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->res_stream));
-      MK_HIP(e, hipStreamSynchronize(e->res_stream));
-      e->slot_clean = true;
-    }
-  }
   if (e->res_side) { /* layout and dump ran on the side stream: their flags and sizes have come back with the result */
     e->res_side = false;
     const int C = e->P.component_num;

@@ -1281,27 +1281,6 @@ __global__ void __launch_bounds__(1024) mk_split_scatter_kernel(mk_dist d, const
 }
 __global__ void mk_set_counter_kernel(unsigned long long *counter, unsigned long long v) { counter[0] = v; }
 
-/* mk_sketch_finish_queue: nothing of a finish is waited for by the host, so two things the host used to decide move to the device.
- * (1) The hashsize-slot table is cleared for the next sketch only if somebody has put a key into it (mk_front::state[1]; the host learnt
- * that from the counters it waited for).  (2) The result goes home by a kernel that knows how much there is: the staged ids and counts
- * to the pinned result arrays, 16 bytes a lane (the arrays end in slack); held back when either side is too small (mk_sketch_finish_end
- * sees that in the totals and lays out and dumps again). */
-__global__ void __launch_bounds__(256) mk_cond_clear_kernel(uint4 *tab, unsigned long long n16, const uint32_t *big_used) {
-  if (__hip_atomic_load(big_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * blockDim.x) tab[i] = z;
-}
-__global__ void __launch_bounds__(256) mk_res_home_kernel(const uint4 *ids, const uint4 *cnt, const unsigned long long *totals, uint32_t ncomp,
-                                                          uint4 *h_ids, uint4 *h_cnt, unsigned long long h_cap, unsigned long long d_cap) {
-  unsigned long long total = 0;
-  for (uint32_t c = 0; c < ncomp; c++) total += totals[c];
-  if (total > h_cap || total > d_cap) return;
-  const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long i = tid; i < (total + 3u) / 4u; i += nt) h_ids[i] = ids[i];
-  if (h_cnt)
-    for (unsigned long long i = tid; i < (total + 7u) / 8u; i += nt) h_cnt[i] = cnt[i];
-}
-
 
 /* ---- sparse bookkeeping for large tables --------------------------------------------------------------------------
  * mk_dirty_list_kernel: bitmap -> list of set block indices (any order), one workgroup.

@@ -609,13 +609,10 @@ def test_batch_small_tables_fall_back_to_alone(capi, shufs, oracle_for, name):
         eng.close()
 
 
-@pytest.mark.parametrize("queued", [False, True])
 @pytest.mark.parametrize("name,sparse", [("L1K7", 0), ("L1K7", 1), ("L3K11", 0), ("L2K11", -1)])
-def test_finish_in_two_halves_pipelined(capi, shufs, oracle_for, name, sparse, queued):
+def test_finish_in_two_halves_pipelined(capi, shufs, oracle_for, name, sparse):
     """mk_sketch_finish_begin / _end: the result of sketch i is copied to the host while sketch i + 1 is already being scanned;
-    every result equals the oracle's (and so the plain mk_sketch_finish's), results larger than the staging arrays included.
-    queued: mk_sketch_finish_queue -- nothing waited for, the key count and the flags stay on the device until _end, which grows the
-    arrays and dumps a second time when the result did not fit (here: inside the NEXT sketch, already begun and pushed)"""
+    every result equals the oracle's (and so the plain mk_sketch_finish's), results larger than the staging arrays included"""
     rs = np.random.RandomState(41)
     eng = capi.Engine(shufs(name), 0, sparse=sparse)
     ora = oracle_for(shufs(name))
@@ -638,11 +635,9 @@ def test_finish_in_two_halves_pipelined(capi, shufs, oracle_for, name, sparse, q
             eng.push_reads(rows, 160, 0)
             if pending is not None:
                 assert_same(eng.finish_end(), wants[pending], "%s sketch %d" % (name, pending))
-            eng.finish_queue() if queued else eng.finish_begin()
+            eng.finish_begin()
             with pytest.raises(capi.MkError):  # one result outstanding: neither finish may run before it has been taken
                 eng.finish_begin()
-            with pytest.raises(capi.MkError):
-                eng.finish_queue()
             pending = i
         assert_same(eng.finish_end(), wants[pending], "%s last sketch" % name)
         with pytest.raises(capi.MkError):
