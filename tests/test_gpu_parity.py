@@ -865,6 +865,13 @@ def test_multi_library_both_merges_equal_oracle(capi, shufs, oracle_for, ndev, m
             assert m.last_merge() == merge
             t = m.last_times()
             assert t["total_ms"] > 0 and (merge == "gather") == (t["gather_ms"] == 0.0)
+        # nothing pushed at all, and rows on ONE engine only (the others' lists, and every part and slice of them, are empty)
+        m.begin(capi.MK_MODE_KOC)
+        got = m.finish()
+        assert len(got) == 1 and len(got[0][0]) == 0
+        m.begin(capi.MK_MODE_KOC)
+        m.push_reads(ndev - 1, rows, stride, 0)
+        assert_same(m.finish(), want, "multi %s x%d, everything on the last engine" % (merge, ndev))
     finally:
         m.close()
 
