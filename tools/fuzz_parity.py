@@ -4,6 +4,7 @@
     python tools/fuzz_parity.py [--cases 200] [--seed 1]
 
 Every case draws a .shuf geometry, a sketch flavour (-A counted / FASTA set / FASTA -u / FASTQ occurrence set), a row stride,
+(half of the -A cases: the sketch merged from 2 / 3 / 5 shards through the multi-GPU ABI, by the gather or by key slices,)
 a number of pushes and reads with random lengths, strands, lower case, N runs and odd bytes, and compares the engine's
 sketch with the oracle's, bit for bit.  Exits non-zero on the first difference and prints how to reproduce it."""
 import argparse
@@ -44,6 +45,17 @@ def random_reads(rs, n, dense):
             s = s[:L]
         out.append(s)
     return out
+
+
+def _hip():
+    return ctypes.CDLL("libamdhip64.so")
+
+
+def _dmalloc(hip, held, nbytes):
+    q = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(q), ctypes.c_size_t(max(16, nbytes))) == 0
+    held.append(q)
+    return q.value
 
 
 def main():
@@ -89,6 +101,76 @@ def main():
             tuned = bool(capi.lib.mk_params_packed_ok(ctypes.byref(P)))
             packed = tuned and need <= 153 and rs.rand() < 0.5   # 64-byte packed rows (mk_scan_packed_kernel)
             desc += " packed=%d" % packed
+            merge = [None, None, "gather", "slices"][rs.randint(0, 4)] if rc == 0 else None
+            if merge:
+                # SURVEY 8e through the C ABI, on this one engine shard after shard: contiguous read ranges with global ordinals, every
+                # shard's list exported (whole, or cut by key % G); then one sketch that imports them all (gather), or G sketches that each
+                # fold one key slice, whose reduced lists are adopted as the last sketch's key list (slices)
+                G = int(rs.choice([2, 3, 5]))
+                n = len(seqs)
+                cuts = [n * g // G for g in range(G + 1)]
+                desc += " merge=%s G=%d" % (merge, G)
+                hip = _hip()
+                held, shards = [], []
+                try:
+                    for g in range(G):
+                        eng.begin(capi.MK_MODE_KOC)
+                        eng.push_reads(rows[cuts[g] * stride:cuts[g + 1] * stride], stride, cuts[g])
+                        d = eng.partial_count()
+                        bk, bc, bo = _dmalloc(hip, held, 8 * d), _dmalloc(hip, held, 4 * d), _dmalloc(hip, held, 8 * d)
+                        if merge == "gather":
+                            assert eng.partial_export(bk, bc, bo, d) == d
+                            parts = [d]
+                        else:
+                            got_n, parts = eng.partial_export_split(G, bk, bc, bo, d)
+                            assert got_n == d and sum(parts) == d
+                        shards.append((bk, bc, bo, parts))
+                        eng.finish()  # (the shard's own sketch: spent)
+                    if merge == "gather":
+                        eng.begin(capi.MK_MODE_KOC)
+                        for bk, bc, bo, parts in shards:
+                            if parts[0]:
+                                eng.partial_import(bk, bc, bo, parts[0])
+                    else:
+                        slices = []
+                        for g in range(G):
+                            eng.begin(capi.MK_MODE_KOC)
+                            for bk, bc, bo, parts in shards:
+                                off = sum(parts[:g])
+                                if parts[g]:
+                                    eng.partial_import(bk + 8 * off, bc + 4 * off, bo + 8 * off, parts[g])
+                            r = eng.partial_count()
+                            lk, lc, lo = eng.partial_list_reserve(r)
+                            ck, cc, co = _dmalloc(hip, held, 8 * r), _dmalloc(hip, held, 4 * r), _dmalloc(hip, held, 8 * r)
+                            eng.sync()
+                            for dst, src, w in ((ck, lk, 8), (cc, lc, 4), (co, lo, 8)):
+                                assert hip.hipMemcpy(ctypes.c_void_p(dst), ctypes.c_void_p(src), ctypes.c_size_t(w * r), 3) == 0
+                            slices.append((ck, cc, co, r))
+                            eng.finish()
+                        eng.begin(capi.MK_MODE_KOC)
+                        at = 0
+                        for ck, cc, co, r in slices:
+                            eng.partial_list_adopt(ck, cc, co, r, at)
+                            at += r
+                        eng.partial_list_commit(at)
+                    # (finished below, the buffers live until then)
+                    try:
+                        got = eng.finish()
+                        grc = 0
+                    except capi.CrowdedError:
+                        grc, got = -2, None
+                finally:
+                    for q in held:
+                        hip.hipFree(q)
+                n_ids = sum(len(w[0]) for w in want)
+                ok = grc == 0 and len(got) == len(want) and all(np.array_equal(g_[0], w[0]) and np.array_equal(g_[1], w[1]) for g_, w in zip(got, want))
+                nonempty += n_ids > 0
+                total_ids += n_ids
+                if not ok:
+                    bad += 1
+                    print("MISMATCH", desc, "oracle rc", rc, "engine rc", grc)
+                    break
+                continue
             eng.begin(capi.MK_MODE_KOC)
             pushes = int(rs.choice([1, 2, 5]))
             n = len(seqs)
