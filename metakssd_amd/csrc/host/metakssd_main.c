@@ -509,7 +509,7 @@ static uint8_t *arena_map_untouched(size_t bytes, size_t *len_out) {
   uint8_t *m = mmap(NULL, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
   if (m == MAP_FAILED) return NULL;
 #ifdef MADV_HUGEPAGE
-  if (!getenv("MK_NO_THP")) (void)madvise(m, len, MADV_HUGEPAGE);
+  (void)madvise(m, len, MADV_HUGEPAGE);
 #endif
   *len_out = len;
   return m;
