@@ -127,7 +127,6 @@ typedef struct {
   pthread_mutex_t mu;
   pthread_cond_t cv;
   int done, rc, device;
-  int hip_up;           /* the first HIP call has returned (t_hip_ready is set) */
   int ndev, devs[64];   /* --devices: more than one GPU -> libmetakssd_multi.so */
   unsigned multi_flags; /* MK_MULTI_ALLOW_DEVICE_COPIES with --allow-device-copies */
   mk_multi *multi;
@@ -214,8 +213,6 @@ static void *engine_thread(void *arg) {
   int rc = mk_device_count(&n); /* first HIP call of the process: runtime start-up, while the main thread reads the .shuf file */
   f->t_hip_ready = now_s() - g_t0;
   pthread_mutex_lock(&f->mu);
-  f->hip_up = 1;
-  pthread_cond_broadcast(&f->cv);
   while (!f->have_params) pthread_cond_wait(&f->cv, &f->mu);
   pthread_mutex_unlock(&f->mu);
   if (rc == MK_OK && !f->P) rc = MK_ERR_ARG; /* the main thread gave up */
