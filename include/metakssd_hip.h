@@ -22,7 +22,9 @@
  *   wrt_co2cmpn_use_inn_subctx() iseq2comem.c:625-652     }
  *   write_fqco2file()            iseq2comem.c:596-621     }
  *   err(errno,"...too crowd")    iseq2comem.c:708-709        MK_ERR_CROWDED (never exit() in here)
- *   -- (no counterpart: single process) --                   mk_partial_count/export/import (multi-GPU merge)
+ *   -- (no counterpart: single process; the thread team of mt_shortreads2koc, iseq2comem.c:675-720, spread over GPUs) --
+ *                                                            mk_partial_count/export/import (merge by gather),
+ *                                                            mk_partial_export_split/restart/list_reserve/adopt/commit (merge by key slices)
  *   sketch_union()/uniq_sketch_union() dictionaries  command_set.c:279-316,466-509   mk_setop_begin/add/finish
  *   sketch_operate() membership filter               command_set.c:361-405           mk_setop_filter
  *   grouping_genomes() per-taxon table               command_set.c:866-915           mk_setop_group
