@@ -200,7 +200,7 @@ def wait_device_quiet(tag="gpu", least=2.0, most=8.0):
         time.sleep(2.5)
 
 
-def leg_e2e(capi, shuf, n, resident_sketch, reps=4):
+def leg_e2e(capi, shuf, n, resident_sketch, reps=5):
     """t_e2e: `metakssd dist -L L3K11.shuf -A` on the workload as a FASTQ file in /dev/shm, process start to sketch on disk"""
     import numpy as np
     cores = os.cpu_count() or 1
@@ -260,9 +260,10 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=4):
                               "gbases_s_excl_init": round(bases / max(work(t), 1e-9) / 1e9, 2)} for w, t, _ in runs],
                 "sketch_equals_resident_run": same, "fastq_write_s": t_write,
                 "what": "`metakssd dist -L L3K11.shuf -A -o out --quiet --timing reads.fq`, %d reads = %.2f GB of FASTQ in /dev/shm, "
-                        "run %d times with a second in between; every figure is the MEDIAN over those runs.  seconds = process start "
-                        "until the sketch directory is complete on disk (HIP runtime start-up, engine creation, mapping + framing the "
-                        "file on %s host threads, H2D, scan, finish, file output); gbases_s = bases / seconds.  wall_s = the "
+                        "run %d times after a warm-up run, the device's free memory back at its level and two seconds in between; every figure is the MEDIAN "
+                        "over those runs, `all_runs` has each.  seconds = process start "
+                        "until the sketch directory is complete on disk (HIP runtime start-up, engine creation, reading (pread) + framing the "
+                        "file on %s host threads into packed rows, H2D, scan, finish, file output); gbases_s = bases / seconds.  wall_s = the "
                         "parent's clock around the whole process (spawn and the runtime's teardown at exit on top); gbases_s_wall = "
                         "bases / wall_s.  seconds_excl_init = the same as seconds from the moment the first HIP call has returned "
                         "(init_s after process start); gbases_s_excl_init = bases / seconds_excl_init" % (
