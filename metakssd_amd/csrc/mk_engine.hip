@@ -448,6 +448,19 @@ static int mk_engine_init(mk_engine *e, const mk_params *p, bool lazy_tables) {
   MK_HIP(e, hipSetDevice(e->device));
   MK_HIP(e, hipDeviceGetAttribute(&e->num_cu, hipDeviceAttributeMultiprocessorCount, e->device)); /* hipGetDeviceProperties takes 30 ms */
   MK_TICK("device");
+#ifdef MK_TUNING
+  /* experiment builds: the engine's queue on MK_TUNE_CUS compute units from bit MK_TUNE_CU_FIRST of the queue's CU mask on (the bits go
+   * round the XCDs), every grid sized for that many -- what a kernel takes on a part of the chip */
+  if (const char *t = getenv("MK_TUNE_CUS")) {
+    const int n = atoi(t), first = getenv("MK_TUNE_CU_FIRST") ? atoi(getenv("MK_TUNE_CU_FIRST")) : 0;
+    if (n < 1 || first < 0 || first + n > e->num_cu) return mk_fail(e, MK_ERR_ARG, "MK_TUNE_CUS / MK_TUNE_CU_FIRST out of range");
+    uint32_t mask[16] = {0};
+    for (int i = first; i < first + n; i++) mask[i >> 5] |= 1u << (i & 31);
+    MK_HIP(e, hipExtStreamCreateWithCUMask(&e->own_stream, (uint32_t)((e->num_cu + 31) / 32), mask));
+    e->num_cu = n;
+    fprintf(stderr, "[tuning] queue on CUs %d..%d of the mask\n", first, first + n - 1);
+  } else
+#endif
   MK_HIP(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   MK_TICK("stream 1");
   /* host-to-device copies ride on the engine's own stream: a second stream means a second hardware queue (30-60 ms of
