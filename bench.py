@@ -578,7 +578,7 @@ def leg_traffic(reads_per_launch):
             for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
                 env.pop(k, None)
             r = subprocess.run([prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                                "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-host-legs"], cwd="/tmp", env=env,
+                                "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-host-legs", "--no-one-queue"], cwd="/tmp", env=env,
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -621,6 +621,12 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-legs", action="store_true", help="skip t_stream / t_e2e / config5 (N = 1 only anyway)")
+    ap.add_argument("--split-cus", type=int, default=32,
+                    help="N = 1: two engines take the passes in turn, the scan kernel on all but this many compute units and what follows a "
+                         "scan on these (MK_OPT_SPLIT_CUS; a multiple of 32); 0: one engine, one queue -- that flow is timed as well "
+                         "either way (`one_queue` in the line)")
+    ap.add_argument("--no-one-queue", action="store_true", help="skip the comparison leg on one engine and one queue (profiling: one flow's kernels only)")
+    ap.add_argument("--split-two-scan-queues", action="store_true", help="experiment: a scan queue per engine instead of one shared")
     ap.add_argument("--serial-finish", action="store_true",
                     help="profiling aid: wait for every pass's result before the next pass starts (no side-stream work beside the scan)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic (N = 1, host legs on)")
@@ -828,22 +834,99 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    eng.profile_enable(True)
-    eng.profile_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    prof = eng.profile()
-    eng.profile_enable(False)
+    # N = 1, --split-cus R > 0: TWO engines take the passes in turn, each with the scan kernel on a queue of its own (all but R compute
+    # units) and everything that follows a scan on the other R (MK_OPT_SPLIT_CUS): the candidate resolution, compaction and clear of
+    # pass i run BESIDE the scan of pass i + 1 -- on one queue they cannot (the two kernels do not fit on one CU
+    # together).  Every pass is still a whole sketch, begin to result in host memory, all of it inside the timed region; the host calls are
+    # ordered so that the next scan is queued before the wait inside mk_sketch_finish_begin.
+    split = args.split_cus if world == 1 and not args.serial_finish else 0
+    eng_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    if split:
+        eng2 = capi.Engine(shuf, local_rank, front_bits=args.front_bits, cand_cap=args.cand_cap)
+        engs = (eng, eng2)
+        for e in engs:
+            e.use_own_stream()
+            e.set_option(capi.MK_OPT_SPLIT_CUS, split)
+        if not args.split_two_scan_queues:
+            eng2.share_scan_queue(eng)  # one scan queue: the scans run one after the other and a kernel's duration is its run time
+        pend = [False, False]
+
+        def drain2(j):
+            if pend[j]:
+                r = engs[j].finish_end_raw()
+                result["distinct"] = int(r.total)
+                capi.lib.mk_result_release(engs[j].h, r)
+                pend[j] = False
+
+        def passes(k):
+            for i in range(k + 1):
+                if i < k:
+                    engs[i & 1].begin(capi.MK_MODE_KOC)
+                    engs[i & 1].push_reads_device(reads.data_ptr(), STRIDE, n, first)
+                if i > 0:
+                    j = (i - 1) & 1
+                    drain2(j)
+                    engs[j].finish_begin()
+                    pend[j] = True
+
+        def fence2():
+            drain2(0)
+            drain2(1)
+            torch.cuda.synchronize()
+
+        passes(max(2, args.warmup))
+        for e in engs:
+            e.profile_enable(True)
+            e.profile_reset()
+        fence2()
+        t0 = time.perf_counter()
+        passes(args.steps)
+        fence2()
+        dt = time.perf_counter() - t0
+        profs = [e.profile() for e in engs]
+        prof = {k: profs[0][k] + profs[1][k] for k in profs[0]}
+        for e in (eng2, eng):
+            e.profile_enable(False)
+            e.set_option(capi.MK_OPT_SPLIT_CUS, 0)
+        eng2.close()
+        eng.set_stream(stream)
+        # the same passes on ONE engine and one queue (every kernel on the whole device, resolve + compaction between two scans), for
+        # comparison: the flow of rounds 1-4, and what the scan kernel takes with all 256 compute units
+        k1 = 0 if args.no_one_queue else max(2, min(args.steps, 100))
+        for _ in range(3 if k1 else 0):
+            step()
+        eng.profile_enable(True)
+        eng.profile_reset()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(k1):
+            step()
+        fence()
+        dt1 = time.perf_counter() - t1
+        p1 = eng.profile()
+        eng.profile_enable(False)
+        one_queue = None if not k1 else {"steps": k1, "ms_per_step": dt1 / k1 * 1e3, "gbases_s": float(n) * READ_LEN * k1 / dt1 / 1e9,
+                     "scan_ms": p1["scan_ms"] / max(1, p1["scan_launches"]), "resolve_ms": p1["resolve_ms"] / k1,
+                     "what": "one engine, one queue, every kernel on all %d compute units: scan, resolve and compaction of a pass one after "
+                             "the other, layout + dump + result copy beside the next pass (the flow of rounds 1-4)" % eng_cus}
+    else:
+        one_queue = None
+        for _ in range(args.warmup):
+            step()
+        eng.profile_enable(True)
+        eng.profile_reset()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        prof = eng.profile()
+        eng.profile_enable(False)
 
     if world > 1:  # rank 0's serial tail (gather + import + finish), from three separately fenced steps
         tail["on"] = True
@@ -978,11 +1061,15 @@ def main():
                        "distinct_keys": result.get("distinct"),
                        "table_load": (result.get("distinct") or 0) / float(eng.params.hashsize),
                        "finish": "serial (--serial-finish: profiling aid)" if args.serial_finish else "result copy beside the next pass",
+                       "queues": ("two engines take the passes in turn; scan kernel on %d compute units, candidate resolution + compaction + "
+                                  "clear of the pass before on the other %d beside it (MK_OPT_SPLIT_CUS)" % (eng_cus - split, split)) if split
+                                 else "one engine, one queue: every kernel on the whole device, one after the other",
                        "parallelism": "reads sharded x%d, gather to rank 0" % world},
             "roofline": {"bound": "hbm", "kernel": "mk_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms,
                          "launches": prof["scan_launches"], "kernel_source_id": kernel_source_id(),
+                         "compute_units": eng_cus - split,
                          "measured_copy_gb_s": copy_gbs},
             "phases_ms_per_step": {"clear": prof["clear_ms"] / args.steps, "scan": prof["scan_ms"] / args.steps,
                                    "resolve": prof["resolve_ms"] / args.steps,
@@ -990,6 +1077,10 @@ def main():
                                    # layout + dump + copy of pass i on the side stream, beside clear + scan of pass i + 1
                                    "finish_side_stream": prof.get("finish_side_ms", 0.0) / args.steps},
         }
+        if one_queue is not None:
+            sb = scan_bytes / (one_queue["scan_ms"] * 1e-3) / 1e9 if one_queue["scan_ms"] > 0 else 0.0
+            one_queue["scan_roofline"] = {"achieved": sb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sb / HBM_PEAK_GBS, "compute_units": eng_cus}
+            line["one_queue"] = one_queue
         if seen is not None:
             line["distributed"] = seen
         if world > 1 and tail["steps"]:

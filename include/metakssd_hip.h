@@ -164,15 +164,25 @@ int mk_engine_destroy(mk_engine *e);
  *                   of hashsize -- 10.7 GB at L2K11 -- and the finish / export that counts more keys grows it and compacts again)
  *   MK_OPT_BATCH_TAB_BITS 0 / 9..22: log2 of the slots every file's table gets in mk_sketch_batch_begin (default 0: about five times
  *                   the keys the batch's largest file is expected to leave); a file whose table is too small is sketched alone
+ *   MK_OPT_SPLIT_CUS 0 / 32, 64 .. half the device's compute units: two hardware queues with complementary CU masks -- the scan kernel on
+ *                   all but this many compute units, everything that follows a scan (candidate resolution, compaction, clears) on
+ *                   these, ordered by events.  One engine gains nothing (its kernels depend on each other); TWO engines taking
+ *                   sketches in turn do: what follows engine A's scan runs beside engine B's scan instead of in front of it
+ *                   (bench.py's flow with device-resident rows, DESIGN.md 4.2: 2.33 instead of 2.44 ms a pass of 50 M reads with 32).
+ *                   Default 0: one queue, every kernel on the whole device
  *   (8 and 9 were MK_OPT_ROWS160 and MK_OPT_BATCH_QUEUES in round 4: a scan kernel that kept a lane's text row in registers and a
  *   second queue for every other batch.  Both measured slower than what they replaced -- profiles/r04_b_kernel_stats_rows160_variant.csv,
  *   profiles/r04_d_config5_two_queues.txt -- and were removed in round 5; the numbers stay retired.)
  * Results are bit-identical for every setting; the tests run both. */
 enum { MK_OPT_SPARSE = 1, MK_OPT_CAND_CAP = 2, MK_OPT_RESULT_CAP = 3, MK_OPT_DIRECT_HOST = 4, MK_OPT_FRONT_BITS = 5, MK_OPT_KEYLIST_CAP = 6,
-       MK_OPT_BATCH_TAB_BITS = 7 };
+       MK_OPT_BATCH_TAB_BITS = 7, MK_OPT_SPLIT_CUS = 10 };
 int mk_engine_set_option(mk_engine *e, int option, int64_t value);
 int mk_engine_set_stream(mk_engine *e, void *hip_stream);
 int mk_engine_use_own_stream(mk_engine *e);
+/* MK_OPT_SPLIT_CUS on two engines of one device: e's scan kernels go to WITH's scan queue, one after the other in the order they are
+ * pushed, instead of to a second queue with the same CU mask (where the workgroups of both scans compete for the units and a kernel's
+ * duration includes its wait for them).  WITH owns the queue: destroy e, or set it back to one queue, before WITH. */
+int mk_engine_share_scan_queue(mk_engine *e, mk_engine *with);
 const char *mk_last_error(const mk_engine *e); /* e may be NULL: last error of a failed create */
 
 int mk_sketch_begin(mk_engine *e, int mode); /* MK_MODE_OCC_SET here means min_occurrence 1 */

@@ -19,6 +19,7 @@ MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET, MK_MODE_OCC_SET = 0, 1, 2, 3
 MK_ROWS_PACKED, MK_PACKED_PITCH, MK_PACKED_MAX_BASES = 0x80000000, 64, 152
 MK_ROWS_WIDE, MK_WIDE_MAX_BASES = 0x40000000, 240
 MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP, MK_OPT_DIRECT_HOST, MK_OPT_FRONT_BITS, MK_OPT_KEYLIST_CAP, MK_OPT_BATCH_TAB_BITS = 1, 2, 3, 4, 5, 6, 7
+MK_OPT_SPLIT_CUS = 10  # scan kernel on a queue of its own, the rest on this many compute units (two engines in turn: bench.py)
 
 
 class MkError(RuntimeError):
@@ -116,6 +117,7 @@ def _load():
         "mk_engine_set_option": [vp, C.c_int, C.c_int64],
         "mk_engine_set_stream": [vp, vp],
         "mk_engine_use_own_stream": [vp],
+        "mk_engine_share_scan_queue": [vp, vp],
         "mk_sketch_begin": [vp, C.c_int],
         "mk_sketch_begin_occ": [vp, C.c_int],
         "mk_sketch_push_reads": [vp, vp, u32, u64, u64],
@@ -442,6 +444,10 @@ class Engine:
 
     def use_own_stream(self):
         _check(lib.mk_engine_use_own_stream(self.h), self.h)
+
+    def share_scan_queue(self, owner):
+        """mk_engine_share_scan_queue: this engine's scans go to OWNER's scan queue (both with the same MK_OPT_SPLIT_CUS setting)"""
+        _check(lib.mk_engine_share_scan_queue(self.h, owner.h), self.h)
 
     def begin(self, mode=MK_MODE_KOC):
         _check(lib.mk_sketch_begin(self.h, mode), self.h)

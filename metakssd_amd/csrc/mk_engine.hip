@@ -33,6 +33,13 @@ struct mk_engine {
   mk_keyparams kp{};
   char err[512] = "";
   hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+  /* MK_OPT_SPLIT_CUS: the scan kernel on a queue of its own whose CU mask leaves split_cus compute units free, everything else
+   * (resolve, compaction, clears) on a queue confined to those -- so that what follows one engine's scan runs BESIDE another
+   * engine's scan instead of behind it */
+  hipStream_t scan_stream = nullptr, split_stream = nullptr;
+  hipEvent_t ev_scan_pre = nullptr, ev_scan_post = nullptr;
+  int split_cus = 0, scan_cus = 0;
+  bool scan_shared = false; /* scan_stream is another engine's (mk_engine_share_scan_queue): not destroyed here */
 
   int32_t *d_shuf = nullptr;
   uint32_t *d_accept = nullptr;
@@ -295,6 +302,10 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   hipFree(e->d_res_ids); hipFree(e->d_res_cnt); hipFree(e->d_snap);
   if (e->h_snap) hipHostFree(e->h_snap);
   if (e->res_stream) hipStreamDestroy(e->res_stream);
+  if (e->scan_stream && !e->scan_shared) hipStreamDestroy(e->scan_stream);
+  if (e->split_stream) hipStreamDestroy(e->split_stream);
+  if (e->ev_scan_pre) hipEventDestroy(e->ev_scan_pre);
+  if (e->ev_scan_post) hipEventDestroy(e->ev_scan_post);
   if (e->ev_res) hipEventDestroy(e->ev_res);
   hipFree(e->d_text); hipFree(e->d_stream); hipFree(e->d_stream_tmp); hipFree(e->d_fa_sum); hipFree(e->d_fa_state);
   if (e->h_fa_state) hipHostFree(e->h_fa_state);
@@ -610,6 +621,36 @@ extern "C" int mk_engine_create_ex(const mk_params *p, int device, unsigned flag
 
 static int mk_flush_region(mk_engine *e);
 
+/* MK_OPT_SPLIT_CUS.  The bits of a queue's CU mask go round the XCDs (bit i = compute unit i / 8 of XCD i % 8), so the first
+ * num_cu - r bits and the last r are both spread evenly over the eight of them -- and r is a multiple of 32 so that every shader engine
+ * (four an XCD) keeps the same number of units on either side: workgroups are dealt to the shader engines in turn whatever units they
+ * have left, and with 24, 40 or 48 units on the second queue two of the one-a-CU workgroups of a kernel land on one unit and run one
+ * after the other (a pass 3.2 - 4.8 ms instead of 2.33, profiles/r05_split_queues.txt).  The caller has waited for the engine's streams. */
+static int mk_config_split(mk_engine *e, int r) {
+  if (r != 0 && (r < 32 || r > e->num_cu / 2 || r % 32 != 0))
+    return mk_fail(e, MK_ERR_ARG, "MK_OPT_SPLIT_CUS takes 0 (one queue) or a multiple of 32 up to half the device's %d compute units", e->num_cu);
+  if (e->batch_begun != e->batch_ended) return mk_fail(e, MK_ERR_STATE, "MK_OPT_SPLIT_CUS while a batch is in flight");
+  if (e->stream == e->split_stream && e->split_stream) e->stream = e->own_stream;
+  if (e->scan_stream) { (void)hipStreamSynchronize(e->scan_stream); if (!e->scan_shared) (void)hipStreamDestroy(e->scan_stream); e->scan_stream = nullptr; }
+  if (e->split_stream) { (void)hipStreamSynchronize(e->split_stream); (void)hipStreamDestroy(e->split_stream); e->split_stream = nullptr; }
+  e->split_cus = 0; e->scan_cus = 0; e->scan_shared = false;
+  if (e->init_queued) { MK_HIP(e, hipStreamSynchronize(e->own_stream)); e->init_queued = false; } /* (what creation queued is ordered with no other stream) */
+  if (r == 0) return MK_OK;
+  const int n = e->num_cu;
+  uint32_t scan_mask[16] = {0}, rest_mask[16] = {0};
+  if (n > 512) return mk_fail(e, MK_ERR_ARG, "MK_OPT_SPLIT_CUS: %d compute units", n);
+  for (int i = 0; i < n; i++) (i < n - r ? scan_mask : rest_mask)[i >> 5] |= 1u << (i & 31);
+  MK_HIP(e, hipExtStreamCreateWithCUMask(&e->scan_stream, (uint32_t)((n + 31) / 32), scan_mask));
+  MK_HIP(e, hipExtStreamCreateWithCUMask(&e->split_stream, (uint32_t)((n + 31) / 32), rest_mask));
+  if (!e->ev_scan_pre) {
+    MK_HIP(e, hipEventCreateWithFlags(&e->ev_scan_pre, hipEventDisableTiming));
+    MK_HIP(e, hipEventCreateWithFlags(&e->ev_scan_post, hipEventDisableTiming));
+  }
+  e->split_cus = r; e->scan_cus = n - r;
+  if (e->stream == e->own_stream) e->stream = e->split_stream; /* (a caller's stream stays: only the scan moves to its queue) */
+  return MK_OK;
+}
+
 extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
   if (!e) return MK_ERR_ARG;
   if (e->begun) return mk_fail(e, MK_ERR_STATE, "mk_engine_set_option inside a sketch (between begin and finish)");
@@ -638,6 +679,7 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
     case MK_OPT_DIRECT_HOST:
       e->direct_host = value != 0;
       return MK_OK;
+    case MK_OPT_SPLIT_CUS: return mk_config_split(e, (int)value);
     case MK_OPT_BATCH_TAB_BITS:
       if (value != 0 && (value < 9 || value > 22)) return mk_fail(e, MK_ERR_ARG, "MK_OPT_BATCH_TAB_BITS takes 0 (by file size) or 9..22");
       if (e->batch_begun != e->batch_ended) return mk_fail(e, MK_ERR_STATE, "MK_OPT_BATCH_TAB_BITS while a batch is in flight");
@@ -681,6 +723,21 @@ extern "C" int mk_engine_set_stream(mk_engine *e, void *hip_stream) {
   e->stream = (hipStream_t)hip_stream;
   return MK_OK;
 }
+/* Two engines with the same MK_OPT_SPLIT_CUS setting: e's scans go to WITH's scan queue from now on, one after the other in the order
+ * they are pushed (two queues with the same CU mask would have both scans' workgroups compete for the units, and every kernel's
+ * duration would include its wait for them).  WITH owns the queue: e is destroyed, or set back to one queue, first. */
+extern "C" int mk_engine_share_scan_queue(mk_engine *e, mk_engine *with) {
+  if (!e || !with || e == with) return MK_ERR_ARG;
+  if (e->begun) return mk_fail(e, MK_ERR_STATE, "mk_engine_share_scan_queue inside a sketch");
+  if (!e->scan_stream || !with->scan_stream || with->scan_shared || e->split_cus != with->split_cus || e->device != with->device)
+    return mk_fail(e, MK_ERR_ARG, "mk_engine_share_scan_queue: both engines need the same MK_OPT_SPLIT_CUS setting on one device, and the owner a queue of its own");
+  MK_HIP(e, hipSetDevice(e->device));
+  MK_HIP(e, hipStreamSynchronize(e->scan_stream));
+  if (!e->scan_shared) MK_HIP(e, hipStreamDestroy(e->scan_stream));
+  e->scan_stream = with->scan_stream;
+  e->scan_shared = true;
+  return MK_OK;
+}
 extern "C" int mk_engine_use_own_stream(mk_engine *e) {
   if (!e) return MK_ERR_ARG;
   if (e->region_open) {
@@ -688,7 +745,7 @@ extern "C" int mk_engine_use_own_stream(mk_engine *e) {
     int rc = mk_flush_region(e);
     if (rc) return rc;
   }
-  e->stream = e->own_stream;
+  e->stream = e->split_stream ? e->split_stream : e->own_stream;
   return MK_OK;
 }
 
@@ -917,7 +974,8 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
 #ifdef MK_TUNING
   if (const char *t = getenv("MK_SCAN_WGS_PER_CU")) { const int v = atoi(t); if (v >= 1 && v * waves <= 16u) wgs_per_cu = (uint64_t)v; } /* (cand_slots = 16 waves a CU) */
 #endif
-  if (blocks > (uint64_t)e->num_cu * wgs_per_cu) blocks = (uint64_t)e->num_cu * wgs_per_cu;
+  const uint64_t scan_cus = e->scan_stream ? (uint64_t)e->scan_cus : (uint64_t)e->num_cu; /* (MK_OPT_SPLIT_CUS: the scan queue's share) */
+  if (blocks > scan_cus * wgs_per_cu) blocks = scan_cus * wgs_per_cu;
   dim3 grid((unsigned)blocks);
 #ifdef MK_TUNING
   if (getenv("MK_DEBUG")) {
@@ -928,8 +986,15 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
 #endif
 
   if (!a.batch) e->big_maybe_dirty = true; /* until a counter copy says otherwise (mk_check_counters) */
+  /* the stream the scan kernel goes to: the engine's, or (MK_OPT_SPLIT_CUS) the scan queue, ordered with the engine's on both sides */
+  hipStream_t ss = e->stream;
+  if (e->scan_stream) {
+    MK_HIP(e, hipEventRecord(e->ev_scan_pre, e->stream));
+    MK_HIP(e, hipStreamWaitEvent(e->scan_stream, e->ev_scan_pre, 0));
+    ss = e->scan_stream;
+  }
   mk_evpair ev{};
-  if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
+  if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, ss)); }
   hipError_t r;
   if (packed) {
     auto launch_packed = [&](auto kern) -> hipError_t {
@@ -942,7 +1007,7 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
         if (rr != hipSuccess) return rr;
         *granted = lds;
       }
-      hipLaunchKernelGGL(kern, grid, dim3(1024), lds, e->stream, a);
+      hipLaunchKernelGGL(kern, grid, dim3(1024), lds, ss, a);
       return hipGetLastError();
     };
     if (wide) switch (tuned_k * 10 + e->P.subk) {
@@ -958,18 +1023,22 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
     }
   } else
   switch (tuned_k * 10 + (tuned_k ? e->P.subk : 0)) {
-    case 116: r = vec ? mk_launch_scan_k<11, 6, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<11, 6, false>(e, threads, false, a, grid, lds, e->stream); break;
-    case 106: r = vec ? mk_launch_scan_k<10, 6, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<10, 6, false>(e, threads, false, a, grid, lds, e->stream); break;
-    case 96: r = vec ? mk_launch_scan_k<9, 6, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<9, 6, false>(e, threads, false, a, grid, lds, e->stream); break;
-    case 115: r = vec ? mk_launch_scan_k<11, 5, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<11, 5, false>(e, threads, false, a, grid, lds, e->stream); break;
-    default: r = vec ? mk_launch_scan_k<0, 0, true>(e, threads, onepass, a, grid, lds, e->stream) : mk_launch_scan_k<0, 0, false>(e, threads, false, a, grid, lds, e->stream); break;
+    case 116: r = vec ? mk_launch_scan_k<11, 6, true>(e, threads, onepass, a, grid, lds, ss) : mk_launch_scan_k<11, 6, false>(e, threads, false, a, grid, lds, ss); break;
+    case 106: r = vec ? mk_launch_scan_k<10, 6, true>(e, threads, onepass, a, grid, lds, ss) : mk_launch_scan_k<10, 6, false>(e, threads, false, a, grid, lds, ss); break;
+    case 96: r = vec ? mk_launch_scan_k<9, 6, true>(e, threads, onepass, a, grid, lds, ss) : mk_launch_scan_k<9, 6, false>(e, threads, false, a, grid, lds, ss); break;
+    case 115: r = vec ? mk_launch_scan_k<11, 5, true>(e, threads, onepass, a, grid, lds, ss) : mk_launch_scan_k<11, 5, false>(e, threads, false, a, grid, lds, ss); break;
+    default: r = vec ? mk_launch_scan_k<0, 0, true>(e, threads, onepass, a, grid, lds, ss) : mk_launch_scan_k<0, 0, false>(e, threads, false, a, grid, lds, ss); break;
   }
   if (r != hipSuccess) return mk_fail(e, MK_ERR_HIP, "scan launch: %s", hipGetErrorString(r));
   if (e->profiling) {
-    MK_HIP(e, hipEventRecord(ev.b, e->stream));
+    MK_HIP(e, hipEventRecord(ev.b, ss));
     e->ev_scan.push_back(ev);
     e->prof_rows += nreads;
     e->prof_bytes += nreads * stride;
+  }
+  if (e->scan_stream) {
+    MK_HIP(e, hipEventRecord(e->ev_scan_post, ss));
+    MK_HIP(e, hipStreamWaitEvent(e->stream, e->ev_scan_post, 0));
   }
   /* resolve the appended candidates: canonical k-mer, exact .shuf check, upsert */
   {
@@ -978,7 +1047,8 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
     if (e->profiling) { ev2 = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev2.a, e->stream)); }
     /* one resolve workgroup per CU (LDS: the exact filter + two rings per wave); a resolve wave owns whole slots */
     const uint32_t rwgs = (used_slots + MK_RESOLVE_THREADS / 64 - 1) / (MK_RESOLVE_THREADS / 64);
-    uint32_t rgrid = rwgs < (uint32_t)e->num_cu ? rwgs : (uint32_t)e->num_cu;
+    const uint32_t rcus = e->scan_stream && e->stream == e->split_stream ? (uint32_t)e->split_cus : (uint32_t)e->num_cu; /* one workgroup a CU of ITS queue */
+    uint32_t rgrid = rwgs < rcus ? rwgs : rcus;
 #ifdef MK_TUNING
     if (const char *t = getenv("MK_RESOLVE_GRID")) { const uint32_t g = (uint32_t)atoi(t); if (g && g <= used_slots) rgrid = g; }
 #endif
@@ -1717,6 +1787,8 @@ static int mk_finish_keylist(mk_engine *e, mk_result *out, mk_evpair ev) {
  * sketch on this engine) costs a second round: grow, write again. */
 static int mk_res_reserve(mk_engine *e, uint64_t want) {
   if (!e->res_stream) {
+    /* (not confined by MK_OPT_SPLIT_CUS: layout and dump on the second queue's few compute units make THEM the bottleneck --
+     * 2.80 ms a pass against 2.35, profiles/r05_split_queues.txt; beside the scan they cost it 0.1 ms as they do with one queue) */
     MK_HIP(e, hipStreamCreateWithFlags(&e->res_stream, hipStreamNonBlocking));
     MK_HIP(e, hipEventCreateWithFlags(&e->ev_res, hipEventDisableTiming));
     MK_HIP(e, hipMalloc(&e->d_snap, 8 * sizeof(unsigned long long)));

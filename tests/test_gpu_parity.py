@@ -650,6 +650,82 @@ def test_finish_in_two_halves_pipelined(capi, shufs, oracle_for, name, sparse):
         eng.close()
 
 
+@pytest.mark.parametrize("name,cus,own_queues", [("L3K11", 32, False), ("L1K7", 32, True), ("L2K11", 64, False), ("L3K11", 128, False)])
+def test_split_queues_two_engines_in_turn(capi, shufs, oracle_for, name, cus, own_queues):
+    """MK_OPT_SPLIT_CUS: the scan kernel on a queue of its own, what follows it on the remaining compute units; two engines take
+    sketches in turn in bench.py's call order (the next scan is queued before the wait inside the last sketch's finish_begin).  Every
+    sketch equals the oracle's: several pushes a sketch, host rows and device rows, an empty sketch; bad values are refused and
+    going back to one queue works"""
+    hip = C.CDLL("libamdhip64.so")
+    rs = np.random.RandomState(43)
+    engs = [capi.Engine(shufs(name), 0), capi.Engine(shufs(name), 0)]
+    dev_rows = []
+    ora = oracle_for(shufs(name))
+    try:
+        for bad in (3, 8, 24, 48, 160, -32):
+            with pytest.raises(capi.MkError):
+                engs[0].set_option(capi.MK_OPT_SPLIT_CUS, bad)
+        with pytest.raises(capi.MkError):  # no queue to share yet
+            engs[1].share_scan_queue(engs[0])
+        for e in engs:
+            e.set_option(capi.MK_OPT_SPLIT_CUS, cus)
+        if not own_queues:  # one case keeps a scan queue per engine
+            engs[1].share_scan_queue(engs[0])
+            with pytest.raises(capi.MkError):  # a borrowed queue is not lent on
+                engs[0].share_scan_queue(engs[1])
+        sizes = [3000, 20000, 0, 500, 64000, 7, 12000]
+        batches, wants = [], []
+        for n in sizes:
+            rows = ui.rows_from_seqs(ui.pool_reads(rs, 4000, n), 160) if n else np.zeros(0, np.uint8)
+            rc, want = ora.koc_from_rows(rows, 160)
+            assert rc == 0
+            batches.append(rows)
+            wants.append(want)
+        for b in batches:
+            p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(p), C.c_size_t(max(b.size, 16))) == 0
+            if b.size:
+                assert hip.hipMemcpy(p, C.c_void_p(b.ctypes.data), C.c_size_t(b.size), 1) == 0
+            dev_rows.append(p)
+        assert hip.hipDeviceSynchronize() == 0
+        pend = [None, None]
+
+        def take(j):
+            if pend[j] is not None:
+                assert_same(engs[j].finish_end(), wants[pend[j]], "%s split %d sketch %d" % (name, cus, pend[j]))
+                pend[j] = None
+
+        k = len(batches)
+        for i in range(k + 1):
+            if i < k:
+                e, rows, n = engs[i & 1], batches[i], sizes[i]
+                e.begin(capi.MK_MODE_KOC)
+                if i % 3 == 0 and n:  # device-resident rows, two pushes
+                    h = n // 2
+                    e.push_reads_device(dev_rows[i].value, 160, h, 0)
+                    e.push_reads_device(dev_rows[i].value + h * 160, 160, n - h, h)
+                elif n:
+                    e.push_reads(rows, 160, 0)
+            if i > 0:
+                j = (i - 1) & 1
+                take(j)
+                engs[j].finish_begin()
+                pend[j] = i - 1
+        take(0)
+        take(1)
+        # back to one queue (the borrower first); the plain finish
+        engs[1].set_option(capi.MK_OPT_SPLIT_CUS, 0)
+        engs[0].set_option(capi.MK_OPT_SPLIT_CUS, 0)
+        engs[1].set_option(capi.MK_OPT_SPLIT_CUS, cus)
+        assert_same(run_koc(capi, engs[0], batches[1], 160, pushes=3), wants[1], "%s one queue again" % name)
+        assert_same(run_koc(capi, engs[1], batches[4], 160), wants[4], "%s split, plain finish" % name)
+    finally:
+        for e in reversed(engs):
+            e.close()
+        for p in dev_rows:
+            hip.hipFree(p)
+
+
 @pytest.mark.parametrize("front", [None, 0, 5])
 def test_sparse_key_list_grows_on_demand(capi, shufs, oracle_for, front):
     """engines with sparse bookkeeping start with a short distinct-key list (32 M entries instead of hashsize: 10.7 GB at L2K11);

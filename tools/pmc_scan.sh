@@ -9,7 +9,7 @@ i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
   rm -rf gpurun_out/pmc_$i   # (a directory left by an earlier call would hand its counters to this one)
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d gpurun_out/pmc_$i -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-host-legs $MK_BENCH_FLAGS > gpurun_out/pmc_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d gpurun_out/pmc_$i -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-host-legs --no-one-queue $MK_BENCH_FLAGS > gpurun_out/pmc_$i.log 2>&1
   f=$(find gpurun_out/pmc_$i -name "*counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections

@@ -10,7 +10,7 @@ if [ -n "$MK_LIBRARY" ] && [ -z "$MK_TRAFFIC_VARIANT" ]; then echo "tools/pmc_tr
 # mk_scan_kernel; e.g. mk_scan_packed_kernel); both only together with MK_TRAFFIC_VARIANT=<tag>, which names the output file
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/traffic_$C
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/traffic_$C -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-host-legs $MK_BENCH_FLAGS > gpurun_out/traffic_$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/traffic_$C -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-host-legs --no-one-queue $MK_BENCH_FLAGS > gpurun_out/traffic_$C.log 2>&1
 done
 python3 - <<'PY'
 import collections, csv, glob, json, os, sys

@@ -10,7 +10,7 @@ O=gpurun_out/round; mkdir -p $O
 for mode in "" "--serial-finish"; do
   tag=kernel_stats${mode:+_serial_finish}
   rm -rf gpurun_out/prof_$tag
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 30 --warmup 3 --no-host-legs --no-cpu-baseline $mode > $O/bench_${tag#kernel_stats}under_rocprof.json 2> $O/$tag.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 30 --warmup 3 --no-host-legs --no-cpu-baseline --no-one-queue $mode > $O/bench_${tag#kernel_stats}under_rocprof.json 2> $O/$tag.err
   f=$(ls -t $(find gpurun_out/prof_$tag -name "*kernel_stats.csv") | head -1)
   cp "$f" $O/$tag.csv; echo "== $tag"; head -8 $O/$tag.csv | cut -c1-160
 done
