@@ -181,7 +181,8 @@ int mk_engine_set_stream(mk_engine *e, void *hip_stream);
 int mk_engine_use_own_stream(mk_engine *e);
 /* MK_OPT_SPLIT_CUS on two engines of one device: e's scan kernels go to WITH's scan queue, one after the other in the order they are
  * pushed, instead of to a second queue with the same CU mask (where the workgroups of both scans compete for the units and a kernel's
- * duration includes its wait for them).  WITH owns the queue: destroy e, or set it back to one queue, before WITH. */
+ * duration includes its wait for them).  WITH owns the queue and keeps it while it is lent: setting WITH back to one queue or destroying
+ * it fails with MK_ERR_STATE until e has been destroyed or set back to one queue. */
 int mk_engine_share_scan_queue(mk_engine *e, mk_engine *with);
 const char *mk_last_error(const mk_engine *e); /* e may be NULL: last error of a failed create */
 

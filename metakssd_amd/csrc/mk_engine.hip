@@ -40,6 +40,8 @@ struct mk_engine {
   hipEvent_t ev_scan_pre = nullptr, ev_scan_post = nullptr;
   int split_cus = 0, scan_cus = 0;
   bool scan_shared = false; /* scan_stream is another engine's (mk_engine_share_scan_queue): not destroyed here */
+  mk_engine *scan_owner = nullptr; /* ... that engine */
+  int scan_lent = 0;               /* engines that borrow THIS engine's scan queue: it stays while they do */
 
   int32_t *d_shuf = nullptr;
   uint32_t *d_accept = nullptr;
@@ -289,6 +291,8 @@ static void mk_bctx_free(struct mk_bctx *c);
 
 extern "C" int mk_engine_destroy(mk_engine *e) {
   if (!e) return MK_ERR_ARG;
+  if (e->scan_lent > 0) return mk_fail(e, MK_ERR_STATE, "mk_engine_destroy: %d engine(s) still borrow this engine's scan queue (mk_engine_share_scan_queue): destroy them first", e->scan_lent);
+  if (e->scan_owner) { e->scan_owner->scan_lent--; e->scan_owner = nullptr; }
   hipSetDevice(e->device);
   hipDeviceSynchronize();
   hipFree(e->d_pairs);
@@ -630,6 +634,8 @@ static int mk_config_split(mk_engine *e, int r) {
   if (r != 0 && (r < 32 || r > e->num_cu / 2 || r % 32 != 0))
     return mk_fail(e, MK_ERR_ARG, "MK_OPT_SPLIT_CUS takes 0 (one queue) or a multiple of 32 up to half the device's %d compute units", e->num_cu);
   if (e->batch_begun != e->batch_ended) return mk_fail(e, MK_ERR_STATE, "MK_OPT_SPLIT_CUS while a batch is in flight");
+  if (e->scan_lent > 0) return mk_fail(e, MK_ERR_STATE, "MK_OPT_SPLIT_CUS: %d engine(s) borrow this engine's scan queue (set them back to one queue first)", e->scan_lent);
+  if (e->scan_owner) { e->scan_owner->scan_lent--; e->scan_owner = nullptr; }
   if (e->stream == e->split_stream && e->split_stream) e->stream = e->own_stream;
   if (e->scan_stream) { (void)hipStreamSynchronize(e->scan_stream); if (!e->scan_shared) (void)hipStreamDestroy(e->scan_stream); e->scan_stream = nullptr; }
   if (e->split_stream) { (void)hipStreamSynchronize(e->split_stream); (void)hipStreamDestroy(e->split_stream); e->split_stream = nullptr; }
@@ -725,7 +731,8 @@ extern "C" int mk_engine_set_stream(mk_engine *e, void *hip_stream) {
 }
 /* Two engines with the same MK_OPT_SPLIT_CUS setting: e's scans go to WITH's scan queue from now on, one after the other in the order
  * they are pushed (two queues with the same CU mask would have both scans' workgroups compete for the units, and every kernel's
- * duration would include its wait for them).  WITH owns the queue: e is destroyed, or set back to one queue, first. */
+ * duration would include its wait for them).  WITH owns the queue and keeps it while it is lent (scan_lent): its own
+ * MK_OPT_SPLIT_CUS and mk_engine_destroy fail until e has gone back to one queue or been destroyed. */
 extern "C" int mk_engine_share_scan_queue(mk_engine *e, mk_engine *with) {
   if (!e || !with || e == with) return MK_ERR_ARG;
   if (e->begun) return mk_fail(e, MK_ERR_STATE, "mk_engine_share_scan_queue inside a sketch");
@@ -733,9 +740,13 @@ extern "C" int mk_engine_share_scan_queue(mk_engine *e, mk_engine *with) {
     return mk_fail(e, MK_ERR_ARG, "mk_engine_share_scan_queue: both engines need the same MK_OPT_SPLIT_CUS setting on one device, and the owner a queue of its own");
   MK_HIP(e, hipSetDevice(e->device));
   MK_HIP(e, hipStreamSynchronize(e->scan_stream));
+  if (e->scan_lent > 0) return mk_fail(e, MK_ERR_STATE, "mk_engine_share_scan_queue: this engine's own queue is lent to another engine");
   if (!e->scan_shared) MK_HIP(e, hipStreamDestroy(e->scan_stream));
+  if (e->scan_owner) e->scan_owner->scan_lent--;
   e->scan_stream = with->scan_stream;
   e->scan_shared = true;
+  e->scan_owner = with;
+  with->scan_lent++;
   return MK_OK;
 }
 extern "C" int mk_engine_use_own_stream(mk_engine *e) {

@@ -673,6 +673,9 @@ def test_split_queues_two_engines_in_turn(capi, shufs, oracle_for, name, cus, ow
             engs[1].share_scan_queue(engs[0])
             with pytest.raises(capi.MkError):  # a borrowed queue is not lent on
                 engs[0].share_scan_queue(engs[1])
+            with pytest.raises(capi.MkError):  # the owner keeps its queue while it is lent
+                engs[0].set_option(capi.MK_OPT_SPLIT_CUS, 0)
+            assert capi.lib.mk_engine_destroy(engs[0].h) == capi.MK_ERR_STATE
         sizes = [3000, 20000, 0, 500, 64000, 7, 12000]
         batches, wants = [], []
         for n in sizes:
