@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--big-rate", type=float, default=0.08, help="share of the cases that draw it (with --big)")
     ap.add_argument("--sparse", type=int, default=-1, help="MK_OPT_SPARSE: -1 by table size, 0 off, 1 on")
     ap.add_argument("--front-bits", type=int, default=None, help="MK_OPT_FRONT_BITS: front table of 2^n slots (with --sparse 0)")
+    ap.add_argument("--split-cus", type=int, default=0, help="MK_OPT_SPLIT_CUS on every engine (32, 64, ..): the scan kernel on a queue of its own")
     a = ap.parse_args()
     from metakssd_amd import capi
     from oracle_binding import Oracle
@@ -83,6 +84,8 @@ def main():
         if key not in shufs:
             shufs[key] = capi.Shuf.generate(k, subk, drl, 1000 + k * 100 + subk * 10 + drl)
             engines[key] = capi.Engine(shufs[key], 0, sparse=a.sparse, front_bits=a.front_bits)
+            if a.split_cus:
+                engines[key].set_option(capi.MK_OPT_SPLIT_CUS, a.split_cus)
             oracles[key] = Oracle(shufs[key].c.id, k, subk, drl, shufs[key].table)
         eng, ora, P = engines[key], oracles[key], shufs[key].params()
         dense = P.dim_end - P.dim_start >= 16 ** subk  # accept-everything tables crowd quickly
