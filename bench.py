@@ -841,14 +841,29 @@ def main():
     # ordered so that the next scan is queued before the wait inside mk_sketch_finish_begin.
     split = args.split_cus if world == 1 and not args.serial_finish else 0
     eng_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    split_note = None
     if split:
-        eng2 = capi.Engine(shuf, local_rank, front_bits=args.front_bits, cand_cap=args.cand_cap)
+        # a device this option does not fit (fewer than 64 compute units, a runtime without CU masks): the one-queue flow, said so in the line
+        eng2 = None
+        try:
+            eng2 = capi.Engine(shuf, local_rank, front_bits=args.front_bits, cand_cap=args.cand_cap)
+            for e in (eng, eng2):
+                e.use_own_stream()
+                e.set_option(capi.MK_OPT_SPLIT_CUS, split)
+            if not args.split_two_scan_queues:
+                eng2.share_scan_queue(eng)  # one scan queue: the scans run one after the other and a kernel's duration is its run time
+        except capi.MkError as ex:
+            split_note = "split queues not available here (%s): one engine, one queue" % str(ex)[:160]
+            if eng2 is not None:
+                eng2.close()
+            try:
+                eng.set_option(capi.MK_OPT_SPLIT_CUS, 0)
+            except capi.MkError:
+                pass
+            eng.set_stream(stream)
+            split = 0
+    if split:
         engs = (eng, eng2)
-        for e in engs:
-            e.use_own_stream()
-            e.set_option(capi.MK_OPT_SPLIT_CUS, split)
-        if not args.split_two_scan_queues:
-            eng2.share_scan_queue(eng)  # one scan queue: the scans run one after the other and a kernel's duration is its run time
         pend = [False, False]
 
         def drain2(j):
@@ -1063,7 +1078,7 @@ def main():
                        "finish": "serial (--serial-finish: profiling aid)" if args.serial_finish else "result copy beside the next pass",
                        "queues": ("two engines take the passes in turn; scan kernel on %d compute units, candidate resolution + compaction + "
                                   "clear of the pass before on the other %d beside it (MK_OPT_SPLIT_CUS)" % (eng_cus - split, split)) if split
-                                 else "one engine, one queue: every kernel on the whole device, one after the other",
+                                 else (split_note or "one engine, one queue: every kernel on the whole device, one after the other"),
                        "parallelism": "reads sharded x%d, gather to rank 0" % world},
             "roofline": {"bound": "hbm", "kernel": "mk_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
