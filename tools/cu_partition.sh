@@ -1,7 +1,8 @@
 #!/bin/bash
 # What the scan and the resolve kernel take on a PART of the chip (would the resolve of one pass fit beside the scan of the next
 # on compute units of its own?).  Needs the experiment build: make -C metakssd_amd/csrc tuning TUNING_OUT=../lib_tuning/base
-# The engine's queue gets a CU mask (MK_TUNE_CUS units from mask bit MK_TUNE_CU_FIRST on) and sizes every grid for it.
+# The engine sizes every grid for MK_TUNE_CUS units (and its own queue gets a CU mask from bit MK_TUNE_CU_FIRST on -- bench.py runs the engine on
+# torch's stream, so here it is the grids that confine the kernels; the other units are idle).
 cd $GRAFT_REPO_ROOT
 export MK_LIBRARY=metakssd_amd/lib_tuning/base/libmetakssd_hip.so
 out=gpurun_out/cu_partition.txt; : > $out
