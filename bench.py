@@ -1092,6 +1092,10 @@ def main():
                                    # layout + dump + copy of pass i on the side stream, beside clear + scan of pass i + 1
                                    "finish_side_stream": prof.get("finish_side_ms", 0.0) / args.steps},
         }
+        if split:
+            line["roofline"]["note"] = ("the timed flow runs this kernel on %d of the device's %d compute units (config.queues: the other %d resolve the "
+                                        "pass before beside it), which is what this entry measures" % (eng_cus - split, eng_cus, split)) + (
+                                            "; the same kernel on all %d in the same run: one_queue.scan_roofline" % eng_cus if one_queue is not None else "")
         if one_queue is not None:
             sb = scan_bytes / (one_queue["scan_ms"] * 1e-3) / 1e9 if one_queue["scan_ms"] > 0 else 0.0
             one_queue["scan_roofline"] = {"achieved": sb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sb / HBM_PEAK_GBS, "compute_units": eng_cus}
