@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=${1:-24}
 rm -rf gpurun_out/split_trace
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/split_trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-legs --no-traffic --split-cus $R > gpurun_out/split_trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/split_trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-legs --no-traffic --no-one-queue --split-cus $R > gpurun_out/split_trace.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/split_trace/**/*kernel_trace.csv", recursive=True)[0]
