@@ -631,7 +631,13 @@ static int mk_flush_region(mk_engine *e);
  * have left, and with 24, 40 or 48 units on the second queue two of the one-a-CU workgroups of a kernel land on one unit and run one
  * after the other (a pass 3.2 - 4.8 ms instead of 2.33, profiles/r05_split_queues.txt).  The caller has waited for the engine's streams. */
 static int mk_config_split(mk_engine *e, int r) {
-  if (r != 0 && (r < 32 || r > e->num_cu / 2 || r % 32 != 0))
+  bool nomask = false;
+#ifdef MK_TUNING
+  /* experiment builds: the same two queues WITHOUT CU masks -- the grids alone (num_cu - r scan workgroups, r resolve workgroups, one a CU by
+   * their LDS) divide the device, the dispatcher places them where there is room; any multiple of 8 */
+  nomask = getenv("MK_TUNE_SPLIT_NOMASK") != nullptr;
+#endif
+  if (r != 0 && !nomask && (r < 32 || r > e->num_cu / 2 || r % 32 != 0))
     return mk_fail(e, MK_ERR_ARG, "MK_OPT_SPLIT_CUS takes 0 (one queue) or a multiple of 32 up to half the device's %d compute units", e->num_cu);
   if (e->batch_begun != e->batch_ended) return mk_fail(e, MK_ERR_STATE, "MK_OPT_SPLIT_CUS while a batch is in flight");
   if (e->scan_lent > 0) return mk_fail(e, MK_ERR_STATE, "MK_OPT_SPLIT_CUS: %d engine(s) borrow this engine's scan queue (set them back to one queue first)", e->scan_lent);
@@ -646,8 +652,13 @@ static int mk_config_split(mk_engine *e, int r) {
   uint32_t scan_mask[16] = {0}, rest_mask[16] = {0};
   if (n > 512) return mk_fail(e, MK_ERR_ARG, "MK_OPT_SPLIT_CUS: %d compute units", n);
   for (int i = 0; i < n; i++) (i < n - r ? scan_mask : rest_mask)[i >> 5] |= 1u << (i & 31);
-  MK_HIP(e, hipExtStreamCreateWithCUMask(&e->scan_stream, (uint32_t)((n + 31) / 32), scan_mask));
-  MK_HIP(e, hipExtStreamCreateWithCUMask(&e->split_stream, (uint32_t)((n + 31) / 32), rest_mask));
+  if (nomask) {
+    MK_HIP(e, hipStreamCreateWithFlags(&e->scan_stream, hipStreamNonBlocking));
+    MK_HIP(e, hipStreamCreateWithFlags(&e->split_stream, hipStreamNonBlocking));
+  } else {
+    MK_HIP(e, hipExtStreamCreateWithCUMask(&e->scan_stream, (uint32_t)((n + 31) / 32), scan_mask));
+    MK_HIP(e, hipExtStreamCreateWithCUMask(&e->split_stream, (uint32_t)((n + 31) / 32), rest_mask));
+  }
   if (!e->ev_scan_pre) {
     MK_HIP(e, hipEventCreateWithFlags(&e->ev_scan_pre, hipEventDisableTiming));
     MK_HIP(e, hipEventCreateWithFlags(&e->ev_scan_post, hipEventDisableTiming));
