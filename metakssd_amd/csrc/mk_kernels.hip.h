@@ -742,14 +742,26 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   auto loff_of = [&](int i) { if constexpr (VEC16) return offtab[128 * i + 64]; else return loff_calc(i); };
   auto issue_loads = [&](uint32_t tile_id, uint32_t cb) {
     const uint32_t row0 = tile_id << 6;
+#if defined(MK_TUNING) && defined(MK_ABL_MEM) /* experiment: every wave stages ITS FIRST tile again and again (cache-resident): the kernel without its HBM stream, results wrong */
+    const uint8_t *base = a.rows + (uint64_t)((wave_global < ntiles ? wave_global : 0u) << 6) * a.pitch + (uint64_t)cb * a.CB;
+#else
     const uint8_t *base = a.rows + (uint64_t)row0 * a.pitch + (uint64_t)cb * a.CB;
+#endif
     const uint32_t cols_here = min(a.CB, a.stride - cb * a.CB);
     if constexpr (ONEPASS) {
       /* host guarantees: ncb == 2, stride == 2*CB.  cb is 0 here. */
       if (row0 + 64u <= nreads) {
 #pragma unroll
         for (int i = 0; i < NP; i++)
+#if defined(MK_TUNING) && defined(MK_SCAN_NT) /* experiment: the rows are read once -- non-temporal loads */
+          if ((uint32_t)i < a.ppr) {
+            typedef uint32_t mk_u32x4 __attribute__((ext_vector_type(4)));
+            const mk_u32x4 v1 = __builtin_nontemporal_load((const mk_u32x4 *)(base + goff_of(i))), v2 = __builtin_nontemporal_load((const mk_u32x4 *)(base + a.CB + goff_of(i)));
+            if constexpr (VEC16) { regs[i] = make_uint4(v1.x, v1.y, v1.z, v1.w); regs2[i] = make_uint4(v2.x, v2.y, v2.z, v2.w); }
+          }
+#else
           if ((uint32_t)i < a.ppr) { regs[i] = *(const piece_t *)(base + goff_of(i)); regs2[i] = *(const piece_t *)(base + a.CB + goff_of(i)); }
+#endif
       } else {
         const uint32_t rows_here = (uint32_t)(nreads - row0);
 #pragma unroll
