@@ -1148,6 +1148,8 @@ def main():
             del reads
             eng.close()  # the command line brings its own engine: give the memory back first
             torch.cuda.empty_cache()
+            if hasattr(torch._C, "_host_emptyCache"):  # ... and the 11 GB of pinned host memory torch keeps cached from the t_stream leg
+                torch._C._host_emptyCache()
             try:
                 line["t_e2e"] = leg_e2e(capi, shuf, n, sketch)
             except Exception as ex:
