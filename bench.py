@@ -261,7 +261,7 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=5):
                 "sketch_equals_resident_run": same, "fastq_write_s": t_write,
                 "what": "`metakssd dist -L L3K11.shuf -A -o out --quiet --timing reads.fq`, %d reads = %.2f GB of FASTQ in /dev/shm, "
                         "run %d times after a warm-up run, the device's free memory back at its level and two seconds in between; every figure is the MEDIAN "
-                        "over those runs, `all_runs` has each.  seconds = process start "
+                        "over those runs, `all_runs` has each (fastest first).  seconds = process start "
                         "until the sketch directory is complete on disk (HIP runtime start-up, engine creation, reading (pread) + framing the "
                         "file on %s host threads into packed rows, H2D, scan, finish, file output); gbases_s = bases / seconds.  wall_s = the "
                         "parent's clock around the whole process (spawn and the runtime's teardown at exit on top); gbases_s_wall = "
