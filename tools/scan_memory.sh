@@ -4,7 +4,7 @@
 #   ablmem  every wave stages its FIRST tile again and again (cache-resident; results wrong): the kernel without its HBM stream
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for round in 1 2 3; do
-  for v in base nt ablmem; do
+  for v in ${VARIANTS:-base nt ablmem}; do
     MK_LIBRARY=$PWD/metakssd_amd/lib_tuning/$v/libmetakssd_hip.so python3 bench.py --steps 100 --split-cus 0 --no-host-legs --no-cpu-baseline --no-traffic 2>/dev/null |
       python3 -c "
 import json,sys
