@@ -790,25 +790,6 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
       }
     }
   };
-#if defined(MK_TUNING) && defined(MK_SCAN_SPLIT_ISSUE)
-  /* experiment (one-pass kernels): the two column blocks of the NEXT tile are requested at different times -- block 0 as soon as this tile's
-   * block 0 has left its registers, block 1 behind this tile's block 1 -- a whole tile of lead for either instead of half a tile for block 0 */
-  auto issue_half = [&](uint32_t tile_id, uint32_t half) {
-    const uint32_t row0 = tile_id << 6;
-    const uint8_t *base = a.rows + (uint64_t)row0 * a.pitch + (half ? a.CB : 0u);
-    const uint32_t rows_here = row0 + 64u <= nreads ? 64u : (uint32_t)(nreads - row0);
-#pragma unroll
-    for (int i = 0; i < NP; i++) {
-      if ((uint32_t)i < a.ppr) {
-        const uint32_t q = lane + 64u * i;
-        const uint32_t r = (q * a.ppr_inv) >> 20;
-        if (rows_here == 64u || r < rows_here) {
-          if constexpr (ONEPASS) { if (half) regs2[i] = *(const piece_t *)(base + goff_of(i)); else regs[i] = *(const piece_t *)(base + goff_of(i)); }
-        }
-      }
-    }
-  };
-#endif
   auto commit = [&](uint32_t cb) {
     (void)cb;
 #pragma unroll
@@ -984,12 +965,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
       }
       if constexpr (ONEPASS) {
         /* both halves of this tile are in registers; the next tile's loads go out once the second half is in LDS */
-#if defined(MK_TUNING) && defined(MK_SCAN_SPLIT_ISSUE)
-        if (cb == 0u) { if (nt_tile + nwaves < ntiles) issue_half(nt_tile + nwaves, 0u); }
-        else { nt_tile += nwaves; if (nt_tile < ntiles) issue_half(nt_tile, 1u); }
-#else
         if (cb == 1u) { nt_tile += nwaves; if (nt_tile < ntiles) issue_loads(nt_tile, 0u); }
-#endif
       } else {
         if (++nt_cb == a.ncb) { nt_cb = 0; nt_tile += nwaves; }
         if (nt_tile < ntiles) issue_loads(nt_tile, nt_cb);
