@@ -942,17 +942,10 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     resolve4(q, pos0);
   };
 
-#if defined(MK_TUNING) && defined(MK_SCAN_CONTIG) /* experiment: a wave takes CONSECUTIVE tiles (one stream per wave) instead of every nwaves-th */
-  const uint32_t tpw = (ntiles + nwaves - 1u) / nwaves;
-  const uint32_t tfirst = wave_global * tpw, tstep = 1u, tend = min(ntiles, tfirst + tpw);
-  if (tfirst >= tend) { if (lane == 0) a.cand_count[wave_global] = 0u; return; }
-#else
-  const uint32_t tfirst = wave_global, tstep = nwaves, tend = ntiles;
-#endif
-  uint32_t nt_tile = tfirst; /* next step to load */
+  uint32_t nt_tile = wave_global; /* next step to load */
   uint32_t nt_cb = 0;
   issue_loads(nt_tile, nt_cb);
-  for (uint32_t tile_id = tfirst; tile_id < tend; tile_id += tstep) {
+  for (uint32_t tile_id = wave_global; tile_id < ntiles; tile_id += nwaves) {
     const uint32_t row0 = tile_id << 6;
     km.reset(); run = 0; hh = 0;
     done = row0 + lane >= nreads;
@@ -972,10 +965,10 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
       }
       if constexpr (ONEPASS) {
         /* both halves of this tile are in registers; the next tile's loads go out once the second half is in LDS */
-        if (cb == 1u) { nt_tile += tstep; if (nt_tile < tend) issue_loads(nt_tile, 0u); }
+        if (cb == 1u) { nt_tile += nwaves; if (nt_tile < ntiles) issue_loads(nt_tile, 0u); }
       } else {
-        if (++nt_cb == a.ncb) { nt_cb = 0; nt_tile += tstep; }
-        if (nt_tile < tend) issue_loads(nt_tile, nt_cb);
+        if (++nt_cb == a.ncb) { nt_cb = 0; nt_tile += nwaves; }
+        if (nt_tile < ntiles) issue_loads(nt_tile, nt_cb);
       }
       if (__all(done)) continue;
 
