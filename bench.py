@@ -178,12 +178,16 @@ def leg_packed(torch, capi, eng, pinned_text_rows, n, distinct_text, reps=3):
 
 
 _FREE_BASELINE = {}
+_GPU_TOUCHED = [False]  # set when main() makes its first HIP call
 
 
 def wait_device_quiet(tag="gpu", least=2.0, most=8.0):
     """between two runs of the command line: the driver takes a process's device memory back for a while AFTER the process has gone
     (21 GB at L2K11), and the next process's start-up waits for that.  Instead of sleeping a fixed time: poll the device's free
     memory (this process keeps its HIP context; it holds nothing large by now) until it is back at what it was before the first run."""
+    if not _GPU_TOUCHED[0]:  # the command-line legs run BEFORE this process has a HIP context (see main): nothing to poll with, a pause
+        time.sleep(2.5)
+        return
     try:
         import torch
         time.sleep(least)
@@ -247,7 +251,8 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=5):
         t_written, t_wall, t_work = med([written(t) for _, t, _ in runs]), med([w for w, _, _ in runs]), med([work(t) for _, t, _ in runs])
         ids = np.fromfile(os.path.join(out, "combco.0"), dtype=np.uint32)
         cnt = np.fromfile(os.path.join(out, "combco.0.a"), dtype=np.uint16)
-        same = bool(np.array_equal(ids, resident_sketch[0][0]) and np.array_equal(cnt, resident_sketch[0][1]))
+        # (resident_sketch None: the leg ran before the resident passes -- the caller compares `_sketch` with their result later)
+        same = None if resident_sketch is None else bool(np.array_equal(ids, resident_sketch[0][0]) and np.array_equal(cnt, resident_sketch[0][1]))
         keys = ("hip_ready", "engine_ready", "first_push", "last_push", "unmapped", "written", "finish_s", "threads", "chunks",
                 "chunks_discarded", "serial_rows", "stream_setup_s", "stream_wait_frame_s", "push_call_s", "wait_call_s")
         return {"gbases_s": bases / max(t_written, 1e-9) / 1e9, "seconds": t_written,
@@ -258,7 +263,7 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=5):
                 "all_runs": [{"wall_s": round(w, 4), "written_s": t.get("written"), "init_s": t.get("hip_ready"),
                               "gbases_s": round(bases / max(written(t), 1e-9) / 1e9, 2),
                               "gbases_s_excl_init": round(bases / max(work(t), 1e-9) / 1e9, 2)} for w, t, _ in runs],
-                "sketch_equals_resident_run": same, "fastq_write_s": t_write,
+                "sketch_equals_resident_run": same, "_sketch": (ids, cnt), "fastq_write_s": t_write,
                 "what": "`metakssd dist -L L3K11.shuf -A -o out --quiet --timing reads.fq`, %d reads = %.2f GB of FASTQ in /dev/shm, "
                         "run %d times after a warm-up run, the device's free memory back at its level and two seconds in between; every figure is the MEDIAN "
                         "over those runs, `all_runs` has each (fastest first).  seconds = process start "
@@ -667,6 +672,22 @@ def main():
                          (args.gpus, world, args.gpus))
     if args.same_device:
         local_rank = 0
+    # The command-line legs (t_e2e, config 5) run FIRST, while this process has no HIP context: a child's runtime start-up is slower, and
+    # now and then much slower (0.2 instead of 0.055 s), beside a parent that holds one (tools/probe_e2e_parent.py,
+    # profiles/r05_e2e_parent_state.txt).  Their sketches are compared with the resident passes' further down.
+    early = {}
+    if world == 1 and not args.no_host_legs and args.total_reads is None:
+        n_cli = args.reads_per_gpu if args.reads_per_gpu is not None else CONFIG3_READS
+        try:
+            early["t_e2e"] = leg_e2e(capi, capi.Shuf.generate(11, 6, 3, 11), n_cli, None)
+        except Exception as ex:  # noqa: BLE001
+            early["t_e2e"] = {"gbases_s": None, "what": "failed: %s" % ex}
+        if not args.no_config5:
+            try:
+                early["config5"] = leg_config5(capi)
+            except Exception as ex:  # noqa: BLE001
+                early["config5"] = {"what": "failed: %s" % ex}
+    _GPU_TOUCHED[0] = True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the exchanged lists live
@@ -1150,15 +1171,28 @@ def main():
             torch.cuda.empty_cache()
             if hasattr(torch._C, "_host_emptyCache"):  # ... and the 11 GB of pinned host memory torch keeps cached from the t_stream leg
                 torch._C._host_emptyCache()
-            try:
-                line["t_e2e"] = leg_e2e(capi, shuf, n, sketch)
-            except Exception as ex:
-                line["t_e2e"] = {"gbases_s": None, "what": "failed: %s" % ex}
+            if "t_e2e" in early:  # ran before this process had a HIP context; its sketch against the resident passes' now
+                import numpy as np
+                te = early["t_e2e"]
+                sk2 = te.pop("_sketch", None)
+                if sk2 is not None:
+                    te["sketch_equals_resident_run"] = bool(np.array_equal(sk2[0], sketch[0][0]) and np.array_equal(sk2[1], sketch[0][1]))
+                    te["what"] += ".  The leg ran before this process made its first HIP call (a parent with a HIP context slows the child's start-up)"
+                line["t_e2e"] = te
+            else:
+                try:
+                    line["t_e2e"] = leg_e2e(capi, shuf, n, sketch)
+                    line["t_e2e"].pop("_sketch", None)
+                except Exception as ex:
+                    line["t_e2e"] = {"gbases_s": None, "what": "failed: %s" % ex}
         if world == 1 and not args.no_host_legs and not args.no_config5:
-            try:
-                line["config5"] = leg_config5(capi)
-            except Exception as ex:
-                line["config5"] = {"what": "failed: %s" % ex}
+            if "config5" in early:
+                line["config5"] = early["config5"]
+            else:
+                try:
+                    line["config5"] = leg_config5(capi)
+                except Exception as ex:
+                    line["config5"] = {"what": "failed: %s" % ex}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
