@@ -1074,6 +1074,33 @@ def test_bench_launches_its_own_ranks(capi, ranks, merge):
     assert im["equals_process_per_gpu_sketch"] is True and im["distinct_keys"] == d["config"]["distinct_keys"] and im["gbases_s"] > 0
 
 
+def test_bench_default_flow_one_gpu(capi):
+    """`python3 bench.py` at N = 1 as the driver starts it (device legs only, a small workload): two engines in turn on split queues
+    (MK_OPT_SPLIT_CUS) for the timed region, the one-queue flow beside it, the shards-merged check; and the fall-back to one queue when
+    the option does not fit"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(root, "bench.py"), "--reads-per-gpu", "2000000", "--steps", "7", "--warmup", "2", "--no-host-legs",
+            "--no-cpu-baseline", "--no-traffic", "--verify"]
+    lines = []
+    for extra in ([], ["--split-cus", "24"], ["--split-cus", "0"]):
+        r = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+        lines.append(json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]))
+    d, bad, one = lines
+    assert "two engines take the passes in turn" in d["config"]["queues"] and d["roofline"]["compute_units"] == 256 - 32
+    assert d["one_queue"]["ms_per_step"] > 0 and d["one_queue"]["scan_roofline"]["compute_units"] == 256
+    assert "split queues not available here" in bad["config"]["queues"] and "one_queue" not in bad
+    assert one["config"]["queues"].startswith("one engine, one queue") and "one_queue" not in one
+    assert d["config"]["distinct_keys"] == bad["config"]["distinct_keys"] == one["config"]["distinct_keys"] > 0
+    for x in lines:
+        assert x["merged_equals_single_engine"] is True and x["steps"] == 7 and x["value"] > 0
+
+
 # ---- FASTQ without -A (SURVEY 8f N1): fastq2co + write_fqco2file through MK_MODE_OCC_SET -----------------------
 def run_occ(capi, eng, data, TL, M, Q=0, stride=304, pushes=1):
     rows, n, nrec, used, rc = capi.fastq_frame_q(data, stride, TL, qmin=Q)
