@@ -630,6 +630,8 @@ def main():
                     help="N = 1: two engines take the passes in turn, the scan kernel on all but this many compute units and what follows a "
                          "scan on these (MK_OPT_SPLIT_CUS; a multiple of 32); 0: one engine, one queue -- that flow is timed as well "
                          "either way (`one_queue` in the line)")
+    ap.add_argument("--no-queue-trial", action="store_true",
+                    help="N = 1: time the split-queue flow whatever a trial says (default: 30 passes of either flow first, the faster one is timed)")
     ap.add_argument("--no-one-queue", action="store_true", help="skip the comparison leg on one engine and one queue (profiling: one flow's kernels only)")
     ap.add_argument("--split-two-scan-queues", action="store_true", help="experiment: a scan queue per engine instead of one shared")
     ap.add_argument("--serial-finish", action="store_true",
@@ -863,106 +865,129 @@ def main():
     split = args.split_cus if world == 1 and not args.serial_finish else 0
     eng_cus = torch.cuda.get_device_properties(dev).multi_processor_count
     split_note = None
+    engs = None
+
+    def make_split():  # the two split-queue engines; they live only while their flow runs (their six queues cost the OTHER flow 0.3 ms a pass)
+        nonlocal engs
+        made = []
+        try:
+            for _ in range(2):
+                made.append(capi.Engine(shuf, local_rank, front_bits=args.front_bits, cand_cap=args.cand_cap))
+                made[-1].set_option(capi.MK_OPT_SPLIT_CUS, split)
+            if not args.split_two_scan_queues:
+                made[1].share_scan_queue(made[0])  # one scan queue: the scans run one after the other and a kernel's duration is its run time
+        except capi.MkError:
+            for e in reversed(made):
+                e.close()
+            raise
+        engs = tuple(made)
+
+    def close_split():
+        nonlocal engs
+        if engs is not None:
+            for e in reversed(engs):
+                e.close()
+            engs = None
+
     if split:
         # a device this option does not fit (fewer than 64 compute units, a runtime without CU masks): the one-queue flow, said so in the line
-        eng2 = None
         try:
-            eng2 = capi.Engine(shuf, local_rank, front_bits=args.front_bits, cand_cap=args.cand_cap)
-            for e in (eng, eng2):
-                e.use_own_stream()
-                e.set_option(capi.MK_OPT_SPLIT_CUS, split)
-            if not args.split_two_scan_queues:
-                eng2.share_scan_queue(eng)  # one scan queue: the scans run one after the other and a kernel's duration is its run time
+            make_split()
+            close_split()
         except capi.MkError as ex:
             split_note = "split queues not available here (%s): one engine, one queue" % str(ex)[:160]
-            if eng2 is not None:
-                eng2.close()
-            try:
-                eng.set_option(capi.MK_OPT_SPLIT_CUS, 0)
-            except capi.MkError:
-                pass
-            eng.set_stream(stream)
             split = 0
-    if split:
-        engs = (eng, eng2)
-        pend = [False, False]
+    pend = [False, False]
 
-        def drain2(j):
-            if pend[j]:
-                r = engs[j].finish_end_raw()
-                result["distinct"] = int(r.total)
-                capi.lib.mk_result_release(engs[j].h, r)
-                pend[j] = False
+    def drain2(j):
+        if pend[j]:
+            r = engs[j].finish_end_raw()
+            result["distinct"] = int(r.total)
+            capi.lib.mk_result_release(engs[j].h, r)
+            pend[j] = False
 
-        def passes(k):
-            for i in range(k + 1):
-                if i < k:
-                    engs[i & 1].begin(capi.MK_MODE_KOC)
-                    engs[i & 1].push_reads_device(reads.data_ptr(), STRIDE, n, first)
-                if i > 0:
-                    j = (i - 1) & 1
-                    drain2(j)
-                    engs[j].finish_begin()
-                    pend[j] = True
+    def passes(k):
+        for i in range(k + 1):
+            if i < k:
+                engs[i & 1].begin(capi.MK_MODE_KOC)
+                engs[i & 1].push_reads_device(reads.data_ptr(), STRIDE, n, first)
+            if i > 0:
+                j = (i - 1) & 1
+                drain2(j)
+                engs[j].finish_begin()
+                pend[j] = True
 
-        def fence2():
-            drain2(0)
-            drain2(1)
-            torch.cuda.synchronize()
+    def fence2():
+        drain2(0)
+        drain2(1)
+        torch.cuda.synchronize()
 
-        passes(max(2, args.warmup))
+    def run_split(k, warm):  # k passes on the two split-queue engines in turn -> (seconds, the engines' event times summed)
+        make_split()
+        passes(warm)
         for e in engs:
             e.profile_enable(True)
             e.profile_reset()
         fence2()
         t0 = time.perf_counter()
-        passes(args.steps)
+        passes(k)
         fence2()
         dt = time.perf_counter() - t0
         profs = [e.profile() for e in engs]
-        prof = {k: profs[0][k] + profs[1][k] for k in profs[0]}
-        for e in (eng2, eng):
-            e.profile_enable(False)
-            e.set_option(capi.MK_OPT_SPLIT_CUS, 0)
-        eng2.close()
-        eng.set_stream(stream)
-        # the same passes on ONE engine and one queue (every kernel on the whole device, resolve + compaction between two scans), for
-        # comparison: the flow of rounds 1-4, and what the scan kernel takes with all 256 compute units
-        k1 = 0 if args.no_one_queue else max(2, min(args.steps, 100))
-        for _ in range(3 if k1 else 0):
-            step()
-        eng.profile_enable(True)
-        eng.profile_reset()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(k1):
-            step()
-        fence()
-        dt1 = time.perf_counter() - t1
-        p1 = eng.profile()
-        eng.profile_enable(False)
-        one_queue = None if not k1 else {"steps": k1, "ms_per_step": dt1 / k1 * 1e3, "gbases_s": float(n) * READ_LEN * k1 / dt1 / 1e9,
-                     "scan_ms": p1["scan_ms"] / max(1, p1["scan_launches"]), "resolve_ms": p1["resolve_ms"] / k1,
-                     "what": "one engine, one queue, every kernel on all %d compute units: scan, resolve and compaction of a pass one after "
-                             "the other, layout + dump + result copy beside the next pass (the flow of rounds 1-4)" % eng_cus}
-    else:
-        one_queue = None
-        for _ in range(args.warmup):
+        close_split()
+        return dt, {key: profs[0][key] + profs[1][key] for key in profs[0]}
+
+    def run_one(k, warm):  # k passes on the one engine with one queue (torch's stream) -> (seconds, its event times)
+        for _ in range(warm):
             step()
         eng.profile_enable(True)
         eng.profile_reset()
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(k):
             step()
         fence()
         dt = time.perf_counter() - t0
+        pr = eng.profile()
+        eng.profile_enable(False)
+        return dt, pr
+
+    one_queue = split_queues = trial = None
+    split_timed = 0  # the compute units the TIMED flow leaves to the second queue (0: one engine, one queue)
+    if split:
+        # which flow the timed region runs: the faster of a short trial of both (on a box whose GPU is throttled hard the 32 units the scan
+        # gives up cost more than the overlap brings: profiles/r05_split_queues.txt), the other one is timed as a comparison leg afterwards
+        split_timed = split
+        if not (args.no_one_queue or args.no_queue_trial):
+            ts, _ = run_split(30, max(2, args.warmup))
+            to, _ = run_one(30, 3)
+            trial = {"passes": 30, "split_ms_per_step": ts / 30 * 1e3, "one_queue_ms_per_step": to / 30 * 1e3}
+            if to < ts:
+                split_timed = 0
+        k1 = 0 if args.no_one_queue else max(2, min(args.steps, 100))
+        if split_timed:
+            dt, prof = run_split(args.steps, max(2, args.warmup))
+            if k1:
+                dt1, p1 = run_one(k1, 3)
+                one_queue = {"steps": k1, "ms_per_step": dt1 / k1 * 1e3, "gbases_s": float(n) * READ_LEN * k1 / dt1 / 1e9,
+                             "scan_ms": p1["scan_ms"] / max(1, p1["scan_launches"]), "resolve_ms": p1["resolve_ms"] / k1,
+                             "what": "one engine, one queue, every kernel on all %d compute units: scan, resolve and compaction of a pass one "
+                                     "after the other, layout + dump + result copy beside the next pass (the flow of rounds 1-4)" % eng_cus}
+        else:
+            dt, prof = run_one(args.steps, args.warmup)
+            dt1, p1 = run_split(k1, 2)
+            split_queues = {"steps": k1, "ms_per_step": dt1 / k1 * 1e3, "gbases_s": float(n) * READ_LEN * k1 / dt1 / 1e9,
+                            "scan_ms": p1["scan_ms"] / max(1, p1["scan_launches"]), "resolve_ms": p1["resolve_ms"] / k1,
+                            "what": "two engines in turn, scan kernel on %d compute units, what follows a scan on the other %d "
+                                    "(MK_OPT_SPLIT_CUS): slower than one queue in this run's trial, so not the timed flow" % (eng_cus - split, split)}
+            split_note = "one engine, one queue: every kernel on the whole device, one after the other (the split-queue flow was slower in " \
+                         "this run's trial of 30 passes each: %.3f against %.3f ms)" % (trial["split_ms_per_step"], trial["one_queue_ms_per_step"])
+    else:
+        dt, prof = run_one(args.steps, args.warmup)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        prof = eng.profile()
-        eng.profile_enable(False)
 
     if world > 1:  # rank 0's serial tail (gather + import + finish), from three separately fenced steps
         tail["on"] = True
@@ -1098,14 +1123,14 @@ def main():
                        "table_load": (result.get("distinct") or 0) / float(eng.params.hashsize),
                        "finish": "serial (--serial-finish: profiling aid)" if args.serial_finish else "result copy beside the next pass",
                        "queues": ("two engines take the passes in turn; scan kernel on %d compute units, candidate resolution + compaction + "
-                                  "clear of the pass before on the other %d beside it (MK_OPT_SPLIT_CUS)" % (eng_cus - split, split)) if split
+                                  "clear of the pass before on the other %d beside it (MK_OPT_SPLIT_CUS)" % (eng_cus - split_timed, split_timed)) if split_timed
                                  else (split_note or "one engine, one queue: every kernel on the whole device, one after the other"),
                        "parallelism": "reads sharded x%d, gather to rank 0" % world},
             "roofline": {"bound": "hbm", "kernel": "mk_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms,
                          "launches": prof["scan_launches"], "kernel_source_id": kernel_source_id(),
-                         "compute_units": eng_cus - split,
+                         "compute_units": eng_cus - split_timed,
                          "measured_copy_gb_s": copy_gbs},
             "phases_ms_per_step": {"clear": prof["clear_ms"] / args.steps, "scan": prof["scan_ms"] / args.steps,
                                    "resolve": prof["resolve_ms"] / args.steps,
@@ -1113,9 +1138,13 @@ def main():
                                    # layout + dump + copy of pass i on the side stream, beside clear + scan of pass i + 1
                                    "finish_side_stream": prof.get("finish_side_ms", 0.0) / args.steps},
         }
-        if split:
+        if trial is not None:
+            line["queue_trial"] = trial
+        if split_queues is not None:
+            line["split_queues"] = split_queues
+        if split_timed:
             line["roofline"]["note"] = ("the timed flow runs this kernel on %d of the device's %d compute units (config.queues: the other %d resolve the "
-                                        "pass before beside it), which is what this entry measures" % (eng_cus - split, eng_cus, split)) + (
+                                        "pass before beside it), which is what this entry measures" % (eng_cus - split_timed, eng_cus, split_timed)) + (
                                             "; the same kernel on all %d in the same run: one_queue.scan_roofline" % eng_cus if one_queue is not None else "")
         if one_queue is not None:
             sb = scan_bytes / (one_queue["scan_ms"] * 1e-3) / 1e9 if one_queue["scan_ms"] > 0 else 0.0

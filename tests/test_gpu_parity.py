@@ -1087,11 +1087,19 @@ def test_bench_default_flow_one_gpu(capi):
     base = [sys.executable, os.path.join(root, "bench.py"), "--reads-per-gpu", "2000000", "--steps", "7", "--warmup", "2", "--no-host-legs",
             "--no-cpu-baseline", "--no-traffic", "--verify"]
     lines = []
-    for extra in ([], ["--split-cus", "24"], ["--split-cus", "0"]):
+    for extra in (["--no-queue-trial"], ["--split-cus", "24"], ["--split-cus", "0"], []):
         r = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
         assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
         lines.append(json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]))
-    d, bad, one = lines
+    d, bad, one, auto = lines
+    # the default: a trial of both flows, the faster one is timed and the other reported beside it
+    tr = auto["queue_trial"]
+    if tr["split_ms_per_step"] <= tr["one_queue_ms_per_step"]:
+        assert "two engines take the passes in turn" in auto["config"]["queues"] and "one_queue" in auto and "split_queues" not in auto
+    else:
+        assert auto["config"]["queues"].startswith("one engine, one queue") and "split_queues" in auto and "one_queue" not in auto
+        assert auto["roofline"]["compute_units"] == 256
+    assert "queue_trial" not in d and "queue_trial" not in one
     assert "two engines take the passes in turn" in d["config"]["queues"] and d["roofline"]["compute_units"] == 256 - 32
     assert d["one_queue"]["ms_per_step"] > 0 and d["one_queue"]["scan_roofline"]["compute_units"] == 256
     assert "split queues not available here" in bad["config"]["queues"] and "one_queue" not in bad
