@@ -630,8 +630,8 @@ def main():
                     help="N = 1: two engines take the passes in turn, the scan kernel on all but this many compute units and what follows a "
                          "scan on these (MK_OPT_SPLIT_CUS; a multiple of 32); 0: one engine, one queue -- that flow is timed as well "
                          "either way (`one_queue` in the line)")
-    ap.add_argument("--no-queue-trial", action="store_true",
-                    help="N = 1: time the split-queue flow whatever a trial says (default: 30 passes of either flow first, the faster one is timed)")
+    ap.add_argument("--no-tail-hint", action="store_true", help="experiment: the last pass of a split-queue run does not say that nothing follows it")
+    ap.add_argument("--no-queue-trial", action="store_true", help="(kept for scripts: same as --no-one-queue)")
     ap.add_argument("--no-one-queue", action="store_true", help="skip the comparison leg on one engine and one queue (profiling: one flow's kernels only)")
     ap.add_argument("--split-two-scan-queues", action="store_true", help="experiment: a scan queue per engine instead of one shared")
     ap.add_argument("--serial-finish", action="store_true",
@@ -909,7 +909,9 @@ def main():
     def passes(k):
         for i in range(k + 1):
             if i < k:
-                engs[i & 1].begin(capi.MK_MODE_KOC)
+                # the last pass of a run says so (MK_BEGIN_NOTHING_FOLLOWS): no scan is queued behind it, its resolve and compaction take the
+                # whole device instead of the second queue's 32 units -- a tail of 0.8 instead of 2.3 ms, which matters at --steps 20
+                engs[i & 1].begin(capi.MK_MODE_KOC | (capi.MK_BEGIN_NOTHING_FOLLOWS if i == k - 1 and not args.no_tail_hint else 0))
                 engs[i & 1].push_reads_device(reads.data_ptr(), STRIDE, n, first)
             if i > 0:
                 j = (i - 1) & 1
@@ -953,35 +955,34 @@ def main():
         return dt, pr
 
     one_queue = split_queues = trial = None
-    split_timed = 0  # the compute units the TIMED flow leaves to the second queue (0: one engine, one queue)
+    split_timed = 0  # the compute units the HEADLINE flow leaves to the second queue (0: one engine, one queue)
     if split:
-        # which flow the timed region runs: the faster of a short trial of both (on a box whose GPU is throttled hard the 32 units the scan
-        # gives up cost more than the overlap brings: profiles/r05_split_queues.txt), the other one is timed as a comparison leg afterwards
-        split_timed = split
-        if not (args.no_one_queue or args.no_queue_trial):
-            ts, _ = run_split(30, max(2, args.warmup))
-            to, _ = run_one(30, 3)
-            trial = {"passes": 30, "split_ms_per_step": ts / 30 * 1e3, "one_queue_ms_per_step": to / 30 * 1e3}
-            if to < ts:
-                split_timed = 0
-        k1 = 0 if args.no_one_queue else max(2, min(args.steps, 100))
-        if split_timed:
-            dt, prof = run_split(args.steps, max(2, args.warmup))
-            if k1:
-                dt1, p1 = run_one(k1, 3)
-                one_queue = {"steps": k1, "ms_per_step": dt1 / k1 * 1e3, "gbases_s": float(n) * READ_LEN * k1 / dt1 / 1e9,
-                             "scan_ms": p1["scan_ms"] / max(1, p1["scan_launches"]), "resolve_ms": p1["resolve_ms"] / k1,
-                             "what": "one engine, one queue, every kernel on all %d compute units: scan, resolve and compaction of a pass one "
-                                     "after the other, layout + dump + result copy beside the next pass (the flow of rounds 1-4)" % eng_cus}
+        # Both flows are timed for exactly --steps passes each, fenced on both sides; the faster one is the line's headline, the other is
+        # reported beside it (`one_queue` / `split_queues`).  The split-queue flow wins by 3-5 % over hundreds of passes and by 0-4 % over the
+        # driver's 20 (its tail is longer and a late host call costs it a whole bubble); on a box whose GPU is throttled hard it loses
+        # (profiles/r05_split_queues.txt).  The two split-queue engines exist only while their flow runs: their idle queues cost the
+        # one-queue flow 0.3 ms a pass.
+        def leg(dtx, px, what):
+            return {"steps": args.steps, "ms_per_step": dtx / args.steps * 1e3, "gbases_s": float(n) * READ_LEN * args.steps / dtx / 1e9,
+                    "scan_ms": px["scan_ms"] / max(1, px["scan_launches"]), "resolve_ms": px["resolve_ms"] / args.steps, "what": what}
+        what_one = ("one engine, one queue, every kernel on all %d compute units: scan, resolve and compaction of a pass one after the other, "
+                    "layout + dump + result copy beside the next pass (the flow of rounds 1-4)" % eng_cus)
+        what_split = ("two engines in turn, scan kernel on %d compute units, what follows a scan on the other %d (MK_OPT_SPLIT_CUS)"
+                      % (eng_cus - split, split))
+        dt_s, prof_s = run_split(args.steps, max(5, args.warmup))
+        if args.no_one_queue or args.no_queue_trial:
+            dt, prof, split_timed = dt_s, prof_s, split
         else:
-            dt, prof = run_one(args.steps, args.warmup)
-            dt1, p1 = run_split(k1, 2)
-            split_queues = {"steps": k1, "ms_per_step": dt1 / k1 * 1e3, "gbases_s": float(n) * READ_LEN * k1 / dt1 / 1e9,
-                            "scan_ms": p1["scan_ms"] / max(1, p1["scan_launches"]), "resolve_ms": p1["resolve_ms"] / k1,
-                            "what": "two engines in turn, scan kernel on %d compute units, what follows a scan on the other %d "
-                                    "(MK_OPT_SPLIT_CUS): slower than one queue in this run's trial, so not the timed flow" % (eng_cus - split, split)}
-            split_note = "one engine, one queue: every kernel on the whole device, one after the other (the split-queue flow was slower in " \
-                         "this run's trial of 30 passes each: %.3f against %.3f ms)" % (trial["split_ms_per_step"], trial["one_queue_ms_per_step"])
+            dt_o, prof_o = run_one(args.steps, max(3, args.warmup))
+            trial = {"passes_each": args.steps, "split_ms_per_step": dt_s / args.steps * 1e3, "one_queue_ms_per_step": dt_o / args.steps * 1e3}
+            if dt_s <= dt_o:
+                dt, prof, split_timed = dt_s, prof_s, split
+                one_queue = leg(dt_o, prof_o, what_one)
+            else:
+                dt, prof = dt_o, prof_o
+                split_queues = leg(dt_s, prof_s, what_split + ": slower than one queue in this run, so not the headline")
+                split_note = "one engine, one queue: every kernel on the whole device, one after the other (the split-queue flow, timed for the " \
+                             "same %d passes in this run, took %.3f ms a pass against %.3f)" % (args.steps, trial["split_ms_per_step"], trial["one_queue_ms_per_step"])
     else:
         dt, prof = run_one(args.steps, args.warmup)
         if world > 1:
@@ -1139,7 +1140,7 @@ def main():
                                    "finish_side_stream": prof.get("finish_side_ms", 0.0) / args.steps},
         }
         if trial is not None:
-            line["queue_trial"] = trial
+            line["queue_flows"] = trial
         if split_queues is not None:
             line["split_queues"] = split_queues
         if split_timed:

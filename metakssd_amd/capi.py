@@ -19,6 +19,7 @@ MK_MODE_KOC, MK_MODE_SET, MK_MODE_UNIQ_SET, MK_MODE_OCC_SET = 0, 1, 2, 3
 MK_ROWS_PACKED, MK_PACKED_PITCH, MK_PACKED_MAX_BASES = 0x80000000, 64, 152
 MK_ROWS_WIDE, MK_WIDE_MAX_BASES = 0x40000000, 240
 MK_OPT_SPARSE, MK_OPT_CAND_CAP, MK_OPT_RESULT_CAP, MK_OPT_DIRECT_HOST, MK_OPT_FRONT_BITS, MK_OPT_KEYLIST_CAP, MK_OPT_BATCH_TAB_BITS = 1, 2, 3, 4, 5, 6, 7
+MK_BEGIN_NOTHING_FOLLOWS = 0x100  # mk_sketch_begin(mode | this): the last sketch of a run on split queues -- its tail on the whole device
 MK_OPT_SPLIT_CUS = 10  # scan kernel on a queue of its own, the rest on this many compute units (two engines in turn: bench.py)
 
 

@@ -39,6 +39,8 @@ struct mk_engine {
   hipStream_t scan_stream = nullptr, split_stream = nullptr;
   hipEvent_t ev_scan_pre = nullptr, ev_scan_post = nullptr;
   int split_cus = 0, scan_cus = 0;
+  bool tail = false, tail_active = false; /* MK_BEGIN_NOTHING_FOLLOWS: this sketch's work behind its first scan runs on own_stream (the whole
+                                           * device) instead of split_stream; tail_active: e->stream has been switched, the next begin switches back */
   bool scan_shared = false; /* scan_stream is another engine's (mk_engine_share_scan_queue): not destroyed here */
   mk_engine *scan_owner = nullptr; /* ... that engine */
   int scan_lent = 0;               /* engines that borrow THIS engine's scan queue: it stays while they do */
@@ -643,8 +645,11 @@ static int mk_config_split(mk_engine *e, int r) {
   if (e->scan_lent > 0) return mk_fail(e, MK_ERR_STATE, "MK_OPT_SPLIT_CUS: %d engine(s) borrow this engine's scan queue (set them back to one queue first)", e->scan_lent);
   if (e->scan_owner) { e->scan_owner->scan_lent--; e->scan_owner = nullptr; }
   if (e->stream == e->split_stream && e->split_stream) e->stream = e->own_stream;
+  e->tail = e->tail_active = false;
   if (e->scan_stream) { (void)hipStreamSynchronize(e->scan_stream); if (!e->scan_shared) (void)hipStreamDestroy(e->scan_stream); e->scan_stream = nullptr; }
   if (e->split_stream) { (void)hipStreamSynchronize(e->split_stream); (void)hipStreamDestroy(e->split_stream); e->split_stream = nullptr; }
+  /* the side stream carries the scan queue's mask under this option: made anew at the next finish (mk_res_reserve) */
+  if (e->res_stream) { (void)hipStreamSynchronize(e->res_stream); (void)hipStreamDestroy(e->res_stream); e->res_stream = nullptr; }
   e->split_cus = 0; e->scan_cus = 0; e->scan_shared = false;
   if (e->init_queued) { MK_HIP(e, hipStreamSynchronize(e->own_stream)); e->init_queued = false; } /* (what creation queued is ordered with no other stream) */
   if (r == 0) return MK_OK;
@@ -827,9 +832,21 @@ extern "C" int mk_sketch_begin_occ(mk_engine *e, int min_occurrence) {
 }
 
 extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
-  if (!e || mode < MK_MODE_KOC || mode > MK_MODE_OCC_SET) return MK_ERR_ARG;
+  if (!e) return MK_ERR_ARG;
+  const bool tail = (mode & MK_BEGIN_NOTHING_FOLLOWS) != 0;
+  mode &= ~MK_BEGIN_NOTHING_FOLLOWS;
+  if (mode < MK_MODE_KOC || mode > MK_MODE_OCC_SET) return MK_ERR_ARG;
   MK_HIP(e, hipSetDevice(e->device));
   { int rc = mk_tables_alloc(e); if (rc) return rc; } /* MK_ENGINE_LAZY_TABLES: the first sketch of one input makes them */
+  if (e->tail_active) { /* the last sketch ended on own_stream (MK_BEGIN_NOTHING_FOLLOWS): back to the second queue, behind that work */
+    if (e->split_stream && e->stream == e->own_stream) {
+      MK_HIP(e, hipEventRecord(e->ev_scan_pre, e->own_stream));
+      MK_HIP(e, hipStreamWaitEvent(e->split_stream, e->ev_scan_pre, 0));
+      e->stream = e->split_stream;
+    }
+    e->tail_active = false;
+  }
+  e->tail = tail && e->scan_stream && e->stream == e->split_stream; /* (means something on split queues only) */
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   /* the table clear the reference does with memset(co,0,..) (iseq2comem.c:223,663) */
@@ -1060,6 +1077,14 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   }
   if (e->scan_stream) {
     MK_HIP(e, hipEventRecord(e->ev_scan_post, ss));
+    if (e->tail && e->stream == e->split_stream) {
+      /* MK_BEGIN_NOTHING_FOLLOWS: no other engine's scan will want the device behind this one -- the engine's unmasked queue takes over for the
+       * rest of the sketch (resolve with a workgroup on every CU, compaction, ...), ordered behind what the second queue has done so far */
+      MK_HIP(e, hipEventRecord(e->ev_scan_pre, e->split_stream));
+      MK_HIP(e, hipStreamWaitEvent(e->own_stream, e->ev_scan_pre, 0));
+      e->stream = e->own_stream;
+      e->tail_active = true;
+    }
     MK_HIP(e, hipStreamWaitEvent(e->stream, e->ev_scan_post, 0));
   }
   /* resolve the appended candidates: canonical k-mer, exact .shuf check, upsert */
@@ -1809,9 +1834,18 @@ static int mk_finish_keylist(mk_engine *e, mk_result *out, mk_evpair ev) {
  * sketch on this engine) costs a second round: grow, write again. */
 static int mk_res_reserve(mk_engine *e, uint64_t want) {
   if (!e->res_stream) {
-    /* (not confined by MK_OPT_SPLIT_CUS: layout and dump on the second queue's few compute units make THEM the bottleneck --
-     * 2.80 ms a pass against 2.35, profiles/r05_split_queues.txt; beside the scan they cost it 0.1 ms as they do with one queue) */
-    MK_HIP(e, hipStreamCreateWithFlags(&e->res_stream, hipStreamNonBlocking));
+    if (e->split_cus) {
+      /* MK_OPT_SPLIT_CUS: layout, dump and the result copy on the SCAN queue's compute units, beside the scan as they are with one queue
+       * (small kernels: they fit next to its workgroups).  On the second queue's few units they make THOSE the bottleneck (2.80 ms a pass
+       * against 2.35), and left unmasked they land there whenever the units are idle and stretch the resolve kernel's chain past the next
+       * scan's end every other run (2.29 or 2.38 ms a pass, profiles/r05_split_queues.txt) */
+      uint32_t scan_mask[16] = {0};
+      for (int i = 0; i < e->num_cu - e->split_cus; i++) scan_mask[i >> 5] |= 1u << (i & 31);
+      MK_HIP(e, hipExtStreamCreateWithCUMask(&e->res_stream, (uint32_t)((e->num_cu + 31) / 32), scan_mask));
+    } else
+      MK_HIP(e, hipStreamCreateWithFlags(&e->res_stream, hipStreamNonBlocking));
+  }
+  if (!e->ev_res) {
     MK_HIP(e, hipEventCreateWithFlags(&e->ev_res, hipEventDisableTiming));
     MK_HIP(e, hipMalloc(&e->d_snap, 8 * sizeof(unsigned long long)));
     MK_HIP(e, hipHostMalloc((void **)&e->h_snap, 8 * sizeof(unsigned long long), hipHostMallocDefault));
