@@ -181,12 +181,37 @@ _FREE_BASELINE = {}
 _GPU_TOUCHED = [False]  # set when main() makes its first HIP call
 
 
+def _vram_used_no_context():
+    """bytes of device memory in use by ANY process, from `rocm-smi --showmeminfo vram --json` (the largest figure if it lists several cards); None when
+    that is not to be had"""
+    try:
+        r = subprocess.run(["rocm-smi", "--showmeminfo", "vram", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=5)
+        txt = r.stdout.decode(errors="replace")
+        j = json.loads(txt[txt.index("{"):])
+        vals = [int(v["VRAM Total Used Memory (B)"]) for v in j.values() if isinstance(v, dict) and "VRAM Total Used Memory (B)" in v]
+        return max(vals) if vals else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def wait_device_quiet(tag="gpu", least=2.0, most=8.0):
     """between two runs of the command line: the driver takes a process's device memory back for a while AFTER the process has gone
     (21 GB at L2K11), and the next process's start-up waits for that.  Instead of sleeping a fixed time: poll the device's free
     memory (this process keeps its HIP context; it holds nothing large by now) until it is back at what it was before the first run."""
-    if not _GPU_TOUCHED[0]:  # the command-line legs run BEFORE this process has a HIP context (see main): nothing to poll with, a pause
-        time.sleep(2.5)
+    if not _GPU_TOUCHED[0]:
+        # the command-line legs run BEFORE this process has a HIP context (see main): the device's used memory comes from rocm-smi (sysfs, no
+        # context: 0.08 s a call); an idle device shows 0.3 GB.  Without rocm-smi: a pause
+        time.sleep(least)
+        t0 = time.monotonic()
+        while time.monotonic() - t0 < most:
+            used = _vram_used_no_context()
+            if used is None:
+                time.sleep(0.5)
+                break
+            if used < (3 << 29):
+                break
+            time.sleep(0.1)
+        time.sleep(0.25)
         return
     try:
         import torch
@@ -680,6 +705,7 @@ def main():
     early = {}
     if world == 1 and not args.no_host_legs and args.total_reads is None:
         n_cli = args.reads_per_gpu if args.reads_per_gpu is not None else CONFIG3_READS
+        wait_device_quiet(least=0.0, most=15.0)  # whatever ran on the device before this process may still be handing its memory back
         try:
             early["t_e2e"] = leg_e2e(capi, capi.Shuf.generate(11, 6, 3, 11), n_cli, None)
         except Exception as ex:  # noqa: BLE001
