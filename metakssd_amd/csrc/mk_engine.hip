@@ -822,6 +822,21 @@ extern "C" int mk_profile_get(mk_engine *e, mk_profile *out) {
   return MK_OK;
 }
 
+/* MK_BEGIN_NOTHING_FOLLOWS is over with its sketch: whatever begins next (a sketch, a batch) starts on the second queue again, behind the work
+ * the unmasked queue did for the last one, and without the mark */
+static int mk_tail_end(mk_engine *e) {
+  e->tail = false;
+  if (e->tail_active) {
+    if (e->split_stream && e->stream == e->own_stream) {
+      MK_HIP(e, hipEventRecord(e->ev_scan_pre, e->own_stream));
+      MK_HIP(e, hipStreamWaitEvent(e->split_stream, e->ev_scan_pre, 0));
+      e->stream = e->split_stream;
+    }
+    e->tail_active = false;
+  }
+  return MK_OK;
+}
+
 extern "C" int mk_sketch_begin_occ(mk_engine *e, int min_occurrence) {
   if (!e) return MK_ERR_ARG;
   if (min_occurrence < 1 || min_occurrence >= 15) /* iseq2comem.c:325 */
@@ -838,14 +853,7 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   if (mode < MK_MODE_KOC || mode > MK_MODE_OCC_SET) return MK_ERR_ARG;
   MK_HIP(e, hipSetDevice(e->device));
   { int rc = mk_tables_alloc(e); if (rc) return rc; } /* MK_ENGINE_LAZY_TABLES: the first sketch of one input makes them */
-  if (e->tail_active) { /* the last sketch ended on own_stream (MK_BEGIN_NOTHING_FOLLOWS): back to the second queue, behind that work */
-    if (e->split_stream && e->stream == e->own_stream) {
-      MK_HIP(e, hipEventRecord(e->ev_scan_pre, e->own_stream));
-      MK_HIP(e, hipStreamWaitEvent(e->split_stream, e->ev_scan_pre, 0));
-      e->stream = e->split_stream;
-    }
-    e->tail_active = false;
-  }
+  { int rc = mk_tail_end(e); if (rc) return rc; }
   e->tail = tail && e->scan_stream && e->stream == e->split_stream; /* (means something on split queues only) */
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
@@ -1077,7 +1085,7 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   }
   if (e->scan_stream) {
     MK_HIP(e, hipEventRecord(e->ev_scan_post, ss));
-    if (e->tail && e->stream == e->split_stream) {
+    if (e->tail && e->begun && !a.batch && e->stream == e->split_stream) {
       /* MK_BEGIN_NOTHING_FOLLOWS: no other engine's scan will want the device behind this one -- the engine's unmasked queue takes over for the
        * rest of the sketch (resolve with a workgroup on every CU, compaction, ...), ordered behind what the second queue has done so far */
       MK_HIP(e, hipEventRecord(e->ev_scan_pre, e->split_stream));
@@ -2154,6 +2162,7 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
   if (nfiles < 1 || nfiles > MK_BATCH_MAX_FILES) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: 1 .. %u files", MK_BATCH_MAX_FILES);
   if (e->begun) return mk_fail(e, MK_ERR_STATE, "mk_sketch_batch_begin inside a sketch (between begin and finish)");
   if (e->batch_begun - e->batch_ended >= 2) return mk_fail(e, MK_ERR_STATE, "mk_sketch_batch_begin: two batches are in flight (mk_sketch_batch_end first)");
+  { int rc0 = mk_tail_end(e); if (rc0) return rc0; } /* (a batch keeps the stream it starts on: no mark of an earlier sketch may move it) */
   if (e->P.TL + MK_FA_PITCH > 4000u) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin: k-mer too long for the stream rows");
   if (rows && !mk_params_packed_ok(&e->P)) return mk_fail(e, MK_ERR_ARG, "mk_sketch_batch_begin_rows: no scan kernel for packed rows at k %d, subk %d", e->P.k, e->P.subk);
   uint64_t total = 0, nmax = 0;

@@ -718,6 +718,25 @@ def test_split_queues_two_engines_in_turn(capi, shufs, oracle_for, name, cus, ow
                 pend[j] = i - 1
         take(0)
         take(1)
+        # a mark that never met a scan (an empty sketch that said "nothing follows") must not move the NEXT thing's stream: a batch keeps
+        # the stream it starts on (a stale mark once sent its resolve kernel to another queue than the rest of the batch)
+        rs2 = np.random.RandomState(7)
+        texts = _batch_texts(rs2, name == "L3K11")[:4] if name != "L2K11" else []  # (the oracle's L2K11 table makes every file a minute)
+        tw = []
+        for t in texts:
+            rc, w = ora.co_from_fasta(t, uniq=False) if t else (0, None)
+            assert rc == 0
+            tw.append(w)
+        for e in engs if texts else []:
+            e.begin(capi.MK_MODE_KOC | capi.MK_BEGIN_NOTHING_FOLLOWS)
+            assert sum(len(c[0]) for c in e.finish()) == 0
+            e.batch_begin(texts, capi.MK_MODE_SET)
+            for i, (st, alone, comps) in enumerate(e.batch_end()):
+                assert st == 0
+                if tw[i] is None:
+                    assert all(len(c) == 0 for c in comps)
+                else:
+                    assert_same([(c, None) for c in comps], tw[i], "%s batch behind a stale mark, file %d" % (name, i))
         # back to one queue (the borrower first); the plain finish
         engs[1].set_option(capi.MK_OPT_SPLIT_CUS, 0)
         engs[0].set_option(capi.MK_OPT_SPLIT_CUS, 0)

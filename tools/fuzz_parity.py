@@ -69,9 +69,18 @@ def main():
     ap.add_argument("--sparse", type=int, default=-1, help="MK_OPT_SPARSE: -1 by table size, 0 off, 1 on")
     ap.add_argument("--front-bits", type=int, default=None, help="MK_OPT_FRONT_BITS: front table of 2^n slots (with --sparse 0)")
     ap.add_argument("--split-cus", type=int, default=0, help="MK_OPT_SPLIT_CUS on every engine (32, 64, ..): the scan kernel on a queue of its own")
+    ap.add_argument("--tail-rate", type=float, default=0.0,
+                    help="with --split-cus: this share of the sketches begin with MK_BEGIN_NOTHING_FOLLOWS (their tail on the engine's unmasked queue)")
     a = ap.parse_args()
     from metakssd_amd import capi
     from oracle_binding import Oracle
+    if a.tail_rate > 0:  # every Engine.begin of the run draws: the engine goes to its unmasked queue and back between sketches of all kinds
+        _begin0 = capi.Engine.begin
+        trs = np.random.RandomState(a.seed ^ 0x5A5A)
+
+        def _begin(self, mode=capi.MK_MODE_KOC):
+            return _begin0(self, mode | (capi.MK_BEGIN_NOTHING_FOLLOWS if trs.rand() < a.tail_rate else 0))
+        capi.Engine.begin = _begin
     engines, oracles, shufs = {}, {}, {}
     bad = 0
     nonempty = total_ids = crowded = 0
