@@ -19,6 +19,7 @@
 #define _GNU_SOURCE
 #include "metakssd_hip.h"
 #include "metakssd_multi.h"
+#include "mk_host_internal.h" /* mk_poison_byte(): the MK_POISON test hook */
 
 #include <dirent.h>
 #include <dlfcn.h>
@@ -331,6 +332,9 @@ static void close_input(input_t *in) {
 }
 
 /* buffers of the windowed paths (pipes, FASTA); a mapped FASTQ file does not need them */
+/* MK_POISON (mk_host_internal.h): a pool buffer taken back for another file / batch is overwritten with the pattern first */
+static void repoison(void *p, size_t n) { const int pz = mk_poison_byte(); if (pz >= 0 && p && n) memset(p, pz, n); }
+
 static void ensure_buffers(ctx_t *c) {
   if (c->io) return;
   c->io = malloc(IOBUF);
@@ -342,6 +346,7 @@ static void push_rows(ctx_t *c, const uint8_t *rows, uint32_t stride, uint64_t n
   CHECK(e, mk_sketch_push_reads(e, rows, stride, nrows, c->next_ordinal));
   c->next_ordinal += nrows;
   c->nrows_total += nrows;
+  if (rows == c->rows) repoison(c->rows, ROWBUF); /* (push returned: the rows have been copied) */
 }
 
 /* ---- the row-buffer arena is pinned PIECE BY PIECE, behind the framers and in front of the pushes -----------------------------
@@ -508,6 +513,7 @@ static uint8_t *arena_map_untouched(size_t bytes, size_t *len_out) {
 #ifdef MADV_HUGEPAGE
   (void)madvise(m, len, MADV_HUGEPAGE);
 #endif
+  repoison(m, len); /* (MK_POISON: fresh anonymous pages are zeros otherwise) */
   *len_out = len;
   return m;
 }
@@ -531,7 +537,7 @@ static uint8_t *arena_map_unpinned(size_t bytes, size_t *len_out) {
 }
 static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) { /* the arena (and what is pinned of it) is kept for the next file and goes with the process */
   ctx_t *c = ctx;
-  if (c->arena && c->arena_bytes >= bytes) { pin_reset(c->pin); return c->arena; }
+  if (c->arena && c->arena_bytes >= bytes) { pin_reset(c->pin); repoison(c->arena, c->arena_bytes); return c->arena; }
   if (c->pin) { pin_destroy(c->pin); c->pin = NULL; }
   if (c->arena) munmap(c->arena, c->arena_bytes);
   c->arena = NULL; c->arena_bytes = 0;
@@ -772,6 +778,7 @@ static void *pf_worker(void *arg) {
     const int i = pf->next++;
     const int b = pf->free_bufs[--pf->nfree];
     pthread_mutex_unlock(&pf->mu);
+    repoison(pf->bufs[b], ROWBUF);
 
     pf_slot s = {0};
     s.buf = b;
@@ -2418,6 +2425,7 @@ int main(int argc, char **argv) {
         if (rc != MK_OK) die("writing sketch for %s failed (%d)", path_, rc); \
         if (!quiet) printf("%d/%d decomposing %s\r", ++done_files, files.n, path_); \
       } \
+      repoison(br.buf[bj_->batch % nbufs], br.bufcap); /* (MK_POISON: the next batch in this buffer starts from the pattern) */ \
       pthread_mutex_lock(&br.mu); br.released++; pthread_cond_broadcast(&br.cv_free); pthread_mutex_unlock(&br.mu); \
       fly[0] = fly[1]; nfly--; \
     } while (0)

@@ -21,6 +21,22 @@ static inline MK_HD uint64_t mk_mix64(uint64_t z) {
 static inline MK_HD uint64_t mk_synth_word(uint64_t seed, uint64_t read, uint64_t j) {
   return mk_mix64(mk_mix64(seed ^ read) + j);
 }
+
+/* MK_POISON=<byte> (environment, read once; "1" means 0xA5): every device and pinned allocation of the library and of the command
+ * line, and every buffer they take back for another batch / sketch / file, is filled with that byte before use -- the substitute for
+ * a GPU address sanitizer on hosts that have none: a kernel that reads what nobody wrote in THIS use of the buffer then reads the
+ * pattern instead of a previous process's zeros or a previous batch's bytes.  Returns -1 when the hook is off.  0x43 ('C') makes
+ * stale TEXT a run of valid bases, 0xA5 makes stale table slots and indices garbage. */
+#include <stdlib.h>
+static inline int mk_poison_byte(void) {
+  static int v = -2;
+  if (v == -2) {
+    const char *t = getenv("MK_POISON");
+    if (!t || !*t) v = -1;
+    else { long x = strtol(t, NULL, 0); v = x <= 0 ? -1 : (x == 1 ? 0xA5 : (int)(x & 0xff)); }
+  }
+  return v;
+}
 #if !defined(__HIPCC__)
 #include <stddef.h>
 /* range forms of the two FASTQ framers (mk_frontend.c), shared with the whole-file stream (mk_fastq_stream.c) */

@@ -6,6 +6,7 @@
  * list and the output arrays.  There is no CPU implementation behind these entry points.
  */
 #include "metakssd_hip.h"
+#include "mk_poison.hip.h"
 #include "mk_kernels.hip.h"
 #include "mk_stream.hip.h"
 #include "mk_batch.hip.h"
@@ -191,8 +192,8 @@ extern "C" int mk_device_count(int *n) {
 
 extern "C" int mk_host_alloc(void **p, size_t bytes) {
   if (!p) return MK_ERR_ARG;
-  hipError_t r = hipHostMalloc(p, bytes, hipHostMallocDefault);
-  return r == hipSuccess ? MK_OK : mk_fail(nullptr, MK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(r));
+  hipError_t r = mk_pin_alloc(p, bytes, hipHostMallocDefault);
+  return r == hipSuccess ? MK_OK : mk_fail(nullptr, MK_ERR_NOMEM, "mk_pin_alloc(%zu): %s", bytes, hipGetErrorString(r));
 }
 extern "C" int mk_host_free(void *p) { return hipHostFree(p) == hipSuccess ? MK_OK : MK_ERR_HIP; }
 /* A large pinned block made the cheap way: anonymous mapping (huge pages where the kernel gives them), its pages touched by
@@ -203,7 +204,9 @@ extern "C" int mk_host_free(void *p) { return hipHostFree(p) == hipSuccess ? MK_
 struct mk_touch_job { uint8_t *p; size_t n; pthread_t th; };
 static void *mk_touch_run(void *arg) {
   mk_touch_job *j = (mk_touch_job *)arg;
-  for (size_t off = 0; off < j->n; off += 4096) j->p[off] = 0;
+  const int pz = mk_poison_byte();
+  if (pz >= 0) memset(j->p, pz, j->n); /* MK_POISON: the whole block, not just a touch of every page */
+  else for (size_t off = 0; off < j->n; off += 4096) j->p[off] = 0;
   return nullptr;
 }
 extern "C" int mk_host_arena_alloc(void **out, size_t bytes) {
@@ -345,11 +348,11 @@ static int mk_config_sparse(mk_engine *e, bool on) {
   e->acc_words = (e->acc_blocks + 31u) / 32u;
   const uint32_t nch = (uint32_t)((S + MK_DUMP_CHUNK - 1) / MK_DUMP_CHUNK);
   e->slot_words = (nch + 31u) / 32u;
-  MK_HIP(e, hipMalloc(&e->d_dirty_acc, (size_t)e->acc_words * 4));
-  MK_HIP(e, hipMalloc(&e->d_dirty_slot, (size_t)e->slot_words * 4));
-  MK_HIP(e, hipMalloc(&e->d_list_acc, (size_t)e->acc_words * 32 * 4));
-  MK_HIP(e, hipMalloc(&e->d_list_slot, (size_t)e->slot_words * 32 * 4));
-  MK_HIP(e, hipMalloc(&e->d_nlist, 4 * sizeof(uint32_t)));
+  MK_HIP(e, mk_dev_alloc(&e->d_dirty_acc, (size_t)e->acc_words * 4));
+  MK_HIP(e, mk_dev_alloc(&e->d_dirty_slot, (size_t)e->slot_words * 4));
+  MK_HIP(e, mk_dev_alloc(&e->d_list_acc, (size_t)e->acc_words * 32 * 4));
+  MK_HIP(e, mk_dev_alloc(&e->d_list_slot, (size_t)e->slot_words * 32 * 4));
+  MK_HIP(e, mk_dev_alloc(&e->d_nlist, 4 * sizeof(uint32_t)));
   e->tab.dirty = e->d_dirty_acc;
   e->tab.dirty_shift = MK_SPARSE_SHIFT;
   return MK_OK;
@@ -359,8 +362,8 @@ static int mk_config_cand(mk_engine *e, uint32_t cap) {
   hipFree(e->d_cand); hipFree(e->d_cand_count);
   e->d_cand = nullptr; e->d_cand_count = nullptr;
   e->cand_cap = cap;
-  MK_HIP(e, hipMalloc(&e->d_cand, (size_t)e->cand_slots * (e->cand_cap + 1) * sizeof(uint4)));
-  MK_HIP(e, hipMalloc(&e->d_cand_count, (size_t)e->cand_slots * sizeof(uint32_t)));
+  MK_HIP(e, mk_dev_alloc(&e->d_cand, (size_t)e->cand_slots * (e->cand_cap + 1) * sizeof(uint4)));
+  MK_HIP(e, mk_dev_alloc(&e->d_cand_count, (size_t)e->cand_slots * sizeof(uint32_t)));
   /* (the scan kernel writes every count its resolve pass reads; the fill only keeps the unused ones defined) */
   hipLaunchKernelGGL(mk_fill16_kernel, dim3(4), dim3(256), 0, e->stream, (uint4 *)e->d_cand_count, (unsigned long long)e->cand_slots / 4ull, 0u);
   MK_HIP(e, hipGetLastError());
@@ -398,8 +401,8 @@ static int mk_config_front(mk_engine *e, int bits) {
   }
   if (bits == 0) return MK_OK;
   e->front_slots = 1ull << bits;
-  MK_HIP(e, hipMalloc(&e->d_front, e->front_slots * 16));
-  if (!e->d_front_desc) MK_HIP(e, hipMalloc((void **)&e->d_front_desc, sizeof(mk_front)));
+  MK_HIP(e, mk_dev_alloc(&e->d_front, e->front_slots * 16));
+  if (!e->d_front_desc) MK_HIP(e, mk_dev_alloc((void **)&e->d_front_desc, sizeof(mk_front)));
   e->front.kc1 = (unsigned long long *)e->d_front;
   e->front.ordinv1 = e->front.kc1 + e->front_slots;
   e->front.state = (uint32_t *)(e->d_counters + 4);
@@ -416,9 +419,9 @@ static int mk_dist_reserve(mk_engine *e, uint64_t cap) {
   if (cap <= e->dist.cap && e->dist.key) return MK_OK;
   hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
   e->dist.key = nullptr; e->dist.ord = nullptr; e->dist.cnt = nullptr; e->dist.cap = 0;
-  MK_HIP(e, hipMalloc(&e->dist.key, cap * 8));
-  MK_HIP(e, hipMalloc(&e->dist.ord, cap * 8));
-  MK_HIP(e, hipMalloc(&e->dist.cnt, cap * 4));
+  MK_HIP(e, mk_dev_alloc(&e->dist.key, cap * 8));
+  MK_HIP(e, mk_dev_alloc(&e->dist.ord, cap * 8));
+  MK_HIP(e, mk_dev_alloc(&e->dist.cnt, cap * 4));
   e->dist.cap = cap;
   return MK_OK;
 }
@@ -509,9 +512,9 @@ static int mk_engine_init(mk_engine *e, const mk_params *p, bool lazy_tables) {
    * set accept bit and nowhere else, so the rest of the device's table stays unwritten. */
   const uint32_t dbits = 4u * (uint32_t)p->subk;
   const size_t bit_bytes = ((size_t)((L + 31) / 32) * sizeof(uint32_t) + 15u) & ~(size_t)15u;
-  MK_HIP(e, hipMalloc(&e->d_shuf, L * sizeof(int32_t)));
-  MK_HIP(e, hipMalloc(&e->d_accept_bits, bit_bytes));
-  MK_HIP(e, hipMalloc(&e->d_counters, 8 * sizeof(unsigned long long)));
+  MK_HIP(e, mk_dev_alloc(&e->d_shuf, L * sizeof(int32_t)));
+  MK_HIP(e, mk_dev_alloc(&e->d_accept_bits, bit_bytes));
+  MK_HIP(e, mk_dev_alloc(&e->d_counters, 8 * sizeof(unsigned long long)));
   MK_TICK("events + first allocs");
   join_accept();
   size_t npairs = 0;
@@ -521,7 +524,7 @@ static int mk_engine_init(mk_engine *e, const mk_params *p, bool lazy_tables) {
   /* one pinned block: the counters' mirror, the component sizes, and the accepted pairs on their way up (a pageable source
    * costs the first upload 8 ms of staging set-up) */
   const size_t fixed = (16 + MK_MAX_COMP) * sizeof(unsigned long long);
-  MK_HIP(e, hipHostMalloc((void **)&e->h_counters, fixed + (npairs + 1) * sizeof(mk_accept_pair), hipHostMallocDefault));
+  MK_HIP(e, mk_pin_alloc((void **)&e->h_counters, fixed + (npairs + 1) * sizeof(mk_accept_pair), hipHostMallocDefault));
   e->h_comp_totals = e->h_counters + 16;
   mk_accept_pair *hp = (mk_accept_pair *)((uint8_t *)e->h_counters + fixed);
   {
@@ -529,7 +532,7 @@ static int mk_engine_init(mk_engine *e, const mk_params *p, bool lazy_tables) {
     for (int t = 0; t < nt; t++) { if (!job[t].out.empty()) memcpy(hp + at, job[t].out.data(), job[t].out.size() * sizeof(mk_accept_pair)); at += job[t].out.size(); }
   }
   MK_TICK("accept pass joined + pinned block");
-  MK_HIP(e, hipMalloc(&e->d_accept, ((size_t)e->n_accept + 2) * sizeof(uint32_t)));
+  MK_HIP(e, mk_dev_alloc(&e->d_accept, ((size_t)e->n_accept + 2) * sizeof(uint32_t)));
   if (warm.started) { pthread_join(warm.th, nullptr); warm.started = false; }
   MK_TICK("code object");
   hipLaunchKernelGGL(mk_fill16_kernel, dim3((unsigned)e->num_cu * 2u), dim3(256), 0, e->own_stream, (uint4 *)e->d_accept_bits,
@@ -580,10 +583,10 @@ static int mk_tables_alloc(mk_engine *e) {
   MK_HIP(e, hipSetDevice(e->device));
   const uint64_t S = p->hashsize;
   e->tab_bytes = S * (8 + 8);
-  MK_HIP(e, hipMalloc(&e->d_tab, e->tab_bytes));
+  MK_HIP(e, mk_dev_alloc(&e->d_tab, e->tab_bytes));
   e->tab.kc = (unsigned long long *)e->d_tab;
   e->tab.ordinv = e->tab.kc + S;
-  MK_HIP(e, hipMalloc(&e->d_slot, S * sizeof(uint32_t)));
+  MK_HIP(e, mk_dev_alloc(&e->d_slot, S * sizeof(uint32_t)));
   MK_TICK("table + layout table");
   /* sparse bookkeeping from 2^26 slots up (L2K11: 537 M slots for a genome's few thousand keys);
    * mk_engine_set_option(MK_OPT_SPARSE) forces it off/on (the tests run the small tables both ways) */
@@ -594,8 +597,8 @@ static int mk_tables_alloc(mk_engine *e) {
    * With sparse bookkeeping (537 M slots at L2K11: 10.7 GB of list for sketches of a few thousand keys) it starts at 32 M
    * entries and grows when a compaction counts more (mk_dist_fit) */
   { int rc = mk_dist_reserve(e, e->sparse && S > (32ull << 20) ? (32ull << 20) : S); if (rc) return rc; }
-  MK_HIP(e, hipMalloc(&e->d_chunk, (size_t)e->nchunks * (size_t)p->component_num * sizeof(uint32_t)));
-  MK_HIP(e, hipMalloc(&e->d_comp_totals, MK_MAX_COMP * sizeof(unsigned long long)));
+  MK_HIP(e, mk_dev_alloc(&e->d_chunk, (size_t)e->nchunks * (size_t)p->component_num * sizeof(uint32_t)));
+  MK_HIP(e, mk_dev_alloc(&e->d_comp_totals, MK_MAX_COMP * sizeof(unsigned long long)));
   MK_TICK("key list + dump tables");
   e->tables_ready = true;
   return MK_OK;
@@ -626,6 +629,39 @@ extern "C" int mk_engine_create_ex(const mk_params *p, int device, unsigned flag
 }
 
 static int mk_flush_region(mk_engine *e);
+
+/* MK_POISON: what the last sketch left in the engine's scratch -- candidate records, the key list, the dump's arrays, the FASTA
+ * stream's buffers, the staging regions -- is overwritten with the pattern at the next mk_sketch_begin, on the stream the new sketch's
+ * kernels follow on.  Buffers the side stream may still work on (an outstanding mk_sketch_finish_begin) are left alone; so are the tables,
+ * whose clears are the engine's own business (that is what the hook is there to check). */
+static int mk_poison_scratch(mk_engine *e) {
+  if (mk_poison_byte() < 0) return MK_OK;
+  hipStream_t s = e->stream;
+  if (e->d_cand) MK_HIP(e, mk_dev_repoison(e->d_cand, (size_t)e->cand_slots * (e->cand_cap + 1) * sizeof(uint4), s));
+  if (e->d_kl) MK_HIP(e, mk_dev_repoison(e->d_kl, (size_t)e->kl_cap * (8 + 8 + 4 + 4 + 2) + 64, s));
+  if (e->d_kl_buckets) MK_HIP(e, mk_dev_repoison(e->d_kl_buckets, (size_t)e->kl_bucket_cap * 4, s));
+  if (e->d_split) MK_HIP(e, mk_dev_repoison(e->d_split, 2 * MK_SPLIT_MAX * sizeof(unsigned long long), s));
+  if (!e->res_pending) {
+    if (e->dist.key) {
+      MK_HIP(e, mk_dev_repoison(e->dist.key, (size_t)e->dist.cap * 8, s));
+      MK_HIP(e, mk_dev_repoison(e->dist.ord, (size_t)e->dist.cap * 8, s));
+      MK_HIP(e, mk_dev_repoison(e->dist.cnt, (size_t)e->dist.cap * 4, s));
+    }
+    if (e->d_chunk) MK_HIP(e, mk_dev_repoison(e->d_chunk, (size_t)e->nchunks * (size_t)e->P.component_num * sizeof(uint32_t), s));
+    if (e->d_comp_totals) MK_HIP(e, mk_dev_repoison(e->d_comp_totals, MK_MAX_COMP * sizeof(unsigned long long), s));
+    if (e->d_res_ids) {
+      MK_HIP(e, mk_dev_repoison(e->d_res_ids, (size_t)e->res_cap * 4, s));
+      MK_HIP(e, mk_dev_repoison(e->d_res_cnt, (size_t)e->res_cap * 2, s));
+    }
+  }
+  if (e->d_text) MK_HIP(e, mk_dev_repoison(e->d_text, e->text_cap, s));
+  if (e->d_stream) MK_HIP(e, mk_dev_repoison(e->d_stream, e->stream_cap, s));
+  if (e->d_stream_tmp) MK_HIP(e, mk_dev_repoison(e->d_stream_tmp, 8192, s));
+  if (e->d_fa_sum) MK_HIP(e, mk_dev_repoison(e->d_fa_sum, e->fa_sum_cap * sizeof(mk_fa_sum), s));
+  if (e->d_stage[0] && e->copy_stream == e->stream) /* (rows staged for a sketch that was never finished are dropped by the begin) */
+    for (int i = 0; i < MK_REGIONS; i++) MK_HIP(e, mk_dev_repoison(e->d_stage[i], e->stage_bytes, s));
+  return MK_OK;
+}
 
 /* MK_OPT_SPLIT_CUS.  The bits of a queue's CU mask go round the XCDs (bit i = compute unit i / 8 of XCD i % 8), so the first
  * num_cu - r bits and the last r are both spread evenly over the eight of them -- and r is a multiple of 32 so that every shader engine
@@ -719,8 +755,8 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
       if (e->h_ids) hipHostFree(e->h_ids);
       if (e->h_cnt) hipHostFree(e->h_cnt);
       e->h_ids = nullptr; e->h_cnt = nullptr; e->h_cap = 0;
-      MK_HIP(e, hipHostMalloc((void **)&e->h_ids, (size_t)value * 4, hipHostMallocDefault));
-      MK_HIP(e, hipHostMalloc((void **)&e->h_cnt, (size_t)value * 2, hipHostMallocDefault));
+      MK_HIP(e, mk_pin_alloc((void **)&e->h_ids, (size_t)value * 4, hipHostMallocDefault));
+      MK_HIP(e, mk_pin_alloc((void **)&e->h_cnt, (size_t)value * 2, hipHostMallocDefault));
       e->h_cap = (uint64_t)value;
       return MK_OK;
     }
@@ -855,6 +891,7 @@ extern "C" int mk_sketch_begin(mk_engine *e, int mode) {
   { int rc = mk_tables_alloc(e); if (rc) return rc; } /* MK_ENGINE_LAZY_TABLES: the first sketch of one input makes them */
   { int rc = mk_tail_end(e); if (rc) return rc; }
   e->tail = tail && e->scan_stream && e->stream == e->split_stream; /* (means something on split queues only) */
+  { int rc = mk_poison_scratch(e); if (rc) return rc; }
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   /* the table clear the reference does with memset(co,0,..) (iseq2comem.c:223,663) */
@@ -1230,7 +1267,7 @@ extern "C" int mk_sketch_push_reads_async(mk_engine *e, const uint8_t *rows, uin
   }
   if (!e->d_stage[0]) {
     e->stage_bytes = MK_REGION_BYTES;
-    for (int i = 0; i < MK_REGIONS; i++) MK_HIP(e, hipMalloc(&e->d_stage[i], e->stage_bytes));
+    for (int i = 0; i < MK_REGIONS; i++) MK_HIP(e, mk_dev_alloc(&e->d_stage[i], e->stage_bytes));
   }
 #ifdef MK_TUNING
   if (first_push_) MK_TICK("push1: staging alloc");
@@ -1314,9 +1351,9 @@ extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t 
 
 static int mk_fa_reserve(mk_engine *e, size_t n) {
   if (!e->d_fa_state) {
-    MK_HIP(e, hipMalloc(&e->d_fa_state, sizeof(mk_fa_state)));
+    MK_HIP(e, mk_dev_alloc(&e->d_fa_state, sizeof(mk_fa_state)));
     MK_HIP(e, hipMemset(e->d_fa_state, 0, sizeof(mk_fa_state)));
-    MK_HIP(e, hipHostMalloc((void **)&e->h_fa_state, sizeof(mk_fa_state), hipHostMallocDefault));
+    MK_HIP(e, mk_pin_alloc((void **)&e->h_fa_state, sizeof(mk_fa_state), hipHostMallocDefault));
   }
   /* whole segments: the last wave of a piece loads MK_FA_SEG bytes from its segment's start (mk_fa_stage), so the text buffer holds
    * the piece rounded up to a segment */
@@ -1327,9 +1364,9 @@ static int mk_fa_reserve(mk_engine *e, size_t n) {
     uint8_t *nt = nullptr, *ns = nullptr, *ntmp = nullptr;
     /* stream: what is carried (less than one row and one step) + the new text + a row's width of slack behind it */
     const size_t scap = cap + 8192;
-    MK_HIP(e, hipMalloc(&nt, cap));
-    MK_HIP(e, hipMalloc(&ns, scap));
-    MK_HIP(e, hipMalloc(&ntmp, 8192));
+    MK_HIP(e, mk_dev_alloc(&nt, cap));
+    MK_HIP(e, mk_dev_alloc(&ns, scap));
+    MK_HIP(e, mk_dev_alloc(&ntmp, 8192));
     MK_HIP(e, hipMemset(ns, 0, scap));
     if (e->d_stream && e->fa_tail) MK_HIP(e, hipMemcpy(ns, e->d_stream, e->fa_tail, hipMemcpyDeviceToDevice));
     hipFree(e->d_text); hipFree(e->d_stream); hipFree(e->d_stream_tmp);
@@ -1341,7 +1378,7 @@ static int mk_fa_reserve(mk_engine *e, size_t n) {
     MK_HIP(e, hipStreamSynchronize(e->stream));
     hipFree(e->d_fa_sum);
     e->d_fa_sum = nullptr; e->fa_sum_cap = 0;
-    MK_HIP(e, hipMalloc(&e->d_fa_sum, (nseg + nseg / 4 + 256) * sizeof(mk_fa_sum)));
+    MK_HIP(e, mk_dev_alloc(&e->d_fa_sum, (nseg + nseg / 4 + 256) * sizeof(mk_fa_sum)));
     e->fa_sum_cap = nseg + nseg / 4 + 256;
   }
   return MK_OK;
@@ -1600,7 +1637,7 @@ extern "C" int mk_partial_export_split_async(mk_engine *e, uint32_t nparts, uint
   if (d > capacity) return mk_fail(e, MK_ERR_ARG, "partial_export_split: capacity %llu < %llu keys", (unsigned long long)capacity, (unsigned long long)d);
   if (d == 0) return MK_OK;
   if (!keys_dev || !counts_dev || !ords_dev) return MK_ERR_ARG;
-  if (!e->d_split) MK_HIP(e, hipMalloc(&e->d_split, 2 * MK_SPLIT_MAX * sizeof(unsigned long long)));
+  if (!e->d_split) MK_HIP(e, mk_dev_alloc(&e->d_split, 2 * MK_SPLIT_MAX * sizeof(unsigned long long)));
   MK_HIP(e, hipMemsetAsync(e->d_split, 0, 2 * MK_SPLIT_MAX * sizeof(unsigned long long), e->stream));
   uint64_t blocks = (d + 1023) / 1024;
   if (blocks > (uint64_t)e->num_cu * 2) blocks = (uint64_t)e->num_cu * 2;
@@ -1643,9 +1680,9 @@ extern "C" int mk_partial_list_reserve(mk_engine *e, uint64_t n, uint64_t **keys
     const uint64_t cap = n + n / 8 + 1024;
     unsigned long long *nk = nullptr, *no = nullptr;
     uint32_t *nc = nullptr;
-    MK_HIP(e, hipMalloc(&nk, cap * 8));
-    MK_HIP(e, hipMalloc(&no, cap * 8));
-    MK_HIP(e, hipMalloc(&nc, cap * 4));
+    MK_HIP(e, mk_dev_alloc(&nk, cap * 8));
+    MK_HIP(e, mk_dev_alloc(&no, cap * 8));
+    MK_HIP(e, mk_dev_alloc(&nc, cap * 4));
     if (keep) {
       MK_HIP(e, hipMemcpy(nk, e->dist.key, keep * 8, hipMemcpyDeviceToDevice));
       MK_HIP(e, hipMemcpy(no, e->dist.ord, keep * 8, hipMemcpyDeviceToDevice));
@@ -1693,8 +1730,8 @@ static int mk_result_capacity(mk_engine *e, uint64_t want) {
   if (e->h_cnt) hipHostFree(e->h_cnt);
   e->h_ids = nullptr; e->h_cnt = nullptr; e->h_cap = 0;
   const uint64_t cap = want + want / 8 + 1024;
-  MK_HIP(e, hipHostMalloc((void **)&e->h_ids, cap * 4, hipHostMallocDefault));
-  MK_HIP(e, hipHostMalloc((void **)&e->h_cnt, cap * 2, hipHostMallocDefault));
+  MK_HIP(e, mk_pin_alloc((void **)&e->h_ids, cap * 4, hipHostMallocDefault));
+  MK_HIP(e, mk_pin_alloc((void **)&e->h_cnt, cap * 2, hipHostMallocDefault));
   e->h_cap = cap;
   return MK_OK;
 }
@@ -1757,7 +1794,7 @@ static int mk_finish_keylist(mk_engine *e, mk_result *out, mk_evpair ev) {
     hipFree(e->d_kl);
     e->d_kl = nullptr; e->kl_cap = 0;
     const uint64_t cap = D + D / 4 + 65536;
-    MK_HIP(e, hipMalloc(&e->d_kl, cap * (8 + 8 + 4 + 4 + 2) + 64));
+    MK_HIP(e, mk_dev_alloc(&e->d_kl, cap * (8 + 8 + 4 + 4 + 2) + 64));
     e->kl_cap = cap;
   }
   rc = mk_result_capacity(e, D ? D : 1);
@@ -1782,7 +1819,7 @@ static int mk_finish_keylist(mk_engine *e, mk_result *out, mk_evpair ev) {
     hipFree(e->d_kl_buckets);
     e->d_kl_buckets = nullptr; e->kl_bucket_cap = 0;
     const uint64_t cap = (uint64_t)a.nbuckets * 2 + 2 + 4096;
-    MK_HIP(e, hipMalloc(&e->d_kl_buckets, cap * 4));
+    MK_HIP(e, mk_dev_alloc(&e->d_kl_buckets, cap * 4));
     e->kl_bucket_cap = cap;
   }
   a.bcount = e->d_kl_buckets; a.bcursor = e->d_kl_buckets + a.nbuckets + 1u;
@@ -1855,14 +1892,14 @@ static int mk_res_reserve(mk_engine *e, uint64_t want) {
   }
   if (!e->ev_res) {
     MK_HIP(e, hipEventCreateWithFlags(&e->ev_res, hipEventDisableTiming));
-    MK_HIP(e, hipMalloc(&e->d_snap, 8 * sizeof(unsigned long long)));
-    MK_HIP(e, hipHostMalloc((void **)&e->h_snap, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    MK_HIP(e, mk_dev_alloc(&e->d_snap, 8 * sizeof(unsigned long long)));
+    MK_HIP(e, mk_pin_alloc((void **)&e->h_snap, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   }
   if (want <= e->res_cap && e->d_res_ids) return MK_OK;
   hipFree(e->d_res_ids); hipFree(e->d_res_cnt);
   e->d_res_ids = nullptr; e->d_res_cnt = nullptr; e->res_cap = 0;
-  MK_HIP(e, hipMalloc(&e->d_res_ids, want * 4));
-  MK_HIP(e, hipMalloc(&e->d_res_cnt, want * 2));
+  MK_HIP(e, mk_dev_alloc(&e->d_res_ids, want * 4));
+  MK_HIP(e, mk_dev_alloc(&e->d_res_cnt, want * 2));
   e->res_cap = want;
   return MK_OK;
 }
@@ -1918,6 +1955,7 @@ extern "C" int mk_sketch_finish_end(mk_engine *e, mk_result *out) {
 static int mk_finish_impl(mk_engine *e, mk_result *out, bool staged) {
   if (!e->begun) return mk_fail(e, MK_ERR_STATE, "finish before mk_sketch_begin");
   MK_HIP(e, hipSetDevice(e->device));
+  if (!e->res_pending) { mk_pin_repoison(e->h_ids, (size_t)e->h_cap * 4); mk_pin_repoison(e->h_cnt, (size_t)e->h_cap * 2); } /* (MK_POISON: the last result's arrays) */
   mk_evpair ev{};
   if (e->profiling) { ev = mk_ev_get(e); MK_HIP(e, hipEventRecord(ev.a, e->stream)); }
   int rc = MK_OK;
@@ -2105,20 +2143,20 @@ struct mk_bctx {
 };
 
 static int mk_dbuf_fit(mk_engine *e, mk_dbuf &b, size_t need) {
-  if (b.p && need <= b.cap) return MK_OK;
+  if (b.p && need <= b.cap) { MK_HIP(e, mk_dev_repoison(b.p, b.cap, e->stream)); return MK_OK; } /* (MK_POISON: what the context's last batch left) */
   hipFree(b.p);
   b.p = nullptr; b.cap = 0;
   const size_t cap = need + need / 4 + 4096;
-  MK_HIP(e, hipMalloc(&b.p, cap));
+  MK_HIP(e, mk_dev_alloc(&b.p, cap));
   b.cap = cap;
   return MK_OK;
 }
 static int mk_pinned_fit(mk_engine *e, void **p, size_t *cap, size_t need) {
-  if (*p && need <= *cap) return MK_OK;
+  if (*p && need <= *cap) { mk_pin_repoison(*p, *cap); return MK_OK; }
   if (*p) hipHostFree(*p);
   *p = nullptr; *cap = 0;
   const size_t c = need + need / 4 + 4096;
-  MK_HIP(e, hipHostMalloc(p, c, hipHostMallocDefault));
+  MK_HIP(e, mk_pin_alloc(p, c, hipHostMallocDefault));
   *cap = c;
   return MK_OK;
 }
@@ -2437,7 +2475,7 @@ extern "C" int mk_sketch_batch_end(mk_engine *e, mk_batch_result *out) {
   const bool more_ids = n_out > c->spec_ids; /* more than came with the batch's own sequence: the rest now */
   if (more_ids) {
     uint32_t *bigger = nullptr;
-    MK_HIP(e, hipHostMalloc((void **)&bigger, (size_t)n_out * 4 + 4096, hipHostMallocDefault));
+    MK_HIP(e, mk_pin_alloc((void **)&bigger, (size_t)n_out * 4 + 4096, hipHostMallocDefault));
     memcpy(bigger, c->h_ids, (size_t)c->spec_ids * 4);
     hipHostFree(c->h_ids);
     c->h_ids = bigger; c->h_ids_cap = (size_t)n_out * 4 + 4096;

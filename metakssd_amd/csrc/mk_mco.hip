@@ -17,6 +17,7 @@
  *                           genome lists are repacked to 16 bits (mk_mco_pack16_kernel) below 65 535 genomes
  */
 #include <hip/hip_runtime.h>
+#include "mk_poison.hip.h"
 
 #include "mk_sort.hip.h"
 
@@ -108,7 +109,7 @@ static int mk_mco_grow(mk_mco *m, T **p, uint64_t *cap, uint64_t need) {
   (void)hipFree(*p);
   *p = nullptr; *cap = 0;
   const uint64_t c = need + need / 8 + 1024;
-  MK_MCO_HIP(m, hipMalloc((void **)p, c * sizeof(T)));
+  MK_MCO_HIP(m, mk_dev_alloc((void **)p, c * sizeof(T)));
   *cap = c;
   return MK_OK;
 }
@@ -345,8 +346,8 @@ extern "C" int mk_mco_create(int device, mk_mco **out) {
   }
   m->num_cu = prop.multiProcessorCount;
   hipError_t r = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
-  if (r == hipSuccess) r = hipMalloc(&m->d_total, 8);
-  if (r == hipSuccess) r = hipHostMalloc((void **)&m->h_total, 8, hipHostMallocDefault);
+  if (r == hipSuccess) r = mk_dev_alloc(&m->d_total, 8);
+  if (r == hipSuccess) r = mk_pin_alloc((void **)&m->h_total, 8, hipHostMallocDefault);
   if (r != hipSuccess) {
     mk_mco_fail(nullptr, MK_ERR_NOMEM, "mco allocation: %s", hipGetErrorString(r));
     mk_mco_destroy(m);
@@ -404,7 +405,7 @@ static int mk_mco_upload(mk_mco *m, void *dst, const void *src, size_t bytes) {
     return MK_OK;
   }
   for (int b = 0; b < 2; b++) {
-    if (!m->h_stage[b]) MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_stage[b], piece, hipHostMallocDefault));
+    if (!m->h_stage[b]) MK_MCO_HIP(m, mk_pin_alloc((void **)&m->h_stage[b], piece, hipHostMallocDefault));
     if (!m->ev_stage[b]) MK_MCO_HIP(m, hipEventCreateWithFlags(&m->ev_stage[b], hipEventDisableTiming));
   }
   /* (the staging pieces also carry mk_mco_count_finish's matrix: that call is over when it returns) */
@@ -452,7 +453,7 @@ extern "C" int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *inde
     if (m->h_gids) (void)hipHostFree(m->h_gids);
     m->h_gids = nullptr; m->h_gid_cap = 0;
     const uint64_t c = n + n / 8 + 1024;
-    MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_gids, c * 4, hipHostMallocDefault));
+    MK_MCO_HIP(m, mk_pin_alloc((void **)&m->h_gids, c * 4, hipHostMallocDefault));
     m->h_gid_cap = c;
   }
   uint64_t total = 0;
@@ -476,10 +477,10 @@ extern "C" int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *inde
       if (tmp_bytes > m->tmp_cap || !m->d_tmp) {
         (void)hipFree(m->d_tmp);
         m->d_tmp = nullptr; m->tmp_cap = 0;
-        MK_MCO_HIP(m, hipMalloc(&m->d_tmp, tmp_bytes));
+        MK_MCO_HIP(m, mk_dev_alloc(&m->d_tmp, tmp_bytes));
         m->tmp_cap = tmp_bytes;
       }
-      if (!m->h_sort_flag) MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_sort_flag, 4 * sizeof(uint32_t), hipHostMallocDefault));
+      if (!m->h_sort_flag) MK_MCO_HIP(m, mk_pin_alloc((void **)&m->h_sort_flag, 4 * sizeof(uint32_t), hipHostMallocDefault));
       uint32_t *hist = (uint32_t *)m->d_tmp;
       unsigned long long *tot = (unsigned long long *)((uint8_t *)m->d_tmp + (size_t)256 * MK_RS_MAXB * 4);
       uint32_t *flag = (uint32_t *)((uint8_t *)m->d_tmp + (size_t)256 * MK_RS_MAXB * 4 + 256 * 8);
@@ -514,8 +515,8 @@ extern "C" int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *inde
     if (m->h_row_ends) (void)hipHostFree(m->h_row_ends);
     m->h_row_ids = nullptr; m->h_row_ends = nullptr; m->h_row_cap = 0;
     const uint64_t c = total + total / 8 + 1024;
-    MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_row_ids, c * 4, hipHostMallocDefault));
-    MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_row_ends, c * 8, hipHostMallocDefault));
+    MK_MCO_HIP(m, mk_pin_alloc((void **)&m->h_row_ids, c * 4, hipHostMallocDefault));
+    MK_MCO_HIP(m, mk_pin_alloc((void **)&m->h_row_ends, c * 8, hipHostMallocDefault));
     m->h_row_cap = c;
   }
   if (n) {
@@ -551,10 +552,10 @@ extern "C" int mk_mco_sort_pairs(mk_mco *m, uint32_t *keys, uint32_t *vals, uint
   if (tmp_bytes > m->tmp_cap || !m->d_tmp) {
     (void)hipFree(m->d_tmp);
     m->d_tmp = nullptr; m->tmp_cap = 0;
-    MK_MCO_HIP(m, hipMalloc(&m->d_tmp, tmp_bytes));
+    MK_MCO_HIP(m, mk_dev_alloc(&m->d_tmp, tmp_bytes));
     m->tmp_cap = tmp_bytes;
   }
-  if (!m->h_sort_flag) MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_sort_flag, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  if (!m->h_sort_flag) MK_MCO_HIP(m, mk_pin_alloc((void **)&m->h_sort_flag, 4 * sizeof(uint32_t), hipHostMallocDefault));
   if ((rc = mk_mco_upload(m, m->d_key[0], keys, n * 4)) || (rc = mk_mco_upload(m, m->d_val[0], vals, n * 4))) return rc;
   uint32_t *hist = (uint32_t *)m->d_tmp;
   unsigned long long *tot = (unsigned long long *)((uint8_t *)m->d_tmp + (size_t)256 * MK_RS_MAXB * 4);
@@ -573,7 +574,7 @@ extern "C" int mk_mco_index_rows(mk_mco *m, uint64_t row0, uint64_t nrows, uint6
   if (nrows > MK_MCO_SLAB_ROWS || row0 + nrows > (1ull << 32)) return mk_mco_fail(m, MK_ERR_ARG, "row range out of bounds");
   if (nrows == 0) return MK_OK;
   MK_MCO_HIP(m, hipSetDevice(m->device));
-  if (!m->d_slab) MK_MCO_HIP(m, hipMalloc((void **)&m->d_slab, MK_MCO_SLAB_ROWS * 8));
+  if (!m->d_slab) MK_MCO_HIP(m, mk_dev_alloc((void **)&m->d_slab, MK_MCO_SLAB_ROWS * 8));
   hipLaunchKernelGGL(mk_mco_index_kernel, dim3((unsigned)((nrows + MK_MCO_INDEX_ROWS - 1) / MK_MCO_INDEX_ROWS)), dim3(256), 0, m->stream, m->d_row_ids, m->d_row_ends,
                      m->nrows, row0, nrows, m->d_slab);
   MK_MCO_HIP(m, hipGetLastError());
@@ -700,8 +701,8 @@ extern "C" int mk_mco_count_finish(mk_mco *m, uint32_t *ct) {
   /* the matrix comes back through two pinned pieces: the copy of piece i+1 runs while piece i is added into ct */
   const uint64_t piece = MK_MCO_STAGE_CELLS;
   if (!m->h_stage[0]) {
-    MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_stage[0], piece * 4, hipHostMallocDefault));
-    MK_MCO_HIP(m, hipHostMalloc((void **)&m->h_stage[1], piece * 4, hipHostMallocDefault));
+    MK_MCO_HIP(m, mk_pin_alloc((void **)&m->h_stage[0], piece * 4, hipHostMallocDefault));
+    MK_MCO_HIP(m, mk_pin_alloc((void **)&m->h_stage[1], piece * 4, hipHostMallocDefault));
   }
   const uint64_t npieces = (cells + piece - 1) / piece;
   MK_MCO_HIP(m, hipMemcpyAsync(m->h_stage[0], m->d_ct, (cells < piece ? cells : piece) * 4, hipMemcpyDeviceToHost, m->stream));

@@ -4,6 +4,7 @@
  * device copies when the same GPU is named twice or RCCL is not usable.
  */
 #include "metakssd_multi.h"
+#include "mk_poison.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -220,9 +221,9 @@ static int mm_fit3(mk_multi *m, int dev, unsigned long long **k, uint32_t **c, u
   hipFree(*k); hipFree(*c); hipFree(*o);
   *k = nullptr; *c = nullptr; *o = nullptr; *cap = 0;
   const uint64_t want = need + need / 8 + 1024;
-  MM_HIP(m, hipMalloc(k, want * 8));
-  MM_HIP(m, hipMalloc(c, want * 4));
-  MM_HIP(m, hipMalloc(o, want * 8));
+  MM_HIP(m, mk_dev_alloc(k, want * 8));
+  MM_HIP(m, mk_dev_alloc(c, want * 4));
+  MM_HIP(m, mk_dev_alloc(o, want * 8));
   *cap = want;
   return MK_OK;
 }
@@ -246,7 +247,7 @@ static int mm_finish_slices(mk_multi *m, mk_result *out, double *gather_ms, doub
   const double t0 = mm_now();
   const int n = m->n;
   const uint32_t G = (uint32_t)n;
-  if (!m->h_parts) MM_HIP(m, hipHostMalloc((void **)&m->h_parts, (size_t)n * 16 * sizeof(uint64_t), hipHostMallocDefault));
+  if (!m->h_parts) MM_HIP(m, mk_pin_alloc((void **)&m->h_parts, (size_t)n * 16 * sizeof(uint64_t), hipHostMallocDefault));
   if (m->sk.empty()) { m->sk.assign((size_t)n, nullptr); m->sc.assign((size_t)n, nullptr); m->so.assign((size_t)n, nullptr); m->scap.assign((size_t)n, 0); }
   /* 1. every engine: compaction (all queued first), then its list cut into n parts by key % n, in its exchange buffers */
   for (int i = 0; i < n; i++) {
@@ -384,9 +385,9 @@ extern "C" int mk_multi_finish(mk_multi *m, mk_result *out, double *gather_ms, d
       hipFree(m->xk[(size_t)i]); hipFree(m->xc[(size_t)i]); hipFree(m->xo[(size_t)i]);
       m->xk[(size_t)i] = nullptr; m->xc[(size_t)i] = nullptr; m->xo[(size_t)i] = nullptr; m->xcap[(size_t)i] = 0;
       const uint64_t cap = d + d / 8 + 1024;
-      MM_HIP(m, hipMalloc(&m->xk[(size_t)i], cap * 8));
-      MM_HIP(m, hipMalloc(&m->xc[(size_t)i], cap * 4));
-      MM_HIP(m, hipMalloc(&m->xo[(size_t)i], cap * 8));
+      MM_HIP(m, mk_dev_alloc(&m->xk[(size_t)i], cap * 8));
+      MM_HIP(m, mk_dev_alloc(&m->xc[(size_t)i], cap * 4));
+      MM_HIP(m, mk_dev_alloc(&m->xo[(size_t)i], cap * 8));
       m->xcap[(size_t)i] = cap;
     }
     uint64_t got = 0;
@@ -407,9 +408,9 @@ extern "C" int mk_multi_finish(mk_multi *m, mk_result *out, double *gather_ms, d
     hipFree(m->rk); hipFree(m->rc); hipFree(m->ro);
     m->rk = nullptr; m->rc = nullptr; m->ro = nullptr; m->rcap = 0;
     const uint64_t cap = total + total / 8 + 1024;
-    MM_HIP(m, hipMalloc(&m->rk, cap * 8));
-    MM_HIP(m, hipMalloc(&m->rc, cap * 4));
-    MM_HIP(m, hipMalloc(&m->ro, cap * 8));
+    MM_HIP(m, mk_dev_alloc(&m->rk, cap * 8));
+    MM_HIP(m, mk_dev_alloc(&m->rc, cap * 4));
+    MM_HIP(m, mk_dev_alloc(&m->ro, cap * 8));
     m->rcap = cap;
   }
   if (total) {

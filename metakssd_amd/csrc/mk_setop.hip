@@ -15,6 +15,7 @@
  * ascending id order is observable, and that is what the reference's MSB-first walk produces too.
  */
 #include <hip/hip_runtime.h>
+#include "mk_poison.hip.h"
 
 #include <cstdarg>
 #include <cstdint>
@@ -406,14 +407,14 @@ extern "C" int mk_setop_create(int device, mk_setop **out) {
   }
   s->num_cu = prop.multiProcessorCount;
   hipError_t r = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-  if (r == hipSuccess) r = hipMalloc(&s->d_seen, MK_SET_WORDS * 4);
-  if (r == hipSuccess) r = hipMalloc(&s->d_dup, MK_SET_WORDS * 4);
-  if (r == hipSuccess) r = hipMalloc(&s->d_chunk, (size_t)MK_SET_NCHUNKS * 4);
-  if (r == hipSuccess) r = hipMalloc(&s->d_chunk_off, (size_t)MK_SET_NCHUNKS * 8);
-  if (r == hipSuccess) r = hipMalloc(&s->d_total, 8);
-  if (r == hipSuccess) r = hipHostMalloc((void **)&s->h_total, 8, hipHostMallocDefault);
+  if (r == hipSuccess) r = mk_dev_alloc(&s->d_seen, MK_SET_WORDS * 4);
+  if (r == hipSuccess) r = mk_dev_alloc(&s->d_dup, MK_SET_WORDS * 4);
+  if (r == hipSuccess) r = mk_dev_alloc(&s->d_chunk, (size_t)MK_SET_NCHUNKS * 4);
+  if (r == hipSuccess) r = mk_dev_alloc(&s->d_chunk_off, (size_t)MK_SET_NCHUNKS * 8);
+  if (r == hipSuccess) r = mk_dev_alloc(&s->d_total, 8);
+  if (r == hipSuccess) r = mk_pin_alloc((void **)&s->h_total, 8, hipHostMallocDefault);
   for (int b = 0; b < 2 && r == hipSuccess; b++) {
-    r = hipMalloc(&s->d_stage[b], MK_SET_STAGE_IDS * 4);
+    r = mk_dev_alloc(&s->d_stage[b], MK_SET_STAGE_IDS * 4);
     if (r == hipSuccess) r = hipEventCreateWithFlags(&s->ev_stage[b], hipEventDisableTiming);
   }
   if (r != hipSuccess) {
@@ -515,14 +516,14 @@ extern "C" int mk_setop_finish(mk_setop *s, const uint32_t **ids_out, uint64_t *
     (void)hipFree(s->d_out);
     s->d_out = nullptr; s->out_cap = 0;
     const uint64_t cap = total + total / 8 + 1024;
-    MK_SET_HIP(s, hipMalloc(&s->d_out, cap * 4));
+    MK_SET_HIP(s, mk_dev_alloc(&s->d_out, cap * 4));
     s->out_cap = cap;
   }
   if (total > s->h_cap) {
     if (s->h_out) (void)hipHostFree(s->h_out);
     s->h_out = nullptr; s->h_cap = 0;
     const uint64_t cap = total + total / 8 + 1024;
-    MK_SET_HIP(s, hipHostMalloc((void **)&s->h_out, cap * 4, hipHostMallocDefault));
+    MK_SET_HIP(s, mk_pin_alloc((void **)&s->h_out, cap * 4, hipHostMallocDefault));
     s->h_cap = cap;
   }
   if (total) {
@@ -545,7 +546,7 @@ static int mk_set_grow(mk_setop *s, void **p, uint64_t *cap, uint64_t need, size
   (void)hipFree(*p);
   *p = nullptr; *cap = 0;
   const uint64_t c = need + need / 8 + 1024;
-  MK_SET_HIP(s, hipMalloc(p, c * elem));
+  MK_SET_HIP(s, mk_dev_alloc(p, c * elem));
   *cap = c;
   return MK_OK;
 }
@@ -607,7 +608,7 @@ static int mk_set_result_to_host(mk_setop *s, uint64_t total) {
     if (s->h_out) (void)hipHostFree(s->h_out);
     s->h_out = nullptr; s->h_cap = 0;
     const uint64_t cap = total + total / 8 + 1024;
-    MK_SET_HIP(s, hipHostMalloc((void **)&s->h_out, cap * 4, hipHostMallocDefault));
+    MK_SET_HIP(s, mk_pin_alloc((void **)&s->h_out, cap * 4, hipHostMallocDefault));
     s->h_cap = cap;
   }
   if (total) {

@@ -68,3 +68,70 @@ def oracle_for():
         return Oracle(shuf.c.id, shuf.c.k, shuf.c.subk, shuf.c.drlevel, shuf.table)
 
     return make
+
+
+# ---- failing tests keep their evidence ------------------------------------------------------------------------------------------
+# Every subprocess.run() of a test is logged (command, return code, ends of stdout / stderr); when the test fails, the log, pytest's
+# report and the test's tmp_path (files up to 4 MiB each, 48 MiB in all; no .shuf tables) are copied to gpurun_out/fail_<test>/ --
+# the directory gpurun brings home from the GPU box.  A pipeline test of seven product processes then says WHICH process differed.
+_FAIL_ROOT = os.path.join(ROOT, "gpurun_out")
+
+
+@pytest.fixture(autouse=True)
+def _stage_log(request, monkeypatch):
+    import subprocess
+    log = []
+    real_run = subprocess.run
+
+    def run(*args, **kw):
+        r = real_run(*args, **kw)
+        try:
+            def tail(b):
+                if b is None:
+                    return ""
+                if isinstance(b, bytes):
+                    b = b.decode(errors="replace")
+                return b[-2000:]
+            log.append({"cmd": r.args if isinstance(r.args, (list, tuple)) else [r.args], "rc": r.returncode,
+                        "stdout_tail": tail(r.stdout), "stderr_tail": tail(r.stderr)})
+        except Exception:  # the log must never fail a test
+            pass
+        return r
+
+    monkeypatch.setattr(subprocess, "run", run)
+    request.node._mk_stage_log = log
+    yield
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.when != "call" or not rep.failed:
+        return
+    try:
+        import json
+        import re
+        import shutil
+        name = re.sub(r"[^A-Za-z0-9_.-]+", "_", item.nodeid.split("::", 1)[-1])[:120]
+        dst = os.path.join(_FAIL_ROOT, "fail_" + name)
+        os.makedirs(dst, exist_ok=True)
+        with open(os.path.join(dst, "report.txt"), "w") as f:
+            f.write(item.nodeid + "\n\n" + str(rep.longrepr) + "\n")
+        with open(os.path.join(dst, "stages.json"), "w") as f:
+            json.dump([{**s, "cmd": [str(c) for c in s["cmd"]]} for s in getattr(item, "_mk_stage_log", [])], f, indent=1)
+        tmp = item.funcargs.get("tmp_path") if hasattr(item, "funcargs") else None
+        if tmp is not None and os.path.isdir(str(tmp)):
+            budget = 48 << 20
+            for d, _, files in os.walk(str(tmp)):
+                for fn in sorted(files):
+                    src = os.path.join(d, fn)
+                    sz = os.path.getsize(src)
+                    if fn.endswith(".shuf") or sz > (4 << 20) or sz > budget:
+                        continue
+                    out = os.path.join(dst, "tmp", os.path.relpath(src, str(tmp)))
+                    os.makedirs(os.path.dirname(out), exist_ok=True)
+                    shutil.copyfile(src, out)
+                    budget -= sz
+    except Exception as exc:  # never mask the test's own failure
+        sys.stderr.write("conftest: could not keep the failure's evidence: %r\n" % (exc,))
