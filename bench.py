@@ -181,15 +181,26 @@ _FREE_BASELINE = {}
 _GPU_TOUCHED = [False]  # set when main() makes its first HIP call
 
 
+def _card_index():
+    """the rocm-smi card this process's device 0 is: the first entry of HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when it is a number, else 0"""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var, "").split(",")[0].strip()
+        if v.isdigit():
+            return int(v)
+    return 0
+
+
 def _vram_used_no_context():
-    """bytes of device memory in use by ANY process, from `rocm-smi --showmeminfo vram --json` (the largest figure if it lists several cards); None when
-    that is not to be had"""
+    """bytes of device memory in use by ANY process on THIS process's card, from `rocm-smi --showmeminfo vram --json` (sysfs, no HIP context);
+    None when that is not to be had (no rocm-smi, or the card is not listed)"""
     try:
         r = subprocess.run(["rocm-smi", "--showmeminfo", "vram", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=5)
         txt = r.stdout.decode(errors="replace")
         j = json.loads(txt[txt.index("{"):])
-        vals = [int(v["VRAM Total Used Memory (B)"]) for v in j.values() if isinstance(v, dict) and "VRAM Total Used Memory (B)" in v]
-        return max(vals) if vals else None
+        v = j.get("card%d" % _card_index())
+        if isinstance(v, dict) and "VRAM Total Used Memory (B)" in v:
+            return int(v["VRAM Total Used Memory (B)"])
+        return None
     except Exception:  # noqa: BLE001
         return None
 
@@ -227,6 +238,89 @@ def wait_device_quiet(tag="gpu", least=2.0, most=8.0):
         time.sleep(0.25)
     except Exception:  # noqa: BLE001
         time.sleep(2.5)
+
+
+def _file_read_seconds(path, threads=32, piece=8 << 20):
+    """seconds `threads` threads take to pread the whole file (page cache / tmpfs) into buffers of their own: the floor under any front end
+    that has to look at every byte of the FASTQ (os.preadv releases the GIL)"""
+    import threading
+    size = os.path.getsize(path)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        npieces = (size + piece - 1) // piece
+        nxt = [0]
+        lock = threading.Lock()
+
+        def work():
+            buf = bytearray(piece)
+            while True:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 1
+                if i >= npieces:
+                    return
+                os.preadv(fd, [buf], i * piece)
+        th = [threading.Thread(target=work) for _ in range(threads)]
+        t0 = time.perf_counter()
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return time.perf_counter() - t0
+    finally:
+        os.close(fd)
+
+
+def leg_e2e_gz(capi, cli, sp, tmp, nreads=5_000_000, pieces=16, reps=2):
+    """row a5's everyday form: the same kind of reads gzip-compressed.  The command line reads a .gz through ONE `zcat -fc` child like the
+    reference (iseq2comem.c:666-669), so inflate on one core bounds it -- two orders of magnitude under the plain-file rate."""
+    import numpy as np
+    import statistics
+    gz = os.path.join(tmp, "reads_gz.fq.gz")
+    per = nreads // pieces
+    procs = []
+    for i in range(pieces):  # written and compressed piece by piece in parallel (gzip -1), concatenated: a multi-member .gz, which zcat reads as one
+        part = os.path.join(tmp, "gzpart%02d.fq" % i)
+        rc = capi.lib.mk_synth_fastq_write_mt(part.encode(), SEED, i * per, per, READ_LEN, 2)
+        if rc != 0:
+            return {"gbases_s": None, "what": "skipped: writing a FASTQ piece failed (%d)" % rc}
+        procs.append(subprocess.Popen(["gzip", "-1", part]))
+    if any(p.wait() != 0 for p in procs):
+        return {"gbases_s": None, "what": "skipped: gzip failed"}
+    with open(gz, "wb") as f:
+        for i in range(pieces):
+            part = os.path.join(tmp, "gzpart%02d.fq.gz" % i)
+            with open(part, "rb") as g:
+                shutil.copyfileobj(g, f, 16 << 20)
+            os.unlink(part)
+    n = per * pieces
+    plain = os.path.join(tmp, "reads_gz_plain.fq")
+    capi.lib.mk_synth_fastq_write_mt(plain.encode(), SEED, 0, n, READ_LEN, 16)
+    walls, out = [], None
+    for rep in range(reps + 1):
+        out = os.path.join(tmp, "out_gz%d" % rep)
+        wait_device_quiet()
+        m0 = time.monotonic()
+        r = subprocess.run([cli, "dist", "-L", sp, "-A", "-o", out, "--quiet", gz], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        m1 = time.monotonic()
+        if r.returncode != 0:
+            return {"gbases_s": None, "what": "CLI failed on the .gz: " + r.stderr.decode(errors="replace")[-300:]}
+        if rep:
+            walls.append(m1 - m0)
+    t0 = time.perf_counter()
+    subprocess.run("zcat -fc %s > /dev/null" % gz, shell=True)
+    t_zcat = time.perf_counter() - t0
+    outp = os.path.join(tmp, "out_gz_plain")
+    r = subprocess.run([cli, "dist", "-L", sp, "-A", "-o", outp, "--quiet", plain], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    same = None
+    if r.returncode == 0:
+        same = all(open(os.path.join(out, f), "rb").read() == open(os.path.join(outp, f), "rb").read() for f in ("combco.0", "combco.0.a", "combco.index.0"))
+    w = statistics.median(walls)
+    os.unlink(plain)
+    return {"gbases_s": n * READ_LEN / w / 1e9, "seconds": w, "all_runs_s": [round(x, 3) for x in walls], "reads": n,
+            "gz_bytes": os.path.getsize(gz), "zcat_alone_s": t_zcat, "zcat_alone_gbases_s": n * READ_LEN / t_zcat / 1e9,
+            "sketch_equals_plain_file_run": same,
+            "what": "`metakssd dist -L L3K11.shuf -A -o out --quiet reads.fq.gz`, %d reads (gzip -1, %d members), the parent's clock around the whole "
+                    "process, median of %d runs after a warm-up; the input comes through one `zcat -fc` child as in the reference "
+                    "(iseq2comem.c:666-669): `zcat_alone_s` is that child's time on its own, the floor of this leg" % (n, pieces, reps)}
 
 
 def leg_e2e(capi, shuf, n, resident_sketch, reps=5):
@@ -280,7 +374,25 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=5):
         same = None if resident_sketch is None else bool(np.array_equal(ids, resident_sketch[0][0]) and np.array_equal(cnt, resident_sketch[0][1]))
         keys = ("hip_ready", "engine_ready", "first_push", "last_push", "unmapped", "written", "finish_s", "threads", "chunks",
                 "chunks_discarded", "serial_rows", "stream_setup_s", "stream_wait_frame_s", "push_call_s", "wait_call_s")
-        return {"gbases_s": bases / max(t_written, 1e-9) / 1e9, "seconds": t_written,
+        # what this leg cannot go below on this box: every byte of the file has to come out of tmpfs once (measured here: 32 threads pread
+        # it into buffers of their own, best of 3) and the HIP runtime has to come up (the runs' own median); the framers, the link (0.06 s
+        # for the packed rows at 55 GB/s) and the kernels run beside the reading
+        try:
+            t_read = min(_file_read_seconds(fq) for _ in range(3))
+        except Exception:  # noqa: BLE001
+            t_read = None
+        t_init = med([t.get("hip_ready", 0.0) for _, t, _ in runs])
+        ceiling = None if t_read is None else {
+            "file_read_s": t_read, "file_read_gb_s": os.path.getsize(fq) / t_read / 1e9, "hip_init_s": t_init,
+            "gbases_s": bases / (t_read + t_init) / 1e9,
+            "what": "bases / (file_read_s + hip_init_s): the file's bytes out of tmpfs once (32 threads, pread, best of 3, measured in this run) "
+                    "and the HIP runtime's start-up (median of the runs); t_e2e.gbases_s is to be read against THIS, not against `value`"}
+        try:
+            gz = leg_e2e_gz(capi, cli, sp, tmp)
+        except Exception as ex:  # noqa: BLE001
+            gz = {"gbases_s": None, "what": "failed: %s" % str(ex)[:200]}
+        return {"gbases_s": bases / max(t_written, 1e-9) / 1e9, "seconds": t_written, "ceiling": ceiling,
+                "frac_of_ceiling": None if not ceiling else bases / max(t_written, 1e-9) / 1e9 / ceiling["gbases_s"], "t_e2e_gz": gz,
                 "gbases_s_wall": bases / t_wall / 1e9, "wall_s": t_wall,
                 "gbases_s_excl_init": bases / max(t_work, 1e-9) / 1e9, "seconds_excl_init": t_work, "init_s": tm.get("hip_ready"),
                 "file_gb": os.path.getsize(fq) / 1e9,
@@ -319,6 +431,31 @@ def _sketch_blocks(d):
     return out
 
 
+def write_genomes(gd, genomes, mbases, want_seqs=0):
+    """`genomes` multi-FASTA files g0000.fna .. in directory gd: one pool of random bases laid out as 70-column lines; a genome = two contigs,
+    each a run of whole lines from a position of its own (distinct genomes, no per-genome formatting work).  Returns (bases per genome,
+    the first `want_seqs` genomes' sequences as bytes without line ends -- for drawing reads from)"""
+    import numpy as np
+    os.makedirs(gd)
+    rs = np.random.RandomState(5)
+    nlines_pool = int(3 * mbases * 1e6 / 70)
+    pool = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, size=(nlines_pool, 70))]
+    pool = np.concatenate([pool, np.full((nlines_pool, 1), 10, np.uint8)], axis=1).reshape(-1)
+    half = int(mbases * 1e6 / 2 / 70)  # lines per contig
+    seqs = []
+    for i in range(genomes):
+        a = (i * 7919) % (nlines_pool - 2 * half - 1)
+        b = (a + half + 1 + (i * 104729) % (nlines_pool - 2 * half - 1)) % (nlines_pool - half)
+        with open(os.path.join(gd, "g%04d.fna" % i), "wb") as f:
+            f.write(b">g%d_contig0\n" % i)
+            f.write(pool[71 * a: 71 * (a + half)].tobytes())
+            f.write(b">g%d_contig1\n" % i)
+            f.write(pool[71 * b: 71 * (b + half)].tobytes())
+        if i < want_seqs:
+            seqs.append((pool[71 * a: 71 * (a + half)].reshape(-1, 71)[:, :70].tobytes(), pool[71 * b: 71 * (b + half)].reshape(-1, 71)[:, :70].tobytes()))
+    return 2 * half * 70, seqs
+
+
 def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=48, extra_flags=(), only=None):
     """BASELINE config 5: `metakssd dist -L <shuf> -o out <genome directory>` (no -A) on synthetic multi-FASTA genomes in
     /dev/shm, L3K10 and L2K11, whole command line by the parent's clock; the compiled reference on a few of the genomes"""
@@ -333,25 +470,9 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=4
     tmp = tempfile.mkdtemp(prefix="mkc5_", dir=shm)
     try:
         gd = os.path.join(tmp, "genomes")
-        os.makedirs(gd)
-        # one pool of random bases laid out as 70-column lines; a genome = two contigs, each a run of whole lines from a
-        # position of its own (distinct genomes, no per-genome formatting work)
-        rs = np.random.RandomState(5)
-        nlines_pool = int(3 * mbases * 1e6 / 70)
-        pool = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, size=(nlines_pool, 70))]
-        pool = np.concatenate([pool, np.full((nlines_pool, 1), 10, np.uint8)], axis=1).reshape(-1)
-        half = int(mbases * 1e6 / 2 / 70)  # lines per contig
         t0 = time.perf_counter()
-        for i in range(genomes):
-            a = (i * 7919) % (nlines_pool - 2 * half - 1)
-            b = (a + half + 1 + (i * 104729) % (nlines_pool - 2 * half - 1)) % (nlines_pool - half)
-            with open(os.path.join(gd, "g%04d.fna" % i), "wb") as f:
-                f.write(b">g%d_contig0\n" % i)
-                f.write(pool[71 * a: 71 * (a + half)].tobytes())
-                f.write(b">g%d_contig1\n" % i)
-                f.write(pool[71 * b: 71 * (b + half)].tobytes())
+        bases_each, _ = write_genomes(gd, genomes, mbases)
         t_write = time.perf_counter() - t0
-        bases_each = 2 * half * 70
         cli = os.path.join(ROOT, "metakssd_amd", "bin", "metakssd")
         ref = os.path.join(ROOT, "oracle", "_ref", "metakssd")
         out = {"genomes": genomes, "bases_per_genome": bases_each, "threads": threads, "write_s": round(t_write, 2),
@@ -442,6 +563,255 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=4
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def leg_next_rows_cli(capi, genomes=1024, mbases=4.0, queries=8, reads_per_query=200_000, search_queries=64):
+    """SURVEY.md 8f rows N3 / N4 through the product command line on a stated synthetic database, the compiled reference timed beside it on
+    the SAME directories (they are the reference's own formats) and its outputs compared:
+      markers   `set -g tax` -> `set -q` -> `set -i`   the README's MarkerDB recipe on the L3K10 sketch directory of `genomes` genomes, one species each
+      composite `composite -r db -q qsk`                `queries` -A sketches of reads drawn from the first genomes (command_composite.c:446-649)
+      stage II  `dist -o mco sk`                        the inverted index incl. its 32 GiB mco.index.0 (co2mco.c:12-87)
+      search    `dist -r mco -o hits qsk64`             shared-k-mer counts + distance.out of `search_queries` genome sketches (command_dist.c:902-1079)
+    Every figure is the parent's clock around a whole process."""
+    import numpy as np
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    if not shm:
+        return {"what": "skipped: no /dev/shm"}
+    st = os.statvfs(shm)
+    free = st.f_bavail * st.f_frsize
+    if free < 50e9:
+        return {"what": "skipped: /dev/shm has %.0f GB free (the product's mco.index.0 alone is 34 GB)" % (free / 1e9)}
+    with_ref_index = free > 95e9
+    tmp = tempfile.mkdtemp(prefix="mknext_", dir=shm)
+    cli = os.path.join(ROOT, "metakssd_amd", "bin", "metakssd")
+    ref = os.path.join(ROOT, "oracle", "_ref", "metakssd")
+    cores = os.cpu_count() or 1
+    out = {"database": "%d synthetic genomes of %.1f Mbases (BASELINE config 5's generator), L3K10, one species per genome" % (genomes, mbases)}
+
+    def run(cmd, timeout=None, **kw):
+        wait_device_quiet(least=0.5, most=4.0)
+        m0 = time.monotonic()
+        r = subprocess.run(cmd, cwd=tmp, input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, **kw)
+        return r, time.monotonic() - m0
+
+    def run_ref(cmd, timeout):
+        m0 = time.monotonic()
+        try:
+            r = subprocess.run(cmd, cwd=tmp, input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            return r, time.monotonic() - m0
+        except subprocess.TimeoutExpired:
+            return None, time.monotonic() - m0
+    try:
+        gd = os.path.join(tmp, "genomes")
+        bases_each, seqs = write_genomes(gd, genomes, mbases, want_seqs=2 * queries)
+        sp = os.path.join(tmp, "L3K10.shuf")
+        capi.Shuf.generate(10, 6, 3, 10).write(sp)
+        open(os.path.join(tmp, "tax.tsv"), "w").write("".join("%d\tspecies %d\n" % (i + 1, i + 1) for i in range(genomes)))
+        # queries: reads of 150 bases from two genomes each, both strands
+        rs = np.random.RandomState(77)
+        comp = np.zeros(256, np.uint8)
+        comp[list(b"ACGT")] = list(b"TGCA")
+        for q in range(queries):
+            recs = np.empty((reads_per_query, 3 + READ_LEN + 3 + READ_LEN + 1), np.uint8)
+            recs[:, :3] = np.frombuffer(b"@r\n", np.uint8)
+            recs[:, 3 + READ_LEN:6 + READ_LEN] = np.frombuffer(b"\n+\n", np.uint8)
+            recs[:, 6 + READ_LEN:6 + 2 * READ_LEN] = ord("I")
+            recs[:, -1] = 10
+            half = reads_per_query // 2
+            for j, (lo, hi) in enumerate(((0, half), (half, reads_per_query))):
+                g = np.frombuffer(seqs[2 * q + j][rs.randint(0, 2)], np.uint8)
+                pos = rs.randint(0, g.size - READ_LEN, size=hi - lo)
+                win = np.lib.stride_tricks.sliding_window_view(g, READ_LEN)[pos]
+                rc_ = rs.rand(hi - lo) < 0.5
+                win = np.where(rc_[:, None], comp[win[:, ::-1]], win)
+                recs[lo:hi, 3:3 + READ_LEN] = win
+            recs.tofile(os.path.join(tmp, "q%d.fq" % q))
+        del seqs
+        qfiles = ["q%d.fq" % q for q in range(queries)]
+        steps = [("dist", [cli, "dist", "-L", sp, "-o", "sk", "--quiet", gd]),
+                 ("set_g", [cli, "set", "-g", "tax.tsv", "-o", "grp", "sk"]), ("set_q", [cli, "set", "-q", "-o", "uq", "grp"]),
+                 ("set_i", [cli, "set", "-i", "uq", "-o", "db", "grp"]),
+                 ("dist_A_queries", [cli, "dist", "-L", sp, "-A", "-o", "qsk", "--quiet"] + qfiles),
+                 ("dist_search_queries", [cli, "dist", "-L", sp, "-o", "qsk64", "--quiet"] + [os.path.join(gd, "g%04d.fna" % i) for i in range(search_queries)])]
+        walls = {}
+        for name, cmd in steps:
+            r, w = run(cmd)
+            if r.returncode != 0:
+                out["what"] = "step %s failed: %s" % (name, r.stderr.decode(errors="replace")[-300:])
+                return out
+            walls[name] = round(w, 4)
+        out["markerdb_steps_s"] = walls
+        ncomp = 1
+        out["db_ids"] = int(os.path.getsize(os.path.join(tmp, "db", "combco.0")) // 4) if os.path.exists(os.path.join(tmp, "db", "combco.0")) else None
+        out["query_ids"] = int(os.path.getsize(os.path.join(tmp, "qsk", "combco.0")) // 4)
+
+        # ---- composite (N3) ----
+        ws, txt = [], None
+        for rep in range(4):
+            r, w = run([cli, "composite", "-r", "db", "-q", "qsk"])
+            if r.returncode != 0:
+                out["composite"] = {"what": "failed: " + r.stderr.decode(errors="replace")[-300:]}
+                break
+            txt = r.stdout
+            if rep:
+                ws.append(w)
+        if txt is not None:
+            import statistics
+            comp_leg = {"seconds": statistics.median(ws), "all_runs_s": [round(x, 4) for x in ws], "lines": len(txt.splitlines()), "queries": queries,
+                        "what": "`metakssd composite -r db -q qsk`: %d query sketches (-A, %d reads each) against the marker database of %d species; the "
+                                "parent's clock around the whole process, median of 3 after a warm-up" % (queries, reads_per_query, genomes)}
+            if os.path.exists(ref):
+                rr, wr = run_ref([ref, "composite", "-r", "db", "-q", "qsk"], 120)
+                comp_leg["cpu_baseline"] = ({"seconds": wr, "cores": cores, "kind": "reference",
+                                             "sample": "oracle/_ref/metakssd composite on the same two directories (the whole workload)",
+                                             "output_equals_reference": bool(rr.returncode == 0 and rr.stdout == txt)} if rr is not None else
+                                            {"seconds": None, "kind": "reference", "sample": "not finished after 120 s (stopped)"})
+            out["composite"] = comp_leg
+
+        # ---- stage II (N4) ----
+        r, w = run([cli, "dist", "--quiet", "-o", "mco", "sk"])
+        if r.returncode != 0:
+            out["stage2"] = {"what": "failed: " + r.stderr.decode(errors="replace")[-300:]}
+            return out
+        n_ids = int(os.path.getsize(os.path.join(tmp, "sk", "combco.0")) // 4)
+        out["stage2"] = {"seconds": w, "ids": n_ids, "index_bytes": os.path.getsize(os.path.join(tmp, "mco", "mco.index.0")),
+                         "what": "`metakssd dist -o mco sk`: the inverted index of the %d-genome sketch directory (%d ids) incl. the dense 2^32-row "
+                                 "mco.index.0 written to tmpfs; one run, the parent's clock" % (genomes, n_ids)}
+        # ---- search (N4) ----
+        ws = []
+        for rep in range(3):
+            shutil.rmtree(os.path.join(tmp, "hits"), ignore_errors=True)
+            r, w = run([cli, "dist", "--quiet", "-r", "mco", "-o", "hits", "qsk64"])
+            if r.returncode != 0:
+                out["search"] = {"what": "failed: " + r.stderr.decode(errors="replace")[-300:]}
+                return out
+            if rep:
+                ws.append(w)
+        import statistics
+        out["search"] = {"seconds": statistics.median(ws), "all_runs_s": [round(x, 4) for x in ws], "queries": search_queries, "references": genomes,
+                         "distance_lines": sum(1 for _ in open(os.path.join(tmp, "hits", "distance.out"))),
+                         "what": "`metakssd dist -r mco -o hits qsk64`: %d genome sketches against the %d-genome index (index gather on the host, "
+                                 "counting on the device, distance.out); median of 2 after a warm-up" % (search_queries, genomes)}
+        if os.path.exists(ref) and with_ref_index:
+            rr, wr = run_ref([ref, "dist", "-p", str(cores), "-o", "mco_ref", "sk"], 100)
+            if rr is None or rr.returncode != 0:
+                out["stage2"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "cores": cores,
+                                                 "sample": "oracle/_ref/metakssd dist -o on the same sketch directory: not finished after 100 s (stopped)"}
+            else:
+                import filecmp
+                same = all(filecmp.cmp(os.path.join(tmp, "mco", f), os.path.join(tmp, "mco_ref", f), shallow=False) for f in ("mco.0", "mcofiles.stat", "mco.index.0"))
+                out["stage2"]["cpu_baseline"] = {"seconds": wr, "kind": "reference", "cores": cores,
+                                                 "sample": "oracle/_ref/metakssd dist -p %d -o on the same sketch directory (the whole workload)" % cores,
+                                                 "files_equal_reference": bool(same)}
+                rr2, wr2 = run_ref([ref, "dist", "-p", str(cores), "-r", "mco_ref", "-o", "hits_ref", "qsk64"], 60)
+                if rr2 is not None and rr2.returncode == 0:
+                    out["search"]["cpu_baseline"] = {"seconds": wr2, "kind": "reference", "cores": cores,
+                                                     "sample": "oracle/_ref/metakssd dist -p %d -r on the same index and queries" % cores,
+                                                     "distance_out_equals_reference": bool(filecmp.cmp(os.path.join(tmp, "hits", "distance.out"),
+                                                                                                       os.path.join(tmp, "hits_ref", "distance.out"), shallow=False))}
+                else:
+                    out["search"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "sample": "not finished after 60 s (stopped)"}
+        elif os.path.exists(ref):
+            out["stage2"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "sample": "skipped: /dev/shm too small for a second 34 GB index"}
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def leg_next_rows_kernels(capi, device=0, refs=5000, ids=20000, queries=500, join_ref_ids=100_000_000, join_query_ids=1_573_525):
+    """the dominant kernels of rows N3 / N4 at a stated synthetic size, in this process through the C ABI, each with a roofline entry from the
+    handle's own HIP events (mk_setop_last_join_ms / mk_mco_last_kernel_ms):
+      join   mk_setop_join: a query sketch of config 3's size against 100 M reference ids in 20 000 blocks (HBM: every reference id read)
+      sort   the radix sort inside mk_mco_build: 4 passes over (id, genome) pairs (HBM: a pair read and written per pass)
+      count  mk_mco_count_add's counting kernel: LDS counters, the genome lists streamed from HBM"""
+    import numpy as np
+    out = {}
+    rs = np.random.RandomState(5)
+    # ---- join ----
+    q = np.unique(rs.randint(0, 2 ** 32, size=join_query_ids, dtype=np.uint64).astype(np.uint32))
+    qab = rs.randint(1, 200, size=q.size).astype(np.uint16)
+    ref = rs.randint(0, 2 ** 32, size=join_ref_ids, dtype=np.uint64).astype(np.uint32)
+    ref[::50] = q[rs.randint(0, q.size, size=ref[::50].size)]  # 2 % of the reference ids are in the query
+    bounds = np.sort(np.concatenate([[0, ref.size], rs.randint(0, ref.size, size=19999)])).astype(np.uint64)
+    so = capi.SetOp(device)
+    try:
+        ms, walls, nmatch = [], [], 0
+        for it in range(4):
+            t0 = time.perf_counter()
+            cts, _ = so.join(q, qab, ref, bounds)
+            walls.append(time.perf_counter() - t0)
+            ms.append(so.last_join_ms())
+            nmatch = int(cts.size)
+        k_ms = min(ms[1:])
+        asize = 1024
+        while asize < 2 * q.size:
+            asize <<= 1
+        alg = 4.0 * ref.size + 4.0 * nmatch + 6.0 * q.size + 8.0 * asize  # reference ids in, matched counts out, the query's ids + counts, its dictionary
+        out["join"] = {"ref_ids": int(ref.size), "blocks": 20000, "query_ids": int(q.size), "matches": nmatch, "kernel_ms": k_ms,
+                       "call_ms_with_copies": min(walls[1:]) * 1e3,
+                       "roofline": {"bound": "hbm", "kernel": "mk_grp_insert_kernel + mk_set_fcount_kernel<join> + mk_set_fwrite_kernel<join>",
+                                    "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "traffic": None, "algorithmic_bytes": alg,
+                                    "note": "algorithmic = 4 B per reference id + 4 B per match + the query (6 B an id) + its dictionary (8 B a slot); the two "
+                                            "passes (count, write) read the reference ids twice and probe the dictionary (random 8-byte reads, L2-resident at "
+                                            "this size): expect traffic of about twice the algorithmic bytes"},
+                       "what": "mk_setop_join, host arrays in; kernel_ms = dictionary build + both passes over the reference ids from the handle's HIP "
+                               "events (best of 3 after a warm-up), call_ms_with_copies = the whole call incl. the 400 MB upload from pageable memory"}
+    finally:
+        so.close()
+    del ref, q, qab
+    # ---- stage II sort + counting ----
+    R, G, Q = refs, ids, queries
+    universe = np.unique(rs.randint(0, 2 ** 32, size=R * 40 + 4 * G, dtype=np.uint64).astype(np.uint32))
+    sizes = rs.randint(G // 2, G + G // 2, size=R)
+    starts = np.sort(rs.randint(0, universe.size - 2 * G, size=R))
+    parts = [rs.permutation(universe[a:a + n]) for a, n in zip(starts, sizes)]
+    allids = np.concatenate(parts)
+    index = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    sel = rs.randint(0, R, size=Q)
+    qids = np.concatenate([parts[i] for i in sel])
+    qindex = np.concatenate([[0], np.cumsum(sizes[sel])]).astype(np.uint64)
+    qctx = sizes[sel].astype(np.uint32)
+    m = capi.Mco(device)
+    try:
+        sort_ms, build_walls = [], []
+        for it in range(3):
+            t0 = time.perf_counter()
+            m.build(allids, index, copy=False)
+            build_walls.append(time.perf_counter() - t0)
+            sort_ms.append(m.last_kernel_ms()[0])
+        s_ms = min(sort_ms[1:])
+        passes = 4
+        alg = passes * 16.0 * allids.size
+        out["stage2_sort"] = {"ids": int(allids.size), "genomes": R, "kernel_ms": s_ms, "call_ms_with_copies": min(build_walls[1:]) * 1e3,
+                              "roofline": {"bound": "hbm", "kernel": "mk_rs_hist_kernel + mk_rs_scan_kernel + mk_rs_scatter_kernel x %d passes" % passes,
+                                           "achieved": alg / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg,
+                                           "note": "algorithmic = %d passes x (8 B pair read + 8 B pair written) per id; the histogram pass reads the keys once "
+                                                   "more (4 B an id a pass)" % passes},
+                              "what": "the stable LSD radix sort of (id, genome) pairs inside mk_mco_build (what combco2mco()'s append loop amounts to); kernel_ms "
+                                      "from the handle's HIP events around all passes, best of 2 after a warm-up"}
+        cnt_ms, cnt_walls, incr = [], [], 0
+        for it in range(3):
+            t0 = time.perf_counter()
+            ct = m.count(R, qindex, qctx, [{"qry_ids": qids}])
+            cnt_walls.append(time.perf_counter() - t0)
+            cnt_ms.append(m.last_kernel_ms()[1])
+            incr = int(ct.sum(dtype=np.uint64))
+        c_ms = min(cnt_ms[1:])
+        alg = 2.0 * incr + 16.0 * qids.size  # the genome lists (16-bit entries below 65 536 genomes) + a row extent per query id
+        out["search_count"] = {"queries": Q, "query_ids": int(qids.size), "references": R, "increments": incr, "kernel_ms": c_ms,
+                               "g_increments_per_s": incr / (c_ms * 1e-3) / 1e9, "call_ms_with_copies": min(cnt_walls[1:]) * 1e3,
+                               "roofline": {"bound": "hbm", "kernel": "mk_mco_pack16_kernel + mk_mco_count_kernel<LDS counters, 16-bit lists>",
+                                            "achieved": alg / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": alg / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg,
+                                            "note": "algorithmic = 2 B per increment (a genome-list entry read) + 16 B per query id (its row extent); what bounds the "
+                                                    "kernel is the LDS atomic rate (one ds_add per increment), not HBM: g_increments_per_s is the figure to read"},
+                               "what": "mk_mco_count_add on the index of the build above (row extents looked up on the device, one LDS counter per reference genome and "
+                                       "workgroup); kernel_ms from the handle's HIP events, best of 2 after a warm-up"}
+    finally:
+        m.close()
+    return out
 
 
 def self_launch(args):
@@ -643,7 +1013,7 @@ def kernel_source_id():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300, help="default: about a second of timed work at 3.5 ms per step")
+    ap.add_argument("--steps", type=int, default=None, help="default: 300 at N = 1 (about a second of timed work at 2.4 ms per step), 40 at N > 1")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads-per-gpu", type=int, default=None, help="weak scaling: this many reads on every rank")
     ap.add_argument("--total-reads", type=int, default=None,
@@ -652,17 +1022,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-legs", action="store_true", help="skip t_stream / t_e2e / config5 (N = 1 only anyway)")
     ap.add_argument("--split-cus", type=int, default=32,
-                    help="N = 1: two engines take the passes in turn, the scan kernel on all but this many compute units and what follows a "
-                         "scan on these (MK_OPT_SPLIT_CUS; a multiple of 32); 0: one engine, one queue -- that flow is timed as well "
-                         "either way (`one_queue` in the line)")
+                    help="N = 1: the SIDE leg `split_queues` -- two engines take the passes in turn, the scan kernel on all but this many compute "
+                         "units and what follows a scan on these (MK_OPT_SPLIT_CUS; a multiple of 32); 0: no side leg.  The headline is always "
+                         "one engine on one queue")
     ap.add_argument("--no-tail-hint", action="store_true", help="experiment: the last pass of a split-queue run does not say that nothing follows it")
-    ap.add_argument("--no-queue-trial", action="store_true", help="(kept for scripts: same as --no-one-queue)")
-    ap.add_argument("--no-one-queue", action="store_true", help="skip the comparison leg on one engine and one queue (profiling: one flow's kernels only)")
+    ap.add_argument("--no-split-leg", dest="no_one_queue", action="store_true", help="skip the split-queue side leg (profiling: the headline flow's kernels only)")
+    ap.add_argument("--split-leg-only", action="store_true",
+                    help="profiling aid: ONLY the split-queue flow is run and timed (its kernels alone under a profiler); the line says so and is "
+                         "not the driver's line")
+    ap.add_argument("--no-queue-trial", action="store_true", help="(kept for scripts: same as --no-split-leg)")
+    ap.add_argument("--no-one-queue", dest="no_one_queue", action="store_true", help="(kept for scripts: same as --no-split-leg)")
     ap.add_argument("--split-two-scan-queues", action="store_true", help="experiment: a scan queue per engine instead of one shared")
     ap.add_argument("--serial-finish", action="store_true",
                     help="profiling aid: wait for every pass's result before the next pass starts (no side-stream work beside the scan)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic (N = 1, host legs on)")
     ap.add_argument("--no-config5", action="store_true", help="skip the genome-directory leg (BASELINE config 5 through the command line)")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the `next_rows` leg (SURVEY.md 8f N3 / N4: composite, stage II, dist -r)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo moves the lists through the host (debug)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (needs --backend gloo)")
@@ -673,13 +1048,20 @@ def main():
                     help="N > 1: how the ranks' partial sketches are merged.  gather: every list to rank 0, one import there.  slices: "
                          "SURVEY.md 8e's alternative -- all-to-all by key %% N, every rank folds a key slice, the reduced slices are rank 0's "
                          "key list.  auto (default): gather below four ranks, slices from four on (what libmetakssd_multi.so does)")
-    ap.add_argument("--inproc-multi", action="store_true",
-                    help="N > 1: after the timed region rank 0 ALSO drives the C product's own multi-GPU path in its process -- "
-                         "libmetakssd_multi.so on devices 0..N-1 (mk_multi_create, one engine per GPU, RCCL group send/recv, "
-                         "mk_multi_finish) -- on the same workload while the other ranks wait off the GPU; reported as `inproc_multi`")
+    ap.add_argument("--inproc-multi", action=argparse.BooleanOptionalAction, default=True,
+                    help="N > 1 (on by default; --no-inproc-multi skips it): after the timed region rank 0 ALSO drives the C product's own "
+                         "multi-GPU path in its process -- libmetakssd_multi.so on devices 0..N-1 (mk_multi_create, one engine per GPU, RCCL "
+                         "group send/recv, mk_multi_finish: what `metakssd dist --devices` runs) -- on the same workload while the other ranks "
+                         "wait off the GPU; reported as `inproc_multi`")
+    ap.add_argument("--one-gpu-reference", action=argparse.BooleanOptionalAction, default=True,
+                    help="N > 1 (on by default): after the timed region rank 0 sketches the WHOLE workload alone on its GPU (the N = 1 point of "
+                         "the same curve: --gpus 1 --total-reads T gives the same figure as a line of its own) -> `same_workload_one_gpu` with "
+                         "speedup and efficiency")
     ap.add_argument("--verify", action="store_true",
                     help="after timing, rank 0 re-sketches ALL ranks' reads on one engine and compares with the merged result")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 300 if args.gpus == 1 else 40
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: start the N ranks ourselves, as a CHILD process, before this process has imported torch or
@@ -700,7 +1082,7 @@ def main():
     if args.same_device:
         local_rank = 0
     # The command-line legs (t_e2e, config 5) run FIRST, while this process has no HIP context: a child's runtime start-up is slower, and
-    # now and then much slower (0.2 instead of 0.055 s), beside a parent that holds one (tools/probe_e2e_parent.py,
+    # now and then much slower (0.2 instead of 0.055 s), beside a parent that holds one (
     # profiles/r05_e2e_parent_state.txt).  Their sketches are compared with the resident passes' further down.
     early = {}
     if world == 1 and not args.no_host_legs and args.total_reads is None:
@@ -715,6 +1097,11 @@ def main():
                 early["config5"] = leg_config5(capi)
             except Exception as ex:  # noqa: BLE001
                 early["config5"] = {"what": "failed: %s" % ex}
+        if not args.no_next_rows:
+            try:
+                early["next_rows"] = leg_next_rows_cli(capi)
+            except Exception as ex:  # noqa: BLE001
+                early["next_rows"] = {"what": "failed: %s" % str(ex)[:300]}
     _GPU_TOUCHED[0] = True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -980,41 +1367,34 @@ def main():
         eng.profile_enable(False)
         return dt, pr
 
+    # The HEADLINE flow is fixed before anything is timed: one engine, one queue, every kernel on the whole device -- what every caller of
+    # the library gets.  The split-queue flow (two engines in turn, MK_OPT_SPLIT_CUS) stays an option of the library and is timed BESIDE the
+    # headline for the same passes and the same warm-up (`split_queues` in the line), never instead of it: over the driver's 20 passes it
+    # won by 0-3 % on some boxes and lost on others (profiles/r05_f_bench_driver_steps20*.json), which is not a rule to pick a headline by.
     one_queue = split_queues = trial = None
-    split_timed = 0  # the compute units the HEADLINE flow leaves to the second queue (0: one engine, one queue)
-    if split:
-        # Both flows are timed for exactly --steps passes each, fenced on both sides; the faster one is the line's headline, the other is
-        # reported beside it (`one_queue` / `split_queues`).  The split-queue flow wins by 3-5 % over hundreds of passes and by 0-4 % over the
-        # driver's 20 (its tail is longer and a late host call costs it a whole bubble); on a box whose GPU is throttled hard it loses
-        # (profiles/r05_split_queues.txt).  The two split-queue engines exist only while their flow runs: their idle queues cost the
-        # one-queue flow 0.3 ms a pass.
-        def leg(dtx, px, what):
-            return {"steps": args.steps, "ms_per_step": dtx / args.steps * 1e3, "gbases_s": float(n) * READ_LEN * args.steps / dtx / 1e9,
-                    "scan_ms": px["scan_ms"] / max(1, px["scan_launches"]), "resolve_ms": px["resolve_ms"] / args.steps, "what": what}
-        what_one = ("one engine, one queue, every kernel on all %d compute units: scan, resolve and compaction of a pass one after the other, "
-                    "layout + dump + result copy beside the next pass (the flow of rounds 1-4)" % eng_cus)
-        what_split = ("two engines in turn, scan kernel on %d compute units, what follows a scan on the other %d (MK_OPT_SPLIT_CUS)"
-                      % (eng_cus - split, split))
-        dt_s, prof_s = run_split(args.steps, max(5, args.warmup))
-        if args.no_one_queue or args.no_queue_trial:
-            dt, prof, split_timed = dt_s, prof_s, split
-        else:
-            dt_o, prof_o = run_one(args.steps, max(3, args.warmup))
-            trial = {"passes_each": args.steps, "split_ms_per_step": dt_s / args.steps * 1e3, "one_queue_ms_per_step": dt_o / args.steps * 1e3}
-            if dt_s <= dt_o:
-                dt, prof, split_timed = dt_s, prof_s, split
-                one_queue = leg(dt_o, prof_o, what_one)
-            else:
-                dt, prof = dt_o, prof_o
-                split_queues = leg(dt_s, prof_s, what_split + ": slower than one queue in this run, so not the headline")
-                split_note = "one engine, one queue: every kernel on the whole device, one after the other (the split-queue flow, timed for the " \
-                             "same %d passes in this run, took %.3f ms a pass against %.3f)" % (args.steps, trial["split_ms_per_step"], trial["one_queue_ms_per_step"])
+    split_timed = 0  # compute units the TIMED flow leaves to a second queue: 0 except under --split-leg-only
+    if args.split_leg_only and split:
+        dt, prof = run_split(args.steps, args.warmup)
+        split_timed = split
     else:
         dt, prof = run_one(args.steps, args.warmup)
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if split and not (args.no_one_queue or args.no_queue_trial or args.split_leg_only) and n <= CONFIG3_READS:
+        try:
+            dt_s, prof_s = run_split(args.steps, args.warmup)
+            split_queues = {"steps": args.steps, "ms_per_step": dt_s / args.steps * 1e3, "gbases_s": float(n) * READ_LEN * args.steps / dt_s / 1e9,
+                            "scan_ms": prof_s["scan_ms"] / max(1, prof_s["scan_launches"]), "resolve_ms": prof_s["resolve_ms"] / args.steps,
+                            "compute_units_scan": eng_cus - split, "compute_units_rest": split,
+                            "what": "NOT the headline: two engines take the passes in turn, scan kernel on %d compute units, candidate resolution + "
+                                    "compaction + clear of the pass before on the other %d beside it (MK_OPT_SPLIT_CUS), same passes and warm-up as "
+                                    "the headline, timed after it" % (eng_cus - split, split)}
+            trial = {"passes_each": args.steps, "warmup_each": args.warmup, "one_queue_ms_per_step": dt / args.steps * 1e3,
+                     "split_ms_per_step": dt_s / args.steps * 1e3, "headline": "one_queue (fixed, not chosen by this run)"}
+        except capi.MkError as ex:
+            split_note = "split queues not available here (%s)" % str(ex)[:160]
 
     if world > 1:  # rank 0's serial tail (gather + import + finish), from three separately fenced steps
         tail["on"] = True
@@ -1045,54 +1425,88 @@ def main():
         del pinned
 
     verified = None
-    need_sketch = args.verify or (world == 1 and not args.no_host_legs) or (world > 1 and args.inproc_multi)
+    need_sketch = args.verify or (world == 1 and not args.no_host_legs) or (world > 1 and (args.inproc_multi or args.one_gpu_reference))
     if need_sketch:
         flags["keep"] = True
         step()
         fence()
         flags["keep"] = False
-    if args.verify and rank == 0:
+    if args.verify and rank == 0 and world == 1:
         import numpy as np
-        tot = total_reads
-        allreads = reads if world == 1 else torch.empty(tot * STRIDE, dtype=torch.uint8, device=dev)
-        if world > 1:
-            capi.synth_rows_device(local_rank, stream, SEED, 0, tot, READ_LEN, STRIDE, allreads.data_ptr())
-            torch.cuda.synchronize()
         # N = 1: the shards-merged-through-export/import sketch of the same reads (8 shards on this one engine) is the check
-        if world == 1:
-            merged = sharded_sketch_one_gpu(torch, capi, eng, reads, n, 8, cap, dev)
-            single = result["sketch"]
-            verified = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(single, merged))
-        else:
-            eng.begin(capi.MK_MODE_KOC)
-            eng.push_reads_device(allreads.data_ptr(), STRIDE, tot, 0)
-            single = eng.finish()
-            verified = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(single, result["sketch"]))
-            if not verified:
-                a, b = single[0], result["sketch"][0]
-                ka = np.sort(a[0].astype(np.uint64) << np.uint64(16) | a[1].astype(np.uint64))
-                kb = np.sort(b[0].astype(np.uint64) << np.uint64(16) | b[1].astype(np.uint64))
-                result["verify_detail"] = {"n_single": int(len(a[0])), "n_merged": int(len(b[0])),
-                                           "same_multiset": bool(len(ka) == len(kb) and np.array_equal(ka, kb))}
-            del allreads
+        merged = sharded_sketch_one_gpu(torch, capi, eng, reads, n, 8, cap, dev)
+        single = result["sketch"]
+        verified = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(single, merged))
 
-    inproc = None
-    if world > 1 and args.inproc_multi:
-        # the other ranks wait on the rendezvous store (a host-side wait: a collective's kernel would spin on their GPUs beside the
-        # engines rank 0 puts there)
+    # ---- N > 1: what rank 0 does alone after the timed region, while the other ranks wait on the rendezvous store (a host-side wait: a
+    # collective's kernel would spin on their GPUs beside the engines rank 0 puts there) --------------------------------------------
+    inproc = one_gpu = None
+    if world > 1 and (args.inproc_multi or args.one_gpu_reference or args.verify):
         import datetime
         store = dist.distributed_c10d._get_default_store()
         torch.cuda.synchronize()
         dist.barrier()
         if rank == 0:
-            try:
-                devs = [0] * world if args.same_device else list(range(world))
-                inproc = leg_inproc_multi(torch, capi, shuf, devs, total_reads, max(3, min(args.steps, 20)), args.merge, result.get("sketch"))
-            except Exception as ex:  # noqa: BLE001
-                inproc = {"gbases_s": None, "what": "failed: %s" % ex}
-            store.set("mk_inproc_multi_done", "1")
+            if args.one_gpu_reference or args.verify:
+                # the SAME workload on ONE GPU: all ranks' reads generated into rank 0's HBM, sketched there by the N = 1 flow (begin, one
+                # push, finish in two halves) -- the N = 1 point of this curve, measured in the same run on the same GPU; its sketch is
+                # also the check of the merged one (--verify)
+                try:
+                    import numpy as np
+                    allreads = torch.empty(total_reads * STRIDE, dtype=torch.uint8, device=dev)
+                    capi.synth_rows_device(local_rank, stream, SEED, 0, total_reads, READ_LEN, STRIDE, allreads.data_ptr())
+                    torch.cuda.synchronize()
+
+                    def whole():
+                        eng.begin(capi.MK_MODE_KOC)
+                        eng.push_reads_device(allreads.data_ptr(), STRIDE, total_reads, 0)
+                        drain()
+                        eng.finish_begin()
+                        flags["pending"] = True
+                    k1 = max(3, min(args.steps, 10))
+                    whole()
+                    drain()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(k1):
+                        whole()
+                    drain()
+                    torch.cuda.synchronize()
+                    dt1 = (time.perf_counter() - t0) / k1
+                    eng.begin(capi.MK_MODE_KOC)
+                    eng.push_reads_device(allreads.data_ptr(), STRIDE, total_reads, 0)
+                    single = eng.finish()
+                    del allreads
+                    torch.cuda.empty_cache()
+                    same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(single, result["sketch"]))
+                    if args.verify:
+                        verified = same
+                        if not same:
+                            a, b = single[0], result["sketch"][0]
+                            ka = np.sort(a[0].astype(np.uint64) << np.uint64(16) | a[1].astype(np.uint64))
+                            kb = np.sort(b[0].astype(np.uint64) << np.uint64(16) | b[1].astype(np.uint64))
+                            result["verify_detail"] = {"n_single": int(len(a[0])), "n_merged": int(len(b[0])),
+                                                       "same_multiset": bool(len(ka) == len(kb) and np.array_equal(ka, kb))}
+                    ms_n = dt / args.steps * 1e3
+                    one_gpu = {"ms_per_step": dt1 * 1e3, "gbases_s": total_reads * READ_LEN / dt1 / 1e9, "passes": k1,
+                               "speedup": dt1 * 1e3 / ms_n, "efficiency": dt1 * 1e3 / ms_n / world, "n_gpus": world,
+                               "sketch_equals_merged": bool(same),
+                               "what": "all %d reads of this workload in rank 0's HBM, sketched by one engine on one GPU (begin, one push of resident "
+                                       "rows with global ordinals, finish in two halves: the N = 1 flow), wall clock over %d passes after a warm-up, after "
+                                       "the timed region while the other ranks wait off their GPUs; speedup = this ms_per_step / the line's "
+                                       "ms_per_step, efficiency = speedup / n_gpus.  `python bench.py --gpus 1 --total-reads %d` prints the same "
+                                       "point as a line of its own" % (total_reads, k1, total_reads)}
+                except Exception as ex:  # noqa: BLE001
+                    one_gpu = {"ms_per_step": None, "efficiency": None, "what": "failed: %s" % str(ex)[:300]}
+            if args.inproc_multi:
+                try:
+                    devs = [0] * world if args.same_device else list(range(world))
+                    inproc = leg_inproc_multi(torch, capi, shuf, devs, total_reads, max(3, min(args.steps, 20)), args.merge, result.get("sketch"))
+                except Exception as ex:  # noqa: BLE001
+                    inproc = {"gbases_s": None, "transport": None, "what": "failed: %s" % ex}
+            store.set("mk_rank0_legs_done", "1")
         else:
-            store.wait(["mk_inproc_multi_done"], datetime.timedelta(seconds=3600))
+            store.wait(["mk_rank0_legs_done"], datetime.timedelta(seconds=3600))
 
     if rank == 0:
         bases_per_step = float(total_reads) * READ_LEN
@@ -1149,14 +1563,17 @@ def main():
                        "distinct_keys": result.get("distinct"),
                        "table_load": (result.get("distinct") or 0) / float(eng.params.hashsize),
                        "finish": "serial (--serial-finish: profiling aid)" if args.serial_finish else "result copy beside the next pass",
-                       "queues": ("two engines take the passes in turn; scan kernel on %d compute units, candidate resolution + compaction + "
-                                  "clear of the pass before on the other %d beside it (MK_OPT_SPLIT_CUS)" % (eng_cus - split_timed, split_timed)) if split_timed
-                                 else (split_note or "one engine, one queue: every kernel on the whole device, one after the other"),
+                       "queues": ("--split-leg-only (profiling aid, NOT the driver's line): two engines in turn, scan kernel on %d compute units, what "
+                                  "follows a scan on the other %d (MK_OPT_SPLIT_CUS)" % (eng_cus - split_timed, split_timed)) if split_timed else
+                                 "one engine, one queue: every kernel on the whole device, one after the other (the flow every caller of the library gets)",
                        "parallelism": "reads sharded x%d, gather to rank 0" % world},
             "roofline": {"bound": "hbm", "kernel": "mk_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms,
                          "launches": prof["scan_launches"], "kernel_source_id": kernel_source_id(),
+                         "profile_files": "profiles/r06_%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this flow, tools/profile_round.sh), "
+                                          "_kernel_stats_serial_finish.csv, _pmc_one_queue.txt, _scan_traffic.json -- present when the profiles were taken "
+                                          "on this kernel source" % kernel_source_id(),
                          "compute_units": eng_cus - split_timed,
                          "measured_copy_gb_s": copy_gbs},
             "phases_ms_per_step": {"clear": prof["clear_ms"] / args.steps, "scan": prof["scan_ms"] / args.steps,
@@ -1169,14 +1586,8 @@ def main():
             line["queue_flows"] = trial
         if split_queues is not None:
             line["split_queues"] = split_queues
-        if split_timed:
-            line["roofline"]["note"] = ("the timed flow runs this kernel on %d of the device's %d compute units (config.queues: the other %d resolve the "
-                                        "pass before beside it), which is what this entry measures" % (eng_cus - split_timed, eng_cus, split_timed)) + (
-                                            "; the same kernel on all %d in the same run: one_queue.scan_roofline" % eng_cus if one_queue is not None else "")
-        if one_queue is not None:
-            sb = scan_bytes / (one_queue["scan_ms"] * 1e-3) / 1e9 if one_queue["scan_ms"] > 0 else 0.0
-            one_queue["scan_roofline"] = {"achieved": sb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sb / HBM_PEAK_GBS, "compute_units": eng_cus}
-            line["one_queue"] = one_queue
+        if split_note:
+            line["split_queues_note"] = split_note
         if seen is not None:
             line["distributed"] = seen
         if world > 1 and tail["steps"]:
@@ -1197,6 +1608,8 @@ def main():
                                 "what": "every rank: %d of its reads as %d-byte rows in pinned host memory -> mk_sketch_push_reads over "
                                         "its own PCIe link -> export, gather to rank 0, one import, finish on rank 0; mean of 3 fenced "
                                         "steps, max over ranks; aggregate over %d ranks" % (ns, STRIDE, world)}
+        if one_gpu is not None:
+            line["same_workload_one_gpu"] = one_gpu
         if inproc is not None:
             line["inproc_multi"] = inproc
         if verified is not None:
@@ -1249,6 +1662,13 @@ def main():
                     line["config5"] = leg_config5(capi)
                 except Exception as ex:
                     line["config5"] = {"what": "failed: %s" % ex}
+        if world == 1 and not args.no_host_legs and not args.no_next_rows:
+            nr = early.get("next_rows", {})
+            try:
+                nr["kernels"] = leg_next_rows_kernels(capi, local_rank)
+            except Exception as ex:  # noqa: BLE001
+                nr["kernels"] = {"what": "failed: %s" % str(ex)[:300]}
+            line["next_rows"] = nr
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

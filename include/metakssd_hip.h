@@ -548,6 +548,9 @@ uint32_t mk_setop_group_table_size(uint64_t total_ids);
 int mk_setop_join(mk_setop *s, const uint32_t *qry_ids, const uint16_t *qry_counts, uint64_t nq, const uint32_t *ref_ids,
                   uint64_t nref, const uint64_t *bounds, uint32_t nb, const uint32_t **counts_out, uint64_t *n_out,
                   uint64_t *bounds_out);
+/* measurement (bench.py's `next_rows` leg): device time of the last join -- dictionary build and the two passes over the reference
+ * ids -- from HIP events on the handle's stream (the loop it replaces: command_composite.c:525-553) */
+int mk_setop_last_join_ms(mk_setop *s, double *ms);
 
 /* ---- stage II and the reference-database search ---------------------------------------------
  * combco2mco() (co2mco.c:12-87) turns a component's combined sketch file (genome-major: combco.N + combco.index.N) into
@@ -587,6 +590,9 @@ int mk_mco_count_begin(mk_mco *m, uint32_t ref_num, uint32_t qry_num);
 int mk_mco_count_add(mk_mco *m, const uint32_t *gids, uint64_t ngids, const uint32_t *qry_ids, const uint64_t *ext_start,
                      const uint64_t *ext_end, const uint64_t *qry_index, const uint32_t *qry_ctx_ct);
 int mk_mco_count_finish(mk_mco *m, uint32_t *ct);
+/* measurement (bench.py's `next_rows` leg): device time of the last build's radix sort and of the last count_add's kernels, from HIP
+ * events on the handle's stream -- the loops they replace are co2mco.c:37-59 and command_dist.c:1035-1048 */
+int mk_mco_last_kernel_ms(mk_mco *m, double *sort_ms, double *count_ms);
 
 /* distance.out (host).  Options as command_dist_wrapper.c:83-92. */
 typedef struct mk_dist_opts {

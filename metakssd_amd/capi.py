@@ -178,6 +178,8 @@ def _load():
         "mk_setop_add_device": [vp, vp, u64],
         "mk_setop_finish": [vp, C.POINTER(vp), C.POINTER(u64)],
         "mk_setop_result_device": [vp, C.POINTER(vp), C.POINTER(u64)],
+        "mk_setop_join": [vp, vp, vp, u64, vp, u64, vp, u32, C.POINTER(vp), C.POINTER(u64), vp],
+        "mk_setop_last_join_ms": [vp, C.POINTER(C.c_double)],
         "mk_mco_create": [C.c_int, C.POINTER(vp)],
         "mk_mco_destroy": [vp],
         "mk_mco_build": [vp, vp, vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
@@ -187,6 +189,7 @@ def _load():
         "mk_mco_count_begin": [vp, u32, u32],
         "mk_mco_count_add": [vp, vp, u64, vp, vp, vp, vp, vp],
         "mk_mco_count_finish": [vp, vp],
+        "mk_mco_last_kernel_ms": [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)],
         "mk_dist_print": [vp, C.POINTER(DistOptsC), i32, i32, u32, u32, vp, vp, vp, vp, vp],
         "mk_sketchdir_open": [C.c_char_p, C.POINTER(ParamsC), C.c_int, C.c_int, C.POINTER(vp)],
         "mk_sketchdir_add": [vp, C.c_char_p, C.POINTER(ResultC)],
@@ -852,6 +855,26 @@ class SetOp:
     def stream(self):
         return lib.mk_setop_stream(self.h)
 
+    def join(self, qry_ids, qry_counts, ref_ids, bounds):
+        """composite -q's join (mk_setop_join): the query's count for every reference position whose id the query holds, in reference
+        order, and where each reference sketch's segment of them ends -> (counts uint32, bounds_out uint64)"""
+        q = np.ascontiguousarray(qry_ids, dtype=np.uint32)
+        qa = np.ascontiguousarray(qry_counts, dtype=np.uint16)
+        r = np.ascontiguousarray(ref_ids, dtype=np.uint32)
+        b = np.ascontiguousarray(bounds, dtype=np.uint64)
+        bout = np.zeros(b.size, np.uint64)
+        out, n = C.c_void_p(), C.c_uint64(0)
+        self._check(lib.mk_setop_join(self.h, q.ctypes.data if q.size else None, qa.ctypes.data if qa.size else None, q.size,
+                                      r.ctypes.data if r.size else None, r.size, b.ctypes.data if b.size else None, b.size,
+                                      C.byref(out), C.byref(n), bout.ctypes.data if b.size else None))
+        cts = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint32)), shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint32)
+        return cts, bout
+
+    def last_join_ms(self):
+        ms = C.c_double(0.0)
+        self._check(lib.mk_setop_last_join_ms(self.h, C.byref(ms)))
+        return ms.value
+
     def close(self):
         if self.h:
             lib.mk_setop_destroy(self.h)
@@ -938,6 +961,12 @@ class Mco:
         if ct.size:
             self._check(lib.mk_mco_count_finish(self.h, ct.ctypes.data))
         return ct
+
+    def last_kernel_ms(self):
+        """(radix sort of the last build, kernels of the last count_add) in ms, from the handle's HIP events"""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        self._check(lib.mk_mco_last_kernel_ms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def close(self):
         if self.h:

@@ -70,11 +70,15 @@ typedef struct {
 } fs_t;
 
 /* the text from offset `off` on: all of it (mapping), or the next piece (descriptor; `scratch` holds FS_PIECE bytes) */
-static fs_view fs_fetch(const fs_t *f, size_t off, uint8_t *scratch) {
+/* `upto`: the caller frames records that START below this offset -- a piece need not reach further than one maximal record (four lines of
+ * fastq2co()'s fgets width) behind it; FS_NONE: a whole piece */
+#define FS_RECORD_MAX ((size_t)4 * 20000 + 4096)
+static fs_view fs_fetch_upto(const fs_t *f, size_t off, uint8_t *scratch, size_t upto) {
   fs_view v = {NULL, 0, 1, 0};
   if (off >= f->n) return v;
   if (f->text) { v.p = f->text + off; v.avail = f->n - off; return v; }
-  const size_t want = f->n - off < f->piece ? f->n - off : f->piece;
+  size_t want = f->n - off < f->piece ? f->n - off : f->piece;
+  if (upto != FS_NONE && upto > off && upto - off + FS_RECORD_MAX < want) want = upto - off + FS_RECORD_MAX;
   size_t got = 0;
   while (got < want) {
     const ssize_t r = pread(f->fd, scratch + got, want - got, (off_t)(off + got));
@@ -85,6 +89,7 @@ static fs_view fs_fetch(const fs_t *f, size_t off, uint8_t *scratch) {
   v.p = scratch; v.avail = got; v.eof = off + got >= f->n;
   return v;
 }
+static fs_view fs_fetch(const fs_t *f, size_t off, uint8_t *scratch) { return fs_fetch_upto(f, off, scratch, (size_t)-1); }
 
 static double fs_now(void) {
   struct timespec ts;
@@ -147,10 +152,10 @@ static uint32_t fs_sample_stride(const uint8_t *t, size_t n, size_t start, int o
  * piece's end is framed from the next piece, which starts at it).  `scratch`: the calling thread's piece buffer (descriptor only). */
 static void fs_frame_range(const fs_t *f, size_t start, size_t stop, int first_of_file, uint8_t *buf, fs_slot *s, uint8_t *scratch) {
   uint32_t stride;
-  {
-    const fs_view v0 = fs_fetch(f, start, scratch);
-    stride = fs_sample_stride(v0.p, v0.avail, 0, f->occ);
-  }
+  /* (descriptor: the piece the stride is sampled from is the first piece the loop below frames -- read once, not twice) */
+  fs_view held = fs_fetch_upto(f, start, scratch, stop);
+  size_t held_off = start;
+  stride = fs_sample_stride(held.p, held.avail, 0, f->occ);
   if (f->occ && stride < 2u * (uint32_t)f->TL + 4u) stride = fs_round_stride(2u * (size_t)f->TL + 4u);
   /* packed rows (64 bytes a read, MK_ROWS_PACKED) when every read of the range has at most 152 bases; a longer one turns up as
    * MK_ERR_ARG and the range is framed again as ASCII rows */
@@ -163,7 +168,8 @@ static void fs_frame_range(const fs_t *f, size_t start, size_t stop, int first_o
     size_t pos = start;
     int rc = MK_OK, again = 0;
     while (pos < stop && rows < max_rows) {
-      const fs_view v = fs_fetch(f, pos, scratch);
+      if (pos != held_off) { held = fs_fetch_upto(f, pos, scratch, stop); held_off = pos; }
+      const fs_view v = held;
       if (v.err) { rc = MK_ERR_IO; break; }
       if (!v.avail) break;
       const size_t st = stop - pos < v.avail ? stop - pos : v.avail;

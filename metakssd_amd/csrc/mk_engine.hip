@@ -629,6 +629,7 @@ extern "C" int mk_engine_create_ex(const mk_params *p, int device, unsigned flag
 }
 
 static int mk_flush_region(mk_engine *e);
+static int mk_tail_end(mk_engine *e);
 
 /* MK_POISON: what the last sketch left in the engine's scratch -- candidate records, the key list, the dump's arrays, the FASTA
  * stream's buffers, the staging regions -- is overwritten with the pattern at the next mk_sketch_begin, on the stream the new sketch's
@@ -716,7 +717,9 @@ extern "C" int mk_engine_set_option(mk_engine *e, int option, int64_t value) {
    * works on are what several options free */
   if (e->res_pending) return mk_fail(e, MK_ERR_STATE, "mk_engine_set_option while a result is outstanding (mk_sketch_finish_end first)");
   MK_HIP(e, hipSetDevice(e->device));
-  { int rc = mk_tables_alloc(e); if (rc) return rc; } /* (a lazily created engine: the options below rebuild pieces of the tables) */
+  /* a lazily created engine (MK_ENGINE_LAZY_TABLES): only the options that rebuild pieces of the hashsize-slot tables make them now; the
+   * others (the command line's --direct, batch table bits, split queues, ..) leave the 21 GB of an L2K11 engine unmade */
+  if (option == MK_OPT_SPARSE || option == MK_OPT_FRONT_BITS || option == MK_OPT_KEYLIST_CAP) { int rc = mk_tables_alloc(e); if (rc) return rc; }
   MK_HIP(e, hipStreamSynchronize(e->stream));
   if (e->res_stream) MK_HIP(e, hipStreamSynchronize(e->res_stream));
   switch (option) {
@@ -776,6 +779,14 @@ extern "C" int mk_engine_set_stream(mk_engine *e, void *hip_stream) {
     MK_HIP(e, hipStreamSynchronize(e->own_stream));
     e->init_queued = false;
   }
+  /* a sketch begun with MK_BEGIN_NOTHING_FOLLOWS left its tail on the unmasked queue: the second queue waits for it and takes over
+   * again first (mk_tail_end), so that what the NEW stream is ordered with below is everything the engine has queued */
+  { int rc = mk_tail_end(e); if (rc) return rc; }
+  if (e->split_stream && (hipStream_t)hip_stream != e->split_stream) { /* (the caller's stream starts behind the engine's queued work) */
+    MK_HIP(e, hipSetDevice(e->device));
+    MK_HIP(e, hipEventRecord(e->ev_scan_pre, e->split_stream));
+    MK_HIP(e, hipStreamWaitEvent((hipStream_t)hip_stream, e->ev_scan_pre, 0));
+  }
   /* NULL is a real stream (HIP's default stream, which is what torch.cuda.current_stream() usually is): it must
    * not mean "keep the engine's own stream", or caller-side ordering silently disappears */
   e->stream = (hipStream_t)hip_stream;
@@ -808,6 +819,7 @@ extern "C" int mk_engine_use_own_stream(mk_engine *e) {
     int rc = mk_flush_region(e);
     if (rc) return rc;
   }
+  { int rc = mk_tail_end(e); if (rc) return rc; } /* (MK_BEGIN_NOTHING_FOLLOWS: the second queue waits for the tail on the unmasked one) */
   e->stream = e->split_stream ? e->split_stream : e->own_stream;
   return MK_OK;
 }
@@ -971,12 +983,6 @@ static hipError_t mk_launch_scan_k(mk_engine *e, int threads, bool onepass, cons
   constexpr int NPBIG = V ? MK_MAX_PIECES : MK_MAX_CB / 4;
   constexpr int NPSMALL = V ? 5 : 20;
   const bool small = a.ppr <= (uint32_t)NPSMALL;
-#ifdef MK_HOT_ONLY /* experiment (make tuning VARIANT=-DMK_HOT_ONLY): what the size of this library's code object costs the first dispatch */
-  if constexpr (V && K != 0) {
-    if (threads == 1024 && small) return onepass ? mk_launch_scan_t<K, SK, V, 1024, NPSMALL, true>(e, a, grid, lds, s) : mk_launch_scan_t<K, SK, V, 1024, NPSMALL, false>(e, a, grid, lds, s);
-  }
-  return hipErrorInvalidValue;
-#else
   if constexpr (V) {
     if (onepass && small) /* one-pass staging: 2 x 5 pieces live */
       return threads >= 1024 ? mk_launch_scan_t<K, SK, V, 1024, NPSMALL, true>(e, a, grid, lds, s)
@@ -988,7 +994,6 @@ static hipError_t mk_launch_scan_k(mk_engine *e, int threads, bool onepass, cons
     case 768: return small ? mk_launch_scan_t<K, SK, V, 768, NPSMALL, false>(e, a, grid, lds, s) : mk_launch_scan_t<K, SK, V, 768, NPBIG, false>(e, a, grid, lds, s);
     default: return small ? mk_launch_scan_t<K, SK, V, 512, NPSMALL, false>(e, a, grid, lds, s) : mk_launch_scan_t<K, SK, V, 512, NPBIG, false>(e, a, grid, lds, s);
   }
-#endif
 }
 
 /* stride: bytes staged per row.  pitch: address step between rows (== stride for rows side by side; the overlapping virtual
@@ -1042,7 +1047,6 @@ static int mk_launch_scan_ex(mk_engine *e, const uint8_t *rows_dev, uint32_t str
   /* workgroup size: as many waves as the LDS budget (filter + per-wave tile and queue) admits */
   int threads = e->tune_threads;
   size_t lds = 0;
-  /* (experiment builds: the pair filter of the tuned subk-6 kernels may be smaller than a.bm_words, MK_ZF_WORDS in mk_kernels.hip.h) */
   const size_t fwords = tuned_k && e->P.subk == 6 && !packed ? (size_t)MK_ZF_WORDS : (size_t)a.bm_words;
   for (;; threads -= 256) {
     lds = ((size_t)a.mt_words + fwords + (size_t)(threads / 64) * a.wave_lds_dwords) * 4u;
@@ -2189,7 +2193,7 @@ static uint64_t mk_rows_per_launch(const mk_engine *e, uint32_t row_bases, int t
 
 /* rows: the files are PACKED ROWS already (mk_fasta_pack_rows on the reader's thread: the FASTA walk done by the host) -- no text,
  * no mk_fab_* kernels; where the rows lie in ONE stretch of pinned memory the scan kernel reads them THERE, through the mapping
- * (tools/attic/probe_hostread.hip: a kernel reads registered host memory at 55.5 GB/s, the copy engine moves it at 57.0 and costs 7.7 ms
+ * (profiles/r04_probe_hostread.jsonl: a kernel reads registered host memory at 55.5 GB/s, the copy engine moves it at 57.0 and costs 7.7 ms
  * of set-up at the first copy of a process) */
 static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *files, uint32_t nfiles, const uint32_t format) {
   if (!e || !files) return MK_ERR_ARG;

@@ -387,12 +387,7 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
       uint4 v;
       const bool on = mk_wring_pop(r2, lane, v);
       mk_wave_lds_fence();
-#if defined(MK_TUNING) && defined(MK_ABL_R) && MK_ABL_R >= 1
-      /* ablation builds (timing only, results WRONG): the .shuf look-up and the table update left out */
-      if (on && v.x == 0xDEADBEEFu && v.y == 0x12345u) atomicOr(&a.tab.err[0], 32u);
-#else
       installed += (uint32_t)__popcll(__ballot(mk_resolve_accepted(ka, on, v, front_open)));
-#endif
     }
   };
   auto drain1 = [&](uint32_t least) {
@@ -400,12 +395,7 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
       uint4 v;
       const bool on = mk_wring_pop(r1, lane, v);
       mk_wave_lds_fence();
-#if defined(MK_TUNING) && defined(MK_ABL_R) && MK_ABL_R >= 2
-      /* ablation: no canonical k-mer, no accept-bit look-up: every 64th candidate goes on so that ring 2 still works */
-      mk_wring_push(r2, on && (v.x & 63u) == 0u, v);
-#else
       mk_resolve_candidate(a, on, v, r2);
-#endif
       mk_wave_lds_fence();
       drain2(64u);
     }
@@ -442,11 +432,6 @@ __global__ void __launch_bounds__(MK_RESOLVE_THREADS) mk_resolve_kernel(const mk
   };
 
   auto process = [&](const uint4 r) {
-#if defined(MK_TUNING) && defined(MK_ABL_R) && MK_ABL_R >= 3
-    /* ablation: the records are fetched and looked at, nothing else */
-    if (__any(r.x == 0xDEADBEEFu && r.y == 0x12345u && r.z == 7u)) atomicOr(&a.tab.err[0], 32u);
-    return;
-#endif
     const bool single = (r.w & 0x80000000u) != 0u;
     if (__any(single)) { /* slow tiers and the generic kernel hand over whole k-mers */
       mk_wring_push(r1, single, make_uint4(r.x, r.y, r.z, r.w & 0x7FFFFFFFu));
@@ -619,13 +604,8 @@ __device__ __forceinline__ uint32_t mk_zmask(uint32_t b) {
   }
   return m;
 }
-/* words of the pair filter.  16384 (64 KiB) in the product.  An experiment build (make tuning VARIANT=-DMK_ZF_WORDS=8192, round 5) halves
- * it -- the word index drops the key's top bit -- so that TWO 512-thread workgroups fit a CU (MK_SCAN_THREADS=512 MK_SCAN_WGS_PER_CU=2):
- * VERDICT r04 item 3(ii); measured in profiles/r05_scan_variants.txt */
-#if !defined(MK_TUNING) || !defined(MK_ZF_WORDS)
-#undef MK_ZF_WORDS
+/* words of the pair filter: 16384 (64 KiB).  (Half of it with two 512-thread workgroups a CU measured slower: profiles/r05_scan_variants.txt) */
 #define MK_ZF_WORDS 16384u
-#endif
 __device__ __forceinline__ void mk_build_zfilter(uint32_t *masktab, uint32_t *bitmap, const mk_scan_args &a) {
   for (uint32_t i = threadIdx.x; i < MK_ZMASK_WORDS; i += blockDim.x) masktab[i] = mk_zmask(i);
   for (uint32_t i = threadIdx.x; i < MK_ZF_WORDS; i += blockDim.x) bitmap[i] = 0u;
@@ -665,7 +645,7 @@ __device__ __forceinline__ void mk_build_filter(uint32_t *bitmap, const mk_scan_
 
 /* ONEPASS (only with exactly two column blocks per row): the loads for BOTH blocks of a tile are issued together,
  * so every 64-byte sector of the rows is requested once -- two separate 80-byte passes re-fetch the sector the
- * halves share (+37 % HBM reads, tools/attic/ubench_fetch.hip).  Costs NPIECES more piece registers. */
+ * halves share (+37 % HBM reads, measured with a fetch micro-benchmark in round 1).  Costs NPIECES more piece registers. */
 template <int K, int SUBK, bool VEC16, int THREADS, int NPIECES, bool ONEPASS>
 __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) {
   static_assert(K == 0 || SUBK == 6 || (SUBK == 5 && K == 11), "tuned instantiations: k 9..11 with subk 6, k 11 with subk 5");
@@ -742,26 +722,14 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
   auto loff_of = [&](int i) { if constexpr (VEC16) return offtab[128 * i + 64]; else return loff_calc(i); };
   auto issue_loads = [&](uint32_t tile_id, uint32_t cb) {
     const uint32_t row0 = tile_id << 6;
-#if defined(MK_TUNING) && defined(MK_ABL_MEM) /* experiment: every wave stages ITS FIRST tile again and again (cache-resident): the kernel without its HBM stream, results wrong */
-    const uint8_t *base = a.rows + (uint64_t)((wave_global < ntiles ? wave_global : 0u) << 6) * a.pitch + (uint64_t)cb * a.CB;
-#else
     const uint8_t *base = a.rows + (uint64_t)row0 * a.pitch + (uint64_t)cb * a.CB;
-#endif
     const uint32_t cols_here = min(a.CB, a.stride - cb * a.CB);
     if constexpr (ONEPASS) {
       /* host guarantees: ncb == 2, stride == 2*CB.  cb is 0 here. */
       if (row0 + 64u <= nreads) {
 #pragma unroll
         for (int i = 0; i < NP; i++)
-#if defined(MK_TUNING) && defined(MK_SCAN_NT) /* experiment: the rows are read once -- non-temporal loads */
-          if ((uint32_t)i < a.ppr) {
-            typedef uint32_t mk_u32x4 __attribute__((ext_vector_type(4)));
-            const mk_u32x4 v1 = __builtin_nontemporal_load((const mk_u32x4 *)(base + goff_of(i))), v2 = __builtin_nontemporal_load((const mk_u32x4 *)(base + a.CB + goff_of(i)));
-            if constexpr (VEC16) { regs[i] = make_uint4(v1.x, v1.y, v1.z, v1.w); regs2[i] = make_uint4(v2.x, v2.y, v2.z, v2.w); }
-          }
-#else
           if ((uint32_t)i < a.ppr) { regs[i] = *(const piece_t *)(base + goff_of(i)); regs2[i] = *(const piece_t *)(base + a.CB + goff_of(i)); }
-#endif
       } else {
         const uint32_t rows_here = (uint32_t)(nreads - row0);
 #pragma unroll
@@ -840,13 +808,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
     if (m == 0) return;
     const uint32_t cnt = (uint32_t)__popcll(m);
     if (qn + cnt > a.cand_cap) { /* buffer full (dense tables only): resolve right here */
-#if defined(MK_TUNING) && defined(MK_ABL) && MK_ABL == 6
-      /* ablation 6: the overflow path without its call (records beyond the buffer are DROPPED: timing only) -- what the call
-       * site inside the hot loop costs the loop */
-      atomicOr(&a.tab.err[0], 16u);
-#else
       mk_resolve_inline(ka, hit, r, K != 0 ? nullptr : bitmap);
-#endif
       return;
     }
     if (hit) my_cand[qn + mk_mbcnt(m)] = r;
@@ -995,7 +957,7 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
          * TL bytes up to it are bases of one row.  The first version of B was the byte-wise predicated path of the generic
          * kernel, entered for the rest of the row: 50 M reads trimmed to 100..150 bases 4.6 -> 2.4 ms, an N in 1 % of the
          * reads 4.5 -> 2.24 ms, in 5 % 7.6 -> 2.5 ms, and the untouched rows 2.28 -> 2.14 ms on the same box (the kernel
-         * lost the byte-wise path, its registers and its spills) (tools/attic/probe_ragged_reads.py). */
+         * lost the byte-wise path, its registers and its spills) (profiles/r02_c_probe_ragged_reads.json). */
         constexpr uint32_t SH = 2u * (K - SUBK) - 2u; /* out2 - 2 */
         constexpr uint32_t HM = mk_kmer<K>::HMASK;
         static_assert(SH + 4u * SUBK <= 32u, "inner substring must lie inside flo(j-1)");
@@ -1064,21 +1026,8 @@ __global__ void __launch_bounds__(THREADS) mk_scan_kernel(const mk_scan_args a) 
 #pragma unroll
               for (uint32_t t = 0; t < 4; t++) {
                 const uint32_t wsrc = bj[2u * t + 1u];
-#if defined(MK_TUNING) && defined(MK_ABL)
-                /* ablation builds (make tuning VARIANT=-DMK_ABL=n): timing probes with WRONG results, never shipped
-                 * (profiles/r03_a_scan_ablation.txt).  2: no mask reads; 3: mask reads at conflict-free addresses (bank := lane);
-                 * 4: filter-word reads at conflict-free addresses; 5: both conflict-free */
-                uint32_t wa = ((wsrc >> (SH + 8u)) & ((MK_ZF_WORDS - 1u) << 2)) + MK_ZMASK_WORDS * 4u;
-                uint32_t ma = 2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t];
-                const uint32_t lane4 = (lane & 31u) << 2;
-                if (MK_ABL == 3 || MK_ABL == 5) ma = (ma & ~0x7Cu) | lane4;
-                if (MK_ABL == 4 || MK_ABL == 5) wa = (wa & ~0x7Cu) | lane4;
-                dd[t] = *(mk_lds_cu32)(uintptr_t)wa;
-                if (MK_ABL == 2) mm[t] = ma | 0x80000000u; else mm[t] = *(mk_lds_cu32)(uintptr_t)ma;
-#else
                 dd[t] = *(mk_lds_cu32)(uintptr_t)(((wsrc >> (SH + 8u)) & ((MK_ZF_WORDS - 1u) << 2)) + MK_ZMASK_WORDS * 4u);
                 mm[t] = *(mk_lds_cu32)(uintptr_t)(2u * t >= D ? bj[2u * t - D] & 0x3FCu : pa[2u * t]);
-#endif
               }
 #pragma unroll
               for (uint32_t k = 0; k < D; k++) pa[k] = bj[8u - D + k] & 0x3FCu;

@@ -84,6 +84,10 @@ struct mk_mco {
   bool lds_configured = false;
   uint32_t *h_stage[2] = {nullptr, nullptr};
   hipEvent_t ev_stage[2] = {nullptr, nullptr}; /* a staging piece has crossed to the device */
+  /* mk_mco_last_kernel_ms: events around the last build's radix sort and around the last count_add's kernels */
+  hipEvent_t ev_sort[2] = {nullptr, nullptr}, ev_count[2] = {nullptr, nullptr};
+  bool sort_timed = false, count_timed = false;
+  uint32_t sort_passes = 0;
   char err[256] = {0};
 };
 
@@ -374,6 +378,8 @@ extern "C" int mk_mco_destroy(mk_mco *m) {
   for (int b = 0; b < 2; b++) {
     if (m->h_stage[b]) (void)hipHostFree(m->h_stage[b]);
     if (m->ev_stage[b]) (void)hipEventDestroy(m->ev_stage[b]);
+    if (m->ev_sort[b]) (void)hipEventDestroy(m->ev_sort[b]);
+    if (m->ev_count[b]) (void)hipEventDestroy(m->ev_count[b]);
   }
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -485,7 +491,12 @@ extern "C" int mk_mco_build(mk_mco *m, const uint32_t *ids, const uint64_t *inde
       unsigned long long *tot = (unsigned long long *)((uint8_t *)m->d_tmp + (size_t)256 * MK_RS_MAXB * 4);
       uint32_t *flag = (uint32_t *)((uint8_t *)m->d_tmp + (size_t)256 * MK_RS_MAXB * 4 + 256 * 8);
       int where = 0;
+      for (int b = 0; b < 2; b++) if (!m->ev_sort[b]) MK_MCO_HIP(m, hipEventCreate(&m->ev_sort[b]));
+      m->sort_timed = false;
+      MK_MCO_HIP(m, hipEventRecord(m->ev_sort[0], m->stream));
       MK_MCO_HIP(m, mk_radix_sort_pairs_u32(m->d_key, m->d_val, n, m->num_cu, hist, tot, flag, m->h_sort_flag, m->stream, &where));
+      MK_MCO_HIP(m, hipEventRecord(m->ev_sort[1], m->stream));
+      m->sort_timed = true;
       if (where == 0) { /* the passes that moved anything were even in number: the result sits in pair 0 */
         uint32_t *tk = m->d_key[0]; m->d_key[0] = m->d_key[1]; m->d_key[1] = tk;
         uint32_t *tv = m->d_val[0]; m->d_val[0] = m->d_val[1]; m->d_val[1] = tv;
@@ -659,6 +670,9 @@ extern "C" int mk_mco_count_add(mk_mco *m, const uint32_t *gids, uint64_t ngids,
   /* LDS counters pay when a slice brings more increments than the R-counter zero + flush costs */
   const bool lds = R <= MK_MCO_LDS_REFS && nq / nitems >= R / 16u && !m->opt_global_counters;
   const bool narrow = R <= 0xFFFFu && nlists > 0 && !m->opt_wide_lists;
+  for (int b = 0; b < 2; b++) if (!m->ev_count[b]) MK_MCO_HIP(m, hipEventCreate(&m->ev_count[b]));
+  m->count_timed = false;
+  MK_MCO_HIP(m, hipEventRecord(m->ev_count[0], m->stream));
   if (narrow) {
     if ((rc = mk_mco_grow(m, &m->d_gids16, &m->gids16_cap, nlists))) return rc;
     hipLaunchKernelGGL(mk_mco_pack16_kernel, dim3(mk_mco_blocks(m, nlists, 256)), dim3(256), 0, m->stream, d_lists, nlists, m->d_gids16);
@@ -687,7 +701,21 @@ extern "C" int mk_mco_count_add(mk_mco *m, const uint32_t *gids, uint64_t ngids,
                          m->d_ee, R, m->d_ct);
   }
   MK_MCO_HIP(m, hipGetLastError());
+  MK_MCO_HIP(m, hipEventRecord(m->ev_count[1], m->stream));
+  m->count_timed = true;
   MK_MCO_HIP(m, hipStreamSynchronize(m->stream)); /* the caller's buffers are free again */
+  return MK_OK;
+}
+
+/* device time of the last mk_mco_build's radix sort (all its passes) and of the last mk_mco_count_add's kernels (16-bit packing of the
+ * lists where it applies + the counting kernel), from HIP events on the handle's stream; 0 for a part that has not run */
+extern "C" int mk_mco_last_kernel_ms(mk_mco *m, double *sort_ms, double *count_ms) {
+  if (!m || !sort_ms || !count_ms) return MK_ERR_ARG;
+  *sort_ms = *count_ms = 0.0;
+  MK_MCO_HIP(m, hipSetDevice(m->device));
+  float f = 0.f;
+  if (m->sort_timed) { MK_MCO_HIP(m, hipEventSynchronize(m->ev_sort[1])); MK_MCO_HIP(m, hipEventElapsedTime(&f, m->ev_sort[0], m->ev_sort[1])); *sort_ms = (double)f; }
+  if (m->count_timed) { MK_MCO_HIP(m, hipEventSynchronize(m->ev_count[1])); MK_MCO_HIP(m, hipEventElapsedTime(&f, m->ev_count[0], m->ev_count[1])); *count_ms = (double)f; }
   return MK_OK;
 }
 

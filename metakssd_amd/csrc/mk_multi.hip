@@ -18,6 +18,8 @@
 
 #include <vector>
 
+#define MM_SLICES_MAX 16 /* = MK_SPLIT_MAX of mk_partial_export_split (mk_kernels.hip.h); h_parts is laid out [n][16] */
+
 static thread_local char g_multi_error[512] = "";
 
 struct mk_multi {
@@ -156,10 +158,10 @@ extern "C" int mk_multi_create_ex(const mk_params *p, const int *devices, int n,
     }
   }
   if (const char *mg = getenv("MK_MULTI_MERGE")) /* "gather" / "slices": mk_multi_set_merge for callers that cannot call it (the command line's --devices) */
-    m->merge = !strcmp(mg, "gather") ? MK_MULTI_MERGE_GATHER : !strcmp(mg, "slices") ? MK_MULTI_MERGE_SLICES : MK_MULTI_MERGE_AUTO;
+    m->merge = !strcmp(mg, "gather") ? MK_MULTI_MERGE_GATHER : (!strcmp(mg, "slices") && n <= MM_SLICES_MAX) ? MK_MULTI_MERGE_SLICES : MK_MULTI_MERGE_AUTO;
   if (n > 1)
     fprintf(stderr, "metakssd multi: %d engines, exchange transport: %s, merge: %s\n", n, m->rccl ? "rccl" : "device copies",
-            m->merge == MK_MULTI_MERGE_GATHER || (m->merge == MK_MULTI_MERGE_AUTO && n < 4) ? "gather to engine 0" : "key slices (all-to-all, then gather)");
+            m->merge == MK_MULTI_MERGE_GATHER || n > MM_SLICES_MAX || (m->merge == MK_MULTI_MERGE_AUTO && n < 4) ? "gather to engine 0" : "key slices (all-to-all, then gather)");
   *out = m;
   return MK_OK;
 }
@@ -230,6 +232,8 @@ static int mm_fit3(mk_multi *m, int dev, unsigned long long **k, uint32_t **c, u
 
 extern "C" int mk_multi_set_merge(mk_multi *m, int how) {
   if (!m || how < MK_MULTI_MERGE_AUTO || how > MK_MULTI_MERGE_SLICES) return MK_ERR_ARG;
+  if (how == MK_MULTI_MERGE_SLICES && m->n > MM_SLICES_MAX) /* mk_partial_export_split cuts a list into at most 16 parts */
+    return mm_fail(m, MK_ERR_ARG, "mk_multi_set_merge: the merge by key slices takes at most %d engines (this set has %d): use the gather", MM_SLICES_MAX, m->n);
   m->merge = how;
   return MK_OK;
 }
@@ -363,7 +367,8 @@ static int mm_finish_slices(mk_multi *m, mk_result *out, double *gather_ms, doub
 extern "C" int mk_multi_finish(mk_multi *m, mk_result *out, double *gather_ms, double *tail_ms) {
   if (!m || !out) return MK_ERR_ARG;
   /* which merge: the slices pay from four engines on (the fold on engine 0 shrinks by n - 1, two more exchange steps come in) */
-  if (m->n > 1 && (m->merge == MK_MULTI_MERGE_SLICES || (m->merge == MK_MULTI_MERGE_AUTO && m->n >= 4))) return mm_finish_slices(m, out, gather_ms, tail_ms);
+  if (m->n > 1 && m->n <= MM_SLICES_MAX && (m->merge == MK_MULTI_MERGE_SLICES || (m->merge == MK_MULTI_MERGE_AUTO && m->n >= 4)))
+    return mm_finish_slices(m, out, gather_ms, tail_ms); /* (more than 16 engines -- the command line takes 64 -- gather) */
   const double t0 = mm_now();
   const int n = m->n;
   std::vector<uint64_t> cnt((size_t)n, 0), off((size_t)n, 0);

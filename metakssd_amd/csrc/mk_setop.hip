@@ -63,6 +63,9 @@ struct mk_setop {
   int mode = -1;
   bool begun = false;
   int num_cu = 256;
+  /* mk_setop_last_join_ms: events around the last join's kernels (table build + both probe passes), on the handle's stream */
+  hipEvent_t ev_join[2] = {nullptr, nullptr};
+  bool join_timed = false;
   char err[256] = {0};
 };
 
@@ -439,6 +442,7 @@ extern "C" int mk_setop_destroy(mk_setop *s) {
   for (int b = 0; b < 2; b++) {
     (void)hipFree(s->d_stage[b]);
     if (s->ev_stage[b]) (void)hipEventDestroy(s->ev_stage[b]);
+    if (s->ev_join[b]) (void)hipEventDestroy(s->ev_join[b]);
   }
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -715,6 +719,9 @@ extern "C" int mk_setop_join(mk_setop *s, const uint32_t *qry_ids, const uint16_
   MK_SET_HIP(s, hipMemcpyAsync(s->d_qids, qry_ids, nq * 4, hipMemcpyHostToDevice, s->stream));
   MK_SET_HIP(s, hipMemcpyAsync(s->d_qab, qry_counts, nq * 2, hipMemcpyHostToDevice, s->stream));
   MK_SET_HIP(s, hipMemcpyAsync(s->d_in, ref_ids, nref * 4, hipMemcpyHostToDevice, s->stream));
+  for (int b = 0; b < 2; b++) if (!s->ev_join[b]) MK_SET_HIP(s, hipEventCreate(&s->ev_join[b]));
+  s->join_timed = false;
+  MK_SET_HIP(s, hipEventRecord(s->ev_join[0], s->stream)); /* (behind the uploads: the window below holds kernels and one memset only) */
   MK_SET_HIP(s, hipMemsetAsync(s->d_aux, 0xFF, asize * 8, s->stream));
   uint64_t ib = (nq + 255) / 256;
   if (ib > (uint64_t)s->num_cu * 16) ib = (uint64_t)s->num_cu * 16;
@@ -726,6 +733,8 @@ extern "C" int mk_setop_join(mk_setop *s, const uint32_t *qry_ids, const uint16_
   hipLaunchKernelGGL(mk_set_fwrite_kernel<mk_pred_join>, dim3(fb), dim3(256), 0, s->stream, pj, nref, nchunks, s->d_fcount, s->d_foff,
                      s->d_out);
   MK_SET_HIP(s, hipGetLastError());
+  MK_SET_HIP(s, hipEventRecord(s->ev_join[1], s->stream));
+  s->join_timed = true;
   MK_SET_HIP(s, hipMemcpyAsync(s->h_total, s->d_total, 8, hipMemcpyDeviceToHost, s->stream));
   if (nb) {
     MK_SET_HIP(s, hipMemcpyAsync(s->d_bounds, bounds, (size_t)nb * 8, hipMemcpyHostToDevice, s->stream));
@@ -739,6 +748,19 @@ extern "C" int mk_setop_join(mk_setop *s, const uint32_t *qry_ids, const uint16_
   if ((rc = mk_set_result_to_host(s, total))) return rc;
   *counts_out = s->h_out;
   *n_out = total;
+  return MK_OK;
+}
+
+/* the last mk_setop_join's device time: dictionary build (memset + insert kernel) and the two passes over the reference ids (count,
+ * write), from HIP events on the handle's stream; the uploads in front and the result copies behind are outside the window */
+extern "C" int mk_setop_last_join_ms(mk_setop *s, double *ms) {
+  if (!s || !ms) return MK_ERR_ARG;
+  *ms = 0.0;
+  if (!s->join_timed) return mk_set_fail(s, MK_ERR_STATE, "mk_setop_last_join_ms: no join has run on this handle");
+  MK_SET_HIP(s, hipSetDevice(s->device));
+  float f = 0.f;
+  MK_SET_HIP(s, hipEventElapsedTime(&f, s->ev_join[0], s->ev_join[1]));
+  *ms = (double)f;
   return MK_OK;
 }
 

@@ -976,6 +976,32 @@ def test_multi_library_both_merges_equal_oracle(capi, shufs, oracle_for, ndev, m
         m.close()
 
 
+def test_multi_library_seventeen_engines_fall_back_to_the_gather(capi, shufs, oracle_for):
+    """more engines than mk_partial_export_split has parts (16): MK_MULTI_MERGE_AUTO gathers instead of failing inside the split, and asking
+    for the slices by name is refused when it is asked for (the command line takes up to 64 devices, the same one several times)"""
+    shuf = shufs("L1K7")
+    rs = np.random.RandomState(5)
+    seqs = ui.pool_reads(rs, 20000, 3000)
+    stride = 304
+    rows = ui.rows_from_seqs(seqs, stride)
+    rc, want = oracle_for(shuf).koc_from_rows(rows, stride)
+    assert rc == 0
+    ndev = 17
+    m = capi.Multi(shuf, [0] * ndev)
+    try:
+        with pytest.raises(capi.MkError):
+            m.set_merge(capi.MK_MULTI_MERGE_SLICES)
+        m.begin(capi.MK_MODE_KOC)
+        piece = 100
+        for i, a in enumerate(range(0, len(seqs), piece)):
+            b = min(len(seqs), a + piece)
+            m.push_reads(i % ndev, rows[a * stride:b * stride], stride, a)
+        assert_same(m.finish(), want, "17 engines, auto merge")
+        assert m.last_merge() == "gather"
+    finally:
+        m.close()
+
+
 def test_device_resident_push_and_device_synth(capi, engine_for, shufs, oracle_for):
     """bench path: reads generated on the device, pushed from HBM; bytes identical to the host generator"""
     import ctypes as C
@@ -1096,9 +1122,9 @@ def test_bench_launches_its_own_ranks(capi, ranks, merge):
 
 
 def test_bench_default_flow_one_gpu(capi):
-    """`python3 bench.py` at N = 1 as the driver starts it (device legs only, a small workload): two engines in turn on split queues
-    (MK_OPT_SPLIT_CUS) for the timed region, the one-queue flow beside it, the shards-merged check; and the fall-back to one queue when
-    the option does not fit"""
+    """`python3 bench.py` at N = 1 as the driver starts it (device legs only, a small workload): the headline is ALWAYS one engine on one
+    queue -- fixed before anything is timed, not the faster of two flows -- and the split-queue flow (MK_OPT_SPLIT_CUS) is a side leg timed
+    for the same passes and warm-up; a setting the option does not fit, or 0, leaves the headline alone"""
     import json
     import os
     import subprocess
@@ -1108,27 +1134,48 @@ def test_bench_default_flow_one_gpu(capi):
     base = [sys.executable, os.path.join(root, "bench.py"), "--reads-per-gpu", "2000000", "--steps", "7", "--warmup", "2", "--no-host-legs",
             "--no-cpu-baseline", "--no-traffic", "--verify"]
     lines = []
-    for extra in (["--no-queue-trial"], ["--split-cus", "24"], ["--split-cus", "0"], []):
+    for extra in (["--no-split-leg"], ["--split-cus", "24"], ["--split-cus", "0"], []):
         r = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
         assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
         lines.append(json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]))
     d, bad, one, auto = lines
-    # the default: both flows timed for the same passes, the faster one is the headline and the other is reported beside it
     tr = auto["queue_flows"]
-    if tr["split_ms_per_step"] <= tr["one_queue_ms_per_step"]:
-        assert "two engines take the passes in turn" in auto["config"]["queues"] and "one_queue" in auto and "split_queues" not in auto
-        assert abs(auto["ms_per_step"] - tr["split_ms_per_step"]) < 1e-6 and auto["roofline"]["compute_units"] == 256 - 32
-    else:
-        assert auto["config"]["queues"].startswith("one engine, one queue") and "split_queues" in auto and "one_queue" not in auto
-        assert abs(auto["ms_per_step"] - tr["one_queue_ms_per_step"]) < 1e-6 and auto["roofline"]["compute_units"] == 256
-    assert "queue_flows" not in d and "queue_flows" not in one
-    assert "two engines take the passes in turn" in d["config"]["queues"] and d["roofline"]["compute_units"] == 256 - 32
-    assert "one_queue" not in d  # (--no-queue-trial: the split-queue flow alone)
-    assert "split queues not available here" in bad["config"]["queues"] and "one_queue" not in bad
-    assert one["config"]["queues"].startswith("one engine, one queue") and "one_queue" not in one
-    assert d["config"]["distinct_keys"] == bad["config"]["distinct_keys"] == one["config"]["distinct_keys"] > 0
+    assert tr["passes_each"] == 7 and tr["warmup_each"] == 2 and tr["headline"].startswith("one_queue")
+    assert abs(auto["ms_per_step"] - tr["one_queue_ms_per_step"]) < 1e-6  # whichever flow was faster in this run
+    sq = auto["split_queues"]
+    assert sq["compute_units_scan"] == 256 - 32 and sq["compute_units_rest"] == 32 and abs(sq["ms_per_step"] - tr["split_ms_per_step"]) < 1e-6
+    assert "one_queue" not in auto
     for x in lines:
+        assert x["config"]["queues"].startswith("one engine, one queue") and x["roofline"]["compute_units"] == 256
         assert x["merged_equals_single_engine"] is True and x["steps"] == 7 and x["value"] > 0
+    assert "queue_flows" not in d and "split_queues" not in d
+    assert "queue_flows" not in one and "split_queues" not in one
+    assert "split queues not available here" in bad["split_queues_note"] and "split_queues" not in bad
+    assert d["config"]["distinct_keys"] == bad["config"]["distinct_keys"] == one["config"]["distinct_keys"] == auto["config"]["distinct_keys"] > 0
+
+
+def test_bench_bare_two_ranks_is_interpretable(capi):
+    """`python3 bench.py --gpus 2`, nothing else (on this one-GPU box the ranks share GPU 0 over gloo, and the line says so): BASELINE config 4
+    split over the ranks, and with NO flag the line carries what a scaling curve needs -- the C product's own multi-GPU library timed
+    (`inproc_multi`, with its transport), the same workload on one GPU in the same run (`same_workload_one_gpu`: ms, speedup, efficiency),
+    every rank seen"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, env=env)
+    assert r.returncode == 0, "\n".join(l for l in r.stderr.decode(errors="replace").splitlines() if "rror" in l or "rank0" in l)[-4000:]
+    d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_reads"] == 500_000_000 and d["steps"] == 40
+    assert d["distributed"]["ranks_seen"] == [0, 1]
+    im = d["inproc_multi"]
+    assert im["transport"] in ("device copies", "rccl") and im["engines"] == 2 and im["equals_process_per_gpu_sketch"] is True and im["ms_per_step"] > 0
+    one = d["same_workload_one_gpu"]
+    assert one["n_gpus"] == 2 and one["ms_per_step"] > 0 and one["sketch_equals_merged"] is True
+    assert abs(one["speedup"] - one["ms_per_step"] / d["ms_per_step"]) < 1e-9 and abs(one["efficiency"] - one["speedup"] / 2) < 1e-9
+    assert d["config"]["distinct_keys"] == 15_692_589  # config 4's sketch (tests/test_gpu_fullsize.py; profiles/r05_fullsize_config4_vs_reference.json)
 
 
 # ---- FASTQ without -A (SURVEY 8f N1): fastq2co + write_fqco2file through MK_MODE_OCC_SET -----------------------

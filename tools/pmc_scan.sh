@@ -9,7 +9,7 @@ i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
   rm -rf gpurun_out/pmc_$i   # (a directory left by an earlier call would hand its counters to this one)
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d gpurun_out/pmc_$i -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-host-legs --no-one-queue $MK_BENCH_FLAGS > gpurun_out/pmc_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d gpurun_out/pmc_$i -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-host-legs ${MK_BENCH_FLAGS:---no-split-leg} > gpurun_out/pmc_$i.log 2>&1
   f=$(find gpurun_out/pmc_$i -name "*counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections
@@ -18,7 +18,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"][:40]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
 for k in acc:
-    if "scan" in k:
+    if "mk_scan_kernel" in k or "mk_resolve_kernel" in k:
         for c, v in acc[k].items():
             print(k, c, v / max(1, n[(k, c)]))
 PY
