@@ -513,7 +513,6 @@ static uint8_t *arena_map_untouched(size_t bytes, size_t *len_out) {
 #ifdef MADV_HUGEPAGE
   (void)madvise(m, len, MADV_HUGEPAGE);
 #endif
-  repoison(m, len); /* (MK_POISON: fresh anonymous pages are zeros otherwise) */
   *len_out = len;
   return m;
 }
@@ -537,7 +536,7 @@ static uint8_t *arena_map_unpinned(size_t bytes, size_t *len_out) {
 }
 static uint8_t *cli_sink_alloc(void *ctx, size_t bytes) { /* the arena (and what is pinned of it) is kept for the next file and goes with the process */
   ctx_t *c = ctx;
-  if (c->arena && c->arena_bytes >= bytes) { pin_reset(c->pin); repoison(c->arena, c->arena_bytes); return c->arena; }
+  if (c->arena && c->arena_bytes >= bytes) { pin_reset(c->pin); return c->arena; } /* (MK_POISON: the stream fills every buffer it takes) */
   if (c->pin) { pin_destroy(c->pin); c->pin = NULL; }
   if (c->arena) munmap(c->arena, c->arena_bytes);
   c->arena = NULL; c->arena_bytes = 0;
@@ -1071,7 +1070,9 @@ static int set_group(const char *in, const char *taxfile, const char *outdir, in
       if (tax[t].taxid == 0) continue; /* taxid 0 = leave these sketches out (:866) */
       uint64_t total = 0;
       for (int g = 0; g < tax[t].ng; g++) total += pos[tax[t].gids[g] + 1] - pos[tax[t].gids[g]];
-      if (total == 0) die("grouping_genomes(): taxid %d has no k-mer in component %d (LOG2(0) in the reference)", tax[t].taxid, c);
+      /* a taxon without a k-mer in this component: the reference evaluates LOG2(0 * 1.5) there (command_set.c:878: __builtin_clzll(0),
+       * undefined; every build seen so far ends up with primer[0] slots and nothing in them) and writes an EMPTY block: so do we */
+      if (total == 0) { outidx[++outfn] = offset; continue; }
       if (total > cat_cap) {
         if (cat) mk_host_free(cat);
         cat_cap = total + total / 4 + 1024;
@@ -2376,8 +2377,8 @@ int main(int argc, char **argv) {
     br.nbufs = nbufs;
     size_t arena_len = 0;
     uint8_t *arena = batch_rows ? arena_map_untouched((size_t)nbufs * br.bufcap, &arena_len) : arena_map_unpinned((size_t)nbufs * br.bufcap, &arena_len);
-    (void)arena_len;
     if (!arena) die("out of memory (%zu bytes of batch buffers)", (size_t)nbufs * br.bufcap);
+    repoison(arena, arena_len); /* (MK_POISON: fresh anonymous pages are zeros otherwise) */
     for (int b = 0; b < nbufs; b++) br.buf[b] = arena + (size_t)b * br.bufcap;
     int buf_pinned[BATCH_BUFS_MAX];
     memset(buf_pinned, 0, sizeof buf_pinned);

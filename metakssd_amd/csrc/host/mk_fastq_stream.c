@@ -251,6 +251,7 @@ static void *fs_worker(void *arg) {
     const uint64_t c = f->next++;
     const int b = f->freelist[--f->nfree]; /* taken together with the chunk number: the lowest open chunk always has a buffer */
     pthread_mutex_unlock(&f->mu);
+    { const int pz = mk_poison_byte(); if (pz >= 0) memset(f->bufs[b], pz, f->buf_bytes); } /* MK_POISON: a fresh or reused row buffer starts from the pattern */
 
     fs_slot s;
     memset(&s, 0, sizeof s);
@@ -395,6 +396,7 @@ int mk_fastq_stream(const uint8_t *text, size_t n, const mk_fastq_opts *o, const
       while (rc == MK_OK && sp_ < sto_) {                                                                          \
         fs_slot ss_;                                                                                               \
         memset(&ss_, 0, sizeof ss_);                                                                               \
+        { const int pz_ = mk_poison_byte(); if (pz_ >= 0) memset(serial_buf, pz_, f.buf_bytes); }                  \
         fs_frame_range(&f, sp_, sto_, sp_ == 0, serial_buf, &ss_, serial_scratch);                                 \
         if (ss_.nrows) {                                                                                           \
           uint64_t tok_ = 0;                                                                                       \

@@ -409,6 +409,15 @@ def main():
     group_case("L0K6z_set_g", "L0K6z_set_u", ["5\tfive", "5\tfive", "6"])
     group_case("L2K11_set_g", "L2K11_set_u", ["77\ta b c", "78\td", "77\ta b c", "78\td"])
     group_case("L1K7_set_g_reads_A", "L1K7_set_u_reads_A", ["9", "9", "10\tten"])
+    # a taxon WITHOUT a k-mer in some component (three genomes of a few kilobases over L2K11's 16 components): the reference evaluates
+    # LOG2(0) there (command_set.c:878) and writes an empty block for that component
+    tiny = []
+    for i, (a, b) in enumerate([(0, 3000), (5000, 9000), (20000, 22500)]):
+        pth = os.path.join(work, "tiny%d.fa" % i)
+        write_fa(pth, [g[a:b]])
+        tiny.append(pth)
+    set_case("L2K11_tiny_set_u", "L2K11", tiny, [], "-u")
+    group_case("set_g_empty_component", "L2K11_tiny_set_u", ["1\tone", "2", "3\tthree"])
 
     # `composite -r <db> -q <qry> [-b]` (get_species_abundance, command_composite.c:446-649): marker db from the grouped
     # directory above by the reference's set -q / -i, queries = the three -A read sketches; stdout and .abv compared

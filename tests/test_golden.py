@@ -412,6 +412,46 @@ def test_product_cli_set_print_names_and_id_mismatch(shuf_files, tmp_path):
     assert r.returncode != 0 and b"sketcing id not match" in r.stderr
 
 
+@pytest.mark.gpu
+def test_product_cli_set_g_taxon_without_kmer_in_a_component(shuf_files, tmp_path):
+    """three genomes of a few kilobases over L2K11's 16 components: some (taxon, component) pairs hold no k-mer at all.  The reference
+    evaluates LOG2(0) there (command_set.c:878) and writes an EMPTY block for that component -- pinned against the compiled reference in
+    oracle/check_vs_ref.py (case set_g_empty_component); the product used to stop with an error (found by tools/fuzz_pipeline.py,
+    round 6).  Product == oracle on the same sketch directory, and the README's next steps (-q, -i) take the grouped directory."""
+    import numpy as np
+    import util_inputs as ui
+    g = ui.rand_seq(np.random.RandomState(66), 30000)
+    refs = []
+    for i, (a, b) in enumerate([(0, 3000), (5000, 9000), (20000, 22500)]):
+        p = str(tmp_path / ("tiny%d.fa" % i))
+        open(p, "wb").write(ui.fasta_bytes([g[a:b]]))
+        refs.append(p)
+    taxf = str(tmp_path / "tax.tsv")
+    open(taxf, "w").write("1\tone\n2\n3\tthree\n")
+    sk = str(tmp_path / "sk")
+    r = subprocess.run([PRODUCT_CLI, "dist", "-L", shuf_files("L2K11"), "-o", sk] + refs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    sizes = np.stack([np.diff(np.fromfile(os.path.join(sk, "combco.index.%d" % c), np.uint64).astype(np.int64)) for c in range(16)])
+    assert (sizes == 0).any() and sizes.sum() > 0  # the case is what it says
+    outs = {}
+    for who, cli in (("product", [PRODUCT_CLI, "set"]), ("oracle", [ORACLE_CLI, "set"])):
+        d = str(tmp_path / ("grp_" + who))
+        r = subprocess.run(cli + ["-g", taxf, "-o", d, sk], input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, (who, r.stderr.decode())
+        outs[who] = d
+    assert sorted(os.listdir(outs["product"])) == sorted(os.listdir(outs["oracle"]))
+    for f in sorted(os.listdir(outs["oracle"])):
+        a, b = os.path.join(outs["product"], f), os.path.join(outs["oracle"], f)
+        if f == "cofiles.stat":
+            assert parse_stat(a) == parse_stat(b)
+        else:
+            assert filecmp.cmp(a, b, shallow=False), f
+    uq, db = str(tmp_path / "uq"), str(tmp_path / "db")
+    for cmd in ([PRODUCT_CLI, "set", "-q", "-o", uq, outs["product"]], [PRODUCT_CLI, "set", "-i", uq, "-o", db, outs["product"]]):
+        r = subprocess.run(cmd, input=b"N\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, (cmd, r.stderr.decode())
+
+
 # ---- composite -q (SURVEY.md 8f N3): marker database by set -g / -q / -i, then the abundance report ------------------
 def run_composite_case(case, shuf_files, tmp_path, dist_cmd, set_cmd, comp_cmd):
     entry = MANIFEST["composite_cases"][case]

@@ -137,6 +137,32 @@ def make_case(rs, work, l2k11):
     return (k, subk, drl), refs, tax, qfiles
 
 
+KEPT = [0]
+KEEP_FULL = 6  # cases kept with their files (gpurun brings at most 64 MiB home); every further one keeps its log only
+
+
+def keep_case(keep, name, work, info):
+    import threading
+    dst = os.path.join(keep, name)
+    shutil.rmtree(dst, ignore_errors=True)
+    with keep_case.lock:
+        KEPT[0] += 1
+        full = KEPT[0] <= KEEP_FULL
+    if full:  # everything but files above 2 MiB (the inputs of the large geometries: the case is reproducible from its seed)
+        for d, _, files in os.walk(work):
+            for fn in files:
+                src = os.path.join(d, fn)
+                if os.path.getsize(src) <= (2 << 20):
+                    out = os.path.join(dst, os.path.relpath(src, work))
+                    os.makedirs(os.path.dirname(out), exist_ok=True)
+                    shutil.copyfile(src, out)
+    os.makedirs(dst, exist_ok=True)
+    json.dump(info, open(os.path.join(dst, "log.json"), "w"), indent=1)
+
+
+import threading  # noqa: E402
+keep_case.lock = threading.Lock()
+
 SELFCHECK = False  # --selfcheck: the checker's commands stand in for the product's (tests this tool where there is no GPU)
 
 
@@ -167,8 +193,11 @@ def one_case(case, seed, l2k11, poison, keep, shuf_dir):
         for (name, cc), (_, pc) in zip(steps_c, steps_p):
             rc_ = run(cc, work, log)
             rp_ = run(pc, work, log, env=penv)
+            if rc_.returncode < 0:  # the reference died of a signal (division by zero ..): there is no behaviour to compare with
+                verdict = "reference crashed in stage %s (signal %d), product rc %d" % (name, -rc_.returncode, rp_.returncode)
+                break
             if (rc_.returncode != 0) != (rp_.returncode != 0):
-                verdict = "stage %s: checker rc %d, product rc %d" % (name, rc_.returncode, rp_.returncode)
+                verdict = "stage %s: checker rc %d, product rc %d: %s" % (name, rc_.returncode, rp_.returncode, rp_.stderr.decode(errors="replace").strip()[-160:])
                 break
             if rc_.returncode != 0:  # both refuse (an empty group, a crowded table ..): the case ends here, in agreement
                 return {"case": case, "geom": [k, subk, drl], "ok": True, "ended": name}
@@ -179,8 +208,10 @@ def one_case(case, seed, l2k11, poison, keep, shuf_dir):
         if verdict is None:
             rc_ = run([REF, "composite", "-r", "c_db", "-q", "c_qsk"], work, log)
             rp_ = run(comp_p + ["-r", "p_db", "-q", "p_qsk"], work, log, env=penv)
-            if rc_.returncode != rp_.returncode and (rc_.returncode == 0 or rp_.returncode == 0):
-                verdict = "composite: checker rc %d, product rc %d" % (rc_.returncode, rp_.returncode)
+            if rc_.returncode < 0:
+                verdict = "reference crashed in composite (signal %d), product rc %d" % (-rc_.returncode, rp_.returncode)
+            elif rc_.returncode != rp_.returncode and (rc_.returncode == 0 or rp_.returncode == 0):
+                verdict = "composite: checker rc %d, product rc %d: %s" % (rc_.returncode, rp_.returncode, rp_.stderr.decode(errors="replace").strip()[-160:])
             elif rc_.returncode == 0 and norm_composite(rc_.stdout.decode()) != norm_composite(rp_.stdout.decode()):
                 verdict = "composite: text differs"
             elif rc_.returncode == 0:
@@ -192,11 +223,10 @@ def one_case(case, seed, l2k11, poison, keep, shuf_dir):
                     d = same_dir(os.path.join(work, "c_abv"), os.path.join(work, "p_abv"))
                     if d:
                         verdict = "composite -b: " + d
+        if verdict and verdict.startswith("reference crashed"):
+            return {"case": case, "geom": [k, subk, drl], "ok": True, "reference_crashed": verdict}
         if verdict:
-            dst = os.path.join(keep, "case_%d_%d" % (seed, case))
-            shutil.rmtree(dst, ignore_errors=True)
-            shutil.copytree(work, dst)
-            json.dump({"verdict": verdict, "geom": [k, subk, drl], "log": log}, open(os.path.join(dst, "log.json"), "w"), indent=1)
+            keep_case(keep, "case_%d_%d" % (seed, case), work, {"verdict": verdict, "geom": [k, subk, drl], "product_flags": pflags, "log": log})
         return {"case": case, "geom": [k, subk, drl], "ok": verdict is None, "what": verdict, "product_flags": pflags}
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -247,10 +277,7 @@ def golden_once(it, case, poison, keep, shuf_dir, first):
             for name, _ in steps:  # this run is the yardstick for the stages' bytes
                 shutil.copytree(os.path.join(work, name), os.path.join(first, name))
         if verdict:
-            dst = os.path.join(keep, "golden_%s_%d" % (case, it))
-            shutil.rmtree(dst, ignore_errors=True)
-            shutil.copytree(work, dst, ignore=shutil.ignore_patterns("*.fa", "*.fq"))
-            json.dump({"verdict": verdict, "log": log}, open(os.path.join(dst, "log.json"), "w"), indent=1)
+            keep_case(keep, "golden_%s_%d" % (case, it), work, {"verdict": verdict, "log": log})
         return {"it": it, "ok": verdict is None, "what": verdict}
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -299,12 +326,18 @@ def main():
             with cf.ThreadPoolExecutor(max_workers=a.workers) as ex:
                 res = list(ex.map(lambda i: one_case(i, a.seed, bool(l2[i]), a.poison, a.keep, shuf_dir), range(a.cases)))
             bad = [r for r in res if not r["ok"]]
+            kinds = {}
+            for r in bad:
+                kind = r["what"].split(":")[0] + (": " + r["what"].split(": ")[-1][:90] if "rc" in r["what"] else "")
+                kinds[kind] = kinds.get(kind, 0) + 1
             by_geom = {}
             for r in res:
                 by_geom["L%dK%d" % (r["geom"][2], r["geom"][0])] = by_geom.get("L%dK%d" % (r["geom"][2], r["geom"][0]), 0) + 1
             print(json.dumps({"tool": "fuzz_pipeline", "cases": len(res), "seed": a.seed, "workers": a.workers, "poison": a.poison or None,
                               "by_geometry": by_geom, "ended_early_in_agreement": sum(1 for r in res if r.get("ended")),
-                              "mismatches": len(bad), "what": [(b["case"], b["what"]) for b in bad][:10], "seconds": round(time.time() - t0, 1)}))
+                              "reference_crashed": sum(1 for r in res if r.get("reference_crashed")),
+                              "mismatches": len(bad), "mismatch_kinds": kinds, "what": [(b["case"], b["what"]) for b in bad][:10],
+                              "seconds": round(time.time() - t0, 1)}))
     finally:
         shutil.rmtree(shuf_dir, ignore_errors=True)
     return 1 if bad else 0
