@@ -546,7 +546,10 @@ extern "C" int mk_setop_finish(mk_setop *s, const uint32_t **ids_out, uint64_t *
 static int mk_set_result_to_host(mk_setop *s, uint64_t total);
 
 static int mk_set_grow(mk_setop *s, void **p, uint64_t *cap, uint64_t need, size_t elem) {
-  if (need <= *cap) return MK_OK;
+  if (need <= *cap) { /* (MK_POISON: the scratch of the call before, filled on the stream this call's kernels follow on) */
+    if (*p) MK_SET_HIP(s, mk_dev_repoison(*p, (size_t)*cap * elem, s->stream));
+    return MK_OK;
+  }
   (void)hipFree(*p);
   *p = nullptr; *cap = 0;
   const uint64_t c = need + need / 8 + 1024;
