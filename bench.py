@@ -178,6 +178,7 @@ def leg_packed(torch, capi, eng, pinned_text_rows, n, distinct_text, reps=3):
 
 
 _FREE_BASELINE = {}
+_KFD_SNAPSHOT = [None]  # KFD processes seen at the end of the last wait_device_quiet (before the next child was started)
 _GPU_TOUCHED = [False]  # set when main() makes its first HIP call
 
 
@@ -205,14 +206,42 @@ def _vram_used_no_context():
         return None
 
 
+def _kfd_other_processes():
+    """pids that still hold a KFD (GPU compute) context, other than this process: /sys/class/kfd/kfd/proc lists one directory per such
+    process, and a process that has exited stays listed until the driver has finished tearing its queues, its device memory and its pinned
+    pages down -- which is exactly what the next process's HIP start-up otherwise waits for.  None when the directory cannot be read."""
+    try:
+        me = str(os.getpid())
+        return [p for p in os.listdir("/sys/class/kfd/kfd/proc") if p.isdigit() and p != me]
+    except OSError:
+        return None
+
+
 def wait_device_quiet(tag="gpu", least=2.0, most=8.0):
     """between two runs of the command line: the driver takes a process's device memory back for a while AFTER the process has gone
     (21 GB at L2K11), and the next process's start-up waits for that.  Instead of sleeping a fixed time: poll the device's free
     memory (this process keeps its HIP context; it holds nothing large by now) until it is back at what it was before the first run."""
     if not _GPU_TOUCHED[0]:
-        # the command-line legs run BEFORE this process has a HIP context (see main): the device's used memory comes from rocm-smi (sysfs, no
-        # context: 0.08 s a call); an idle device shows 0.3 GB.  Without rocm-smi: a pause
-        time.sleep(least)
+        # the command-line legs run BEFORE this process has a HIP context (see main).  First: until the driver has let go of every process
+        # that used the GPU before (the child that has just exited, above all) -- the list of KFD processes in sysfs; then the device's used
+        # memory from rocm-smi (sysfs as well, 0.08 s a call; an idle device shows 0.3 GB).  Without either: a pause
+        time.sleep(min(least, 0.5))
+        t0 = time.monotonic()
+        saw_kfd = False
+        while time.monotonic() - t0 < most:
+            others = _kfd_other_processes()
+            if others is None:
+                break
+            saw_kfd = True
+            # (sysfs is not namespaced: other tenants' processes on the host are listed too.  What is waited for are the entries that were
+            # not there when the last wait ended, i.e. the child started since -- under whatever pid the host knows it by)
+            if _KFD_SNAPSHOT[0] is None or not (set(others) - _KFD_SNAPSHOT[0]):
+                break  # (the first call only takes the snapshot: nothing of ours has run yet)
+            time.sleep(0.02)
+        if saw_kfd:
+            _KFD_SNAPSHOT[0] = set(_kfd_other_processes() or [])
+        else:
+            time.sleep(max(0.0, least - 0.5))
         t0 = time.monotonic()
         while time.monotonic() - t0 < most:
             used = _vram_used_no_context()
@@ -431,21 +460,27 @@ def _sketch_blocks(d):
     return out
 
 
-def write_genomes(gd, genomes, mbases, want_seqs=0):
+def write_genomes(gd, genomes, mbases, want_seqs=0, distinct=False):
     """`genomes` multi-FASTA files g0000.fna .. in directory gd: one pool of random bases laid out as 70-column lines; a genome = two contigs,
-    each a run of whole lines from a position of its own (distinct genomes, no per-genome formatting work).  Returns (bases per genome,
-    the first `want_seqs` genomes' sequences as bytes without line ends -- for drawing reads from)"""
+    each a run of whole lines from a position of its own (no per-genome formatting work).  The pool is three genomes long (config 5: the
+    genomes overlap, which the sketching does not care about); distinct=True: as long as all genomes together, every genome its own lines
+    (a marker database needs species that differ).  Returns (bases per genome, the first `want_seqs` genomes' sequences as bytes without
+    line ends -- for drawing reads from)"""
     import numpy as np
     os.makedirs(gd)
     rs = np.random.RandomState(5)
-    nlines_pool = int(3 * mbases * 1e6 / 70)
-    pool = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, size=(nlines_pool, 70))]
-    pool = np.concatenate([pool, np.full((nlines_pool, 1), 10, np.uint8)], axis=1).reshape(-1)
     half = int(mbases * 1e6 / 2 / 70)  # lines per contig
+    nlines_pool = genomes * 2 * half + 2 if distinct else int(3 * mbases * 1e6 / 70)
+    # (the overlapping pool keeps round 4's random stream: the same genomes as in every earlier line)
+    pool = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, size=(nlines_pool, 70), dtype=np.uint8) if distinct else rs.randint(0, 4, size=(nlines_pool, 70))]
+    pool = np.concatenate([pool, np.full((nlines_pool, 1), 10, np.uint8)], axis=1).reshape(-1)
     seqs = []
     for i in range(genomes):
-        a = (i * 7919) % (nlines_pool - 2 * half - 1)
-        b = (a + half + 1 + (i * 104729) % (nlines_pool - 2 * half - 1)) % (nlines_pool - half)
+        if distinct:
+            a, b = 2 * half * i, 2 * half * i + half
+        else:
+            a = (i * 7919) % (nlines_pool - 2 * half - 1)
+            b = (a + half + 1 + (i * 104729) % (nlines_pool - 2 * half - 1)) % (nlines_pool - half)
         with open(os.path.join(gd, "g%04d.fna" % i), "wb") as f:
             f.write(b">g%d_contig0\n" % i)
             f.write(pool[71 * a: 71 * (a + half)].tobytes())
@@ -565,7 +600,7 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=4
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def leg_next_rows_cli(capi, genomes=1024, mbases=4.0, queries=8, reads_per_query=200_000, search_queries=64):
+def leg_next_rows_cli(capi, genomes=1024, mbases=0.25, queries=8, reads_per_query=100_000, search_queries=64):
     """SURVEY.md 8f rows N3 / N4 through the product command line on a stated synthetic database, the compiled reference timed beside it on
     the SAME directories (they are the reference's own formats) and its outputs compared:
       markers   `set -g tax` -> `set -q` -> `set -i`   the README's MarkerDB recipe on the L3K10 sketch directory of `genomes` genomes, one species each
@@ -586,7 +621,8 @@ def leg_next_rows_cli(capi, genomes=1024, mbases=4.0, queries=8, reads_per_query
     cli = os.path.join(ROOT, "metakssd_amd", "bin", "metakssd")
     ref = os.path.join(ROOT, "oracle", "_ref", "metakssd")
     cores = os.cpu_count() or 1
-    out = {"database": "%d synthetic genomes of %.1f Mbases (BASELINE config 5's generator), L3K10, one species per genome" % (genomes, mbases)}
+    out = {"database": "%d synthetic genomes of %.2f Mbases, every one random bases of its own (config 5's generator with distinct=True), L3K10, one "
+                       "species per genome" % (genomes, mbases)}
 
     def run(cmd, timeout=None, **kw):
         wait_device_quiet(least=0.5, most=4.0)
@@ -603,7 +639,7 @@ def leg_next_rows_cli(capi, genomes=1024, mbases=4.0, queries=8, reads_per_query
             return None, time.monotonic() - m0
     try:
         gd = os.path.join(tmp, "genomes")
-        bases_each, seqs = write_genomes(gd, genomes, mbases, want_seqs=2 * queries)
+        bases_each, seqs = write_genomes(gd, genomes, mbases, want_seqs=2 * queries, distinct=True)
         sp = os.path.join(tmp, "L3K10.shuf")
         capi.Shuf.generate(10, 6, 3, 10).write(sp)
         open(os.path.join(tmp, "tax.tsv"), "w").write("".join("%d\tspecies %d\n" % (i + 1, i + 1) for i in range(genomes)))
@@ -692,27 +728,33 @@ def leg_next_rows_cli(capi, genomes=1024, mbases=4.0, queries=8, reads_per_query
                          "distance_lines": sum(1 for _ in open(os.path.join(tmp, "hits", "distance.out"))),
                          "what": "`metakssd dist -r mco -o hits qsk64`: %d genome sketches against the %d-genome index (index gather on the host, "
                                  "counting on the device, distance.out); median of 2 after a warm-up" % (search_queries, genomes)}
-        if os.path.exists(ref) and with_ref_index:
-            rr, wr = run_ref([ref, "dist", "-p", str(cores), "-o", "mco_ref", "sk"], 100)
-            if rr is None or rr.returncode != 0:
-                out["stage2"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "cores": cores,
-                                                 "sample": "oracle/_ref/metakssd dist -o on the same sketch directory: not finished after 100 s (stopped)"}
+        if os.path.exists(ref):
+            import filecmp
+            # the search by the reference on the PRODUCT's index (the formats are the reference's own; stage II by the reference itself takes
+            # minutes for ANY input -- it builds and writes the 32 GiB index row by row -- and is bounded below)
+            rr2, wr2 = run_ref([ref, "dist", "-p", str(cores), "-r", "mco", "-o", "hits_ref", "qsk64"], 90)
+            if rr2 is not None and rr2.returncode == 0:
+                out["search"]["cpu_baseline"] = {"seconds": wr2, "kind": "reference", "cores": cores,
+                                                 "sample": "oracle/_ref/metakssd dist -p %d -r on the same index and queries (the whole workload)" % cores,
+                                                 "distance_out_equals_reference": bool(filecmp.cmp(os.path.join(tmp, "hits", "distance.out"),
+                                                                                                   os.path.join(tmp, "hits_ref", "distance.out"), shallow=False))}
             else:
-                import filecmp
-                same = all(filecmp.cmp(os.path.join(tmp, "mco", f), os.path.join(tmp, "mco_ref", f), shallow=False) for f in ("mco.0", "mcofiles.stat", "mco.index.0"))
-                out["stage2"]["cpu_baseline"] = {"seconds": wr, "kind": "reference", "cores": cores,
-                                                 "sample": "oracle/_ref/metakssd dist -p %d -o on the same sketch directory (the whole workload)" % cores,
-                                                 "files_equal_reference": bool(same)}
-                rr2, wr2 = run_ref([ref, "dist", "-p", str(cores), "-r", "mco_ref", "-o", "hits_ref", "qsk64"], 60)
-                if rr2 is not None and rr2.returncode == 0:
-                    out["search"]["cpu_baseline"] = {"seconds": wr2, "kind": "reference", "cores": cores,
-                                                     "sample": "oracle/_ref/metakssd dist -p %d -r on the same index and queries" % cores,
-                                                     "distance_out_equals_reference": bool(filecmp.cmp(os.path.join(tmp, "hits", "distance.out"),
-                                                                                                       os.path.join(tmp, "hits_ref", "distance.out"), shallow=False))}
+                out["search"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "sample": "not finished after 90 s (stopped)" if rr2 is None else
+                                                 "failed: " + rr2.stderr.decode(errors="replace")[-200:]}
+            if with_ref_index:
+                rr, wr = run_ref([ref, "dist", "-p", str(cores), "-o", "mco_ref", "sk"], 45)
+                if rr is None or rr.returncode != 0:
+                    out["stage2"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "cores": cores,
+                                                     "sample": "oracle/_ref/metakssd dist -p %d -o on the same sketch directory: not finished after 45 s (stopped; "
+                                                               "85 s for 10 M ids on this pool's scratch disk, profiles/r01_search_cli_vs_reference.json, files "
+                                                               "identical there)" % cores}
                 else:
-                    out["search"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "sample": "not finished after 60 s (stopped)"}
-        elif os.path.exists(ref):
-            out["stage2"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "sample": "skipped: /dev/shm too small for a second 34 GB index"}
+                    same = all(filecmp.cmp(os.path.join(tmp, "mco", f), os.path.join(tmp, "mco_ref", f), shallow=False) for f in ("mco.0", "mcofiles.stat", "mco.index.0"))
+                    out["stage2"]["cpu_baseline"] = {"seconds": wr, "kind": "reference", "cores": cores,
+                                                     "sample": "oracle/_ref/metakssd dist -p %d -o on the same sketch directory (the whole workload)" % cores,
+                                                     "files_equal_reference": bool(same)}
+            else:
+                out["stage2"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "sample": "skipped: /dev/shm too small for a second 34 GB index"}
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -809,6 +851,27 @@ def leg_next_rows_kernels(capi, device=0, refs=5000, ids=20000, queries=500, joi
                                                     "kernel is the LDS atomic rate (one ds_add per increment), not HBM: g_increments_per_s is the figure to read"},
                                "what": "mk_mco_count_add on the index of the build above (row extents looked up on the device, one LDS counter per reference genome and "
                                        "workgroup); kernel_ms from the handle's HIP events, best of 2 after a warm-up"}
+        # the oracle's restatement of the two loops on one core, on a bounded sample (200 of the genomes, 20 of the queries)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_binding as ob
+            rc_ = min(200, R)
+            sub = allids[:int(index[rc_])]
+            t0 = time.perf_counter()
+            og, ori, ore = ob.mco_build(sub, index[:rc_ + 1])
+            tb = time.perf_counter() - t0
+            near = [k for k in range(Q) if sel[k] < rc_][:20] or [0]
+            sq = np.concatenate([parts[sel[k]] for k in near])
+            sqi = np.concatenate([[0], np.cumsum([parts[sel[k]].size for k in near])]).astype(np.uint64)
+            t0 = time.perf_counter()
+            oct_ = ob.mco_count(og, ori, ore, sq, sqi, np.diff(sqi).astype(np.uint32), rc_)
+            tc = time.perf_counter() - t0
+            out["stage2_sort"]["cpu_baseline"] = {"m_ids_per_s": sub.size / tb / 1e6, "seconds": tb, "cores": 1, "kind": "port",
+                                                  "sample": "the oracle's combco2mco() restatement on %d of the genomes (%d ids): the whole build, not only its sort" % (rc_, sub.size)}
+            out["search_count"]["cpu_baseline"] = {"g_increments_per_s": int(oct_.sum(dtype=np.uint64)) / max(tc, 1e-9) / 1e9, "seconds": tc, "cores": 1, "kind": "port",
+                                                   "sample": "the oracle's counting loop on %d query sketches against those %d genomes" % (len(near), rc_)}
+        except Exception as ex:  # noqa: BLE001
+            out["stage2_sort"]["cpu_baseline"] = {"kind": "port", "sample": "failed: %s" % str(ex)[:200]}
     finally:
         m.close()
     return out

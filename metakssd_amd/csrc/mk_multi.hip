@@ -18,7 +18,6 @@
 
 #include <vector>
 
-#define MM_SLICES_MAX 16 /* = MK_SPLIT_MAX of mk_partial_export_split (mk_kernels.hip.h); h_parts is laid out [n][16] */
 
 static thread_local char g_multi_error[512] = "";
 
@@ -99,6 +98,10 @@ extern "C" int mk_multi_destroy(mk_multi *m) {
  * adding at 0xF00000 and every import adds at most 65535 per key: 16 concurrent imports stay below the key bits with room to
  * spare (16 * 65535 < 2^20 <= 2^24 - 0xF00000), 17 and more could carry. */
 #define MK_MULTI_MAX_ENGINES 16
+/* the merge by key slices cuts every list into one part per engine: mk_partial_export_split takes at most 16 parts (MK_SPLIT_MAX,
+ * mk_kernels.hip.h) and h_parts is laid out [n][16] -- mk_multi_create refuses more engines than that (the command line's --devices list
+ * may name 64: the error comes from here, before anything is sketched) */
+static_assert(MK_MULTI_MAX_ENGINES <= 16, "mm_finish_slices: one part per engine, at most 16 parts");
 
 extern "C" int mk_multi_create_ex(const mk_params *p, const int *devices, int n, unsigned flags, mk_multi **out) {
   if (!p || !devices || !out || n < 1) return mm_fail(nullptr, MK_ERR_ARG, "mk_multi_create: bad argument");
@@ -158,10 +161,10 @@ extern "C" int mk_multi_create_ex(const mk_params *p, const int *devices, int n,
     }
   }
   if (const char *mg = getenv("MK_MULTI_MERGE")) /* "gather" / "slices": mk_multi_set_merge for callers that cannot call it (the command line's --devices) */
-    m->merge = !strcmp(mg, "gather") ? MK_MULTI_MERGE_GATHER : (!strcmp(mg, "slices") && n <= MM_SLICES_MAX) ? MK_MULTI_MERGE_SLICES : MK_MULTI_MERGE_AUTO;
+    m->merge = !strcmp(mg, "gather") ? MK_MULTI_MERGE_GATHER : !strcmp(mg, "slices") ? MK_MULTI_MERGE_SLICES : MK_MULTI_MERGE_AUTO;
   if (n > 1)
     fprintf(stderr, "metakssd multi: %d engines, exchange transport: %s, merge: %s\n", n, m->rccl ? "rccl" : "device copies",
-            m->merge == MK_MULTI_MERGE_GATHER || n > MM_SLICES_MAX || (m->merge == MK_MULTI_MERGE_AUTO && n < 4) ? "gather to engine 0" : "key slices (all-to-all, then gather)");
+            m->merge == MK_MULTI_MERGE_GATHER || (m->merge == MK_MULTI_MERGE_AUTO && n < 4) ? "gather to engine 0" : "key slices (all-to-all, then gather)");
   *out = m;
   return MK_OK;
 }
@@ -232,8 +235,6 @@ static int mm_fit3(mk_multi *m, int dev, unsigned long long **k, uint32_t **c, u
 
 extern "C" int mk_multi_set_merge(mk_multi *m, int how) {
   if (!m || how < MK_MULTI_MERGE_AUTO || how > MK_MULTI_MERGE_SLICES) return MK_ERR_ARG;
-  if (how == MK_MULTI_MERGE_SLICES && m->n > MM_SLICES_MAX) /* mk_partial_export_split cuts a list into at most 16 parts */
-    return mm_fail(m, MK_ERR_ARG, "mk_multi_set_merge: the merge by key slices takes at most %d engines (this set has %d): use the gather", MM_SLICES_MAX, m->n);
   m->merge = how;
   return MK_OK;
 }
@@ -367,8 +368,7 @@ static int mm_finish_slices(mk_multi *m, mk_result *out, double *gather_ms, doub
 extern "C" int mk_multi_finish(mk_multi *m, mk_result *out, double *gather_ms, double *tail_ms) {
   if (!m || !out) return MK_ERR_ARG;
   /* which merge: the slices pay from four engines on (the fold on engine 0 shrinks by n - 1, two more exchange steps come in) */
-  if (m->n > 1 && m->n <= MM_SLICES_MAX && (m->merge == MK_MULTI_MERGE_SLICES || (m->merge == MK_MULTI_MERGE_AUTO && m->n >= 4)))
-    return mm_finish_slices(m, out, gather_ms, tail_ms); /* (more than 16 engines -- the command line takes 64 -- gather) */
+  if (m->n > 1 && (m->merge == MK_MULTI_MERGE_SLICES || (m->merge == MK_MULTI_MERGE_AUTO && m->n >= 4))) return mm_finish_slices(m, out, gather_ms, tail_ms);
   const double t0 = mm_now();
   const int n = m->n;
   std::vector<uint64_t> cnt((size_t)n, 0), off((size_t)n, 0);

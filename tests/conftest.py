@@ -135,3 +135,15 @@ def pytest_runtest_makereport(item, call):
                     budget -= sz
     except Exception as exc:  # never mask the test's own failure
         sys.stderr.write("conftest: could not keep the failure's evidence: %r\n" % (exc,))
+
+
+def pytest_runtest_logreport(report):
+    """MK_TEST_DURATIONS=<file>: one line per finished test (seconds, outcome, id), written as the run goes -- a suite that is stopped from
+    outside (gpurun's limit) still says where its time went"""
+    path = os.environ.get("MK_TEST_DURATIONS")
+    if path and report.when == "call":
+        try:
+            with open(path, "a") as f:
+                f.write("%9.3f %s %s\n" % (report.duration, report.outcome, report.nodeid))
+        except OSError:
+            pass

@@ -976,28 +976,29 @@ def test_multi_library_both_merges_equal_oracle(capi, shufs, oracle_for, ndev, m
         m.close()
 
 
-def test_multi_library_seventeen_engines_fall_back_to_the_gather(capi, shufs, oracle_for):
-    """more engines than mk_partial_export_split has parts (16): MK_MULTI_MERGE_AUTO gathers instead of failing inside the split, and asking
-    for the slices by name is refused when it is asked for (the command line takes up to 64 devices, the same one several times)"""
+def test_multi_library_refuses_more_engines_than_the_slices_have_parts(capi, shufs, oracle_for):
+    """the merge by key slices cuts every list into one part per engine, sixteen at most (mk_partial_export_split): a seventeenth engine is
+    refused when the set is MADE, with a message that says so -- not inside the first finish (the command line's --devices takes 64 names);
+    sixteen engines on one GPU work, by slices"""
     shuf = shufs("L1K7")
+    with pytest.raises(capi.MkError, match="at most 16"):
+        capi.Multi(shuf, [0] * 17)
     rs = np.random.RandomState(5)
     seqs = ui.pool_reads(rs, 20000, 3000)
     stride = 304
     rows = ui.rows_from_seqs(seqs, stride)
     rc, want = oracle_for(shuf).koc_from_rows(rows, stride)
     assert rc == 0
-    ndev = 17
+    ndev = 16
     m = capi.Multi(shuf, [0] * ndev)
     try:
-        with pytest.raises(capi.MkError):
-            m.set_merge(capi.MK_MULTI_MERGE_SLICES)
         m.begin(capi.MK_MODE_KOC)
         piece = 100
         for i, a in enumerate(range(0, len(seqs), piece)):
             b = min(len(seqs), a + piece)
             m.push_reads(i % ndev, rows[a * stride:b * stride], stride, a)
-        assert_same(m.finish(), want, "17 engines, auto merge")
-        assert m.last_merge() == "gather"
+        assert_same(m.finish(), want, "16 engines, auto merge")
+        assert m.last_merge() == "slices"
     finally:
         m.close()
 
