@@ -298,7 +298,7 @@ def _file_read_seconds(path, threads=32, piece=8 << 20):
         os.close(fd)
 
 
-def leg_e2e_gz(capi, cli, sp, tmp, nreads=5_000_000, pieces=16, reps=2):
+def leg_e2e_gz(capi, cli, sp, tmp, nreads=2_000_000, pieces=16, reps=2):
     """row a5's everyday form: the same kind of reads gzip-compressed.  The command line reads a .gz through ONE `zcat -fc` child like the
     reference (iseq2comem.c:666-669), so inflate on one core bounds it -- two orders of magnitude under the plain-file rate."""
     import numpy as np
@@ -600,7 +600,7 @@ def leg_config5(capi, genomes=1024, mbases=4.0, threads=0, reps=5, ref_genomes=4
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def leg_next_rows_cli(capi, genomes=1024, mbases=0.25, queries=8, reads_per_query=100_000, search_queries=64):
+def leg_next_rows_cli(capi, genomes=1024, mbases=0.25, queries=8, reads_per_query=100_000, search_queries=64, ref_stage2_timeout=0):
     """SURVEY.md 8f rows N3 / N4 through the product command line on a stated synthetic database, the compiled reference timed beside it on
     the SAME directories (they are the reference's own formats) and its outputs compared:
       markers   `set -g tax` -> `set -q` -> `set -i`   the README's MarkerDB recipe on the L3K10 sketch directory of `genomes` genomes, one species each
@@ -741,13 +741,16 @@ def leg_next_rows_cli(capi, genomes=1024, mbases=0.25, queries=8, reads_per_quer
             else:
                 out["search"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "sample": "not finished after 90 s (stopped)" if rr2 is None else
                                                  "failed: " + rr2.stderr.decode(errors="replace")[-200:]}
-            if with_ref_index:
-                rr, wr = run_ref([ref, "dist", "-p", str(cores), "-o", "mco_ref", "sk"], 45)
+            if not ref_stage2_timeout:
+                out["stage2"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "cores": cores,
+                                                 "sample": "not run inside the default bench (`--ref-stage2-timeout S` runs it): the reference builds and writes the 32 GiB "
+                                                           "index whatever the input, minutes on this pool -- its time for THIS directory, with the files compared, is in "
+                                                           "profiles/r06_next_rows_reference_stage2.json; 85 s for 10 M ids in profiles/r01_search_cli_vs_reference.json"}
+            elif with_ref_index:
+                rr, wr = run_ref([ref, "dist", "-p", str(cores), "-o", "mco_ref", "sk"], ref_stage2_timeout)
                 if rr is None or rr.returncode != 0:
                     out["stage2"]["cpu_baseline"] = {"seconds": None, "kind": "reference", "cores": cores,
-                                                     "sample": "oracle/_ref/metakssd dist -p %d -o on the same sketch directory: not finished after 45 s (stopped; "
-                                                               "85 s for 10 M ids on this pool's scratch disk, profiles/r01_search_cli_vs_reference.json, files "
-                                                               "identical there)" % cores}
+                                                     "sample": "oracle/_ref/metakssd dist -p %d -o on the same sketch directory: not finished after %d s (stopped)" % (cores, ref_stage2_timeout)}
                 else:
                     same = all(filecmp.cmp(os.path.join(tmp, "mco", f), os.path.join(tmp, "mco_ref", f), shallow=False) for f in ("mco.0", "mcofiles.stat", "mco.index.0"))
                     out["stage2"]["cpu_baseline"] = {"seconds": wr, "kind": "reference", "cores": cores,
@@ -1101,6 +1104,9 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic (N = 1, host legs on)")
     ap.add_argument("--no-config5", action="store_true", help="skip the genome-directory leg (BASELINE config 5 through the command line)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the `next_rows` leg (SURVEY.md 8f N3 / N4: composite, stage II, dist -r)")
+    ap.add_argument("--ref-stage2-timeout", type=int, default=0,
+                    help="next_rows: also run the compiled reference's stage II on the same sketch directory, for at most this many seconds (0: not run; "
+                         "it takes minutes whatever the input)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo moves the lists through the host (debug)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses GPU 0 (needs --backend gloo)")
@@ -1162,7 +1168,7 @@ def main():
                 early["config5"] = {"what": "failed: %s" % ex}
         if not args.no_next_rows:
             try:
-                early["next_rows"] = leg_next_rows_cli(capi)
+                early["next_rows"] = leg_next_rows_cli(capi, ref_stage2_timeout=args.ref_stage2_timeout)
             except Exception as ex:  # noqa: BLE001
                 early["next_rows"] = {"what": "failed: %s" % str(ex)[:300]}
     _GPU_TOUCHED[0] = True

@@ -46,6 +46,8 @@ struct mk_setop {
   uint32_t *d_fcount = nullptr;
   unsigned long long *d_foff = nullptr;
   uint64_t fchunk_cap = 0;
+  uint16_t *d_fflags = nullptr; /* pass 1's keep decisions, 16 bits a lane: [chunks][64] */
+  uint64_t fflags_cap = 0;
   unsigned long long *d_bounds = nullptr, *d_bounds_out = nullptr;
   uint64_t bounds_cap = 0;
   /* mk_setop_group: auxiliary first-position table, first-occurrence list, the taxon's slot table */
@@ -194,8 +196,11 @@ __global__ void __launch_bounds__(256) mk_set_write_kernel(const uint32_t *seen,
 #define MK_SET_FCHUNK 1024u /* ids per wave: lane l owns the 16 consecutive ids [16 l, 16 l + 16) of the chunk */
 
 /* Ordered stream compaction shared by -i / -s (membership), and by -g (first occurrences; occupied table slots): a
- * predicate P maps an input position to {keep?, value}.  Pass 1 counts per chunk, pass 2 (after the prefix) rewrites:
- * lane l owns the 16 consecutive positions [16 l, 16 l + 16) of its wave's chunk, so the output keeps the input order. */
+ * predicate P maps an input position to {keep?, value}.  Pass 1 counts per chunk and KEEPS every lane's 16 decisions (2 bytes a lane:
+ * n / 8 bytes in all), pass 2 (after the prefix) rewrites from those and asks P only for the values of kept positions -- the predicate
+ * (a dictionary probe, a bitmap read) is evaluated once per position, not twice: the join of a MarkerDB keeps 2 % of 100 M positions,
+ * its second pass went from a second round of 100 M probes to 2 M (round 6: 5.1 -> see DESIGN.md 4.6).
+ * Lane l owns the 16 consecutive positions [16 l, 16 l + 16) of its wave's chunk, so the output keeps the input order. */
 struct mk_pred_member { /* ids[i] kept iff its dictionary bit == keep */
   const uint32_t *ids, *seen;
   uint32_t keep;
@@ -203,6 +208,7 @@ struct mk_pred_member { /* ids[i] kept iff its dictionary bit == keep */
     v = ids[i];
     return ((seen[v >> 5] >> (v & 31u)) & 1u) == keep;
   }
+  __device__ __forceinline__ uint32_t value(uint64_t i) const { return ids[i]; } /* of a position pass 1 has kept */
 };
 
 template <class P>
@@ -217,12 +223,14 @@ __device__ __forceinline__ uint32_t mk_set_keep16(const P &p, uint64_t i0, uint6
 }
 
 template <class P>
-__global__ void __launch_bounds__(256) mk_set_fcount_kernel(const P p, uint64_t n, uint64_t nchunks, uint32_t *chunk_count) {
+__global__ void __launch_bounds__(256) mk_set_fcount_kernel(const P p, uint64_t n, uint64_t nchunks, uint32_t *chunk_count, uint16_t *flags_out) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (chunk >= nchunks) return;
   uint32_t v[16];
-  uint32_t c = __popc(mk_set_keep16(p, chunk * MK_SET_FCHUNK + 16u * lane, n, v));
+  const uint32_t flags = mk_set_keep16(p, chunk * MK_SET_FCHUNK + 16u * lane, n, v);
+  flags_out[chunk * 64u + lane] = (uint16_t)flags;
+  uint32_t c = __popc(flags);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
   if (lane == 0) chunk_count[chunk] = c;
@@ -252,12 +260,13 @@ __global__ void __launch_bounds__(1024) mk_set_scan_n_kernel(const uint32_t *cou
 
 template <class P>
 __global__ void __launch_bounds__(256) mk_set_fwrite_kernel(const P p, uint64_t n, uint64_t nchunks, const uint32_t *chunk_count,
-                                                            const unsigned long long *chunk_off, uint32_t *out) {
+                                                            const unsigned long long *chunk_off, uint32_t *out, const uint16_t *flags_in) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (chunk >= nchunks || chunk_count[chunk] == 0u) return; /* wave-uniform */
-  uint32_t v[16];
-  const uint32_t flags = mk_set_keep16(p, chunk * MK_SET_FCHUNK + 16u * lane, n, v);
+  (void)n;
+  const uint64_t i0 = chunk * MK_SET_FCHUNK + 16u * lane;
+  const uint32_t flags = flags_in[chunk * 64u + lane]; /* pass 1's decisions (positions at and beyond n: 0) */
   const uint32_t mine = __popc(flags);
   uint32_t incl = mine;
 #pragma unroll
@@ -268,7 +277,7 @@ __global__ void __launch_bounds__(256) mk_set_fwrite_kernel(const P p, uint64_t 
   uint32_t *o = out + chunk_off[chunk] + (incl - mine);
 #pragma unroll
   for (uint32_t k = 0; k < 16; k++)
-    if ((flags >> k) & 1u) *o++ = v[k];
+    if ((flags >> k) & 1u) *o++ = p.value(i0 + k);
 }
 
 /* ---- set -g: one taxon's table of grouping_genomes() (command_set.c:874-915) ------------------------------------------
@@ -322,6 +331,7 @@ struct mk_pred_first { /* position i kept iff it is the first occurrence of ids[
       h = (h + 1u) & amask;
     }
   }
+  __device__ __forceinline__ uint32_t value(uint64_t i) const { return ids[i]; }
 };
 
 struct mk_pred_slot { /* slot s kept iff occupied; value = the id whose rank it holds */
@@ -332,6 +342,7 @@ struct mk_pred_slot { /* slot s kept iff occupied; value = the id whose rank it 
     v = L[r];
     return true;
   }
+  __device__ __forceinline__ uint32_t value(uint64_t s) const { return L[slot[s]]; }
 };
 
 /* composite -q (command_composite.c:537-553): reference position i kept iff its id occurs among the query's ids; value =
@@ -351,6 +362,7 @@ struct mk_pred_join {
       h = (h + 1u) & amask;
     }
   }
+  __device__ __forceinline__ uint32_t value(uint64_t i) const { uint32_t v = 0; (void)(*this)(i, v); return v; } /* (kept positions only: 2 % of a MarkerDB) */
 };
 
 __global__ void __launch_bounds__(256) mk_grp_layout_kernel(const uint32_t *L, uint32_t D, uint32_t *slot, uint32_t S) {
@@ -378,17 +390,15 @@ __global__ void __launch_bounds__(256) mk_grp_layout_kernel(const uint32_t *L, u
 template <class P>
 __global__ void __launch_bounds__(256) mk_set_bounds_kernel(const P p, uint64_t n, uint64_t nchunks, const unsigned long long *chunk_off,
                                                             const unsigned long long *total, const unsigned long long *bounds,
-                                                            uint32_t nb, unsigned long long *out) {
+                                                            uint32_t nb, unsigned long long *out, const uint16_t *flags_in) {
+  (void)p;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nb) return;
   uint64_t b = bounds[j];
   if (b > n) b = n;
   const uint64_t c = b / MK_SET_FCHUNK;
   unsigned long long acc = c < nchunks ? chunk_off[c] : *total;
-  for (uint64_t i = c * MK_SET_FCHUNK; i < b; i++) {
-    uint32_t v;
-    acc += p(i, v) ? 1u : 0u;
-  }
+  for (uint64_t i = c * MK_SET_FCHUNK; i < b; i++) acc += (flags_in[i >> 4] >> (i & 15u)) & 1u; /* (position i: lane (i % 1024) / 16 of chunk i / 1024, bit i % 16) */
   out[j] = acc;
 }
 
@@ -436,7 +446,7 @@ extern "C" int mk_setop_destroy(mk_setop *s) {
   (void)hipFree(s->d_seen); (void)hipFree(s->d_dup); (void)hipFree(s->d_chunk); (void)hipFree(s->d_chunk_off);
   (void)hipFree(s->d_total); (void)hipFree(s->d_out);
   (void)hipFree(s->d_aux); (void)hipFree(s->d_first); (void)hipFree(s->d_slot); (void)hipFree(s->d_qids); (void)hipFree(s->d_qab);
-  (void)hipFree(s->d_in); (void)hipFree(s->d_fcount); (void)hipFree(s->d_foff); (void)hipFree(s->d_bounds); (void)hipFree(s->d_bounds_out);
+  (void)hipFree(s->d_in); (void)hipFree(s->d_fcount); (void)hipFree(s->d_foff); (void)hipFree(s->d_fflags); (void)hipFree(s->d_bounds); (void)hipFree(s->d_bounds_out);
   if (s->h_total) (void)hipHostFree(s->h_total);
   if (s->h_out) (void)hipHostFree(s->h_out);
   for (int b = 0; b < 2; b++) {
@@ -573,6 +583,7 @@ extern "C" int mk_setop_filter(mk_setop *s, int keep_members, const uint32_t *id
     if ((rc = mk_set_grow(s, (void **)&s->d_fcount, &c1, nchunks, 4))) return rc;
     if ((rc = mk_set_grow(s, (void **)&s->d_foff, &c2, nchunks, 8))) return rc;
     s->fchunk_cap = c1 < c2 ? c1 : c2;
+    if ((rc = mk_set_grow(s, (void **)&s->d_fflags, &s->fflags_cap, nchunks * 64u, 2))) return rc;
   }
   {
     uint64_t c1 = s->bounds_cap, c2 = s->bounds_cap;
@@ -585,16 +596,16 @@ extern "C" int mk_setop_filter(mk_setop *s, int keep_members, const uint32_t *id
     MK_SET_HIP(s, hipMemcpyAsync(s->d_in, ids, n * 4, hipMemcpyHostToDevice, s->stream));
     const unsigned blocks = (unsigned)((nchunks + 3) / 4);
     const mk_pred_member pm{s->d_in, s->d_seen, keep};
-    hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_member>, dim3(blocks), dim3(256), 0, s->stream, pm, n, nchunks, s->d_fcount);
+    hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_member>, dim3(blocks), dim3(256), 0, s->stream, pm, n, nchunks, s->d_fcount, s->d_fflags);
     hipLaunchKernelGGL(mk_set_scan_n_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_fcount, nchunks, s->d_foff, s->d_total);
     hipLaunchKernelGGL(mk_set_fwrite_kernel<mk_pred_member>, dim3(blocks), dim3(256), 0, s->stream, pm, n, nchunks, s->d_fcount,
-                       s->d_foff, s->d_out);
+                       s->d_foff, s->d_out, (const uint16_t *)s->d_fflags);
     MK_SET_HIP(s, hipGetLastError());
     MK_SET_HIP(s, hipMemcpyAsync(s->h_total, s->d_total, 8, hipMemcpyDeviceToHost, s->stream));
     if (nb) {
       MK_SET_HIP(s, hipMemcpyAsync(s->d_bounds, bounds, (size_t)nb * 8, hipMemcpyHostToDevice, s->stream));
       hipLaunchKernelGGL(mk_set_bounds_kernel<mk_pred_member>, dim3((nb + 255) / 256), dim3(256), 0, s->stream, pm, n, nchunks,
-                         s->d_foff, s->d_total, s->d_bounds, nb, s->d_bounds_out);
+                         s->d_foff, s->d_total, s->d_bounds, nb, s->d_bounds_out, (const uint16_t *)s->d_fflags);
       MK_SET_HIP(s, hipGetLastError());
       MK_SET_HIP(s, hipMemcpyAsync(bounds_out, s->d_bounds_out, (size_t)nb * 8, hipMemcpyDeviceToHost, s->stream));
     }
@@ -648,6 +659,7 @@ extern "C" int mk_setop_group(mk_setop *s, const uint32_t *ids, uint64_t n, uint
     if ((rc = mk_set_grow(s, (void **)&s->d_fcount, &c1, maxchunks, 4))) return rc;
     if ((rc = mk_set_grow(s, (void **)&s->d_foff, &c2, maxchunks, 8))) return rc;
     s->fchunk_cap = c1 < c2 ? c1 : c2;
+    if ((rc = mk_set_grow(s, (void **)&s->d_fflags, &s->fflags_cap, maxchunks * 64u, 2))) return rc;
   }
   MK_SET_HIP(s, hipMemcpyAsync(s->d_in, ids, n * 4, hipMemcpyHostToDevice, s->stream));
   MK_SET_HIP(s, hipMemsetAsync(s->d_aux, 0xFF, asize * 8, s->stream));
@@ -658,10 +670,10 @@ extern "C" int mk_setop_group(mk_setop *s, const uint32_t *ids, uint64_t n, uint
   /* first occurrences, in input order */
   const mk_pred_first pf{s->d_in, s->d_aux, (uint32_t)(asize - 1)};
   const unsigned fb = (unsigned)((nchunks + 3) / 4);
-  hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_first>, dim3(fb), dim3(256), 0, s->stream, pf, n, nchunks, s->d_fcount);
+  hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_first>, dim3(fb), dim3(256), 0, s->stream, pf, n, nchunks, s->d_fcount, s->d_fflags);
   hipLaunchKernelGGL(mk_set_scan_n_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_fcount, nchunks, s->d_foff, s->d_total);
   hipLaunchKernelGGL(mk_set_fwrite_kernel<mk_pred_first>, dim3(fb), dim3(256), 0, s->stream, pf, n, nchunks, s->d_fcount, s->d_foff,
-                     s->d_first);
+                     s->d_first, (const uint16_t *)s->d_fflags);
   MK_SET_HIP(s, hipGetLastError());
   MK_SET_HIP(s, hipMemcpyAsync(s->h_total, s->d_total, 8, hipMemcpyDeviceToHost, s->stream));
   MK_SET_HIP(s, hipStreamSynchronize(s->stream));
@@ -672,10 +684,10 @@ extern "C" int mk_setop_group(mk_setop *s, const uint32_t *ids, uint64_t n, uint
     hipLaunchKernelGGL(mk_grp_layout_kernel, dim3((unsigned)lb), dim3(256), 0, s->stream, s->d_first, (uint32_t)D, s->d_slot, table_size);
     const mk_pred_slot ps{s->d_slot, s->d_first};
     const unsigned sb = (unsigned)((schunks + 3) / 4);
-    hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_slot>, dim3(sb), dim3(256), 0, s->stream, ps, (uint64_t)table_size, schunks, s->d_fcount);
+    hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_slot>, dim3(sb), dim3(256), 0, s->stream, ps, (uint64_t)table_size, schunks, s->d_fcount, s->d_fflags);
     hipLaunchKernelGGL(mk_set_scan_n_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_fcount, schunks, s->d_foff, s->d_total);
     hipLaunchKernelGGL(mk_set_fwrite_kernel<mk_pred_slot>, dim3(sb), dim3(256), 0, s->stream, ps, (uint64_t)table_size, schunks, s->d_fcount,
-                       s->d_foff, s->d_out);
+                       s->d_foff, s->d_out, (const uint16_t *)s->d_fflags);
     MK_SET_HIP(s, hipGetLastError());
     MK_SET_HIP(s, hipMemcpyAsync(s->h_total, s->d_total, 8, hipMemcpyDeviceToHost, s->stream));
     MK_SET_HIP(s, hipStreamSynchronize(s->stream));
@@ -712,6 +724,7 @@ extern "C" int mk_setop_join(mk_setop *s, const uint32_t *qry_ids, const uint16_
     if ((rc = mk_set_grow(s, (void **)&s->d_fcount, &c1, nchunks, 4))) return rc;
     if ((rc = mk_set_grow(s, (void **)&s->d_foff, &c2, nchunks, 8))) return rc;
     s->fchunk_cap = c1 < c2 ? c1 : c2;
+    if ((rc = mk_set_grow(s, (void **)&s->d_fflags, &s->fflags_cap, nchunks * 64u, 2))) return rc;
   }
   {
     uint64_t c1 = s->bounds_cap, c2 = s->bounds_cap;
@@ -731,10 +744,10 @@ extern "C" int mk_setop_join(mk_setop *s, const uint32_t *qry_ids, const uint16_
   hipLaunchKernelGGL(mk_grp_insert_kernel, dim3((unsigned)ib), dim3(256), 0, s->stream, s->d_qids, nq, s->d_aux, (uint32_t)(asize - 1), 0);
   const mk_pred_join pj{s->d_in, s->d_aux, (uint32_t)(asize - 1), s->d_qab};
   const unsigned fb = (unsigned)((nchunks + 3) / 4);
-  hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_join>, dim3(fb), dim3(256), 0, s->stream, pj, nref, nchunks, s->d_fcount);
+  hipLaunchKernelGGL(mk_set_fcount_kernel<mk_pred_join>, dim3(fb), dim3(256), 0, s->stream, pj, nref, nchunks, s->d_fcount, s->d_fflags);
   hipLaunchKernelGGL(mk_set_scan_n_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_fcount, nchunks, s->d_foff, s->d_total);
   hipLaunchKernelGGL(mk_set_fwrite_kernel<mk_pred_join>, dim3(fb), dim3(256), 0, s->stream, pj, nref, nchunks, s->d_fcount, s->d_foff,
-                     s->d_out);
+                     s->d_out, (const uint16_t *)s->d_fflags);
   MK_SET_HIP(s, hipGetLastError());
   MK_SET_HIP(s, hipEventRecord(s->ev_join[1], s->stream));
   s->join_timed = true;
@@ -742,7 +755,7 @@ extern "C" int mk_setop_join(mk_setop *s, const uint32_t *qry_ids, const uint16_
   if (nb) {
     MK_SET_HIP(s, hipMemcpyAsync(s->d_bounds, bounds, (size_t)nb * 8, hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(mk_set_bounds_kernel<mk_pred_join>, dim3((nb + 255) / 256), dim3(256), 0, s->stream, pj, nref, nchunks, s->d_foff,
-                       s->d_total, s->d_bounds, nb, s->d_bounds_out);
+                       s->d_total, s->d_bounds, nb, s->d_bounds_out, (const uint16_t *)s->d_fflags);
     MK_SET_HIP(s, hipGetLastError());
     MK_SET_HIP(s, hipMemcpyAsync(bounds_out, s->d_bounds_out, (size_t)nb * 8, hipMemcpyDeviceToHost, s->stream));
   }
