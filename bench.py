@@ -916,6 +916,15 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def sketch_digest(ids, counts):
+    """sha256 over a one-component sketch's ids and counts as they lie in combco.0 / combco.0.a"""
+    import numpy as np
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(ids, dtype=np.uint32).tobytes())
+    h.update(np.ascontiguousarray(counts, dtype=np.uint16).tobytes())
+    return h.hexdigest()
+
+
 def leg_inproc_multi(torch, capi, shuf, devices, total_reads, steps, merge, reference_sketch):
     """the C product's own multi-GPU path in THIS process: libmetakssd_multi.so (what `metakssd dist --devices` runs on) -- one engine
     per listed GPU, every engine scans its contiguous read range out of its GPU's HBM, mk_multi_finish merges (RCCL grouped
@@ -953,14 +962,14 @@ def leg_inproc_multi(torch, capi, shuf, devices, total_reads, steps, merge, refe
                 phases[k] = phases.get(k, 0.0) + v
         dt = (time.perf_counter() - t0) / steps
         same = None
+        comp = r.components[0]
+        ids = np.ctypeslib.as_array(comp.ids, shape=(comp.n,)) if comp.n else np.zeros(0, np.uint32)
+        cnt = np.ctypeslib.as_array(comp.counts, shape=(comp.n,)) if comp.n else np.zeros(0, np.uint16)
         if reference_sketch is not None:  # the last result against the torch.distributed flow's merged sketch, ids and counts in order
-            comp = r.components[0]
-            ids = np.ctypeslib.as_array(comp.ids, shape=(comp.n,)) if comp.n else np.zeros(0, np.uint32)
-            cnt = np.ctypeslib.as_array(comp.counts, shape=(comp.n,)) if comp.n else np.zeros(0, np.uint16)
             same = bool(r.component_num == len(reference_sketch) and np.array_equal(ids, reference_sketch[0][0]) and
                         np.array_equal(cnt, reference_sketch[0][1]))
         return {"gbases_s": total_reads * READ_LEN / dt / 1e9, "ms_per_step": dt * 1e3, "steps": steps, "engines": n, "devices": list(devices),
-                "transport": m.transport(), "merge": m.last_merge(), "distinct_keys": int(r.total),
+                "transport": m.transport(), "merge": m.last_merge(), "distinct_keys": int(r.total), "sketch_sha256": sketch_digest(ids, cnt),
                 "gather_ms": sum(gathers) / len(gathers), "tail_ms": sum(tails) / len(tails),
                 "tail_phases_ms": {k: v / steps for k, v in phases.items()},
                 "equals_process_per_gpu_sketch": same,
@@ -1128,9 +1137,19 @@ def main():
                          "speedup and efficiency")
     ap.add_argument("--verify", action="store_true",
                     help="after timing, rank 0 re-sketches ALL ranks' reads on one engine and compares with the merged result")
+    ap.add_argument("--inproc-child", default=None,
+                    help="(internal) run ONLY the libmetakssd_multi.so leg on this comma-separated device list and print its JSON: rank 0 of an N > 1 run "
+                         "starts this as a child process so that an RCCL that hangs or dies there cannot take the bench line with it")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 300 if args.gpus == 1 else 40
+    if args.inproc_child is not None:
+        import torch
+        from metakssd_amd import capi
+        devs = [int(x) for x in args.inproc_child.split(",")]
+        out = leg_inproc_multi(torch, capi, capi.Shuf.generate(11, 6, 3, 11), devs, args.total_reads or CONFIG4_READS, args.steps, args.merge, None)
+        print(json.dumps(out), flush=True)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: start the N ranks ourselves, as a CHILD process, before this process has imported torch or
@@ -1568,9 +1587,30 @@ def main():
                 except Exception as ex:  # noqa: BLE001
                     one_gpu = {"ms_per_step": None, "efficiency": None, "what": "failed: %s" % str(ex)[:300]}
             if args.inproc_multi:
+                # in a CHILD process with a time limit: libmetakssd_multi.so's RCCL path has not run on real links yet; whatever it does there,
+                # the line of this run still comes out.  (A child may use the GPUs beside this process: a new program started as a child, not
+                # this one replaced.)
                 try:
                     devs = [0] * world if args.same_device else list(range(world))
-                    inproc = leg_inproc_multi(torch, capi, shuf, devs, total_reads, max(3, min(args.steps, 20)), args.merge, result.get("sketch"))
+                    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                            "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+                    if args.same_device:
+                        env["MK_MULTI_ALLOW_COPIES"] = "1"
+                    cr = subprocess.run([sys.executable, os.path.abspath(__file__), "--inproc-child", ",".join(str(d) for d in devs), "--total-reads",
+                                         str(total_reads), "--steps", str(max(3, min(args.steps, 20))), "--merge", args.merge],
+                                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+                    lines = [ln for ln in cr.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+                    if cr.returncode != 0 or not lines:
+                        inproc = {"gbases_s": None, "transport": None, "what": "the child process failed (rc %d): %s" % (
+                            cr.returncode, cr.stderr.decode(errors="replace")[-400:])}
+                    else:
+                        inproc = json.loads(lines[-1])
+                        sk0 = result.get("sketch")
+                        inproc["equals_process_per_gpu_sketch"] = None if sk0 is None else bool(
+                            len(sk0) == 1 and inproc.get("sketch_sha256") == sketch_digest(sk0[0][0], sk0[0][1]))
+                        inproc["what"] = inproc["what"].replace("in rank 0's process", "in a child process of rank 0 (time limit 900 s)")
+                except subprocess.TimeoutExpired:
+                    inproc = {"gbases_s": None, "transport": None, "what": "the child process did not finish within 900 s (stopped)"}
                 except Exception as ex:  # noqa: BLE001
                     inproc = {"gbases_s": None, "transport": None, "what": "failed: %s" % ex}
             store.set("mk_rank0_legs_done", "1")

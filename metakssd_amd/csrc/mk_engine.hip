@@ -637,6 +637,7 @@ static int mk_tail_end(mk_engine *e);
  * whose clears are the engine's own business (that is what the hook is there to check). */
 static int mk_poison_scratch(mk_engine *e) {
   if (mk_poison_byte() < 0) return MK_OK;
+  { static const bool off = getenv("MK_POISON_SCRATCH") && atoi(getenv("MK_POISON_SCRATCH")) == 0; if (off) return MK_OK; } /* (bisecting: allocations only) */
   hipStream_t s = e->stream;
   if (e->d_cand) MK_HIP(e, mk_dev_repoison(e->d_cand, (size_t)e->cand_slots * (e->cand_cap + 1) * sizeof(uint4), s));
   if (e->d_kl) MK_HIP(e, mk_dev_repoison(e->d_kl, (size_t)e->kl_cap * (8 + 8 + 4 + 4 + 2) + 64, s));
@@ -2301,10 +2302,16 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
 
   /* ---- tables: 2^tb slots per file, about five times the keys the largest file is expected to leave (its k-mers / 16^drlevel) */
   uint32_t tb = 10;
+  uint64_t est_ids = 0; /* ids the whole batch is expected to leave: every file's bases / 16^drlevel */
   {
     /* (bases of the largest file: its text, or its rows' 153 - TL new bases each) */
     const uint64_t nbases = rows ? nmax / MK_PACKED_PITCH * (row_bases + 1u - TL) : nmax;
-    const uint64_t est = (nbases >> (4u * (uint32_t)e->P.drlevel)) * 5u;
+    est_ids = (rows ? total / MK_PACKED_PITCH * (row_bases + 1u - TL) : total) >> (4u * (uint32_t)e->P.drlevel);
+    /* three times the keys the largest file is expected to leave (round 6; five before): every kernel behind a batch's scan sweeps the
+     * tables or the maps -- clear, compaction, both bucket passes -- and the link idles while they run.  At L2K11 (15 600 keys a 4 Mbase genome)
+     * that is 2^16 instead of 2^17 slots a file, load 0.24: the 32 batches of 1 024 genomes lose 2.3 of 11.3 ms of such kernels
+     * (profiles/r06_config5_trace.txt).  A file with more keys than half its table is sketched alone, as before */
+    const uint64_t est = (nbases >> (4u * (uint32_t)e->P.drlevel)) * 3u;
     while (tb < 22u && (1ull << tb) < est) tb++;
     if (e->batch_tb_opt) tb = (uint32_t)e->batch_tb_opt;
     while (tb > 9u && ((uint64_t)nfiles << tb) > (1ull << 26)) tb--; /* (files that do not fit then are sketched alone) */
@@ -2438,7 +2445,10 @@ static int mk_batch_begin_impl(mk_engine *e, int mode, const mk_batch_file *file
    * hand every result out one batch late with the device idle meanwhile; a copy COMMAND here would have to guess the count, and be
    * the process's first use of the copy engine where the rows are read in place).  The block holds half of every table, 8 M ids at
    * most; a batch with more -- none so far -- gets the rest by a copy in mk_sketch_batch_end. */
+  /* (twice the ids the batch is expected to leave, not half of every table: pinned memory costs 0.2 ms a MiB to make, and the first three
+   * batches of a run each make a block -- 8.4 MB at L2K11, now 4) */
   c->spec_ids = N / 2u < ((uint64_t)8 << 20) ? N / 2u : ((uint64_t)8 << 20);
+  { const uint64_t want = (2u * est_ids + 65536u + 3u) & ~(uint64_t)3u; if (want < c->spec_ids) c->spec_ids = want; }
   if ((rc = mk_pinned_fit(e, (void **)&c->h_ids, &c->h_ids_cap, (size_t)c->spec_ids * 4))) return rc;
   hipLaunchKernelGGL(mk_b_home_kernel, dim3((unsigned)e->num_cu), dim3(256), 0, s, c->hb, (uint4 *)c->h_stat, (uint32_t)(c->stat_bytes / 16u), (uint4 *)c->h_ids,
                      (unsigned long long)c->spec_ids, (const uint32_t *)e->tab.err);
