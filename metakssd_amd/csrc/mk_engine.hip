@@ -299,7 +299,12 @@ extern "C" int mk_engine_destroy(mk_engine *e) {
   if (e->scan_lent > 0) return mk_fail(e, MK_ERR_STATE, "mk_engine_destroy: %d engine(s) still borrow this engine's scan queue (mk_engine_share_scan_queue): destroy them first", e->scan_lent);
   if (e->scan_owner) { e->scan_owner->scan_lent--; e->scan_owner = nullptr; }
   hipSetDevice(e->device);
-  hipDeviceSynchronize();
+  /* everything this engine has queued, on the streams it knows: its own, the caller's (mk_engine_set_stream), the queues of MK_OPT_SPLIT_CUS
+   * (a borrowed scan queue too: this engine's scans are on it), the side stream.  Not hipDeviceSynchronize(): other engines' work is none of
+   * this engine's business */
+  (void)hipStreamSynchronize(e->stream); /* (a caller's stream may be the default stream, i.e. NULL: waited for like any other) */
+  for (hipStream_t st : {e->own_stream, e->copy_stream, e->scan_stream, e->split_stream, e->res_stream})
+    if (st && st != e->stream) (void)hipStreamSynchronize(st);
   hipFree(e->d_pairs);
   hipFree(e->d_cand); hipFree(e->d_cand_count);
   hipFree(e->d_shuf); hipFree(e->d_accept); hipFree(e->d_accept_bits); hipFree(e->d_tab); hipFree(e->d_front); hipFree(e->d_front_desc); hipFree(e->d_slot);
@@ -1357,7 +1362,7 @@ extern "C" int mk_sketch_push_reads(mk_engine *e, const uint8_t *rows, uint32_t 
 static int mk_fa_reserve(mk_engine *e, size_t n) {
   if (!e->d_fa_state) {
     MK_HIP(e, mk_dev_alloc(&e->d_fa_state, sizeof(mk_fa_state)));
-    MK_HIP(e, hipMemset(e->d_fa_state, 0, sizeof(mk_fa_state)));
+    MK_HIP(e, hipMemsetAsync(e->d_fa_state, 0, sizeof(mk_fa_state), e->stream)); /* (never the default stream: see mk_poison.hip.h) */
     MK_HIP(e, mk_pin_alloc((void **)&e->h_fa_state, sizeof(mk_fa_state), hipHostMallocDefault));
   }
   /* whole segments: the last wave of a piece loads MK_FA_SEG bytes from its segment's start (mk_fa_stage), so the text buffer holds
@@ -1372,8 +1377,9 @@ static int mk_fa_reserve(mk_engine *e, size_t n) {
     MK_HIP(e, mk_dev_alloc(&nt, cap));
     MK_HIP(e, mk_dev_alloc(&ns, scap));
     MK_HIP(e, mk_dev_alloc(&ntmp, 8192));
-    MK_HIP(e, hipMemset(ns, 0, scap));
-    if (e->d_stream && e->fa_tail) MK_HIP(e, hipMemcpy(ns, e->d_stream, e->fa_tail, hipMemcpyDeviceToDevice));
+    MK_HIP(e, hipMemsetAsync(ns, 0, scap, e->stream));
+    if (e->d_stream && e->fa_tail) MK_HIP(e, hipMemcpyAsync(ns, e->d_stream, e->fa_tail, hipMemcpyDeviceToDevice, e->stream));
+    MK_HIP(e, hipStreamSynchronize(e->stream)); /* the old buffers go now */
     hipFree(e->d_text); hipFree(e->d_stream); hipFree(e->d_stream_tmp);
     e->d_text = nt; e->d_stream = ns; e->d_stream_tmp = ntmp;
     e->text_cap = cap; e->stream_cap = scap;
@@ -1689,9 +1695,10 @@ extern "C" int mk_partial_list_reserve(mk_engine *e, uint64_t n, uint64_t **keys
     MK_HIP(e, mk_dev_alloc(&no, cap * 8));
     MK_HIP(e, mk_dev_alloc(&nc, cap * 4));
     if (keep) {
-      MK_HIP(e, hipMemcpy(nk, e->dist.key, keep * 8, hipMemcpyDeviceToDevice));
-      MK_HIP(e, hipMemcpy(no, e->dist.ord, keep * 8, hipMemcpyDeviceToDevice));
-      MK_HIP(e, hipMemcpy(nc, e->dist.cnt, keep * 4, hipMemcpyDeviceToDevice));
+      MK_HIP(e, hipMemcpyAsync(nk, e->dist.key, keep * 8, hipMemcpyDeviceToDevice, e->stream));
+      MK_HIP(e, hipMemcpyAsync(no, e->dist.ord, keep * 8, hipMemcpyDeviceToDevice, e->stream));
+      MK_HIP(e, hipMemcpyAsync(nc, e->dist.cnt, keep * 4, hipMemcpyDeviceToDevice, e->stream));
+      MK_HIP(e, hipStreamSynchronize(e->stream)); /* the old list goes now */
     }
     hipFree(e->dist.key); hipFree(e->dist.ord); hipFree(e->dist.cnt);
     e->dist.key = nk; e->dist.ord = no; e->dist.cnt = nc; e->dist.cap = cap;

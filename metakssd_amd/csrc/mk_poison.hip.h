@@ -5,13 +5,36 @@
 #include <string.h>
 #include "host/mk_host_internal.h"
 
+/* the fill of a fresh allocation runs on a stream of its own (non-blocking, one per device and process, made at the first poisoned allocation) and
+ * is waited for there: nobody else knows the buffer yet, so nothing else has to be ordered with it.  NOT the default stream: that one is
+ * implicitly ordered with every stream made without hipStreamNonBlocking -- the CU-masked queues of MK_OPT_SPLIT_CUS are such streams -- and a
+ * device-wide wait in the middle of an engine's two-queue hand-over is not something an allocation should do. */
+#include <mutex>
+static inline hipError_t mk_poison_stream(hipStream_t *out) {
+  static std::mutex mu;
+  static hipStream_t streams[64] = {};
+  int dev = 0;
+  hipError_t r = hipGetDevice(&dev);
+  if (r != hipSuccess) return r;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> g(mu);
+  if (!streams[dev]) {
+    r = hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking);
+    if (r != hipSuccess) { streams[dev] = nullptr; return r; }
+  }
+  *out = streams[dev];
+  return hipSuccess;
+}
+
 template <class T>
 static inline hipError_t mk_dev_alloc(T **p, size_t bytes) {
   hipError_t r = hipMalloc((void **)p, bytes);
   const int pz = mk_poison_byte();
   if (r == hipSuccess && pz >= 0 && bytes) {
-    r = hipMemset((void *)*p, pz, bytes);
-    if (r == hipSuccess) r = hipDeviceSynchronize(); /* (the engines' queues are not ordered with the default stream) */
+    hipStream_t ps = nullptr;
+    r = mk_poison_stream(&ps);
+    if (r == hipSuccess) r = hipMemsetAsync((void *)*p, pz, bytes, ps);
+    if (r == hipSuccess) r = hipStreamSynchronize(ps);
   }
   return r;
 }
