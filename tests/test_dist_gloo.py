@@ -5,6 +5,8 @@ import sys
 
 import pytest
 
+import util_inputs as ui
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -14,7 +16,7 @@ def test_sharded_sketch_merge_over_gloo(world, tmp_path):
     reduced slices (tests/dist_worker.py)"""
     result = str(tmp_path / "result.txt")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MK_DIST_RESULT=result)
-    port = 29500 + (os.getpid() % 2000) + world
+    port = ui.free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
@@ -28,7 +30,7 @@ def test_file_sharded_sketches_gather_in_file_order_over_gloo(world, tmp_path):
     arrays in file order"""
     result = str(tmp_path / "result.txt")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MK_DIST_RESULT=result)
-    port = 31500 + (os.getpid() % 2000) + world
+    port = ui.free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_files_worker.py")]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
@@ -42,7 +44,7 @@ def test_query_sharded_search_rows_gather_over_gloo(world, tmp_path):
     rank 0 receives the rows in sketch order -- equal to the unsharded matrix"""
     result = str(tmp_path / "result.txt")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MK_DIST_RESULT=result)
-    port = 33500 + (os.getpid() % 2000) + world
+    port = ui.free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_search_worker.py")]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)

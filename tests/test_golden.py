@@ -645,7 +645,7 @@ def test_product_cli_stage2_search_end_to_end(shuf_files, tmp_path):
         tool = os.path.join(ROOT, "tools", "search_multi.py")
         for world in (1, 2):
             launch = [sys.executable] if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                                                          "--master-addr", "127.0.0.1", "--master-port", str(34500 + os.getpid() % 2000)]
+                                                          "--master-addr", "127.0.0.1", "--master-port", str(__import__("util_inputs").free_port())]
             extra = [] if world == 1 else ["--backend", "gloo", "--same-device"]
             r = subprocess.run(launch + [tool, "-r", db + ".mco", "-o", "multi%d" % world] + SEARCH_CASES[case]["flags"] + [case + ".qsk"] + extra,
                                cwd=str(tmp_path), env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdin=subprocess.DEVNULL,

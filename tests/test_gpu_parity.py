@@ -908,6 +908,9 @@ def test_slice_merge_equals_oracle(capi, shufs, oracle_for, name, flavour, G):
             e.sync()
             for dst, src, w in ((ck, lk, 8), (cc, lc, 4), (co, lo, 8)):
                 assert hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(w * r), 3) == 0
+            # a device-to-device hipMemcpy does not wait for its copy: the engine must not get its list back (the next begin of this
+            # engine overwrites it -- at once under MK_POISON, which is how this was found: four suites at a time, round 6) before it is done
+            assert hip.hipDeviceSynchronize() == 0
             slices.append((ck, cc, co, r))
         # 3. the first engine: all slices behind one another in its key list, finished from the list
         if len(engines) == 1:
@@ -1061,7 +1064,7 @@ def test_bench_two_rank_flow_merged_equals_single(capi):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29700 + os.getpid() % 1000
+    port = ui.free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
            "--reads-per-gpu", "1000000", "--steps", "1", "--warmup", "1", "--verify"]  # (the N > 1 t_stream leg runs too)
@@ -1085,7 +1088,7 @@ def test_engine_export_import_across_processes(capi, world, merge, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     result = str(tmp_path / "result.txt")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MK_DIST_RESULT=result, MK_DIST_MERGE=merge)
-    port = 35500 + (os.getpid() % 2000) + world
+    port = ui.free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker.py")]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)

@@ -88,3 +88,14 @@ def random_quals(rs, seqs, p_low=0.08, low=b"#+5?", high=b"I"):
         q[m] = lo[rs.randint(0, len(lo), size=int(m.sum()))]
         out.append(q.tobytes())
     return out
+
+
+def free_port():
+    """a TCP port nobody listens on right now (for torch.distributed rendezvous on 127.0.0.1): asked from the kernel, not derived from the pid --
+    several suites at a time met each other's pid-derived ports (round 6)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p

@@ -157,6 +157,7 @@ def main():
                             eng.sync()
                             for dst, src, w in ((ck, lk, 8), (cc, lc, 4), (co, lo, 8)):
                                 assert hip.hipMemcpy(ctypes.c_void_p(dst), ctypes.c_void_p(src), ctypes.c_size_t(w * r), 3) == 0
+                            assert hip.hipDeviceSynchronize() == 0  # (a device-to-device hipMemcpy does not wait for its copy; the finish below hands the list back)
                             slices.append((ck, cc, co, r))
                             eng.finish()
                         eng.begin(capi.MK_MODE_KOC)
