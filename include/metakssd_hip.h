@@ -168,7 +168,8 @@ int mk_engine_destroy(mk_engine *e);
  *                   all but this many compute units, everything that follows a scan (candidate resolution, compaction, clears) on
  *                   these, ordered by events.  One engine gains nothing (its kernels depend on each other); TWO engines taking
  *                   sketches in turn do: what follows engine A's scan runs beside engine B's scan instead of in front of it
- *                   (bench.py's flow with device-resident rows, DESIGN.md 4.2: 2.33 instead of 2.44 ms a pass of 50 M reads with 32).
+ *                   (device-resident rows only, DESIGN.md 4.4: 2.25-2.35 instead of 2.38-2.42 ms a pass of 50 M reads with 32 over hundreds of
+ *                   sketches, 0-3 % over twenty, a loss on a throttled GPU -- an option; bench.py times it as a side leg, never as its headline).
  *                   Layout, dump and the result copy of mk_sketch_finish_begin run on the scan queue's units under this option.
  *                   Default 0: one queue, every kernel on the whole device
  *   (8 and 9 were MK_OPT_ROWS160 and MK_OPT_BATCH_QUEUES in round 4: a scan kernel that kept a lane's text row in registers and a
