@@ -269,7 +269,7 @@ def wait_device_quiet(tag="gpu", least=2.0, most=8.0):
         time.sleep(2.5)
 
 
-def _file_read_seconds(path, threads=32, piece=64 << 20):
+def _file_read_seconds(path, threads=32, piece=8 << 20):
     """seconds `threads` threads take to pread the whole file (page cache / tmpfs) into buffers of their own: the floor under any front end
     that has to look at every byte of the FASTQ (os.preadv releases the GIL)"""
     import threading
@@ -414,7 +414,7 @@ def leg_e2e(capi, shuf, n, resident_sketch, reps=5):
         ceiling = None if t_read is None else {
             "file_read_s": t_read, "file_read_gb_s": os.path.getsize(fq) / t_read / 1e9, "hip_init_s": t_init,
             "gbases_s": bases / (t_read + t_init) / 1e9,
-            "what": "bases / (file_read_s + hip_init_s): the file's bytes out of tmpfs once (32 threads, pread of 64 MiB pieces, best of 5, measured in "
+            "what": "bases / (file_read_s + hip_init_s): the file's bytes out of tmpfs once (32 threads, pread of 8 MiB pieces into buffers that stay in cache, best of 5, measured in "
                     "this run by this process -- other tenants of the host move it: 0.105-0.19 s seen) and the HIP runtime's start-up (median of the "
                     "runs); t_e2e.gbases_s is to be read against THIS, not against `value`"}
         try:
