@@ -696,7 +696,10 @@ def leg_next_rows_cli(capi, genomes=1024, mbases=0.25, queries=8, reads_per_quer
             import statistics
             comp_leg = {"seconds": statistics.median(ws), "all_runs_s": [round(x, 4) for x in ws], "lines": len(txt.splitlines()), "queries": queries,
                         "what": "`metakssd composite -r db -q qsk`: %d query sketches (-A, %d reads each) against the marker database of %d species; the "
-                                "parent's clock around the whole process, median of 3 after a warm-up" % (queries, reads_per_query, genomes)}
+                                "parent's clock around the whole process, median of 3 after a warm-up.  At this database size (tens of thousands of ids) that "
+                                "is the process's start-up -- HIP runtime, code object, dictionaries: 0.1 s and more -- around a join of microseconds; a reference "
+                                "that does the same on the host needs no start-up at all (cpu_baseline).  The join itself at MarkerDB scale: next_rows.kernels.join"
+                                % (queries, reads_per_query, genomes)}
             if os.path.exists(ref):
                 rr, wr = run_ref([ref, "composite", "-r", "db", "-q", "qsk"], 120)
                 comp_leg["cpu_baseline"] = ({"seconds": wr, "cores": cores, "kind": "reference",
